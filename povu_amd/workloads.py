@@ -1,0 +1,209 @@
+"""Deterministic synthetic bidirected graphs for parity tests and bench.py.
+
+The shapes are the ones SURVEY.md section 8(d) fixes for BASELINE.json's
+configs.  A graph is returned as a :class:`Links` record: segment ids in
+ascending order plus one row per GFA L-line, already translated to vertex
+*indices* and sides the way the loader does (`+` on the source = right side,
+`+` on the sink = left side; reference src/mto/from_gfa.cpp:223-243).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+L, R = 0, 1
+
+
+@dataclass
+class Links:
+    vid: np.ndarray  # uint32 [V] ascending segment ids
+    v1: np.ndarray   # uint32 [E] vertex idx
+    s1: np.ndarray   # uint8  [E] side (0 = l, 1 = r)
+    v2: np.ndarray   # uint32 [E]
+    s2: np.ndarray   # uint8  [E]
+
+    @property
+    def n_vtx(self) -> int:
+        return int(self.vid.shape[0])
+
+    @property
+    def n_links(self) -> int:
+        return int(self.v1.shape[0])
+
+    def to_gfa(self) -> str:
+        """GFA text: S lines first (sequence `A`), then L lines, all `0M`."""
+        out = ["H\tVN:Z:1.0"]
+        out += [f"S\t{i}\tA" for i in self.vid.tolist()]
+        vid = self.vid
+        for a, sa, b, sb in zip(self.v1.tolist(), self.s1.tolist(), self.v2.tolist(), self.s2.tolist()):
+            out.append(f"L\t{vid[a]}\t{'+' if sa == R else '-'}\t{vid[b]}\t{'+' if sb == L else '-'}\t0M")
+        return "\n".join(out) + "\n"
+
+
+def _mk(vid, v1, s1, v2, s2) -> Links:
+    return Links(np.ascontiguousarray(vid, dtype=np.uint32), np.ascontiguousarray(v1, dtype=np.uint32),
+                 np.ascontiguousarray(s1, dtype=np.uint8), np.ascontiguousarray(v2, dtype=np.uint32),
+                 np.ascontiguousarray(s2, dtype=np.uint8))
+
+
+def from_plus_links(vid, src_idx, dst_idx) -> Links:
+    """All links `a + b +`."""
+    e = len(src_idx)
+    return _mk(vid, src_idx, np.full(e, R), dst_idx, np.full(e, L))
+
+
+def chain_of_bubbles(k: int) -> Links:
+    """BASELINE config 2: K units, ids 1..3K+1; unit i has a=3i+1, x=a+1,
+    y=a+2, b=a+3 and links a>x a>y x>y x>b y>b a>b.  K=333333 -> 1 000 000 segments,
+    1 999 998 links, one component, K flubbles."""
+    vid = np.arange(1, 3 * k + 2, dtype=np.uint32)
+    a = 3 * np.arange(k, dtype=np.int64)  # vertex idx of `a`
+    src = np.stack([a, a, a + 1, a + 1, a + 2, a], axis=1).reshape(-1)
+    dst = np.stack([a + 1, a + 2, a + 2, a + 3, a + 3, a + 3], axis=1).reshape(-1)
+    return from_plus_links(vid, src, dst)
+
+
+def nested_towers(depth: int, towers: int) -> Links:
+    """BASELINE config 5 shape: per tower a_0..a_{d-1}, c, b_{d-1}..b_0 (ids in
+    that order), links a_i>a_{i+1} and b_{i+1}>b_i interleaved, a_{d-1}>c, c>b_{d-1}, bypasses
+    a_i>b_i, towers chained b_0(t)>a_0(t+1)."""
+    d = depth
+    per = 2 * d + 1
+    vid = np.arange(1, per * towers + 1, dtype=np.uint32)
+    src, dst = [], []
+    i = np.arange(d - 1, dtype=np.int64)
+    a = lambda j: j            # noqa: E731  idx inside tower
+    b = lambda j: 2 * d - j    # noqa: E731  b_j : b_{d-1} = d+1 ... b_0 = 2d
+    c = d
+    inter_s = np.stack([a(i), b(i + 1)], axis=1).reshape(-1)
+    inter_d = np.stack([a(i + 1), b(i)], axis=1).reshape(-1)
+    j = np.arange(d, dtype=np.int64)
+    ts = np.concatenate([inter_s, [a(d - 1), c], a(j)])
+    td = np.concatenate([inter_d, [c, b(d - 1)], b(j)])
+    for t in range(towers):
+        base = t * per
+        src.append(ts + base)
+        dst.append(td + base)
+        if t + 1 < towers:
+            src.append(np.array([b(0) + base]))
+            dst.append(np.array([a(0) + base + per]))
+    return from_plus_links(vid, np.concatenate(src), np.concatenate(dst))
+
+
+class _PCG32:
+    """PCG32 (XSH-RR) so the HPRC-shaped generator is reproducible everywhere."""
+
+    def __init__(self, seed: int, seq: int = 54):
+        self.m = (1 << 64) - 1
+        self.state = 0
+        self.inc = ((seq << 1) | 1) & self.m
+        self.next()
+        self.state = (self.state + seed) & self.m
+        self.next()
+
+    def next(self) -> int:
+        old = self.state
+        self.state = (old * 6364136223846793005 + self.inc) & self.m
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+
+def hprc_shaped(backbone_sizes, seed: int = 20260612, tiny: int = 0) -> Links:
+    """HPRC-shaped multi-component graph: per component a backbone of
+    N segments with bubble density 0.35/segment; bubble mix SNP 70 % / indel 20 % / nested 8 % /
+    inversion 2 %; plus `tiny` small (<50 segment) components.  Uses numpy's PCG64 for the bulk
+    draws (seeded) -- the graph is deterministic for a given numpy version and is always fed
+    to both the oracle and the HIP path in the same process."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vids, s_all, d_all, s1_all, s2_all = [], [], [], [], []
+    next_id = 1
+    base_idx = 0
+
+    def emit_component(n_backbone: int):
+        nonlocal next_id, base_idx
+        kinds = rng.random(n_backbone - 1)
+        has = rng.random(n_backbone - 1) < 0.35
+        # extra segments per backbone gap: SNP 2 (two alleles), indel 1, nested 4, inversion 0
+        k_snp = has & (kinds < 0.70)
+        k_indel = has & (kinds >= 0.70) & (kinds < 0.90)
+        k_nest = has & (kinds >= 0.90) & (kinds < 0.98)
+        k_inv = has & (kinds >= 0.98)
+        extra = np.zeros(n_backbone - 1, dtype=np.int64)
+        extra[k_snp] = 2
+        extra[k_indel] = 1
+        extra[k_nest] = 4
+        # layout: backbone segment i followed by its gap's extra segments
+        stride = np.concatenate([[0], np.cumsum(1 + extra)])
+        bb = stride[:-1] if len(stride) == n_backbone else stride[:n_backbone]
+        bb = np.concatenate([bb, [stride[-1]]])[:n_backbone]
+        n_local = int(stride[-1] + 1)
+        a = bb[:-1]
+        b = bb[1:]
+        S, D, S1, S2 = [], [], [], []
+
+        def plus(s, d):
+            S.append(s)
+            D.append(d)
+            S1.append(np.full(len(s), R, dtype=np.uint8))
+            S2.append(np.full(len(s), L, dtype=np.uint8))
+
+        plain = ~has
+        plus(a[plain], b[plain])
+        # SNP: a>x a>y x>b y>b
+        m = k_snp
+        x, y = a[m] + 1, a[m] + 2
+        plus(a[m], x); plus(a[m], y); plus(x, b[m]); plus(y, b[m])
+        # indel: a>x x>b a>b
+        m = k_indel
+        x = a[m] + 1
+        plus(a[m], x); plus(x, b[m]); plus(a[m], b[m])
+        # nested: a>p p>q p>r q>s r>s s>b a>b   (p..s = a+1..a+4)
+        m = k_nest
+        p_, q_, r_, s_ = a[m] + 1, a[m] + 2, a[m] + 3, a[m] + 4
+        plus(a[m], p_); plus(p_, q_); plus(p_, r_); plus(q_, s_); plus(r_, s_); plus(s_, b[m]); plus(a[m], b[m])
+        # inversion: a>b plus the reverse link `b - a -` written as a `+ -` style link a+ -> b-
+        m = k_inv
+        plus(a[m], b[m])
+        S.append(a[m]); D.append(b[m])
+        S1.append(np.full(int(m.sum()), R, dtype=np.uint8)); S2.append(np.full(int(m.sum()), R, dtype=np.uint8))
+        s = np.concatenate(S); d = np.concatenate(D)
+        s1 = np.concatenate(S1); s2 = np.concatenate(S2)
+        # L-line order: by source backbone position then as emitted (stable)
+        order = np.argsort(np.minimum(s, d), kind="stable")
+        vids.append(np.arange(next_id, next_id + n_local, dtype=np.uint32))
+        s_all.append(s[order] + base_idx); d_all.append(d[order] + base_idx)
+        s1_all.append(s1[order]); s2_all.append(s2[order])
+        next_id += n_local
+        base_idx += n_local
+
+    for n in backbone_sizes:
+        emit_component(int(n))
+    for _ in range(tiny):
+        emit_component(int(rng.integers(3, 20)))
+    return _mk(np.concatenate(vids), np.concatenate(s_all), np.concatenate(s1_all), np.concatenate(d_all),
+               np.concatenate(s2_all))
+
+
+def random_bidirected(n_vtx: int, n_links: int, seed: int, self_loops: bool = True,
+                      connected: bool = False) -> Links:
+    """Differential-fuzz input: random sides, parallel links, self loops, several components."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vid = np.sort(rng.choice(np.arange(1, 4 * n_vtx + 1), size=n_vtx, replace=False)).astype(np.uint32)
+    v1 = rng.integers(0, n_vtx, size=n_links)
+    v2 = rng.integers(0, n_vtx, size=n_links)
+    if connected and n_vtx > 1:
+        k = min(n_links, n_vtx - 1)
+        v1[:k] = np.arange(k)
+        v2[:k] = np.arange(1, k + 1)
+    if not self_loops:
+        same = v1 == v2
+        v2[same] = (v2[same] + 1) % n_vtx
+    s1 = rng.integers(0, 2, size=n_links)
+    s2 = rng.integers(0, 2, size=n_links)
+    # mostly "forward" links so that long chains / bubbles appear
+    fwd = rng.random(n_links) < 0.7
+    s1[fwd] = R
+    s2[fwd] = L
+    return _mk(vid, v1, s1, v2, s2)

@@ -1,0 +1,192 @@
+"""CPU tests: the oracle against every known answer the reference pins for this path
+ and against the survey-time md5 anchors of reference outputs."""
+import ctypes as C
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from povu_amd import workloads as W
+
+
+def md5(s: str) -> str:
+    return hashlib.md5(s.encode()).hexdigest()
+
+
+def _anchors(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "anchors.json")))
+
+
+def test_reference_fixture_known_answers(golden_dir, tmp_path):
+    names = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(golden_dir, "pvst", "*.pvst")))
+    assert len(names) == 12
+    for name in names:
+        out = tmp_path / name
+        out.mkdir()
+        n = O.decompose_gfa(os.path.join(golden_dir, "gfa", name + ".gfa"), str(out))
+        assert n == 1
+        got = (out / "1.pvst").read_text()
+        want = open(os.path.join(golden_dir, "pvst", name + ".pvst")).read()
+        assert got == want, name
+
+
+def test_gfa_md5_anchors(golden_dir, tmp_path):
+    a = _anchors(golden_dir)
+    for name in ("LPA.gfa", "pvst_tests_graph.gfa"):
+        out = tmp_path / name
+        out.mkdir()
+        O.decompose_gfa(os.path.join(golden_dir, "gfa", name), str(out))
+        text = (out / "1.pvst").read_text()
+        assert md5(text) == a["md5"][name]
+    assert text.count("\n") == 3 + 1
+    lpa = (tmp_path / "LPA.gfa" / "1.pvst").read_text()
+    assert lpa.count("\n") == a["lines"]["LPA.gfa"]
+
+
+@pytest.mark.parametrize("key", ["chain_of_bubbles:3333", "chain_of_bubbles:333333", "nested_towers:5x1",
+                                 "nested_towers:1000x100"])
+def test_synthetic_md5_anchors(golden_dir, key):
+    a = _anchors(golden_dir)
+    name, arg = key.split(":")
+    if name == "chain_of_bubbles":
+        g = W.chain_of_bubbles(int(arg))
+    else:
+        d, t = arg.split("x")
+        g = W.nested_towers(int(d), int(t))
+    text = O.decompose(g)[1]
+    assert md5(text) == a["md5"][key]
+    if key in a["bytes"]:
+        assert len(text.encode()) == a["bytes"][key]
+
+
+def test_gfa_text_roundtrip_equals_arrays(tmp_path):
+    g = W.chain_of_bubbles(50)
+    p = tmp_path / "c.gfa"
+    p.write_text(g.to_gfa())
+    out = tmp_path / "o"
+    out.mkdir()
+    O.decompose_gfa(str(p), str(out))
+    assert (out / "1.pvst").read_text() == O.decompose(g)[1]
+
+
+class _Dump(C.Structure):
+    _fields_ = [("nv", C.c_uint32), ("ne", C.c_uint32), ("gidx", C.POINTER(C.c_uint32)),
+                ("ev1", C.POINTER(C.c_uint32)), ("ev2", C.POINTER(C.c_uint32)),
+                ("es1", C.POINTER(C.c_uint8)), ("es2", C.POINTER(C.c_uint8)),
+                ("n_tree", C.c_uint32), ("gid", C.POINTER(C.c_uint32)), ("par", C.POINTER(C.c_uint32)),
+                ("pe_id", C.POINTER(C.c_uint32)), ("cls", C.POINTER(C.c_uint32)), ("hi", C.POINTER(C.c_uint32)),
+                ("typ", C.POINTER(C.c_uint8)), ("pe_black", C.POINTER(C.c_uint8)),
+                ("n_be0", C.c_uint32), ("n_be", C.c_uint32), ("be_src", C.POINTER(C.c_uint32)),
+                ("be_tgt", C.POINTER(C.c_uint32)), ("be_type", C.POINTER(C.c_uint8)),
+                ("n_stack", C.c_uint32), ("s_id", C.POINTER(C.c_uint32)), ("s_st_idx", C.POINTER(C.c_uint32)),
+                ("s_edge_id", C.POINTER(C.c_uint32)), ("s_cls", C.POINTER(C.c_uint32)),
+                ("next_seen", C.POINTER(C.c_uint32)), ("s_orient", C.POINTER(C.c_uint8)),
+                ("n_pvst", C.c_uint32), ("p_parent", C.POINTER(C.c_uint32)), ("p_a_id", C.POINTER(C.c_uint32)),
+                ("p_z_id", C.POINTER(C.c_uint32)), ("p_ai", C.POINTER(C.c_uint32)), ("p_zi", C.POINTER(C.c_uint32)),
+                ("p_a_or", C.POINTER(C.c_uint8)), ("p_z_or", C.POINTER(C.c_uint8)),
+                ("n_bry", C.c_uint32), ("bry", C.POINTER(C.c_uint64))]
+
+
+def dump_component(links, comp=0, tips=None):
+    lib = O.lib()
+    lib.orc_dump_component.restype = C.POINTER(_Dump)
+    lib.orc_dump_component.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_uint32]
+    lib.orc_dump_free.argtypes = [C.POINTER(_Dump)]
+    tp = None if tips is None else np.ascontiguousarray(tips, dtype=np.uint8).ctypes.data
+    d = lib.orc_dump_component(links.n_vtx, links.vid.ctypes.data, links.n_links, links.v1.ctypes.data,
+                               links.s1.ctypes.data, links.v2.ctypes.data, links.s2.ctypes.data, tp, comp)
+    c = d.contents
+    out = {}
+    def arr(p, n):
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)
+    for f, n in [("gid", c.n_tree), ("par", c.n_tree), ("pe_id", c.n_tree), ("cls", c.n_tree), ("hi", c.n_tree),
+                 ("typ", c.n_tree), ("pe_black", c.n_tree), ("be_src", c.n_be), ("be_tgt", c.n_be),
+                 ("be_type", c.n_be), ("s_id", c.n_stack), ("s_st_idx", c.n_stack), ("s_edge_id", c.n_stack),
+                 ("s_cls", c.n_stack), ("next_seen", c.n_stack), ("s_orient", c.n_stack),
+                 ("p_parent", c.n_pvst), ("p_a_id", c.n_pvst), ("p_z_id", c.n_pvst), ("ev1", c.ne), ("ev2", c.ne),
+                 ("es1", c.ne), ("es2", c.ne), ("gidx", c.nv)]:
+        out[f] = arr(getattr(c, f), n)
+    out["n_be0"] = c.n_be0
+    out["bry"] = arr(c.bry, 2 * c.n_bry).reshape(-1, 2)
+    lib.orc_dump_free(d)
+    return out
+
+
+def _load_gfa_links(path):
+    ids, links = [], []
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == "S":
+            ids.append(int(f[1]))
+        elif f[0] == "L":
+            links.append((int(f[1]), f[2], int(f[3]), f[4]))
+    ids = sorted(ids)
+    pos = {v: i for i, v in enumerate(ids)}
+    v1 = [pos[a] for a, _, _, _ in links]
+    v2 = [pos[b] for _, _, b, _ in links]
+    s1 = [W.R if o == "+" else W.L for _, o, _, _ in links]
+    s2 = [W.L if o == "+" else W.R for _, _, _, o in links]
+    return W._mk(np.array(ids), np.array(v1), np.array(s1), np.array(v2), np.array(s2))
+
+
+def test_cycle_class_partitions_match_conformance_oracles(golden_dir):
+    """tests/lean4_conformance/src/main.rs:1594-1622: classes of the black tree edges by tree-edge id."""
+    groups = _anchors(golden_dir)["cycle_class_groups"]
+    for name, want in groups.items():
+        d = dump_component(_load_gfa_links(os.path.join(golden_dir, "gfa", name + ".gfa")))
+        by_cls = {}
+        for eid, c in zip(d["s_edge_id"].tolist(), d["s_cls"].tolist()):
+            by_cls.setdefault(c, []).append(eid)
+        got = sorted(sorted(v) for v in by_cls.values())
+        assert got == sorted(sorted(v) for v in want), name
+
+
+def test_worked_example_nested_deletion(golden_dir):
+    """SURVEY.md appendix B (reference dump of nested_deletion.gfa)."""
+    d = dump_component(_load_gfa_links(os.path.join(golden_dir, "gfa", "nested_deletion.gfa")))
+    assert d["par"].tolist()[1:] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 11]
+    assert d["pe_id"].tolist()[1:] == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12]
+    assert list(zip(d["be_src"].tolist(), d["be_tgt"].tolist())) == [(10, 0), (12, 2), (7, 4), (9, 2), (0, 0)]
+    assert d["be_type"].tolist() == [0, 0, 0, 1, 2]
+    assert d["s_id"].tolist() == [0, 1, 3, 4, 2, 5]
+    assert d["s_orient"].tolist() == [0, 0, 0, 0, 1, 0]
+    assert d["next_seen"].tolist() == [5, 3, 2, 3, 4, 5]
+
+
+def test_in_memory_graph_without_tips_like_pvst_tests(golden_dir):
+    """pvst_tests.cc builds the graph with add_vertex/add_edge only (no tips): no dummy root."""
+    g = _load_gfa_links(os.path.join(golden_dir, "gfa", "pvst_tests_graph.gfa"))
+    text = O.decompose(g, tips=np.zeros(g.n_vtx, dtype=np.uint8))[1]
+    labels = [l.split("\t")[2] for l in text.splitlines()[1:]]
+    assert sorted(labels) == sorted([".", ">1>7", ">4>6"])
+    rows = {l.split("\t")[2]: l.split("\t") for l in text.splitlines()[1:]}
+    assert rows["."][3] == rows[">1>7"][1] and rows[">1>7"][3] == rows[">4>6"][1] and rows[">4>6"][3] == "."
+
+
+def test_component_numbering_and_small_component_skip():
+    # components: {0,1} (2 vertices, skipped), {2,3,4} chain, {5} isolated, {6,7,8,9} diamond
+    vid = np.arange(10, 20)
+    src = np.array([0, 2, 3, 6, 6, 7, 8])
+    dst = np.array([1, 3, 4, 7, 8, 9, 9])
+    g = W.from_plus_links(vid, src, dst)
+    out, info = O.decompose(g, timings=True)
+    assert info["n_comp"] == 4
+    assert sorted(out) == [2, 4]
+    assert out[2] == "H\t0.0.3\t.\t.\t.\nD\t0\t.\t.\t.\n"
+    assert "F\t1\t>16>19\t.\tL" in out[4]
+
+
+def test_rescan_from_start_equals_cursor_resume():
+    lib = O.lib()
+    for seed in range(60):
+        g = W.random_bidirected(40 + seed, 70 + 2 * seed, seed)
+        lib.orc_set_faithful_rescan(1)
+        a = O.decompose(g)
+        lib.orc_set_faithful_rescan(0)
+        b = O.decompose(g)
+        assert a == b
