@@ -1,0 +1,137 @@
+/*
+ * povu_hip.h -- C ABI of the MI355X (gfx950) `decompose` hot path.
+ *
+ * This is the boundary a povu maintainer binds instead of the CPU calls that
+ * sit between "GFA parsed" and "PVST ready to write" in
+ *   povu::subcommands::decompose::do_decompose   app/subcommand/decompose.cpp:94-160
+ * i.e. it replaces, for that path and nothing else:
+ *   bd::VG (adjacency built by mto::from_gfa::to_bd)    src/mto/from_gfa.cpp:191-277
+ *   bd::VG::componetize                                  src/povu/graph/bidirected.cpp:477-602
+ *   pst::Tree::from_bd                                   src/povu/graph/spanning_tree.cpp:262-463
+ *   povu::flubbles::find_flubbles                        src/povu/algorithms/flubbles.cpp:721-745
+ * (INTEGRATION.md shows the reference-side stub.)
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All functions return 0 / non-NULL on success; on failure they return
+ * non-zero / NULL and write a message to `err` (when given).  There is no CPU
+ * fallback: without a usable HIP device every compute entry point fails.
+ *
+ * Threading: a context owns one HIP stream and one workspace arena and must be
+ * used by one thread at a time; independent contexts may be used concurrently
+ * (the reference's FFI makes the same promise, povu-rs/src/graph.rs:425).
+ */
+#ifndef POVU_HIP_H
+#define POVU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POVU_HIP_NIL 0xFFFFFFFFu
+/* vertex sides, reference pgt::v_end_e (include/povu/graph/types.hpp:39-42) */
+#define POVU_SIDE_L 0
+#define POVU_SIDE_R 1
+/* tip marks per vertex (reference bd::VG::tips_, src/mto/from_gfa.cpp:262-277) */
+#define POVU_TIP_NONE 0
+#define POVU_TIP_L 1
+#define POVU_TIP_R 2
+
+typedef struct povu_hip_ctx povu_hip_ctx;
+typedef struct povu_hip_forest povu_hip_forest;
+
+/* number of visible HIP devices (0 when none; never touches a device) */
+int povu_hip_device_count(void);
+
+/* create / destroy a context on `device` */
+povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen);
+void povu_hip_destroy(povu_hip_ctx *ctx);
+
+/*
+ * Row A (device part).  Copies the link arrays to HBM and builds the per-side
+ * CSR of the bidirected graph there (what bd::VG::add_vertex/add_edge/add_tip
+ * build on the CPU, bidirected.cpp:309-340).
+ *   vid[n_vtx]   segment id of vertex idx (the loader adds vertices ascending by id)
+ *   v1,v2[n_links] endpoint vertex idx, s1,s2[n_links] endpoint side (POVU_SIDE_*)
+ *   tips[n_vtx]  POVU_TIP_* per vertex, or NULL to infer them as to_bd does
+ * The graph stays resident until the next upload or povu_hip_destroy.
+ */
+int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links,
+			  const uint32_t *v1, const uint8_t *s1, const uint32_t *v2, const uint8_t *s2,
+			  const uint8_t *tips, char *err, size_t errlen);
+
+typedef struct {
+	uint32_t rank;	/* this process' shard (component sharding, 0-based) */
+	uint32_t world; /* number of shards; 0 or 1 = everything */
+	uint32_t flags; /* POVU_HIP_F_* */
+} povu_hip_opts;
+#define POVU_HIP_F_HAIRPINS 1u /* also report hairpin boundaries (--hairpins, flubbles.cpp:712-717) */
+#define POVU_HIP_F_SEQUENTIAL 2u /* force the one-lane-per-component kernels for every stage */
+
+/*
+ * Rows B-G.  Decomposes the resident graph: weakly connected components
+ * (numbered 1.. by minimum vertex idx, decompose.cpp:129), component
+ * re-indexing, biedged spanning tree, cycle-equivalence classes, candidate
+ * stack, next_seen and the PVST of every component with >= 3 vertices
+ * (decompose.cpp:135-142) that belongs to this shard.  The result lives in
+ * host memory.
+ */
+povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip_opts *opts, char *err, size_t errlen);
+
+/* components of the WHOLE graph (all shards), including skipped ones */
+uint32_t povu_hip_forest_total_components(const povu_hip_forest *f);
+/* PVSTs held by this forest (this shard's components with >= 3 vertices) */
+uint32_t povu_hip_forest_tree_count(const povu_hip_forest *f);
+
+typedef struct {
+	uint32_t component_id; /* 1-based, file name <id>.pvst */
+	uint32_t n_vtx, n_links;
+	uint32_t n_pvst; /* PVST vertices incl. the dummy root 0 */
+	/* arrays of n_pvst entries, PVST vertex idx = emission order; entry 0 = dummy root */
+	const uint32_t *a_id, *z_id;   /* flubble endpoints (segment ids) */
+	const uint8_t *a_or, *z_or;    /* 0 forward '>', 1 reverse '<' */
+	const uint32_t *parent;	       /* PVST parent idx, POVU_HIP_NIL for the root */
+	uint32_t n_hairpins;	       /* with POVU_HIP_F_HAIRPINS */
+	const uint64_t *hairpins;      /* pairs (b1,b2) */
+} povu_hip_tree;
+
+int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hip_tree *out);
+void povu_hip_forest_free(povu_hip_forest *f);
+
+/*
+ * Serialises tree `i` exactly as mto::to_pvst::write_pvst does
+ * (src/mto/to_pvst.cpp:23-109).  Returns a malloc'd buffer (free with
+ * povu_hip_buffer_free) and its length.
+ */
+char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i, size_t *len);
+void povu_hip_buffer_free(void *p);
+
+/* ---- measurement (bench.py, povu-stage-cost lines) ---- */
+typedef struct {
+	char name[48];	  /* kernel group */
+	double ms;	  /* HIP-event time on the context's stream, last decompose */
+	uint32_t launches;
+} povu_hip_stage_time;
+/* stage timings of the last povu_hip_decompose on this context */
+int povu_hip_last_stage_times(const povu_hip_ctx *ctx, povu_hip_stage_time *out, int max);
+/* number of links in the components this shard processed in the last decompose */
+uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx);
+
+/* ---- stage-level parity hooks (tests only; device state of the last decompose) ---- */
+/* copies comp_of[v] (0-based component rank) and local vertex idx for every GLOBAL vertex idx */
+int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *local_idx);
+/* tree arrays of component `comp` (0-based rank): sizes via n_tree first call with NULLs */
+int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *gid, uint8_t *typ,
+			uint32_t *par, uint32_t *cls);
+/* candidate stack of component `comp`: tree vertex of each entry, class, next_seen */
+int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t *tree_vtx, uint32_t *cls,
+			 uint32_t *next_seen);
+
+const char *povu_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

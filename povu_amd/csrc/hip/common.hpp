@@ -1,0 +1,132 @@
+// common.hpp -- shared declarations of the gfx950 decompose library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#define POVU_NIL 0xFFFFFFFFu
+
+namespace povu_hip
+{
+
+struct HipError : std::runtime_error {
+	using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                          \
+	do {                                                                                     \
+		hipError_t e__ = (expr);                                                         \
+		if (e__ != hipSuccess)                                                           \
+			throw povu_hip::HipError(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + \
+						 __FILE__ + ":" + std::to_string(__LINE__) + ")");   \
+	} while (0)
+
+// One growable device arena per context: stages carve typed spans with a bump
+// pointer, nothing is hipMalloc'd inside the timed path once the arena is warm.
+class Arena
+{
+public:
+	~Arena() { release(); }
+	void release()
+	{
+		if (base_)
+			(void)hipFree(base_);
+		base_ = nullptr;
+		cap_ = 0;
+		top_ = 0;
+	}
+	// make sure `bytes` are available from offset 0; invalidates earlier spans
+	void reserve(size_t bytes)
+	{
+		if (bytes > cap_) {
+			release();
+			size_t want = bytes + bytes / 8 + (1u << 20);
+			HIP_CHECK(hipMalloc(&base_, want));
+			cap_ = want;
+		}
+		top_ = 0;
+	}
+	template <typename T>
+	T *take(size_t n)
+	{
+		size_t off = (top_ + 255) & ~size_t(255);
+		size_t bytes = n * sizeof(T);
+		if (off + bytes > cap_)
+			throw HipError("povu_hip arena overflow (internal sizing bug)");
+		top_ = off + bytes;
+		return reinterpret_cast<T *>(static_cast<char *>(base_) + off);
+	}
+	static size_t padded(size_t n, size_t elem) { return ((n * elem) + 255) & ~size_t(255); }
+	size_t capacity() const { return cap_; }
+	size_t used() const { return top_; }
+
+private:
+	void *base_ = nullptr;
+	size_t cap_ = 0, top_ = 0;
+};
+
+// HIP-event stage timer on the context's stream.
+struct StageTimer {
+	struct Rec {
+		std::string name;
+		hipEvent_t a, b;
+		uint32_t launches;
+	};
+	std::vector<Rec> recs;
+	std::vector<hipEvent_t> pool;
+	size_t pool_used = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t get()
+	{
+		if (pool_used == pool.size()) {
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreate(&e));
+			pool.push_back(e);
+		}
+		return pool[pool_used++];
+	}
+	void reset()
+	{
+		recs.clear();
+		pool_used = 0;
+	}
+	void begin(const char *name)
+	{
+		Rec r{name, get(), get(), 0};
+		HIP_CHECK(hipEventRecord(r.a, stream));
+		recs.push_back(r);
+	}
+	void end(uint32_t launches)
+	{
+		recs.back().launches = launches;
+		HIP_CHECK(hipEventRecord(recs.back().b, stream));
+	}
+	~StageTimer()
+	{
+		for (auto e : pool)
+			(void)hipEventDestroy(e);
+	}
+};
+
+// device-wide primitives (primitives.hip)
+void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
+size_t scan_tmp_bytes(size_t n);
+// stable LSD radix sort of (key,value) pairs on the low `bits` bits of the key
+void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
+		    void *tmp, size_t tmp_bytes, hipStream_t s);
+size_t sort_tmp_bytes(size_t n);
+
+inline unsigned bits_for(uint64_t max_value)
+{
+	unsigned b = 1;
+	while (b < 32 && (uint64_t(1) << b) <= max_value)
+		b++;
+	return b;
+}
+
+} // namespace povu_hip

@@ -1,0 +1,324 @@
+// graph_kernels.hip -- rows A and B of the scope table on the GPU:
+//   per-side CSR of the bidirected graph           (bd::VG::add_edge, bidirected.cpp:317-335)
+//   weakly connected components                    (bd::VG::componetize, bidirected.cpp:477-602)
+//   component re-indexing: local vertex idx, first-encounter local edge idx,
+//   local per-side adjacency                       (bidirected.cpp:552-569, Edge::get_other_vtx :66-77)
+// All kernels are integer/index work bounded by HBM traffic; accesses are
+// coalesced over edge / side / slot ids, the scattered part goes through L2.
+#include "graph_kernels.hpp"
+
+namespace povu_hip
+{
+
+static constexpr int TPB = 256;
+static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+
+// ---------------------------------------------------------------- row A: CSR
+__global__ void k_side_degree(uint32_t E, const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1,
+			      const uint32_t *__restrict__ v2, const uint8_t *__restrict__ s2,
+			      uint32_t *__restrict__ deg, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+			      uint32_t sentinel)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= E)
+		return;
+	uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
+	atomicAdd(&deg[a], 1u);
+	keys[2 * e] = a;
+	vals[2 * e] = e;
+	// a same-side self loop sits once in the side's std::set (bidirected.cpp:324-333)
+	if (b != a) {
+		atomicAdd(&deg[b], 1u);
+		keys[2 * e + 1] = b;
+	} else {
+		keys[2 * e + 1] = sentinel;
+	}
+	vals[2 * e + 1] = e;
+}
+
+// tips as the loader infers them, src/mto/from_gfa.cpp:262-277
+__global__ void k_infer_tips(uint32_t V, const uint32_t *__restrict__ off, uint8_t *__restrict__ tip)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V)
+		return;
+	bool le = off[2 * v + 1] == off[2 * v], re = off[2 * v + 2] == off[2 * v + 1];
+	tip[v] = le ? 1 : (re ? 2 : 0);
+}
+
+// ---------------------------------------------------------------- row B: WCC
+// Lock-free union-find over the links: roots are hooked larger-under-smaller
+// with a CAS, finds use path halving.  The surviving root of a component is
+// its smallest vertex idx, which is exactly the key componetize orders
+// components by (next-unvisited linear rescan, bidirected.cpp:585-596).
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
+{
+	uint32_t p = parent[x];
+	while (p != x) {
+		uint32_t gp = parent[p];
+		if (gp != p)
+			parent[x] = gp; // halving; racy but monotone
+		x = p;
+		p = gp;
+	}
+	return x;
+}
+
+__global__ void k_uf_init(uint32_t V, uint32_t *parent)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V)
+		parent[v] = v;
+}
+
+__global__ void k_uf_union(uint32_t E, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
+			   uint32_t *parent)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= E)
+		return;
+	uint32_t a = v1[e], b = v2[e];
+	if (a == b)
+		return;
+	uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
+	while (ra != rb) {
+		uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+		uint32_t old = atomicCAS(&parent[hi], hi, lo);
+		if (old == hi)
+			break;
+		ra = uf_find(parent, old);
+		rb = uf_find(parent, lo);
+	}
+}
+
+__global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint32_t *__restrict__ is_root)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V)
+		return;
+	uint32_t r = v;
+	while (true) {
+		uint32_t p = parent[r];
+		if (p == r)
+			break;
+		r = p;
+	}
+	parent[v] = r; // readers of parent[] in this kernel only ever walk towards roots
+	is_root[v] = (r == v) ? 1u : 0u;
+}
+
+__global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const uint32_t *__restrict__ crank,
+			  uint32_t *__restrict__ comp_of, uint32_t *__restrict__ iota)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V)
+		return;
+	comp_of[v] = crank[label[v]];
+	iota[v] = v;
+}
+
+// after the stable sort by component: sorted position i holds global vertex perm[i]
+__global__ void k_sorted_vertices(uint32_t V, uint32_t C, const uint32_t *__restrict__ ckey,
+				  const uint32_t *__restrict__ perm, const uint32_t *__restrict__ off,
+				  const uint32_t *__restrict__ vid, const uint8_t *__restrict__ tip,
+				  uint32_t *__restrict__ pos, uint32_t *__restrict__ voff, uint32_t *__restrict__ vdeg,
+				  uint32_t *__restrict__ gid_s, uint8_t *__restrict__ tip_s,
+				  unsigned long long *__restrict__ start_key)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= V)
+		return;
+	uint32_t v = perm[i], c = ckey[i];
+	pos[v] = i;
+	if (i == 0 || ckey[i - 1] != c)
+		voff[c] = i;
+	if (i == V - 1)
+		voff[C] = V;
+	vdeg[i] = off[2 * v + 2] - off[2 * v];
+	uint32_t id = vid[v];
+	gid_s[i] = id;
+	uint8_t t = tip[v];
+	tip_s[i] = t;
+	// start of the spanning tree = *tips().begin(): smallest (id, then l<r), types.cpp:60-68
+	if (t)
+		atomicMin(&start_key[c], ((unsigned long long)id << 32) | (unsigned long long)(2u * i + (t == 1 ? 0u : 1u)));
+}
+
+// slot order of componetize's edge loop: vertices ascending, e_l then e_r ascending
+// (bidirected.cpp:558-569).  P = sbase[i] + rank of the slot inside vertex i.
+__global__ void k_first_slot(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ off,
+			     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ sbase,
+			     uint32_t *__restrict__ first)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x; // sorted side id
+	if (S >= 2 * V)
+		return;
+	uint32_t i = S >> 1, s = S & 1, v = perm[i];
+	uint32_t lo = off[2 * v + s], hi = off[2 * v + s + 1], P = sbase[i] + (lo - off[2 * v]);
+	for (uint32_t k = lo; k < hi; k++, P++)
+		atomicMin(&first[adj[k]], P);
+}
+
+__global__ void k_mark_first(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ off,
+			     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ sbase,
+			     const uint32_t *__restrict__ first, uint32_t *__restrict__ flag)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= 2 * V)
+		return;
+	uint32_t i = S >> 1, s = S & 1, v = perm[i];
+	uint32_t lo = off[2 * v + s], hi = off[2 * v + s + 1], P = sbase[i] + (lo - off[2 * v]);
+	for (uint32_t k = lo; k < hi; k++, P++)
+		flag[P] = (first[adj[k]] == P) ? 1u : 0u;
+}
+
+// local edge le = rank of the first-encounter slot; stored from the encountering side, a self loop
+// always as (ve, complement(ve)) whatever its original sides (Edge::get_other_vtx(v_idx, ve), :66-77)
+__global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
+			      const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
+			      const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ first,
+			      const uint32_t *__restrict__ erank, const uint32_t *__restrict__ v1,
+			      const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
+			      const uint8_t *__restrict__ s2, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+			      uint32_t *__restrict__ ldeg)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= 2 * V)
+		return;
+	uint32_t i = S >> 1, s = S & 1, v = perm[i];
+	uint32_t lo = off[2 * v + s], hi = off[2 * v + s + 1], P = sbase[i] + (lo - off[2 * v]);
+	for (uint32_t k = lo; k < hi; k++, P++) {
+		uint32_t e = adj[k];
+		if (first[e] != P)
+			continue;
+		uint32_t le = erank[P];
+		uint32_t a = v1[e], b = v2[e], So;
+		if (a == b)
+			So = 2 * i + (1 - s);
+		else if (a == v)
+			So = 2 * pos[b] + s2[e];
+		else
+			So = 2 * pos[a] + s1[e];
+		// two slots per local edge, generated in local-edge order so that the stable sort by
+		// side leaves every side's list ascending by local edge idx (std::set order)
+		keys[2 * le] = S;
+		vals[2 * le] = So;
+		keys[2 * le + 1] = So;
+		vals[2 * le + 1] = S;
+		atomicAdd(&ldeg[S], 1u);
+		atomicAdd(&ldeg[So], 1u);
+	}
+}
+
+__global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ sbase,
+				    const uint32_t *__restrict__ erank, uint32_t *__restrict__ eoff)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c > C)
+		return;
+	eoff[c] = erank[sbase[voff[c]]];
+}
+
+__global__ void k_fill_u32(size_t n, uint32_t *p, uint32_t val)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		p[i] = val;
+}
+__global__ void k_fill_u64(size_t n, unsigned long long *p, unsigned long long val)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		p[i] = val;
+}
+
+void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s)
+{
+	if (n)
+		hipLaunchKernelGGL(k_fill_u32, dim3(nblk(n)), dim3(TPB), 0, s, n, p, val);
+}
+
+// ------------------------------------------------------------------ host side
+void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
+{
+	const uint32_t V = g.V, E = g.E;
+	const size_t nS = 2 * (size_t)V;
+	tmp_arena.reserve(Arena::padded(2 * (size_t)E + 2, 4) * 4 + Arena::padded(nS + 2, 4) + sort_tmp_bytes(2 * (size_t)E) +
+			  scan_tmp_bytes(nS + 1) + (1 << 16));
+	uint32_t *keys = tmp_arena.take<uint32_t>(2 * (size_t)E + 1), *vals = tmp_arena.take<uint32_t>(2 * (size_t)E + 1);
+	uint32_t *keys2 = tmp_arena.take<uint32_t>(2 * (size_t)E + 1), *vals2 = tmp_arena.take<uint32_t>(2 * (size_t)E + 1);
+	uint32_t *deg = tmp_arena.take<uint32_t>(nS + 1);
+	size_t sb = sort_tmp_bytes(2 * (size_t)E), cb = scan_tmp_bytes(nS + 1);
+	void *stmp = tmp_arena.take<char>(sb), *ctmp = tmp_arena.take<char>(cb);
+	HIP_CHECK(hipMemsetAsync(deg, 0, (nS + 1) * 4, s));
+	if (E) {
+		hipLaunchKernelGGL(k_side_degree, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.s1, g.v2, g.s2, deg, keys, vals,
+				   (uint32_t)nS);
+	}
+	scan_exclusive_u32(deg, g.off, nS + 1, ctmp, cb, s);
+	sort_pairs_u32(keys, keys2, vals, vals2, 2 * (size_t)E, bits_for(nS), stmp, sb, s);
+	uint32_t n_slots = 0;
+	HIP_CHECK(hipMemcpyAsync(&n_slots, g.off + nS, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	g.n_slots = n_slots;
+	if (n_slots)
+		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)n_slots * 4, hipMemcpyDeviceToDevice, s));
+	if (!g.tips_given && V)
+		hipLaunchKernelGGL(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
+	HIP_CHECK(hipStreamSynchronize(s));
+}
+
+uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
+{
+	const uint32_t V = g.V, E = g.E;
+	tm.begin("wcc_label");
+	hipLaunchKernelGGL(k_uf_init, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label);
+	if (E)
+		hipLaunchKernelGGL(k_uf_union, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.v2, st.label);
+	hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
+	HIP_CHECK(hipMemsetAsync(st.flag + V, 0, 4, s));
+	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+	tm.end(4);
+	uint32_t C = 0;
+	HIP_CHECK(hipMemcpyAsync(&C, st.crank + V, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return C;
+}
+
+void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s)
+{
+	const uint32_t V = g.V, E = g.E;
+	const size_t nS = 2 * (size_t)V;
+	tm.begin("component_reindex");
+	uint32_t launches = 0;
+	// stable sort of vertices by component rank: local vertex idx = rank inside the component,
+	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
+	hipLaunchKernelGGL(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a);
+	sort_pairs_u32(st.comp_of, st.ckey, st.tmp_a, st.perm, V, bits_for(C), st.sort_tmp, st.sort_tmp_bytes, s);
+	hipLaunchKernelGGL(k_fill_u64, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, (size_t)C + 1,
+			   (unsigned long long *)st.start_key, ~0ull);
+	hipLaunchKernelGGL(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
+			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key);
+	HIP_CHECK(hipMemsetAsync(st.vdeg + V, 0, 4, s));
+	scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+	launches += 5;
+	// first-encounter rank of every edge
+	fill_u32(st.first, E, POVU_NIL, s);
+	HIP_CHECK(hipMemsetAsync(st.flag, 0, ((size_t)g.n_slots + 1) * 4, s));
+	hipLaunchKernelGGL(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
+	hipLaunchKernelGGL(k_mark_first, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first,
+			   st.flag);
+	scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+	HIP_CHECK(hipMemsetAsync(st.ldeg, 0, (nS + 1) * 4, s));
+	hipLaunchKernelGGL(k_local_edges, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, st.sbase,
+			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg);
+	hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
+			   st.eoff);
+	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+	// local per-side adjacency (other side ids), ascending local edge idx
+	sort_pairs_u32(st.keys, st.keys2, st.vals, st.ladj, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);
+	launches += 9;
+	tm.end(launches);
+}
+
+} // namespace povu_hip

@@ -1,0 +1,41 @@
+// graph_kernels.hpp -- device state of rows A/B (see graph_kernels.hip)
+#pragma once
+#include "common.hpp"
+
+namespace povu_hip
+{
+
+// The bidirected graph resident in HBM after povu_hip_graph_upload.
+// side id = 2 * vertex idx + end (0 = l, 1 = r).
+struct ResidentGraph {
+	uint32_t V = 0, E = 0, n_slots = 0;
+	bool tips_given = false;
+	uint32_t *vid = nullptr;		    // [V]   segment id
+	uint32_t *v1 = nullptr, *v2 = nullptr;	    // [E]   link endpoints (vertex idx)
+	uint8_t *s1 = nullptr, *s2 = nullptr;	    // [E]   link endpoint sides
+	uint8_t *tip = nullptr;			    // [V]   POVU_TIP_*
+	uint32_t *off = nullptr;		    // [2V+1] per-side CSR offsets
+	uint32_t *adj = nullptr;		    // [n_slots] incident link idx, ascending per side
+	void *block = nullptr;			    // one allocation backing all of the above
+};
+
+// Rows B outputs, all in the "sorted" vertex space: sorted position i = vertices
+// ordered by (component rank, global idx); component c owns positions
+// [voff[c], voff[c+1]) and local vertex idx = i - voff[c]; sorted side id = 2i + end.
+struct CompState {
+	uint32_t *label, *flag, *crank, *comp_of, *tmp_a, *ckey, *perm, *pos;
+	uint32_t *voff, *eoff, *vdeg, *sbase, *first, *erank, *ldeg, *loff, *ladj;
+	uint32_t *keys, *vals, *keys2;
+	uint32_t *gid_s;
+	uint8_t *tip_s;
+	uint64_t *start_key; // [C+1] (segment id << 32 | sorted side) of the smallest tip, ~0 if none
+	void *scan_tmp, *sort_tmp;
+	size_t scan_tmp_bytes, sort_tmp_bytes;
+};
+
+void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s);
+void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);
+uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
+void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s);
+
+} // namespace povu_hip

@@ -1,0 +1,651 @@
+// povu_hip.hip -- C ABI (include/povu_hip.h) and host orchestration of the gfx950
+// decompose path.  Mirrors povu::subcommands::decompose::do_decompose
+// (app/subcommand/decompose.cpp:94-160) from "graph built" to "PVST ready to write".
+#include "../../../include/povu_hip.h"
+
+#include "graph_kernels.hpp"
+#include "seq_kernels.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <memory>
+#include <numeric>
+#include <type_traits>
+
+using namespace povu_hip;
+
+struct povu_hip_forest {
+	uint32_t total_components = 0;
+	struct Tree {
+		uint32_t component_id, n_vtx, n_links, n_pvst;
+		size_t off;	// into the flat arrays below
+		size_t hp_off;	// into hairpins (pairs)
+		uint32_t n_hairpins;
+	};
+	std::vector<Tree> trees;
+	std::vector<uint32_t> a_id, z_id, parent;
+	std::vector<uint8_t> a_or, z_or;
+	std::vector<uint64_t> hairpins;
+};
+
+struct povu_hip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	ResidentGraph g;
+	Arena ws, upload_tmp;
+	StageTimer timer;
+	std::vector<povu_hip_stage_time> last_times;
+	uint64_t last_links = 0;
+	// device state of the last decompose (debug / parity hooks)
+	bool have_state = false;
+	uint32_t C = 0;
+	CompState cs{};
+	SeqWs sw{};
+};
+
+static void set_err(char *err, size_t errlen, const std::string &msg)
+{
+	if (err && errlen) {
+		snprintf(err, errlen, "%s", msg.c_str());
+	}
+}
+
+extern "C" const char *povu_hip_version(void) { return "povu-hip 0.1.0 (gfx950)"; }
+
+extern "C" int povu_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
+{
+	try {
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+			throw HipError("no HIP device available: the decompose path has no CPU fallback");
+		if (device < 0 || device >= n)
+			throw HipError("HIP device index out of range");
+		HIP_CHECK(hipSetDevice(device));
+		auto ctx = std::make_unique<povu_hip_ctx>();
+		ctx->device = device;
+		HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+		ctx->timer.stream = ctx->stream;
+		return ctx.release();
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+static void free_graph(ResidentGraph &g)
+{
+	if (g.block)
+		(void)hipFree(g.block);
+	g = ResidentGraph{};
+}
+
+extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	free_graph(ctx->g);
+	ctx->ws.release();
+	ctx->upload_tmp.release();
+	if (ctx->stream)
+		(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links,
+				     const uint32_t *v1, const uint8_t *s1, const uint32_t *v2, const uint8_t *s2,
+				     const uint8_t *tips, char *err, size_t errlen)
+{
+	try {
+		if (!ctx)
+			throw HipError("null context");
+		if (n_vtx == 0)
+			throw HipError("graph has no vertices");
+		if (n_vtx > 0x7FFFFFF0u || n_links > 0x7FFFFFF0u)
+			throw HipError("graph too large for 32-bit indices (the reference has the same limit, core.hpp:20-21)");
+		// operand validation on the host: the kernels index by these values unchecked
+		for (uint32_t e = 0; e < n_links; e++)
+			if (v1[e] >= n_vtx || v2[e] >= n_vtx || s1[e] > 1 || s2[e] > 1)
+				throw HipError("link " + std::to_string(e) + " references an unknown vertex or side");
+		if (tips)
+			for (uint32_t v = 0; v < n_vtx; v++)
+				if (tips[v] > 2)
+					throw HipError("bad tip mark");
+		HIP_CHECK(hipSetDevice(ctx->device));
+		free_graph(ctx->g);
+		ctx->have_state = false;
+		ResidentGraph &g = ctx->g;
+		g.V = n_vtx;
+		g.E = n_links;
+		g.tips_given = tips != nullptr;
+		const size_t V = n_vtx, E = n_links;
+		size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
+			       Arena::padded(2 * V + 2, 4) + Arena::padded(2 * E + 2, 4) + 4096;
+		HIP_CHECK(hipMalloc(&g.block, bytes));
+		char *p = static_cast<char *>(g.block);
+		auto carve = [&](size_t n, size_t elem) {
+			void *r = p;
+			p += Arena::padded(n, elem);
+			return r;
+		};
+		g.vid = (uint32_t *)carve(V, 4);
+		g.v1 = (uint32_t *)carve(E + 1, 4);
+		g.v2 = (uint32_t *)carve(E + 1, 4);
+		g.s1 = (uint8_t *)carve(E + 1, 1);
+		g.s2 = (uint8_t *)carve(E + 1, 1);
+		g.tip = (uint8_t *)carve(V, 1);
+		g.off = (uint32_t *)carve(2 * V + 2, 4);
+		g.adj = (uint32_t *)carve(2 * E + 2, 4);
+		hipStream_t s = ctx->stream;
+		HIP_CHECK(hipMemcpyAsync(g.vid, vid, V * 4, hipMemcpyHostToDevice, s));
+		if (E) {
+			HIP_CHECK(hipMemcpyAsync(g.v1, v1, E * 4, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(g.v2, v2, E * 4, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(g.s1, s1, E, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(g.s2, s2, E, hipMemcpyHostToDevice, s));
+		}
+		if (tips)
+			HIP_CHECK(hipMemcpyAsync(g.tip, tips, V, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		build_global_csr(g, ctx->upload_tmp, s);
+		return 0;
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return 1;
+	}
+}
+
+namespace
+{
+struct Sizes {
+	size_t V, E, Cmax, T, B, nS, slots;
+};
+
+// carve every span of one decompose call out of the arena (or just measure when `ar` is null)
+size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool hairpins)
+{
+	size_t total = 0;
+	auto take = [&](auto **dst, size_t n, size_t elem) {
+		total += Arena::padded(n, elem) + 256;
+		if (ar) {
+			using P = std::remove_reference_t<decltype(*dst)>;
+			*dst = reinterpret_cast<P>(ar->take<char>(n * elem));
+		}
+	};
+	const size_t V = z.V, E = z.E, C = z.Cmax, T = z.T, B = z.B, nS = z.nS;
+	// rows A/B
+	take(&cs.label, V + 1, 4);
+	take(&cs.flag, std::max(V, z.slots) + 2, 4);
+	take(&cs.crank, V + 2, 4);
+	take(&cs.comp_of, V + 1, 4);
+	take(&cs.tmp_a, V + 1, 4);
+	take(&cs.ckey, V + 1, 4);
+	take(&cs.perm, V + 1, 4);
+	take(&cs.pos, V + 1, 4);
+	take(&cs.voff, C + 2, 4);
+	take(&cs.eoff, C + 2, 4);
+	take(&cs.vdeg, V + 2, 4);
+	take(&cs.sbase, V + 2, 4);
+	take(&cs.first, E + 1, 4);
+	take(&cs.erank, z.slots + 2, 4);
+	take(&cs.ldeg, nS + 2, 4);
+	take(&cs.loff, nS + 2, 4);
+	take(&cs.ladj, 2 * E + 2, 4);
+	take(&cs.keys, 2 * E + 2, 4);
+	take(&cs.vals, 2 * E + 2, 4);
+	take(&cs.keys2, 2 * E + 2, 4);
+	take(&cs.gid_s, V + 1, 4);
+	take(&cs.tip_s, V + 1, 1);
+	take(&cs.start_key, C + 2, 8);
+	cs.scan_tmp_bytes = scan_tmp_bytes(std::max<size_t>(nS, z.slots) + 2);
+	cs.sort_tmp_bytes = sort_tmp_bytes(std::max<size_t>(2 * E, V) + 2);
+	take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);
+	take((char **)&cs.sort_tmp, cs.sort_tmp_bytes, 1);
+	// rows C-G
+	uint32_t *order = nullptr, *owner = nullptr;
+	take(&order, C + 1, 4);
+	take(&owner, C + 1, 4);
+	sw.order = order;
+	sw.owner = owner;
+	take(&sw.t_gid, T, 4);
+	take(&sw.t_par, T, 4);
+	take(&sw.t_cls, T, 4);
+	take(&sw.t_hi, T, 4);
+	take(&sw.first_child, T, 4);
+	take(&sw.next_sib, T, 4);
+	take(&sw.last_child, T, 4);
+	take(&sw.t_flags, T, 1);
+	take(&sw.ctr, nS + 1, 4);
+	take(&sw.cur, nS + 1, 4);
+	take(&sw.stk, T, 4);
+	take(&sw.selfloop, V + 1, 1);
+	take(&sw.be_src, B, 4);
+	take(&sw.be_tgt, B, 4);
+	take(&sw.o_next, B, 4);
+	take(&sw.i_next, B, 4);
+	take(&sw.b_prev, B, 4);
+	take(&sw.b_next, B, 4);
+	take(&sw.b_rsize, B, 4);
+	take(&sw.b_rclass, B, 4);
+	take(&sw.be_type, B, 1);
+	take(&sw.b_in, B, 1);
+	take(&sw.be_cdef, B, 1);
+	take(&sw.o_head, T, 4);
+	take(&sw.o_tail, T, 4);
+	take(&sw.i_head, T, 4);
+	take(&sw.i_tail, T, 4);
+	take(&sw.l_head, T, 4);
+	take(&sw.l_tail, T, 4);
+	take(&sw.l_size, T, 4);
+	take(&sw.bl, T, 4);
+	take(&sw.nxt, T, 4);
+	take(&sw.st_head, T, 4);
+	take(&sw.st_tail, T, 4);
+	take(&sw.s_vtx, V + 1, 4);
+	take(&sw.s_cls, V + 1, 4);
+	take(&sw.next_seen, V + 1, 4);
+	take(&sw.last, B + T, 4);
+	take(&sw.p_parent, V + C + 1, 4);
+	take(&sw.p_a, V + C + 1, 4);
+	take(&sw.p_z, V + C + 1, 4);
+	take(&sw.p_or, V + C + 1, 1);
+	take(&sw.aux, V + C + 1, 4);
+	take(&sw.in_s, B + T, 1);
+	if (hairpins)
+		take(&sw.hairpins, 2 * (V + C + 1), 8);
+	else
+		sw.hairpins = nullptr;
+	take(&sw.c_ntree, C + 1, 4);
+	take(&sw.c_nbe0, C + 1, 4);
+	take(&sw.c_nbe, C + 1, 4);
+	take(&sw.c_nstack, C + 1, 4);
+	take(&sw.c_npvst, C + 1, 4);
+	take(&sw.c_nclass, C + 1, 4);
+	take(&sw.c_nbry, C + 1, 4);
+	take(&sw.c_status, C + 1, 4);
+	return total + (1 << 20);
+}
+} // namespace
+
+extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip_opts *opts, char *err, size_t errlen)
+{
+	try {
+		if (!ctx || !ctx->g.block)
+			throw HipError("no graph resident: call povu_hip_graph_upload first");
+		HIP_CHECK(hipSetDevice(ctx->device));
+		const ResidentGraph &g = ctx->g;
+		hipStream_t s = ctx->stream;
+		povu_hip_opts o{0, 1, 0};
+		if (opts)
+			o = *opts;
+		if (o.world == 0)
+			o.world = 1;
+		if (o.rank >= o.world)
+			throw HipError("shard rank >= world");
+		const bool hairpins = (o.flags & POVU_HIP_F_HAIRPINS) != 0;
+
+		Sizes z;
+		z.V = g.V;
+		z.E = g.E;
+		z.Cmax = g.V; // component count is only known after labelling; size for the worst case
+		z.nS = 2 * z.V;
+		z.slots = g.n_slots;
+		z.T = 2 * z.V + z.Cmax;
+		z.B = z.E + z.V + 2 * z.T;
+		CompState &cs = ctx->cs;
+		SeqWs &sw = ctx->sw;
+		ctx->have_state = false;
+		ctx->ws.reserve(carve_workspace(nullptr, z, cs, sw, hairpins));
+		carve_workspace(&ctx->ws, z, cs, sw, hairpins);
+
+		StageTimer &tm = ctx->timer;
+		tm.reset();
+		hipEvent_t ev_all0 = tm.get(), ev_all1 = tm.get();
+		HIP_CHECK(hipEventRecord(ev_all0, s));
+
+		// ---- row B
+		const uint32_t C = label_components(g, cs, tm, s);
+		reindex_components(g, cs, C, tm, s);
+
+		// component sizes on the host: shard assignment (LPT over link counts) and launch order
+		std::vector<uint32_t> voff(C + 1), eoff(C + 1);
+		HIP_CHECK(hipMemcpyAsync(voff.data(), cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(eoff.data(), cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		std::vector<uint32_t> order(C), owner(C, 0);
+		std::iota(order.begin(), order.end(), 0u);
+		auto weight = [&](uint32_t c) { return (uint64_t)(eoff[c + 1] - eoff[c]) + (voff[c + 1] - voff[c]); };
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
+		if (o.world > 1) { // greedy longest-processing-time assignment, deterministic on every rank
+			std::vector<uint64_t> load(o.world, 0);
+			for (uint32_t c : order) {
+				uint32_t best = 0;
+				for (uint32_t r = 1; r < o.world; r++)
+					if (load[r] < load[best])
+						best = r;
+				owner[c] = best;
+				load[best] += weight(c) + 1;
+			}
+		}
+		uint64_t links = 0;
+		for (uint32_t c = 0; c < C; c++)
+			if (owner[c] == o.rank || o.world == 1)
+				links += eoff[c + 1] - eoff[c];
+		ctx->last_links = links;
+		HIP_CHECK(hipMemcpyAsync((void *)sw.order, order.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync((void *)sw.owner, owner.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
+
+		// ---- rows C-G
+		sw.V = g.V;
+		sw.E = g.E;
+		sw.C = C;
+		sw.rank = o.rank;
+		sw.world = o.world;
+		sw.flags = o.flags;
+		sw.voff = cs.voff;
+		sw.eoff = cs.eoff;
+		sw.loff = cs.loff;
+		sw.ladj = cs.ladj;
+		sw.gid_s = cs.gid_s;
+		sw.tip_s = cs.tip_s;
+		sw.start_key = cs.start_key;
+		const size_t T = 2 * (size_t)g.V + C, B = (size_t)g.E + g.V + 2 * T;
+		tm.begin("traversal_init");
+		HIP_CHECK(hipMemsetAsync(sw.first_child, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.o_head, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.i_head, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.bl, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.t_hi, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.t_cls, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.st_head, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.st_tail, 0xFF, T * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.ctr, 0xFF, z.nS * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.cur, 0, z.nS * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.selfloop, 0, g.V, s));
+		HIP_CHECK(hipMemsetAsync(sw.last, 0xFF, (B + T) * 4, s));
+		HIP_CHECK(hipMemsetAsync(sw.in_s, 0, B + T, s));
+		for (uint32_t *p : {sw.c_ntree, sw.c_nbe0, sw.c_nbe, sw.c_nstack, sw.c_npvst, sw.c_nclass, sw.c_nbry, sw.c_status})
+			HIP_CHECK(hipMemsetAsync(p, 0, (size_t)(C + 1) * 4, s));
+		tm.end(15);
+		tm.begin("traversal_seq");
+		launch_seq_components(sw, s);
+		tm.end(1);
+
+		// ---- PVST arrays back to the host
+		tm.begin("pvst_d2h");
+		std::vector<uint32_t> npvst(C), nbry(C);
+		HIP_CHECK(hipMemcpyAsync(npvst.data(), sw.c_npvst, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(nbry.data(), sw.c_nbry, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		auto f = std::make_unique<povu_hip_forest>();
+		f->total_components = C;
+		size_t total = 0, total_hp = 0;
+		for (uint32_t c = 0; c < C; c++) {
+			if (npvst[c] == 0)
+				continue;
+			povu_hip_forest::Tree t;
+			t.component_id = c + 1; // decompose.cpp:129
+			t.n_vtx = voff[c + 1] - voff[c];
+			t.n_links = eoff[c + 1] - eoff[c];
+			t.n_pvst = npvst[c];
+			t.off = total;
+			t.hp_off = total_hp;
+			t.n_hairpins = hairpins ? nbry[c] : 0;
+			total += npvst[c];
+			total_hp += t.n_hairpins;
+			f->trees.push_back(t);
+		}
+		f->a_id.resize(total);
+		f->z_id.resize(total);
+		f->parent.resize(total);
+		f->a_or.resize(total);
+		f->z_or.resize(total);
+		f->hairpins.resize(2 * total_hp);
+		std::vector<uint8_t> ors(total);
+		if (f->trees.size() <= 32) { // few trees: copy exactly their spans
+			for (const auto &t : f->trees) {
+				const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
+				HIP_CHECK(hipMemcpyAsync(f->a_id.data() + t.off, sw.p_a + pb, (size_t)t.n_pvst * 4,
+							 hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(f->z_id.data() + t.off, sw.p_z + pb, (size_t)t.n_pvst * 4,
+							 hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(f->parent.data() + t.off, sw.p_parent + pb, (size_t)t.n_pvst * 4,
+							 hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(ors.data() + t.off, sw.p_or + pb, t.n_pvst, hipMemcpyDeviceToHost, s));
+				if (t.n_hairpins)
+					HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t.hp_off, sw.hairpins + 2 * pb,
+								 (size_t)t.n_hairpins * 16, hipMemcpyDeviceToHost, s));
+			}
+			tm.end(0);
+			HIP_CHECK(hipEventRecord(ev_all1, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+		} else { // many trees: one bulk copy per array, sliced on the host
+			const size_t P = (size_t)g.V + C;
+			std::vector<uint32_t> ha(P), hz(P), hp(P);
+			std::vector<uint8_t> ho(P);
+			std::vector<uint64_t> hh(hairpins ? 2 * P : 0);
+			HIP_CHECK(hipMemcpyAsync(ha.data(), sw.p_a, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(hz.data(), sw.p_z, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(hp.data(), sw.p_parent, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(ho.data(), sw.p_or, P, hipMemcpyDeviceToHost, s));
+			if (hairpins)
+				HIP_CHECK(hipMemcpyAsync(hh.data(), sw.hairpins, 2 * P * 8, hipMemcpyDeviceToHost, s));
+			tm.end(0);
+			HIP_CHECK(hipEventRecord(ev_all1, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			for (const auto &t : f->trees) {
+				const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
+				std::copy_n(ha.begin() + pb, t.n_pvst, f->a_id.begin() + t.off);
+				std::copy_n(hz.begin() + pb, t.n_pvst, f->z_id.begin() + t.off);
+				std::copy_n(hp.begin() + pb, t.n_pvst, f->parent.begin() + t.off);
+				std::copy_n(ho.begin() + pb, t.n_pvst, ors.begin() + t.off);
+				if (t.n_hairpins)
+					std::copy_n(hh.begin() + 2 * pb, 2 * (size_t)t.n_hairpins, f->hairpins.begin() + 2 * t.hp_off);
+			}
+		}
+		for (size_t i = 0; i < total; i++) {
+			f->a_or[i] = ors[i] & 1;
+			f->z_or[i] = (ors[i] >> 1) & 1;
+		}
+		// stage times
+		ctx->last_times.clear();
+		for (auto &r : tm.recs) {
+			povu_hip_stage_time st{};
+			snprintf(st.name, sizeof st.name, "%s", r.name.c_str());
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+			st.ms = ms;
+			st.launches = r.launches;
+			ctx->last_times.push_back(st);
+		}
+		{
+			povu_hip_stage_time st{};
+			snprintf(st.name, sizeof st.name, "total");
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, ev_all0, ev_all1));
+			st.ms = ms;
+			ctx->last_times.push_back(st);
+		}
+		ctx->C = C;
+		ctx->have_state = true;
+		return f.release();
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+extern "C" uint32_t povu_hip_forest_total_components(const povu_hip_forest *f) { return f ? f->total_components : 0; }
+extern "C" uint32_t povu_hip_forest_tree_count(const povu_hip_forest *f) { return f ? (uint32_t)f->trees.size() : 0; }
+
+extern "C" int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hip_tree *out)
+{
+	if (!f || !out || i >= f->trees.size())
+		return 1;
+	const auto &t = f->trees[i];
+	out->component_id = t.component_id;
+	out->n_vtx = t.n_vtx;
+	out->n_links = t.n_links;
+	out->n_pvst = t.n_pvst;
+	out->a_id = f->a_id.data() + t.off;
+	out->z_id = f->z_id.data() + t.off;
+	out->a_or = f->a_or.data() + t.off;
+	out->z_or = f->z_or.data() + t.off;
+	out->parent = f->parent.data() + t.off;
+	out->n_hairpins = t.n_hairpins;
+	out->hairpins = t.n_hairpins ? f->hairpins.data() + 2 * t.hp_off : nullptr;
+	return 0;
+}
+
+extern "C" void povu_hip_forest_free(povu_hip_forest *f) { delete f; }
+extern "C" void povu_hip_buffer_free(void *p) { free(p); }
+
+// mto::to_pvst::write_pvst, src/mto/to_pvst.cpp:23-109
+extern "C" char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i, size_t *len)
+{
+	povu_hip_tree t;
+	if (povu_hip_forest_get(f, i, &t) != 0)
+		return nullptr;
+	const uint32_t n = t.n_pvst;
+	// children of every PVST vertex in emission order (children_v push_back, pvst.hpp:882-892)
+	std::vector<uint32_t> coff(n + 1, 0), cadj(n);
+	for (uint32_t v = 1; v < n; v++)
+		coff[t.parent[v] + 1]++;
+	for (uint32_t v = 0; v < n; v++)
+		coff[v + 1] += coff[v];
+	{
+		std::vector<uint32_t> cur(coff.begin(), coff.end() - 1);
+		for (uint32_t v = 1; v < n; v++)
+			cadj[cur[t.parent[v]]++] = v;
+	}
+	std::string out;
+	out.reserve((size_t)n * 36 + 64);
+	out += "H\t0.0.3\t.\t.\t.\n"; // to_pvst.cpp:23-28
+	char num[16];
+	auto put = [&](uint32_t v) {
+		int l = snprintf(num, sizeof num, "%u", v);
+		out.append(num, (size_t)l);
+	};
+	for (uint32_t v = 0; v < n; v++) {
+		out += v == 0 ? "D\t" : "F\t";
+		put(v);
+		out += '\t';
+		if (v == 0) {
+			out += '.';
+		} else { // id_or_t::as_str, include/povu/graph/types.hpp:85-95
+			out += t.a_or[v] ? '<' : '>';
+			put(t.a_id[v]);
+			out += t.z_or[v] ? '<' : '>';
+			put(t.z_id[v]);
+		}
+		out += '\t';
+		if (coff[v] == coff[v + 1]) {
+			out += '.';
+		} else { // print_with_comma, include/povu/common/utils.hpp:44-55
+			for (uint32_t k = coff[v]; k < coff[v + 1]; k++) {
+				put(cadj[k]);
+				if (k + 1 < coff[v + 1])
+					out += ", ";
+			}
+		}
+		out += v == 0 ? "\t.\n" : "\tL\n";
+	}
+	char *buf = (char *)malloc(out.size() + 1);
+	if (!buf)
+		return nullptr;
+	memcpy(buf, out.data(), out.size());
+	buf[out.size()] = 0;
+	if (len)
+		*len = out.size();
+	return buf;
+}
+
+extern "C" int povu_hip_last_stage_times(const povu_hip_ctx *ctx, povu_hip_stage_time *out, int max)
+{
+	if (!ctx)
+		return 0;
+	int n = (int)ctx->last_times.size();
+	if (out)
+		for (int i = 0; i < n && i < max; i++)
+			out[i] = ctx->last_times[i];
+	return n;
+}
+
+extern "C" uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx) { return ctx ? ctx->last_links : 0; }
+
+// ---- stage-level parity hooks
+extern "C" int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *local_idx)
+{
+	if (!ctx || !ctx->have_state)
+		return 1;
+	try {
+		HIP_CHECK(hipSetDevice(ctx->device));
+		const uint32_t V = ctx->g.V, C = ctx->C;
+		std::vector<uint32_t> pos(V), voff(C + 1);
+		HIP_CHECK(hipMemcpy(comp_of, ctx->cs.comp_of, (size_t)V * 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(pos.data(), ctx->cs.pos, (size_t)V * 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(voff.data(), ctx->cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost));
+		for (uint32_t v = 0; v < V; v++)
+			local_idx[v] = pos[v] - voff[comp_of[v]];
+		return 0;
+	} catch (const std::exception &) {
+		return 2;
+	}
+}
+
+extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *gid, uint8_t *typ,
+				   uint32_t *par, uint32_t *cls)
+{
+	if (!ctx || !ctx->have_state || comp >= ctx->C || !n_tree)
+		return 1;
+	try {
+		HIP_CHECK(hipSetDevice(ctx->device));
+		uint32_t voff = 0, N = 0;
+		HIP_CHECK(hipMemcpy(&voff, ctx->cs.voff + comp, 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&N, ctx->sw.c_ntree + comp, 4, hipMemcpyDeviceToHost));
+		*n_tree = N;
+		const size_t tb = 2 * (size_t)voff + comp;
+		if (gid)
+			HIP_CHECK(hipMemcpy(gid, ctx->sw.t_gid + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
+		if (par)
+			HIP_CHECK(hipMemcpy(par, ctx->sw.t_par + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
+		if (cls)
+			HIP_CHECK(hipMemcpy(cls, ctx->sw.t_cls + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
+		if (typ)
+			HIP_CHECK(hipMemcpy(typ, ctx->sw.t_flags + tb, N, hipMemcpyDeviceToHost));
+		return 0;
+	} catch (const std::exception &) {
+		return 2;
+	}
+}
+
+extern "C" int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t *tree_vtx, uint32_t *cls,
+				    uint32_t *next_seen)
+{
+	if (!ctx || !ctx->have_state || comp >= ctx->C || !n)
+		return 1;
+	try {
+		HIP_CHECK(hipSetDevice(ctx->device));
+		uint32_t voff = 0, ns = 0;
+		HIP_CHECK(hipMemcpy(&voff, ctx->cs.voff + comp, 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&ns, ctx->sw.c_nstack + comp, 4, hipMemcpyDeviceToHost));
+		*n = ns;
+		if (tree_vtx)
+			HIP_CHECK(hipMemcpy(tree_vtx, ctx->sw.s_vtx + voff, (size_t)ns * 4, hipMemcpyDeviceToHost));
+		if (cls)
+			HIP_CHECK(hipMemcpy(cls, ctx->sw.s_cls + voff, (size_t)ns * 4, hipMemcpyDeviceToHost));
+		if (next_seen)
+			HIP_CHECK(hipMemcpy(next_seen, ctx->sw.next_seen + voff, (size_t)ns * 4, hipMemcpyDeviceToHost));
+		return 0;
+	} catch (const std::exception &) {
+		return 2;
+	}
+}

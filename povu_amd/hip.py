@@ -1,0 +1,239 @@
+"""ctypes mirror of include/povu_hip.h.
+
+Fails loudly when the HIP library is missing or no GPU is visible: there is no CPU
+fallback on the product path (the CPU oracle lives under oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libpovu_hip.so")
+
+
+class _Opts(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class _Tree(C.Structure):
+    _fields_ = [("component_id", C.c_uint32), ("n_vtx", C.c_uint32), ("n_links", C.c_uint32),
+                ("n_pvst", C.c_uint32), ("a_id", C.POINTER(C.c_uint32)), ("z_id", C.POINTER(C.c_uint32)),
+                ("a_or", C.POINTER(C.c_uint8)), ("z_or", C.POINTER(C.c_uint8)), ("parent", C.POINTER(C.c_uint32)),
+                ("n_hairpins", C.c_uint32), ("hairpins", C.POINTER(C.c_uint64))]
+
+
+class _StageTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32)]
+
+
+F_HAIRPINS = 1
+F_SEQUENTIAL = 2
+
+_lib = None
+
+
+def load_lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HipUnavailable(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)")
+    l = C.CDLL(p)
+    l.povu_hip_device_count.restype = C.c_int
+    l.povu_hip_create.restype = C.c_void_p
+    l.povu_hip_create.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    l.povu_hip_destroy.argtypes = [C.c_void_p]
+    l.povu_hip_graph_upload.restype = C.c_int
+    l.povu_hip_graph_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_decompose.restype = C.c_void_p
+    l.povu_hip_decompose.argtypes = [C.c_void_p, C.POINTER(_Opts), C.c_char_p, C.c_size_t]
+    l.povu_hip_forest_total_components.restype = C.c_uint32
+    l.povu_hip_forest_total_components.argtypes = [C.c_void_p]
+    l.povu_hip_forest_tree_count.restype = C.c_uint32
+    l.povu_hip_forest_tree_count.argtypes = [C.c_void_p]
+    l.povu_hip_forest_get.restype = C.c_int
+    l.povu_hip_forest_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Tree)]
+    l.povu_hip_forest_free.argtypes = [C.c_void_p]
+    l.povu_hip_forest_pvst_text.restype = C.c_void_p
+    l.povu_hip_forest_pvst_text.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]
+    l.povu_hip_buffer_free.argtypes = [C.c_void_p]
+    l.povu_hip_last_stage_times.restype = C.c_int
+    l.povu_hip_last_stage_times.argtypes = [C.c_void_p, C.POINTER(_StageTime), C.c_int]
+    l.povu_hip_last_links_processed.restype = C.c_uint64
+    l.povu_hip_last_links_processed.argtypes = [C.c_void_p]
+    l.povu_hip_debug_components.restype = C.c_int
+    l.povu_hip_debug_components.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    l.povu_hip_debug_tree.restype = C.c_int
+    l.povu_hip_debug_tree.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+    l.povu_hip_debug_stack.restype = C.c_int
+    l.povu_hip_debug_stack.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+    l.povu_hip_version.restype = C.c_char_p
+    _lib = l
+    return l
+
+
+@dataclass
+class PvstTree:
+    component_id: int
+    n_vtx: int
+    n_links: int
+    a_id: np.ndarray
+    z_id: np.ndarray
+    a_or: np.ndarray
+    z_or: np.ndarray
+    parent: np.ndarray
+    hairpins: np.ndarray
+    text: Optional[str] = None
+
+
+class Forest:
+    """Result of one decompose call (host memory)."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.povu_hip_forest_free(self._h)
+            self._h = None
+
+    @property
+    def total_components(self) -> int:
+        return self._lib.povu_hip_forest_total_components(self._h)
+
+    def __len__(self) -> int:
+        return self._lib.povu_hip_forest_tree_count(self._h)
+
+    def tree(self, i: int, with_text: bool = False) -> PvstTree:
+        t = _Tree()
+        if self._lib.povu_hip_forest_get(self._h, i, C.byref(t)) != 0:
+            raise IndexError(i)
+        n = t.n_pvst
+        arr = lambda p, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True)  # noqa: E731
+        hp = (np.ctypeslib.as_array(t.hairpins, shape=(2 * t.n_hairpins,)).reshape(-1, 2).copy()
+              if t.n_hairpins else np.zeros((0, 2), dtype=np.uint64))
+        out = PvstTree(t.component_id, t.n_vtx, t.n_links, arr(t.a_id, np.uint32), arr(t.z_id, np.uint32),
+                       arr(t.a_or, np.uint8), arr(t.z_or, np.uint8), arr(t.parent, np.uint32), hp)
+        if with_text:
+            out.text = self.text(i)
+        return out
+
+    def text(self, i: int) -> str:
+        ln = C.c_size_t(0)
+        p = self._lib.povu_hip_forest_pvst_text(self._h, i, C.byref(ln))
+        if not p:
+            raise IndexError(i)
+        s = C.string_at(p, ln.value).decode()
+        self._lib.povu_hip_buffer_free(p)
+        return s
+
+    def texts(self) -> Dict[int, str]:
+        """{component_id: pvst text} -- what `povu decompose` writes as <id>.pvst."""
+        out = {}
+        for i in range(len(self)):
+            t = _Tree()
+            self._lib.povu_hip_forest_get(self._h, i, C.byref(t))
+            out[t.component_id] = self.text(i)
+        return out
+
+
+class HipDecomposer:
+    """One context = one GPU, one stream, one workspace arena."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_lib()
+        if self._lib.povu_hip_device_count() <= 0:
+            raise HipUnavailable("no HIP device visible: the decompose path has no CPU fallback")
+        err = C.create_string_buffer(512)
+        self._ctx = self._lib.povu_hip_create(device, err, 512)
+        if not self._ctx:
+            raise HipUnavailable(err.value.decode())
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.povu_hip_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def upload(self, links, tips=None):
+        """links: povu_amd.workloads.Links (vertex idx based link arrays)."""
+        vid = np.ascontiguousarray(links.vid, dtype=np.uint32)
+        v1 = np.ascontiguousarray(links.v1, dtype=np.uint32)
+        v2 = np.ascontiguousarray(links.v2, dtype=np.uint32)
+        s1 = np.ascontiguousarray(links.s1, dtype=np.uint8)
+        s2 = np.ascontiguousarray(links.s2, dtype=np.uint8)
+        tp = None
+        if tips is not None:
+            tips = np.ascontiguousarray(tips, dtype=np.uint8)
+            tp = tips.ctypes.data
+        err = C.create_string_buffer(512)
+        rc = self._lib.povu_hip_graph_upload(self._ctx, len(vid), vid.ctypes.data, len(v1), v1.ctypes.data,
+                                             s1.ctypes.data, v2.ctypes.data, s2.ctypes.data, tp, err, 512)
+        if rc != 0:
+            raise RuntimeError(err.value.decode())
+
+    def decompose(self, rank: int = 0, world: int = 1, flags: int = 0) -> Forest:
+        o = _Opts(rank, world, flags)
+        err = C.create_string_buffer(512)
+        h = self._lib.povu_hip_decompose(self._ctx, C.byref(o), err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return Forest(self._lib, h)
+
+    def stage_times(self) -> List[dict]:
+        buf = (_StageTime * 64)()
+        n = self._lib.povu_hip_last_stage_times(self._ctx, buf, 64)
+        return [dict(name=buf[i].name.decode(), ms=buf[i].ms, launches=buf[i].launches) for i in range(min(n, 64))]
+
+    def links_processed(self) -> int:
+        return int(self._lib.povu_hip_last_links_processed(self._ctx))
+
+    # ---- parity hooks
+    def debug_components(self, n_vtx: int):
+        comp = np.zeros(n_vtx, dtype=np.uint32)
+        loc = np.zeros(n_vtx, dtype=np.uint32)
+        if self._lib.povu_hip_debug_components(self._ctx, comp.ctypes.data, loc.ctypes.data) != 0:
+            raise RuntimeError("no decompose state")
+        return comp, loc
+
+    def debug_tree(self, comp: int):
+        n = C.c_uint32(0)
+        if self._lib.povu_hip_debug_tree(self._ctx, comp, C.byref(n), None, None, None, None) != 0:
+            raise RuntimeError("no decompose state")
+        gid = np.zeros(n.value, dtype=np.uint32)
+        typ = np.zeros(n.value, dtype=np.uint8)
+        par = np.zeros(n.value, dtype=np.uint32)
+        cls = np.zeros(n.value, dtype=np.uint32)
+        self._lib.povu_hip_debug_tree(self._ctx, comp, C.byref(n), gid.ctypes.data, typ.ctypes.data, par.ctypes.data,
+                                      cls.ctypes.data)
+        return dict(gid=gid, typ=typ & 3, black=(typ >> 2) & 1, par=par, cls=cls)
+
+    def debug_stack(self, comp: int):
+        n = C.c_uint32(0)
+        if self._lib.povu_hip_debug_stack(self._ctx, comp, C.byref(n), None, None, None) != 0:
+            raise RuntimeError("no decompose state")
+        vtx = np.zeros(n.value, dtype=np.uint32)
+        cls = np.zeros(n.value, dtype=np.uint32)
+        ns = np.zeros(n.value, dtype=np.uint32)
+        self._lib.povu_hip_debug_stack(self._ctx, comp, C.byref(n), vtx.ctypes.data, cls.ctypes.data, ns.ctypes.data)
+        return dict(tree_vtx=vtx, cls=cls, next_seen=ns)
