@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- edges/sec decomposed (flubble + PVST) on the MI355X decompose path.
+
+One "step" = one full pass of the hot path (rows B-G: component labelling, re-indexing, spanning
+tree, cycle classes, candidate stack, PVST) over the workload, from "graph resident in HBM as CSR"
+to "PVST arrays on the host" (SURVEY.md 8d).  At N=1 the workload is BASELINE.json configs[1]:
+the synthetic chain-of-bubbles GFA, 1 000 000 segments / 1 999 998 links, one component.  At N>1
+every rank owns one such component (components are the sharding unit; weak scaling) and the
+timed region also contains the PVST gather to rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def algorithmic_bytes(E, V, F):
+    """whole path 48E + 108V + 16F; traversal kernels (rows C-G) 24E + 80V + 16F."""
+    return 48 * E + 108 * V + 16 * F, 24 * E + 80 * V + 16 * F
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--units", type=int, default=333333, help="bubble units per component (K)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="chain", choices=["chain", "nest", "hprc"])
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from povu_amd import HipDecomposer, workloads
+    from povu_amd.sharded import gather_forest
+
+    if args.workload == "chain":
+        g = workloads.chain_of_bubbles(args.units)
+        wl = f"chain-of-bubbles K={args.units}: {g.n_vtx} segments / {g.n_links} links, 1 component per GPU"
+    elif args.workload == "nest":
+        g = workloads.nested_towers(1000, max(1, args.units // 100))
+        wl = f"nested towers depth 1000 x {max(1, args.units // 100)}: {g.n_vtx} segments / {g.n_links} links"
+    else:
+        g = workloads.hprc_shaped([args.units * 3], seed=20260612 + rank)
+        wl = f"HPRC-shaped backbone {args.units * 3}: {g.n_vtx} segments / {g.n_links} links"
+
+    hip = HipDecomposer(local_rank)
+    hip.upload(g)  # inputs resident in HBM before the timed region
+
+    def step():
+        f = hip.decompose()
+        if world > 1:
+            gather_forest(f, rank, world, torch.device("cuda", local_rank))
+        return f
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    f = None
+    for _ in range(args.warmup):
+        f = step()
+    stage_acc = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f = step()
+        for st in hip.stage_times():
+            a = stage_acc.setdefault(st["name"], [0.0, 0])
+            a[0] += st["ms"]
+            a[1] += 1
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n_flub = sum(f.tree(i).a_id.shape[0] - 1 for i in range(len(f)))
+    E, V = g.n_links, g.n_vtx
+    total_links = E * world * args.steps
+    value = total_links / dt
+
+    if rank == 0:
+        stages = {k: v[0] / max(1, v[1]) for k, v in stage_acc.items()}
+        dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
+        whole_b, trav_b = algorithmic_bytes(E, V, n_flub)
+        dom_bytes = trav_b if dom.startswith("traversal") else whole_b - trav_b
+        achieved = dom_bytes / (stages[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "edges/sec decomposed (flubble+PVST)",
+            "value": value,
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": wl, "links_per_gpu": E, "segments_per_gpu": V, "flubbles_per_gpu": n_flub,
+                       "sharding": "one weakly-connected component per GPU; PVST gather to rank 0 over RCCL"
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": stages[dom],
+                         "whole_path_frac": whole_b / (stages.get("total", dt / args.steps * 1e3) * 1e-3) / 1e9
+                         / HBM_PEAK_GBS},
+            "stage_ms": stages,
+        }
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib  # CPU oracle: reported baseline only, never the product path
+            k = min(args.units, 333333)
+            sample = workloads.chain_of_bubbles(k) if args.workload == "chain" else g
+            t1 = time.perf_counter()
+            _, info = oracle_lib.decompose(sample, want_text=False, timings=True)
+            cpu_dt = info["t_componetize"] + info["t_tree"] + info["t_classes"] + info["t_stack"] + info["t_pvst"]
+            out["cpu_baseline"] = {"value": sample.n_links / cpu_dt, "unit": "edges/s", "cores": 1, "kind": "port",
+                                   "sample": f"{sample.n_links} links of the same workload, one pass "
+                                             f"(componetize..add_flubbles {cpu_dt:.2f} s, wall {time.perf_counter() - t1:.2f} s)"}
+        print(json.dumps(out))
+    hip.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
