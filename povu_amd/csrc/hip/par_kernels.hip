@@ -1,0 +1,790 @@
+// par_kernels.hip -- rows D-G as data-parallel kernels over ALL components at once.
+//
+// The reference computes these stages with sequential sweeps (reverse pre-order bracket lists,
+// a list-splicing tree walk, a hash-map sweep and a stack machine).  Because the tree vertex idx
+// IS the DFS pre-order number, every one of them has an exact closed form over pre-order
+// intervals [v, v+size(v)); the kernels below evaluate those closed forms with scans, radix
+// sorts and min-segment-tree descents.  DESIGN.md ("Parallel formulations") derives each one;
+// tests/ differential-test them against the oracle (and the sequential kernels) bit for bit.
+//
+//   D  cycle classes      flubbles.cpp:503-719 (handle_vertex), bracket_list.cpp:61-100
+//   E  candidate stack    tree_utils.cpp:19-155, flubbles.cpp:412-501
+//   F  next_seen          flubbles.cpp:375-410
+//   G  PVST               flubbles.cpp:295-367
+//
+// Index spaces: T-space = global tree vertex idx (component c starts at 2*voff[c]+c, holes are
+// marked gsize == 0); bracket space (dense, all components); stack space (one entry per black
+// tree edge, component-major); emitted-flubble space.
+#include "par_kernels.hpp"
+
+#include <algorithm>
+
+namespace povu_hip
+{
+
+#define NIL POVU_NIL
+static constexpr int TPB = 256;
+static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+#define LAUNCH(k, n, s, ...)                                                                     \
+	do {                                                                                     \
+		if ((n) > 0)                                                                     \
+			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
+	} while (0)
+
+// ------------------------------------------------------------- segment tree
+__global__ void k_seg_leaves(uint32_t P, uint32_t n, const uint32_t *__restrict__ val, uint32_t *__restrict__ tree)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < P)
+		tree[P + i] = i < n ? val[i] : NIL;
+}
+__global__ void k_seg_level(uint32_t first, uint32_t count, uint32_t *tree)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < count) {
+		uint32_t k = first + i;
+		tree[k] = min(tree[2 * k], tree[2 * k + 1]);
+	}
+}
+static void seg_build(SegTree &st, const uint32_t *val, size_t n, hipStream_t s)
+{
+	st.P = SegTree::pow2(std::max<size_t>(n, 1));
+	LAUNCH(k_seg_leaves, st.P, s, st.P, (uint32_t)n, val, st.tree);
+	for (uint32_t first = st.P / 2; first >= 1; first /= 2) {
+		LAUNCH(k_seg_level, first, s, first, first, st.tree);
+		if (first == 1)
+			break;
+	}
+}
+
+__device__ __forceinline__ uint32_t seg_min(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r)
+{
+	uint32_t m = NIL;
+	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
+		if (l & 1)
+			m = min(m, tree[l++]);
+		if (r & 1)
+			m = min(m, tree[--r]);
+	}
+	return m;
+}
+__device__ __forceinline__ uint32_t seg_descend_first(const uint32_t *__restrict__ tree, uint32_t P, uint32_t node,
+						      uint32_t x)
+{
+	while (node < P)
+		node = tree[2 * node] < x ? 2 * node : 2 * node + 1;
+	return node - P;
+}
+__device__ __forceinline__ uint32_t seg_descend_last(const uint32_t *__restrict__ tree, uint32_t P, uint32_t node,
+						     uint32_t x)
+{
+	while (node < P)
+		node = tree[2 * node + 1] < x ? 2 * node + 1 : 2 * node;
+	return node - P;
+}
+// first idx in [l, r) whose value is < x, NIL if none
+__device__ uint32_t seg_first_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
+{
+	if (l >= r)
+		return NIL;
+	uint32_t right[32];
+	int nr = 0;
+	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
+		if (l & 1) {
+			if (tree[l] < x)
+				return seg_descend_first(tree, P, l, x);
+			l++;
+		}
+		if (r & 1)
+			right[nr++] = --r;
+	}
+	for (int k = nr - 1; k >= 0; k--)
+		if (tree[right[k]] < x)
+			return seg_descend_first(tree, P, right[k], x);
+	return NIL;
+}
+// last idx in [l, r) whose value is < x, NIL if none
+__device__ uint32_t seg_last_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
+{
+	if (l >= r)
+		return NIL;
+	uint32_t left[32];
+	int nl = 0;
+	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
+		if (r & 1) {
+			--r;
+			if (tree[r] < x)
+				return seg_descend_last(tree, P, r, x);
+		}
+		if (l & 1)
+			left[nl++] = l++;
+	}
+	for (int k = nl - 1; k >= 0; k--)
+		if (tree[left[k]] < x)
+			return seg_descend_last(tree, P, left[k], x);
+	return NIL;
+}
+
+// ------------------------------------------------------------- T-space setup
+__global__ void k_tcomp_vertices(uint32_t V, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ t_comp)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= V)
+		return;
+	uint32_t c = ckey[i];
+	t_comp[2 * i + c] = c;
+	t_comp[2 * i + 1 + c] = c;
+}
+__global__ void k_tcomp_last(uint32_t C, const uint32_t *__restrict__ voff, uint32_t *__restrict__ t_comp)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < C)
+		t_comp[2 * voff[c + 1] + c] = c;
+}
+__global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ voff,
+			    const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ t_par,
+			    const uint32_t *__restrict__ t_size, uint32_t *__restrict__ gpar, uint32_t *__restrict__ gsize,
+			    uint32_t *__restrict__ t_root)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= T)
+		return;
+	uint32_t c = t_comp[t];
+	uint32_t base = 2 * voff[c] + c, l = t - base;
+	t_root[t] = base;
+	if (l < c_ntree[c]) {
+		uint32_t p = t_par[t];
+		gpar[t] = p == NIL ? NIL : base + p;
+		gsize[t] = t_size[t];
+	} else {
+		gpar[t] = NIL;
+		gsize[t] = 0;
+	}
+}
+__global__ void k_dense_be(uint32_t NB0, uint32_t C, const uint32_t *__restrict__ dbo, const uint32_t *__restrict__ voff,
+			   const uint32_t *__restrict__ eoff, const uint32_t *__restrict__ be_src,
+			   const uint32_t *__restrict__ be_tgt, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB0)
+		return;
+	uint32_t lo = 0, hi = C; // last c with dbo[c] <= j
+	while (hi - lo > 1) {
+		uint32_t mid = (lo + hi) >> 1;
+		if (dbo[mid] <= j)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	uint32_t c = lo, b = j - dbo[c];
+	uint64_t tb = 2ull * voff[c] + c, bb = (uint64_t)eoff[c] + voff[c] + 2 * tb;
+	b_src[j] = (uint32_t)tb + be_src[bb + b];
+	b_tgt[j] = (uint32_t)tb + be_tgt[bb + b];
+}
+
+// ------------------------------------------------------------- row D
+__global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
+		      uint32_t *__restrict__ hi0)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < NB0)
+		atomicMin(&hi0[b_src[j]], b_tgt[j]);
+}
+// hiA(v) = min target of the ordinary back edges leaving subtree(v); bridge(v): none of them
+// reaches a proper ancestor of v (the bracket list of v would be empty but for simplifying edges)
+__global__ void k_hiA(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+		      const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ hiA,
+		      uint32_t *__restrict__ bridge)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= T)
+		return;
+	uint32_t sz = gsize[t];
+	if (sz == 0) {
+		hiA[t] = NIL;
+		bridge[t] = 0;
+		return;
+	}
+	uint32_t m = seg_min(segA, P, t, t + sz);
+	hiA[t] = m;
+	bridge[t] = (gpar[t] != NIL && (m == NIL || m >= t)) ? 1u : 0u;
+}
+// simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
+// the root, flubbles.cpp:621-643); hi(v) = root as soon as subtree(v) holds a simplifying edge
+__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hiA,
+			  const uint32_t *__restrict__ bridge, const uint32_t *__restrict__ psb,
+			  const uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi, uint32_t *__restrict__ simp)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= T)
+		return;
+	uint32_t sz = gsize[t];
+	if (sz == 0) {
+		hi[t] = NIL;
+		simp[t] = 0;
+		return;
+	}
+	uint32_t cnt = psb[t + sz] - psb[t];
+	hi[t] = cnt > 0 ? t_root[t] : hiA[t];
+	simp[t] = (bridge[t] && cnt == 1) ? 1u : 0u;
+}
+// capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
+// ascending idx are v+1, then each next sibling at c + size(c).
+__global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi,
+			  const uint32_t *__restrict__ hi0, uint32_t *__restrict__ cap_tgt, uint32_t *__restrict__ capf)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	uint32_t sz = gsize[v];
+	cap_tgt[v] = NIL;
+	capf[v] = 0;
+	if (sz <= 1)
+		return;
+	const uint32_t end = v + sz;
+	uint32_t hi_1 = NIL;
+	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u))
+		hi_1 = min(hi_1, hi[c]);
+	uint32_t hi_child = NIL;
+	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u))
+		if (hi[c] == hi_1) {
+			hi_child = c;
+			break;
+		}
+	uint32_t hi_2 = NIL;
+	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u))
+		if (c != hi_child && hi[c] < v) {
+			hi_2 = hi[c];
+			break;
+		}
+	if (hi_2 < hi0[v]) {
+		cap_tgt[v] = hi_2;
+		capf[v] = 1;
+	}
+}
+// mirror pre-order (children visited in DESCENDING idx): the order brackets sit in a bracket list,
+// because each child's list is spliced in front of its earlier siblings' (flubbles.cpp:586-588).
+// delta(a) = 1 + sizes of the later siblings of a; mpre(v) = sum of delta over the path root..v.
+__global__ void k_mpre_delta(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+			     uint32_t *__restrict__ dlt)
+{
+	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= T)
+		return;
+	uint32_t sz = gsize[a], p = gpar[a];
+	if (sz == 0 || p == NIL)
+		return;
+	uint32_t d = 1 + (p + gsize[p]) - (a + sz);
+	atomicAdd(&dlt[a], d);
+	atomicAdd(&dlt[a + sz], 0u - d);
+}
+__global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ dlt,
+		       const uint32_t *__restrict__ dlt_ps, const uint32_t *__restrict__ t_root, uint32_t *__restrict__ mpre)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	mpre[v] = gsize[v] ? t_root[v] + dlt_ps[v] + dlt[v] : NIL;
+}
+// sort key of a bracket: (mirror pre-order of its source) then, inside one source, the later pushed
+// first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643)
+__global__ void k_bracket_keys_ord(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ mpre,
+				   unsigned long long *__restrict__ key, uint32_t *__restrict__ val,
+				   uint32_t *__restrict__ incnt, const uint32_t *__restrict__ b_tgt)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB0)
+		return;
+	key[j] = ((unsigned long long)mpre[b_src[j]] << 32) | (unsigned long long)(0xFFFFFFFFu - j);
+	val[j] = j;
+	atomicAdd(&incnt[b_tgt[j]], 1u);
+}
+__global__ void k_bracket_keys_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ capf,
+				     const uint32_t *__restrict__ pscap, const uint32_t *__restrict__ simp,
+				     const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
+				     const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ mpre,
+				     unsigned long long *__restrict__ key, uint32_t *__restrict__ val,
+				     uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt, uint32_t *__restrict__ incnt)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	if (capf[v]) {
+		uint32_t j = NB0 + pscap[v];
+		b_src[j] = v;
+		b_tgt[j] = cap_tgt[v];
+		key[j] = ((unsigned long long)mpre[v] << 32) | (unsigned long long)(0xFFFFFFFFu - 0x80000000u);
+		val[j] = j;
+		atomicAdd(&incnt[cap_tgt[v]], 1u);
+	}
+	if (simp[v]) {
+		uint32_t j = NB0 + ncap + pssimp[v];
+		b_src[j] = v;
+		b_tgt[j] = t_root[v];
+		key[j] = ((unsigned long long)mpre[v] << 32) | (unsigned long long)(0xFFFFFFFFu - 0x80000001u);
+		val[j] = j;
+		atomicAdd(&incnt[t_root[v]], 1u);
+	}
+}
+__global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src,
+			     uint32_t *__restrict__ dst)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		dst[i] = src[idx[i]];
+}
+__device__ __forceinline__ uint32_t lower_bound_hi32(const unsigned long long *__restrict__ key, uint32_t n, uint32_t x)
+{
+	uint32_t lo = 0, hi = n; // first i with (key[i] >> 32) >= x
+	while (lo < hi) {
+		uint32_t mid = (lo + hi) >> 1;
+		if ((uint32_t)(key[mid] >> 32) < x)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+// top bracket and bracket-list size at v when the class of tree edge (parent(v), v) is decided
+// (flubbles.cpp:664-686): the live brackets are those with source in subtree(v) and target a
+// proper ancestor of v; in list order they are a contiguous key range, the top is the first live one.
+__global__ void k_top_bracket(uint32_t T, uint32_t NB, const uint32_t *__restrict__ gsize,
+			      const uint32_t *__restrict__ gpar, const uint32_t *__restrict__ mpre,
+			      const unsigned long long *__restrict__ rkey, const uint32_t *__restrict__ segB, uint32_t P,
+			      const uint32_t *__restrict__ psin, unsigned long long *__restrict__ ckey,
+			      uint32_t *__restrict__ cval, uint32_t *__restrict__ lsz, uint32_t *__restrict__ err)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	cval[v] = v;
+	uint32_t sz = gsize[v];
+	if (sz == 0 || gpar[v] == NIL) {
+		ckey[v] = ~0ull;
+		lsz[v] = 0;
+		return;
+	}
+	uint32_t m = mpre[v];
+	uint32_t lo = lower_bound_hi32(rkey, NB, m), hi = lower_bound_hi32(rkey, NB, m + sz);
+	uint32_t i = seg_first_less(segB, P, lo, hi, v);
+	if (i == NIL) {
+		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
+		ckey[v] = ~0ull;
+		lsz[v] = 0;
+		return;
+	}
+	lsz[v] = (hi - lo) - (psin[v + sz] - psin[v]);
+	// same top bracket => same group; inside a group the pass runs from the deepest vertex up
+	ckey[v] = ((unsigned long long)i << 32) | (unsigned long long)(0xFFFFFFFFu - v);
+}
+// a bracket hands out a new class whenever the list size differs from the size it saw last
+// (recent_size / recent_class, flubbles.cpp:668-676)
+__global__ void k_class_flags(uint32_t T, const unsigned long long *__restrict__ skey, const uint32_t *__restrict__ sval,
+			      const uint32_t *__restrict__ lsz, uint32_t *__restrict__ flag)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= T)
+		return;
+	unsigned long long k = skey[q];
+	if (k == ~0ull) {
+		flag[q] = 0;
+		return;
+	}
+	bool fresh = q == 0 || (uint32_t)(skey[q - 1] >> 32) != (uint32_t)(k >> 32) || lsz[sval[q - 1]] != lsz[sval[q]];
+	flag[q] = fresh ? 1u : 0u;
+}
+__global__ void k_class_scatter(uint32_t T, const unsigned long long *__restrict__ skey, const uint32_t *__restrict__ sval,
+				const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
+				uint32_t *__restrict__ gcls)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= T)
+		return;
+	if (skey[q] == ~0ull)
+		gcls[sval[q]] = NIL;
+	else
+		gcls[sval[q]] = ps[q] + flag[q] - 1; // inclusive scan - 1
+}
+
+// ------------------------------------------------------------- row E
+// candidate-stack order = pre-order, except that under a branching entered side `a` the black
+// child's subtree comes after the gray children's (tree_utils.cpp:47-76, flubbles.cpp:446-457)
+__global__ void k_shift_delta(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+			      const uint8_t *__restrict__ tf, uint32_t *__restrict__ dlt)
+{
+	uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= T)
+		return;
+	uint32_t sb = gsize[b];
+	if (sb == 0 || !(tf[b] & TF_BLACK))
+		return;
+	uint32_t a = gpar[b], g = gsize[a] - 1 - sb;
+	if (g == 0)
+		return;
+	atomicAdd(&dlt[b], g);		       // the black subtree moves behind the gray ones
+	atomicAdd(&dlt[b + sb], 0u - g - sb); // the gray subtrees move forward by size(black)
+	atomicAdd(&dlt[a + gsize[a]], sb);
+}
+__global__ void k_mpos_scatter(uint32_t T, const uint32_t *__restrict__ dlt, const uint32_t *__restrict__ dlt_ps,
+			       uint32_t *__restrict__ inv)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < T)
+		inv[v + dlt_ps[v] + dlt[v]] = v;
+}
+__global__ void k_black_flag(uint32_t T, const uint32_t *__restrict__ inv, const uint32_t *__restrict__ gsize,
+			     const uint8_t *__restrict__ tf, uint32_t *__restrict__ flag)
+{
+	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= T)
+		return;
+	uint32_t v = inv[m];
+	flag[m] = (gsize[v] && (tf[v] & TF_BLACK)) ? 1u : 0u;
+}
+__global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const uint32_t *__restrict__ flag,
+			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
+			     const uint32_t *__restrict__ t_comp, uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls,
+			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ s_iota)
+{
+	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= T || !flag[m])
+		return;
+	uint32_t v = inv[m], i = ps[m];
+	s_vtx[i] = v;
+	s_cls[i] = gcls[v];
+	s_comp[i] = t_comp[v];
+	s_iota[i] = i;
+}
+__global__ void k_stack_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ ps,
+				uint32_t T, uint32_t *__restrict__ soff)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c > C)
+		return;
+	soff[c] = c == C ? ps[T] : ps[2 * voff[c] + c];
+}
+
+// ------------------------------------------------------------- row F
+__global__ void k_next_prev(uint32_t S, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+			    uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= S)
+		return;
+	uint32_t i = sval[q];
+	bool has_next = q + 1 < S && skey[q + 1] == skey[q];
+	ns[i] = has_next ? sval[q + 1] : i;
+	bool has_prev = q > 0 && skey[q - 1] == skey[q];
+	prev[i] = has_prev ? sval[q - 1] : NIL;
+}
+
+// ------------------------------------------------------------- row G
+// add_flubbles as a stack machine: at entry i, "class already open" pops through it and moves the
+// PVST parent one level up (U, saturating at the root); a non-adjacent next occurrence emits a
+// flubble and descends (D).  When the (prev, i) intervals are laminar the class is open iff it
+// occurred before, so U/D are known per entry; a crossing pair sends the component to the
+// sequential kernel instead.
+__global__ void k_laminar(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
+			  const uint32_t *__restrict__ s_comp, uint32_t *__restrict__ comp_bad)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= S)
+		return;
+	uint32_t p = prev[i];
+	if (p == NIL || p + 1 >= i)
+		return;
+	if (seg_min(segP, P, p + 1, i) < p)
+		comp_bad[s_comp[i]] = 1;
+}
+__global__ void k_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ ns,
+		       uint32_t *__restrict__ walk, uint32_t *__restrict__ dflag)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= S)
+		return;
+	uint32_t d = (i + 1 < ns[i]) ? 1u : 0u;
+	walk[2 * i] = prev[i] != NIL ? 0xFFFFFFFFu : 0u; // -1
+	walk[2 * i + 1] = d;
+	dflag[i] = d;
+}
+__global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const uint32_t *__restrict__ ps,
+			    uint32_t *__restrict__ out)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n)
+		out[k] = ps[k] + walk[k] + 0x80000000u; // inclusive prefix sum, biased so that u32 order = int order
+}
+__global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
+			 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
+			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ segW, uint32_t P,
+			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= S || !dflag[i])
+		return;
+	uint32_t c = s_comp[i], k0 = 2 * soff[c], k = 2 * i + 1;
+	int base = k0 ? (int)(wb[k0 - 1] - 0x80000000u) : 0;
+	int cur = (int)(wb[k] - 0x80000000u) - base;
+	int mn = (int)(seg_min(segW, P, k0, k + 1) - 0x80000000u) - base;
+	if (mn > 0)
+		mn = 0;
+	uint32_t j = erank[i];
+	lev[j] = (uint32_t)(cur - mn); // depth of the new flubble (>= 1)
+	e_i[j] = i;
+}
+__global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const uint32_t *__restrict__ e_i,
+			    const uint32_t *__restrict__ segL, uint32_t P, const uint32_t *__restrict__ s_comp,
+			    const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
+			    const uint32_t *__restrict__ voff, const uint32_t *__restrict__ ns,
+			    const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
+			    const uint32_t *__restrict__ t_gid, uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a,
+			    uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_or)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NE)
+		return;
+	uint32_t i = e_i[j], c = s_comp[i], jb = erank[soff[c]];
+	uint32_t jp = seg_last_less(segL, P, jb, j, lev[j]);
+	uint64_t pb = (uint64_t)voff[c] + c;
+	uint32_t k = 1 + (j - jb);
+	uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
+	uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
+	if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
+		p_a[pb + k] = t_gid[vz];
+		p_z[pb + k] = t_gid[va];
+		p_or[pb + k] = 0;
+	} else {
+		p_a[pb + k] = t_gid[va];
+		p_z[pb + k] = t_gid[vz];
+		p_or[pb + k] = (uint8_t)(ra | (rz << 1));
+	}
+	p_parent[pb + k] = jp == NIL ? 0u : 1 + (jp - jb);
+}
+__global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ c_ntree,
+			     const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
+			     uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
+			     uint8_t *__restrict__ p_or, uint32_t *__restrict__ c_npvst, uint32_t *__restrict__ c_nstack)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	if (c_ntree[c] == 0) {
+		c_npvst[c] = 0;
+		return;
+	}
+	uint64_t pb = (uint64_t)voff[c] + c;
+	p_parent[pb] = NIL;
+	p_a[pb] = p_z[pb] = NIL;
+	p_or[pb] = 0;
+	c_npvst[c] = 1 + (erank[soff[c + 1]] - erank[soff[c]]);
+	c_nstack[c] = soff[c + 1] - soff[c];
+}
+// copies of the parallel results into the per-component layout the debug hooks read
+__global__ void k_export_stack(uint32_t S, const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
+			       const uint32_t *__restrict__ voff, const uint32_t *__restrict__ s_vtx,
+			       const uint32_t *__restrict__ s_cls, const uint32_t *__restrict__ ns,
+			       uint32_t *__restrict__ o_vtx, uint32_t *__restrict__ o_cls, uint32_t *__restrict__ o_ns)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= S)
+		return;
+	uint32_t c = s_comp[i], l = i - soff[c], base = 2 * voff[c] + c;
+	o_vtx[voff[c] + l] = s_vtx[i] - base;
+	o_cls[voff[c] + l] = s_cls[i];
+	o_ns[voff[c] + l] = ns[i] - soff[c];
+}
+__global__ void k_export_cls(uint32_t T, const uint32_t *__restrict__ gcls, uint32_t *__restrict__ t_cls)
+{
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < T)
+		t_cls[t] = gcls[t];
+}
+
+// ------------------------------------------------------------- workspace
+template <typename F>
+static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
+{
+	const size_t T = 2 * V + Cmax, NB = E + V + 2 * T, S = V + 1;
+	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.hiA, &pw.hi, &pw.flagA, &pw.psA,
+			     &pw.flagB, &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
+			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.inv, &pw.vals_t, &pw.vals_t2})
+		take((void **)p, (T + 2) * 4);
+	take((void **)&pw.keys_t, (T + 2) * 8);
+	take((void **)&pw.keys_t2, (T + 2) * 8);
+	take((void **)&pw.dbo, (Cmax + 2) * 4);
+	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_val, &pw.b_val2, &pw.tgtR})
+		take((void **)p, (NB + 2) * 4);
+	take((void **)&pw.b_key, (NB + 2) * 8);
+	take((void **)&pw.b_key2, (NB + 2) * 8);
+	for (uint32_t **p : {&pw.s_vtx, &pw.s_cls, &pw.s_comp, &pw.ns, &pw.prev, &pw.s_key, &pw.s_key2, &pw.s_val, &pw.s_val2,
+			     &pw.erank, &pw.lev, &pw.e_i})
+		take((void **)p, (S + 2) * 4);
+	take((void **)&pw.soff, (Cmax + 2) * 4);
+	take((void **)&pw.walk, (2 * S + 4) * 4);
+	take((void **)&pw.walk_ps, (2 * S + 4) * 4);
+	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
+	take((void **)&pw.err, 64);
+	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
+	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
+	take((void **)&pw.segP.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
+	take((void **)&pw.segW.tree, 2 * (size_t)SegTree::pow2(2 * S + 2) * 4);
+	take((void **)&pw.segL.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
+	pw.scan_tmp_bytes = scan_tmp_bytes(std::max(T, NB) + 4);
+	pw.sort_tmp_bytes = std::max(sort64_tmp_bytes(std::max(T, NB) + 4), sort_tmp_bytes(S + 4));
+	take(&pw.scan_tmp, pw.scan_tmp_bytes);
+	take(&pw.sort_tmp, pw.sort_tmp_bytes);
+}
+
+size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax)
+{
+	ParWs tmp{};
+	size_t total = 0;
+	for_each_span(tmp, V, E, Cmax, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
+	return total + (1 << 20);
+}
+
+void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax)
+{
+	for_each_span(pw, V, E, Cmax, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+}
+
+// ------------------------------------------------------------- driver
+static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
+{
+	uint32_t v = 0;
+	HIP_CHECK(hipMemcpyAsync(&v, dptr, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return v;
+}
+
+uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s)
+{
+	const uint32_t V = sw.V, T = 2 * V + C;
+	pw.V = V;
+	pw.E = sw.E;
+	pw.C = C;
+	pw.T = T;
+	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
+		scan_exclusive_u32(in, out, n, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	};
+
+	// ---- T-space + dense back edges
+	tm.begin("par_setup");
+	fill_u32(pw.t_comp, (size_t)T + 1, NIL, s);
+	LAUNCH(k_tcomp_vertices, V, s, V, cs.ckey, pw.t_comp);
+	LAUNCH(k_tcomp_last, C, s, C, cs.voff, pw.t_comp);
+	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root);
+	HIP_CHECK(hipMemsetAsync(sw.c_nbe0 + C, 0, 4, s));
+	scan(sw.c_nbe0, pw.dbo, (size_t)C + 1);
+	HIP_CHECK(hipMemsetAsync(pw.err, 0, 64, s));
+	HIP_CHECK(hipMemsetAsync(pw.comp_bad, 0, ((size_t)C + 1) * 4, s));
+	const uint32_t NB0 = read_u32(pw.dbo + C, s);
+	LAUNCH(k_dense_be, NB0, s, NB0, C, pw.dbo, cs.voff, cs.eoff, sw.be_src, sw.be_tgt, pw.b_src, pw.b_tgt);
+	tm.end(7);
+
+	// ---- row D
+	tm.begin("par_classes");
+	uint32_t launches = 0;
+	fill_u32(pw.hi0, (size_t)T + 1, NIL, s);
+	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0);
+	seg_build(pw.segA, pw.hi0, T, s);
+	uint32_t *bridge = pw.flagA, *psb = pw.psA, *simp = pw.flagB, *pssimp = pw.psB, *capf = pw.flagC, *pscap = pw.psC;
+	LAUNCH(k_hiA, T, s, T, pw.gsize, pw.gpar, pw.segA.tree, pw.segA.P, pw.hiA, bridge);
+	HIP_CHECK(hipMemsetAsync(bridge + T, 0, 4, s));
+	scan(bridge, psb, (size_t)T + 1);
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, pw.hiA, bridge, psb, pw.t_root, pw.hi, simp);
+	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi, pw.hi0, pw.cap_tgt, capf);
+	HIP_CHECK(hipMemsetAsync(simp + T, 0, 4, s));
+	HIP_CHECK(hipMemsetAsync(capf + T, 0, 4, s));
+	scan(simp, pssimp, (size_t)T + 1);
+	scan(capf, pscap, (size_t)T + 1);
+	HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)T + 2) * 4, s));
+	LAUNCH(k_mpre_delta, T, s, T, pw.gsize, pw.gpar, pw.dlt);
+	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
+	LAUNCH(k_mpre, T, s, T, pw.gsize, pw.dlt, pw.dlt_ps, pw.t_root, pw.mpre);
+	uint32_t extra[2];
+	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
+	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)T + 2) * 4, s));
+	LAUNCH(k_bracket_keys_ord, NB0, s, NB0, pw.b_src, pw.mpre, (unsigned long long *)pw.b_key, pw.b_val, pw.incnt,
+	       pw.b_tgt);
+	LAUNCH(k_bracket_keys_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.mpre,
+	       (unsigned long long *)pw.b_key, pw.b_val, pw.b_src, pw.b_tgt, pw.incnt);
+	scan(pw.incnt, pw.psin, (size_t)T + 1);
+	sort_pairs_u64(pw.b_key, pw.b_key2, pw.b_val, pw.b_val2, NB, 64, pw.sort_tmp, pw.sort_tmp_bytes, s);
+	LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
+	seg_build(pw.segB, pw.tgtR, NB, s);
+	LAUNCH(k_top_bracket, T, s, T, NB, pw.gsize, pw.gpar, pw.mpre, (const unsigned long long *)pw.b_key2,
+	       pw.segB.tree, pw.segB.P, pw.psin, (unsigned long long *)pw.keys_t, pw.vals_t, pw.lsz, pw.err);
+	sort_pairs_u64(pw.keys_t, pw.keys_t2, pw.vals_t, pw.vals_t2, T, 64, pw.sort_tmp, pw.sort_tmp_bytes, s);
+	uint32_t *cflag = pw.flagA, *cps = pw.psA; // bridge flags are dead by now
+	LAUNCH(k_class_flags, T, s, T, (const unsigned long long *)pw.keys_t2, pw.vals_t2, pw.lsz, cflag);
+	HIP_CHECK(hipMemsetAsync(cflag + T, 0, 4, s));
+	scan(cflag, cps, (size_t)T + 1);
+	LAUNCH(k_class_scatter, T, s, T, (const unsigned long long *)pw.keys_t2, pw.vals_t2, cflag, cps, pw.gcls);
+	LAUNCH(k_export_cls, T, s, T, pw.gcls, sw.t_cls);
+	launches = 30 + 2 * 22;
+	tm.end(launches);
+
+	// ---- row E
+	tm.begin("par_stack");
+	HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)T + 2) * 4, s));
+	LAUNCH(k_shift_delta, T, s, T, pw.gsize, pw.gpar, sw.t_flags, pw.dlt);
+	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
+	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.inv);
+	uint32_t *bflag = pw.flagB, *bps = pw.psB;
+	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
+	HIP_CHECK(hipMemsetAsync(bflag + T, 0, 4, s));
+	scan(bflag, bps, (size_t)T + 1);
+	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.s_val);
+	LAUNCH(k_stack_offsets, (size_t)C + 1, s, C, cs.voff, bps, T, pw.soff);
+	const uint32_t S = read_u32(bps + T, s);
+	const uint32_t n_class = read_u32(cps + T, s);
+	tm.end(9);
+
+	// ---- row F
+	tm.begin("par_next_seen");
+	sort_pairs_u32(pw.s_cls, pw.s_key2, pw.s_val, pw.s_val2, S, bits_for((uint64_t)n_class + 1), pw.sort_tmp,
+		       pw.sort_tmp_bytes, s);
+	LAUNCH(k_next_prev, S, s, S, pw.s_key2, pw.s_val2, pw.ns, pw.prev);
+	tm.end(2);
+
+	// ---- row G
+	tm.begin("par_pvst");
+	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
+	LAUNCH(k_laminar, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.comp_bad);
+	uint32_t *dflag = pw.s_key; // scratch
+	LAUNCH(k_walk, S, s, S, pw.prev, pw.ns, pw.walk, dflag);
+	HIP_CHECK(hipMemsetAsync(dflag + S, 0, 4, s));
+	scan(dflag, pw.erank, (size_t)S + 1);
+	scan(pw.walk, pw.walk_ps, (size_t)2 * S);
+	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
+	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb);
+	seg_build(pw.segW, wb, (size_t)2 * S, s);
+	const uint32_t NE = read_u32(pw.erank + S, s);
+	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i);
+	seg_build(pw.segL, pw.lev, NE, s);
+	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, cs.voff, pw.ns,
+	       pw.s_vtx, sw.t_flags, sw.t_gid, sw.p_parent, sw.p_a, sw.p_z, sw.p_or);
+	LAUNCH(k_pvst_roots, C, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, sw.p_parent, sw.p_a, sw.p_z, sw.p_or,
+	       sw.c_npvst, sw.c_nstack);
+	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
+	       sw.next_seen);
+	tm.end(12 + 3 * 22);
+
+	uint32_t err0 = read_u32(pw.err, s);
+	if (err0)
+		throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
+	// count flagged components
+	std::vector<uint32_t> bad(C);
+	HIP_CHECK(hipMemcpyAsync(bad.data(), pw.comp_bad, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	uint32_t nbad = 0;
+	for (uint32_t c = 0; c < C; c++)
+		nbad += bad[c] ? 1 : 0;
+	return nbad;
+}
+
+} // namespace povu_hip

@@ -1,0 +1,54 @@
+// par_kernels.hpp -- data-parallel formulations of rows D-G (see par_kernels.hip)
+#pragma once
+#include "common.hpp"
+#include "graph_kernels.hpp"
+#include "seq_kernels.hpp"
+
+namespace povu_hip
+{
+
+// Array-based min segment tree over n values (padded to a power of two with +inf).
+struct SegTree {
+	uint32_t *tree = nullptr; // [2P], node 1 = root, leaves at [P, 2P)
+	uint32_t P = 1;
+	static uint32_t pow2(size_t n)
+	{
+		uint32_t p = 1;
+		while (p < n)
+			p <<= 1;
+		return p;
+	}
+};
+
+struct ParWs {
+	uint32_t V, E, C, T;
+	// T-space (global tree vertex idx)
+	uint32_t *t_comp, *t_root, *gpar, *gsize;
+	uint32_t *hi0, *hiA, *hi, *flagA, *psA, *flagB, *psB, *flagC, *psC; // flags + their exclusive scans [T+1]
+	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
+	uint32_t *inv, *vals_t, *vals_t2;
+	uint64_t *keys_t, *keys_t2; // [T]
+	// dense back edges / brackets
+	uint32_t *dbo;			 // [C+1]
+	uint32_t *b_src, *b_tgt, *b_val, *b_val2, *tgtR; // [NBmax]
+	uint64_t *b_key, *b_key2;	 // [NBmax]
+	// candidate stack space
+	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev, *soff; // [V+1] / soff [C+1]
+	uint32_t *s_key, *s_key2, *s_val, *s_val2;
+	uint32_t *walk, *walk_ps;	 // [2V+2]
+	uint32_t *erank, *lev, *e_i;	 // [V+1]
+	uint32_t *comp_bad;		 // [C+1] components that must be redone sequentially
+	uint32_t *err;			 // [4] internal error words
+	SegTree segA, segB, segP, segW, segL;
+	void *scan_tmp, *sort_tmp;
+	size_t scan_tmp_bytes, sort_tmp_bytes;
+};
+
+size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax);
+void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
+
+// Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
+// left in `sw`.  Returns the number of components flagged for a sequential redo (comp_bad).
+uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s);
+
+} // namespace povu_hip

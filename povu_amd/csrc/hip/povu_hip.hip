@@ -5,6 +5,7 @@
 
 #include "graph_kernels.hpp"
 #include "seq_kernels.hpp"
+#include "par_kernels.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -41,6 +42,8 @@ struct povu_hip_ctx {
 	uint32_t C = 0;
 	CompState cs{};
 	SeqWs sw{};
+	ParWs pw{};
+	uint32_t last_seq_redo = 0;
 };
 
 static void set_err(char *err, size_t errlen, const std::string &msg)
@@ -222,6 +225,7 @@ size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool
 	take(&sw.first_child, T, 4);
 	take(&sw.next_sib, T, 4);
 	take(&sw.last_child, T, 4);
+	take(&sw.t_size, T, 4);
 	take(&sw.t_flags, T, 1);
 	take(&sw.ctr, nS + 1, 4);
 	take(&sw.cur, nS + 1, 4);
@@ -303,8 +307,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
-		ctx->ws.reserve(carve_workspace(nullptr, z, cs, sw, hairpins));
+		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0 || hairpins;
+		ctx->ws.reserve(carve_workspace(nullptr, z, cs, sw, hairpins) +
+				(all_seq ? 0 : par_workspace_bytes(z.V, z.E, z.Cmax)));
 		carve_workspace(&ctx->ws, z, cs, sw, hairpins);
+		if (!all_seq)
+			par_carve(ctx->ws, ctx->pw, z.V, z.E, z.Cmax);
 
 		StageTimer &tm = ctx->timer;
 		tm.reset();
@@ -375,9 +383,29 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		for (uint32_t *p : {sw.c_ntree, sw.c_nbe0, sw.c_nbe, sw.c_nstack, sw.c_npvst, sw.c_nclass, sw.c_nbry, sw.c_status})
 			HIP_CHECK(hipMemsetAsync(p, 0, (size_t)(C + 1) * 4, s));
 		tm.end(15);
-		tm.begin("traversal_seq");
-		launch_seq_components(sw, s);
-		tm.end(1);
+		sw.comp_sel = nullptr;
+		ctx->last_seq_redo = 0;
+		if (all_seq) {
+			tm.begin("traversal_seq");
+			sw.stages = SEQ_STAGE_ALL;
+			launch_seq_components(sw, s);
+			tm.end(1);
+		} else {
+			tm.begin("tree_seq");
+			sw.stages = SEQ_STAGE_TREE;
+			launch_seq_components(sw, s);
+			tm.end(1);
+			const uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, tm, s);
+			ctx->last_seq_redo = nbad;
+			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
+				tm.begin("redo_seq");
+				sw.stages = SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST;
+				sw.comp_sel = ctx->pw.comp_bad;
+				launch_seq_components(sw, s);
+				sw.comp_sel = nullptr;
+				tm.end(1);
+			}
+		}
 
 		// ---- PVST arrays back to the host
 		tm.begin("pvst_d2h");

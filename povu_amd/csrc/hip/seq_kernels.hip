@@ -28,7 +28,7 @@ struct CompView {
 	const uint32_t *loff, *ladj; // global arrays (indexed by sorted side id / slot)
 	const uint32_t *gid_s;
 	// tree arrays, local tree idx
-	uint32_t *gid, *par, *cls, *hi, *fchild, *nsib, *lchild;
+	uint32_t *gid, *par, *cls, *hi, *fchild, *nsib, *lchild, *size;
 	uint8_t *tf;
 	uint32_t *ctr, *cur; // indexed by (sorted side id - Sb)
 	uint32_t *stk;
@@ -158,9 +158,13 @@ __device__ static void seq_spanning_tree(CompView &c, uint64_t start_key)
 				add_be(c, p, x, 0);
 		}
 		c.cur[ls] = k - lo;
-		if (!found)
+		if (!found) {
+			c.size[p] = counter - p; // tree idx = pre-order number, so the subtree is [p, counter)
 			sp--;
+		}
 	}
+	if (has_tips)
+		c.size[0] = counter;
 }
 
 // ------------------------------------------------------------------ row D
@@ -414,11 +418,11 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 		const uint32_t ci = w.order[slot];
 		if (w.world > 1 && w.owner[ci] != w.rank)
 			continue;
+		if (w.comp_sel && !w.comp_sel[ci])
+			continue;
 		CompView c;
 		c.nv = w.voff[ci + 1] - w.voff[ci];
 		c.ne = w.eoff[ci + 1] - w.eoff[ci];
-		w.c_status[ci] = 0;
-		w.c_npvst[ci] = 0;
 		if (c.nv < 3) // decompose.cpp:135-142
 			continue;
 		const uint64_t tb = 2ull * w.voff[ci] + ci;
@@ -435,6 +439,7 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 		c.fchild = w.first_child + tb;
 		c.nsib = w.next_sib + tb;
 		c.lchild = w.last_child + tb;
+		c.size = w.t_size + tb;
 		c.tf = w.t_flags + tb;
 		c.ctr = w.ctr + c.Sb;
 		c.cur = w.cur + c.Sb;
@@ -474,16 +479,29 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 		c.aux = w.aux + pb;
 		c.hairpins = w.hairpins ? w.hairpins + 2 * pb : nullptr;
 
-		seq_spanning_tree(c, w.start_key[ci]);
-		w.c_ntree[ci] = c.N;
-		w.c_nbe0[ci] = c.n_be;
-		seq_cycle_classes(c, w.hairpins != nullptr);
-		w.c_nbe[ci] = c.n_be;
-		w.c_nclass[ci] = c.n_class;
-		w.c_nbry[ci] = c.n_bry;
-		const uint32_t n = seq_candidate_stack(c);
-		w.c_nstack[ci] = n;
-		w.c_npvst[ci] = seq_pvst(c, n);
+		if (w.stages & SEQ_STAGE_TREE) {
+			seq_spanning_tree(c, w.start_key[ci]);
+			w.c_ntree[ci] = c.N;
+			w.c_nbe0[ci] = c.n_be;
+		} else {
+			c.N = w.c_ntree[ci];
+			c.n_be = w.c_nbe0[ci];
+		}
+		if (w.stages & SEQ_STAGE_CLASSES) {
+			seq_cycle_classes(c, w.hairpins != nullptr);
+			w.c_nbe[ci] = c.n_be;
+			w.c_nclass[ci] = c.n_class;
+			w.c_nbry[ci] = c.n_bry;
+		} else {
+			c.n_class = w.c_nclass[ci];
+		}
+		uint32_t n = w.c_nstack[ci];
+		if (w.stages & SEQ_STAGE_STACK) {
+			n = seq_candidate_stack(c);
+			w.c_nstack[ci] = n;
+		}
+		if (w.stages & SEQ_STAGE_PVST)
+			w.c_npvst[ci] = seq_pvst(c, n);
 		w.c_status[ci] = 1;
 	}
 }

@@ -9,6 +9,12 @@ namespace povu_hip
 #define TF_TYPE_MASK 3u /* 0 = l, 1 = r, 2 = dummy */
 #define TF_BLACK 4u	/* parent tree edge is black */
 
+#define SEQ_STAGE_TREE 1u
+#define SEQ_STAGE_CLASSES 2u
+#define SEQ_STAGE_STACK 4u
+#define SEQ_STAGE_PVST 8u
+#define SEQ_STAGE_ALL 15u
+
 // Sizes: V vertices, E links, C components.
 //   T = 2V + C tree vertices;  component c owns [toff(c), toff(c)+2*nv_c+1),  toff(c) = 2*voff[c] + c
 //   B = E + V + 2T back edges; component c owns [boff(c), ...), boff(c) = eoff[c] + voff[c] + 2*toff(c)
@@ -17,6 +23,8 @@ namespace povu_hip
 struct SeqWs {
 	uint32_t V, E, C;
 	uint32_t rank, world, flags;
+	uint32_t stages;	  // SEQ_STAGE_* mask
+	const uint32_t *comp_sel; // optional [C]: only components with a non-zero entry are processed
 	// inputs (sorted space)
 	const uint32_t *voff, *eoff, *loff, *ladj, *gid_s;
 	const uint8_t *tip_s;
@@ -25,6 +33,7 @@ struct SeqWs {
 	const uint32_t *owner; // [C] shard that owns the component
 	// spanning tree
 	uint32_t *t_gid, *t_par, *t_cls, *t_hi, *first_child, *next_sib, *last_child; // [T]
+	uint32_t *t_size;							       // [T] subtree sizes
 	uint8_t *t_flags;							       // [T]
 	uint32_t *ctr, *cur;							       // [2V]
 	uint32_t *stk;								       // [T]

@@ -117,3 +117,21 @@ def test_nested_towers_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))
     assert md5(gpu_texts(hip, W.nested_towers(5, 1))[1]) == a["md5"]["nested_towers:5x1"]
     assert md5(gpu_texts(hip, W.nested_towers(1000, 100))[1]) == a["md5"]["nested_towers:1000x100"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sequential_kernels_match_oracle(hip, seed):
+    """POVU_HIP_F_SEQUENTIAL: the one-lane-per-component fallback for every stage."""
+    from povu_amd.hip import F_SEQUENTIAL
+    n = 50 + 23 * seed
+    g = W.random_bidirected(n, int(n * 1.4), 500 + seed)
+    hip.upload(g)
+    assert hip.decompose(flags=F_SEQUENTIAL).texts() == O.decompose(g)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_dense_random_graphs(hip, seed):
+    """Higher link density: many capping edges, >= 3 children with hi < v (the hi_2 quirk)."""
+    n = 40 + 11 * seed
+    g = W.random_bidirected(n, int(n * (2.0 + 0.1 * (seed % 10))), 9000 + seed, connected=True)
+    assert gpu_texts(hip, g) == O.decompose(g)
