@@ -69,6 +69,7 @@ typedef struct {
 } povu_hip_opts;
 #define POVU_HIP_F_HAIRPINS 1u /* also report hairpin boundaries (--hairpins, flubbles.cpp:712-717) */
 #define POVU_HIP_F_SEQUENTIAL 2u /* force the one-lane-per-component kernels for every stage */
+#define POVU_HIP_F_SEQ_TREE 4u /* sequential spanning tree, parallel classes/stack/PVST (A/B testing) */
 
 /*
  * Rows B-G.  Decomposes the resident graph: weakly connected components

@@ -72,23 +72,27 @@ __global__ void k_uf_init(uint32_t V, uint32_t *parent)
 }
 
 __global__ void k_uf_union(uint32_t E, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
-			   uint32_t *parent)
+			   uint32_t *parent, uint32_t *__restrict__ hook)
 {
 	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= E)
 		return;
 	uint32_t a = v1[e], b = v2[e];
-	if (a == b)
-		return;
-	uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
-	while (ra != rb) {
-		uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
-		uint32_t old = atomicCAS(&parent[hi], hi, lo);
-		if (old == hi)
-			break;
-		ra = uf_find(parent, old);
-		rb = uf_find(parent, lo);
+	uint32_t merged = 0;
+	if (a != b) {
+		uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
+		while (ra != rb) {
+			uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+			uint32_t old = atomicCAS(&parent[hi], hi, lo);
+			if (old == hi) {
+				merged = 1; // the links that win a hook form a spanning forest of the segments
+				break;
+			}
+			ra = uf_find(parent, old);
+			rb = uf_find(parent, lo);
+		}
 	}
+	hook[e] = merged;
 }
 
 __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint32_t *__restrict__ is_root)
@@ -180,7 +184,8 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 			      const uint32_t *__restrict__ erank, const uint32_t *__restrict__ v1,
 			      const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
 			      const uint8_t *__restrict__ s2, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-			      uint32_t *__restrict__ ldeg)
+			      uint32_t *__restrict__ ldeg, const uint32_t *__restrict__ hook, uint32_t *__restrict__ la,
+			      uint32_t *__restrict__ lb, uint32_t *__restrict__ tgray)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
@@ -202,12 +207,27 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 		// two slots per local edge, generated in local-edge order so that the stable sort by
 		// side leaves every side's list ascending by local edge idx (std::set order)
 		keys[2 * le] = S;
-		vals[2 * le] = So;
+		vals[2 * le] = 2 * le; // slot origin: even = the la end, odd = the lb end
 		keys[2 * le + 1] = So;
-		vals[2 * le + 1] = S;
+		vals[2 * le + 1] = 2 * le + 1;
+		la[le] = S;
+		lb[le] = So;
+		tgray[le] = hook[e];
 		atomicAdd(&ldeg[S], 1u);
 		atomicAdd(&ldeg[So], 1u);
 	}
+}
+
+// after the stable sort by side: other side and local edge of every adjacency slot
+__global__ void k_local_slots(uint32_t n, const uint32_t *__restrict__ origin, const uint32_t *__restrict__ la,
+			      const uint32_t *__restrict__ lb, uint32_t *__restrict__ ladj, uint32_t *__restrict__ lle)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n)
+		return;
+	uint32_t o = origin[k], le = o >> 1;
+	ladj[k] = (o & 1) ? la[le] : lb[le];
+	lle[k] = le;
 }
 
 __global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ sbase,
@@ -274,7 +294,7 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	tm.begin("wcc_label");
 	hipLaunchKernelGGL(k_uf_init, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label);
 	if (E)
-		hipLaunchKernelGGL(k_uf_union, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.v2, st.label);
+		hipLaunchKernelGGL(k_uf_union, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.v2, st.label, st.hook);
 	hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
 	HIP_CHECK(hipMemsetAsync(st.flag + V, 0, 4, s));
 	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
@@ -311,13 +331,17 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	HIP_CHECK(hipMemsetAsync(st.ldeg, 0, (nS + 1) * 4, s));
 	hipLaunchKernelGGL(k_local_edges, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, st.sbase,
-			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg);
+			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg, st.hook, st.la, st.lb,
+			   st.tgray);
 	hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
 			   st.eoff);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	// local per-side adjacency (other side ids), ascending local edge idx
-	sort_pairs_u32(st.keys, st.keys2, st.vals, st.ladj, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);
-	launches += 9;
+	sort_pairs_u32(st.keys, st.keys2, st.vals, st.vals2, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);
+	if (E)
+		hipLaunchKernelGGL(k_local_slots, dim3(nblk(2 * (size_t)E)), dim3(TPB), 0, s, 2 * E, st.vals2, st.la, st.lb,
+				   st.ladj, st.lle);
+	launches += 10;
 	tm.end(launches);
 }
 

@@ -16,6 +16,7 @@
 // marked gsize == 0); bracket space (dense, all components); stack space (one entry per black
 // tree edge, component-major); emitted-flubble space.
 #include "par_kernels.hpp"
+#include "segtree.hpp"
 
 #include <algorithm>
 
@@ -30,100 +31,6 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 		if ((n) > 0)                                                                     \
 			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
 	} while (0)
-
-// ------------------------------------------------------------- segment tree
-__global__ void k_seg_leaves(uint32_t P, uint32_t n, const uint32_t *__restrict__ val, uint32_t *__restrict__ tree)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < P)
-		tree[P + i] = i < n ? val[i] : NIL;
-}
-__global__ void k_seg_level(uint32_t first, uint32_t count, uint32_t *tree)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < count) {
-		uint32_t k = first + i;
-		tree[k] = min(tree[2 * k], tree[2 * k + 1]);
-	}
-}
-static void seg_build(SegTree &st, const uint32_t *val, size_t n, hipStream_t s)
-{
-	st.P = SegTree::pow2(std::max<size_t>(n, 1));
-	LAUNCH(k_seg_leaves, st.P, s, st.P, (uint32_t)n, val, st.tree);
-	for (uint32_t first = st.P / 2; first >= 1; first /= 2) {
-		LAUNCH(k_seg_level, first, s, first, first, st.tree);
-		if (first == 1)
-			break;
-	}
-}
-
-__device__ __forceinline__ uint32_t seg_min(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r)
-{
-	uint32_t m = NIL;
-	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
-		if (l & 1)
-			m = min(m, tree[l++]);
-		if (r & 1)
-			m = min(m, tree[--r]);
-	}
-	return m;
-}
-__device__ __forceinline__ uint32_t seg_descend_first(const uint32_t *__restrict__ tree, uint32_t P, uint32_t node,
-						      uint32_t x)
-{
-	while (node < P)
-		node = tree[2 * node] < x ? 2 * node : 2 * node + 1;
-	return node - P;
-}
-__device__ __forceinline__ uint32_t seg_descend_last(const uint32_t *__restrict__ tree, uint32_t P, uint32_t node,
-						     uint32_t x)
-{
-	while (node < P)
-		node = tree[2 * node + 1] < x ? 2 * node + 1 : 2 * node;
-	return node - P;
-}
-// first idx in [l, r) whose value is < x, NIL if none
-__device__ uint32_t seg_first_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
-{
-	if (l >= r)
-		return NIL;
-	uint32_t right[32];
-	int nr = 0;
-	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
-		if (l & 1) {
-			if (tree[l] < x)
-				return seg_descend_first(tree, P, l, x);
-			l++;
-		}
-		if (r & 1)
-			right[nr++] = --r;
-	}
-	for (int k = nr - 1; k >= 0; k--)
-		if (tree[right[k]] < x)
-			return seg_descend_first(tree, P, right[k], x);
-	return NIL;
-}
-// last idx in [l, r) whose value is < x, NIL if none
-__device__ uint32_t seg_last_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
-{
-	if (l >= r)
-		return NIL;
-	uint32_t left[32];
-	int nl = 0;
-	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
-		if (r & 1) {
-			--r;
-			if (tree[r] < x)
-				return seg_descend_last(tree, P, r, x);
-		}
-		if (l & 1)
-			left[nl++] = l++;
-	}
-	for (int k = nl - 1; k >= 0; k--)
-		if (tree[left[k]] < x)
-			return seg_descend_last(tree, P, left[k], x);
-	return NIL;
-}
 
 // ------------------------------------------------------------- T-space setup
 __global__ void k_tcomp_vertices(uint32_t V, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ t_comp)
@@ -264,27 +171,22 @@ __global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const 
 }
 // mirror pre-order (children visited in DESCENDING idx): the order brackets sit in a bracket list,
 // because each child's list is spliced in front of its earlier siblings' (flubbles.cpp:586-588).
-// delta(a) = 1 + sizes of the later siblings of a; mpre(v) = sum of delta over the path root..v.
-__global__ void k_mpre_delta(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
-			     uint32_t *__restrict__ dlt)
-{
-	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= T)
-		return;
-	uint32_t sz = gsize[a], p = gpar[a];
-	if (sz == 0 || p == NIL)
-		return;
-	uint32_t d = 1 + (p + gsize[p]) - (a + sz);
-	atomicAdd(&dlt[a], d);
-	atomicAdd(&dlt[a + sz], 0u - d);
-}
-__global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ dlt,
-		       const uint32_t *__restrict__ dlt_ps, const uint32_t *__restrict__ t_root, uint32_t *__restrict__ mpre)
+// With q(v) = mpre(v) + v + size(v) one gets q(child) = q(parent) + 1, hence
+// mpre(v) = depth(v) + N - v - size(v)  (local indices, N = tree vertices of the component).
+__global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ depth,
+		       const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ t_comp,
+		       const uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ mpre)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
 		return;
-	mpre[v] = gsize[v] ? t_root[v] + dlt_ps[v] + dlt[v] : NIL;
+	uint32_t sz = gsize[v];
+	if (!sz) {
+		mpre[v] = NIL;
+		return;
+	}
+	uint32_t r = t_root[v];
+	mpre[v] = r + depth[v] + c_ntree[t_comp[v]] - (v - r) - sz;
 }
 // sort key of a bracket: (mirror pre-order of its source) then, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643)
@@ -630,7 +532,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segW.tree, 2 * (size_t)SegTree::pow2(2 * S + 2) * 4);
 	take((void **)&pw.segL.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
 	pw.scan_tmp_bytes = scan_tmp_bytes(std::max(T, NB) + 4);
-	pw.sort_tmp_bytes = std::max(sort64_tmp_bytes(std::max(T, NB) + 4), sort_tmp_bytes(S + 4));
+	pw.sort_tmp_bytes = std::max(sort64_tmp_bytes(std::max(T, NB) + 4), sort_tmp_bytes(std::max(S, 4 * V + 8) + 4));
 	take(&pw.scan_tmp, pw.scan_tmp_bytes);
 	take(&pw.sort_tmp, pw.sort_tmp_bytes);
 }
@@ -657,7 +559,8 @@ static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
 	return v;
 }
 
-uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s)
+uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int64_t dense_nb0, StageTimer &tm,
+			 hipStream_t s)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	pw.V = V;
@@ -674,12 +577,17 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_tcomp_vertices, V, s, V, cs.ckey, pw.t_comp);
 	LAUNCH(k_tcomp_last, C, s, C, cs.voff, pw.t_comp);
 	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root);
-	HIP_CHECK(hipMemsetAsync(sw.c_nbe0 + C, 0, 4, s));
-	scan(sw.c_nbe0, pw.dbo, (size_t)C + 1);
 	HIP_CHECK(hipMemsetAsync(pw.err, 0, 64, s));
 	HIP_CHECK(hipMemsetAsync(pw.comp_bad, 0, ((size_t)C + 1) * 4, s));
-	const uint32_t NB0 = read_u32(pw.dbo + C, s);
-	LAUNCH(k_dense_be, NB0, s, NB0, C, pw.dbo, cs.voff, cs.eoff, sw.be_src, sw.be_tgt, pw.b_src, pw.b_tgt);
+	uint32_t NB0;
+	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
+		NB0 = (uint32_t)dense_nb0;
+	} else {
+		HIP_CHECK(hipMemsetAsync(sw.c_nbe0 + C, 0, 4, s));
+		scan(sw.c_nbe0, pw.dbo, (size_t)C + 1);
+		NB0 = read_u32(pw.dbo + C, s);
+		LAUNCH(k_dense_be, NB0, s, NB0, C, pw.dbo, cs.voff, cs.eoff, sw.be_src, sw.be_tgt, pw.b_src, pw.b_tgt);
+	}
 	tm.end(7);
 
 	// ---- row D
@@ -698,10 +606,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	HIP_CHECK(hipMemsetAsync(capf + T, 0, 4, s));
 	scan(simp, pssimp, (size_t)T + 1);
 	scan(capf, pscap, (size_t)T + 1);
-	HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)T + 2) * 4, s));
-	LAUNCH(k_mpre_delta, T, s, T, pw.gsize, pw.gpar, pw.dlt);
-	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
-	LAUNCH(k_mpre, T, s, T, pw.gsize, pw.dlt, pw.dlt_ps, pw.t_root, pw.mpre);
+	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre);
 	uint32_t extra[2];
 	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));

@@ -49,6 +49,8 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
 
 // Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
 // left in `sw`.  Returns the number of components flagged for a sequential redo (comp_bad).
-uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s);
+// dense_nb0 < 0: densify the back edges the sequential tree stage wrote; otherwise b_src/b_tgt hold them.
+uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int64_t dense_nb0, StageTimer &tm,
+			 hipStream_t s);
 
 } // namespace povu_hip

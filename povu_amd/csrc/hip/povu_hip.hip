@@ -6,6 +6,7 @@
 #include "graph_kernels.hpp"
 #include "seq_kernels.hpp"
 #include "par_kernels.hpp"
+#include "tree_kernels.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -43,6 +44,7 @@ struct povu_hip_ctx {
 	CompState cs{};
 	SeqWs sw{};
 	ParWs pw{};
+	TreeWs tw{};
 	uint32_t last_seq_redo = 0;
 };
 
@@ -205,6 +207,12 @@ size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool
 	take(&cs.keys, 2 * E + 2, 4);
 	take(&cs.vals, 2 * E + 2, 4);
 	take(&cs.keys2, 2 * E + 2, 4);
+	take(&cs.vals2, 2 * E + 2, 4);
+	take(&cs.hook, E + 2, 4);
+	take(&cs.la, E + 2, 4);
+	take(&cs.lb, E + 2, 4);
+	take(&cs.lle, 2 * E + 2, 4);
+	take(&cs.tgray, E + 2, 4);
 	take(&cs.gid_s, V + 1, 4);
 	take(&cs.tip_s, V + 1, 1);
 	take(&cs.start_key, C + 2, 8);
@@ -226,6 +234,7 @@ size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool
 	take(&sw.next_sib, T, 4);
 	take(&sw.last_child, T, 4);
 	take(&sw.t_size, T, 4);
+	take(&sw.t_depth, T, 4);
 	take(&sw.t_flags, T, 1);
 	take(&sw.ctr, nS + 1, 4);
 	take(&sw.cur, nS + 1, 4);
@@ -309,10 +318,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		ctx->have_state = false;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0 || hairpins;
 		ctx->ws.reserve(carve_workspace(nullptr, z, cs, sw, hairpins) +
-				(all_seq ? 0 : par_workspace_bytes(z.V, z.E, z.Cmax)));
+				(all_seq ? 0 : par_workspace_bytes(z.V, z.E, z.Cmax) + tree_workspace_bytes(z.V, z.E, z.Cmax)));
 		carve_workspace(&ctx->ws, z, cs, sw, hairpins);
-		if (!all_seq)
+		if (!all_seq) {
 			par_carve(ctx->ws, ctx->pw, z.V, z.E, z.Cmax);
+			tree_carve(ctx->ws, ctx->tw, z.V, z.E, z.Cmax);
+		}
 
 		StageTimer &tm = ctx->timer;
 		tm.reset();
@@ -391,15 +402,29 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			launch_seq_components(sw, s);
 			tm.end(1);
 		} else {
-			tm.begin("tree_seq");
-			sw.stages = SEQ_STAGE_TREE;
-			launch_seq_components(sw, s);
-			tm.end(1);
-			const uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, tm, s);
+			int64_t dense_nb0 = -1;
+			if (o.flags & POVU_HIP_F_SEQ_TREE) {
+				tm.begin("tree_seq");
+				sw.stages = SEQ_STAGE_TREE;
+				launch_seq_components(sw, s);
+				tm.end(1);
+			} else {
+				std::vector<uint32_t> cproc(C + 1, 0);
+				uint32_t max_nv = 1;
+				for (uint32_t c = 0; c < C; c++) {
+					const uint32_t nv = voff[c + 1] - voff[c];
+					max_nv = std::max(max_nv, nv);
+					cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
+				}
+				HIP_CHECK(hipMemcpyAsync(ctx->tw.cproc, cproc.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
+				HIP_CHECK(hipStreamSynchronize(s));
+				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, max_nv, tm, s);
+			}
+			const uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
 			ctx->last_seq_redo = nbad;
 			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
 				tm.begin("redo_seq");
-				sw.stages = SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST;
+				sw.stages = dense_nb0 >= 0 ? SEQ_STAGE_ALL : (SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST);
 				sw.comp_sel = ctx->pw.comp_bad;
 				launch_seq_components(sw, s);
 				sw.comp_sel = nullptr;

@@ -28,7 +28,7 @@ struct CompView {
 	const uint32_t *loff, *ladj; // global arrays (indexed by sorted side id / slot)
 	const uint32_t *gid_s;
 	// tree arrays, local tree idx
-	uint32_t *gid, *par, *cls, *hi, *fchild, *nsib, *lchild, *size;
+	uint32_t *gid, *par, *cls, *hi, *fchild, *nsib, *lchild, *size, *depth;
 	uint8_t *tf;
 	uint32_t *ctr, *cur; // indexed by (sorted side id - Sb)
 	uint32_t *stk;
@@ -90,6 +90,7 @@ __device__ static void seq_spanning_tree(CompView &c, uint64_t start_key)
 		c.gid[0] = NIL;
 		c.tf[0] = 2;
 		c.par[0] = NIL;
+		c.depth[0] = 0;
 		counter = 1;
 		p = 0;
 	}
@@ -105,6 +106,8 @@ __device__ static void seq_spanning_tree(CompView &c, uint64_t start_key)
 		c.ctr[ls] = a;
 		c.ctr[ls ^ 1] = b;
 		c.par[a] = p;
+		c.depth[a] = p != NIL ? c.depth[p] + 1 : 0;
+		c.depth[b] = c.depth[a] + 1;
 		if (p != NIL)
 			add_child(c, p, a);
 		c.par[b] = a;
@@ -440,6 +443,7 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 		c.nsib = w.next_sib + tb;
 		c.lchild = w.last_child + tb;
 		c.size = w.t_size + tb;
+		c.depth = w.t_depth + tb;
 		c.tf = w.t_flags + tb;
 		c.ctr = w.ctr + c.Sb;
 		c.cur = w.cur + c.Sb;

@@ -33,7 +33,7 @@ struct SeqWs {
 	const uint32_t *owner; // [C] shard that owns the component
 	// spanning tree
 	uint32_t *t_gid, *t_par, *t_cls, *t_hi, *first_child, *next_sib, *last_child; // [T]
-	uint32_t *t_size;							       // [T] subtree sizes
+	uint32_t *t_size, *t_depth;						       // [T] subtree sizes, depths
 	uint8_t *t_flags;							       // [T]
 	uint32_t *ctr, *cur;							       // [2V]
 	uint32_t *stk;								       // [T]

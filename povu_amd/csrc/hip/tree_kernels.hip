@@ -1,0 +1,663 @@
+// tree_kernels.hip -- row C (pst::Tree::from_bd, spanning_tree.cpp:262-463) without a sequential
+// walk over the whole component.
+//
+// from_bd is the lexicographic DFS of the biedged graph H (vertices = segment sides, one black edge
+// per segment, one gray edge per link) in which every side scans [black edge, gray links by local
+// edge idx].  Lexicographic DFS is sequential in general, but it decomposes along the bridges of H:
+// the DFS can enter a 2-edge-connected class only through the unique bridge that leads to the root,
+// and its walk inside a class never depends on the rest of the graph.  So
+//   1. spanning forest of H  (black edges + the links that won a hook in the WCC union-find)
+//   2. root it at the DFS start side: Euler tour + list ranking (pointer jumping)
+//   3. bridges: subtree min/max of the non-tree links' far ends (segment trees over pre-order)
+//   4. 2-edge-connected classes: union-find over the non-bridge edges
+//   5. per class: entry side = top of the class, DFS parent = far end of its bridge
+//   6. ONE LANE PER CLASS runs the reference DFS inside its class (pangenome graphs are chains of
+//      small bubbles, so there are very many small classes)
+//   7. pre-order / subtree size / depth of the union tree: Euler tour of (parent, scan-slot)
+//      ordered children + list ranking
+//   8. tree arrays in pre-order + the from_bd back edges (de-duplication rules of :360-398)
+// tests/test_parallel_tree_model.py checks this formulation against the oracle on the CPU.
+#include "tree_kernels.hpp"
+
+#include "segtree.hpp"
+
+#include <algorithm>
+
+namespace povu_hip
+{
+
+static constexpr int TPB = 256;
+static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+#define LAUNCH(k, n, s, ...)                                                                     \
+	do {                                                                                     \
+		if ((n) > 0)                                                                     \
+			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
+	} while (0)
+
+// ------------------------------------------------------------------ 1. arcs of the spanning forest
+__global__ void k_arcs_black(uint32_t V, uint32_t *__restrict__ arc_src, uint32_t *__restrict__ arc_dst,
+			     uint32_t *__restrict__ arc_le)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= V)
+		return;
+	arc_src[2 * i] = 2 * i;
+	arc_dst[2 * i] = 2 * i + 1;
+	arc_src[2 * i + 1] = 2 * i + 1;
+	arc_dst[2 * i + 1] = 2 * i;
+	arc_le[i] = NIL;
+}
+__global__ void k_arcs_gray(uint32_t E, uint32_t V, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
+			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ lb, uint32_t *__restrict__ arc_src,
+			    uint32_t *__restrict__ arc_dst, uint32_t *__restrict__ arc_le)
+{
+	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
+	if (le >= E || !tgray[le])
+		return;
+	uint32_t k = V + tg_ps[le];
+	arc_src[2 * k] = la[le];
+	arc_dst[2 * k] = lb[le];
+	arc_src[2 * k + 1] = lb[le];
+	arc_dst[2 * k + 1] = la[le];
+	arc_le[k] = le;
+}
+__global__ void k_iota(uint32_t n, uint32_t *p)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		p[i] = i;
+}
+__global__ void k_arc_positions(uint32_t NA, const uint32_t *__restrict__ ssrc, const uint32_t *__restrict__ sarc,
+				uint32_t *__restrict__ apos, uint32_t *__restrict__ afirst, uint32_t *__restrict__ alast)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= NA)
+		return;
+	uint32_t src = ssrc[q];
+	apos[sarc[q]] = q;
+	if (q == 0 || ssrc[q - 1] != src)
+		afirst[src] = q;
+	if (q == NA - 1 || ssrc[q + 1] != src)
+		alast[src] = q;
+}
+// Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
+__global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
+			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ afirst,
+			   const uint32_t *__restrict__ alast, uint32_t *__restrict__ nxt, uint32_t *__restrict__ cnt)
+{
+	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= NA)
+		return;
+	uint32_t t = a ^ 1, w = arc_src[t], q = apos[t];
+	uint32_t qn = (q == alast[w]) ? afirst[w] : q + 1;
+	nxt[a] = sarc[qn];
+	cnt[a] = 1;
+}
+// sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
+__device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
+{
+	unsigned long long k = start_key[c];
+	return k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
+}
+__global__ void k_tour_cut(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
+			   const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ alast, uint32_t *__restrict__ nxt,
+			   uint32_t *__restrict__ cnt)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	uint32_t r = comp_root_side(start_key, voff, c);
+	uint32_t a_end = sarc[alast[r]] ^ 1; // the arc that returns to the root for the last time
+	nxt[a_end] = NIL;
+	cnt[a_end] = 0;
+}
+// one round of pointer jumping with two accumulators (suffix sums along the list)
+__global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const uint32_t *__restrict__ a_in,
+			 const uint32_t *__restrict__ b_in, uint32_t *__restrict__ nxt_out, uint32_t *__restrict__ a_out,
+			 uint32_t *__restrict__ b_out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	uint32_t nx = nxt_in[i], a = a_in[i], b = b_in ? b_in[i] : 0;
+	if (nx != NIL) {
+		a += a_in[nx];
+		if (b_in)
+			b += b_in[nx];
+		nx = nxt_in[nx];
+	}
+	nxt_out[i] = nx;
+	a_out[i] = a;
+	if (b_out)
+		b_out[i] = b;
+}
+// runs `rounds` rounds; returns which buffer set (0 = A, 1 = B) holds the result
+static int list_rank(uint32_t n, unsigned rounds, uint32_t *nxtA, uint32_t *nxtB, uint32_t *aA, uint32_t *aB, uint32_t *bA,
+		     uint32_t *bB, hipStream_t s)
+{
+	int cur = 0;
+	for (unsigned r = 0; r < rounds; r++) {
+		if (cur == 0)
+			LAUNCH(k_wyllie, n, s, n, nxtA, aA, bA, nxtB, aB, bB);
+		else
+			LAUNCH(k_wyllie, n, s, n, nxtB, aB, bB, nxtA, aA, bA);
+		cur ^= 1;
+	}
+	return cur;
+}
+
+// ------------------------------------------------------------------ 2. rooted forest T0
+// dist[a] = arcs after a in its tour.  u->w is the advance arc of tree edge {u,w} iff it comes first.
+__global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
+			     const uint32_t *__restrict__ arc_dst, const uint32_t *__restrict__ arc_le,
+			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff, uint32_t *__restrict__ par0,
+			     uint32_t *__restrict__ size0, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ tourflag)
+{
+	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= NA)
+		return;
+	uint32_t da = dist[a], dt = dist[a ^ 1];
+	uint32_t u = arc_src[a], c = ckey[u >> 1];
+	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
+	uint32_t tix = abase + (L - 1 - da);
+	if (da > dt) {
+		uint32_t w = arc_dst[a];
+		par0[w] = u;
+		size0[w] = (da - dt + 1) / 2;
+		pe_le0[w] = arc_le[a >> 1];
+		tourflag[tix] = 1;
+	} else {
+		tourflag[tix] = 0;
+	}
+}
+__global__ void k_t0_roots(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
+			   uint32_t *__restrict__ par0, uint32_t *__restrict__ size0, uint32_t *__restrict__ P0)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	uint32_t r = comp_root_side(start_key, voff, c);
+	par0[r] = NIL;
+	size0[r] = 2 * (voff[c + 1] - voff[c]);
+	P0[r] = 2 * voff[c];
+}
+__global__ void k_t0_pre(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
+			 const uint32_t *__restrict__ arc_dst, const uint32_t *__restrict__ ckey,
+			 const uint32_t *__restrict__ voff, const uint32_t *__restrict__ tour_ps, uint32_t *__restrict__ P0)
+{
+	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= NA)
+		return;
+	uint32_t da = dist[a], dt = dist[a ^ 1];
+	if (da <= dt)
+		return;
+	uint32_t u = arc_src[a], c = ckey[u >> 1];
+	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
+	uint32_t tix = abase + (L - 1 - da);
+	P0[arc_dst[a]] = 2 * voff[c] + 1 + (tour_ps[tix] - tour_ps[abase]);
+}
+
+// ------------------------------------------------------------------ 3. bridges
+__global__ void k_lowhigh(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ P0,
+			  uint32_t *__restrict__ lowP, uint32_t *__restrict__ highP)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	uint32_t me = P0[S], lo = me, hi = me;
+	for (uint32_t k = loff[S]; k < loff[S + 1]; k++) {
+		if (tgray[lle[k]])
+			continue;
+		uint32_t o = P0[ladj[k]];
+		lo = min(lo, o);
+		hi = max(hi, o);
+	}
+	lowP[me] = lo;
+	highP[me] = ~hi;
+}
+__global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ size0,
+			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ segLo, uint32_t PLo,
+			  const uint32_t *__restrict__ segHi, uint32_t PHi, uint32_t *__restrict__ isbridge)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	if (par0[S] == NIL) {
+		isbridge[S] = 0;
+		return;
+	}
+	uint32_t a = P0[S], b = a + size0[S];
+	uint32_t mn = seg_min(segLo, PLo, a, b), mx = ~seg_min(segHi, PHi, a, b);
+	isbridge[S] = (mn >= a && mx < b) ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------ 4. 2-edge-connected classes
+__device__ __forceinline__ uint32_t uf_find2(uint32_t *parent, uint32_t x)
+{
+	uint32_t p = parent[x];
+	while (p != x) {
+		uint32_t gp = parent[p];
+		if (gp != p)
+			parent[x] = gp;
+		x = p;
+		p = gp;
+	}
+	return x;
+}
+__device__ __forceinline__ void uf_union2(uint32_t *parent, uint32_t a, uint32_t b)
+{
+	uint32_t ra = uf_find2(parent, a), rb = uf_find2(parent, b);
+	while (ra != rb) {
+		uint32_t hi = max(ra, rb), lo = min(ra, rb);
+		uint32_t old = atomicCAS(&parent[hi], hi, lo);
+		if (old == hi)
+			break;
+		ra = uf_find2(parent, old);
+		rb = uf_find2(parent, lo);
+	}
+}
+__global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
+			   uint32_t *ecc)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS || par0[S] == NIL || isbridge[S])
+		return;
+	uf_union2(ecc, S, par0[S]);
+}
+__global__ void k_ecc_nontree(uint32_t E, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ la,
+			      const uint32_t *__restrict__ lb, uint32_t *ecc)
+{
+	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
+	if (le >= E || tgray[le])
+		return;
+	uf_union2(ecc, la[le], lb[le]);
+}
+__global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	uint32_t r = S;
+	while (ecc[r] != r)
+		r = ecc[r];
+	ecc[S] = r;
+}
+
+// ------------------------------------------------------------------ 5. class entries
+__global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
+			  const uint32_t *__restrict__ pe_le0, const uint32_t *__restrict__ loff,
+			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
+			  const uint32_t *__restrict__ cproc, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
+			  uint8_t *__restrict__ dvis, uint32_t *__restrict__ entry_flag)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	dpar[S] = NIL;
+	cslot[S] = 0;
+	dvis[S] = 0;
+	entry_flag[S] = 0;
+	if (!cproc[ckey[S >> 1]])
+		return;
+	uint32_t p = par0[S];
+	if (p == NIL) { // DFS start of the component
+		dvis[S] = 1;
+		entry_flag[S] = 1;
+		return;
+	}
+	if (!isbridge[S])
+		return;
+	dvis[S] = 1;
+	entry_flag[S] = 1;
+	dpar[S] = p;
+	if (p == (S ^ 1)) {
+		cslot[S] = 0; // black edge: scanned first
+	} else { // gray bridge: its slot in the parent's list (ascending local edge idx)
+		uint32_t le = pe_le0[S], lo = loff[p], hi = loff[p + 1];
+		while (lo < hi) {
+			uint32_t mid = (lo + hi) >> 1;
+			if (lle[mid] < le)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		cslot[S] = lo - loff[p] + 1;
+	}
+}
+__global__ void k_compact(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
+			  uint32_t *__restrict__ out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && flag[i])
+		out[ps[i]] = i;
+}
+
+// ------------------------------------------------------------------ 6. the DFS inside every class
+// Stackless: cur[] holds the scan position of every side (0 = black edge, k = k-th gray link),
+// dpar[] is the way back.  Classes are disjoint, so lanes never touch each other's sides.
+__global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
+			    const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ecc, uint32_t *__restrict__ dpar,
+			    uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis, uint32_t *__restrict__ cur)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_entry)
+		return;
+	const uint32_t s = entry_list[i], cls = ecc[s];
+	uint32_t u = s;
+	while (true) {
+		const uint32_t lo = loff[u], n = loff[u + 1] - lo;
+		uint32_t k = cur[u];
+		bool adv = false;
+		while (k <= n) {
+			const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
+			const uint32_t slot = k++;
+			if (ecc[o] == cls && !dvis[o]) {
+				dvis[o] = 1;
+				dpar[o] = u;
+				cslot[o] = slot;
+				cur[u] = k;
+				u = o;
+				adv = true;
+				break;
+			}
+		}
+		if (adv)
+			continue;
+		cur[u] = k;
+		if (u == s)
+			break;
+		u = dpar[u];
+	}
+}
+
+// ------------------------------------------------------------------ 7. pre-order of the union tree
+__global__ void k_child_keys(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
+			     unsigned long long *__restrict__ key, uint32_t *__restrict__ val)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	uint32_t p = dpar[S];
+	key[S] = p == NIL ? ~0ull : (((unsigned long long)p << 32) | cslot[S]);
+	val[S] = S;
+}
+__global__ void k_child_links(uint32_t nS, const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+			      uint32_t *__restrict__ fc, uint32_t *__restrict__ nsib)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nS)
+		return;
+	unsigned long long k = key[q];
+	uint32_t S = val[q];
+	if (k == ~0ull) {
+		nsib[S] = NIL;
+		return;
+	}
+	uint32_t p = (uint32_t)(k >> 32);
+	if (q == 0 || (uint32_t)(key[q - 1] >> 32) != p)
+		fc[p] = S;
+	nsib[S] = (q + 1 < nS && key[q + 1] != ~0ull && (uint32_t)(key[q + 1] >> 32) == p) ? val[q + 1] : NIL;
+}
+// events: 2S = enter S, 2S+1 = leave S
+__global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
+			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ nxt, uint32_t *__restrict__ cnt,
+			 uint32_t *__restrict__ dep)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	uint32_t c = fc[S];
+	nxt[2 * S] = c != NIL ? 2 * c : 2 * S + 1;
+	cnt[2 * S] = 1;
+	dep[2 * S] = 1;
+	uint32_t ns = nsib[S], p = dpar[S];
+	nxt[2 * S + 1] = ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL);
+	cnt[2 * S + 1] = 0;
+	dep[2 * S + 1] = 0xFFFFFFFFu; // -1
+}
+
+// ------------------------------------------------------------------ 8. tree arrays + back edges
+__global__ void k_tree_emit(uint32_t nS, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ dep,
+			    const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ ckey,
+			    const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
+			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
+			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
+			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	uint32_t c = ckey[S >> 1];
+	side_tidx[S] = NIL;
+	if (!cproc[c])
+		return;
+	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u;
+	const uint32_t tb = 2 * voff[c] + c;
+	// suffix sums from the enter event: cnt = enters from here to the end, dep = net depth change
+	const uint32_t pre = Nh - cnt[2 * S], size = cnt[2 * S] - cnt[2 * S + 1];
+	const uint32_t depth = 0u - dep[2 * S];
+	const uint32_t t = tb + hd + pre;
+	t_gid[t] = gid_s[S >> 1];
+	const uint32_t p = dpar[S];
+	t_flags[t] = (uint8_t)((S & 1) | ((p == (S ^ 1)) ? TF_BLACK : 0));
+	t_par[t] = p == NIL ? (hd ? 0u : NIL) : hd + (Nh - cnt[2 * p]);
+	t_size[t] = size;
+	t_depth[t] = depth + hd;
+	side_tidx[S] = t;
+}
+__global__ void k_tree_roots(uint32_t C, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
+			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ t_gid,
+			     uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par, uint32_t *__restrict__ t_size,
+			     uint32_t *__restrict__ t_depth, uint32_t *__restrict__ c_ntree)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	if (!cproc[c]) {
+		c_ntree[c] = 0;
+		return;
+	}
+	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u, tb = 2 * voff[c] + c;
+	c_ntree[c] = Nh + hd;
+	if (hd) { // dummy root, spanning_tree.cpp:397-402
+		t_gid[tb] = NIL;
+		t_flags[tb] = 2;
+		t_par[tb] = NIL;
+		t_size[tb] = Nh + 1;
+		t_depth[tb] = 0;
+	}
+}
+// back edges of from_bd out of side S, in scan order (process_edge, spanning_tree.cpp:360-398):
+//  - a side without links points back at the root unless the root is its tree parent (:433-438)
+//  - self-loop links: one back edge per segment, from the black child, at its first loop slot
+//  - a link to a descendant was already turned into a back edge by the descendant
+//  - a link to the tree parent, or a repeated link to the same side, is already "connected"
+template <bool EMIT>
+__global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+			     const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ side_tidx,
+			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
+			     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ be_cnt,
+			     const uint32_t *__restrict__ be_ps, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	const uint32_t p = side_tidx[S];
+	uint32_t n = 0, at = EMIT ? be_ps[S] : 0;
+	if (p != NIL) {
+		const uint32_t c = ckey[S >> 1], root = 2 * voff[c] + c;
+		const uint32_t lo = loff[S], hi = loff[S + 1];
+		auto out = [&](uint32_t tgt) {
+			if (EMIT) {
+				b_src[at + n] = p;
+				b_tgt[at + n] = tgt;
+			}
+			n++;
+		};
+		if (lo == hi) {
+			if (p == root || t_par[p] != 0)
+				out(root);
+		} else {
+			const uint32_t dp = dpar[S];
+			bool loop_seen = false;
+			for (uint32_t k = lo; k < hi; k++) {
+				const uint32_t o = ladj[k];
+				if (o == (S ^ 1)) {
+					if (dp == o && !loop_seen)
+						out(side_tidx[o]);
+					loop_seen = true;
+					continue;
+				}
+				const uint32_t x = side_tidx[o];
+				if (x > p || o == dp)
+					continue;
+				bool dup = false;
+				for (uint32_t j = lo; j < k; j++)
+					if (ladj[j] == o) {
+						dup = true;
+						break;
+					}
+				if (!dup)
+					out(x);
+			}
+		}
+	}
+	if (!EMIT)
+		be_cnt[S] = n;
+}
+
+// ------------------------------------------------------------------ workspace
+template <typename F>
+static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
+{
+	const size_t nS = 2 * V + 2, NA = 4 * V + 8;
+	take((void **)&tw.tg_ps, (E + 2) * 4);
+	for (uint32_t **p : {&tw.arc_src, &tw.arc_dst, &tw.k1, &tw.k2, &tw.v1, &tw.v2, &tw.apos, &tw.nxtA, &tw.nxtB, &tw.cntA,
+			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
+		take((void **)p, NA * 4);
+	take((void **)&tw.arc_le, NA * 2);
+	for (uint32_t **p : {&tw.afirst, &tw.alast, &tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.isbridge,
+			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_flag, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
+			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
+		take((void **)p, nS * 4);
+	take((void **)&tw.dvis, nS);
+	take((void **)&tw.ckey, nS * 8);
+	take((void **)&tw.ckey2, nS * 8);
+	take((void **)&tw.cproc, (Cmax + 2) * 4);
+	take((void **)&tw.segLo.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
+	take((void **)&tw.segHi.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
+}
+
+size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax)
+{
+	TreeWs tmp{};
+	size_t total = 0;
+	tree_spans(tmp, V, E, Cmax, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
+	return total + (1 << 20);
+}
+
+void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax)
+{
+	tree_spans(tw, V, E, Cmax, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+}
+
+static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
+{
+	uint32_t v = 0;
+	HIP_CHECK(hipMemcpyAsync(&v, dptr, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	return v;
+}
+
+// ------------------------------------------------------------------ driver
+uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t max_nv,
+			   StageTimer &tm, hipStream_t s)
+{
+	const uint32_t V = sw.V, E = sw.E, nS = 2 * V;
+	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
+		scan_exclusive_u32(in, out, n, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	};
+	const unsigned long long *start_key = (const unsigned long long *)cs.start_key;
+	const unsigned rounds = bits_for(4ull * max_nv + 4) + 1;
+
+	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
+	tm.begin("tree_root_forest");
+	HIP_CHECK(hipMemsetAsync(cs.tgray + E, 0, 4, s));
+	scan(cs.tgray, tw.tg_ps, (size_t)E + 1);
+	const uint32_t NTG = read_u32(tw.tg_ps + E, s);
+	if (NTG != V - C)
+		throw HipError("spanning forest of the links has the wrong size (internal)");
+	const uint32_t NA = 2 * (V + NTG);
+	LAUNCH(k_arcs_black, V, s, V, tw.arc_src, tw.arc_dst, tw.arc_le);
+	LAUNCH(k_arcs_gray, E, s, E, V, cs.tgray, tw.tg_ps, cs.la, cs.lb, tw.arc_src, tw.arc_dst, tw.arc_le);
+	LAUNCH(k_iota, NA, s, NA, tw.v1);
+	sort_pairs_u32(tw.arc_src, tw.k2, tw.v1, tw.v2, NA, bits_for(nS), pw.sort_tmp, pw.sort_tmp_bytes, s);
+	LAUNCH(k_arc_positions, NA, s, NA, tw.k2, tw.v2, tw.apos, tw.afirst, tw.alast);
+	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, tw.afirst, tw.alast, tw.nxtA, tw.cntA);
+	LAUNCH(k_tour_cut, C, s, C, cs.voff, start_key, tw.v2, tw.alast, tw.nxtA, tw.cntA);
+	int side = list_rank(NA, rounds, tw.nxtA, tw.nxtB, tw.cntA, tw.cntB, nullptr, nullptr, s);
+	const uint32_t *dist = side ? tw.cntB : tw.cntA;
+	LAUNCH(k_t0_parents, NA, s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0, tw.pe_le0,
+	       tw.tourflag);
+	HIP_CHECK(hipMemsetAsync(tw.tourflag + NA, 0, 4, s));
+	scan(tw.tourflag, tw.tour_ps, (size_t)NA + 1);
+	LAUNCH(k_t0_roots, C, s, C, cs.voff, start_key, tw.par0, tw.size0, tw.P0);
+	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, tw.arc_dst, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
+	tm.end(12 + rounds);
+
+	// ---- 3-4. bridges and 2-edge-connected classes
+	tm.begin("tree_bridges_classes");
+	LAUNCH(k_lowhigh, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.P0, tw.lowP, tw.highP);
+	seg_build(tw.segLo, tw.lowP, nS, s);
+	seg_build(tw.segHi, tw.highP, nS, s);
+	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, tw.segLo.tree, tw.segLo.P, tw.segHi.tree, tw.segHi.P, tw.isbridge);
+	LAUNCH(k_iota, nS, s, nS, tw.ecc);
+	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc);
+	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc);
+	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc);
+	tm.end(8 + 44);
+
+	// ---- 5-6. entries and the per-class DFS
+	tm.begin("tree_class_dfs");
+	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, tw.dpar, tw.cslot,
+	       tw.dvis, tw.entry_flag);
+	HIP_CHECK(hipMemsetAsync(tw.entry_flag + nS, 0, 4, s));
+	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
+	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
+	const uint32_t n_entry = read_u32(tw.entry_ps + nS, s);
+	HIP_CHECK(hipMemsetAsync(sw.cur, 0, (size_t)nS * 4, s));
+	if (n_entry)
+		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj,
+				   tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
+	tm.end(5);
+
+	// ---- 7. pre-order, sizes, depths
+	tm.begin("tree_preorder");
+	LAUNCH(k_child_keys, nS, s, nS, tw.dpar, tw.cslot, (unsigned long long *)tw.ckey, tw.cval);
+	sort_pairs_u64(tw.ckey, tw.ckey2, tw.cval, tw.cval2, nS, 64, pw.sort_tmp, pw.sort_tmp_bytes, s);
+	fill_u32(tw.fc, nS, NIL, s);
+	LAUNCH(k_child_links, nS, s, nS, (const unsigned long long *)tw.ckey2, tw.cval2, tw.fc, tw.nsib);
+	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA);
+	side = list_rank(2 * nS, rounds, tw.nxtA, tw.nxtB, tw.cntA, tw.cntB, tw.depA, tw.depB, s);
+	const uint32_t *cnt = side ? tw.cntB : tw.cntA, *dep = side ? tw.depB : tw.depA;
+	tm.end(5 + rounds);
+
+	// ---- 8. tree arrays in pre-order and the from_bd back edges
+	tm.begin("tree_emit");
+	LAUNCH(k_tree_emit, nS, s, nS, cnt, dep, tw.dpar, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
+	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx);
+	LAUNCH(k_tree_roots, C, s, C, tw.cproc, cs.voff, start_key, sw.t_gid, sw.t_flags, sw.t_par, sw.t_size, sw.t_depth,
+	       sw.c_ntree);
+	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
+	       tw.be_ps, pw.b_src, pw.b_tgt);
+	HIP_CHECK(hipMemsetAsync(tw.be_cnt + nS, 0, 4, s));
+	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
+	const uint32_t NB0 = read_u32(tw.be_ps + nS, s);
+	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
+	       tw.be_ps, pw.b_src, pw.b_tgt);
+	tm.end(6);
+	return NB0;
+}
+
+} // namespace povu_hip

@@ -1,0 +1,40 @@
+// tree_kernels.hpp -- parallel spanning tree (row C), see tree_kernels.hip
+#pragma once
+#include "common.hpp"
+#include "graph_kernels.hpp"
+#include "par_kernels.hpp"
+#include "seq_kernels.hpp"
+
+namespace povu_hip
+{
+
+struct TreeWs {
+	// unrooted spanning forest of the biedged graph H, as arcs
+	uint32_t *tg_ps;				  // [E+1] rank of tree-gray links
+	uint32_t *arc_src, *arc_dst, *arc_le;		  // [NA], arc_le per tree edge [NA/2]
+	uint32_t *k1, *k2, *v1, *v2;			  // [4V+4] sort buffers
+	uint32_t *apos, *afirst, *alast;		  // [NA], [2V], [2V]
+	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
+	uint32_t *tourflag, *tour_ps;			  // [4V+4]
+	uint32_t *par0, *size0, *P0, *pe_le0;		  // [2V]
+	uint32_t *lowP, *highP;				  // [2V]
+	uint32_t *isbridge, *ecc, *dpar, *cslot;	  // [2V]
+	uint8_t *dvis;					  // [2V]
+	uint32_t *entry_flag, *entry_ps, *entry_list;	  // [2V+1]
+	uint64_t *ckey, *ckey2;				  // [2V]
+	uint32_t *cval, *cval2, *fc, *nsib;		  // [2V]
+	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]
+	uint32_t *be_cnt, *be_ps;			  // [2V+1]
+	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
+	SegTree segLo, segHi;
+};
+
+size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax);
+void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax);
+
+// Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
+// layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.
+uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t max_nv,
+			   StageTimer &tm, hipStream_t s);
+
+} // namespace povu_hip

@@ -40,6 +40,7 @@ class _StageTime(C.Structure):
 
 F_HAIRPINS = 1
 F_SEQUENTIAL = 2
+F_SEQ_TREE = 4
 
 _lib = None
 

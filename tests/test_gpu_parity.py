@@ -135,3 +135,13 @@ def test_dense_random_graphs(hip, seed):
     n = 40 + 11 * seed
     g = W.random_bidirected(n, int(n * (2.0 + 0.1 * (seed % 10))), 9000 + seed, connected=True)
     assert gpu_texts(hip, g) == O.decompose(g)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sequential_tree_parallel_rest(hip, seed):
+    """POVU_HIP_F_SEQ_TREE: one-lane DFS feeding the parallel class / stack / PVST kernels."""
+    from povu_amd.hip import F_SEQ_TREE
+    n = 60 + 19 * seed
+    g = W.random_bidirected(n, int(n * 1.5), 700 + seed)
+    hip.upload(g)
+    assert hip.decompose(flags=F_SEQ_TREE).texts() == O.decompose(g)

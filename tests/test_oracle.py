@@ -100,6 +100,8 @@ def dump_component(links, comp=0, tips=None):
     tp = None if tips is None else np.ascontiguousarray(tips, dtype=np.uint8).ctypes.data
     d = lib.orc_dump_component(links.n_vtx, links.vid.ctypes.data, links.n_links, links.v1.ctypes.data,
                                links.s1.ctypes.data, links.v2.ctypes.data, links.s2.ctypes.data, tp, comp)
+    if not d:
+        return None
     c = d.contents
     out = {}
     def arr(p, n):
