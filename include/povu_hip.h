@@ -70,6 +70,7 @@ typedef struct {
 #define POVU_HIP_F_HAIRPINS 1u /* also report hairpin boundaries (--hairpins, flubbles.cpp:712-717) */
 #define POVU_HIP_F_SEQUENTIAL 2u /* force the one-lane-per-component kernels for every stage */
 #define POVU_HIP_F_SEQ_TREE 4u /* sequential spanning tree, parallel classes/stack/PVST (A/B testing) */
+#define POVU_HIP_F_FORCE_REDO 8u /* treat every component as flagged for the sequential redo (tests) */
 
 /*
  * Rows B-G.  Decomposes the resident graph: weakly connected components
@@ -117,6 +118,8 @@ typedef struct {
 } povu_hip_stage_time;
 /* stage timings of the last povu_hip_decompose on this context */
 int povu_hip_last_stage_times(const povu_hip_ctx *ctx, povu_hip_stage_time *out, int max);
+/* components the parallel kernels handed to the sequential redo in the last decompose */
+uint32_t povu_hip_last_seq_redo(const povu_hip_ctx *ctx);
 /* number of links in the components this shard processed in the last decompose */
 uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx);
 

@@ -420,10 +420,16 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				HIP_CHECK(hipStreamSynchronize(s));
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, max_nv, tm, s);
 			}
-			const uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
+			uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
+			if (o.flags & POVU_HIP_F_FORCE_REDO) {
+				fill_u32(ctx->pw.comp_bad, C, 1u, s);
+				nbad = C;
+			}
 			ctx->last_seq_redo = nbad;
 			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
 				tm.begin("redo_seq");
+				if (dense_nb0 >= 0) // the per-class DFS used the scan cursors
+					HIP_CHECK(hipMemsetAsync(sw.cur, 0, z.nS * 4, s));
 				sw.stages = dense_nb0 >= 0 ? SEQ_STAGE_ALL : (SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST);
 				sw.comp_sel = ctx->pw.comp_bad;
 				launch_seq_components(sw, s);
@@ -434,10 +440,15 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 
 		// ---- PVST arrays back to the host
 		tm.begin("pvst_d2h");
-		std::vector<uint32_t> npvst(C), nbry(C);
+		std::vector<uint32_t> npvst(C), nbry(C), cstat(C);
+		HIP_CHECK(hipMemcpyAsync(cstat.data(), sw.c_status, (size_t)C * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipMemcpyAsync(npvst.data(), sw.c_npvst, (size_t)C * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipMemcpyAsync(nbry.data(), sw.c_nbry, (size_t)C * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
+		for (uint32_t c = 0; c < C; c++)
+			if (cstat[c] == 2)
+				throw HipError("internal error: the spanning tree of component " + std::to_string(c + 1) +
+					       " did not reach every side");
 		auto f = std::make_unique<povu_hip_forest>();
 		f->total_components = C;
 		size_t total = 0, total_hp = 0;
@@ -631,6 +642,8 @@ extern "C" int povu_hip_last_stage_times(const povu_hip_ctx *ctx, povu_hip_stage
 			out[i] = ctx->last_times[i];
 	return n;
 }
+
+extern "C" uint32_t povu_hip_last_seq_redo(const povu_hip_ctx *ctx) { return ctx ? ctx->last_seq_redo : 0; }
 
 extern "C" uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx) { return ctx ? ctx->last_links : 0; }
 

@@ -168,6 +168,8 @@ __device__ static void seq_spanning_tree(CompView &c, uint64_t start_key)
 	}
 	if (has_tips)
 		c.size[0] = counter;
+	if (counter != c.N)
+		c.N = 0; // not every side was reached: the caller reports an internal error
 }
 
 // ------------------------------------------------------------------ row D
@@ -487,6 +489,11 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 			seq_spanning_tree(c, w.start_key[ci]);
 			w.c_ntree[ci] = c.N;
 			w.c_nbe0[ci] = c.n_be;
+			if (c.N == 0) {
+				w.c_status[ci] = 2;
+				w.c_npvst[ci] = 0;
+				continue;
+			}
 		} else {
 			c.N = w.c_ntree[ci];
 			c.n_be = w.c_nbe0[ci];

@@ -41,6 +41,7 @@ class _StageTime(C.Structure):
 F_HAIRPINS = 1
 F_SEQUENTIAL = 2
 F_SEQ_TREE = 4
+F_FORCE_REDO = 8
 
 _lib = None
 
@@ -75,6 +76,8 @@ def load_lib():
     l.povu_hip_buffer_free.argtypes = [C.c_void_p]
     l.povu_hip_last_stage_times.restype = C.c_int
     l.povu_hip_last_stage_times.argtypes = [C.c_void_p, C.POINTER(_StageTime), C.c_int]
+    l.povu_hip_last_seq_redo.restype = C.c_uint32
+    l.povu_hip_last_seq_redo.argtypes = [C.c_void_p]
     l.povu_hip_last_links_processed.restype = C.c_uint64
     l.povu_hip_last_links_processed.argtypes = [C.c_void_p]
     l.povu_hip_debug_components.restype = C.c_int
@@ -205,6 +208,9 @@ class HipDecomposer:
         buf = (_StageTime * 64)()
         n = self._lib.povu_hip_last_stage_times(self._ctx, buf, 64)
         return [dict(name=buf[i].name.decode(), ms=buf[i].ms, launches=buf[i].launches) for i in range(min(n, 64))]
+
+    def seq_redo_count(self) -> int:
+        return int(self._lib.povu_hip_last_seq_redo(self._ctx))
 
     def links_processed(self) -> int:
         return int(self._lib.povu_hip_last_links_processed(self._ctx))

@@ -145,3 +145,61 @@ def test_sequential_tree_parallel_rest(hip, seed):
     g = W.random_bidirected(n, int(n * 1.5), 700 + seed)
     hip.upload(g)
     assert hip.decompose(flags=F_SEQ_TREE).texts() == O.decompose(g)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_forced_sequential_redo(hip, seed):
+    """The guard path: components the parallel PVST stage would flag are redone sequentially."""
+    from povu_amd.hip import F_FORCE_REDO, F_SEQ_TREE
+    g = W.hprc_shaped([200 + 50 * seed, 90], seed=seed, tiny=8)
+    hip.upload(g)
+    want = O.decompose(g)
+    assert hip.decompose(flags=F_FORCE_REDO).texts() == want
+    assert hip.seq_redo_count() > 0
+    assert hip.decompose(flags=F_FORCE_REDO | F_SEQ_TREE).texts() == want
+    assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
+
+
+# ---- BASELINE.json full-size configurations
+def test_config2_chain_1m_nodes_bit_exact_vs_reference_md5(hip, golden_dir):
+    a = json.load(open(os.path.join(golden_dir, "anchors.json")))
+    t = gpu_texts(hip, W.chain_of_bubbles(333333))
+    assert list(t) == [1]
+    assert len(t[1].encode()) == a["bytes"]["chain_of_bubbles:333333"]
+    assert md5(t[1]) == a["md5"]["chain_of_bubbles:333333"]
+
+
+def test_config5_deep_nest_10m_links_vs_oracle(hip):
+    g = W.nested_towers(1000, 3333)
+    assert g.n_links > 9_900_000
+    got = gpu_texts(hip, g)
+    want = O.decompose(g)
+    assert list(got) == [1] and md5(got[1]) == md5(want[1])
+    # PVST recursion depth 1000: the deepest flubble chain
+    depth = {0: 0}
+    hip.upload(g)
+    t = hip.decompose().tree(0)
+    par = t.parent
+    d = np.zeros(len(par), dtype=np.int64)
+    for i in range(1, len(par)):
+        d[i] = d[par[i]] + 1
+    assert d.max() == 1000
+
+
+def test_config3_hprc_shaped_component_vs_oracle(hip):
+    g = W.hprc_shaped([1_000_000], seed=20260612)
+    got = gpu_texts(hip, g)
+    want = O.decompose(g)
+    assert {k: md5(v) for k, v in got.items()} == {k: md5(v) for k, v in want.items()}
+
+
+def test_config4_many_components_sharded_vs_oracle(hip):
+    sizes = [int(x) for x in np.linspace(60_000, 8_000, 24)]
+    g = W.hprc_shaped(sizes, seed=4, tiny=500)
+    want = {k: md5(v) for k, v in O.decompose(g).items()}
+    hip.upload(g)
+    got = {}
+    for r in range(8):
+        part = hip.decompose(rank=r, world=8).texts()
+        got.update({k: md5(v) for k, v in part.items()})
+    assert got == want
