@@ -108,6 +108,9 @@ void povu_hip_forest_free(povu_hip_forest *f);
  * povu_hip_buffer_free) and its length.
  */
 char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i, size_t *len);
+/* the same serialiser on caller-provided PVST arrays (host only, no GPU needed); NULL on bad input */
+char *povu_hip_pvst_format(uint32_t n_pvst, const uint32_t *a_id, const uint32_t *z_id, const uint8_t *a_or,
+			   const uint8_t *z_or, const uint32_t *parent, size_t *len);
 void povu_hip_buffer_free(void *p);
 
 /* ---- measurement (bench.py, povu-stage-cost lines) ---- */

@@ -578,6 +578,22 @@ extern "C" char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i,
 	povu_hip_tree t;
 	if (povu_hip_forest_get(f, i, &t) != 0)
 		return nullptr;
+	return povu_hip_pvst_format(t.n_pvst, t.a_id, t.z_id, t.a_or, t.z_or, t.parent, len);
+}
+
+extern "C" char *povu_hip_pvst_format(uint32_t n_pvst, const uint32_t *a_id, const uint32_t *z_id, const uint8_t *a_or,
+				      const uint8_t *z_or, const uint32_t *parent, size_t *len)
+{
+	if (n_pvst == 0 || !a_id || !z_id || !a_or || !z_or || !parent)
+		return nullptr;
+	struct {
+		uint32_t n_pvst;
+		const uint32_t *a_id, *z_id, *parent;
+		const uint8_t *a_or, *z_or;
+	} t{n_pvst, a_id, z_id, parent, a_or, z_or};
+	for (uint32_t v = 1; v < n_pvst; v++)
+		if (parent[v] >= v)
+			return nullptr; // a PVST parent always precedes its children (emission order)
 	const uint32_t n = t.n_pvst;
 	// children of every PVST vertex in emission order (children_v push_back, pvst.hpp:882-892)
 	std::vector<uint32_t> coff(n + 1, 0), cadj(n);

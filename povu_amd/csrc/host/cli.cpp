@@ -1,0 +1,113 @@
+// cli.cpp -- the `povu` command line for the decompose path.
+// Same surface as the reference for this path (app/cli/cli.cpp:14-26,236-262,324-382, app/main.cpp):
+//   povu [--version] [-v <int>] [-t <int>] decompose -i <gfa> [-o <dir>] [-h|--hairpins] [-s|--subflubbles]
+#include "decompose.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+static const char *VERSION = "0.0.1-alpha"; // app/cli/cli.hpp:10
+
+static void usage(std::ostream &os)
+{
+	os << "  povu {OPTIONS} [COMMAND]\n\n"
+	      "    Explore variation in a variation graph\n\n"
+	      "  OPTIONS:\n\n"
+	      "      commands\n"
+	      "        decompose                         Find regions of variation\n"
+	      "        gfa2vcf, call, info, prune, vcf   (not part of the MI355X decompose build)\n"
+	      "      arguments\n"
+	      "        --version                         The current version of povu\n"
+	      "        -v[verbosity],\n"
+	      "        --verbosity=[verbosity]           Level of output [default: 0]\n"
+	      "        -t[threads], --threads=[threads]  Number of threads to use [default: 1]\n"
+	      "        -h, --help                        help\n\n"
+	      "  decompose OPTIONS:\n"
+	      "        -i[gfa], --input-gfa=[gfa]        path to input gfa [required]\n"
+	      "        -o[output_dir],\n"
+	      "        --output-dir=[output_dir]         Output directory [default: .]\n"
+	      "        -h, --hairpins                    Find hairpins in the variation graph [default: false]\n"
+	      "        -s, --subflubbles                 Find subflubbles in the variation graph [default: false]\n";
+}
+
+int main(int argc, char **argv)
+{
+	povu_host::Config cfg;
+	std::string command;
+	bool version = false, help = false, have_input = false;
+	auto value = [&](int &i, const char *a, const char *shortf, const char *longf, std::string &out) -> bool {
+		const size_t ls = strlen(shortf), ll = strlen(longf);
+		if (!strncmp(a, longf, ll) && a[ll] == '=') {
+			out = a + ll + 1;
+			return true;
+		}
+		if (!strcmp(a, longf) || !strcmp(a, shortf)) {
+			if (i + 1 >= argc) {
+				std::cerr << "Flag '" << a << "' requires an argument but received none" << std::endl;
+				usage(std::cerr);
+				std::exit(1);
+			}
+			out = argv[++i];
+			return true;
+		}
+		if (!strncmp(a, shortf, ls) && a[ls] && a[1] != '-') {
+			out = a + ls;
+			return true;
+		}
+		return false;
+	};
+	for (int i = 1; i < argc; i++) {
+		const char *a = argv[i];
+		std::string v;
+		if (!strcmp(a, "--version")) {
+			version = true;
+		} else if (!strcmp(a, "--help") || (!strcmp(a, "-h") && command.empty())) {
+			help = true;
+		} else if (value(i, a, "-v", "--verbosity", v)) {
+			cfg.verbosity = atoi(v.c_str());
+		} else if (value(i, a, "-t", "--threads", v)) {
+			cfg.threads = atoi(v.c_str());
+		} else if (command == "decompose" && value(i, a, "-i", "--input-gfa", v)) {
+			cfg.input_gfa = v;
+			have_input = true;
+		} else if (command == "decompose" && value(i, a, "-o", "--output-dir", v)) {
+			cfg.output_dir = v;
+		} else if (command == "decompose" && (!strcmp(a, "-h") || !strcmp(a, "--hairpins"))) {
+			cfg.hairpins = true;
+		} else if (command == "decompose" && (!strcmp(a, "-s") || !strcmp(a, "--subflubbles"))) {
+			cfg.subflubbles = true;
+		} else if (command.empty() && a[0] != '-') {
+			command = a;
+		} else {
+			if (!version) {
+				std::cerr << "Flag could not be matched: " << a << std::endl;
+				usage(std::cerr);
+				return 1;
+			}
+		}
+	}
+	if (version) {
+		std::cout << VERSION << std::endl;
+		return EXIT_SUCCESS;
+	}
+	if (help || command.empty()) {
+		usage(std::cout);
+		return 0;
+	}
+	if (command != "decompose") {
+		std::cerr << "povu (MI355X build): only the `decompose` subcommand is provided; `" << command
+			  << "` belongs to the reference CPU tool" << std::endl;
+		return 1;
+	}
+	if (!have_input) {
+		std::cerr << "Flag 'gfa' is required" << std::endl;
+		usage(std::cerr);
+		return 1;
+	}
+	if (const char *d = std::getenv("POVU_HIP_DEVICE"))
+		cfg.device = atoi(d);
+	povu_host::do_decompose(cfg); // exceptions propagate like in the reference (uncaught -> terminate)
+	return 0;
+}

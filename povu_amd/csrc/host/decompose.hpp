@@ -1,0 +1,26 @@
+// decompose.hpp -- host orchestration of `povu decompose` on the HIP path.
+// Mirrors povu::subcommands::decompose::do_decompose (app/subcommand/decompose.cpp:94-160) and the
+// decompose-relevant part of core::config (include/povu/common/app.hpp:129-182).
+#pragma once
+#include <cstdint>
+#include <string>
+
+namespace povu_host
+{
+
+struct Config {
+	std::string input_gfa;
+	std::string output_dir = "."; // app.hpp default
+	int verbosity = 0;
+	int threads = 1;
+	bool hairpins = false;
+	bool subflubbles = false;
+	int device = 0;
+};
+
+// Loads the GFA, decomposes it on the GPU and writes <output_dir>/<component id>.pvst.
+// Invalid GFA -> std::runtime_error (uncaught in the reference too, from_gfa.cpp:28-32);
+// unwritable output -> message + exit(EXIT_FAILURE) (to_pvst.cpp:39-42).
+void do_decompose(const Config &cfg);
+
+} // namespace povu_host

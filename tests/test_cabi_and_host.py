@@ -1,0 +1,243 @@
+"""CPU tests of the drop-in boundary: the C-ABI libraries load and export every declared symbol, the
+host-side pieces (GFA tokenizer, FFI graph builder, PVST serialiser, CLI argument handling) behave
+like the reference, and compute entry points fail loudly without a GPU."""
+import ctypes as C
+import glob
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from povu_amd import hip as H
+from povu_amd import workloads as W
+from test_oracle import _load_gfa_links, dump_component
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "povu_amd", "lib")
+POVU = os.path.join(ROOT, "povu_amd", "bin", "povu")
+
+
+def _built():
+    if not (os.path.exists(os.path.join(LIB, "libpovu_hip.so")) and os.path.exists(os.path.join(LIB, "libpovu_ffi.so"))
+            and os.path.exists(POVU)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(povu_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    _built()
+    lib = C.CDLL(os.path.join(LIB, "libpovu_hip.so"))
+    names = _declared("povu_hip.h")
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_ffi_library_exports_the_reference_abi():
+    _built()
+    lib = C.CDLL(os.path.join(LIB, "libpovu_ffi.so"))
+    names = _declared("povu_ffi.h")
+    reference_33 = """povu_graph_new povu_graph_from_gfa povu_graph_free povu_graph_add_vertex povu_graph_add_edge
+        povu_graph_add_path povu_graph_finalize povu_graph_vertex_count povu_graph_edge_count povu_graph_path_count
+        povu_graph_get_vertices povu_graph_get_edges povu_graph_get_paths povu_vertices_free povu_edges_free
+        povu_paths_free povu_graph_set_references_from_file povu_graph_set_references_from_prefixes
+        povu_graph_find_flubbles povu_flubbles_free povu_flubbles_count povu_flubbles_get povu_flubble_free
+        povu_flubbles_get_pvst_tree povu_pvst_tree_free povu_pvst_tree_vertex_count povu_flubbles_call_variants
+        povu_vcf_write_to_file povu_vcf_to_string povu_vcf_free povu_string_free povu_gfa_to_vcf
+        povu_error_free""".split()
+    assert len(reference_33) == 33
+    for n in reference_33:
+        assert n in names, n
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+class _Err(C.Structure):
+    _fields_ = [("code", C.c_int), ("message", C.c_char_p)]
+
+
+class _Edge(C.Structure):
+    _fields_ = [("from_id", C.c_uint64), ("from_o", C.c_int), ("to_id", C.c_uint64), ("to_o", C.c_int)]
+
+
+class _Vertex(C.Structure):
+    _fields_ = [("id", C.c_uint64), ("sequence", C.c_char_p), ("sequence_len", C.c_size_t)]
+
+
+def _ffi():
+    _built()
+    lib = C.CDLL(os.path.join(LIB, "libpovu_ffi.so"))
+    lib.povu_graph_new.restype = C.c_void_p
+    lib.povu_graph_new.argtypes = [C.c_size_t] * 3
+    lib.povu_graph_from_gfa.restype = C.c_void_p
+    lib.povu_graph_from_gfa.argtypes = [C.c_char_p, C.POINTER(_Err)]
+    lib.povu_graph_free.argtypes = [C.c_void_p]
+    lib.povu_graph_add_vertex.restype = C.c_size_t
+    lib.povu_graph_add_vertex.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
+    lib.povu_graph_add_edge.restype = C.c_size_t
+    lib.povu_graph_add_edge.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
+    lib.povu_graph_add_path.restype = C.c_bool
+    lib.povu_graph_add_path.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    for f in ("vertex", "edge", "path"):
+        getattr(lib, f"povu_graph_{f}_count").restype = C.c_size_t
+        getattr(lib, f"povu_graph_{f}_count").argtypes = [C.c_void_p]
+    lib.povu_graph_get_edges.restype = C.POINTER(_Edge)
+    lib.povu_graph_get_edges.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.povu_graph_get_vertices.restype = C.POINTER(_Vertex)
+    lib.povu_graph_get_vertices.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.povu_edges_free.argtypes = [C.c_void_p, C.c_size_t]
+    lib.povu_vertices_free.argtypes = [C.c_void_p, C.c_size_t]
+    lib.povu_graph_find_flubbles.restype = C.c_void_p
+    lib.povu_graph_find_flubbles.argtypes = [C.c_void_p, C.POINTER(_Err)]
+    lib.povu_flubbles_get.restype = C.c_void_p
+    lib.povu_flubbles_get.argtypes = [C.c_void_p, C.c_size_t]
+    lib.povu_flubbles_count.restype = C.c_size_t
+    lib.povu_flubbles_count.argtypes = [C.c_void_p]
+    lib.povu_gfa_to_vcf.restype = C.c_bool
+    lib.povu_gfa_to_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_Err)]
+    lib.povu_error_free.argtypes = [C.POINTER(_Err)]
+    return lib
+
+
+def test_ffi_builder_matches_reference_semantics():
+    """povu-rs/tests/builder_tests.rs: counts, orientation mapping (FORWARD=l, REVERSE=r), stubs."""
+    lib = _ffi()
+    g = lib.povu_graph_new(4, 4, 0)
+    for i, s in [(1, b"A"), (2, b"C"), (3, b"G"), (4, b"T")]:
+        assert lib.povu_graph_add_vertex(g, i, s) == i - 1
+    assert lib.povu_graph_add_vertex(g, 9, None) == C.c_size_t(-1).value
+    assert lib.povu_graph_add_edge(g, 1, 0, 2, 0) == 0
+    assert lib.povu_graph_add_edge(g, 1, 1, 3, 0) == 1
+    assert lib.povu_graph_add_edge(g, 2, 1, 2, 1) == 2  # self loop accepted (builder_tests.rs:243-254)
+    assert lib.povu_graph_add_edge(g, 1, 0, 77, 0) == C.c_size_t(-1).value  # unknown vertex id
+    assert lib.povu_graph_vertex_count(g) == 4 and lib.povu_graph_edge_count(g) == 3
+    assert lib.povu_graph_path_count(g) == 0
+    assert lib.povu_graph_add_path(g, b"p", None, 0) is False
+    n = C.c_size_t(0)
+    e = lib.povu_graph_get_edges(g, C.byref(n))
+    assert n.value == 3
+    assert (e[1].from_id, e[1].from_o, e[1].to_id, e[1].to_o) == (1, 1, 3, 0)
+    lib.povu_edges_free(e, n)
+    err = _Err(0, None)
+    assert lib.povu_gfa_to_vcf(b"a", b"b", None, C.byref(err)) is False and err.code == 1
+    assert b"not yet implemented" in err.message
+    lib.povu_graph_free(g)
+    assert lib.povu_graph_vertex_count(None) == 0
+
+
+def test_ffi_gfa_loader_contract(golden_dir):
+    """Row A host part: vertices ascending by id, links in L order, `+`/`-` -> sides."""
+    lib = _ffi()
+    for path in sorted(glob.glob(os.path.join(golden_dir, "gfa", "*.gfa"))):
+        name = os.path.basename(path)
+        if name in ("malformed_path_missing_overlaps.gfa",):
+            continue
+        err = _Err(0, None)
+        g = lib.povu_graph_from_gfa(path.encode(), C.byref(err))
+        assert g, (name, err.message)
+        want = _load_gfa_links(path)
+        nv = C.c_size_t(0)
+        v = lib.povu_graph_get_vertices(g, C.byref(nv))
+        assert [v[i].id for i in range(nv.value)] == want.vid.tolist()
+        lib.povu_vertices_free(v, nv)
+        ne = C.c_size_t(0)
+        e = lib.povu_graph_get_edges(g, C.byref(ne))
+        got = [(e[i].from_id, e[i].from_o, e[i].to_id, e[i].to_o) for i in range(ne.value)]
+        exp = [(int(want.vid[a]), int(sa), int(want.vid[b]), int(sb))
+               for a, sa, b, sb in zip(want.v1, want.s1, want.v2, want.s2)]
+        assert got == exp, name
+        lib.povu_edges_free(e, ne)
+        lib.povu_graph_free(g)
+
+
+def test_ffi_gfa_errors(tmp_path):
+    lib = _ffi()
+    err = _Err(0, None)
+    assert not lib.povu_graph_from_gfa(b"", C.byref(err)) and err.message == b"GFA path must not be empty"
+    err = _Err(0, None)
+    assert not lib.povu_graph_from_gfa(b"/nonexistent.gfa", C.byref(err))
+    assert err.message.startswith(b"GFA file does not exist: /nonexistent.gfa")
+    bad = tmp_path / "bad.gfa"
+    bad.write_text("H\tVN:Z:1.0\nS\t1\t\nS\t2\tA\n")
+    err = _Err(0, None)
+    assert not lib.povu_graph_from_gfa(str(bad).encode(), C.byref(err))
+    assert err.message == f"Invalid GFA '{bad}': S record on line 2 has an empty sequence".encode()
+    bad.write_text("S\t1\tA\nX\tfoo\n")
+    err = _Err(0, None)
+    assert not lib.povu_graph_from_gfa(str(bad).encode(), C.byref(err))
+    assert err.message == f"Invalid GFA '{bad}': unsupported record type 'X' on line 2".encode()
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    lib = _ffi()
+    hl = H.load_lib()
+    if hl.povu_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g = lib.povu_graph_new(3, 2, 0)
+    for i in (1, 2, 3):
+        lib.povu_graph_add_vertex(g, i, b"A")
+    lib.povu_graph_add_edge(g, 1, 1, 2, 0)
+    lib.povu_graph_add_edge(g, 2, 1, 3, 0)
+    err = _Err(0, None)
+    assert not lib.povu_graph_find_flubbles(g, C.byref(err))
+    assert err.code == 1 and b"no CPU fallback" in err.message
+    lib.povu_graph_free(g)
+    with pytest.raises(H.HipUnavailable):
+        H.HipDecomposer(0)
+
+
+def test_pvst_serialiser_matches_to_pvst(golden_dir):
+    """povu_hip_pvst_format (host only) on the oracle's PVST arrays == the oracle's text."""
+    hl = H.load_lib()
+    hl.povu_hip_pvst_format.restype = C.c_void_p
+    hl.povu_hip_pvst_format.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_size_t)]
+    graphs = [W.chain_of_bubbles(30), W.nested_towers(7, 2), _load_gfa_links(os.path.join(golden_dir, "gfa", "LPA.gfa")),
+              _load_gfa_links(os.path.join(golden_dir, "gfa", "linear_no_variant.gfa"))]
+    import test_oracle as T
+    for g in graphs:
+        want = O.decompose(g)[1]
+        lib = O.lib()
+        d = lib.orc_dump_component
+        dd = T.dump_component(g, 0)
+        n = len(dd["p_parent"])
+        a, z, p = dd["p_a_id"].astype(np.uint32), dd["p_z_id"].astype(np.uint32), dd["p_parent"].astype(np.uint32)
+        # orientations are not in the python dump dict: recover them from the expected text
+        rows = want.splitlines()[1:]
+        ao = np.array([0] + [1 if r.split("\t")[2][0] == "<" else 0 for r in rows[1:]], dtype=np.uint8)
+        zo = np.array([0] + [1 if re.match(r"^[<>]\d+<", r.split("\t")[2]) else 0 for r in rows[1:]], dtype=np.uint8)
+        ln = C.c_size_t(0)
+        ptr = hl.povu_hip_pvst_format(n, a.ctypes.data, z.ctypes.data, ao.ctypes.data, zo.ctypes.data, p.ctypes.data,
+                                      C.byref(ln))
+        assert ptr
+        got = C.string_at(ptr, ln.value).decode()
+        hl.povu_hip_buffer_free(ptr)
+        assert got == want
+
+
+def test_cli_surface(tmp_path, golden_dir):
+    _built()
+    r = subprocess.run([POVU, "--version"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "0.0.1-alpha"  # app/cli/cli.hpp:10
+    r = subprocess.run([POVU, "decompose"], capture_output=True, text=True)
+    assert r.returncode == 1 and "required" in r.stderr
+    r = subprocess.run([POVU, "call", "-i", "x"], capture_output=True, text=True)
+    assert r.returncode == 1
+    bad = tmp_path / "bad.gfa"
+    bad.write_text("S\t1\n")
+    r = subprocess.run([POVU, "decompose", "-i", str(bad), "-o", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and f"Invalid GFA '{bad}': S record on line 1 is missing a sequence" in r.stderr
+    if H.load_lib().povu_hip_device_count() == 0:
+        r = subprocess.run([POVU, "decompose", "-i", os.path.join(golden_dir, "gfa", "LPA.gfa"), "-o", str(tmp_path)],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr
+        assert not list(tmp_path.glob("*.pvst"))

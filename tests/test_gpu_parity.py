@@ -203,3 +203,82 @@ def test_config4_many_components_sharded_vs_oracle(hip):
         part = hip.decompose(rank=r, world=8).texts()
         got.update({k: md5(v) for k, v in part.items()})
     assert got == want
+
+
+def test_cli_and_ffi_on_gpu(tmp_path, golden_dir):
+    """The two drop-in surfaces end to end: `povu decompose` files and povu_graph_find_flubbles."""
+    import ctypes as C
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    povu = os.path.join(root, "povu_amd", "bin", "povu")
+    g = W.hprc_shaped([150, 70], seed=21, tiny=4)
+    gfa = tmp_path / "g.gfa"
+    gfa.write_text(g.to_gfa())
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, POVU_STAGE_COST_TRACE="1")
+    r = subprocess.run([povu, "-t", "2", "decompose", "-i", str(gfa), "-o", str(out), "-h"], capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    want = O.decompose(g)
+    got = {int(p.name[:-5]): p.read_text() for p in out.glob("*.pvst")}
+    assert got == want
+    assert "povu-stage-cost contract=hip:" in r.stderr and "Boundary: " in r.stderr
+    # LPA through the CLI: md5 anchor of the reference output
+    out2 = tmp_path / "lpa"
+    out2.mkdir()
+    r = subprocess.run([povu, "decompose", "-i", os.path.join(golden_dir, "gfa", "LPA.gfa"), "-o", str(out2)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr == ""
+    a = json.load(open(os.path.join(golden_dir, "anchors.json")))
+    assert md5((out2 / "1.pvst").read_text()) == a["md5"]["LPA.gfa"]
+    # FFI
+    from test_cabi_and_host import _Err, _ffi
+    lib = _ffi()
+    lib.povu_graph_decompose.restype = C.c_void_p
+    lib.povu_graph_decompose.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(_Err)]
+    lib.povu_forest_tree_count.restype = C.c_size_t
+    lib.povu_forest_tree_count.argtypes = [C.c_void_p]
+    lib.povu_forest_component_id.restype = C.c_uint32
+    lib.povu_forest_component_id.argtypes = [C.c_void_p, C.c_size_t]
+    lib.povu_forest_pvst_text.restype = C.c_void_p
+    lib.povu_forest_pvst_text.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.povu_string_free.argtypes = [C.c_void_p]
+    lib.povu_forest_free.argtypes = [C.c_void_p]
+    lib.povu_flubbles_free.argtypes = [C.c_void_p]
+    err = _Err(0, None)
+    gh = lib.povu_graph_from_gfa(str(gfa).encode(), C.byref(err))
+    assert gh
+    fl = lib.povu_graph_find_flubbles(gh, C.byref(err))
+    assert fl, err.message
+    n_flub = sum(t.count("\nF\t") for t in want.values())
+    assert lib.povu_flubbles_count(fl) == n_flub + 1
+    assert lib.povu_flubbles_get(fl, 0) is None
+    lib.povu_flubbles_free(fl)
+    fo = lib.povu_graph_decompose(gh, 0, 0, C.byref(err))
+    assert fo
+    texts = {}
+    for i in range(lib.povu_forest_tree_count(fo)):
+        ln = C.c_size_t(0)
+        p = lib.povu_forest_pvst_text(fo, i, C.byref(ln))
+        texts[lib.povu_forest_component_id(fo, i)] = C.string_at(p, ln.value).decode()
+        lib.povu_string_free(p)
+    assert texts == want
+    lib.povu_forest_free(fo)
+    lib.povu_graph_free(gh)
+    # builder graph (no tips, like tests/integration_tests/pvst_tests.cc): PVST = . -> >1>7 -> >4>6
+    b = lib.povu_graph_new(7, 10, 0)
+    for i in range(1, 8):
+        lib.povu_graph_add_vertex(b, i, b"A")
+    for a_, ao, b_, bo in [(1, 1, 3, 0), (1, 1, 4, 0), (2, 1, 4, 0), (3, 1, 4, 0), (3, 0, 2, 0), (4, 1, 5, 0), (4, 1, 6, 0),
+                           (4, 0, 7, 0), (5, 1, 6, 0), (6, 1, 7, 0)]:
+        lib.povu_graph_add_edge(b, a_, ao, b_, bo)
+    fo = lib.povu_graph_decompose(b, 0, 0, C.byref(err))
+    assert fo and lib.povu_forest_tree_count(fo) == 1
+    ln = C.c_size_t(0)
+    p = lib.povu_forest_pvst_text(fo, 0, C.byref(ln))
+    text = C.string_at(p, ln.value).decode()
+    lib.povu_string_free(p)
+    assert sorted(l.split("\t")[2] for l in text.splitlines()[1:]) == sorted([".", ">1>7", ">4>6"])
+    lib.povu_forest_free(fo)
+    lib.povu_graph_free(b)

@@ -110,7 +110,8 @@ def dump_component(links, comp=0, tips=None):
                  ("typ", c.n_tree), ("pe_black", c.n_tree), ("be_src", c.n_be), ("be_tgt", c.n_be),
                  ("be_type", c.n_be), ("s_id", c.n_stack), ("s_st_idx", c.n_stack), ("s_edge_id", c.n_stack),
                  ("s_cls", c.n_stack), ("next_seen", c.n_stack), ("s_orient", c.n_stack),
-                 ("p_parent", c.n_pvst), ("p_a_id", c.n_pvst), ("p_z_id", c.n_pvst), ("ev1", c.ne), ("ev2", c.ne),
+                 ("p_parent", c.n_pvst), ("p_a_id", c.n_pvst), ("p_z_id", c.n_pvst), ("p_a_or", c.n_pvst),
+                 ("p_z_or", c.n_pvst), ("ev1", c.ne), ("ev2", c.ne),
                  ("es1", c.ne), ("es2", c.ne), ("gidx", c.nv)]:
         out[f] = arr(getattr(c, f), n)
     out["n_be0"] = c.n_be0
