@@ -211,7 +211,15 @@ def test_cli_and_ffi_on_gpu(tmp_path, golden_dir):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     povu = os.path.join(root, "povu_amd", "bin", "povu")
-    g = W.hprc_shaped([150, 70], seed=21, tiny=4)
+    # chain 1>2>3>4 with a bubble 2>6>3, a hairpin 3+ -> 5+/5- and a self loop on 7: one hairpin boundary
+    hl = [(0, 1, 1, 0), (1, 1, 2, 0), (2, 1, 3, 0), (1, 1, 5, 0), (5, 1, 2, 0), (2, 1, 4, 0), (2, 1, 4, 1), (3, 1, 6, 0),
+          (6, 1, 6, 1)]
+    h = W._mk(np.arange(1, 8), [a for a, _, _, _ in hl], [x for _, x, _, _ in hl], [b for _, _, b, _ in hl],
+              [x for _, _, _, x in hl])
+    r0 = W.random_bidirected(120, 170, 31)
+    off = h.n_vtx
+    g = W._mk(np.concatenate([h.vid, r0.vid + 100]), np.concatenate([h.v1, r0.v1 + off]), np.concatenate([h.s1, r0.s1]),
+              np.concatenate([h.v2, r0.v2 + off]), np.concatenate([h.s2, r0.s2]))
     gfa = tmp_path / "g.gfa"
     gfa.write_text(g.to_gfa())
     out = tmp_path / "out"
@@ -223,7 +231,17 @@ def test_cli_and_ffi_on_gpu(tmp_path, golden_dir):
     want = O.decompose(g)
     got = {int(p.name[:-5]): p.read_text() for p in out.glob("*.pvst")}
     assert got == want
-    assert "povu-stage-cost contract=hip:" in r.stderr and "Boundary: " in r.stderr
+    assert "povu-stage-cost contract=hip:" in r.stderr
+    exp_b = []
+    c = 0
+    while True:
+        d = dump_component(g, c)
+        if d is None:
+            break
+        exp_b += [f"Boundary: {int(b1)} {int(b2)}" for b1, b2 in d["bry"].tolist()]
+        c += 1
+    assert [l for l in r.stderr.splitlines() if l.startswith("Boundary: ")] == exp_b
+    assert "Boundary: 7 1" in exp_b
     # LPA through the CLI: md5 anchor of the reference output
     out2 = tmp_path / "lpa"
     out2.mkdir()
