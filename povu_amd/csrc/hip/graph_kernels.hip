@@ -7,6 +7,8 @@
 // coalesced over edge / side / slot ids, the scattered part goes through L2.
 #include "graph_kernels.hpp"
 
+#include <algorithm>
+
 namespace povu_hip
 {
 
@@ -93,6 +95,134 @@ __global__ void k_uf_union(uint32_t E, const uint32_t *__restrict__ v1, const ui
 		}
 	}
 	hook[e] = merged;
+}
+
+// ---- tile-local union-find.  Pangenome GFAs are (mostly) sorted along the genome, so almost every
+// link joins two segments of nearby idx.  A workgroup owns UF_TILE consecutive vertices, keeps their
+// parent pointers in LDS and unions every link whose both ends fall inside the tile there (LDS CAS,
+// no global atomics, no long global pointer chains); only the links that leave a tile go through
+// the global lock-free union-find afterwards.
+static constexpr uint32_t UF_TILE = 4096;
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
+{
+	uint32_t p = par[x];
+	while (p != x) {
+		uint32_t gp = par[p];
+		if (gp != p)
+			par[x] = gp;
+		x = p;
+		p = gp;
+	}
+	return x;
+}
+
+__global__ void __launch_bounds__(512) k_uf_tiles(uint32_t V, uint32_t E, const uint32_t *__restrict__ e_lo,
+						  const uint32_t *__restrict__ e_hi, const uint32_t *__restrict__ eperm,
+						  uint32_t *__restrict__ label, uint32_t *__restrict__ hook)
+{
+	__shared__ uint32_t par[UF_TILE];
+	__shared__ uint32_t kb, ke;
+	const uint32_t v0 = blockIdx.x * UF_TILE, v1 = min(V, v0 + UF_TILE);
+	for (uint32_t i = threadIdx.x; i < UF_TILE; i += blockDim.x)
+		par[i] = i;
+	if (threadIdx.x < 2) { // first sorted link position with e_lo >= v0 (thread 0) / v1 (thread 1)
+		const uint32_t x = threadIdx.x ? v1 : v0;
+		uint32_t lo = 0, hi = E;
+		while (lo < hi) {
+			uint32_t mid = (lo + hi) >> 1;
+			if (e_lo[mid] < x)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		if (threadIdx.x)
+			ke = lo;
+		else
+			kb = lo;
+	}
+	__syncthreads();
+	for (uint32_t k = kb + threadIdx.x; k < ke; k += blockDim.x) {
+		const uint32_t bg = e_hi[k];
+		if (bg >= v1)
+			continue; // leaves the tile: k_uf_cross
+		const uint32_t a = e_lo[k] - v0, b = bg - v0;
+		uint32_t merged = 0;
+		if (a != b) {
+			uint32_t ra = lds_find(par, a), rb = lds_find(par, b);
+			while (ra != rb) {
+				const uint32_t hi = max(ra, rb), lo = min(ra, rb);
+				const uint32_t old = atomicCAS(&par[hi], hi, lo);
+				if (old == hi) {
+					merged = 1;
+					break;
+				}
+				ra = lds_find(par, old);
+				rb = lds_find(par, lo);
+			}
+		}
+		hook[eperm[k]] = merged;
+	}
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < v1 - v0; i += blockDim.x) {
+		uint32_t r = i;
+		while (par[r] != r)
+			r = par[r];
+		label[v0 + i] = v0 + r;
+	}
+}
+
+__global__ void k_uf_cross(uint32_t NX, const uint32_t *__restrict__ xlist, const uint32_t *__restrict__ e_lo,
+			   const uint32_t *__restrict__ e_hi, const uint32_t *__restrict__ eperm, uint32_t *parent,
+			   uint32_t *__restrict__ hook)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NX)
+		return;
+	const uint32_t k = xlist[i];
+	uint32_t merged = 0;
+	uint32_t ra = uf_find(parent, e_lo[k]), rb = uf_find(parent, e_hi[k]);
+	while (ra != rb) {
+		uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+		uint32_t old = atomicCAS(&parent[hi], hi, lo);
+		if (old == hi) {
+			merged = 1;
+			break;
+		}
+		ra = uf_find(parent, old);
+		rb = uf_find(parent, lo);
+	}
+	hook[eperm[k]] = merged;
+}
+
+// upload-time helpers: links keyed by their smaller endpoint
+__global__ void k_edge_min(uint32_t E, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
+			   uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= E)
+		return;
+	key[e] = min(v1[e], v2[e]);
+	val[e] = e;
+}
+__global__ void k_edge_sorted(uint32_t E, const uint32_t *__restrict__ eperm, const uint32_t *__restrict__ v1,
+			      const uint32_t *__restrict__ v2, uint32_t *__restrict__ e_lo, uint32_t *__restrict__ e_hi,
+			      uint32_t *__restrict__ xflag)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= E)
+		return;
+	uint32_t e = eperm[k], a = v1[e], b = v2[e], lo = min(a, b), hi = max(a, b);
+	e_lo[k] = lo;
+	e_hi[k] = hi;
+	xflag[k] = (lo / UF_TILE != hi / UF_TILE) ? 1u : 0u;
+}
+__global__ void k_compact_pos(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
+			      uint32_t *__restrict__ out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && flag[i])
+		out[ps[i]] = i;
 }
 
 __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint32_t *__restrict__ is_root)
@@ -264,11 +394,11 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	const uint32_t V = g.V, E = g.E;
 	const size_t nS = 2 * (size_t)V;
 	tmp_arena.reserve(Arena::padded(2 * (size_t)E + 2, 4) * 4 + Arena::padded(nS + 2, 4) + sort_tmp_bytes(2 * (size_t)E) +
-			  scan_tmp_bytes(nS + 1) + (1 << 16));
+			  scan_tmp_bytes(std::max<size_t>(nS, E) + 2) + (1 << 16));
 	uint32_t *keys = tmp_arena.take<uint32_t>(2 * (size_t)E + 1), *vals = tmp_arena.take<uint32_t>(2 * (size_t)E + 1);
 	uint32_t *keys2 = tmp_arena.take<uint32_t>(2 * (size_t)E + 1), *vals2 = tmp_arena.take<uint32_t>(2 * (size_t)E + 1);
 	uint32_t *deg = tmp_arena.take<uint32_t>(nS + 1);
-	size_t sb = sort_tmp_bytes(2 * (size_t)E), cb = scan_tmp_bytes(nS + 1);
+	size_t sb = sort_tmp_bytes(2 * (size_t)E), cb = scan_tmp_bytes(std::max<size_t>(nS, E) + 2);
 	void *stmp = tmp_arena.take<char>(sb), *ctmp = tmp_arena.take<char>(cb);
 	HIP_CHECK(hipMemsetAsync(deg, 0, (nS + 1) * 4, s));
 	if (E) {
@@ -285,6 +415,18 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)n_slots * 4, hipMemcpyDeviceToDevice, s));
 	if (!g.tips_given && V)
 		hipLaunchKernelGGL(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
+	// links sorted by smaller endpoint + the list of links that cross a union-find tile
+	g.n_cross = 0;
+	if (E) {
+		hipLaunchKernelGGL(k_edge_min, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.v2, keys, vals);
+		sort_pairs_u32(keys, keys2, vals, g.eperm, E, bits_for(V), stmp, sb, s);
+		uint32_t *xflag = keys, *xps = vals; // reuse (2E+1 entries each)
+		hipLaunchKernelGGL(k_edge_sorted, dim3(nblk(E)), dim3(TPB), 0, s, E, g.eperm, g.v1, g.v2, g.e_lo, g.e_hi, xflag);
+		HIP_CHECK(hipMemsetAsync(xflag + E, 0, 4, s));
+		scan_exclusive_u32(xflag, xps, (size_t)E + 1, ctmp, cb, s);
+		hipLaunchKernelGGL(k_compact_pos, dim3(nblk(E)), dim3(TPB), 0, s, E, xflag, xps, g.xlist);
+		HIP_CHECK(hipMemcpyAsync(&g.n_cross, xps + E, 4, hipMemcpyDeviceToHost, s));
+	}
 	HIP_CHECK(hipStreamSynchronize(s));
 }
 
@@ -292,9 +434,11 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
-	hipLaunchKernelGGL(k_uf_init, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label);
-	if (E)
-		hipLaunchKernelGGL(k_uf_union, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.v2, st.label, st.hook);
+	hipLaunchKernelGGL(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(512), 0, s, V, E, g.e_lo, g.e_hi, g.eperm, st.label,
+			   st.hook);
+	if (g.n_cross)
+		hipLaunchKernelGGL(k_uf_cross, dim3(nblk(g.n_cross)), dim3(TPB), 0, s, g.n_cross, g.xlist, g.e_lo, g.e_hi, g.eperm,
+				   st.label, st.hook);
 	hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
 	HIP_CHECK(hipMemsetAsync(st.flag + V, 0, 4, s));
 	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);

@@ -16,6 +16,10 @@ struct ResidentGraph {
 	uint8_t *tip = nullptr;			    // [V]   POVU_TIP_*
 	uint32_t *off = nullptr;		    // [2V+1] per-side CSR offsets
 	uint32_t *adj = nullptr;		    // [n_slots] incident link idx, ascending per side
+	// links sorted by their smaller endpoint (built at upload): tile-local union-find input
+	uint32_t *eperm = nullptr, *e_lo = nullptr, *e_hi = nullptr; // [E] link idx, min / max endpoint
+	uint32_t *xlist = nullptr;		    // [n_cross] sorted positions of links that leave their tile
+	uint32_t n_cross = 0;
 	void *block = nullptr;			    // one allocation backing all of the above
 };
 

@@ -577,8 +577,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_tcomp_vertices, V, s, V, cs.ckey, pw.t_comp);
 	LAUNCH(k_tcomp_last, C, s, C, cs.voff, pw.t_comp);
 	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root);
-	HIP_CHECK(hipMemsetAsync(pw.err, 0, 64, s));
-	HIP_CHECK(hipMemsetAsync(pw.comp_bad, 0, ((size_t)C + 1) * 4, s));
+	HIP_CHECK(hipMemsetAsync(pw.comp_bad, 0, ((size_t)C + 1) * 4, s)); // pw.err is zeroed by the caller
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
 		NB0 = (uint32_t)dense_nb0;
@@ -679,9 +678,13 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	       sw.next_seen);
 	tm.end(12 + 3 * 22);
 
-	uint32_t err0 = read_u32(pw.err, s);
-	if (err0)
+	uint32_t errw[2];
+	HIP_CHECK(hipMemcpyAsync(errw, pw.err, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (errw[0])
 		throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
+	if (errw[1])
+		throw HipError("list ranking: splitter capacity exceeded (internal sizing bug)");
 	// count flagged components
 	std::vector<uint32_t> bad(C);
 	HIP_CHECK(hipMemcpyAsync(bad.data(), pw.comp_bad, (size_t)C * 4, hipMemcpyDeviceToHost, s));

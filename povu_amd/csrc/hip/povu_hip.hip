@@ -133,7 +133,7 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		g.tips_given = tips != nullptr;
 		const size_t V = n_vtx, E = n_links;
 		size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
-			       Arena::padded(2 * V + 2, 4) + Arena::padded(2 * E + 2, 4) + 4096;
+			       Arena::padded(2 * V + 2, 4) + Arena::padded(2 * E + 2, 4) + 4 * Arena::padded(E + 1, 4) + 4096;
 		HIP_CHECK(hipMalloc(&g.block, bytes));
 		char *p = static_cast<char *>(g.block);
 		auto carve = [&](size_t n, size_t elem) {
@@ -149,6 +149,10 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		g.tip = (uint8_t *)carve(V, 1);
 		g.off = (uint32_t *)carve(2 * V + 2, 4);
 		g.adj = (uint32_t *)carve(2 * E + 2, 4);
+		g.eperm = (uint32_t *)carve(E + 1, 4);
+		g.e_lo = (uint32_t *)carve(E + 1, 4);
+		g.e_hi = (uint32_t *)carve(E + 1, 4);
+		g.xlist = (uint32_t *)carve(E + 1, 4);
 		hipStream_t s = ctx->stream;
 		HIP_CHECK(hipMemcpyAsync(g.vid, vid, V * 4, hipMemcpyHostToDevice, s));
 		if (E) {
@@ -377,23 +381,21 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		sw.tip_s = cs.tip_s;
 		sw.start_key = cs.start_key;
 		const size_t T = 2 * (size_t)g.V + C, B = (size_t)g.E + g.V + 2 * T;
+		// the one-lane kernels expect their lists empty; only paid for when they actually run
+		auto init_seq_workspace = [&]() {
+			for (uint32_t *p : {sw.first_child, sw.o_head, sw.i_head, sw.bl, sw.t_hi, sw.t_cls, sw.st_head, sw.st_tail})
+				HIP_CHECK(hipMemsetAsync(p, 0xFF, T * 4, s));
+			HIP_CHECK(hipMemsetAsync(sw.ctr, 0xFF, z.nS * 4, s));
+			HIP_CHECK(hipMemsetAsync(sw.cur, 0, z.nS * 4, s));
+			HIP_CHECK(hipMemsetAsync(sw.selfloop, 0, g.V, s));
+			HIP_CHECK(hipMemsetAsync(sw.last, 0xFF, (B + T) * 4, s));
+			HIP_CHECK(hipMemsetAsync(sw.in_s, 0, B + T, s));
+		};
 		tm.begin("traversal_init");
-		HIP_CHECK(hipMemsetAsync(sw.first_child, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.o_head, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.i_head, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.bl, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.t_hi, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.t_cls, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.st_head, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.st_tail, 0xFF, T * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.ctr, 0xFF, z.nS * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.cur, 0, z.nS * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.selfloop, 0, g.V, s));
-		HIP_CHECK(hipMemsetAsync(sw.last, 0xFF, (B + T) * 4, s));
-		HIP_CHECK(hipMemsetAsync(sw.in_s, 0, B + T, s));
-		for (uint32_t *p : {sw.c_ntree, sw.c_nbe0, sw.c_nbe, sw.c_nstack, sw.c_npvst, sw.c_nclass, sw.c_nbry, sw.c_status})
-			HIP_CHECK(hipMemsetAsync(p, 0, (size_t)(C + 1) * 4, s));
-		tm.end(15);
+		zero_component_counters(sw, C, s);
+		if (all_seq)
+			init_seq_workspace();
+		tm.end(all_seq ? 14 : 1);
 		sw.comp_sel = nullptr;
 		ctx->last_seq_redo = 0;
 		if (all_seq) {
@@ -403,22 +405,24 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			tm.end(1);
 		} else {
 			int64_t dense_nb0 = -1;
+			HIP_CHECK(hipMemsetAsync(ctx->pw.err, 0, 64, s));
 			if (o.flags & POVU_HIP_F_SEQ_TREE) {
+				init_seq_workspace();
 				tm.begin("tree_seq");
 				sw.stages = SEQ_STAGE_TREE;
 				launch_seq_components(sw, s);
 				tm.end(1);
 			} else {
 				std::vector<uint32_t> cproc(C + 1, 0);
-				uint32_t max_nv = 1;
+				uint32_t event_lists = 0;
 				for (uint32_t c = 0; c < C; c++) {
 					const uint32_t nv = voff[c + 1] - voff[c];
-					max_nv = std::max(max_nv, nv);
 					cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
+					event_lists += cproc[c] ? 1u : 2 * nv;
 				}
 				HIP_CHECK(hipMemcpyAsync(ctx->tw.cproc, cproc.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
 				HIP_CHECK(hipStreamSynchronize(s));
-				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, max_nv, tm, s);
+				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, tm, s);
 			}
 			uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
 			if (o.flags & POVU_HIP_F_FORCE_REDO) {
@@ -428,8 +432,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			ctx->last_seq_redo = nbad;
 			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
 				tm.begin("redo_seq");
-				if (dense_nb0 >= 0) // the per-class DFS used the scan cursors
-					HIP_CHECK(hipMemsetAsync(sw.cur, 0, z.nS * 4, s));
+				if (dense_nb0 >= 0) // parallel tree: the one-lane kernels start from scratch
+					init_seq_workspace();
 				sw.stages = dense_nb0 >= 0 ? SEQ_STAGE_ALL : (SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST);
 				sw.comp_sel = ctx->pw.comp_bad;
 				launch_seq_components(sw, s);

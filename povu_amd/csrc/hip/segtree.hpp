@@ -14,29 +14,60 @@ namespace povu_hip
 #define SEG_TPB 256
 #endif
 // ------------------------------------------------------------- segment tree
-static __global__ void k_seg_leaves(uint32_t P, uint32_t n, const uint32_t *__restrict__ val, uint32_t *__restrict__ tree)
+// bottom kernel: a block stages 2*SEG_TPB leaves in LDS and writes that subtree's levels;
+// top kernel: one block finishes the remaining (few thousand) nodes.
+static __global__ void __launch_bounds__(SEG_TPB) k_seg_bottom(uint32_t P, uint32_t n, const uint32_t *__restrict__ val,
+							       uint32_t *__restrict__ tree)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < P)
-		tree[P + i] = i < n ? val[i] : NIL;
+	__shared__ uint32_t sh[2 * SEG_TPB];
+	const uint32_t W = 2 * SEG_TPB; // leaves per block
+	const uint32_t base = blockIdx.x * W;
+	for (uint32_t k = threadIdx.x; k < W; k += SEG_TPB) {
+		uint32_t i = base + k;
+		uint32_t v = (i < n) ? val[i] : NIL;
+		sh[k] = v;
+		if (i < P)
+			tree[P + i] = v;
+	}
+	__syncthreads();
+	// level with `w` nodes inside this block, global node index = (P/(W/w)) + blockIdx*w + k
+	uint32_t lvlP = P;
+	for (uint32_t w = W / 2; w >= 1; w >>= 1) {
+		lvlP >>= 1;
+		if (lvlP == 0)
+			break;
+		uint32_t a = 0;
+		if (threadIdx.x < w)
+			a = min(sh[2 * threadIdx.x], sh[2 * threadIdx.x + 1]);
+		__syncthreads();
+		if (threadIdx.x < w) {
+			sh[threadIdx.x] = a;
+			uint32_t node = lvlP + blockIdx.x * w + threadIdx.x;
+			if (blockIdx.x * w + threadIdx.x < lvlP)
+				tree[node] = a;
+		}
+		__syncthreads();
+	}
 }
-static __global__ void k_seg_level(uint32_t first, uint32_t count, uint32_t *tree)
+static __global__ void __launch_bounds__(1024) k_seg_top(uint32_t top_nodes, uint32_t *tree)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < count) {
-		uint32_t k = first + i;
-		tree[k] = min(tree[2 * k], tree[2 * k + 1]);
+	// nodes [1, top_nodes) ; level by level from the bottom (top_nodes is a power of two)
+	for (uint32_t first = top_nodes / 2; first >= 1; first >>= 1) {
+		for (uint32_t k = first + threadIdx.x; k < 2 * first; k += blockDim.x)
+			tree[k] = min(tree[2 * k], tree[2 * k + 1]);
+		__syncthreads();
+		if (first == 1)
+			break;
 	}
 }
 static void seg_build(SegTree &st, const uint32_t *val, size_t n, hipStream_t s)
 {
 	st.P = SegTree::pow2(std::max<size_t>(n, 1));
-	hipLaunchKernelGGL(k_seg_leaves, dim3((st.P + SEG_TPB - 1) / SEG_TPB), dim3(SEG_TPB), 0, s, st.P, (uint32_t)n, val, st.tree);
-	for (uint32_t first = st.P / 2; first >= 1; first /= 2) {
-		hipLaunchKernelGGL(k_seg_level, dim3((first + SEG_TPB - 1) / SEG_TPB), dim3(SEG_TPB), 0, s, first, first, st.tree);
-		if (first == 1)
-			break;
-	}
+	const uint32_t W = 2 * SEG_TPB;
+	const uint32_t blocks = (st.P + W - 1) / W;
+	hipLaunchKernelGGL(k_seg_bottom, dim3(blocks), dim3(SEG_TPB), 0, s, st.P, (uint32_t)n, val, st.tree);
+	if (st.P > W) // levels above the per-block subtrees: nodes [1, P/W)
+		hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, s, st.P / W, st.tree);
 }
 
 __device__ __forceinline__ uint32_t seg_min(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r)

@@ -60,5 +60,7 @@ struct SeqWs {
 __host__ __device__ inline uint64_t seq_toff(const uint32_t *voff, uint32_t c) { return 2ull * voff[c] + c; }
 
 void launch_seq_components(const SeqWs &ws, hipStream_t s);
+// zeroes the eight per-component result arrays (one launch)
+void zero_component_counters(const SeqWs &ws, uint32_t C, hipStream_t s);
 
 } // namespace povu_hip

@@ -114,10 +114,10 @@ __global__ void k_tour_cut(uint32_t C, const uint32_t *__restrict__ voff, const 
 // one round of pointer jumping with two accumulators (suffix sums along the list)
 __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const uint32_t *__restrict__ a_in,
 			 const uint32_t *__restrict__ b_in, uint32_t *__restrict__ nxt_out, uint32_t *__restrict__ a_out,
-			 uint32_t *__restrict__ b_out)
+			 uint32_t *__restrict__ b_out, const uint32_t *__restrict__ n_dev)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
+	if (i >= n || (n_dev && i >= *n_dev))
 		return;
 	uint32_t nx = nxt_in[i], a = a_in[i], b = b_in ? b_in[i] : 0;
 	if (nx != NIL) {
@@ -133,17 +133,135 @@ __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const 
 }
 // runs `rounds` rounds; returns which buffer set (0 = A, 1 = B) holds the result
 static int list_rank(uint32_t n, unsigned rounds, uint32_t *nxtA, uint32_t *nxtB, uint32_t *aA, uint32_t *aB, uint32_t *bA,
-		     uint32_t *bB, hipStream_t s)
+		     uint32_t *bB, hipStream_t s, const uint32_t *n_dev = nullptr)
 {
 	int cur = 0;
 	for (unsigned r = 0; r < rounds; r++) {
 		if (cur == 0)
-			LAUNCH(k_wyllie, n, s, n, nxtA, aA, bA, nxtB, aB, bB);
+			LAUNCH(k_wyllie, n, s, n, nxtA, aA, bA, nxtB, aB, bB, n_dev);
 		else
-			LAUNCH(k_wyllie, n, s, n, nxtB, aB, bB, nxtA, aA, bA);
+			LAUNCH(k_wyllie, n, s, n, nxtB, aB, bB, nxtA, aA, bA, n_dev);
 		cur ^= 1;
 	}
 	return cur;
+}
+
+// ---- work-efficient list ranking: random splitters cut every list into short segments, each
+// splitter walks its segment (sums), the splitter list is ranked by pointer jumping, a second walk
+// hands every element its suffix sum.  Heads (elements nobody points to) are forced splitters.
+static constexpr uint32_t SPLIT_SHIFT = 29; // 1 element in 8 is a random splitter
+static constexpr uint32_t PK_END = 0x1FFFFFFFu;
+__device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
+
+__global__ void k_rank_has_pred(uint32_t n, const uint32_t *__restrict__ nxt, uint32_t *__restrict__ has_pred)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && nxt[i] != NIL)
+		has_pred[nxt[i]] = 1;
+}
+__global__ void k_rank_flags(uint32_t n, const uint32_t *__restrict__ has_pred, uint32_t *__restrict__ flag)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+		flag[i] = (!has_pred[i] || is_random_splitter(i)) ? 1u : 0u;
+}
+// one word per element so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
+// bit 29 = the element's 0/1 weight, bit 31 = stop after this element (successor is a splitter / end)
+__global__ void k_rank_pack(uint32_t n, const uint32_t *__restrict__ nxt, const uint32_t *__restrict__ w1,
+			    const uint32_t *__restrict__ flag, uint32_t *__restrict__ pk)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	uint32_t nx = nxt[i];
+	uint32_t w = nx == NIL ? PK_END : nx;
+	w |= (w1[i] & 1u) << 29;
+	if (nx == NIL || flag[nx])
+		w |= 0x80000000u;
+	pk[i] = w;
+}
+// TWO: second weight = +1 where the first is 1, -1 where it is 0 (enter / leave events)
+template <bool TWO>
+__global__ void k_rank_walk1(uint32_t n, const uint32_t *__restrict__ pk, const uint32_t *__restrict__ flag,
+			     const uint32_t *__restrict__ ps, uint32_t m_cap, uint32_t *__restrict__ sp_next,
+			     uint32_t *__restrict__ sp_a, uint32_t *__restrict__ sp_b, uint32_t *__restrict__ err)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || !flag[i])
+		return;
+	uint32_t sid = ps[i];
+	if (sid >= m_cap) {
+		atomicAdd(err, 1u);
+		return;
+	}
+	uint32_t a = 0, b = 0, x = i, p;
+	do {
+		p = pk[x];
+		uint32_t w = (p >> 29) & 1u;
+		a += w;
+		if (TWO)
+			b += w ? 1u : 0xFFFFFFFFu;
+		x = p & PK_END;
+	} while (!(p >> 31));
+	uint32_t nx = x == PK_END ? NIL : ps[x];
+	sp_next[sid] = (nx != NIL && nx >= m_cap) ? NIL : nx;
+	sp_a[sid] = a;
+	if (TWO)
+		sp_b[sid] = b;
+}
+template <bool TWO>
+__global__ void k_rank_walk2(uint32_t n, const uint32_t *__restrict__ pk, const uint32_t *__restrict__ flag,
+			     const uint32_t *__restrict__ ps, uint32_t m_cap, const uint32_t *__restrict__ sp_a,
+			     const uint32_t *__restrict__ sp_b, uint32_t *__restrict__ out1, uint32_t *__restrict__ out2)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || !flag[i])
+		return;
+	uint32_t sid = ps[i];
+	if (sid >= m_cap)
+		return;
+	uint32_t a = sp_a[sid], b = TWO ? sp_b[sid] : 0, x = i, p;
+	do {
+		p = pk[x];
+		uint32_t w = (p >> 29) & 1u;
+		out1[x] = a;
+		a -= w;
+		if (TWO) {
+			out2[x] = b;
+			b -= w ? 1u : 0xFFFFFFFFu;
+		}
+		x = p & PK_END;
+	} while (!(p >> 31));
+}
+
+struct RankBufs {
+	uint32_t *has_pred, *flag, *ps;		       // [n+1]
+	uint32_t *nA, *nB, *aA, *aB, *bA, *bB;	       // [m_cap] splitter list ping-pong
+	uint32_t *err;
+	void *scan_tmp;
+	size_t scan_tmp_bytes;
+};
+// suffix sums (inclusive) along the lists given by nxt: out1 of the 0/1 weights w1 and, when TWO,
+// out2 of the +-1 weights derived from them
+template <bool TWO>
+static void list_rank_splitters(uint32_t n, const uint32_t *nxt, const uint32_t *w1, uint32_t *out1, uint32_t *out2,
+				uint32_t max_heads, RankBufs &rb, hipStream_t s)
+{
+	if (n >= PK_END)
+		throw HipError("list ranking: more than 2^29 elements (graph too large for the packed walk)");
+	const uint32_t m_cap = n / 4 + max_heads + 4096; // expected n/8 random splitters + the heads
+	HIP_CHECK(hipMemsetAsync(rb.has_pred, 0, ((size_t)n + 1) * 4, s));
+	LAUNCH(k_rank_has_pred, n, s, n, nxt, rb.has_pred);
+	LAUNCH(k_rank_flags, n, s, n, rb.has_pred, rb.flag);
+	HIP_CHECK(hipMemsetAsync(rb.flag + n, 0, 4, s));
+	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
+	uint32_t *pk = rb.has_pred; // has_pred is dead once the flags exist
+	LAUNCH(k_rank_pack, n, s, n, nxt, w1, rb.flag, pk);
+	LAUNCH(k_rank_walk1<TWO>, n, s, n, pk, rb.flag, rb.ps, m_cap, rb.nA, rb.aA, rb.bA, rb.err);
+	const unsigned rounds = bits_for(m_cap) + 1;
+	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s,
+			     rb.ps + n);
+	LAUNCH(k_rank_walk2<TWO>, n, s, n, pk, rb.flag, rb.ps, m_cap, side ? rb.aB : rb.aA, side ? rb.bB : rb.bA, out1, out2);
 }
 
 // ------------------------------------------------------------------ 2. rooted forest T0
@@ -545,6 +663,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.ckey, nS * 8);
 	take((void **)&tw.ckey2, nS * 8);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
+	for (uint32_t **p : {&tw.rk_has_pred, &tw.rk_flag, &tw.rk_ps})
+		take((void **)p, NA * 4);
+	for (uint32_t **p : {&tw.rk_nA, &tw.rk_nB, &tw.rk_aA, &tw.rk_aB, &tw.rk_bA, &tw.rk_bB})
+		take((void **)p, (NA / 4 + nS + 8192) * 4);
 	take((void **)&tw.segLo.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
 	take((void **)&tw.segHi.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
 }
@@ -571,7 +693,7 @@ static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
 }
 
 // ------------------------------------------------------------------ driver
-uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t max_nv,
+uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = sw.V, E = sw.E, nS = 2 * V;
@@ -579,7 +701,6 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		scan_exclusive_u32(in, out, n, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	};
 	const unsigned long long *start_key = (const unsigned long long *)cs.start_key;
-	const unsigned rounds = bits_for(4ull * max_nv + 4) + 1;
 
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
@@ -596,15 +717,17 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_arc_positions, NA, s, NA, tw.k2, tw.v2, tw.apos, tw.afirst, tw.alast);
 	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, tw.afirst, tw.alast, tw.nxtA, tw.cntA);
 	LAUNCH(k_tour_cut, C, s, C, cs.voff, start_key, tw.v2, tw.alast, tw.nxtA, tw.cntA);
-	int side = list_rank(NA, rounds, tw.nxtA, tw.nxtB, tw.cntA, tw.cntB, nullptr, nullptr, s);
-	const uint32_t *dist = side ? tw.cntB : tw.cntA;
+	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
+		    pw.scan_tmp, pw.scan_tmp_bytes};
+	list_rank_splitters<false>(NA, tw.nxtA, tw.cntA, tw.cntB, nullptr, C, rb, s);
+	const uint32_t *dist = tw.cntB;
 	LAUNCH(k_t0_parents, NA, s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0, tw.pe_le0,
 	       tw.tourflag);
 	HIP_CHECK(hipMemsetAsync(tw.tourflag + NA, 0, 4, s));
 	scan(tw.tourflag, tw.tour_ps, (size_t)NA + 1);
 	LAUNCH(k_t0_roots, C, s, C, cs.voff, start_key, tw.par0, tw.size0, tw.P0);
 	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, tw.arc_dst, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
-	tm.end(12 + rounds);
+	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
@@ -639,9 +762,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	fill_u32(tw.fc, nS, NIL, s);
 	LAUNCH(k_child_links, nS, s, nS, (const unsigned long long *)tw.ckey2, tw.cval2, tw.fc, tw.nsib);
 	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA);
-	side = list_rank(2 * nS, rounds, tw.nxtA, tw.nxtB, tw.cntA, tw.cntB, tw.depA, tw.depB, s);
-	const uint32_t *cnt = side ? tw.cntB : tw.cntA, *dep = side ? tw.depB : tw.depA;
-	tm.end(5 + rounds);
+	// one list per processed component, one two-event list per side of an unprocessed one
+	list_rank_splitters<true>(2 * nS, tw.nxtA, tw.cntA, tw.cntB, tw.depB, event_lists, rb, s);
+	const uint32_t *cnt = tw.cntB, *dep = tw.depB;
+	tm.end(40);
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");

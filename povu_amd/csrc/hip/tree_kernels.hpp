@@ -25,6 +25,7 @@ struct TreeWs {
 	uint32_t *cval, *cval2, *fc, *nsib;		  // [2V]
 	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]
 	uint32_t *be_cnt, *be_ps;			  // [2V+1]
+	uint32_t *rk_has_pred, *rk_flag, *rk_ps, *rk_nA, *rk_nB, *rk_aA, *rk_aB, *rk_bA, *rk_bB; // splitter list ranking
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
 	SegTree segLo, segHi;
 };
@@ -34,7 +35,7 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax);
 
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.
-uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t max_nv,
+uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   StageTimer &tm, hipStream_t s);
 
 } // namespace povu_hip
