@@ -360,6 +360,24 @@ __global__ void k_local_slots(uint32_t n, const uint32_t *__restrict__ origin, c
 	lle[k] = le;
 }
 
+__global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *out)
+{
+	__shared__ uint32_t sh[4];
+	uint32_t m = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		m = max(m, v[i]);
+	for (int off = 32; off; off >>= 1)
+		m = max(m, __shfl_down(m, off));
+	if ((threadIdx.x & 63) == 0)
+		sh[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+		if (m > *(volatile uint32_t *)out) // few blocks ever need the atomic
+			atomicMax(out, m);
+	}
+}
+
 __global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ sbase,
 				    const uint32_t *__restrict__ erank, uint32_t *__restrict__ eoff)
 {
@@ -422,7 +440,6 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 		sort_pairs_u32(keys, keys2, vals, g.eperm, E, bits_for(V), stmp, sb, s);
 		uint32_t *xflag = keys, *xps = vals; // reuse (2E+1 entries each)
 		hipLaunchKernelGGL(k_edge_sorted, dim3(nblk(E)), dim3(TPB), 0, s, E, g.eperm, g.v1, g.v2, g.e_lo, g.e_hi, xflag);
-		HIP_CHECK(hipMemsetAsync(xflag + E, 0, 4, s));
 		scan_exclusive_u32(xflag, xps, (size_t)E + 1, ctmp, cb, s);
 		hipLaunchKernelGGL(k_compact_pos, dim3(nblk(E)), dim3(TPB), 0, s, E, xflag, xps, g.xlist);
 		HIP_CHECK(hipMemcpyAsync(&g.n_cross, xps + E, 4, hipMemcpyDeviceToHost, s));
@@ -440,7 +457,6 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 		hipLaunchKernelGGL(k_uf_cross, dim3(nblk(g.n_cross)), dim3(TPB), 0, s, g.n_cross, g.xlist, g.e_lo, g.e_hi, g.eperm,
 				   st.label, st.hook);
 	hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
-	HIP_CHECK(hipMemsetAsync(st.flag + V, 0, 4, s));
 	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(4);
 	uint32_t C = 0;
@@ -463,7 +479,6 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			   (unsigned long long *)st.start_key, ~0ull);
 	hipLaunchKernelGGL(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
 			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key);
-	HIP_CHECK(hipMemsetAsync(st.vdeg + V, 0, 4, s));
 	scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	launches += 5;
 	// first-encounter rank of every edge
@@ -479,6 +494,8 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			   st.tgray);
 	hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
 			   st.eoff);
+	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
+	hipLaunchKernelGGL(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	// local per-side adjacency (other side ids), ascending local edge idx
 	sort_pairs_u32(st.keys, st.keys2, st.vals, st.vals2, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);

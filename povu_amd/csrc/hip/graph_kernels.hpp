@@ -34,6 +34,7 @@ struct CompState {
 	uint32_t *la, *lb; // [E]  sorted side ids of local edge le (la = first-encounter side)
 	uint32_t *lle;	   // [2E] local edge idx of every adjacency slot
 	uint32_t *tgray;   // [E+1] local edge is in the spanning forest
+	uint32_t *stats;   // [4]  stats[0] = max links on one side
 	uint32_t *gid_s;
 	uint8_t *tip_s;
 	uint64_t *start_key; // [C+1] (segment id << 32 | sorted side) of the smallest tip, ~0 if none

@@ -188,25 +188,15 @@ __global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uin
 	uint32_t r = t_root[v];
 	mpre[v] = r + depth[v] + c_ntree[t_comp[v]] - (v - r) - sz;
 }
-// sort key of a bracket: (mirror pre-order of its source) then, inside one source, the later pushed
-// first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643)
-__global__ void k_bracket_keys_ord(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ mpre,
-				   unsigned long long *__restrict__ key, uint32_t *__restrict__ val,
-				   uint32_t *__restrict__ incnt, const uint32_t *__restrict__ b_tgt)
-{
-	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= NB0)
-		return;
-	key[j] = ((unsigned long long)mpre[b_src[j]] << 32) | (unsigned long long)(0xFFFFFFFFu - j);
-	val[j] = j;
-	atomicAdd(&incnt[b_tgt[j]], 1u);
-}
-__global__ void k_bracket_keys_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ capf,
-				     const uint32_t *__restrict__ pscap, const uint32_t *__restrict__ simp,
-				     const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
-				     const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ mpre,
-				     unsigned long long *__restrict__ key, uint32_t *__restrict__ val,
-				     uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt, uint32_t *__restrict__ incnt)
+// Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
+// first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
+// The brackets are laid out in an initial order that already satisfies the second criterion
+// (simplifying | capping | ordinary by DESCENDING dense idx), so ONE stable 32-bit radix sort by the
+// source's mirror pre-order yields the list order.
+__global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ capf,
+				const uint32_t *__restrict__ pscap, const uint32_t *__restrict__ simp,
+				const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
+				const uint32_t *__restrict__ t_root, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
@@ -215,18 +205,33 @@ __global__ void k_bracket_keys_extra(uint32_t T, uint32_t NB0, uint32_t ncap, co
 		uint32_t j = NB0 + pscap[v];
 		b_src[j] = v;
 		b_tgt[j] = cap_tgt[v];
-		key[j] = ((unsigned long long)mpre[v] << 32) | (unsigned long long)(0xFFFFFFFFu - 0x80000000u);
-		val[j] = j;
-		atomicAdd(&incnt[cap_tgt[v]], 1u);
 	}
 	if (simp[v]) {
 		uint32_t j = NB0 + ncap + pssimp[v];
 		b_src[j] = v;
 		b_tgt[j] = t_root[v];
-		key[j] = ((unsigned long long)mpre[v] << 32) | (unsigned long long)(0xFFFFFFFFu - 0x80000001u);
-		val[j] = j;
-		atomicAdd(&incnt[t_root[v]], 1u);
 	}
+}
+__global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32_t nsimp, const uint32_t *__restrict__ b_src,
+				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ mpre,
+				uint32_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t *__restrict__ incnt,
+				uint32_t *__restrict__ srccnt)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= NB)
+		return;
+	uint32_t j;
+	if (q < nsimp)
+		j = NB0 + ncap + q;
+	else if (q < nsimp + ncap)
+		j = NB0 + (q - nsimp);
+	else
+		j = NB0 - 1 - (q - nsimp - ncap);
+	uint32_t m = mpre[b_src[j]];
+	key[q] = m;
+	val[q] = j;
+	atomicAdd(&incnt[b_tgt[j]], 1u);
+	atomicAdd(&srccnt[m], 1u); // brackets per mirror pre-order position -> range starts
 }
 __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src,
 			     uint32_t *__restrict__ dst)
@@ -235,74 +240,65 @@ __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const
 	if (i < n)
 		dst[i] = src[idx[i]];
 }
-__device__ __forceinline__ uint32_t lower_bound_hi32(const unsigned long long *__restrict__ key, uint32_t n, uint32_t x)
-{
-	uint32_t lo = 0, hi = n; // first i with (key[i] >> 32) >= x
-	while (lo < hi) {
-		uint32_t mid = (lo + hi) >> 1;
-		if ((uint32_t)(key[mid] >> 32) < x)
-			lo = mid + 1;
-		else
-			hi = mid;
-	}
-	return lo;
-}
 // top bracket and bracket-list size at v when the class of tree edge (parent(v), v) is decided
 // (flubbles.cpp:664-686): the live brackets are those with source in subtree(v) and target a
-// proper ancestor of v; in list order they are a contiguous key range, the top is the first live one.
-__global__ void k_top_bracket(uint32_t T, uint32_t NB, const uint32_t *__restrict__ gsize,
-			      const uint32_t *__restrict__ gpar, const uint32_t *__restrict__ mpre,
-			      const unsigned long long *__restrict__ rkey, const uint32_t *__restrict__ segB, uint32_t P,
-			      const uint32_t *__restrict__ psin, unsigned long long *__restrict__ ckey,
-			      uint32_t *__restrict__ cval, uint32_t *__restrict__ lsz, uint32_t *__restrict__ err)
+// proper ancestor of v; in list order they are the contiguous range [bstart[mpre(v)],
+// bstart[mpre(v)+size(v)]), the top is the first live one.  Output in DESCENDING v order so that a
+// stable sort by top bracket leaves every group ordered from the deepest vertex up.
+__global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+			      const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
+			      const uint32_t *__restrict__ segB, uint32_t P, const uint32_t *__restrict__ psin,
+			      uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval, uint32_t *__restrict__ lsz,
+			      uint32_t *__restrict__ err)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
 		return;
-	cval[v] = v;
+	const uint32_t q = T - 1 - v;
+	cval[q] = v;
 	uint32_t sz = gsize[v];
 	if (sz == 0 || gpar[v] == NIL) {
-		ckey[v] = ~0ull;
+		ckey[q] = NIL;
 		lsz[v] = 0;
 		return;
 	}
 	uint32_t m = mpre[v];
-	uint32_t lo = lower_bound_hi32(rkey, NB, m), hi = lower_bound_hi32(rkey, NB, m + sz);
+	uint32_t lo = bstart[m], hi = bstart[m + sz];
 	uint32_t i = seg_first_less(segB, P, lo, hi, v);
 	if (i == NIL) {
 		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
-		ckey[v] = ~0ull;
+		ckey[q] = NIL;
 		lsz[v] = 0;
 		return;
 	}
 	lsz[v] = (hi - lo) - (psin[v + sz] - psin[v]);
-	// same top bracket => same group; inside a group the pass runs from the deepest vertex up
-	ckey[v] = ((unsigned long long)i << 32) | (unsigned long long)(0xFFFFFFFFu - v);
+	ckey[q] = i;
 }
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
-__global__ void k_class_flags(uint32_t T, const unsigned long long *__restrict__ skey, const uint32_t *__restrict__ sval,
+__global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 			      const uint32_t *__restrict__ lsz, uint32_t *__restrict__ flag)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
 		return;
-	unsigned long long k = skey[q];
-	if (k == ~0ull) {
+	uint32_t k = skey[q];
+	if (k == NIL) {
 		flag[q] = 0;
 		return;
 	}
-	bool fresh = q == 0 || (uint32_t)(skey[q - 1] >> 32) != (uint32_t)(k >> 32) || lsz[sval[q - 1]] != lsz[sval[q]];
+	bool fresh = q == 0 || skey[q - 1] != k || lsz[sval[q - 1]] != lsz[sval[q]];
 	flag[q] = fresh ? 1u : 0u;
+	(void)mask;
 }
-__global__ void k_class_scatter(uint32_t T, const unsigned long long *__restrict__ skey, const uint32_t *__restrict__ sval,
+__global__ void k_class_scatter(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 				const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 				uint32_t *__restrict__ gcls)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
 		return;
-	if (skey[q] == ~0ull)
+	if (skey[q] == NIL)
 		gcls[sval[q]] = NIL;
 	else
 		gcls[sval[q]] = ps[q] + flag[q] - 1; // inclusive scan - 1
@@ -582,7 +578,6 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
 		NB0 = (uint32_t)dense_nb0;
 	} else {
-		HIP_CHECK(hipMemsetAsync(sw.c_nbe0 + C, 0, 4, s));
 		scan(sw.c_nbe0, pw.dbo, (size_t)C + 1);
 		NB0 = read_u32(pw.dbo + C, s);
 		LAUNCH(k_dense_be, NB0, s, NB0, C, pw.dbo, cs.voff, cs.eoff, sw.be_src, sw.be_tgt, pw.b_src, pw.b_tgt);
@@ -597,12 +592,9 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	seg_build(pw.segA, pw.hi0, T, s);
 	uint32_t *bridge = pw.flagA, *psb = pw.psA, *simp = pw.flagB, *pssimp = pw.psB, *capf = pw.flagC, *pscap = pw.psC;
 	LAUNCH(k_hiA, T, s, T, pw.gsize, pw.gpar, pw.segA.tree, pw.segA.P, pw.hiA, bridge);
-	HIP_CHECK(hipMemsetAsync(bridge + T, 0, 4, s));
 	scan(bridge, psb, (size_t)T + 1);
 	LAUNCH(k_hi_simp, T, s, T, pw.gsize, pw.hiA, bridge, psb, pw.t_root, pw.hi, simp);
 	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi, pw.hi0, pw.cap_tgt, capf);
-	HIP_CHECK(hipMemsetAsync(simp + T, 0, 4, s));
-	HIP_CHECK(hipMemsetAsync(capf + T, 0, 4, s));
 	scan(simp, pssimp, (size_t)T + 1);
 	scan(capf, pscap, (size_t)T + 1);
 	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre);
@@ -612,22 +604,25 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
 	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)T + 2) * 4, s));
-	LAUNCH(k_bracket_keys_ord, NB0, s, NB0, pw.b_src, pw.mpre, (unsigned long long *)pw.b_key, pw.b_val, pw.incnt,
-	       pw.b_tgt);
-	LAUNCH(k_bracket_keys_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.mpre,
-	       (unsigned long long *)pw.b_key, pw.b_val, pw.b_src, pw.b_tgt, pw.incnt);
+	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
+	HIP_CHECK(hipMemsetAsync(srccnt, 0, ((size_t)T + 2) * 4, s));
+	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt);
+	uint32_t *bk = (uint32_t *)pw.b_key, *bk2 = (uint32_t *)pw.b_key2;
+	LAUNCH(k_bracket_order, NB, s, NB, NB0, ncap, nsimp, pw.b_src, pw.b_tgt, pw.mpre, bk, pw.b_val, pw.incnt, srccnt);
 	scan(pw.incnt, pw.psin, (size_t)T + 1);
-	sort_pairs_u64(pw.b_key, pw.b_key2, pw.b_val, pw.b_val2, NB, 64, pw.sort_tmp, pw.sort_tmp_bytes, s);
+	scan(srccnt, bstart, (size_t)T + 1);
+	sort_pairs_u32(bk, bk2, pw.b_val, pw.b_val2, NB, bits_for(T), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
 	seg_build(pw.segB, pw.tgtR, NB, s);
-	LAUNCH(k_top_bracket, T, s, T, NB, pw.gsize, pw.gpar, pw.mpre, (const unsigned long long *)pw.b_key2,
-	       pw.segB.tree, pw.segB.P, pw.psin, (unsigned long long *)pw.keys_t, pw.vals_t, pw.lsz, pw.err);
-	sort_pairs_u64(pw.keys_t, pw.keys_t2, pw.vals_t, pw.vals_t2, T, 64, pw.sort_tmp, pw.sort_tmp_bytes, s);
+	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
+	LAUNCH(k_top_bracket, T, s, T, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.psin, ck, pw.vals_t,
+	       pw.lsz, pw.err);
+	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, T, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
+	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 	uint32_t *cflag = pw.flagA, *cps = pw.psA; // bridge flags are dead by now
-	LAUNCH(k_class_flags, T, s, T, (const unsigned long long *)pw.keys_t2, pw.vals_t2, pw.lsz, cflag);
-	HIP_CHECK(hipMemsetAsync(cflag + T, 0, 4, s));
+	LAUNCH(k_class_flags, T, s, T, 0u, ck2, pw.vals_t2, pw.lsz, cflag);
 	scan(cflag, cps, (size_t)T + 1);
-	LAUNCH(k_class_scatter, T, s, T, (const unsigned long long *)pw.keys_t2, pw.vals_t2, cflag, cps, pw.gcls);
+	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls);
 	LAUNCH(k_export_cls, T, s, T, pw.gcls, sw.t_cls);
 	launches = 30 + 2 * 22;
 	tm.end(launches);
@@ -640,7 +635,6 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.inv);
 	uint32_t *bflag = pw.flagB, *bps = pw.psB;
 	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
-	HIP_CHECK(hipMemsetAsync(bflag + T, 0, 4, s));
 	scan(bflag, bps, (size_t)T + 1);
 	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.s_val);
 	LAUNCH(k_stack_offsets, (size_t)C + 1, s, C, cs.voff, bps, T, pw.soff);
@@ -661,7 +655,6 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_laminar, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.comp_bad);
 	uint32_t *dflag = pw.s_key; // scratch
 	LAUNCH(k_walk, S, s, S, pw.prev, pw.ns, pw.walk, dflag);
-	HIP_CHECK(hipMemsetAsync(dflag + S, 0, 4, s));
 	scan(dflag, pw.erank, (size_t)S + 1);
 	scan(pw.walk, pw.walk_ps, (size_t)2 * S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive

@@ -217,6 +217,7 @@ size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool
 	take(&cs.lb, E + 2, 4);
 	take(&cs.lle, 2 * E + 2, 4);
 	take(&cs.tgray, E + 2, 4);
+	take(&cs.stats, 16, 4);
 	take(&cs.gid_s, V + 1, 4);
 	take(&cs.tip_s, V + 1, 1);
 	take(&cs.start_key, C + 2, 8);
@@ -342,6 +343,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		std::vector<uint32_t> voff(C + 1), eoff(C + 1);
 		HIP_CHECK(hipMemcpyAsync(voff.data(), cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipMemcpyAsync(eoff.data(), cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		uint32_t gstats[4] = {0, 0, 0, 0};
+		HIP_CHECK(hipMemcpyAsync(gstats, cs.stats, 16, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		std::vector<uint32_t> order(C), owner(C, 0);
 		std::iota(order.begin(), order.end(), 0u);
@@ -422,7 +425,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				}
 				HIP_CHECK(hipMemcpyAsync(ctx->tw.cproc, cproc.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
 				HIP_CHECK(hipStreamSynchronize(s));
-				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, tm, s);
+				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0], tm, s);
 			}
 			uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
 			if (o.flags & POVU_HIP_F_FORCE_REDO) {

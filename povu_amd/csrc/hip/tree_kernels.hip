@@ -253,7 +253,6 @@ static void list_rank_splitters(uint32_t n, const uint32_t *nxt, const uint32_t 
 	HIP_CHECK(hipMemsetAsync(rb.has_pred, 0, ((size_t)n + 1) * 4, s));
 	LAUNCH(k_rank_has_pred, n, s, n, nxt, rb.has_pred);
 	LAUNCH(k_rank_flags, n, s, n, rb.has_pred, rb.flag);
-	HIP_CHECK(hipMemsetAsync(rb.flag + n, 0, 4, s));
 	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
 	uint32_t *pk = rb.has_pred; // has_pred is dead once the flags exist
 	LAUNCH(k_rank_pack, n, s, n, nxt, w1, rb.flag, pk);
@@ -490,32 +489,38 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 }
 
 // ------------------------------------------------------------------ 7. pre-order of the union tree
-__global__ void k_child_keys(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
-			     unsigned long long *__restrict__ key, uint32_t *__restrict__ val)
+// children of every side ordered by the parent's scan slot: LSD = two stable 32-bit radix sorts,
+// by slot first (a few bits), then by parent (roots / unprocessed sides carry NIL and end up last)
+__global__ void k_child_keys(uint32_t nS, const uint32_t *__restrict__ cslot, uint32_t *__restrict__ key,
+			     uint32_t *__restrict__ val)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	uint32_t p = dpar[S];
-	key[S] = p == NIL ? ~0ull : (((unsigned long long)p << 32) | cslot[S]);
+	key[S] = cslot[S];
 	val[S] = S;
 }
-__global__ void k_child_links(uint32_t nS, const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val,
+__global__ void k_gather_parent(uint32_t nS, const uint32_t *__restrict__ val, const uint32_t *__restrict__ dpar,
+				uint32_t *__restrict__ key)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < nS)
+		key[q] = dpar[val[q]];
+}
+__global__ void k_child_links(uint32_t nS, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
 			      uint32_t *__restrict__ fc, uint32_t *__restrict__ nsib)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= nS)
 		return;
-	unsigned long long k = key[q];
-	uint32_t S = val[q];
-	if (k == ~0ull) {
+	uint32_t p = key[q], S = val[q];
+	if (p == NIL) {
 		nsib[S] = NIL;
 		return;
 	}
-	uint32_t p = (uint32_t)(k >> 32);
-	if (q == 0 || (uint32_t)(key[q - 1] >> 32) != p)
+	if (q == 0 || key[q - 1] != p)
 		fc[p] = S;
-	nsib[S] = (q + 1 < nS && key[q + 1] != ~0ull && (uint32_t)(key[q + 1] >> 32) == p) ? val[q + 1] : NIL;
+	nsib[S] = (q + 1 < nS && key[q + 1] == p) ? val[q + 1] : NIL;
 }
 // events: 2S = enter S, 2S+1 = leave S
 __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
@@ -694,7 +699,7 @@ static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
 
 // ------------------------------------------------------------------ driver
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
-			   StageTimer &tm, hipStream_t s)
+			   uint32_t max_side_links, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = sw.V, E = sw.E, nS = 2 * V;
 	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
@@ -704,7 +709,6 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
-	HIP_CHECK(hipMemsetAsync(cs.tgray + E, 0, 4, s));
 	scan(cs.tgray, tw.tg_ps, (size_t)E + 1);
 	const uint32_t NTG = read_u32(tw.tg_ps + E, s);
 	if (NTG != V - C)
@@ -723,7 +727,6 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const uint32_t *dist = tw.cntB;
 	LAUNCH(k_t0_parents, NA, s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0, tw.pe_le0,
 	       tw.tourflag);
-	HIP_CHECK(hipMemsetAsync(tw.tourflag + NA, 0, 4, s));
 	scan(tw.tourflag, tw.tour_ps, (size_t)NA + 1);
 	LAUNCH(k_t0_roots, C, s, C, cs.voff, start_key, tw.par0, tw.size0, tw.P0);
 	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, tw.arc_dst, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
@@ -745,7 +748,6 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	tm.begin("tree_class_dfs");
 	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, tw.dpar, tw.cslot,
 	       tw.dvis, tw.entry_flag);
-	HIP_CHECK(hipMemsetAsync(tw.entry_flag + nS, 0, 4, s));
 	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
 	const uint32_t n_entry = read_u32(tw.entry_ps + nS, s);
@@ -757,10 +759,13 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 7. pre-order, sizes, depths
 	tm.begin("tree_preorder");
-	LAUNCH(k_child_keys, nS, s, nS, tw.dpar, tw.cslot, (unsigned long long *)tw.ckey, tw.cval);
-	sort_pairs_u64(tw.ckey, tw.ckey2, tw.cval, tw.cval2, nS, 64, pw.sort_tmp, pw.sort_tmp_bytes, s);
+	uint32_t *ck = (uint32_t *)tw.ckey, *ck2 = (uint32_t *)tw.ckey2;
+	LAUNCH(k_child_keys, nS, s, nS, tw.cslot, ck, tw.cval);
+	sort_pairs_u32(ck, ck2, tw.cval, tw.cval2, nS, bits_for((uint64_t)max_side_links + 2), pw.sort_tmp, pw.sort_tmp_bytes, s);
+	LAUNCH(k_gather_parent, nS, s, nS, tw.cval2, tw.dpar, ck);
+	sort_pairs_u32(ck, ck2, tw.cval2, tw.cval, nS, bits_for((uint64_t)nS + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	fill_u32(tw.fc, nS, NIL, s);
-	LAUNCH(k_child_links, nS, s, nS, (const unsigned long long *)tw.ckey2, tw.cval2, tw.fc, tw.nsib);
+	LAUNCH(k_child_links, nS, s, nS, ck2, tw.cval, tw.fc, tw.nsib);
 	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA);
 	// one list per processed component, one two-event list per side of an unprocessed one
 	list_rank_splitters<true>(2 * nS, tw.nxtA, tw.cntA, tw.cntB, tw.depB, event_lists, rb, s);
@@ -775,7 +780,6 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       sw.c_ntree);
 	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
 	       tw.be_ps, pw.b_src, pw.b_tgt);
-	HIP_CHECK(hipMemsetAsync(tw.be_cnt + nS, 0, 4, s));
 	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
 	const uint32_t NB0 = read_u32(tw.be_ps + nS, s);
 	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
