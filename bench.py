@@ -46,10 +46,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # POVU_BENCH_BACKEND=gloo + POVU_BENCH_ONE_DEVICE=1 rehearse the N>1 path on a single-GPU box
+    backend = os.environ.get("POVU_BENCH_BACKEND", "nccl")
+    if os.environ.get("POVU_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
+    comm_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     from povu_amd import HipDecomposer, workloads
     from povu_amd.sharded import gather_forest
@@ -65,12 +73,17 @@ def main():
         wl = f"HPRC-shaped backbone {args.units * 3}: {g.n_vtx} segments / {g.n_links} links"
 
     hip = HipDecomposer(local_rank)
+    t_up = time.perf_counter()
     hip.upload(g)  # inputs resident in HBM before the timed region
+    upload_s = time.perf_counter() - t_up
+    # every rank holds ONE component of the job: its global component id is rank + 1
+    import numpy as np
+    id_map = np.array([rank + 1], dtype=np.int64)
 
     def step():
         f = hip.decompose()
         if world > 1:
-            gather_forest(f, rank, world, torch.device("cuda", local_rank))
+            gather_forest(f, rank, world, comm_dev, id_map=id_map)
         return f
 
     def sync():
@@ -94,7 +107,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -131,6 +144,8 @@ def main():
                          "whole_path_frac": whole_b / (stages.get("total", dt / args.steps * 1e3) * 1e-3) / 1e9
                          / HBM_PEAK_GBS},
             "stage_ms": stages,
+            "upload_ms": upload_s * 1e3,
+            "pcie_inclusive_value": E * world / (dt / args.steps + upload_s),
         }
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

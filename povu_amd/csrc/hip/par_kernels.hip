@@ -435,15 +435,17 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 			    const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
 			    const uint32_t *__restrict__ voff, const uint32_t *__restrict__ ns,
 			    const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
-			    const uint32_t *__restrict__ t_gid, uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a,
-			    uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_or)
+			    const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps,
+			    uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
+			    uint8_t *__restrict__ p_or)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= NE)
 		return;
 	uint32_t i = e_i[j], c = s_comp[i], jb = erank[soff[c]];
 	uint32_t jp = seg_last_less(segL, P, jb, j, lev[j]);
-	uint64_t pb = (uint64_t)voff[c] + c;
+	(void)voff;
+	uint64_t pb = (uint64_t)jb + cproc_ps[c]; // dense: flubbles emitted before + one root per earlier component
 	uint32_t k = 1 + (j - jb);
 	uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
 	uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
@@ -460,17 +462,23 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 }
 __global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ c_ntree,
 			     const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
+			     const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ doff,
 			     uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
 			     uint8_t *__restrict__ p_or, uint32_t *__restrict__ c_npvst, uint32_t *__restrict__ c_nstack)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C)
+	if (c > C)
+		return;
+	(void)voff;
+	const uint32_t first = erank[soff[c]] + cproc_ps[c];
+	doff[c] = first;
+	if (c == C)
 		return;
 	if (c_ntree[c] == 0) {
 		c_npvst[c] = 0;
 		return;
 	}
-	uint64_t pb = (uint64_t)voff[c] + c;
+	uint64_t pb = first;
 	p_parent[pb] = NIL;
 	p_a[pb] = p_z[pb] = NIL;
 	p_or[pb] = 0;
@@ -521,6 +529,11 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.walk, (2 * S + 4) * 4);
 	take((void **)&pw.walk_ps, (2 * S + 4) * 4);
 	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
+	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
+	take((void **)&pw.doff, (Cmax + 2) * 4);
+	for (uint32_t **p : {&pw.d_a, &pw.d_z, &pw.d_parent})
+		take((void **)p, (V + Cmax + 2) * 4);
+	take((void **)&pw.d_or, V + Cmax + 2);
 	take((void **)&pw.err, 64);
 	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
@@ -664,9 +677,9 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, cs.voff, pw.ns,
-	       pw.s_vtx, sw.t_flags, sw.t_gid, sw.p_parent, sw.p_a, sw.p_z, sw.p_or);
-	LAUNCH(k_pvst_roots, C, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, sw.p_parent, sw.p_a, sw.p_z, sw.p_or,
-	       sw.c_npvst, sw.c_nstack);
+	       pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_parent, pw.d_a, pw.d_z, pw.d_or);
+	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
+	       pw.d_a, pw.d_z, pw.d_or, sw.c_npvst, sw.c_nstack);
 	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
 	       sw.next_seen);
 	tm.end(12 + 3 * 22);

@@ -38,6 +38,10 @@ struct ParWs {
 	uint32_t *walk, *walk_ps;	 // [2V+2]
 	uint32_t *erank, *lev, *e_i;	 // [V+1]
 	uint32_t *comp_bad;		 // [C+1] components that must be redone sequentially
+	// dense PVST output (all processed components back to back): what goes over PCIe
+	uint32_t *cproc_ps, *doff;	 // [C+1] processed components before c; first dense PVST slot of c
+	uint32_t *d_a, *d_z, *d_parent;	 // [V + C + 1]
+	uint8_t *d_or;			 // [V + C + 1]
 	uint32_t *err;			 // [4] internal error words
 	SegTree segA, segB, segP, segW, segL;
 	void *scan_tmp, *sort_tmp;

@@ -409,6 +409,15 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		} else {
 			int64_t dense_nb0 = -1;
 			HIP_CHECK(hipMemsetAsync(ctx->pw.err, 0, 64, s));
+			{ // processed components before c: where component c starts in the dense PVST output
+				std::vector<uint32_t> pc(C + 1, 0);
+				for (uint32_t c = 0; c < C; c++) {
+					const uint32_t nv = voff[c + 1] - voff[c];
+					pc[c + 1] = pc[c] + ((nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u);
+				}
+				HIP_CHECK(hipMemcpyAsync(ctx->pw.cproc_ps, pc.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
+				HIP_CHECK(hipStreamSynchronize(s));
+			}
 			if (o.flags & POVU_HIP_F_SEQ_TREE) {
 				init_seq_workspace();
 				tm.begin("tree_seq");
@@ -428,7 +437,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0], tm, s);
 			}
 			uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
-			if (o.flags & POVU_HIP_F_FORCE_REDO) {
+			if (nbad || (o.flags & POVU_HIP_F_FORCE_REDO)) {
+				// the parallel stages only keep the dense PVST layout; a (never yet observed) flagged
+				// component sends the whole shard through the sequential kernels
 				fill_u32(ctx->pw.comp_bad, C, 1u, s);
 				nbad = C;
 			}
@@ -481,7 +492,25 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		f->z_or.resize(total);
 		f->hairpins.resize(2 * total_hp);
 		std::vector<uint8_t> ors(total);
-		if (f->trees.size() <= 32) { // few trees: copy exactly their spans
+		const bool dense_out = !all_seq && ctx->last_seq_redo == 0;
+		if (dense_out) { // the parallel stages wrote every PVST back to back: one exact-size copy per array
+			std::vector<uint32_t> doff(C + 1);
+			HIP_CHECK(hipMemcpyAsync(doff.data(), ctx->pw.doff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			if (doff[C] != total)
+				throw HipError("internal error: dense PVST size mismatch");
+			for (auto &t : f->trees)
+				t.off = doff[t.component_id - 1];
+			if (total) {
+				HIP_CHECK(hipMemcpyAsync(f->a_id.data(), ctx->pw.d_a, total * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(f->z_id.data(), ctx->pw.d_z, total * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(f->parent.data(), ctx->pw.d_parent, total * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(ors.data(), ctx->pw.d_or, total, hipMemcpyDeviceToHost, s));
+			}
+			tm.end(0);
+			HIP_CHECK(hipEventRecord(ev_all1, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+		} else if (f->trees.size() <= 32) { // few trees: copy exactly their spans
 			for (const auto &t : f->trees) {
 				const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
 				HIP_CHECK(hipMemcpyAsync(f->a_id.data() + t.off, sw.p_a + pb, (size_t)t.n_pvst * 4,

@@ -66,56 +66,62 @@ def partition_links(links: Links, comp: np.ndarray, owner: np.ndarray, rank: int
 
 
 def _flat(forest, id_map=None):
-    """Forest -> (header int64 [n_trees, 3], payload uint32)."""
+    """Forest -> (header int32 [n_trees, 2] = (component id, n_pvst), payload int32 bit-view of
+    [a_id | z_id | parent | orientation bits] per tree)."""
     hdr, pay = [], []
     for i in range(len(forest)):
         t = forest.tree(i)
         cid = t.component_id if id_map is None else int(id_map[t.component_id - 1])
-        hdr.append((cid, t.a_id.shape[0], 0))
-        pay.append(np.concatenate([t.a_id, t.z_id, t.parent, t.a_or.astype(np.uint32) | (t.z_or.astype(np.uint32) << 1)]))
-    h = np.array(hdr, dtype=np.int64).reshape(-1, 3)
-    p = np.concatenate(pay).astype(np.uint32) if pay else np.zeros(0, dtype=np.uint32)
-    return h, p
+        n = t.a_id.shape[0]
+        hdr.append((cid, n))
+        pay += [t.a_id.astype(np.uint32, copy=False), t.z_id.astype(np.uint32, copy=False),
+                t.parent.astype(np.uint32, copy=False),
+                t.a_or.astype(np.uint32) | (t.z_or.astype(np.uint32) << 1)]
+    h = np.array(hdr, dtype=np.int32).reshape(-1, 2)
+    p = np.concatenate(pay) if pay else np.zeros(0, dtype=np.uint32)
+    return h, np.ascontiguousarray(p).view(np.int32)
+
+
+def _unpack(out, hh, pp):
+    pp = pp.view(np.uint32)
+    off = 0
+    for cid, n in hh.reshape(-1, 2).tolist():
+        blk = pp[off:off + 4 * n]
+        out[int(cid)] = dict(a_id=blk[:n], z_id=blk[n:2 * n], parent=blk[2 * n:3 * n],
+                             a_or=(blk[3 * n:] & 1).astype(np.uint8), z_or=((blk[3 * n:] >> 1) & 1).astype(np.uint8))
+        off += 4 * n
 
 
 def gather_forest(forest, rank: int, world: int, device, id_map=None) -> Dict[int, dict] | None:
-    """PVST gather to rank 0: all-gather of (n_trees, payload length), then grouped send/recv."""
+    """PVST gather to rank 0: one all-gather of (n_trees, payload words), then point-to-point
+    payload transfers (RCCL send/recv over xGMI on GPUs, gloo on CPU).  No collective touches the
+    traversal itself."""
     import torch
     import torch.distributed as dist
 
     h, p = _flat(forest, id_map)
     sizes = torch.tensor([h.shape[0], p.shape[0]], dtype=torch.int64, device=device)
-    all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    ht = torch.from_numpy(h.reshape(-1)).to(device)
-    pt = torch.from_numpy(p.astype(np.int64)).to(device)  # int64 keeps gloo and nccl paths identical
+    all_sizes = torch.zeros(2 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_sizes, sizes)
     if rank != 0:
-        if ht.numel():
-            dist.send(ht, 0)
-            dist.send(pt, 0)
+        if h.shape[0]:
+            buf = torch.from_numpy(np.concatenate([h.reshape(-1), p])).to(device)
+            dist.send(buf, 0)
         return None
     out: Dict[int, dict] = {}
-
-    def unpack(hh, pp):
-        hh = hh.reshape(-1, 3)
-        off = 0
-        for cid, n, _ in hh.tolist():
-            blk = pp[off:off + 4 * n]
-            out[int(cid)] = dict(a_id=blk[:n].astype(np.uint32), z_id=blk[n:2 * n].astype(np.uint32),
-                                 parent=blk[2 * n:3 * n].astype(np.uint32), a_or=(blk[3 * n:] & 1).astype(np.uint8),
-                                 z_or=((blk[3 * n:] >> 1) & 1).astype(np.uint8))
-            off += 4 * n
-
-    unpack(h, p.astype(np.int64))
+    _unpack(out, h, p)
+    szs = all_sizes.cpu().numpy().reshape(world, 2)
+    bufs = []
     for r in range(1, world):
-        nh, npay = (int(x) for x in all_sizes[r].tolist())
+        nh, npay = int(szs[r, 0]), int(szs[r, 1])
         if nh == 0:
             continue
-        hb = torch.zeros(nh * 3, dtype=torch.int64, device=device)
-        pb = torch.zeros(npay, dtype=torch.int64, device=device)
-        dist.recv(hb, r)
-        dist.recv(pb, r)
-        unpack(hb.cpu().numpy(), pb.cpu().numpy())
+        b = torch.empty(2 * nh + npay, dtype=torch.int32, device=device)
+        dist.recv(b, r)
+        bufs.append((nh, b))
+    for nh, b in bufs:
+        a = b.cpu().numpy()
+        _unpack(out, a[:2 * nh], a[2 * nh:])
     return out
 
 
