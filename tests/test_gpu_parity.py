@@ -300,3 +300,44 @@ def test_cli_and_ffi_on_gpu(tmp_path, golden_dir):
     assert sorted(l.split("\t")[2] for l in text.splitlines()[1:]) == sorted([".", ">1>7", ">4>6"])
     lib.povu_forest_free(fo)
     lib.povu_graph_free(b)
+
+
+def _mk(vid, links):
+    return W._mk(np.array(vid), [a for a, _, _, _ in links], [x for _, x, _, _ in links], [b for _, _, b, _ in links],
+                 [x for _, _, _, x in links])
+
+
+def test_edge_cases_match_oracle(hip):
+    R, L = W.R, W.L
+    cases = {
+        "single vertex": _mk([7], []),
+        "two vertices": _mk([1, 2], [(0, R, 1, L)]),
+        "no links, five vertices": _mk([1, 2, 3, 4, 5], []),
+        "three-vertex chain": _mk([1, 2, 3], [(0, R, 1, L), (1, R, 2, L)]),
+        "only self loops": _mk([1, 2, 3], [(0, R, 0, L), (1, L, 1, L), (2, R, 2, R)]),
+        "triangle without tips": _mk([1, 2, 3], [(0, R, 1, L), (1, R, 2, L), (2, R, 0, L)]),
+        "parallel links both orientations": _mk([1, 2, 3, 4], [(0, R, 1, L), (1, L, 0, R), (1, R, 2, L), (1, R, 2, L),
+                                                                (2, R, 3, L), (0, R, 3, L)]),
+        "ids not ascending in idx": _mk([50, 10, 40, 20, 30], [(0, R, 1, L), (1, R, 2, L), (0, R, 2, L), (2, R, 3, L),
+                                                                 (3, R, 4, L), (2, R, 4, L)]),
+        "huge ids": _mk([1, 4294967000, 4294967294], [(0, R, 1, L), (1, R, 2, L), (0, R, 2, L)]),
+        "hub": _mk(list(range(1, 42)), [(0, R, i, L) for i in range(1, 40)] + [(i, R, 40, L) for i in range(1, 40)]),
+        "circular with gray children at the root": _mk([1, 2, 3, 4, 5], [(0, R, 1, L), (1, R, 0, L), (0, L, 2, L),
+                                                                         (2, R, 3, L), (3, R, 4, L), (4, R, 2, L)]),
+    }
+    for name, g in cases.items():
+        want = O.decompose(g)
+        assert gpu_texts(hip, g) == want, name
+        from povu_amd.hip import F_SEQUENTIAL
+        hip.upload(g)
+        assert hip.decompose(flags=F_SEQUENTIAL).texts() == want, name + " (sequential)"
+
+
+def test_invalid_operands_are_rejected_on_the_host(hip):
+    g = _mk([1, 2, 3], [(0, W.R, 1, W.L)])
+    g.v2[0] = 9  # unknown vertex: would index out of bounds on the device
+    with pytest.raises(RuntimeError, match="unknown vertex"):
+        hip.upload(g)
+    g = _mk([1, 2, 3], [(0, W.R, 1, W.L)])
+    with pytest.raises(RuntimeError, match="bad tip"):
+        hip.upload(g, tips=np.array([0, 5, 0], dtype=np.uint8))
