@@ -113,6 +113,21 @@ char *povu_hip_pvst_format(uint32_t n_pvst, const uint32_t *a_id, const uint32_t
 			   const uint8_t *z_or, const uint32_t *parent, size_t *len);
 void povu_hip_buffer_free(void *p);
 
+/* ---- PVST reader (host only): mto::from_pvst::read_pvst + pvst::Tree::comp_heights,
+ * src/mto/from_pvst.cpp:162-302, include/povu/graph/pvst.hpp:807-836 ---- */
+typedef struct {
+	uint32_t n;	    /* vertices in file order */
+	char *type;	    /* D F T O M C S */
+	uint32_t *file_id;  /* second column */
+	uint32_t *a_id, *z_id;
+	uint8_t *a_or, *z_or;
+	uint8_t *route;	    /* 0 = L (start to end), 1 = R */
+	uint32_t *parent;   /* idx of the parent vertex, POVU_HIP_NIL for the root */
+	uint32_t *height;   /* distance from the root */
+} povu_pvst_doc;
+povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *err, size_t errlen);
+void povu_pvst_doc_free(povu_pvst_doc *doc);
+
 /* ---- measurement (bench.py, povu-stage-cost lines) ---- */
 typedef struct {
 	char name[48];	  /* kernel group */

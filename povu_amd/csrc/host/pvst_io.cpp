@@ -1,0 +1,158 @@
+// pvst_io.cpp -- reader for the PVST wire format (the consumer side of row H).
+// Follows mto::from_pvst::read_pvst (src/mto/from_pvst.cpp:162-302) and pvst::Tree::comp_heights
+// (include/povu/graph/pvst.hpp:807-836): five tab-separated columns per line, header `H <version>`
+// (only 0.0.3 is supported, :37-76), vertex lines D/F/T/O/M/C/S with label `<or><id><or><id>`
+// (:136-158), children as comma-separated FILE vertex ids (:83-130, :284-297), route L/R (:155-157).
+#include "../../../include/povu_hip.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace
+{
+void set_err(char *err, size_t n, const std::string &m)
+{
+	if (err && n)
+		snprintf(err, n, "%s", m.c_str());
+}
+} // namespace
+
+extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *err, size_t errlen)
+{
+	if (!text) {
+		set_err(err, errlen, "null PVST text");
+		return nullptr;
+	}
+	struct Line {
+		char typ;
+		uint32_t file_id;
+		std::string label, children, route;
+	};
+	std::vector<Line> rows;
+	size_t line_idx = 0;
+	const char *p = text, *end = text + len;
+	bool have_header = false;
+	while (p < end) {
+		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+		const char *le = nl ? nl : end;
+		std::vector<std::string> tok;
+		for (const char *q = p;;) {
+			const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
+			tok.emplace_back(q, t ? t : le);
+			if (!t)
+				break;
+			q = t + 1;
+		}
+		if (tok.size() != 5) { // EXPECTED_PVST_COL_NUMS, constants.hpp:66
+			set_err(err, errlen, "invalid number of columns. line " + std::to_string(line_idx) + ". Expected 5, got " +
+						     std::to_string(tok.size()));
+			return nullptr;
+		}
+		const char typ = tok[0].empty() ? '?' : tok[0][0];
+		if (typ == 'H') {
+			if (tok[1] != "0.0.3") {
+				set_err(err, errlen, "Unsupported PVST version, got " + tok[1] + ". Supported versions are: 0.0.3.");
+				return nullptr;
+			}
+			have_header = true;
+		} else if (strchr("DFTOMCS", typ)) {
+			char *e = nullptr;
+			unsigned long id = strtoul(tok[1].c_str(), &e, 10);
+			if (e == tok[1].c_str()) {
+				set_err(err, errlen, "non-numeric vertex id on line " + std::to_string(line_idx + 1));
+				return nullptr;
+			}
+			rows.push_back({typ, (uint32_t)id, tok[2], tok[3], tok[4]});
+		} else {
+			set_err(err, errlen, "Unknown vertex type in PVST: L:" + std::to_string(line_idx + 1));
+			return nullptr;
+		}
+		line_idx++;
+		p = nl ? nl + 1 : end;
+	}
+	(void)have_header;
+	const uint32_t n = (uint32_t)rows.size();
+	auto *d = (povu_pvst_doc *)calloc(1, sizeof(povu_pvst_doc));
+	d->n = n;
+	d->type = (char *)calloc(n + 1, 1);
+	d->file_id = (uint32_t *)calloc(n + 1, 4);
+	d->a_id = (uint32_t *)calloc(n + 1, 4);
+	d->z_id = (uint32_t *)calloc(n + 1, 4);
+	d->parent = (uint32_t *)calloc(n + 1, 4);
+	d->height = (uint32_t *)calloc(n + 1, 4);
+	d->a_or = (uint8_t *)calloc(n + 1, 1);
+	d->z_or = (uint8_t *)calloc(n + 1, 1);
+	d->route = (uint8_t *)calloc(n + 1, 1);
+	std::map<uint32_t, uint32_t> by_file_id; // file_v_idx_to_pvst_idx, :180
+	uint32_t root = POVU_HIP_NIL;
+	for (uint32_t i = 0; i < n; i++) {
+		const Line &r = rows[i];
+		d->type[i] = r.typ;
+		d->file_id[i] = r.file_id;
+		d->parent[i] = POVU_HIP_NIL;
+		by_file_id[r.file_id] = i;
+		if (r.typ == 'D') {
+			d->a_id[i] = d->z_id[i] = POVU_HIP_NIL;
+			root = i;
+			continue;
+		}
+		// str_to_id_or_t, :136-151
+		const size_t first = r.label.find_first_of("><"), last = r.label.find_last_of("><");
+		if (first == std::string::npos || last == first) {
+			povu_pvst_doc_free(d);
+			set_err(err, errlen, "malformed vertex label '" + r.label + "'");
+			return nullptr;
+		}
+		d->a_id[i] = (uint32_t)strtoull(r.label.substr(first + 1, last - first - 1).c_str(), nullptr, 10);
+		d->a_or[i] = r.label[first] == '>' ? 0 : 1;
+		d->z_id[i] = (uint32_t)strtoull(r.label.substr(last + 1).c_str(), nullptr, 10);
+		d->z_or[i] = r.label[last] == '>' ? 0 : 1;
+		d->route[i] = (!r.route.empty() && r.route[0] == 'L') ? 0 : 1;
+	}
+	// children column -> parent pointers, in listed order (:284-297, split_numbers :83-130)
+	for (uint32_t i = 0; i < n; i++) {
+		const std::string &ch = rows[i].children;
+		if (ch == ".")
+			continue;
+		size_t pos = 0;
+		while (pos < ch.size()) {
+			size_t comma = ch.find(',', pos);
+			std::string t = ch.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+			char *e = nullptr;
+			long v = strtol(t.c_str(), &e, 10);
+			if (e != t.c_str()) {
+				auto it = by_file_id.find((uint32_t)v);
+				if (it != by_file_id.end())
+					d->parent[it->second] = i;
+			}
+			if (comma == std::string::npos)
+				break;
+			pos = comma + 1;
+		}
+	}
+	// comp_heights: distance from the root (vertices always follow their parent in this format)
+	if (root != POVU_HIP_NIL)
+		for (uint32_t i = 0; i < n; i++)
+			if (d->parent[i] != POVU_HIP_NIL && d->parent[i] < i)
+				d->height[i] = d->height[d->parent[i]] + 1;
+	return d;
+}
+
+extern "C" void povu_pvst_doc_free(povu_pvst_doc *d)
+{
+	if (!d)
+		return;
+	free(d->type);
+	free(d->file_id);
+	free(d->a_id);
+	free(d->z_id);
+	free(d->parent);
+	free(d->height);
+	free(d->a_or);
+	free(d->z_or);
+	free(d->route);
+	free(d);
+}

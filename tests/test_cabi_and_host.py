@@ -241,3 +241,43 @@ def test_cli_surface(tmp_path, golden_dir):
                            capture_output=True, text=True)
         assert r.returncode != 0 and "no CPU fallback" in r.stderr
         assert not list(tmp_path.glob("*.pvst"))
+
+
+class _Doc(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("type", C.POINTER(C.c_char)), ("file_id", C.POINTER(C.c_uint32)),
+                ("a_id", C.POINTER(C.c_uint32)), ("z_id", C.POINTER(C.c_uint32)), ("a_or", C.POINTER(C.c_uint8)),
+                ("z_or", C.POINTER(C.c_uint8)), ("route", C.POINTER(C.c_uint8)), ("parent", C.POINTER(C.c_uint32)),
+                ("height", C.POINTER(C.c_uint32))]
+
+
+def test_pvst_write_read_round_trip(golden_dir):
+    """the reader (read_pvst + comp_heights) on the writer's output."""
+    hl = H.load_lib()
+    hl.povu_pvst_parse.restype = C.POINTER(_Doc)
+    hl.povu_pvst_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    hl.povu_pvst_doc_free.argtypes = [C.POINTER(_Doc)]
+    import test_oracle as T
+    for g in [W.nested_towers(9, 2), W.chain_of_bubbles(25), _load_gfa_links(os.path.join(golden_dir, "gfa", "LPA.gfa"))]:
+        text = O.decompose(g)[1].encode()
+        dd = T.dump_component(g, 0)
+        err = C.create_string_buffer(256)
+        d = hl.povu_pvst_parse(text, len(text), err, 256)
+        assert d, err.value
+        doc = d.contents
+        n = doc.n
+        assert n == len(dd["p_parent"])
+        assert [doc.type[i] for i in range(n)] == [b"D"] + [b"F"] * (n - 1)
+        assert [doc.file_id[i] for i in range(n)] == list(range(n))
+        assert [doc.parent[i] for i in range(n)] == dd["p_parent"].tolist()
+        assert [doc.a_id[i] for i in range(1, n)] == dd["p_a_id"].tolist()[1:]
+        assert [doc.z_id[i] for i in range(1, n)] == dd["p_z_id"].tolist()[1:]
+        assert [doc.a_or[i] for i in range(1, n)] == dd["p_a_or"].tolist()[1:]
+        assert [doc.z_or[i] for i in range(1, n)] == dd["p_z_or"].tolist()[1:]
+        h = [0] * n
+        for i in range(1, n):
+            h[i] = h[dd["p_parent"][i]] + 1
+        assert [doc.height[i] for i in range(n)] == h
+        hl.povu_pvst_doc_free(d)
+    err = C.create_string_buffer(256)
+    assert not hl.povu_pvst_parse(b"H\t0.0.2\t.\t.\t.\n", 16, err, 256) and b"Unsupported PVST version" in err.value
+    assert not hl.povu_pvst_parse(b"H\t0.0.3\t.\t.\n", 12, err, 256) and b"invalid number of columns" in err.value
