@@ -437,7 +437,7 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 			    const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
 			    const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps,
 			    uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
-			    uint8_t *__restrict__ p_or)
+			    uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= NE)
@@ -452,11 +452,13 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 	if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
 		p_a[pb + k] = t_gid[vz];
 		p_z[pb + k] = t_gid[va];
-		p_or[pb + k] = 0;
+		p_aor[pb + k] = 0;
+		p_zor[pb + k] = 0;
 	} else {
 		p_a[pb + k] = t_gid[va];
 		p_z[pb + k] = t_gid[vz];
-		p_or[pb + k] = (uint8_t)(ra | (rz << 1));
+		p_aor[pb + k] = (uint8_t)ra;
+		p_zor[pb + k] = (uint8_t)rz;
 	}
 	p_parent[pb + k] = jp == NIL ? 0u : 1 + (jp - jb);
 }
@@ -464,7 +466,8 @@ __global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, cons
 			     const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
 			     const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ doff,
 			     uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
-			     uint8_t *__restrict__ p_or, uint32_t *__restrict__ c_npvst, uint32_t *__restrict__ c_nstack)
+			     uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor, uint32_t *__restrict__ c_npvst,
+			     uint32_t *__restrict__ c_nstack)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c > C)
@@ -481,7 +484,7 @@ __global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, cons
 	uint64_t pb = first;
 	p_parent[pb] = NIL;
 	p_a[pb] = p_z[pb] = NIL;
-	p_or[pb] = 0;
+	p_aor[pb] = p_zor[pb] = 0;
 	c_npvst[c] = 1 + (erank[soff[c + 1]] - erank[soff[c]]);
 	c_nstack[c] = soff[c + 1] - soff[c];
 }
@@ -533,7 +536,8 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.doff, (Cmax + 2) * 4);
 	for (uint32_t **p : {&pw.d_a, &pw.d_z, &pw.d_parent})
 		take((void **)p, (V + Cmax + 2) * 4);
-	take((void **)&pw.d_or, V + Cmax + 2);
+	take((void **)&pw.d_aor, V + Cmax + 2);
+	take((void **)&pw.d_zor, V + Cmax + 2);
 	take((void **)&pw.err, 64);
 	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
@@ -677,9 +681,9 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, cs.voff, pw.ns,
-	       pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_parent, pw.d_a, pw.d_z, pw.d_or);
+	       pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_parent, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
-	       pw.d_a, pw.d_z, pw.d_or, sw.c_npvst, sw.c_nstack);
+	       pw.d_a, pw.d_z, pw.d_aor, pw.d_zor, sw.c_npvst, sw.c_nstack);
 	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
 	       sw.next_seen);
 	tm.end(12 + 3 * 22);

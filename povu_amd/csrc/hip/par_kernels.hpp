@@ -41,7 +41,7 @@ struct ParWs {
 	// dense PVST output (all processed components back to back): what goes over PCIe
 	uint32_t *cproc_ps, *doff;	 // [C+1] processed components before c; first dense PVST slot of c
 	uint32_t *d_a, *d_z, *d_parent;	 // [V + C + 1]
-	uint8_t *d_or;			 // [V + C + 1]
+	uint8_t *d_aor, *d_zor;		 // [V + C + 1] 0 forward, 1 reverse
 	uint32_t *err;			 // [4] internal error words
 	SegTree segA, segB, segP, segW, segL;
 	void *scan_tmp, *sort_tmp;

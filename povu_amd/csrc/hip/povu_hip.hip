@@ -11,13 +11,84 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <type_traits>
 
 using namespace povu_hip;
 
+// Pinned host blocks for the PVST arrays: D2H into page-locked memory runs at PCIe speed, and a
+// block returns to its context's pool when the forest is freed (steady state: no allocation).
+struct PinnedPool {
+	std::mutex m;
+	std::vector<std::pair<void *, size_t>> free_blocks;
+	~PinnedPool()
+	{
+		for (auto &b : free_blocks)
+			(void)hipHostFree(b.first);
+	}
+	void *get(size_t bytes, size_t &cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(m);
+			for (size_t i = 0; i < free_blocks.size(); i++)
+				if (free_blocks[i].second >= bytes) {
+					void *p = free_blocks[i].first;
+					cap = free_blocks[i].second;
+					free_blocks.erase(free_blocks.begin() + i);
+					return p;
+				}
+		}
+		void *p = nullptr;
+		cap = bytes + bytes / 4 + 4096;
+		if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
+			throw HipError("hipHostMalloc failed for the PVST result block");
+		return p;
+	}
+	void put(void *p, size_t cap)
+	{
+		std::lock_guard<std::mutex> g(m);
+		if (free_blocks.size() < 4)
+			free_blocks.emplace_back(p, cap);
+		else
+			(void)hipHostFree(p);
+	}
+};
+
+template <typename T>
+struct Span { // just enough of std::vector's surface for the code below
+	T *p = nullptr;
+	T *data() const { return p; }
+	T *begin() const { return p; }
+	T &operator[](size_t i) const { return p[i]; }
+};
+
 struct povu_hip_forest {
 	uint32_t total_components = 0;
+	std::shared_ptr<PinnedPool> pool;
+	void *block = nullptr;
+	size_t block_cap = 0;
+	void alloc(size_t total)
+	{
+		const size_t bytes = ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64;
+		block = pool->get(bytes, block_cap);
+		char *q = static_cast<char *>(block);
+		auto carve = [&](size_t b) {
+			char *r = q;
+			q += (b + 63) & ~size_t(63);
+			return r;
+		};
+		a_id.p = (uint32_t *)carve(total * 4);
+		z_id.p = (uint32_t *)carve(total * 4);
+		parent.p = (uint32_t *)carve(total * 4);
+		a_or.p = (uint8_t *)carve(total);
+		z_or.p = (uint8_t *)carve(total);
+	}
+	~povu_hip_forest()
+	{
+		if (block && pool)
+			pool->put(block, block_cap);
+	}
 	struct Tree {
 		uint32_t component_id, n_vtx, n_links, n_pvst;
 		size_t off;	// into the flat arrays below
@@ -25,8 +96,8 @@ struct povu_hip_forest {
 		uint32_t n_hairpins;
 	};
 	std::vector<Tree> trees;
-	std::vector<uint32_t> a_id, z_id, parent;
-	std::vector<uint8_t> a_or, z_or;
+	Span<uint32_t> a_id, z_id, parent;
+	Span<uint8_t> a_or, z_or;
 	std::vector<uint64_t> hairpins;
 };
 
@@ -35,6 +106,7 @@ struct povu_hip_ctx {
 	hipStream_t stream = nullptr;
 	ResidentGraph g;
 	Arena ws, upload_tmp;
+	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 	StageTimer timer;
 	std::vector<povu_hip_stage_time> last_times;
 	uint64_t last_links = 0;
@@ -485,14 +557,11 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			total_hp += t.n_hairpins;
 			f->trees.push_back(t);
 		}
-		f->a_id.resize(total);
-		f->z_id.resize(total);
-		f->parent.resize(total);
-		f->a_or.resize(total);
-		f->z_or.resize(total);
+		f->pool = ctx->pool;
+		f->alloc(total);
 		f->hairpins.resize(2 * total_hp);
-		std::vector<uint8_t> ors(total);
 		const bool dense_out = !all_seq && ctx->last_seq_redo == 0;
+		std::vector<uint8_t> ors(dense_out ? 0 : total);
 		if (dense_out) { // the parallel stages wrote every PVST back to back: one exact-size copy per array
 			std::vector<uint32_t> doff(C + 1);
 			HIP_CHECK(hipMemcpyAsync(doff.data(), ctx->pw.doff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -505,7 +574,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				HIP_CHECK(hipMemcpyAsync(f->a_id.data(), ctx->pw.d_a, total * 4, hipMemcpyDeviceToHost, s));
 				HIP_CHECK(hipMemcpyAsync(f->z_id.data(), ctx->pw.d_z, total * 4, hipMemcpyDeviceToHost, s));
 				HIP_CHECK(hipMemcpyAsync(f->parent.data(), ctx->pw.d_parent, total * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(ors.data(), ctx->pw.d_or, total, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(f->a_or.data(), ctx->pw.d_aor, total, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(f->z_or.data(), ctx->pw.d_zor, total, hipMemcpyDeviceToHost, s));
 			}
 			tm.end(0);
 			HIP_CHECK(hipEventRecord(ev_all1, s));
@@ -551,10 +621,11 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 					std::copy_n(hh.begin() + 2 * pb, 2 * (size_t)t.n_hairpins, f->hairpins.begin() + 2 * t.hp_off);
 			}
 		}
-		for (size_t i = 0; i < total; i++) {
-			f->a_or[i] = ors[i] & 1;
-			f->z_or[i] = (ors[i] >> 1) & 1;
-		}
+		if (!dense_out)
+			for (size_t i = 0; i < total; i++) {
+				f->a_or[i] = ors[i] & 1;
+				f->z_or[i] = (ors[i] >> 1) & 1;
+			}
 		// stage times
 		ctx->last_times.clear();
 		for (auto &r : tm.recs) {

@@ -67,6 +67,44 @@ __global__ void k_iota(uint32_t n, uint32_t *p)
 	if (i < n)
 		p[i] = i;
 }
+// Arc lists per side WITHOUT a sort: any cyclic order of a side's arcs gives a valid Euler tour, so
+// the arcs are only grouped: slot 0 of side S = its black arc, the gray tree arcs follow (atomic cursor).
+__global__ void k_arc_count(uint32_t E, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ la,
+			    const uint32_t *__restrict__ lb, uint32_t *__restrict__ acnt)
+{
+	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
+	if (le >= E || !tgray[le])
+		return;
+	atomicAdd(&acnt[la[le]], 1u);
+	atomicAdd(&acnt[lb[le]], 1u);
+}
+__global__ void k_arc_init_count(uint32_t nS, uint32_t *__restrict__ acnt)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S < nS)
+		acnt[S] = 1; // the black arc
+}
+__global__ void k_arc_place(uint32_t NA, uint32_t nblack_arcs, const uint32_t *__restrict__ arc_src,
+			    const uint32_t *__restrict__ aoff, uint32_t *__restrict__ cursor, uint32_t *__restrict__ apos,
+			    uint32_t *__restrict__ sarc)
+{
+	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a >= NA)
+		return;
+	uint32_t S = arc_src[a];
+	uint32_t q = a < nblack_arcs ? aoff[S] : aoff[S] + 1 + atomicAdd(&cursor[S], 1u);
+	apos[a] = q;
+	sarc[q] = a;
+}
+__global__ void k_arc_bounds(uint32_t nS, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ afirst,
+			     uint32_t *__restrict__ alast)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	afirst[S] = aoff[S];
+	alast[S] = aoff[S + 1] - 1;
+}
 __global__ void k_arc_positions(uint32_t NA, const uint32_t *__restrict__ ssrc, const uint32_t *__restrict__ sarc,
 				uint32_t *__restrict__ apos, uint32_t *__restrict__ afirst, uint32_t *__restrict__ alast)
 {
@@ -716,9 +754,15 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const uint32_t NA = 2 * (V + NTG);
 	LAUNCH(k_arcs_black, V, s, V, tw.arc_src, tw.arc_dst, tw.arc_le);
 	LAUNCH(k_arcs_gray, E, s, E, V, cs.tgray, tw.tg_ps, cs.la, cs.lb, tw.arc_src, tw.arc_dst, tw.arc_le);
-	LAUNCH(k_iota, NA, s, NA, tw.v1);
-	sort_pairs_u32(tw.arc_src, tw.k2, tw.v1, tw.v2, NA, bits_for(nS), pw.sort_tmp, pw.sort_tmp_bytes, s);
-	LAUNCH(k_arc_positions, NA, s, NA, tw.k2, tw.v2, tw.apos, tw.afirst, tw.alast);
+	{
+		uint32_t *acnt = tw.k1, *aoff = tw.k2, *cursor = tw.v1; // [nS+1] each fits the 4V+8 buffers
+		LAUNCH(k_arc_init_count, nS, s, nS, acnt);
+		LAUNCH(k_arc_count, E, s, E, cs.tgray, cs.la, cs.lb, acnt);
+		scan(acnt, aoff, (size_t)nS + 1);
+		HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)nS * 4, s));
+		LAUNCH(k_arc_place, NA, s, NA, 2 * V, tw.arc_src, aoff, cursor, tw.apos, tw.v2);
+		LAUNCH(k_arc_bounds, nS, s, nS, aoff, tw.afirst, tw.alast);
+	}
 	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, tw.afirst, tw.alast, tw.nxtA, tw.cntA);
 	LAUNCH(k_tour_cut, C, s, C, cs.voff, start_key, tw.v2, tw.alast, tw.nxtA, tw.cntA);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
