@@ -247,9 +247,9 @@ __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const
 // stable sort by top bracket leaves every group ordered from the deepest vertex up.
 __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
 			      const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
-			      const uint32_t *__restrict__ segB, uint32_t P, const uint32_t *__restrict__ psin,
-			      uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval, uint32_t *__restrict__ lsz,
-			      uint32_t *__restrict__ err)
+			      const uint32_t *__restrict__ segB, uint32_t P, const uint32_t *__restrict__ tgtR,
+			      const uint32_t *__restrict__ psin, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval,
+			      uint32_t *__restrict__ lsz, uint32_t *__restrict__ err)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
@@ -264,7 +264,17 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 	}
 	uint32_t m = mpre[v];
 	uint32_t lo = bstart[m], hi = bstart[m + sz];
-	uint32_t i = seg_first_less(segB, P, lo, hi, v);
+	// the top bracket is almost always one of the first few of the range: probe them linearly
+	// (one cache line) before falling back to the O(log n) descent
+	uint32_t i = NIL;
+	const uint32_t probe_end = min(hi, lo + 4);
+	for (uint32_t k = lo; k < probe_end; k++)
+		if (tgtR[k] < v) {
+			i = k;
+			break;
+		}
+	if (i == NIL && probe_end < hi)
+		i = seg_first_less(segB, P, probe_end, hi, v);
 	if (i == NIL) {
 		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
 		ckey[q] = NIL;
@@ -632,7 +642,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
 	seg_build(pw.segB, pw.tgtR, NB, s);
 	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
-	LAUNCH(k_top_bracket, T, s, T, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.psin, ck, pw.vals_t,
+	LAUNCH(k_top_bracket, T, s, T, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck, pw.vals_t,
 	       pw.lsz, pw.err);
 	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, T, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
