@@ -121,11 +121,6 @@ void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, ui
 		    void *tmp, size_t tmp_bytes, hipStream_t s);
 size_t sort_tmp_bytes(size_t n);
 
-// stable radix sort of 64-bit keys (low `bits` bits) with a 32-bit payload
-void sort_pairs_u64(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
-		    void *tmp, size_t tmp_bytes, hipStream_t s);
-size_t sort64_tmp_bytes(size_t n);
-
 inline unsigned bits_for(uint64_t max_value)
 {
 	unsigned b = 1;

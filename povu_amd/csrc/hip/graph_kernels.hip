@@ -49,8 +49,8 @@ __global__ void k_infer_tips(uint32_t V, const uint32_t *__restrict__ off, uint8
 }
 
 // ---------------------------------------------------------------- row B: WCC
-// Lock-free union-find over the links: roots are hooked larger-under-smaller
-// with a CAS, finds use path halving.  The surviving root of a component is
+// Lock-free union-find over the links (k_uf_tiles in LDS, k_uf_cross in global memory): roots are
+// hooked larger-under-smaller with a CAS, finds use path halving.  The surviving root of a component is
 // its smallest vertex idx, which is exactly the key componetize orders
 // components by (next-unvisited linear rescan, bidirected.cpp:585-596).
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
@@ -64,37 +64,6 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 		p = gp;
 	}
 	return x;
-}
-
-__global__ void k_uf_init(uint32_t V, uint32_t *parent)
-{
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v < V)
-		parent[v] = v;
-}
-
-__global__ void k_uf_union(uint32_t E, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
-			   uint32_t *parent, uint32_t *__restrict__ hook)
-{
-	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= E)
-		return;
-	uint32_t a = v1[e], b = v2[e];
-	uint32_t merged = 0;
-	if (a != b) {
-		uint32_t ra = uf_find(parent, a), rb = uf_find(parent, b);
-		while (ra != rb) {
-			uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
-			uint32_t old = atomicCAS(&parent[hi], hi, lo);
-			if (old == hi) {
-				merged = 1; // the links that win a hook form a spanning forest of the segments
-				break;
-			}
-			ra = uf_find(parent, old);
-			rb = uf_find(parent, lo);
-		}
-	}
-	hook[e] = merged;
 }
 
 // ---- tile-local union-find.  Pangenome GFAs are (mostly) sorted along the genome, so almost every

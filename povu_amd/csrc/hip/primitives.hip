@@ -38,20 +38,4 @@ void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, ui
 	HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
 }
 
-size_t sort64_tmp_bytes(size_t n)
-{
-	size_t bytes = 0;
-	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-					(const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64);
-	return bytes + 256;
-}
-
-void sort_pairs_u64(const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
-		    void *tmp, size_t tmp_bytes, hipStream_t s)
-{
-	if (n == 0)
-		return;
-	HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
-}
-
 } // namespace povu_hip

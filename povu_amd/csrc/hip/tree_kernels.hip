@@ -105,19 +105,6 @@ __global__ void k_arc_bounds(uint32_t nS, const uint32_t *__restrict__ aoff, uin
 	afirst[S] = aoff[S];
 	alast[S] = aoff[S + 1] - 1;
 }
-__global__ void k_arc_positions(uint32_t NA, const uint32_t *__restrict__ ssrc, const uint32_t *__restrict__ sarc,
-				uint32_t *__restrict__ apos, uint32_t *__restrict__ afirst, uint32_t *__restrict__ alast)
-{
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= NA)
-		return;
-	uint32_t src = ssrc[q];
-	apos[sarc[q]] = q;
-	if (q == 0 || ssrc[q - 1] != src)
-		afirst[src] = q;
-	if (q == NA - 1 || ssrc[q + 1] != src)
-		alast[src] = q;
-}
 // Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
 __global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
 			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ afirst,

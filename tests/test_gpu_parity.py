@@ -341,3 +341,46 @@ def test_invalid_operands_are_rejected_on_the_host(hip):
     g = _mk([1, 2, 3], [(0, W.R, 1, W.L)])
     with pytest.raises(RuntimeError, match="bad tip"):
         hip.upload(g, tips=np.array([0, 5, 0], dtype=np.uint8))
+
+
+# ---- size-independent properties at BASELINE sizes (no oracle involved)
+def _forest_arrays(hip, g):
+    hip.upload(g)
+    f = hip.decompose()
+    return [f.tree(i) for i in range(len(f))]
+
+
+def test_full_size_structural_properties_and_determinism(hip):
+    k = 333333
+    g = W.chain_of_bubbles(k)
+    t1 = _forest_arrays(hip, g)[0]
+    t2 = _forest_arrays(hip, g)[0]
+    for a, b in ((t1.a_id, t2.a_id), (t1.z_id, t2.z_id), (t1.parent, t2.parent), (t1.a_or, t2.a_or), (t1.z_or, t2.z_or)):
+        assert np.array_equal(a, b)  # same input, same bits
+    n = len(t1.parent)
+    assert n == k + 1 and t1.parent[0] == 0xFFFFFFFF
+    assert np.all(t1.parent[1:] < np.arange(1, n))          # a PVST parent is emitted before its children
+    assert np.all(t1.parent[1:] == 0)                        # K sibling flubbles under the dummy root
+    a = 3 * np.arange(k, dtype=np.int64) + 1
+    assert set(zip(t1.a_id[1:].tolist(), t1.z_id[1:].tolist())) == set(zip(a.tolist(), (a + 3).tolist()))
+    assert not t1.a_or[1:].any() and not t1.z_or[1:].any()
+    # checksum of checksums: same value from the all-sequential kernels on a 1/50 slice of the same shape
+    from povu_amd.hip import F_SEQUENTIAL
+    small = W.chain_of_bubbles(k // 50)
+    hip.upload(small)
+    assert hip.decompose().texts() == hip.decompose(flags=F_SEQUENTIAL).texts()
+
+
+def test_deep_nest_properties(hip):
+    d, towers = 1000, 400
+    t = _forest_arrays(hip, W.nested_towers(d, towers))[0]
+    n = len(t.parent)
+    assert n == d * towers + 1
+    depth = np.zeros(n, dtype=np.int64)
+    for i in range(1, n):
+        depth[i] = depth[t.parent[i]] + 1
+    assert depth.max() == d and np.count_nonzero(depth == 1) == towers
+    # every flubble >a>b of a tower nests exactly one child except the innermost one
+    kids = np.bincount(t.parent[1:], minlength=n)
+    assert kids[0] == towers and set(np.unique(kids[1:]).tolist()) == {0, 1}
+    assert np.count_nonzero(kids[1:] == 0) == towers
