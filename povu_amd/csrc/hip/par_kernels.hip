@@ -120,7 +120,8 @@ __global__ void k_hiA(uint32_t T, const uint32_t *__restrict__ gsize, const uint
 // the root, flubbles.cpp:621-643); hi(v) = root as soon as subtree(v) holds a simplifying edge
 __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hiA,
 			  const uint32_t *__restrict__ bridge, const uint32_t *__restrict__ psb,
-			  const uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi, uint32_t *__restrict__ simp)
+			  const uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi, uint32_t *__restrict__ simp,
+			  uint8_t *__restrict__ hpf)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
@@ -129,11 +130,16 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 	if (sz == 0) {
 		hi[t] = NIL;
 		simp[t] = 0;
+		if (hpf)
+			hpf[t] = 0;
 		return;
 	}
 	uint32_t cnt = psb[t + sz] - psb[t];
 	hi[t] = cnt > 0 ? t_root[t] : hiA[t];
-	simp[t] = (bridge[t] && cnt == 1) ? 1u : 0u;
+	const uint32_t sm = (bridge[t] && cnt == 1) ? 1u : 0u;
+	simp[t] = sm;
+	if (hpf)
+		hpf[t] = (uint8_t)sm;
 }
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
 // ascending idx are v+1, then each next sibling at c + size(c).
@@ -249,7 +255,8 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 			      const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
 			      const uint32_t *__restrict__ segB, uint32_t P, const uint32_t *__restrict__ tgtR,
 			      const uint32_t *__restrict__ psin, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval,
-			      uint32_t *__restrict__ lsz, uint32_t *__restrict__ err)
+			      uint32_t *__restrict__ lsz, uint32_t *__restrict__ err, const uint32_t *__restrict__ rid,
+			      uint32_t first_simp_id, uint8_t *__restrict__ hpf)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
@@ -283,6 +290,8 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 	}
 	lsz[v] = (hi - lo) - (psin[v + sz] - psin[v]);
 	ckey[q] = i;
+	if (hpf && rid[i] >= first_simp_id) // the top bracket is a simplifying edge (flubbles.cpp:644-656)
+		hpf[v] |= 2;
 }
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
@@ -519,6 +528,94 @@ __global__ void k_export_cls(uint32_t T, const uint32_t *__restrict__ gcls, uint
 		t_cls[t] = gcls[t];
 }
 
+// ------------------------------------------------------------- hairpin boundaries
+// The reverse pre-order sweep opens a hairpin at every simplifying vertex (b1 = its segment), extends
+// b2 while the top bracket is a simplifying edge, and closes it at the next leaf (or the root)
+// (flubbles.cpp:531-535, 621-656).  Per closing vertex c the window of vertices processed since the
+// previous closer is (c, prev closer]; everything is a "nearest flagged vertex" query.
+__global__ void k_hp_inputs(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+			    const uint8_t *__restrict__ hpf, uint32_t *__restrict__ a_simp, uint32_t *__restrict__ a_q,
+			    uint32_t *__restrict__ a_close)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	const uint32_t sz = gsize[v];
+	const uint8_t f = sz ? hpf[v] : 0;
+	const bool root = sz && gpar[v] == NIL;
+	a_simp[v] = (sz && !root && (f & 1)) ? 0u : 1u;
+	a_q[v] = (sz && !root && !(f & 1) && (f & 2)) ? 0u : 1u;
+	a_close[v] = (sz && (root || sz == 1)) ? 0u : 1u;
+}
+__global__ void k_hp_close(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ t_root,
+			   const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ c_ntree,
+			   const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ a_close,
+			   const uint32_t *__restrict__ s1, uint32_t P1, const uint32_t *__restrict__ s2, uint32_t P2,
+			   const uint32_t *__restrict__ s3, uint32_t P3, uint32_t *__restrict__ push,
+			   unsigned long long *__restrict__ b12)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= T)
+		return;
+	push[c] = 0;
+	if (a_close[c])
+		return;
+	const uint32_t base = t_root[c], end = base + c_ntree[t_comp[c]];
+	// previous closer in processing order = nearest closer with a larger idx
+	const uint32_t cp = seg_first_less(s3, P3, c + 1, end, 1u);
+	const uint32_t hi = cp == NIL ? end : cp + 1; // window (c, hi)
+	const uint32_t smin = seg_first_less(s1, P1, c + 1, hi, 1u);
+	if (smin == NIL)
+		return; // no simplifying vertex since the previous closer: not in a hairpin
+	const uint32_t smax = seg_last_less(s1, P1, c + 1, hi, 1u);
+	const uint32_t q = seg_first_less(s2, P2, c + 1, smax, 1u);
+	push[c] = 1;
+	b12[2 * (size_t)c] = t_gid[smin];
+	b12[2 * (size_t)c + 1] = q == NIL ? (unsigned long long)NIL : (unsigned long long)t_gid[q];
+	(void)gsize;
+}
+// boundaries are reported in processing order: closers by descending idx inside a component
+__global__ void k_hp_emit(uint32_t T, const uint32_t *__restrict__ push, const uint32_t *__restrict__ ps,
+			  const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ t_comp,
+			  const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ voff,
+			  const unsigned long long *__restrict__ b12, unsigned long long *__restrict__ out,
+			  uint32_t *__restrict__ c_nbry)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= T)
+		return;
+	const uint32_t ci = t_comp[c];
+	if (ci == NIL)
+		return;
+	const uint32_t base = t_root[c], end = base + c_ntree[ci];
+	if (c == base && c_ntree[ci])
+		c_nbry[ci] = ps[end] - ps[base];
+	if (!push[c])
+		return;
+	const uint32_t after = ps[end] - ps[c + 1]; // pushes of this component with a larger idx come first
+	const uint64_t pb = (uint64_t)voff[ci] + ci;
+	out[2 * (pb + after)] = b12[2 * (size_t)c];
+	out[2 * (pb + after) + 1] = b12[2 * (size_t)c + 1];
+}
+
+void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s)
+{
+	const uint32_t T = 2 * sw.V + C;
+	tm.begin("par_hairpins");
+	LAUNCH(k_hp_inputs, T, s, T, pw.gsize, pw.gpar, pw.hpf, pw.hp1, pw.hp2, pw.hp3);
+	seg_build(pw.segH1, pw.hp1, T, s);
+	seg_build(pw.segH2, pw.hp2, T, s);
+	seg_build(pw.segH3, pw.hp3, T, s);
+	uint32_t *push = pw.flagA, *pps = pw.psA;
+	unsigned long long *b12 = (unsigned long long *)pw.b_key; // free after the class stage, >= 2T entries
+	LAUNCH(k_hp_close, T, s, T, pw.gsize, pw.t_root, pw.t_comp, sw.c_ntree, sw.t_gid, pw.hp3, pw.segH1.tree, pw.segH1.P,
+	       pw.segH2.tree, pw.segH2.P, pw.segH3.tree, pw.segH3.P, push, b12);
+	scan_exclusive_u32(push, pps, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	LAUNCH(k_hp_emit, T, s, T, push, pps, pw.t_root, pw.t_comp, sw.c_ntree, cs.voff, b12, (unsigned long long *)sw.hairpins,
+	       sw.c_nbry);
+	tm.end(10);
+}
+
 // ------------------------------------------------------------- workspace
 template <typename F>
 static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
@@ -554,6 +651,12 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segP.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
 	take((void **)&pw.segW.tree, 2 * (size_t)SegTree::pow2(2 * S + 2) * 4);
 	take((void **)&pw.segL.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
+	take((void **)&pw.hpf, T + 2);
+	for (uint32_t **p : {&pw.hp1, &pw.hp2, &pw.hp3})
+		take((void **)p, (T + 2) * 4);
+	take((void **)&pw.segH1.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
+	take((void **)&pw.segH2.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
+	take((void **)&pw.segH3.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	pw.scan_tmp_bytes = scan_tmp_bytes(std::max(T, NB) + 4);
 	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), 4 * V + 8) + 4);
 	take(&pw.scan_tmp, pw.scan_tmp_bytes);
@@ -586,6 +689,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 			 hipStream_t s)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
+	const bool want_hp = sw.hairpins != nullptr;
 	pw.V = V;
 	pw.E = sw.E;
 	pw.C = C;
@@ -620,7 +724,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	uint32_t *bridge = pw.flagA, *psb = pw.psA, *simp = pw.flagB, *pssimp = pw.psB, *capf = pw.flagC, *pscap = pw.psC;
 	LAUNCH(k_hiA, T, s, T, pw.gsize, pw.gpar, pw.segA.tree, pw.segA.P, pw.hiA, bridge);
 	scan(bridge, psb, (size_t)T + 1);
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, pw.hiA, bridge, psb, pw.t_root, pw.hi, simp);
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, pw.hiA, bridge, psb, pw.t_root, pw.hi, simp, want_hp ? pw.hpf : nullptr);
 	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi, pw.hi0, pw.cap_tgt, capf);
 	scan(simp, pssimp, (size_t)T + 1);
 	scan(capf, pscap, (size_t)T + 1);
@@ -643,7 +747,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	seg_build(pw.segB, pw.tgtR, NB, s);
 	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
 	LAUNCH(k_top_bracket, T, s, T, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck, pw.vals_t,
-	       pw.lsz, pw.err);
+	       pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr);
 	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, T, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 	uint32_t *cflag = pw.flagA, *cps = pw.psA; // bridge flags are dead by now

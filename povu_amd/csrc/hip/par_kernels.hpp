@@ -44,6 +44,10 @@ struct ParWs {
 	uint8_t *d_aor, *d_zor;		 // [V + C + 1] 0 forward, 1 reverse
 	uint32_t *err;			 // [4] internal error words
 	SegTree segA, segB, segP, segW, segL;
+	// --hairpins on the parallel path
+	uint8_t *hpf;			 // [T] bit0 simplifying vertex, bit1 top bracket is a simplifying edge
+	uint32_t *hp1, *hp2, *hp3;	 // [T+1] segment-tree inputs / push flags
+	SegTree segH1, segH2, segH3;
 	void *scan_tmp, *sort_tmp;
 	size_t scan_tmp_bytes, sort_tmp_bytes;
 };
@@ -56,5 +60,9 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
 // dense_nb0 < 0: densify the back edges the sequential tree stage wrote; otherwise b_src/b_tgt hold them.
 uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int64_t dense_nb0, StageTimer &tm,
 			 hipStream_t s);
+
+// Hairpin boundaries (`--hairpins`, flubbles.cpp:531-535, 621-656, 712-717) from the parallel class stage's
+// per-vertex flags; writes sw.hairpins / sw.c_nbry like the sequential kernels do.
+void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s);
 
 } // namespace povu_hip

@@ -393,7 +393,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
-		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0 || hairpins;
+		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
 		ctx->ws.reserve(carve_workspace(nullptr, z, cs, sw, hairpins) +
 				(all_seq ? 0 : par_workspace_bytes(z.V, z.E, z.Cmax) + tree_workspace_bytes(z.V, z.E, z.Cmax)));
 		carve_workspace(&ctx->ws, z, cs, sw, hairpins);
@@ -509,6 +509,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0], tm, s);
 			}
 			uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
+			if (hairpins && !nbad)
+				run_parallel_hairpins(cs, sw, ctx->pw, C, tm, s);
 			if (nbad || (o.flags & POVU_HIP_F_FORCE_REDO)) {
 				// the parallel stages only keep the dense PVST layout; a (never yet observed) flagged
 				// component sends the whole shard through the sequential kernels
@@ -577,6 +579,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				HIP_CHECK(hipMemcpyAsync(f->a_or.data(), ctx->pw.d_aor, total, hipMemcpyDeviceToHost, s));
 				HIP_CHECK(hipMemcpyAsync(f->z_or.data(), ctx->pw.d_zor, total, hipMemcpyDeviceToHost, s));
 			}
+			for (const auto &t : f->trees)
+				if (t.n_hairpins) {
+					const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
+					HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t.hp_off, sw.hairpins + 2 * pb,
+								 (size_t)t.n_hairpins * 16, hipMemcpyDeviceToHost, s));
+				}
 			tm.end(0);
 			HIP_CHECK(hipEventRecord(ev_all1, s));
 			HIP_CHECK(hipStreamSynchronize(s));

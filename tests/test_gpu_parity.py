@@ -384,3 +384,32 @@ def test_deep_nest_properties(hip):
     kids = np.bincount(t.parent[1:], minlength=n)
     assert kids[0] == towers and set(np.unique(kids[1:]).tolist()) == {0, 1}
     assert np.count_nonzero(kids[1:] == 0) == towers
+
+
+def test_hairpin_boundaries_parallel_and_sequential(hip):
+    """--hairpins (flubbles.cpp:531-535, 621-656, 712-717): Boundary pairs in reporting order."""
+    from povu_amd.hip import F_HAIRPINS, F_SEQUENTIAL
+    n_with = 0
+    for seed in range(60):
+        n = 30 + 7 * seed
+        g = W.random_bidirected(n, int(n * (1.0 + 0.04 * (seed % 9))), 31337 + seed)
+        want = {}
+        c = 0
+        while True:
+            d = dump_component(g, c)
+            if d is None:
+                break
+            if len(d["gid"]):
+                want[c + 1] = d["bry"].tolist()
+            c += 1
+        n_with += sum(1 for v in want.values() if v)
+        hip.upload(g)
+        for flags in (F_HAIRPINS, F_HAIRPINS | F_SEQUENTIAL):
+            f = hip.decompose(flags=flags)
+            got = {}
+            for i in range(len(f)):
+                t = f.tree(i)
+                got[t.component_id] = t.hairpins.tolist()
+            assert got == want, (seed, flags)
+        assert hip.decompose(flags=F_HAIRPINS).texts() == O.decompose(g)
+    assert n_with >= 10  # the sample does exercise hairpins
