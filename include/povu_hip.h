@@ -100,6 +100,13 @@ typedef struct {
 } povu_hip_tree;
 
 int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hip_tree *out);
+/*
+ * The forest's arrays as ONE page-locked host block (what a multi-GPU gather ships):
+ * offsets[0..4] = byte offsets of a_id, z_id, parent (u32 x total) and a_or, z_or (u8 x total);
+ * tree i occupies entries [first[i], first[i] + n_pvst) of every array (first = povu_hip_forest_first).
+ */
+int povu_hip_forest_raw(const povu_hip_forest *f, const void **block, size_t *bytes, uint64_t *total, uint64_t offsets[5]);
+uint64_t povu_hip_forest_first(const povu_hip_forest *f, uint32_t i);
 void povu_hip_forest_free(povu_hip_forest *f);
 
 /*

@@ -67,9 +67,10 @@ struct povu_hip_forest {
 	uint32_t total_components = 0;
 	std::shared_ptr<PinnedPool> pool;
 	void *block = nullptr;
-	size_t block_cap = 0;
+	size_t block_cap = 0, block_bytes = 0, total_entries = 0;
 	void alloc(size_t total)
 	{
+		total_entries = total;
 		const size_t bytes = ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64;
 		block = pool->get(bytes, block_cap);
 		char *q = static_cast<char *>(block);
@@ -83,6 +84,7 @@ struct povu_hip_forest {
 		parent.p = (uint32_t *)carve(total * 4);
 		a_or.p = (uint8_t *)carve(total);
 		z_or.p = (uint8_t *)carve(total);
+		block_bytes = (size_t)(q - static_cast<char *>(block));
 	}
 	~povu_hip_forest()
 	{
@@ -682,6 +684,28 @@ extern "C" int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hi
 	out->n_hairpins = t.n_hairpins;
 	out->hairpins = t.n_hairpins ? f->hairpins.data() + 2 * t.hp_off : nullptr;
 	return 0;
+}
+
+extern "C" int povu_hip_forest_raw(const povu_hip_forest *f, const void **block, size_t *bytes, uint64_t *total,
+				   uint64_t offsets[5])
+{
+	if (!f || !block || !bytes || !total || !offsets)
+		return 1;
+	*block = f->block;
+	*bytes = f->block_bytes;
+	*total = f->total_entries;
+	const char *b = static_cast<const char *>(f->block);
+	offsets[0] = (uint64_t)((const char *)f->a_id.p - b);
+	offsets[1] = (uint64_t)((const char *)f->z_id.p - b);
+	offsets[2] = (uint64_t)((const char *)f->parent.p - b);
+	offsets[3] = (uint64_t)((const char *)f->a_or.p - b);
+	offsets[4] = (uint64_t)((const char *)f->z_or.p - b);
+	return 0;
+}
+
+extern "C" uint64_t povu_hip_forest_first(const povu_hip_forest *f, uint32_t i)
+{
+	return (f && i < f->trees.size()) ? (uint64_t)f->trees[i].off : 0;
 }
 
 extern "C" void povu_hip_forest_free(povu_hip_forest *f) { delete f; }

@@ -71,6 +71,11 @@ def load_lib():
     l.povu_hip_forest_get.restype = C.c_int
     l.povu_hip_forest_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Tree)]
     l.povu_hip_forest_free.argtypes = [C.c_void_p]
+    l.povu_hip_forest_raw.restype = C.c_int
+    l.povu_hip_forest_raw.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)]
+    l.povu_hip_forest_first.restype = C.c_uint64
+    l.povu_hip_forest_first.argtypes = [C.c_void_p, C.c_uint32]
     l.povu_hip_forest_pvst_text.restype = C.c_void_p
     l.povu_hip_forest_pvst_text.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]
     l.povu_hip_buffer_free.argtypes = [C.c_void_p]
@@ -138,6 +143,25 @@ class Forest:
         if with_text:
             out.text = self.text(i)
         return out
+
+    def raw(self):
+        """Zero-copy view of the whole result: (uint8 block over the pinned host memory, total entries,
+        byte offsets of a_id/z_id/parent/a_or/z_or, header int64 [n_trees, 3] = (component id, n_pvst, first))."""
+        blk, nb, tot = C.c_void_p(), C.c_size_t(0), C.c_uint64(0)
+        offs = (C.c_uint64 * 5)()
+        if self._lib.povu_hip_forest_raw(self._h, C.byref(blk), C.byref(nb), C.byref(tot), offs) != 0:
+            raise RuntimeError("forest has no raw block")
+        n = len(self)
+        hdr = np.zeros((n, 3), dtype=np.int64)
+        t = _Tree()
+        for i in range(n):
+            self._lib.povu_hip_forest_get(self._h, i, C.byref(t))
+            hdr[i] = (t.component_id, t.n_pvst, self._lib.povu_hip_forest_first(self._h, i))
+        if nb.value == 0 or not blk.value:
+            block = np.zeros(0, dtype=np.uint8)
+        else:
+            block = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_uint8)), shape=(nb.value,))
+        return block, int(tot.value), [int(x) for x in offs], hdr
 
     def text(self, i: int) -> str:
         ln = C.c_size_t(0)

@@ -92,10 +92,80 @@ def _unpack(out, hh, pp):
         off += 4 * n
 
 
+def _views(out, hdr, block, total, offs, id_map=None):
+    """Slice one rank's raw block (numpy uint8) into per-component array views (no copies)."""
+    a = block[offs[0]:offs[0] + 4 * total].view(np.uint32)
+    z = block[offs[1]:offs[1] + 4 * total].view(np.uint32)
+    p = block[offs[2]:offs[2] + 4 * total].view(np.uint32)
+    ao = block[offs[3]:offs[3] + total]
+    zo = block[offs[4]:offs[4] + total]
+    for cid, n, first in hdr.reshape(-1, 3).tolist():
+        if id_map is not None:
+            cid = int(id_map[cid - 1])
+        sl = slice(first, first + n)
+        out[int(cid)] = dict(a_id=a[sl], z_id=z[sl], parent=p[sl], a_or=ao[sl], z_or=zo[sl])
+
+
+_pinned_cache = {}
+
+
+def _pinned(nbytes: int, key):
+    import torch
+    t = _pinned_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        _pinned_cache[key] = t
+    return t[:nbytes]
+
+
 def gather_forest(forest, rank: int, world: int, device, id_map=None) -> Dict[int, dict] | None:
-    """PVST gather to rank 0: one all-gather of (n_trees, payload words), then point-to-point
-    payload transfers (RCCL send/recv over xGMI on GPUs, gloo on CPU).  No collective touches the
-    traversal itself."""
+    """PVST gather to rank 0.  One all-gather of the sizes, then point-to-point payloads (RCCL
+    send/recv over xGMI on GPUs, gloo on CPU); no collective touches the traversal itself.
+    A HIP forest ships its page-locked result block as is (one H2D, one send per rank; rank 0 lands
+    the blocks in pinned memory and slices views); other forest objects go through `_flat`."""
+    import torch
+    import torch.distributed as dist
+
+    if not hasattr(forest, "raw"):
+        return _gather_flat(forest, rank, world, device, id_map)
+    block, total, offs, hdr = forest.raw()
+    if id_map is not None and len(hdr):
+        hdr = hdr.copy()
+        hdr[:, 0] = np.asarray(id_map, dtype=np.int64)[hdr[:, 0] - 1]
+    meta = np.array([hdr.shape[0], block.shape[0], total] + offs, dtype=np.int64)
+    all_meta = torch.zeros(8 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_meta, torch.from_numpy(meta).to(device))
+    if rank != 0:
+        if hdr.shape[0]:
+            dist.send(torch.from_numpy(hdr.reshape(-1)).to(device), 0)
+            dist.send(torch.from_numpy(block).to(device, non_blocking=True), 0)
+        return None
+    out: Dict[int, dict] = {}
+    _views(out, hdr, block, total, offs)
+    am = all_meta.cpu().numpy().reshape(world, 8)
+    pending = []
+    for r in range(1, world):
+        nh, nb = int(am[r, 0]), int(am[r, 1])
+        if nh == 0:
+            continue
+        hb = torch.empty(3 * nh, dtype=torch.int64, device=device)
+        bb = torch.empty(nb, dtype=torch.uint8, device=device)
+        dist.recv(hb, r)
+        dist.recv(bb, r)
+        pending.append((r, hb, bb))
+    landed = []
+    for r, hb, bb in pending:  # device -> pinned host, all copies in flight before the single sync
+        host = _pinned(bb.numel(), ("blk", r))
+        host.copy_(bb, non_blocking=True)
+        landed.append((r, hb.cpu().numpy(), host))
+    if device.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    for r, h, host in landed:
+        _views(out, h, host.numpy(), int(am[r, 2]), [int(x) for x in am[r, 3:8]])
+    return out
+
+
+def _gather_flat(forest, rank: int, world: int, device, id_map=None) -> Dict[int, dict] | None:
     import torch
     import torch.distributed as dist
 
