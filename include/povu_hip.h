@@ -158,6 +158,11 @@ int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint
 int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t *tree_vtx, uint32_t *cls,
 			 uint32_t *next_seen);
 
+/* device workspace (bytes) one povu_hip_decompose call reserves for a graph of this size, excluding the
+ * resident graph itself (~42 B/link + 13 B/segment) and the sequential kernels' lists; n_components = 0
+ * assumes the worst case (every segment its own component); 0 when it cannot be computed */
+uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components);
+
 const char *povu_hip_version(void);
 
 #ifdef __cplusplus

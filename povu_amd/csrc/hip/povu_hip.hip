@@ -107,7 +107,7 @@ struct povu_hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	ResidentGraph g;
-	Arena ws, upload_tmp;
+	Arena ws, ws2, ws_seq, upload_tmp;
 	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 	StageTimer timer;
 	std::vector<povu_hip_stage_time> last_times;
@@ -173,6 +173,8 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	free_graph(ctx->g);
 	ctx->ws.release();
+	ctx->ws2.release();
+	ctx->ws_seq.release();
 	ctx->upload_tmp.release();
 	if (ctx->stream)
 		(void)hipStreamDestroy(ctx->stream);
@@ -252,8 +254,12 @@ struct Sizes {
 	size_t V, E, Cmax, T, B, nS, slots;
 };
 
-// carve every span of one decompose call out of the arena (or just measure when `ar` is null)
-size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool hairpins)
+// Workspace carving (or just measuring when `ar` is null), in three parts with different life times:
+//   part 0  rows A/B state (CompState), sized before the component count is known (C <= V)
+//   part 1  tree / result arrays every execution mode shares, sized with the real component count
+//   part 2  the one-lane kernels' own lists (back edges, brackets, stacks): only reserved when the
+//           sequential kernels actually run (POVU_HIP_F_SEQUENTIAL / _SEQ_TREE, or a redo)
+size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs &sw, bool hairpins)
 {
 	size_t total = 0;
 	auto take = [&](auto **dst, size_t n, size_t elem) {
@@ -264,108 +270,134 @@ size_t carve_workspace(Arena *ar, const Sizes &z, CompState &cs, SeqWs &sw, bool
 		}
 	};
 	const size_t V = z.V, E = z.E, C = z.Cmax, T = z.T, B = z.B, nS = z.nS;
-	// rows A/B
-	take(&cs.label, V + 1, 4);
-	take(&cs.flag, std::max(V, z.slots) + 2, 4);
-	take(&cs.crank, V + 2, 4);
-	take(&cs.comp_of, V + 1, 4);
-	take(&cs.tmp_a, V + 1, 4);
-	take(&cs.ckey, V + 1, 4);
-	take(&cs.perm, V + 1, 4);
-	take(&cs.pos, V + 1, 4);
-	take(&cs.voff, C + 2, 4);
-	take(&cs.eoff, C + 2, 4);
-	take(&cs.vdeg, V + 2, 4);
-	take(&cs.sbase, V + 2, 4);
-	take(&cs.first, E + 1, 4);
-	take(&cs.erank, z.slots + 2, 4);
-	take(&cs.ldeg, nS + 2, 4);
-	take(&cs.loff, nS + 2, 4);
-	take(&cs.ladj, 2 * E + 2, 4);
-	take(&cs.keys, 2 * E + 2, 4);
-	take(&cs.vals, 2 * E + 2, 4);
-	take(&cs.keys2, 2 * E + 2, 4);
-	take(&cs.vals2, 2 * E + 2, 4);
-	take(&cs.hook, E + 2, 4);
-	take(&cs.la, E + 2, 4);
-	take(&cs.lb, E + 2, 4);
-	take(&cs.lle, 2 * E + 2, 4);
-	take(&cs.tgray, E + 2, 4);
-	take(&cs.stats, 16, 4);
-	take(&cs.gid_s, V + 1, 4);
-	take(&cs.tip_s, V + 1, 1);
-	take(&cs.start_key, C + 2, 8);
-	cs.scan_tmp_bytes = scan_tmp_bytes(std::max<size_t>(nS, z.slots) + 2);
-	cs.sort_tmp_bytes = sort_tmp_bytes(std::max<size_t>(2 * E, V) + 2);
-	take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);
-	take((char **)&cs.sort_tmp, cs.sort_tmp_bytes, 1);
-	// rows C-G
-	uint32_t *order = nullptr, *owner = nullptr;
-	take(&order, C + 1, 4);
-	take(&owner, C + 1, 4);
-	sw.order = order;
-	sw.owner = owner;
-	take(&sw.t_gid, T, 4);
-	take(&sw.t_par, T, 4);
-	take(&sw.t_cls, T, 4);
-	take(&sw.t_hi, T, 4);
-	take(&sw.first_child, T, 4);
-	take(&sw.next_sib, T, 4);
-	take(&sw.last_child, T, 4);
-	take(&sw.t_size, T, 4);
-	take(&sw.t_depth, T, 4);
-	take(&sw.t_flags, T, 1);
-	take(&sw.ctr, nS + 1, 4);
-	take(&sw.cur, nS + 1, 4);
-	take(&sw.stk, T, 4);
-	take(&sw.selfloop, V + 1, 1);
-	take(&sw.be_src, B, 4);
-	take(&sw.be_tgt, B, 4);
-	take(&sw.o_next, B, 4);
-	take(&sw.i_next, B, 4);
-	take(&sw.b_prev, B, 4);
-	take(&sw.b_next, B, 4);
-	take(&sw.b_rsize, B, 4);
-	take(&sw.b_rclass, B, 4);
-	take(&sw.be_type, B, 1);
-	take(&sw.b_in, B, 1);
-	take(&sw.be_cdef, B, 1);
-	take(&sw.o_head, T, 4);
-	take(&sw.o_tail, T, 4);
-	take(&sw.i_head, T, 4);
-	take(&sw.i_tail, T, 4);
-	take(&sw.l_head, T, 4);
-	take(&sw.l_tail, T, 4);
-	take(&sw.l_size, T, 4);
-	take(&sw.bl, T, 4);
-	take(&sw.nxt, T, 4);
-	take(&sw.st_head, T, 4);
-	take(&sw.st_tail, T, 4);
-	take(&sw.s_vtx, V + 1, 4);
-	take(&sw.s_cls, V + 1, 4);
-	take(&sw.next_seen, V + 1, 4);
-	take(&sw.last, B + T, 4);
-	take(&sw.p_parent, V + C + 1, 4);
-	take(&sw.p_a, V + C + 1, 4);
-	take(&sw.p_z, V + C + 1, 4);
-	take(&sw.p_or, V + C + 1, 1);
-	take(&sw.aux, V + C + 1, 4);
-	take(&sw.in_s, B + T, 1);
-	if (hairpins)
-		take(&sw.hairpins, 2 * (V + C + 1), 8);
-	else
-		sw.hairpins = nullptr;
-	take(&sw.c_ntree, C + 1, 4);
-	take(&sw.c_nbe0, C + 1, 4);
-	take(&sw.c_nbe, C + 1, 4);
-	take(&sw.c_nstack, C + 1, 4);
-	take(&sw.c_npvst, C + 1, 4);
-	take(&sw.c_nclass, C + 1, 4);
-	take(&sw.c_nbry, C + 1, 4);
-	take(&sw.c_status, C + 1, 4);
+	if (part == 0) {
+		take(&cs.label, V + 1, 4);
+		take(&cs.flag, std::max(V, z.slots) + 2, 4);
+		take(&cs.crank, V + 2, 4);
+		take(&cs.comp_of, V + 1, 4);
+		take(&cs.tmp_a, V + 1, 4);
+		take(&cs.ckey, V + 1, 4);
+		take(&cs.perm, V + 1, 4);
+		take(&cs.pos, V + 1, 4);
+		take(&cs.voff, C + 2, 4);
+		take(&cs.eoff, C + 2, 4);
+		take(&cs.vdeg, V + 2, 4);
+		take(&cs.sbase, V + 2, 4);
+		take(&cs.first, E + 1, 4);
+		take(&cs.erank, z.slots + 2, 4);
+		take(&cs.ldeg, nS + 2, 4);
+		take(&cs.loff, nS + 2, 4);
+		take(&cs.ladj, 2 * E + 2, 4);
+		take(&cs.keys, 2 * E + 2, 4);
+		take(&cs.vals, 2 * E + 2, 4);
+		take(&cs.keys2, 2 * E + 2, 4);
+		take(&cs.vals2, 2 * E + 2, 4);
+		take(&cs.hook, E + 2, 4);
+		take(&cs.la, E + 2, 4);
+		take(&cs.lb, E + 2, 4);
+		take(&cs.lle, 2 * E + 2, 4);
+		take(&cs.tgray, E + 2, 4);
+		take(&cs.stats, 16, 4);
+		take(&cs.gid_s, V + 1, 4);
+		take(&cs.tip_s, V + 1, 1);
+		take(&cs.start_key, C + 2, 8);
+		cs.scan_tmp_bytes = scan_tmp_bytes(std::max<size_t>(nS, z.slots) + 2);
+		cs.sort_tmp_bytes = sort_tmp_bytes(std::max<size_t>(2 * E, V) + 2);
+		take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);
+		take((char **)&cs.sort_tmp, cs.sort_tmp_bytes, 1);
+	} else if (part == 1) {
+		uint32_t *order = nullptr, *owner = nullptr;
+		take(&order, C + 1, 4);
+		take(&owner, C + 1, 4);
+		sw.order = order;
+		sw.owner = owner;
+		take(&sw.t_gid, T, 4);
+		take(&sw.t_par, T, 4);
+		take(&sw.t_cls, T, 4);
+		take(&sw.t_size, T, 4);
+		take(&sw.t_depth, T, 4);
+		take(&sw.t_flags, T, 1);
+		take(&sw.cur, nS + 1, 4);
+		take(&sw.s_vtx, V + 1, 4);
+		take(&sw.s_cls, V + 1, 4);
+		take(&sw.next_seen, V + 1, 4);
+		if (hairpins)
+			take(&sw.hairpins, 2 * (V + C + 1), 8);
+		else
+			sw.hairpins = nullptr;
+		take(&sw.c_ntree, C + 1, 4);
+		take(&sw.c_nbe0, C + 1, 4);
+		take(&sw.c_nbe, C + 1, 4);
+		take(&sw.c_nstack, C + 1, 4);
+		take(&sw.c_npvst, C + 1, 4);
+		take(&sw.c_nclass, C + 1, 4);
+		take(&sw.c_nbry, C + 1, 4);
+		take(&sw.c_status, C + 1, 4);
+	} else {
+		take(&sw.t_hi, T, 4);
+		take(&sw.first_child, T, 4);
+		take(&sw.next_sib, T, 4);
+		take(&sw.last_child, T, 4);
+		take(&sw.ctr, nS + 1, 4);
+		take(&sw.stk, T, 4);
+		take(&sw.selfloop, V + 1, 1);
+		take(&sw.be_src, B, 4);
+		take(&sw.be_tgt, B, 4);
+		take(&sw.o_next, B, 4);
+		take(&sw.i_next, B, 4);
+		take(&sw.b_prev, B, 4);
+		take(&sw.b_next, B, 4);
+		take(&sw.b_rsize, B, 4);
+		take(&sw.b_rclass, B, 4);
+		take(&sw.be_type, B, 1);
+		take(&sw.b_in, B, 1);
+		take(&sw.be_cdef, B, 1);
+		take(&sw.o_head, T, 4);
+		take(&sw.o_tail, T, 4);
+		take(&sw.i_head, T, 4);
+		take(&sw.i_tail, T, 4);
+		take(&sw.l_head, T, 4);
+		take(&sw.l_tail, T, 4);
+		take(&sw.l_size, T, 4);
+		take(&sw.bl, T, 4);
+		take(&sw.nxt, T, 4);
+		take(&sw.st_head, T, 4);
+		take(&sw.st_tail, T, 4);
+		take(&sw.last, B + T, 4);
+		take(&sw.p_parent, V + C + 1, 4);
+		take(&sw.p_a, V + C + 1, 4);
+		take(&sw.p_z, V + C + 1, 4);
+		take(&sw.p_or, V + C + 1, 1);
+		take(&sw.aux, V + C + 1, 4);
+		take(&sw.in_s, B + T, 1);
+	}
 	return total + (1 << 20);
 }
 } // namespace
+
+extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components)
+{
+	try {
+		Sizes z;
+		z.V = n_vtx;
+		z.E = n_links;
+		z.nS = 2 * z.V;
+		z.slots = 2 * z.E;
+		CompState cs{};
+		SeqWs sw{};
+		z.Cmax = n_vtx;
+		z.T = z.B = 0;
+		uint64_t total = carve_workspace(nullptr, 0, z, cs, sw, false);
+		z.Cmax = n_components ? n_components : n_vtx;
+		z.T = 2 * z.V + z.Cmax;
+		z.B = z.E + z.V + 2 * z.T;
+		total += carve_workspace(nullptr, 1, z, cs, sw, false) + par_workspace_bytes(z.V, z.E, z.Cmax) +
+			 tree_workspace_bytes(z.V, z.E, z.Cmax);
+		return total;
+	} catch (...) {
+		return 0;
+	}
+}
 
 extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip_opts *opts, char *err, size_t errlen)
 {
@@ -387,22 +419,16 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		Sizes z;
 		z.V = g.V;
 		z.E = g.E;
-		z.Cmax = g.V; // component count is only known after labelling; size for the worst case
+		z.Cmax = g.V; // rows A/B run before the component count is known
 		z.nS = 2 * z.V;
 		z.slots = g.n_slots;
-		z.T = 2 * z.V + z.Cmax;
-		z.B = z.E + z.V + 2 * z.T;
+		z.T = z.B = 0;
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
-		ctx->ws.reserve(carve_workspace(nullptr, z, cs, sw, hairpins) +
-				(all_seq ? 0 : par_workspace_bytes(z.V, z.E, z.Cmax) + tree_workspace_bytes(z.V, z.E, z.Cmax)));
-		carve_workspace(&ctx->ws, z, cs, sw, hairpins);
-		if (!all_seq) {
-			par_carve(ctx->ws, ctx->pw, z.V, z.E, z.Cmax);
-			tree_carve(ctx->ws, ctx->tw, z.V, z.E, z.Cmax);
-		}
+		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, hairpins));
+		carve_workspace(&ctx->ws, 0, z, cs, sw, hairpins);
 
 		StageTimer &tm = ctx->timer;
 		tm.reset();
@@ -420,6 +446,25 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		uint32_t gstats[4] = {0, 0, 0, 0};
 		HIP_CHECK(hipMemcpyAsync(gstats, cs.stats, 16, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
+		// stage workspaces, sized with the real component count
+		z.Cmax = C;
+		z.T = 2 * z.V + C;
+		z.B = z.E + z.V + 2 * z.T;
+		ctx->ws2.reserve(carve_workspace(nullptr, 1, z, cs, sw, hairpins) +
+				 (all_seq ? 0 : par_workspace_bytes(z.V, z.E, C) + tree_workspace_bytes(z.V, z.E, C)));
+		carve_workspace(&ctx->ws2, 1, z, cs, sw, hairpins);
+		if (!all_seq) {
+			par_carve(ctx->ws2, ctx->pw, z.V, z.E, C);
+			tree_carve(ctx->ws2, ctx->tw, z.V, z.E, C);
+		}
+		bool seq_ws_ready = false;
+		auto need_seq_workspace = [&]() { // the one-lane kernels' lists live in their own arena
+			if (seq_ws_ready)
+				return;
+			ctx->ws_seq.reserve(carve_workspace(nullptr, 2, z, cs, sw, hairpins));
+			carve_workspace(&ctx->ws_seq, 2, z, cs, sw, hairpins);
+			seq_ws_ready = true;
+		};
 		std::vector<uint32_t> order(C), owner(C, 0);
 		std::iota(order.begin(), order.end(), 0u);
 		auto weight = [&](uint32_t c) { return (uint64_t)(eoff[c + 1] - eoff[c]) + (voff[c + 1] - voff[c]); };
@@ -460,6 +505,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		const size_t T = 2 * (size_t)g.V + C, B = (size_t)g.E + g.V + 2 * T;
 		// the one-lane kernels expect their lists empty; only paid for when they actually run
 		auto init_seq_workspace = [&]() {
+			need_seq_workspace();
 			for (uint32_t *p : {sw.first_child, sw.o_head, sw.i_head, sw.bl, sw.t_hi, sw.t_cls, sw.st_head, sw.st_tail})
 				HIP_CHECK(hipMemsetAsync(p, 0xFF, T * 4, s));
 			HIP_CHECK(hipMemsetAsync(sw.ctr, 0xFF, z.nS * 4, s));

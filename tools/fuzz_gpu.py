@@ -1,0 +1,44 @@
+"""Differential fuzz of the HIP path against the oracle (run on the GPU box)."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import oracle_lib as O
+from povu_amd import HipDecomposer, workloads as W
+from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+hip = HipDecomposer(0)
+rng = np.random.default_rng(12345)
+t0 = time.time(); n_graphs = 0; n_links = 0
+while time.time() - t0 < budget:
+    seed = int(rng.integers(1 << 30))
+    kind = n_graphs % 6
+    if kind == 0:
+        n = int(rng.integers(3, 40)); g = W.random_bidirected(n, int(n * rng.uniform(0.8, 3.5)), seed)
+    elif kind == 1:
+        n = int(rng.integers(40, 400)); g = W.random_bidirected(n, int(n * rng.uniform(1.0, 2.2)), seed, connected=True)
+    elif kind == 2:
+        n = int(rng.integers(400, 4000)); g = W.random_bidirected(n, int(n * rng.uniform(1.0, 1.6)), seed)
+    elif kind == 3:
+        g = W.hprc_shaped([int(rng.integers(50, 3000)) for _ in range(int(rng.integers(1, 5)))], seed=seed, tiny=int(rng.integers(0, 20)))
+    elif kind == 4:
+        n = int(rng.integers(10, 200)); g = W.random_bidirected(n, int(n * rng.uniform(1.5, 4.0)), seed, self_loops=True, connected=True)
+    else:
+        # chains with random extra links (long bridge chains + local tangles)
+        base = W.chain_of_bubbles(int(rng.integers(5, 300)))
+        extra = W.random_bidirected(base.n_vtx, int(base.n_vtx * rng.uniform(0.0, 0.3)), seed)
+        g = W._mk(base.vid, np.concatenate([base.v1, extra.v1]), np.concatenate([base.s1, extra.s1]),
+                  np.concatenate([base.v2, extra.v2]), np.concatenate([base.s2, extra.s2]))
+    tips = None
+    if n_graphs % 11 == 0:
+        tips = np.zeros(g.n_vtx, dtype=np.uint8)  # builder-style graphs without tips
+    want = O.decompose(g, tips=tips)
+    hip.upload(g, tips)
+    flags = [0, F_SEQ_TREE, F_HAIRPINS][n_graphs % 3]
+    got = hip.decompose(flags=flags).texts()
+    if got != want:
+        print('MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', flags, 'tips', tips is not None)
+        np.savez('gpurun_out/fuzz_fail.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
+        sys.exit(1)
+    n_graphs += 1; n_links += g.n_links
+print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's')
