@@ -82,6 +82,25 @@ typedef struct {
  */
 povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip_opts *opts, char *err, size_t errlen);
 
+/*
+ * Row B on its own (what `povu info` and `povu prune` need, app/subcommand/info.cpp:19-45,
+ * prune.cpp:17-41): the components exactly as bd::VG::componetize builds them -- ordered by minimum
+ * vertex idx, vertices ascending, links in first-encounter order stored from the encountering side,
+ * self loops as (ve, complement(ve)) (bidirected.cpp:552-569, :66-77).
+ */
+typedef struct {
+	uint32_t n_components;
+	uint32_t n_vtx, n_links;
+	const uint32_t *vtx_off;  /* [n_components + 1] component c owns vertices [vtx_off[c], vtx_off[c+1]) */
+	const uint32_t *link_off; /* [n_components + 1] */
+	const uint32_t *vtx_id;	  /* [n_vtx] segment id, local vertex order, component-major */
+	const uint8_t *vtx_tip;	  /* [n_vtx] POVU_TIP_* */
+	const uint32_t *l_v1, *l_v2; /* [n_links] LOCAL vertex idx of the two ends, local link order */
+	const uint8_t *l_s1, *l_s2;  /* [n_links] sides */
+} povu_hip_components;
+povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *err, size_t errlen);
+void povu_hip_components_free(povu_hip_components *c);
+
 /* components of the WHOLE graph (all shards), including skipped ones */
 uint32_t povu_hip_forest_total_components(const povu_hip_forest *f);
 /* PVSTs held by this forest (this shard's components with >= 3 vertices) */

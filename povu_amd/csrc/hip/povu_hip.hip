@@ -190,8 +190,10 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 			throw HipError("null context");
 		if (n_vtx == 0)
 			throw HipError("graph has no vertices");
-		if (n_vtx > 0x7FFFFFF0u || n_links > 0x7FFFFFF0u)
-			throw HipError("graph too large for 32-bit indices (the reference has the same limit, core.hpp:20-21)");
+		// 32-bit index spaces: 4 arcs / events per segment must stay below 2^29 (packed list-ranking
+		// words), links below 2^31.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
+		if (n_vtx >= (1u << 27) || n_links > 0x7FFFFFF0u)
+			throw HipError("graph too large for this build: at most 134 217 727 segments and 2 147 483 632 links");
 		// operand validation on the host: the kernels index by these values unchecked
 		for (uint32_t e = 0; e < n_links; e++)
 			if (v1[e] >= n_vtx || v2[e] >= n_vtx || s1[e] > 1 || s2[e] > 1)
@@ -374,6 +376,81 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 	return total + (1 << 20);
 }
 } // namespace
+
+namespace
+{
+struct ComponentsOwner {
+	povu_hip_components view{};
+	std::vector<uint32_t> voff, eoff, vid, v1, v2;
+	std::vector<uint8_t> tip, s1, s2;
+};
+} // namespace
+
+extern "C" povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *err, size_t errlen)
+{
+	try {
+		if (!ctx || !ctx->g.block)
+			throw HipError("no graph resident: call povu_hip_graph_upload first");
+		HIP_CHECK(hipSetDevice(ctx->device));
+		const ResidentGraph &g = ctx->g;
+		hipStream_t s = ctx->stream;
+		Sizes z;
+		z.V = g.V;
+		z.E = g.E;
+		z.Cmax = g.V;
+		z.nS = 2 * z.V;
+		z.slots = g.n_slots;
+		z.T = z.B = 0;
+		CompState &cs = ctx->cs;
+		SeqWs &sw = ctx->sw;
+		ctx->have_state = false;
+		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, false));
+		carve_workspace(&ctx->ws, 0, z, cs, sw, false);
+		StageTimer &tm = ctx->timer;
+		tm.reset();
+		const uint32_t C = label_components(g, cs, tm, s);
+		reindex_components(g, cs, C, tm, s);
+		auto o = std::make_unique<ComponentsOwner>();
+		const size_t V = g.V, E = g.E;
+		o->voff.resize(C + 1);
+		o->eoff.resize(C + 1);
+		o->vid.resize(V);
+		o->tip.resize(V);
+		std::vector<uint32_t> la(E), lb(E);
+		HIP_CHECK(hipMemcpyAsync(o->voff.data(), cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(o->eoff.data(), cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(o->vid.data(), cs.gid_s, V * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(o->tip.data(), cs.tip_s, V, hipMemcpyDeviceToHost, s));
+		if (E) {
+			HIP_CHECK(hipMemcpyAsync(la.data(), cs.la, E * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(lb.data(), cs.lb, E * 4, hipMemcpyDeviceToHost, s));
+		}
+		HIP_CHECK(hipStreamSynchronize(s));
+		o->v1.resize(E);
+		o->v2.resize(E);
+		o->s1.resize(E);
+		o->s2.resize(E);
+		for (uint32_t c = 0; c < C; c++)
+			for (uint32_t e = o->eoff[c]; e < o->eoff[c + 1]; e++) { // sorted side id = 2 * position + end
+				o->v1[e] = (la[e] >> 1) - o->voff[c];
+				o->s1[e] = (uint8_t)(la[e] & 1);
+				o->v2[e] = (lb[e] >> 1) - o->voff[c];
+				o->s2[e] = (uint8_t)(lb[e] & 1);
+			}
+		o->view = povu_hip_components{C, g.V, g.E, o->voff.data(), o->eoff.data(), o->vid.data(), o->tip.data(),
+					      o->v1.data(), o->v2.data(), o->s1.data(), o->s2.data()};
+		ComponentsOwner *raw = o.release();
+		return &raw->view; // view is the first member: the owner is recovered from it in _free
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+extern "C" void povu_hip_components_free(povu_hip_components *c)
+{
+	delete reinterpret_cast<ComponentsOwner *>(c);
+}
 
 extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components)
 {

@@ -17,7 +17,9 @@ static void usage(std::ostream &os)
 	      "  OPTIONS:\n\n"
 	      "      commands\n"
 	      "        decompose                         Find regions of variation\n"
-	      "        gfa2vcf, call, info, prune, vcf   (not part of the MI355X decompose build)\n"
+	      "        info                              Print graph information [uses 1 thread]\n"
+	      "        prune                             Reduce GFA to graph structure\n"
+	      "        gfa2vcf, call, vcf                (not part of the MI355X decompose build)\n"
 	      "      arguments\n"
 	      "        --version                         The current version of povu\n"
 	      "        -v[verbosity],\n"
@@ -36,7 +38,7 @@ int main(int argc, char **argv)
 {
 	povu_host::Config cfg;
 	std::string command;
-	bool version = false, help = false, have_input = false;
+	bool version = false, help = false, have_input = false, print_tips = false;
 	auto value = [&](int &i, const char *a, const char *shortf, const char *longf, std::string &out) -> bool {
 		const size_t ls = strlen(shortf), ll = strlen(longf);
 		if (!strncmp(a, longf, ll) && a[ll] == '=') {
@@ -67,12 +69,14 @@ int main(int argc, char **argv)
 			help = true;
 		} else if (value(i, a, "-v", "--verbosity", v)) {
 			cfg.verbosity = atoi(v.c_str());
+		} else if (command == "info" && (!strcmp(a, "-t") || !strcmp(a, "--print_tips"))) {
+			print_tips = true; // inside `info`, -t means "print the tips" (cli.cpp:220)
 		} else if (value(i, a, "-t", "--threads", v)) {
 			cfg.threads = atoi(v.c_str());
-		} else if (command == "decompose" && value(i, a, "-i", "--input-gfa", v)) {
+		} else if ((command == "decompose" || command == "info" || command == "prune") && value(i, a, "-i", "--input-gfa", v)) {
 			cfg.input_gfa = v;
 			have_input = true;
-		} else if (command == "decompose" && value(i, a, "-o", "--output-dir", v)) {
+		} else if ((command == "decompose" || command == "prune") && value(i, a, "-o", "--output-dir", v)) {
 			cfg.output_dir = v;
 		} else if (command == "decompose" && (!strcmp(a, "-h") || !strcmp(a, "--hairpins"))) {
 			cfg.hairpins = true;
@@ -96,8 +100,8 @@ int main(int argc, char **argv)
 		usage(std::cout);
 		return 0;
 	}
-	if (command != "decompose") {
-		std::cerr << "povu (MI355X build): only the `decompose` subcommand is provided; `" << command
+	if (command != "decompose" && command != "info" && command != "prune") {
+		std::cerr << "povu (MI355X build): only `decompose`, `info` and `prune` are provided; `" << command
 			  << "` belongs to the reference CPU tool" << std::endl;
 		return 1;
 	}
@@ -108,6 +112,12 @@ int main(int argc, char **argv)
 	}
 	if (const char *d = std::getenv("POVU_HIP_DEVICE"))
 		cfg.device = atoi(d);
-	povu_host::do_decompose(cfg); // exceptions propagate like in the reference (uncaught -> terminate)
+	// exceptions propagate like in the reference (uncaught -> terminate)
+	if (command == "info")
+		povu_host::do_info(cfg, print_tips);
+	else if (command == "prune")
+		povu_host::do_prune(cfg);
+	else
+		povu_host::do_decompose(cfg);
 	return 0;
 }

@@ -3,6 +3,7 @@
 #include "../../../include/povu_hip.h"
 #include "gfa.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -123,6 +124,97 @@ void do_decompose(const Config &cfg)
 	povu_hip_destroy(ctx);
 	if (failed)
 		std::exit(EXIT_FAILURE);
+}
+
+namespace
+{
+povu_hip_components *components_of(const Config &cfg, povu_hip_ctx **ctx_out)
+{
+	GfaGraph g = load_gfa(cfg.input_gfa);
+	char err[512] = {0};
+	povu_hip_ctx *ctx = povu_hip_create(cfg.device, err, sizeof err);
+	if (!ctx)
+		throw std::runtime_error(std::string("povu_hip: ") + err);
+	if (povu_hip_graph_upload(ctx, (uint32_t)g.vid.size(), g.vid.data(), (uint32_t)g.v1.size(), g.v1.data(), g.s1.data(),
+				  g.v2.data(), g.s2.data(), nullptr, err, sizeof err) != 0) {
+		povu_hip_destroy(ctx);
+		throw std::runtime_error(std::string("povu_hip: ") + err);
+	}
+	povu_hip_components *c = povu_hip_componetize(ctx, err, sizeof err);
+	if (!c) {
+		povu_hip_destroy(ctx);
+		throw std::runtime_error(std::string("povu_hip: ") + err);
+	}
+	*ctx_out = ctx;
+	return c;
+}
+} // namespace
+
+void do_info(const Config &cfg, bool print_tips)
+{
+	povu_hip_ctx *ctx = nullptr;
+	povu_hip_components *c = components_of(cfg, &ctx);
+	std::cerr << "[povu::main::do_info] Component count " << c->n_components << "\n";
+	for (uint32_t k = 0; k < c->n_components; k++) { // VG::summary
+		const uint32_t v0 = c->vtx_off[k], v1 = c->vtx_off[k + 1];
+		// tips_ is a std::set ordered by (id, then l < r), types.cpp:60-68
+		std::vector<std::pair<uint32_t, uint8_t>> tips;
+		for (uint32_t v = v0; v < v1; v++)
+			if (c->vtx_tip[v])
+				tips.emplace_back(c->vtx_id[v], c->vtx_tip[v]);
+		std::sort(tips.begin(), tips.end());
+		std::cout << "Bidirected Graph: " << std::endl;
+		std::cout << "\t" << "vertex count: " << (v1 - v0) << std::endl;
+		std::cout << "\t" << "edge count: " << (c->link_off[k + 1] - c->link_off[k]) << std::endl;
+		std::cout << "\t" << "Tip count " << tips.size() << std::endl;
+		if (print_tips) {
+			std::cerr << "\t" << "Tips: ";
+			std::cout << "\t";
+			for (size_t i = 0; i < tips.size(); i++) { // operator<<(side_n_id_t): id then +/- (types.cpp:26-33,70-74)
+				std::cout << tips[i].first << (tips[i].second == POVU_TIP_L ? "+" : "-");
+				if (i + 1 < tips.size())
+					std::cout << ", ";
+			}
+			std::cout << std::endl;
+		}
+	}
+	povu_hip_components_free(c);
+	povu_hip_destroy(ctx);
+}
+
+void do_prune(const Config &cfg)
+{
+	const int ll = cfg.verbosity;
+	povu_hip_ctx *ctx = nullptr;
+	if (ll > 1)
+		info("Finding components");
+	povu_hip_components *c = components_of(cfg, &ctx);
+	if (ll > 1)
+		info("Found " + std::to_string(c->n_components) + " components");
+	for (uint32_t k = 0; k < c->n_components; k++) { // write_gfa, to_gfa.cpp:13-56
+		const std::string fp = cfg.output_dir + "/component_" + std::to_string(k + 1) + ".gfa";
+		FILE *o = fopen(fp.c_str(), "wb");
+		if (!o) {
+			std::cerr << "ERR Could not open file " << fp << " for writing" << std::endl;
+			continue;
+		}
+		fputs("H\tVN:Z:1.0\n", o);
+		const uint32_t v0 = c->vtx_off[k];
+		for (uint32_t v = v0; v < c->vtx_off[k + 1]; v++)
+			fprintf(o, "S\t%u\tA\n", c->vtx_id[v]);
+		for (uint32_t e = c->link_off[k]; e < c->link_off[k + 1]; e++) {
+			const uint32_t a = c->l_v1[e], b = c->l_v2[e];
+			const char *ea = "+", *eb = "+"; // a self loop is always written `+ +` (to_gfa.cpp:24-25)
+			if (a != b) {
+				ea = c->l_s1[e] == POVU_SIDE_R ? "+" : "-";
+				eb = c->l_s2[e] == POVU_SIDE_L ? "+" : "-";
+			}
+			fprintf(o, "L\t%u\t%s\t%u\t%s\t0M\n", c->vtx_id[v0 + a], ea, c->vtx_id[v0 + b], eb);
+		}
+		fclose(o);
+	}
+	povu_hip_components_free(c);
+	povu_hip_destroy(ctx);
 }
 
 } // namespace povu_host

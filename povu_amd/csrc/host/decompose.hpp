@@ -23,4 +23,10 @@ struct Config {
 // unwritable output -> message + exit(EXIT_FAILURE) (to_pvst.cpp:39-42).
 void do_decompose(const Config &cfg);
 
+// `povu info` (app/subcommand/info.cpp:19-45 + VG::summary, bidirected.cpp:368-380) and `povu prune`
+// (app/subcommand/prune.cpp:17-41 + mto::to_gfa::write_gfa, src/mto/to_gfa.cpp:13-56): both only need
+// the components of row B.
+void do_info(const Config &cfg, bool print_tips);
+void do_prune(const Config &cfg);
+
 } // namespace povu_host

@@ -413,3 +413,50 @@ def test_hairpin_boundaries_parallel_and_sequential(hip):
             assert got == want, (seed, flags)
         assert hip.decompose(flags=F_HAIRPINS).texts() == O.decompose(g)
     assert n_with >= 10  # the sample does exercise hairpins
+
+
+def test_cli_info_and_prune(tmp_path):
+    """`povu info` / `povu prune` reuse row B: component order, local vertex / link order, tips."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    povu = os.path.join(root, "povu_amd", "bin", "povu")
+    g = W.random_bidirected(90, 120, 4711)
+    gfa = tmp_path / "g.gfa"
+    gfa.write_text(g.to_gfa())
+    out = tmp_path / "pruned"
+    out.mkdir()
+    comps = []
+    c = 0
+    while True:
+        d = dump_component(g, c)
+        if d is None:
+            break
+        comps.append(d)
+        c += 1
+    # loader tips of the whole graph
+    deg = np.zeros((g.n_vtx, 2), dtype=np.int64)
+    for a, sa, b, sb in zip(g.v1.tolist(), g.s1.tolist(), g.v2.tolist(), g.s2.tolist()):
+        deg[a, sa] += 1
+        if not (a == b and sa == sb):
+            deg[b, sb] += 1
+    tip = {int(g.vid[v]): ("+" if deg[v, 0] == 0 else "-") for v in range(g.n_vtx) if deg[v, 0] == 0 or deg[v, 1] == 0}
+    r = subprocess.run([povu, "info", "-i", str(gfa), "-t"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr.startswith(f"[povu::main::do_info] Component count {len(comps)}\n")
+    exp = ""
+    for d in comps:
+        ids = sorted(int(g.vid[v]) for v in d["gidx"].tolist())
+        tl = [f"{i}{tip[i]}" for i in ids if i in tip]
+        exp += f"Bidirected Graph: \n\tvertex count: {len(ids)}\n\tedge count: {len(d['ev1'])}\n\tTip count {len(tl)}\n"
+        exp += "\t" + ", ".join(tl) + "\n"
+    assert r.stdout == exp
+    r = subprocess.run([povu, "prune", "-i", str(gfa), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for k, d in enumerate(comps):
+        ids = [int(g.vid[v]) for v in d["gidx"].tolist()]
+        text = "H\tVN:Z:1.0\n" + "".join(f"S\t{i}\tA\n" for i in ids)
+        for a, sa, b, sb in zip(d["ev1"].tolist(), d["es1"].tolist(), d["ev2"].tolist(), d["es2"].tolist()):
+            ea, eb = ("+", "+") if a == b else ("+" if sa == 1 else "-", "+" if sb == 0 else "-")
+            text += f"L\t{ids[a]}\t{ea}\t{ids[b]}\t{eb}\t0M\n"
+        assert (out / f"component_{k + 1}.gfa").read_text() == text, k
+    assert len(list(out.glob("*.gfa"))) == len(comps)
