@@ -239,6 +239,39 @@ __global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32
 	atomicAdd(&incnt[b_tgt[j]], 1u);
 	atomicAdd(&srccnt[m], 1u); // brackets per mirror pre-order position -> range starts
 }
+// With the per-source rank of every ordinary edge known (parallel tree stage), the list order needs no
+// sort: a bracket's position = (first bracket of its source's mirror pre-order position) + its rank
+// inside the source (simplifying, capping, ordinary edges top first).
+__global__ void k_bracket_count(uint32_t NB, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
+				const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt, uint32_t *__restrict__ srccnt)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB)
+		return;
+	atomicAdd(&incnt[b_tgt[j]], 1u);
+	atomicAdd(&srccnt[mpre[b_src[j]]], 1u);
+}
+__global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ b_src,
+				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ b_ord,
+				const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
+				const uint32_t *__restrict__ capf, const uint32_t *__restrict__ simp,
+				uint32_t *__restrict__ tgtR, uint32_t *__restrict__ rid)
+{
+	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB)
+		return;
+	const uint32_t v = b_src[j];
+	uint32_t rank;
+	if (j < NB0)
+		rank = capf[v] + simp[v] + b_ord[j];
+	else if (j < NB0 + ncap)
+		rank = simp[v];
+	else
+		rank = 0;
+	const uint32_t pos = bstart[mpre[v]] + rank;
+	tgtR[pos] = b_tgt[j];
+	rid[pos] = j;
+}
 __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src,
 			     uint32_t *__restrict__ dst)
 {
@@ -628,7 +661,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.keys_t, (T + 2) * 8);
 	take((void **)&pw.keys_t2, (T + 2) * 8);
 	take((void **)&pw.dbo, (Cmax + 2) * 4);
-	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_val, &pw.b_val2, &pw.tgtR})
+	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_val, &pw.b_val2, &pw.tgtR, &pw.b_ord})
 		take((void **)p, (NB + 2) * 4);
 	take((void **)&pw.b_key, (NB + 2) * 8);
 	take((void **)&pw.b_key2, (NB + 2) * 8);
@@ -738,12 +771,20 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	HIP_CHECK(hipMemsetAsync(srccnt, 0, ((size_t)T + 2) * 4, s));
 	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt);
-	uint32_t *bk = (uint32_t *)pw.b_key, *bk2 = (uint32_t *)pw.b_key2;
-	LAUNCH(k_bracket_order, NB, s, NB, NB0, ncap, nsimp, pw.b_src, pw.b_tgt, pw.mpre, bk, pw.b_val, pw.incnt, srccnt);
-	scan(pw.incnt, pw.psin, (size_t)T + 1);
-	scan(srccnt, bstart, (size_t)T + 1);
-	sort_pairs_u32(bk, bk2, pw.b_val, pw.b_val2, NB, bits_for(T), pw.sort_tmp, pw.sort_tmp_bytes, s);
-	LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
+	if (dense_nb0 >= 0) { // ranks inside every source are known: place directly
+		LAUNCH(k_bracket_count, NB, s, NB, pw.b_src, pw.b_tgt, pw.mpre, pw.incnt, srccnt);
+		scan(pw.incnt, pw.psin, (size_t)T + 1);
+		scan(srccnt, bstart, (size_t)T + 1);
+		LAUNCH(k_bracket_place, NB, s, NB, NB0, ncap, pw.b_src, pw.b_tgt, pw.b_ord, pw.mpre, bstart, capf, simp, pw.tgtR,
+		       pw.b_val2);
+	} else {
+		uint32_t *bk = (uint32_t *)pw.b_key, *bk2 = (uint32_t *)pw.b_key2;
+		LAUNCH(k_bracket_order, NB, s, NB, NB0, ncap, nsimp, pw.b_src, pw.b_tgt, pw.mpre, bk, pw.b_val, pw.incnt, srccnt);
+		scan(pw.incnt, pw.psin, (size_t)T + 1);
+		scan(srccnt, bstart, (size_t)T + 1);
+		sort_pairs_u32(bk, bk2, pw.b_val, pw.b_val2, NB, bits_for(T), pw.sort_tmp, pw.sort_tmp_bytes, s);
+		LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
+	}
 	seg_build(pw.segB, pw.tgtR, NB, s);
 	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
 	LAUNCH(k_top_bracket, T, s, T, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck, pw.vals_t,

@@ -514,38 +514,43 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 }
 
 // ------------------------------------------------------------------ 7. pre-order of the union tree
-// children of every side ordered by the parent's scan slot: LSD = two stable 32-bit radix sorts,
-// by slot first (a few bits), then by parent (roots / unprocessed sides carry NIL and end up last)
-__global__ void k_child_keys(uint32_t nS, const uint32_t *__restrict__ cslot, uint32_t *__restrict__ key,
-			     uint32_t *__restrict__ val)
+// Children of every side in the order of the parent's scan slots, without a sort: side P owns
+// deg(P)+1 scan slots (black edge, then its links) at [loff[P] + P, ...); every child drops itself
+// into the slot it was discovered through (at most one child per slot), then each parent strings
+// its non-empty slots together.
+__global__ void k_child_scatter(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
+				const uint32_t *__restrict__ loff, uint32_t *__restrict__ slot_child)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	key[S] = cslot[S];
-	val[S] = S;
+	uint32_t p = dpar[S];
+	if (p != NIL)
+		slot_child[loff[p] + p + cslot[S]] = S;
 }
-__global__ void k_gather_parent(uint32_t nS, const uint32_t *__restrict__ val, const uint32_t *__restrict__ dpar,
-				uint32_t *__restrict__ key)
+__global__ void k_child_link(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ slot_child,
+			     const uint32_t *__restrict__ dpar, uint32_t *__restrict__ fc, uint32_t *__restrict__ nsib)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q < nS)
-		key[q] = dpar[val[q]];
-}
-__global__ void k_child_links(uint32_t nS, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
-			      uint32_t *__restrict__ fc, uint32_t *__restrict__ nsib)
-{
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= nS)
+	uint32_t P = blockIdx.x * blockDim.x + threadIdx.x;
+	if (P >= nS)
 		return;
-	uint32_t p = key[q], S = val[q];
-	if (p == NIL) {
-		nsib[S] = NIL;
-		return;
+	const uint32_t base = loff[P] + P, n = loff[P + 1] - loff[P] + 1;
+	uint32_t first = NIL, prev = NIL;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t c = slot_child[base + k];
+		if (c == NIL)
+			continue;
+		if (prev == NIL)
+			first = c;
+		else
+			nsib[prev] = c;
+		prev = c;
 	}
-	if (q == 0 || key[q - 1] != p)
-		fc[p] = S;
-	nsib[S] = (q + 1 < nS && key[q + 1] == p) ? val[q + 1] : NIL;
+	if (prev != NIL)
+		nsib[prev] = NIL;
+	fc[P] = first;
+	if (dpar[P] == NIL)
+		nsib[P] = NIL; // roots (and sides of unprocessed components) have no siblings
 }
 // events: 2S = enter S, 2S+1 = leave S
 __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
@@ -626,7 +631,8 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 			     const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ side_tidx,
 			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
 			     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ be_cnt,
-			     const uint32_t *__restrict__ be_ps, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
+			     const uint32_t *__restrict__ be_ps, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
+			     uint32_t *__restrict__ b_ord)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -640,6 +646,7 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 			if (EMIT) {
 				b_src[at + n] = p;
 				b_tgt[at + n] = tgt;
+				b_ord[at + n] = be_cnt[S] - 1 - n; // later pushed = nearer the top of the bracket list
 			}
 			n++;
 		};
@@ -690,8 +697,8 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
-	take((void **)&tw.ckey, nS * 8);
-	take((void **)&tw.ckey2, nS * 8);
+	take((void **)&tw.ckey, (nS + 2 * E + 8) * 4); // scan-slot -> child table of the child ordering
+	take((void **)&tw.ckey2, 64);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	for (uint32_t **p : {&tw.rk_has_pred, &tw.rk_flag, &tw.rk_ps})
 		take((void **)p, NA * 4);
@@ -790,13 +797,14 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 7. pre-order, sizes, depths
 	tm.begin("tree_preorder");
-	uint32_t *ck = (uint32_t *)tw.ckey, *ck2 = (uint32_t *)tw.ckey2;
-	LAUNCH(k_child_keys, nS, s, nS, tw.cslot, ck, tw.cval);
-	sort_pairs_u32(ck, ck2, tw.cval, tw.cval2, nS, bits_for((uint64_t)max_side_links + 2), pw.sort_tmp, pw.sort_tmp_bytes, s);
-	LAUNCH(k_gather_parent, nS, s, nS, tw.cval2, tw.dpar, ck);
-	sort_pairs_u32(ck, ck2, tw.cval2, tw.cval, nS, bits_for((uint64_t)nS + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
-	fill_u32(tw.fc, nS, NIL, s);
-	LAUNCH(k_child_links, nS, s, nS, ck2, tw.cval, tw.fc, tw.nsib);
+	{
+		const size_t n_scan_slots = (size_t)nS + 2 * (size_t)E;
+		uint32_t *slot_child = reinterpret_cast<uint32_t *>(tw.ckey); // [nS + 2E] (see tree_spans)
+		HIP_CHECK(hipMemsetAsync(slot_child, 0xFF, n_scan_slots * 4, s));
+		LAUNCH(k_child_scatter, nS, s, nS, tw.dpar, tw.cslot, cs.loff, slot_child);
+		LAUNCH(k_child_link, nS, s, nS, cs.loff, slot_child, tw.dpar, tw.fc, tw.nsib);
+		(void)max_side_links;
+	}
 	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA);
 	// one list per processed component, one two-event list per side of an unprocessed one
 	list_rank_splitters<true>(2 * nS, tw.nxtA, tw.cntA, tw.cntB, tw.depB, event_lists, rb, s);
@@ -810,11 +818,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_tree_roots, C, s, C, tw.cproc, cs.voff, start_key, sw.t_gid, sw.t_flags, sw.t_par, sw.t_size, sw.t_depth,
 	       sw.c_ntree);
 	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
-	       tw.be_ps, pw.b_src, pw.b_tgt);
+	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord);
 	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
 	const uint32_t NB0 = read_u32(tw.be_ps + nS, s);
 	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
-	       tw.be_ps, pw.b_src, pw.b_tgt);
+	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord);
 	tm.end(6);
 	return NB0;
 }
