@@ -116,6 +116,8 @@ struct StageTimer {
 // device-wide primitives (primitives.hip)
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
 size_t scan_tmp_bytes(size_t n);
+// exclusive running maximum (identity 0)
+void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
 // stable LSD radix sort of (key,value) pairs on the low `bits` bits of the key
 void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
 		    void *tmp, size_t tmp_bytes, hipStream_t s);

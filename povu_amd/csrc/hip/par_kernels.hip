@@ -394,7 +394,8 @@ __global__ void k_black_flag(uint32_t T, const uint32_t *__restrict__ inv, const
 __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const uint32_t *__restrict__ flag,
 			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
 			     const uint32_t *__restrict__ t_comp, uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls,
-			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ s_iota)
+			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns,
+			     uint32_t *__restrict__ prev)
 {
 	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= T || !flag[m])
@@ -403,7 +404,9 @@ __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const
 	s_vtx[i] = v;
 	s_cls[i] = gcls[v];
 	s_comp[i] = t_comp[v];
-	s_iota[i] = i;
+	sidx[v] = i;
+	ns[i] = i; // "no later occurrence" until k_next_from_runs says otherwise (flubbles.cpp:391-399)
+	prev[i] = NIL;
 }
 __global__ void k_stack_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ ps,
 				uint32_t T, uint32_t *__restrict__ soff)
@@ -415,17 +418,34 @@ __global__ void k_stack_offsets(uint32_t C, const uint32_t *__restrict__ voff, c
 }
 
 // ------------------------------------------------------------- row F
-__global__ void k_next_prev(uint32_t S, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-			    uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
+// next_seen without another sort.  The class stage already grouped the tree vertices by top bracket
+// with every group ordered from the deepest vertex up, and a class is a run inside a group.  The
+// members of a class lie on one root-to-leaf path, so their order in the candidate stack is their
+// order by depth: for consecutive BLACK members (deeper d, shallower u) of a run, next_seen[u] = d.
+__global__ void k_black_marks(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+			      const uint8_t *__restrict__ tf, uint32_t *__restrict__ mark)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= S)
+	if (q >= T)
 		return;
-	uint32_t i = sval[q];
-	bool has_next = q + 1 < S && skey[q + 1] == skey[q];
-	ns[i] = has_next ? sval[q + 1] : i;
-	bool has_prev = q > 0 && skey[q - 1] == skey[q];
-	prev[i] = has_prev ? sval[q - 1] : NIL;
+	mark[q] = (skey[q] != NIL && (tf[sval[q]] & TF_BLACK)) ? q + 1 : 0;
+}
+__global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, const uint32_t *__restrict__ lastb,
+				 const uint32_t *__restrict__ sval, const uint32_t *__restrict__ gcls,
+				 const uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= T || !mark[q])
+		return;
+	const uint32_t p = lastb[q]; // 1 + position of the previous black entry of the sorted order
+	if (!p)
+		return;
+	const uint32_t u = sval[q], d = sval[p - 1];
+	if (gcls[u] != gcls[d])
+		return;
+	const uint32_t iu = sidx[u], id = sidx[d];
+	ns[iu] = id;
+	prev[id] = iu;
 }
 
 // ------------------------------------------------------------- row G
@@ -808,18 +828,21 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	uint32_t *bflag = pw.flagB, *bps = pw.psB;
 	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
 	scan(bflag, bps, (size_t)T + 1);
-	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.s_val);
+	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
+	       pw.prev);
 	LAUNCH(k_stack_offsets, (size_t)C + 1, s, C, cs.voff, bps, T, pw.soff);
 	const uint32_t S = read_u32(bps + T, s);
-	const uint32_t n_class = read_u32(cps + T, s);
 	tm.end(9);
 
 	// ---- row F
 	tm.begin("par_next_seen");
-	sort_pairs_u32(pw.s_cls, pw.s_key2, pw.s_val, pw.s_val2, S, bits_for((uint64_t)n_class + 1), pw.sort_tmp,
-		       pw.sort_tmp_bytes, s);
-	LAUNCH(k_next_prev, S, s, S, pw.s_key2, pw.s_val2, pw.ns, pw.prev);
-	tm.end(2);
+	{
+		uint32_t *mark = pw.flagC, *lastb = pw.psC; // capping flags are dead by now
+		LAUNCH(k_black_marks, T, s, T, ck2, pw.vals_t2, sw.t_flags, mark);
+		scan_exclusive_max_u32(mark, lastb, T, pw.scan_tmp, pw.scan_tmp_bytes, s);
+		LAUNCH(k_next_from_runs, T, s, T, mark, lastb, pw.vals_t2, pw.gcls, pw.topi, pw.ns, pw.prev);
+	}
+	tm.end(4);
 
 	// ---- row G
 	tm.begin("par_pvst");

@@ -22,6 +22,13 @@ void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, 
 	HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
 }
 
+void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	if (n == 0)
+		return;
+	HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::maximum<uint32_t>(), s));
+}
+
 size_t sort_tmp_bytes(size_t n)
 {
 	size_t bytes = 0;
