@@ -460,3 +460,32 @@ def test_cli_info_and_prune(tmp_path):
             text += f"L\t{ids[a]}\t{ea}\t{ids[b]}\t{eb}\t0M\n"
         assert (out / f"component_{k + 1}.gfa").read_text() == text, k
     assert len(list(out.glob("*.gfa"))) == len(comps)
+
+
+def test_independent_contexts_run_concurrently():
+    """povu-rs marks handles Send and uses independent ones from several threads (builder_tests.rs:106-137):
+    two contexts on the same GPU decomposing different graphs at the same time."""
+    import threading
+    graphs = [W.hprc_shaped([3000 + 500 * i, 700], seed=50 + i, tiny=10) for i in range(4)]
+    want = [O.decompose(g) for g in graphs]
+    got = [None] * len(graphs)
+    errs = []
+
+    def work(k):
+        try:
+            d = HipDecomposer(0)
+            for rep in range(3):
+                d.upload(graphs[k])
+                got[k] = d.decompose().texts()
+                assert got[k] == want[k]
+            d.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(len(graphs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert got == want
