@@ -711,7 +711,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segH2.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	take((void **)&pw.segH3.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	pw.scan_tmp_bytes = scan_tmp_bytes(std::max(T, NB) + 4);
-	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), 4 * V + 8) + 4);
+	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), std::max(4 * V, 2 * E) + 8) + 4);
 	take(&pw.scan_tmp, pw.scan_tmp_bytes);
 	take(&pw.sort_tmp, pw.sort_tmp_bytes);
 }

@@ -632,7 +632,7 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
 			     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ be_cnt,
 			     const uint32_t *__restrict__ be_ps, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
-			     uint32_t *__restrict__ b_ord)
+			     uint32_t *__restrict__ b_ord, const uint8_t *__restrict__ dupflag)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -668,11 +668,15 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 				if (x > p || o == dp)
 					continue;
 				bool dup = false;
-				for (uint32_t j = lo; j < k; j++)
-					if (ladj[j] == o) {
-						dup = true;
-						break;
-					}
+				if (dupflag) {
+					dup = dupflag[k] != 0;
+				} else {
+					for (uint32_t j = lo; j < k; j++)
+						if (ladj[j] == o) {
+							dup = true;
+							break;
+						}
+				}
 				if (!dup)
 					out(x);
 			}
@@ -682,12 +686,49 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 		be_cnt[S] = n;
 }
 
+// Repeated links of one side (same far side) beyond the first: only the first can become a back edge.
+// Sides with few links find them by looking back over their own list; when some side has many links
+// the look-back is quadratic, so the flags come from a stable two-key radix sort of all slots instead.
+__global__ void k_slot_keys(uint32_t n, const uint32_t *__restrict__ ladj, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n) {
+		key[k] = ladj[k];
+		val[k] = k;
+	}
+}
+__global__ void k_slot_side(uint32_t nS, const uint32_t *__restrict__ loff, uint32_t *__restrict__ side_of)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	for (uint32_t k = loff[S]; k < loff[S + 1]; k++)
+		side_of[k] = S;
+}
+__global__ void k_gather_keys(uint32_t n, const uint32_t *__restrict__ val, const uint32_t *__restrict__ src, uint32_t *__restrict__ key)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n)
+		key[q] = src[val[q]];
+}
+__global__ void k_dup_flags(uint32_t n, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+			    const uint32_t *__restrict__ ladj, uint8_t *__restrict__ dupflag)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n)
+		return;
+	// sorted by (side, far side), slots ascending inside equal pairs (both sorts are stable)
+	const uint32_t k = sval[q];
+	dupflag[k] = (q > 0 && skey[q - 1] == skey[q] && ladj[sval[q - 1]] == ladj[k]) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ workspace
 template <typename F>
 static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 {
-	const size_t nS = 2 * V + 2, NA = 4 * V + 8;
+	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // list-ranking buffers double as slot buffers
 	take((void **)&tw.tg_ps, (E + 2) * 4);
+	take((void **)&tw.dvis_slots, 2 * E + 8);
 	for (uint32_t **p : {&tw.arc_src, &tw.arc_dst, &tw.k1, &tw.k2, &tw.v1, &tw.v2, &tw.apos, &tw.nxtA, &tw.nxtB, &tw.cntA,
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
@@ -817,12 +858,24 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx);
 	LAUNCH(k_tree_roots, C, s, C, tw.cproc, cs.voff, start_key, sw.t_gid, sw.t_flags, sw.t_par, sw.t_size, sw.t_depth,
 	       sw.c_ntree);
+	const uint8_t *dupflag = nullptr;
+	if (max_side_links > 64 && E) { // see k_dup_flags
+		const uint32_t n_slots = 2 * E;
+		uint32_t *k1 = tw.nxtA, *k2 = tw.nxtB, *v1 = tw.cntA, *v2 = tw.cntB, *side_of = tw.depA; // free by now, >= 2E? see tree_spans
+		LAUNCH(k_slot_keys, n_slots, s, n_slots, cs.ladj, k1, v1);
+		sort_pairs_u32(k1, k2, v1, v2, n_slots, bits_for(nS), pw.sort_tmp, pw.sort_tmp_bytes, s);
+		LAUNCH(k_slot_side, nS, s, nS, cs.loff, side_of);
+		LAUNCH(k_gather_keys, n_slots, s, n_slots, v2, side_of, k1);
+		sort_pairs_u32(k1, k2, v2, v1, n_slots, bits_for(nS), pw.sort_tmp, pw.sort_tmp_bytes, s);
+		LAUNCH(k_dup_flags, n_slots, s, n_slots, k2, v1, cs.ladj, tw.dvis_slots);
+		dupflag = tw.dvis_slots;
+	}
 	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
-	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord);
+	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
 	const uint32_t NB0 = read_u32(tw.be_ps + nS, s);
 	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
-	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord);
+	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	tm.end(6);
 	return NB0;
 }

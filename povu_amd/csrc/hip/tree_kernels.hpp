@@ -20,6 +20,7 @@ struct TreeWs {
 	uint32_t *lowP, *highP;				  // [2V]
 	uint32_t *isbridge, *ecc, *dpar, *cslot;	  // [2V]
 	uint8_t *dvis;					  // [2V]
+	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint32_t *entry_flag, *entry_ps, *entry_list;	  // [2V+1]
 	uint64_t *ckey, *ckey2;				  // [2V]
 	uint32_t *cval, *cval2, *fc, *nsib;		  // [2V]

@@ -489,3 +489,19 @@ def test_independent_contexts_run_concurrently():
         t.join()
     assert not errs, errs
     assert got == want
+
+
+def test_hub_with_many_parallel_links(hip):
+    """A segment with thousands of links, many of them repeated: the duplicate-link rule of process_edge
+    (spanning_tree.cpp:379-386) goes through the sort-based flags instead of the per-side look-back."""
+    rng = np.random.default_rng(3)
+    n = 1500
+    spokes = rng.integers(1, n, size=6000)
+    links = [(0, W.R, int(v), W.L) for v in spokes] + [(int(v), W.R, int(v) % (n - 1) + 1, W.L) for v in spokes[:2000]]
+    links += [(int(v), W.R, 0, W.L) for v in spokes[:500]]
+    g = _mk(list(range(1, n + 1)), links)
+    want = O.decompose(g)
+    assert gpu_texts(hip, g) == want
+    from povu_amd.hip import F_SEQ_TREE
+    hip.upload(g)
+    assert hip.decompose(flags=F_SEQ_TREE).texts() == want
