@@ -77,7 +77,6 @@ def main():
     hip.upload(g)  # inputs resident in HBM before the timed region
     upload_s = time.perf_counter() - t_up
     # every rank holds ONE component of the job: its global component id is rank + 1
-    import numpy as np
     id_map = np.array([rank + 1], dtype=np.int64)
 
     def step():
@@ -156,7 +155,7 @@ def main():
             "upload_ms": upload_s * 1e3,
             "pcie_inclusive_value": E * world / (dt / args.steps + upload_s),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib  # CPU oracle: reported baseline only, never the product path
             k = min(args.units, 333333)
