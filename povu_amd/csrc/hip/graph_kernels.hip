@@ -443,9 +443,10 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	// stable sort of vertices by component rank: local vertex idx = rank inside the component,
 	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
 	hipLaunchKernelGGL(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a);
-	if (C == 1) { // one component: the order is already (component, idx)
-		HIP_CHECK(hipMemcpyAsync(st.ckey, st.comp_of, (size_t)V * 4, hipMemcpyDeviceToDevice, s));
-		HIP_CHECK(hipMemcpyAsync(st.perm, st.tmp_a, (size_t)V * 4, hipMemcpyDeviceToDevice, s));
+	if (C == 1) { // one component: the order is already (component, idx); the key / permutation arrays
+		      // simply alias what k_comp_of wrote (all-zero component ranks, identity permutation)
+		st.ckey = st.comp_of;
+		st.perm = st.tmp_a;
 	} else {
 		sort_pairs_u32(st.comp_of, st.ckey, st.tmp_a, st.perm, V, bits_for(C), st.sort_tmp, st.sort_tmp_bytes, s);
 	}

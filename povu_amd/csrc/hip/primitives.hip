@@ -1,5 +1,5 @@
-// primitives.hip -- device-wide scan / stable radix sort (rocPRIM) used as plumbing
-// between the hand-written decompose kernels.
+// primitives.hip -- device-wide primitives between the decompose kernels: hand-written exclusive
+// scans, rocPRIM for the stable radix sorts.
 #include "common.hpp"
 
 #include <rocprim/rocprim.hpp>
@@ -7,26 +7,135 @@
 namespace povu_hip
 {
 
-size_t scan_tmp_bytes(size_t n)
+// ---- exclusive scans (sum / max) of u32, two launches: per-chunk partials, then every block adds the
+// partials in front of it and scans its own chunk tile by tile (8 elements per lane, wave shuffles,
+// one LDS exchange per tile).  The arrays here are 1-30 M elements; the second read of the input comes
+// from L2 / Infinity Cache.
+static constexpr int SC_TPB = 256, SC_ITEMS = 8, SC_TILE = SC_TPB * SC_ITEMS, SC_MAX_BLOCKS = 1024;
+
+template <bool MAX>
+__device__ __forceinline__ uint32_t sc_op(uint32_t a, uint32_t b)
 {
-	size_t bytes = 0;
-	(void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n,
-				      rocprim::plus<uint32_t>());
-	return bytes + 256;
+	return MAX ? (a > b ? a : b) : a + b;
+}
+template <bool MAX>
+__device__ __forceinline__ uint32_t sc_block_reduce(uint32_t v, uint32_t *sh)
+{
+	for (int off = 32; off; off >>= 1)
+		v = sc_op<MAX>(v, __shfl_down(v, off));
+	if ((threadIdx.x & 63) == 0)
+		sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	uint32_t r = sc_op<MAX>(sc_op<MAX>(sh[0], sh[1]), sc_op<MAX>(sh[2], sh[3]));
+	__syncthreads();
+	return r;
+}
+template <bool MAX>
+__global__ void __launch_bounds__(SC_TPB) k_scan_partials(const uint32_t *__restrict__ in, size_t n, size_t chunk,
+							  uint32_t *__restrict__ partial)
+{
+	__shared__ uint32_t sh[4];
+	const size_t b0 = (size_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+	uint32_t acc = 0;
+	for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
+		acc = sc_op<MAX>(acc, in[i]);
+	acc = sc_block_reduce<MAX>(acc, sh);
+	if (threadIdx.x == 0)
+		partial[blockIdx.x] = acc;
+}
+template <bool MAX>
+__global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
+							size_t chunk, const uint32_t *__restrict__ partial)
+{
+	__shared__ uint32_t sh[4];
+	__shared__ uint32_t wave_tot[4];
+	uint32_t base = 0;
+	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += SC_TPB)
+		base = sc_op<MAX>(base, partial[k]);
+	uint32_t carry = sc_block_reduce<MAX>(base, sh);
+	const size_t b0 = (size_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (size_t t0 = b0; t0 < b1; t0 += SC_TILE) {
+		const size_t e0 = t0 + (size_t)threadIdx.x * SC_ITEMS;
+		uint32_t v[SC_ITEMS];
+		if (e0 + SC_ITEMS <= b1) {
+			const uint4 a = *reinterpret_cast<const uint4 *>(in + e0), b = *reinterpret_cast<const uint4 *>(in + e0 + 4);
+			v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+		} else {
+			for (int k = 0; k < SC_ITEMS; k++)
+				v[k] = e0 + k < b1 ? in[e0 + k] : 0u;
+		}
+		uint32_t tot = 0; // lane-local exclusive scan
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const uint32_t x = v[k];
+			v[k] = tot;
+			tot = sc_op<MAX>(tot, x);
+		}
+		uint32_t inc = tot; // inclusive scan of lane totals across the wave
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t y = __shfl_up(inc, off);
+			if (lane >= off)
+				inc = sc_op<MAX>(inc, y);
+		}
+		if (lane == 63)
+			wave_tot[wave] = inc;
+		__syncthreads();
+		uint32_t pre = carry; // everything in front of this lane: carry, earlier waves, earlier lanes
+		for (int w = 0; w < wave; w++)
+			pre = sc_op<MAX>(pre, wave_tot[w]);
+		const uint32_t lane_excl = __shfl_up(inc, 1);
+		if (lane > 0)
+			pre = sc_op<MAX>(pre, lane_excl);
+		const uint32_t tile_tot = sc_op<MAX>(sc_op<MAX>(wave_tot[0], wave_tot[1]), sc_op<MAX>(wave_tot[2], wave_tot[3]));
+		if (e0 + SC_ITEMS <= b1) {
+			uint4 a, b;
+			a.x = sc_op<MAX>(pre, v[0]), a.y = sc_op<MAX>(pre, v[1]), a.z = sc_op<MAX>(pre, v[2]), a.w = sc_op<MAX>(pre, v[3]);
+			b.x = sc_op<MAX>(pre, v[4]), b.y = sc_op<MAX>(pre, v[5]), b.z = sc_op<MAX>(pre, v[6]), b.w = sc_op<MAX>(pre, v[7]);
+			*reinterpret_cast<uint4 *>(out + e0) = a;
+			*reinterpret_cast<uint4 *>(out + e0 + 4) = b;
+		} else {
+			for (int k = 0; k < SC_ITEMS; k++)
+				if (e0 + k < b1)
+					out[e0 + k] = sc_op<MAX>(pre, v[k]);
+		}
+		carry = sc_op<MAX>(carry, tile_tot);
+		__syncthreads();
+	}
+}
+
+size_t scan_tmp_bytes(size_t)
+{
+	return SC_MAX_BLOCKS * sizeof(uint32_t) + 256;
+}
+
+template <bool MAX>
+static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	if (n == 0)
+		return;
+	if (tmp_bytes < SC_MAX_BLOCKS * sizeof(uint32_t))
+		throw HipError("scan: temporary storage too small");
+	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)
+		throw HipError("scan: operands must be 16-byte aligned");
+	size_t blocks = (n + SC_TILE - 1) / SC_TILE;
+	if (blocks > SC_MAX_BLOCKS)
+		blocks = SC_MAX_BLOCKS;
+	size_t chunk = (n + blocks - 1) / blocks;
+	chunk = (chunk + SC_TILE - 1) / SC_TILE * SC_TILE; // whole tiles: every tile base stays 16-byte aligned
+	blocks = (n + chunk - 1) / chunk;
+	uint32_t *partial = static_cast<uint32_t *>(tmp);
+	hipLaunchKernelGGL(k_scan_partials<MAX>, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, in, n, chunk, partial);
+	hipLaunchKernelGGL(k_scan_chunks<MAX>, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, in, out, n, chunk, partial);
 }
 
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
-	if (n == 0)
-		return;
-	HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
+	scan_exclusive<false>(in, out, n, tmp, tmp_bytes, s);
 }
 
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
-	if (n == 0)
-		return;
-	HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0u, n, rocprim::maximum<uint32_t>(), s));
+	scan_exclusive<true>(in, out, n, tmp, tmp_bytes, s);
 }
 
 size_t sort_tmp_bytes(size_t n)
