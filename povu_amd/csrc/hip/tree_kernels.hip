@@ -178,17 +178,30 @@ static constexpr uint32_t SPLIT_SHIFT = 29; // 1 element in 8 is a random splitt
 static constexpr uint32_t PK_END = 0x1FFFFFFFu;
 __device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
 
-__global__ void k_rank_has_pred(uint32_t n, const uint32_t *__restrict__ nxt, uint32_t *__restrict__ has_pred)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && nxt[i] != NIL)
-		has_pred[nxt[i]] = 1;
-}
-__global__ void k_rank_flags(uint32_t n, const uint32_t *__restrict__ has_pred, uint32_t *__restrict__ flag)
+// splitter flags: the random ones, plus every list head (the caller knows where its lists start, so no
+// "who has a predecessor" pass is needed)
+__global__ void k_rank_flags_tours(uint32_t n, uint32_t *__restrict__ flag)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n)
-		flag[i] = (!has_pred[i] || is_random_splitter(i)) ? 1u : 0u;
+		flag[i] = is_random_splitter(i) ? 1u : 0u;
+}
+__global__ void k_rank_heads_tours(uint32_t C, const uint32_t *__restrict__ voff,
+				   const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ sarc,
+				   const uint32_t *__restrict__ afirst, uint32_t *__restrict__ flag)
+{
+	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	unsigned long long k = start_key[c];
+	uint32_t r = k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
+	flag[sarc[afirst[r]]] = 1; // the tour of component c starts with the first arc out of its root side
+}
+__global__ void k_rank_flags_events(uint32_t n, const uint32_t *__restrict__ dpar, uint32_t *__restrict__ flag)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) // event 2S = enter S heads a list iff S has no DFS parent
+		flag[i] = (is_random_splitter(i) || (!(i & 1) && dpar[i >> 1] == NIL)) ? 1u : 0u;
 }
 // one word per element so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
 // bit 29 = the element's 0/1 weight, bit 31 = stop after this element (successor is a splitter / end)
@@ -275,9 +288,7 @@ static void list_rank_splitters(uint32_t n, const uint32_t *nxt, const uint32_t 
 	if (n >= PK_END)
 		throw HipError("list ranking: more than 2^29 elements (graph too large for the packed walk)");
 	const uint32_t m_cap = n / 4 + max_heads + 4096; // expected n/8 random splitters + the heads
-	HIP_CHECK(hipMemsetAsync(rb.has_pred, 0, ((size_t)n + 1) * 4, s));
-	LAUNCH(k_rank_has_pred, n, s, n, nxt, rb.has_pred);
-	LAUNCH(k_rank_flags, n, s, n, rb.has_pred, rb.flag);
+	// rb.flag[0..n) was filled by the caller (random splitters + list heads)
 	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
 	uint32_t *pk = rb.has_pred; // has_pred is dead once the flags exist
 	LAUNCH(k_rank_pack, n, s, n, nxt, w1, rb.flag, pk);
@@ -802,6 +813,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_tour_cut, C, s, C, cs.voff, start_key, tw.v2, tw.alast, tw.nxtA, tw.cntA);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
+	LAUNCH(k_rank_flags_tours, NA, s, NA, rb.flag);
+	LAUNCH(k_rank_heads_tours, C, s, C, cs.voff, start_key, tw.v2, tw.afirst, rb.flag);
 	list_rank_splitters<false>(NA, tw.nxtA, tw.cntA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
 	LAUNCH(k_t0_parents, NA, s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0, tw.pe_le0,
@@ -848,6 +861,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	}
 	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA);
 	// one list per processed component, one two-event list per side of an unprocessed one
+	LAUNCH(k_rank_flags_events, 2 * nS, s, 2 * nS, tw.dpar, rb.flag);
 	list_rank_splitters<true>(2 * nS, tw.nxtA, tw.cntA, tw.cntB, tw.depB, event_lists, rb, s);
 	const uint32_t *cnt = tw.cntB, *dep = tw.depB;
 	tm.end(40);
