@@ -60,7 +60,7 @@ def main():
     comm_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     from povu_amd import HipDecomposer, workloads
-    from povu_amd.sharded import gather_forest
+    from povu_amd.sharded import PipelinedGather
 
     if args.workload == "chain":
         g = workloads.chain_of_bubbles(args.units)
@@ -79,13 +79,19 @@ def main():
     # every rank holds ONE component of the job: its global component id is rank + 1
     id_map = np.array([rank + 1], dtype=np.int64)
 
+    # N > 1: the PVST gather to rank 0 of step k overlaps with the kernels of step k+1 (separate streams);
+    # sync() drains it, so the timed region contains every transfer of its K steps
+    gather = PipelinedGather(rank, world, comm_dev) if world > 1 else None
+
     def step():
         f = hip.decompose()
-        if world > 1:
-            gather_forest(f, rank, world, comm_dev, id_map=id_map)
+        if gather:
+            gather.submit(f, id_map=id_map)
         return f
 
     def sync():
+        if gather:
+            gather.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -165,6 +165,94 @@ def gather_forest(forest, rank: int, world: int, device, id_map=None) -> Dict[in
     return out
 
 
+class PipelinedGather:
+    """PVST gather to rank 0 that overlaps with the next decompose (one process per GPU).
+
+    submit() posts this step's transfers and returns at once: senders `isend` their forest's pinned
+    block (kept alive until the send has completed), rank 0 posts `irecv`s into device buffers and
+    queues the device-to-pinned-host copies behind them on the current stream.  Buffers are double
+    buffered by step parity, so step k's traffic runs under step k+1's kernels.  finish() drains
+    everything and returns the component views of the LAST submitted step (rank 0) / None.
+    """
+
+    def __init__(self, rank: int, world: int, device):
+        self.rank, self.world, self.device = rank, world, device
+        self.step = 0
+        self.inflight = []          # per step: list of (work, keep-alive objects)
+        self.landed = None          # rank 0: what the last step put into host memory
+        self._dev = {}              # (parity, peer, kind) -> device buffer
+
+    def _buf(self, key, n, dtype):
+        import torch
+        t = self._dev.get(key)
+        if t is None or t.numel() < n:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._dev[key] = t
+        return t[:n]
+
+    def _drain(self, keep_last: int):
+        while len(self.inflight) > keep_last:
+            for work, _keep in self.inflight.pop(0):
+                work.wait()
+
+    def submit(self, forest, id_map=None):
+        import torch
+        import torch.distributed as dist
+
+        par = self.step & 1
+        self.step += 1
+        self._drain(1)  # the buffers of this parity were used two steps ago: make sure they are free
+        block, total, offs, hdr = forest.raw()
+        if id_map is not None and len(hdr):
+            hdr = hdr.copy()
+            hdr[:, 0] = np.asarray(id_map, dtype=np.int64)[hdr[:, 0] - 1]
+        meta = np.array([hdr.shape[0], block.shape[0], total] + offs, dtype=np.int64)
+        all_meta = torch.zeros(8 * self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(all_meta, torch.from_numpy(meta).to(self.device))
+        works = []
+        if self.rank != 0:
+            if hdr.shape[0]:
+                ht = torch.from_numpy(hdr.reshape(-1)).to(self.device)
+                bt = torch.from_numpy(block).to(self.device, non_blocking=True)
+                works.append((dist.isend(ht, 0), (ht, forest)))
+                works.append((dist.isend(bt, 0), (bt, forest)))
+            self.inflight.append(works)
+            return
+        am = all_meta.cpu().numpy().reshape(self.world, 8)
+        landed = [(0, hdr, block, total, offs, forest)]
+        for r in range(1, self.world):
+            nh, nb = int(am[r, 0]), int(am[r, 1])
+            if nh == 0:
+                continue
+            hb = self._buf((par, r, "h"), 3 * nh, torch.int64)
+            bb = self._buf((par, r, "b"), nb, torch.uint8)
+            wh, wb = dist.irecv(hb, r), dist.irecv(bb, r)
+            wh.wait()   # NCCL: orders the current stream behind the transfer, the host does not block
+            wb.wait()
+            hh = _pinned(3 * nh * 8, ("ph", par, r)).view(torch.int64)
+            host = _pinned(nb, ("pb", par, r))
+            hh.copy_(hb, non_blocking=True)
+            host.copy_(bb, non_blocking=True)
+            landed.append((r, hh, host, int(am[r, 2]), [int(x) for x in am[r, 3:8]], None))
+        self.inflight.append(works)
+        self.landed = landed
+
+    def finish(self) -> Dict[int, dict] | None:
+        import torch
+
+        self._drain(0)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+        if self.rank != 0 or self.landed is None:
+            return None
+        out: Dict[int, dict] = {}
+        for r, h, blk, total, offs, _keep in self.landed:
+            hn = h if isinstance(h, np.ndarray) else h.numpy()
+            bn = blk if isinstance(blk, np.ndarray) else blk.numpy()
+            _views(out, hn, bn, total, offs)
+        return out
+
+
 def _gather_flat(forest, rank: int, world: int, device, id_map=None) -> Dict[int, dict] | None:
     import torch
     import torch.distributed as dist

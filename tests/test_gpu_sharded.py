@@ -38,8 +38,16 @@ def _worker(rank, world, port, out_path):
     sub, comp_ids = sharded.scatter_links(g, rank, world, dev)
     hip = HipDecomposer(0)
     hip.upload(sub)
-    forest = hip.decompose()
-    got = sharded.gather_forest(forest, rank, world, dev, id_map=comp_ids)
+    pg = sharded.PipelinedGather(rank, world, dev)
+    for _ in range(3):  # the gather of one step runs under the next decompose
+        pg.submit(hip.decompose(), id_map=comp_ids)
+    got = pg.finish()
+    again = sharded.gather_forest(hip.decompose(), rank, world, dev, id_map=comp_ids)
+    if rank == 0:
+        assert sorted(got) == sorted(again)
+        for k in got:
+            for f in ("a_id", "z_id", "parent", "a_or", "z_or"):
+                assert np.array_equal(np.array(got[k][f]), np.array(again[k][f]))
     if rank == 0:
         torch.save({k: {kk: torch.from_numpy(np.array(vv).astype(np.int64)) for kk, vv in v.items()} for k, v in got.items()},
                    out_path)

@@ -45,12 +45,65 @@ class OracleForest:
         return self.trees[i]
 
 
+class OracleForestRaw(OracleForest):
+    """... plus the raw-block surface of povu_amd.hip.Forest (one contiguous result block)."""
+
+    def raw(self):
+        total = sum(len(t.parent) for t in self.trees)
+        pad = lambda n: (n + 63) // 64 * 64  # noqa: E731
+        offs = [0, pad(4 * total), 2 * pad(4 * total), 3 * pad(4 * total), 3 * pad(4 * total) + pad(total)]
+        block = np.zeros(offs[4] + pad(total) + 64, dtype=np.uint8)
+        hdr = np.zeros((len(self.trees), 3), dtype=np.int64)
+        first = 0
+        for k, t in enumerate(self.trees):
+            n = len(t.parent)
+            hdr[k] = (t.component_id, n, first)
+            block[offs[0] + 4 * first:offs[0] + 4 * (first + n)] = t.a_id.astype(np.uint32).view(np.uint8)
+            block[offs[1] + 4 * first:offs[1] + 4 * (first + n)] = t.z_id.astype(np.uint32).view(np.uint8)
+            block[offs[2] + 4 * first:offs[2] + 4 * (first + n)] = t.parent.astype(np.uint32).view(np.uint8)
+            block[offs[3] + first:offs[3] + first + n] = t.a_or
+            block[offs[4] + first:offs[4] + first + n] = t.z_or
+            first += n
+        return block, total, offs, hdr
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _worker_pipelined(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    g = W.hprc_shaped([300, 120, 500, 80], seed=9, tiny=12) if rank == 0 else None
+    sub, comp_ids = sharded.scatter_links(g, rank, world, dev)
+    pg = sharded.PipelinedGather(rank, world, dev)
+    for _ in range(4):  # several steps in flight, as bench.py does
+        pg.submit(OracleForestRaw(sub), id_map=comp_ids)
+    got = pg.finish()
+    if rank == 0:
+        torch.save({k: {kk: torch.from_numpy(np.array(vv).astype(np.int64)) for kk, vv in v.items()} for k, v in got.items()},
+                   out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_world2(tmp_path):
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker_pipelined, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    whole = OracleForest(W.hprc_shaped([300, 120, 500, 80], seed=9, tiny=12))
+    assert sorted(got) == [t.component_id for t in whole.trees]
+    for t in whole.trees:
+        r = got[t.component_id]
+        assert np.array_equal(r["a_id"].numpy(), t.a_id) and np.array_equal(r["z_id"].numpy(), t.z_id)
+        assert np.array_equal(r["parent"].numpy(), t.parent)
+        assert np.array_equal(r["a_or"].numpy(), t.a_or) and np.array_equal(r["z_or"].numpy(), t.z_or)
 
 
 def _worker(rank, world, port, out_path):
