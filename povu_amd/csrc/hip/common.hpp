@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -68,6 +69,54 @@ public:
 private:
 	void *base_ = nullptr;
 	size_t cap_ = 0, top_ = 0;
+};
+
+// Page-locked host scratch of one context.  Every small read-back (a count that sizes the next
+// launch) and every host-built table goes through it, so no copy is staged through pageable
+// memory; spans stay valid until the next reset() (= the next decompose on that context).
+class HostScratch
+{
+public:
+	~HostScratch()
+	{
+		for (auto &c : chunks_)
+			(void)hipHostFree(c.p);
+	}
+	void reset()
+	{
+		for (auto &c : chunks_)
+			c.top = 0;
+	}
+	template <typename T>
+	T *take(size_t n)
+	{
+		const size_t bytes = (n * sizeof(T) + 63) & ~size_t(63);
+		for (auto &c : chunks_)
+			if (c.cap - c.top >= bytes) {
+				char *r = c.p + c.top;
+				c.top += bytes;
+				return reinterpret_cast<T *>(r);
+			}
+		Chunk c{nullptr, std::max<size_t>(2 * bytes, size_t(1) << 16), bytes};
+		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c.p), c.cap, hipHostMallocDefault));
+		chunks_.push_back(c);
+		return reinterpret_cast<T *>(c.p);
+	}
+	// one 32-bit word of device memory, through the stream
+	uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
+	{
+		uint32_t *h = take<uint32_t>(1);
+		HIP_CHECK(hipMemcpyAsync(h, dptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		return *h;
+	}
+
+private:
+	struct Chunk {
+		char *p;
+		size_t cap, top;
+	};
+	std::vector<Chunk> chunks_;
 };
 
 // HIP-event stage timer on the context's stream.

@@ -428,10 +428,7 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
 	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(4);
-	uint32_t C = 0;
-	HIP_CHECK(hipMemcpyAsync(&C, st.crank + V, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	return C;
+	return st.host->read_u32(st.crank + V, s);
 }
 
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s)

@@ -730,15 +730,40 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax)
 }
 
 // ------------------------------------------------------------- driver
-static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
+// Everything the host needs to know about a finished pass, written straight into page-locked host
+// memory: [0..2] error words, then bad[C], status[C], npvst[C], nbry[C], doff[C+1].
+__global__ void k_summary(uint32_t C, const uint32_t *__restrict__ err, const uint32_t *__restrict__ bad,
+			  const uint32_t *__restrict__ status, const uint32_t *__restrict__ npvst,
+			  const uint32_t *__restrict__ nbry, const uint32_t *__restrict__ doff, uint32_t *__restrict__ out)
 {
-	uint32_t v = 0;
-	HIP_CHECK(hipMemcpyAsync(&v, dptr, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	return v;
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > C)
+		return;
+	if (i == 0) {
+		out[0] = err ? err[0] : 0;
+		out[1] = err ? err[1] : 0;
+		out[2] = err ? err[2] : 0;
+		out[3] = 0;
+	}
+	uint32_t *o = out + 4;
+	if (i < C) {
+		o[i] = bad ? bad[i] : 0;
+		o[(size_t)C + i] = status[i];
+		o[2 * (size_t)C + i] = npvst[i];
+		o[3 * (size_t)C + i] = nbry[i];
+	}
+	o[4 * (size_t)C + i] = doff ? doff[i] : 0;
 }
 
-uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int64_t dense_nb0, StageTimer &tm,
+void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_out, hipStream_t s)
+{
+	uint32_t *dev_out = nullptr;
+	HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev_out), host_out, 0));
+	LAUNCH(k_summary, (size_t)C + 1, s, C, pw ? pw->err : nullptr, pw ? pw->comp_bad : nullptr, sw.c_status, sw.c_npvst,
+	       sw.c_nbry, pw ? pw->doff : nullptr, dev_out);
+}
+
+void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int64_t dense_nb0, StageTimer &tm,
 			 hipStream_t s)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
@@ -763,7 +788,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 		NB0 = (uint32_t)dense_nb0;
 	} else {
 		scan(sw.c_nbe0, pw.dbo, (size_t)C + 1);
-		NB0 = read_u32(pw.dbo + C, s);
+		NB0 = pw.host->read_u32(pw.dbo + C, s);
 		LAUNCH(k_dense_be, NB0, s, NB0, C, pw.dbo, cs.voff, cs.eoff, sw.be_src, sw.be_tgt, pw.b_src, pw.b_tgt);
 	}
 	tm.end(7);
@@ -782,7 +807,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	scan(simp, pssimp, (size_t)T + 1);
 	scan(capf, pscap, (size_t)T + 1);
 	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre);
-	uint32_t extra[2];
+	uint32_t *extra = pw.host->take<uint32_t>(2);
 	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -831,7 +856,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
 	       pw.prev);
 	LAUNCH(k_stack_offsets, (size_t)C + 1, s, C, cs.voff, bps, T, pw.soff);
-	const uint32_t S = read_u32(bps + T, s);
+	const uint32_t S = pw.host->read_u32(bps + T, s);
 	tm.end(9);
 
 	// ---- row F
@@ -855,7 +880,7 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb);
 	seg_build(pw.segW, wb, (size_t)2 * S, s);
-	const uint32_t NE = read_u32(pw.erank + S, s);
+	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, cs.voff, pw.ns,
@@ -865,22 +890,6 @@ uint32_t run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, 
 	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
 	       sw.next_seen);
 	tm.end(12 + 3 * 22);
-
-	uint32_t errw[2];
-	HIP_CHECK(hipMemcpyAsync(errw, pw.err, 8, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	if (errw[0])
-		throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
-	if (errw[1])
-		throw HipError("list ranking: splitter capacity exceeded (internal sizing bug)");
-	// count flagged components
-	std::vector<uint32_t> bad(C);
-	HIP_CHECK(hipMemcpyAsync(bad.data(), pw.comp_bad, (size_t)C * 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	uint32_t nbad = 0;
-	for (uint32_t c = 0; c < C; c++)
-		nbad += bad[c] ? 1 : 0;
-	return nbad;
 }
 
 } // namespace povu_hip

@@ -108,6 +108,7 @@ struct povu_hip_ctx {
 	hipStream_t stream = nullptr;
 	ResidentGraph g;
 	Arena ws, ws2, ws_seq, upload_tmp;
+	HostScratch host;
 	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 	StageTimer timer;
 	std::vector<povu_hip_stage_time> last_times;
@@ -404,6 +405,8 @@ extern "C" povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *er
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
+		ctx->host.reset();
+		cs.host = &ctx->host;
 		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, false));
 		carve_workspace(&ctx->ws, 0, z, cs, sw, false);
 		StageTimer &tm = ctx->timer;
@@ -503,6 +506,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
+		ctx->host.reset();
+		cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
 		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, hairpins));
 		carve_workspace(&ctx->ws, 0, z, cs, sw, hairpins);
@@ -517,10 +522,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		reindex_components(g, cs, C, tm, s);
 
 		// component sizes on the host: shard assignment (LPT over link counts) and launch order
-		std::vector<uint32_t> voff(C + 1), eoff(C + 1);
-		HIP_CHECK(hipMemcpyAsync(voff.data(), cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(eoff.data(), cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-		uint32_t gstats[4] = {0, 0, 0, 0};
+		uint32_t *voff = ctx->host.take<uint32_t>((size_t)C + 1), *eoff = ctx->host.take<uint32_t>((size_t)C + 1);
+		uint32_t *gstats = ctx->host.take<uint32_t>(4);
+		HIP_CHECK(hipMemcpyAsync(voff, cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(eoff, cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipMemcpyAsync(gstats, cs.stats, 16, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		// stage workspaces, sized with the real component count
@@ -542,13 +547,16 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			carve_workspace(&ctx->ws_seq, 2, z, cs, sw, hairpins);
 			seq_ws_ready = true;
 		};
-		std::vector<uint32_t> order(C), owner(C, 0);
-		std::iota(order.begin(), order.end(), 0u);
+		// host-built tables live in pinned scratch: their uploads need no synchronisation
+		uint32_t *order = ctx->host.take<uint32_t>(C), *owner = ctx->host.take<uint32_t>(C);
+		std::iota(order, order + C, 0u);
+		std::fill(owner, owner + C, 0u);
 		auto weight = [&](uint32_t c) { return (uint64_t)(eoff[c + 1] - eoff[c]) + (voff[c + 1] - voff[c]); };
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
+		std::stable_sort(order, order + C, [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
 		if (o.world > 1) { // greedy longest-processing-time assignment, deterministic on every rank
 			std::vector<uint64_t> load(o.world, 0);
-			for (uint32_t c : order) {
+			for (uint32_t k = 0; k < C; k++) {
+				const uint32_t c = order[k];
 				uint32_t best = 0;
 				for (uint32_t r = 1; r < o.world; r++)
 					if (load[r] < load[best])
@@ -562,8 +570,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			if (owner[c] == o.rank || o.world == 1)
 				links += eoff[c + 1] - eoff[c];
 		ctx->last_links = links;
-		HIP_CHECK(hipMemcpyAsync((void *)sw.order, order.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
-		HIP_CHECK(hipMemcpyAsync((void *)sw.owner, owner.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync((void *)sw.order, order, (size_t)C * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync((void *)sw.owner, owner, (size_t)C * 4, hipMemcpyHostToDevice, s));
 
 		// ---- rows C-G
 		sw.V = g.V;
@@ -591,6 +599,13 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			HIP_CHECK(hipMemsetAsync(sw.last, 0xFF, (B + T) * 4, s));
 			HIP_CHECK(hipMemsetAsync(sw.in_s, 0, B + T, s));
 		};
+		const uint32_t *sum = nullptr; // outcome of the pass in pinned memory (pass_summary)
+		auto read_summary = [&](bool with_par) -> const uint32_t * {
+			uint32_t *h = ctx->host.take<uint32_t>(5 * (size_t)C + 8);
+			pass_summary(sw, with_par ? &ctx->pw : nullptr, C, h, s);
+			HIP_CHECK(hipStreamSynchronize(s));
+			return h;
+		};
 		tm.begin("traversal_init");
 		zero_component_counters(sw, C, s);
 		if (all_seq)
@@ -607,13 +622,13 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			int64_t dense_nb0 = -1;
 			HIP_CHECK(hipMemsetAsync(ctx->pw.err, 0, 64, s));
 			{ // processed components before c: where component c starts in the dense PVST output
-				std::vector<uint32_t> pc(C + 1, 0);
+				uint32_t *pc = ctx->host.take<uint32_t>((size_t)C + 1);
+				pc[0] = 0;
 				for (uint32_t c = 0; c < C; c++) {
 					const uint32_t nv = voff[c + 1] - voff[c];
 					pc[c + 1] = pc[c] + ((nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u);
 				}
-				HIP_CHECK(hipMemcpyAsync(ctx->pw.cproc_ps, pc.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
-				HIP_CHECK(hipStreamSynchronize(s));
+				HIP_CHECK(hipMemcpyAsync(ctx->pw.cproc_ps, pc, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
 			}
 			if (o.flags & POVU_HIP_F_SEQ_TREE) {
 				init_seq_workspace();
@@ -622,20 +637,32 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				launch_seq_components(sw, s);
 				tm.end(1);
 			} else {
-				std::vector<uint32_t> cproc(C + 1, 0);
+				uint32_t *cproc = ctx->host.take<uint32_t>((size_t)C + 1);
+				cproc[C] = 0;
 				uint32_t event_lists = 0;
 				for (uint32_t c = 0; c < C; c++) {
 					const uint32_t nv = voff[c + 1] - voff[c];
 					cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
 					event_lists += cproc[c] ? 1u : 2 * nv;
 				}
-				HIP_CHECK(hipMemcpyAsync(ctx->tw.cproc, cproc.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
-				HIP_CHECK(hipStreamSynchronize(s));
+				HIP_CHECK(hipMemcpyAsync(ctx->tw.cproc, cproc, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0], tm, s);
 			}
-			uint32_t nbad = run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
-			if (hairpins && !nbad)
+			run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
+			sum = read_summary(true);
+			if (sum[0])
+				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
+			if (sum[1])
+				throw HipError("list ranking: splitter capacity exceeded (internal sizing bug)");
+			if (sum[2])
+				throw HipError("spanning forest of the links has the wrong size (internal)");
+			uint32_t nbad = 0;
+			for (uint32_t c = 0; c < C; c++)
+				nbad += sum[4 + c] ? 1 : 0;
+			if (hairpins && !nbad) {
 				run_parallel_hairpins(cs, sw, ctx->pw, C, tm, s);
+				sum = nullptr;
+			}
 			if (nbad || (o.flags & POVU_HIP_F_FORCE_REDO)) {
 				// the parallel stages only keep the dense PVST layout; a (never yet observed) flagged
 				// component sends the whole shard through the sequential kernels
@@ -652,16 +679,16 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				launch_seq_components(sw, s);
 				sw.comp_sel = nullptr;
 				tm.end(1);
+				sum = nullptr;
 			}
 		}
 
 		// ---- PVST arrays back to the host
 		tm.begin("pvst_d2h");
-		std::vector<uint32_t> npvst(C), nbry(C), cstat(C);
-		HIP_CHECK(hipMemcpyAsync(cstat.data(), sw.c_status, (size_t)C * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(npvst.data(), sw.c_npvst, (size_t)C * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(nbry.data(), sw.c_nbry, (size_t)C * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipStreamSynchronize(s));
+		if (!sum)
+			sum = read_summary(!all_seq);
+		const uint32_t *cstat = sum + 4 + (size_t)C, *npvst = sum + 4 + 2 * (size_t)C, *nbry = sum + 4 + 3 * (size_t)C,
+			       *doff = sum + 4 + 4 * (size_t)C;
 		for (uint32_t c = 0; c < C; c++)
 			if (cstat[c] == 2)
 				throw HipError("internal error: the spanning tree of component " + std::to_string(c + 1) +
@@ -690,9 +717,6 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		const bool dense_out = !all_seq && ctx->last_seq_redo == 0;
 		std::vector<uint8_t> ors(dense_out ? 0 : total);
 		if (dense_out) { // the parallel stages wrote every PVST back to back: one exact-size copy per array
-			std::vector<uint32_t> doff(C + 1);
-			HIP_CHECK(hipMemcpyAsync(doff.data(), ctx->pw.doff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipStreamSynchronize(s));
 			if (doff[C] != total)
 				throw HipError("internal error: dense PVST size mismatch");
 			for (auto &t : f->trees)

@@ -49,12 +49,16 @@ __global__ void k_arcs_black(uint32_t V, uint32_t *__restrict__ arc_src, uint32_
 }
 __global__ void k_arcs_gray(uint32_t E, uint32_t V, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
 			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ lb, uint32_t *__restrict__ arc_src,
-			    uint32_t *__restrict__ arc_dst, uint32_t *__restrict__ arc_le)
+			    uint32_t *__restrict__ arc_dst, uint32_t *__restrict__ arc_le, uint32_t expect, uint32_t *err)
 {
 	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
+	if (le == 0 && tg_ps[E] != expect)
+		atomicExch(err, 1u);
 	if (le >= E || !tgray[le])
 		return;
 	uint32_t k = V + tg_ps[le];
+	if (tg_ps[le] >= expect) // never write past the arcs the launch was sized for
+		return;
 	arc_src[2 * k] = la[le];
 	arc_dst[2 * k] = lb[le];
 	arc_src[2 * k + 1] = lb[le];
@@ -773,14 +777,6 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax)
 	tree_spans(tw, V, E, Cmax, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
 }
 
-static uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
-{
-	uint32_t v = 0;
-	HIP_CHECK(hipMemcpyAsync(&v, dptr, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	return v;
-}
-
 // ------------------------------------------------------------------ driver
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   uint32_t max_side_links, StageTimer &tm, hipStream_t s)
@@ -794,12 +790,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
 	scan(cs.tgray, tw.tg_ps, (size_t)E + 1);
-	const uint32_t NTG = read_u32(tw.tg_ps + E, s);
-	if (NTG != V - C)
-		throw HipError("spanning forest of the links has the wrong size (internal)");
+	const uint32_t NTG = V - C; // a spanning forest; k_arcs_gray raises err[2] if the hooks disagree
 	const uint32_t NA = 2 * (V + NTG);
 	LAUNCH(k_arcs_black, V, s, V, tw.arc_src, tw.arc_dst, tw.arc_le);
-	LAUNCH(k_arcs_gray, E, s, E, V, cs.tgray, tw.tg_ps, cs.la, cs.lb, tw.arc_src, tw.arc_dst, tw.arc_le);
+	LAUNCH(k_arcs_gray, E, s, E, V, cs.tgray, tw.tg_ps, cs.la, cs.lb, tw.arc_src, tw.arc_dst, tw.arc_le, NTG, pw.err + 2);
 	{
 		uint32_t *acnt = tw.k1, *aoff = tw.k2, *cursor = tw.v1; // [nS+1] each fits the 4V+8 buffers
 		LAUNCH(k_arc_init_count, nS, s, nS, acnt);
@@ -842,7 +836,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       tw.dvis, tw.entry_flag);
 	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
-	const uint32_t n_entry = read_u32(tw.entry_ps + nS, s);
+	const uint32_t n_entry = tw.host->read_u32(tw.entry_ps + nS, s);
 	HIP_CHECK(hipMemsetAsync(sw.cur, 0, (size_t)nS * 4, s));
 	if (n_entry)
 		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj,
@@ -887,7 +881,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
 	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
-	const uint32_t NB0 = read_u32(tw.be_ps + nS, s);
+	const uint32_t NB0 = tw.host->read_u32(tw.be_ps + nS, s);
 	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
 	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	tm.end(6);

@@ -9,6 +9,7 @@ namespace povu_hip
 {
 
 struct TreeWs {
+	HostScratch *host; // pinned read-back scratch of the owning context
 	// unrooted spanning forest of the biedged graph H, as arcs
 	uint32_t *tg_ps;				  // [E+1] rank of tree-gray links
 	uint32_t *arc_src, *arc_dst, *arc_le;		  // [NA], arc_le per tree edge [NA/2]

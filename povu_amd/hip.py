@@ -94,6 +94,8 @@ def load_lib():
     l.povu_hip_debug_stack.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
                                        C.c_void_p]
     l.povu_hip_version.restype = C.c_char_p
+    l.povu_hip_workspace_estimate.restype = C.c_uint64
+    l.povu_hip_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     _lib = l
     return l
 
