@@ -38,6 +38,27 @@ __global__ void k_side_degree(uint32_t E, const uint32_t *__restrict__ v1, const
 	vals[2 * e + 1] = e;
 }
 
+// other end of every adjacency slot, as a global side id
+__global__ void k_slot_other(uint32_t nS, const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
+			     const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
+			     const uint8_t *__restrict__ s2, uint32_t *__restrict__ aoth)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	for (uint32_t k = off[S]; k < off[S + 1]; k++) {
+		uint32_t e = adj[k];
+		uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
+		aoth[k] = a == S ? b : a; // same-side self loop: a == b == S
+	}
+}
+__global__ void k_vertex_degree(uint32_t V, const uint32_t *__restrict__ off, uint32_t *__restrict__ deg)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V)
+		deg[v] = off[2 * v + 2] - off[2 * v];
+}
+
 // tips as the loader infers them, src/mto/from_gfa.cpp:262-277
 __global__ void k_infer_tips(uint32_t V, const uint32_t *__restrict__ off, uint8_t *__restrict__ tip)
 {
@@ -317,6 +338,87 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 	}
 }
 
+// ---- sort-free variant (vertices with few links): a side's local adjacency holds the links of its global
+// slots, plus the self loops of the opposite side -- a self loop is stored as (ve, complement(ve)) from the
+// side that met it first, so it owns one slot on either side of its vertex (bidirected.cpp:529-531).
+// k_mark_first2 = k_mark_first + the local degree of every side (no atomics) + the largest of them.
+__global__ void k_mark_first2(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ off,
+			      const uint32_t *__restrict__ adj, const uint32_t *__restrict__ aoth,
+			      const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ first,
+			      uint32_t *__restrict__ flag, uint32_t *__restrict__ ldeg, uint32_t *__restrict__ stats)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t cnt = 0;
+	if (S < 2 * V) {
+		uint32_t i = S >> 1, s = S & 1, v = perm[i];
+		uint32_t b0 = off[2 * v], lo = off[2 * v + s], hi = off[2 * v + s + 1];
+		uint32_t P = sbase[i] + (lo - b0);
+		for (uint32_t k = lo; k < hi; k++, P++) {
+			bool f = first[adj[k]] == P;
+			flag[P] = f ? 1u : 0u;
+			cnt += ((aoth[k] >> 1) == v) ? (f ? 1u : 0u) : 1u;
+		}
+		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sbase[i] + (lo - b0);
+		for (uint32_t k = lo; k < hi; k++, P++)
+			if ((aoth[k] >> 1) == v && first[adj[k]] == P)
+				cnt++;
+		ldeg[S] = cnt;
+	}
+	uint32_t m = cnt;
+	for (int o = 32; o; o >>= 1)
+		m = max(m, __shfl_down(m, o));
+	if ((threadIdx.x & 63) == 0 && m > *(volatile uint32_t *)stats)
+		atomicMax(stats, m);
+}
+
+// every side gathers its (local edge, other side) pairs and keeps them ascending by local edge with an
+// insertion sort in place (std::set order of the per-side edge lists); the first-encounter slot also
+// writes the local edge itself
+__global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
+			    const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
+			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ sbase,
+			    const uint32_t *__restrict__ first, const uint32_t *__restrict__ erank,
+			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ hook, uint32_t *__restrict__ la,
+			    uint32_t *__restrict__ lb, uint32_t *__restrict__ tgray, uint32_t *ladj, uint32_t *lle)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= 2 * V)
+		return;
+	uint32_t i = S >> 1, s = S & 1, v = perm[i];
+	uint32_t b0 = off[2 * v], lo = off[2 * v + s], hi = off[2 * v + s + 1];
+	uint32_t P = sbase[i] + (lo - b0);
+	const uint32_t base = loff[S];
+	uint32_t n = 0;
+	auto insert = [&](uint32_t le, uint32_t other) {
+		uint32_t j = n++;
+		while (j > 0 && lle[base + j - 1] > le) {
+			lle[base + j] = lle[base + j - 1];
+			ladj[base + j] = ladj[base + j - 1];
+			j--;
+		}
+		lle[base + j] = le;
+		ladj[base + j] = other;
+	};
+	for (uint32_t k = lo; k < hi; k++, P++) {
+		uint32_t e = adj[k], o = aoth[k], Pf = first[e];
+		bool loop = (o >> 1) == v;
+		if (loop && Pf != P)
+			continue;
+		uint32_t le = erank[Pf];
+		uint32_t other = loop ? (S ^ 1u) : 2 * pos[o >> 1] + (o & 1u);
+		if (Pf == P) {
+			la[le] = S;
+			lb[le] = other;
+			tgray[le] = hook[e];
+		}
+		insert(le, other);
+	}
+	lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sbase[i] + (lo - b0);
+	for (uint32_t k = lo; k < hi; k++, P++)
+		if ((aoth[k] >> 1) == v && first[adj[k]] == P)
+			insert(erank[P], S ^ 1u);
+}
+
 // after the stable sort by side: other side and local edge of every adjacency slot
 __global__ void k_local_slots(uint32_t n, const uint32_t *__restrict__ origin, const uint32_t *__restrict__ la,
 			      const uint32_t *__restrict__ lb, uint32_t *__restrict__ ladj, uint32_t *__restrict__ lle)
@@ -402,6 +504,16 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)n_slots * 4, hipMemcpyDeviceToDevice, s));
 	if (!g.tips_given && V)
 		hipLaunchKernelGGL(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
+	g.max_vdeg = 0;
+	if (V && E) {
+		hipLaunchKernelGGL(k_slot_other, dim3(nblk(nS)), dim3(TPB), 0, s, (uint32_t)nS, g.off, g.adj, g.v1, g.s1, g.v2, g.s2,
+				   g.aoth);
+		uint32_t *mx = tmp_arena.take<uint32_t>(4);
+		HIP_CHECK(hipMemsetAsync(mx, 0, 16, s));
+		hipLaunchKernelGGL(k_vertex_degree, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, deg);
+		hipLaunchKernelGGL(k_max_u32, dim3(std::min<unsigned>(nblk(V), 1024)), dim3(TPB), 0, s, V, deg, mx);
+		HIP_CHECK(hipMemcpyAsync(&g.max_vdeg, mx, 4, hipMemcpyDeviceToHost, s));
+	}
 	// links sorted by smaller endpoint + the list of links that cross a union-find tile
 	g.n_cross = 0;
 	if (E) {
@@ -431,7 +543,12 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	return st.host->read_u32(st.crank + V, s);
 }
 
-void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s)
+// vertices with more links than this take the radix-sorted adjacency path (an insertion sort per side is
+// quadratic in the side's links)
+static constexpr uint32_t SORT_FREE_MAX_VDEG = 48;
+
+void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
+			bool force_sorted_adjacency)
 {
 	const uint32_t V = g.V, E = g.E;
 	const size_t nS = 2 * (size_t)V;
@@ -455,8 +572,22 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	launches += 5;
 	// first-encounter rank of every edge
 	fill_u32(st.first, E, POVU_NIL, s);
-	HIP_CHECK(hipMemsetAsync(st.flag, 0, ((size_t)g.n_slots + 1) * 4, s));
 	hipLaunchKernelGGL(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
+	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
+		HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
+		hipLaunchKernelGGL(k_mark_first2, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, g.aoth, st.sbase,
+				   st.first, st.flag, st.ldeg, st.stats);
+		scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+		HIP_CHECK(hipMemsetAsync(st.ldeg + nS, 0, 4, s));
+		scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, g.aoth, st.sbase,
+				   st.first, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
+		hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
+				   st.eoff);
+		tm.end(launches + 11);
+		return;
+	}
+	HIP_CHECK(hipMemsetAsync(st.flag, 0, ((size_t)g.n_slots + 1) * 4, s));
 	hipLaunchKernelGGL(k_mark_first, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first,
 			   st.flag);
 	scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);

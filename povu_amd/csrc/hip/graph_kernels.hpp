@@ -16,6 +16,9 @@ struct ResidentGraph {
 	uint8_t *tip = nullptr;			    // [V]   POVU_TIP_*
 	uint32_t *off = nullptr;		    // [2V+1] per-side CSR offsets
 	uint32_t *adj = nullptr;		    // [n_slots] incident link idx, ascending per side
+	uint32_t *aoth = nullptr;		    // [n_slots] global side id (2 * vertex idx + end) at the other end of the slot's
+						    //           link; a self loop points back into its own vertex
+	uint32_t max_vdeg = 0;			    // most links on one vertex (both sides)
 	// links sorted by their smaller endpoint (built at upload): tile-local union-find input
 	uint32_t *eperm = nullptr, *e_lo = nullptr, *e_hi = nullptr; // [E] link idx, min / max endpoint
 	uint32_t *xlist = nullptr;		    // [n_cross] sorted positions of links that leave their tile
@@ -46,6 +49,7 @@ struct CompState {
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s);
 void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);
 uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
-void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s);
+void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
+			bool force_sorted_adjacency = false);
 
 } // namespace povu_hip

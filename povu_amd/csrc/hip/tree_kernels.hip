@@ -140,7 +140,8 @@ __global__ void k_tour_cut(uint32_t C, const uint32_t *__restrict__ voff, const 
 	nxt[a_end] = NIL;
 	cnt[a_end] = 0;
 }
-// one round of pointer jumping with two accumulators (suffix sums along the list)
+// one launch = two rounds of pointer jumping (three hops: every pointer then spans 4x as far), with two
+// accumulators (suffix sums along the list)
 __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const uint32_t *__restrict__ a_in,
 			 const uint32_t *__restrict__ b_in, uint32_t *__restrict__ nxt_out, uint32_t *__restrict__ a_out,
 			 uint32_t *__restrict__ b_out, const uint32_t *__restrict__ n_dev)
@@ -149,7 +150,10 @@ __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const 
 	if (i >= n || (n_dev && i >= *n_dev))
 		return;
 	uint32_t nx = nxt_in[i], a = a_in[i], b = b_in ? b_in[i] : 0;
-	if (nx != NIL) {
+#pragma unroll
+	for (int hop = 0; hop < 3; hop++) {
+		if (nx == NIL)
+			break;
 		a += a_in[nx];
 		if (b_in)
 			b += b_in[nx];
@@ -160,12 +164,13 @@ __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const 
 	if (b_out)
 		b_out[i] = b;
 }
-// runs `rounds` rounds; returns which buffer set (0 = A, 1 = B) holds the result
-static int list_rank(uint32_t n, unsigned rounds, uint32_t *nxtA, uint32_t *nxtB, uint32_t *aA, uint32_t *aB, uint32_t *bA,
+// `bits` = bits_for(longest possible list); returns which buffer set (0 = A, 1 = B) holds the result
+static int list_rank(uint32_t n, unsigned bits, uint32_t *nxtA, uint32_t *nxtB, uint32_t *aA, uint32_t *aB, uint32_t *bA,
 		     uint32_t *bB, hipStream_t s, const uint32_t *n_dev = nullptr)
 {
 	int cur = 0;
-	for (unsigned r = 0; r < rounds; r++) {
+	const unsigned launches = (bits + 1) / 2;
+	for (unsigned r = 0; r < launches; r++) {
 		if (cur == 0)
 			LAUNCH(k_wyllie, n, s, n, nxtA, aA, bA, nxtB, aB, bB, n_dev);
 		else

@@ -42,6 +42,7 @@ F_HAIRPINS = 1
 F_SEQUENTIAL = 2
 F_SEQ_TREE = 4
 F_FORCE_REDO = 8
+F_SORTED_ADJ = 16
 
 _lib = None
 

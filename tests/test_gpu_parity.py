@@ -160,6 +160,29 @@ def test_forced_sequential_redo(hip, seed):
     assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_both_local_adjacency_builders(hip, seed):
+    """Row B's per-side adjacency: insertion sort per side (default) and the radix-sort builder hub graphs
+    take (POVU_HIP_F_SORTED_ADJ) give the same forest; graphs here are rich in self loops of every kind
+    (l-l, r-r, l-r) and repeated links, which componetize stores as (ve, complement(ve)) (bidirected.cpp:529-531)."""
+    from povu_amd.hip import F_SORTED_ADJ
+    rng = np.random.default_rng(4200 + seed)
+    n = 30 + 17 * seed
+    base = W.random_bidirected(n, int(n * 1.6), 4300 + seed, connected=(seed % 2 == 0))
+    k = n // 2
+    lv = rng.integers(0, n, k).astype(np.uint32)
+    g = W.Links(vid=base.vid,
+                v1=np.concatenate([base.v1, lv, base.v1[:k]]), s1=np.concatenate([base.s1, rng.integers(0, 2, k).astype(np.uint8), base.s1[:k]]),
+                v2=np.concatenate([base.v2, lv, base.v2[:k]]), s2=np.concatenate([base.s2, rng.integers(0, 2, k).astype(np.uint8), base.s2[:k]]))
+    # interleave so that loops and repeats are not all at the end of the L-line order
+    order = rng.permutation(g.n_links)
+    g = W.Links(vid=g.vid, v1=g.v1[order], s1=g.s1[order], v2=g.v2[order], s2=g.s2[order])
+    want = O.decompose(g)
+    hip.upload(g)
+    assert hip.decompose().texts() == want
+    assert hip.decompose(flags=F_SORTED_ADJ).texts() == want
+
+
 # ---- BASELINE.json full-size configurations
 def test_config2_chain_1m_nodes_bit_exact_vs_reference_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))
