@@ -130,6 +130,7 @@ struct StageTimer {
 	std::vector<hipEvent_t> pool;
 	size_t pool_used = 0;
 	hipStream_t stream = nullptr;
+	bool enabled = true; // per-stage event pairs cost a few microseconds each; the pass total is always timed
 	hipEvent_t get()
 	{
 		if (pool_used == pool.size()) {
@@ -146,12 +147,16 @@ struct StageTimer {
 	}
 	void begin(const char *name)
 	{
+		if (!enabled)
+			return;
 		Rec r{name, get(), get(), 0};
 		HIP_CHECK(hipEventRecord(r.a, stream));
 		recs.push_back(r);
 	}
 	void end(uint32_t launches)
 	{
+		if (!enabled)
+			return;
 		recs.back().launches = launches;
 		HIP_CHECK(hipEventRecord(recs.back().b, stream));
 	}

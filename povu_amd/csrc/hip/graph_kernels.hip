@@ -449,13 +449,23 @@ __global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *
 	}
 }
 
+// first local edge of every component; also publishes voff / eoff / stats straight into the context's
+// page-locked host buffer [voff C+1 | eoff C+1 | stats 4] when one is given
 __global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ sbase,
-				    const uint32_t *__restrict__ erank, uint32_t *__restrict__ eoff)
+				    const uint32_t *__restrict__ erank, uint32_t *__restrict__ eoff,
+				    const uint32_t *__restrict__ stats, uint32_t *__restrict__ host_pub)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c > C)
 		return;
-	eoff[c] = erank[sbase[voff[c]]];
+	const uint32_t vo = voff[c], eo = erank[sbase[vo]];
+	eoff[c] = eo;
+	if (host_pub) {
+		host_pub[c] = vo;
+		host_pub[(size_t)C + 1 + c] = eo;
+		if (c < 4)
+			host_pub[2 * ((size_t)C + 1) + c] = stats[c];
+	}
 }
 
 __global__ void k_fill_u32(size_t n, uint32_t *p, uint32_t val)
@@ -583,7 +593,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, g.aoth, st.sbase,
 				   st.first, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
 		hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
-				   st.eoff);
+				   st.eoff, st.stats, st.host_pub);
 		tm.end(launches + 11);
 		return;
 	}
@@ -595,10 +605,10 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	hipLaunchKernelGGL(k_local_edges, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, st.sbase,
 			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg, st.hook, st.la, st.lb,
 			   st.tgray);
-	hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
-			   st.eoff);
 	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
 	hipLaunchKernelGGL(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
+	hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
+			   st.eoff, st.stats, st.host_pub);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	// local per-side adjacency (other side ids), ascending local edge idx
 	sort_pairs_u32(st.keys, st.keys2, st.vals, st.vals2, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);

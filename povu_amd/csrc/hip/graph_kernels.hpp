@@ -43,7 +43,8 @@ struct CompState {
 	uint64_t *start_key; // [C+1] (segment id << 32 | sorted side) of the smallest tip, ~0 if none
 	void *scan_tmp, *sort_tmp;
 	size_t scan_tmp_bytes, sort_tmp_bytes;
-	HostScratch *host; // pinned read-back scratch of the owning context
+	HostScratch *host;  // pinned read-back scratch of the owning context
+	uint32_t *host_pub; // device view of a pinned [voff C+1 | eoff C+1 | stats 4] the re-index publishes into (or null)
 };
 
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s);

@@ -694,10 +694,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
 	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
 	take((void **)&pw.doff, (Cmax + 2) * 4);
-	for (uint32_t **p : {&pw.d_a, &pw.d_z, &pw.d_parent})
-		take((void **)p, (V + Cmax + 2) * 4);
-	take((void **)&pw.d_aor, V + Cmax + 2);
-	take((void **)&pw.d_zor, V + Cmax + 2);
+	take((void **)&pw.d_block, (V + Cmax + 2) * 14 + 5 * 64);
 	take((void **)&pw.err, 64);
 	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
@@ -763,8 +760,8 @@ void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_o
 	       sw.c_nbry, pw ? pw->doff : nullptr, dev_out);
 }
 
-void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int64_t dense_nb0, StageTimer &tm,
-			 hipStream_t s)
+void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, int64_t dense_nb0,
+		     StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const bool want_hp = sw.hairpins != nullptr;
@@ -782,7 +779,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int6
 	LAUNCH(k_tcomp_vertices, V, s, V, cs.ckey, pw.t_comp);
 	LAUNCH(k_tcomp_last, C, s, C, cs.voff, pw.t_comp);
 	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root);
-	HIP_CHECK(hipMemsetAsync(pw.comp_bad, 0, ((size_t)C + 1) * 4, s)); // pw.err is zeroed by the caller
+	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
 		NB0 = (uint32_t)dense_nb0;
@@ -881,6 +878,16 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, int6
 	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb);
 	seg_build(pw.segW, wb, (size_t)2 * S, s);
 	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
+	{ // the five PVST arrays back to back, laid out like the host's result block: one exact-size copy brings them over
+		const size_t total = (size_t)NE + n_processed, p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
+		char *blk = static_cast<char *>(pw.d_block);
+		pw.d_a = reinterpret_cast<uint32_t *>(blk);
+		pw.d_z = reinterpret_cast<uint32_t *>(blk + p4);
+		pw.d_parent = reinterpret_cast<uint32_t *>(blk + 2 * p4);
+		pw.d_aor = reinterpret_cast<uint8_t *>(blk + 3 * p4);
+		pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
+		pw.d_total = total;
+	}
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, cs.voff, pw.ns,

@@ -310,11 +310,12 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);
 		take((char **)&cs.sort_tmp, cs.sort_tmp_bytes, 1);
 	} else if (part == 1) {
-		uint32_t *order = nullptr, *owner = nullptr;
-		take(&order, C + 1, 4);
-		take(&owner, C + 1, 4);
-		sw.order = order;
-		sw.owner = owner;
+		// host-built per-component tables, one upload: order | owner | processed-before | processed
+		uint32_t *tables = nullptr;
+		take(&tables, 4 * (C + 1), 4);
+		sw.order = tables;
+		sw.owner = tables + (C + 1);
+		sw.tables = tables;
 		take(&sw.t_gid, T, 4);
 		take(&sw.t_par, T, 4);
 		take(&sw.t_cls, T, 4);
@@ -408,10 +409,12 @@ extern "C" povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *er
 		ctx->have_state = false;
 		ctx->host.reset();
 		cs.host = &ctx->host;
+		cs.host_pub = nullptr;
 		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, false));
 		carve_workspace(&ctx->ws, 0, z, cs, sw, false);
 		StageTimer &tm = ctx->timer;
 		tm.reset();
+		tm.enabled = true;
 		const uint32_t C = label_components(g, cs, tm, s);
 		reindex_components(g, cs, C, tm, s);
 		auto o = std::make_unique<ComponentsOwner>();
@@ -515,20 +518,19 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 
 		StageTimer &tm = ctx->timer;
 		tm.reset();
+		tm.enabled = (o.flags & POVU_HIP_F_NO_STAGE_TIMES) == 0;
 		hipEvent_t ev_all0 = tm.get(), ev_all1 = tm.get();
 		HIP_CHECK(hipEventRecord(ev_all0, s));
 
 		// ---- row B
 		const uint32_t C = label_components(g, cs, tm, s);
+		// component sizes on the host (shard assignment = LPT over link counts, launch order): the last
+		// re-index kernel writes them into pinned memory itself
+		uint32_t *pub = ctx->host.take<uint32_t>(2 * ((size_t)C + 1) + 4);
+		HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&cs.host_pub), pub, 0));
 		reindex_components(g, cs, C, tm, s, (o.flags & POVU_HIP_F_SORTED_ADJ) != 0);
-
-		// component sizes on the host: shard assignment (LPT over link counts) and launch order
-		uint32_t *voff = ctx->host.take<uint32_t>((size_t)C + 1), *eoff = ctx->host.take<uint32_t>((size_t)C + 1);
-		uint32_t *gstats = ctx->host.take<uint32_t>(4);
-		HIP_CHECK(hipMemcpyAsync(voff, cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(eoff, cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(gstats, cs.stats, 16, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
+		const uint32_t *voff = pub, *eoff = pub + (size_t)C + 1, *gstats = pub + 2 * ((size_t)C + 1);
 		// stage workspaces, sized with the real component count
 		z.Cmax = C;
 		z.T = 2 * z.V + C;
@@ -549,7 +551,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			seq_ws_ready = true;
 		};
 		// host-built tables live in pinned scratch: their uploads need no synchronisation
-		uint32_t *order = ctx->host.take<uint32_t>(C), *owner = ctx->host.take<uint32_t>(C);
+		uint32_t *tab_h = ctx->host.take<uint32_t>(4 * ((size_t)C + 1));
+		uint32_t *order = tab_h, *owner = tab_h + ((size_t)C + 1), *pc = tab_h + 2 * ((size_t)C + 1),
+			 *cproc = tab_h + 3 * ((size_t)C + 1);
 		std::iota(order, order + C, 0u);
 		std::fill(owner, owner + C, 0u);
 		auto weight = [&](uint32_t c) { return (uint64_t)(eoff[c + 1] - eoff[c]) + (voff[c + 1] - voff[c]); };
@@ -571,8 +575,19 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			if (owner[c] == o.rank || o.world == 1)
 				links += eoff[c + 1] - eoff[c];
 		ctx->last_links = links;
-		HIP_CHECK(hipMemcpyAsync((void *)sw.order, order, (size_t)C * 4, hipMemcpyHostToDevice, s));
-		HIP_CHECK(hipMemcpyAsync((void *)sw.owner, owner, (size_t)C * 4, hipMemcpyHostToDevice, s));
+		// processed components (>= 3 vertices, owned by this shard), their running count = where a component
+		// starts in the dense PVST output, and the number of event lists of the pre-order ranking
+		uint32_t event_lists = 0;
+		order[C] = owner[C] = cproc[C] = 0;
+		pc[0] = 0;
+		for (uint32_t c = 0; c < C; c++) {
+			const uint32_t nv = voff[c + 1] - voff[c];
+			cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
+			pc[c + 1] = pc[c] + cproc[c];
+			event_lists += cproc[c] ? 1u : 2 * nv;
+		}
+		const uint32_t n_processed = pc[C];
+		HIP_CHECK(hipMemcpyAsync(sw.tables, tab_h, 4 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
 
 		// ---- rows C-G
 		sw.V = g.V;
@@ -608,7 +623,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			return h;
 		};
 		tm.begin("traversal_init");
-		zero_component_counters(sw, C, s);
+		zero_component_counters(sw, C, all_seq ? nullptr : ctx->pw.comp_bad, all_seq ? nullptr : ctx->pw.err, s);
 		if (all_seq)
 			init_seq_workspace();
 		tm.end(all_seq ? 14 : 1);
@@ -621,16 +636,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			tm.end(1);
 		} else {
 			int64_t dense_nb0 = -1;
-			HIP_CHECK(hipMemsetAsync(ctx->pw.err, 0, 64, s));
-			{ // processed components before c: where component c starts in the dense PVST output
-				uint32_t *pc = ctx->host.take<uint32_t>((size_t)C + 1);
-				pc[0] = 0;
-				for (uint32_t c = 0; c < C; c++) {
-					const uint32_t nv = voff[c + 1] - voff[c];
-					pc[c + 1] = pc[c] + ((nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u);
-				}
-				HIP_CHECK(hipMemcpyAsync(ctx->pw.cproc_ps, pc, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
-			}
+			ctx->pw.cproc_ps = sw.tables + 2 * ((size_t)C + 1);
+			ctx->tw.cproc = sw.tables + 3 * ((size_t)C + 1);
 			if (o.flags & POVU_HIP_F_SEQ_TREE) {
 				init_seq_workspace();
 				tm.begin("tree_seq");
@@ -638,18 +645,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				launch_seq_components(sw, s);
 				tm.end(1);
 			} else {
-				uint32_t *cproc = ctx->host.take<uint32_t>((size_t)C + 1);
-				cproc[C] = 0;
-				uint32_t event_lists = 0;
-				for (uint32_t c = 0; c < C; c++) {
-					const uint32_t nv = voff[c + 1] - voff[c];
-					cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
-					event_lists += cproc[c] ? 1u : 2 * nv;
-				}
-				HIP_CHECK(hipMemcpyAsync(ctx->tw.cproc, cproc, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s));
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0], tm, s);
 			}
-			run_parallel_dg(cs, sw, ctx->pw, C, dense_nb0, tm, s);
+			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, dense_nb0, tm, s);
 			sum = read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
@@ -722,13 +720,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				throw HipError("internal error: dense PVST size mismatch");
 			for (auto &t : f->trees)
 				t.off = doff[t.component_id - 1];
-			if (total) {
-				HIP_CHECK(hipMemcpyAsync(f->a_id.data(), ctx->pw.d_a, total * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(f->z_id.data(), ctx->pw.d_z, total * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(f->parent.data(), ctx->pw.d_parent, total * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(f->a_or.data(), ctx->pw.d_aor, total, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(f->z_or.data(), ctx->pw.d_zor, total, hipMemcpyDeviceToHost, s));
-			}
+			if (total != ctx->pw.d_total)
+				throw HipError("internal error: dense PVST layout mismatch");
+			if (total) // the device block has the layout of the host block (povu_hip_forest::alloc)
+				HIP_CHECK(hipMemcpyAsync(f->block, ctx->pw.d_block, f->block_bytes, hipMemcpyDeviceToHost, s));
 			for (const auto &t : f->trees)
 				if (t.n_hairpins) {
 					const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);

@@ -517,18 +517,24 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 	}
 }
 
+// per-component counters, plus (parallel stages) the flagged-component marks and the 16 error words
 __global__ void k_zero_counters(uint32_t n, uint32_t *a, uint32_t *b, uint32_t *c, uint32_t *d, uint32_t *e, uint32_t *f,
-				uint32_t *g, uint32_t *h)
+				uint32_t *g, uint32_t *h, uint32_t *bad, uint32_t *err)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n)
+	if (i < n) {
 		a[i] = b[i] = c[i] = d[i] = e[i] = f[i] = g[i] = h[i] = 0;
+		if (bad)
+			bad[i] = 0;
+	}
+	if (err && i < 16)
+		err[i] = 0;
 }
 
-void zero_component_counters(const SeqWs &ws, uint32_t C, hipStream_t s)
+void zero_component_counters(const SeqWs &ws, uint32_t C, uint32_t *comp_bad, uint32_t *err, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_zero_counters, dim3((C + 256) / 256), dim3(256), 0, s, C + 1, ws.c_ntree, ws.c_nbe0, ws.c_nbe,
-			   ws.c_nstack, ws.c_npvst, ws.c_nclass, ws.c_nbry, ws.c_status);
+			   ws.c_nstack, ws.c_npvst, ws.c_nclass, ws.c_nbry, ws.c_status, comp_bad, err);
 }
 
 void launch_seq_components(const SeqWs &ws, hipStream_t s)

@@ -31,6 +31,7 @@ struct SeqWs {
 	const uint64_t *start_key;
 	const uint32_t *order; // [C] components by size descending
 	const uint32_t *owner; // [C] shard that owns the component
+	uint32_t *tables;      // [4(C+1)] order | owner | processed-before | processed: one upload per pass
 	// spanning tree
 	uint32_t *t_gid, *t_par, *t_cls, *t_hi, *first_child, *next_sib, *last_child; // [T]
 	uint32_t *t_size, *t_depth;						       // [T] subtree sizes, depths
@@ -61,6 +62,6 @@ __host__ __device__ inline uint64_t seq_toff(const uint32_t *voff, uint32_t c) {
 
 void launch_seq_components(const SeqWs &ws, hipStream_t s);
 // zeroes the eight per-component result arrays (one launch)
-void zero_component_counters(const SeqWs &ws, uint32_t C, hipStream_t s);
+void zero_component_counters(const SeqWs &ws, uint32_t C, uint32_t *comp_bad, uint32_t *err, hipStream_t s);
 
 } // namespace povu_hip

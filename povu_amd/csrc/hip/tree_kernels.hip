@@ -34,9 +34,15 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
 	} while (0)
 
+// list-ranking splitters (section "work-efficient list ranking" below): 1 element in 8, by a multiplicative hash
+static constexpr uint32_t SPLIT_SHIFT = 29;
+static constexpr uint32_t PK_END = 0x1FFFFFFFu;
+__device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
+
 // ------------------------------------------------------------------ 1. arcs of the spanning forest
+// also: every side starts with one arc (the black one) and an empty cursor for its gray arcs
 __global__ void k_arcs_black(uint32_t V, uint32_t *__restrict__ arc_src, uint32_t *__restrict__ arc_dst,
-			     uint32_t *__restrict__ arc_le)
+			     uint32_t *__restrict__ arc_le, uint32_t *__restrict__ acnt, uint32_t *__restrict__ cursor)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= V)
@@ -46,6 +52,8 @@ __global__ void k_arcs_black(uint32_t V, uint32_t *__restrict__ arc_src, uint32_
 	arc_src[2 * i + 1] = 2 * i + 1;
 	arc_dst[2 * i + 1] = 2 * i;
 	arc_le[i] = NIL;
+	acnt[2 * i] = acnt[2 * i + 1] = 1;
+	cursor[2 * i] = cursor[2 * i + 1] = 0;
 }
 __global__ void k_arcs_gray(uint32_t E, uint32_t V, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
 			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ lb, uint32_t *__restrict__ arc_src,
@@ -65,12 +73,6 @@ __global__ void k_arcs_gray(uint32_t E, uint32_t V, const uint32_t *__restrict__
 	arc_dst[2 * k + 1] = la[le];
 	arc_le[k] = le;
 }
-__global__ void k_iota(uint32_t n, uint32_t *p)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n)
-		p[i] = i;
-}
 // Arc lists per side WITHOUT a sort: any cyclic order of a side's arcs gives a valid Euler tour, so
 // the arcs are only grouped: slot 0 of side S = its black arc, the gray tree arcs follow (atomic cursor).
 __global__ void k_arc_count(uint32_t E, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ la,
@@ -81,12 +83,6 @@ __global__ void k_arc_count(uint32_t E, const uint32_t *__restrict__ tgray, cons
 		return;
 	atomicAdd(&acnt[la[le]], 1u);
 	atomicAdd(&acnt[lb[le]], 1u);
-}
-__global__ void k_arc_init_count(uint32_t nS, uint32_t *__restrict__ acnt)
-{
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S < nS)
-		acnt[S] = 1; // the black arc
 }
 __global__ void k_arc_place(uint32_t NA, uint32_t nblack_arcs, const uint32_t *__restrict__ arc_src,
 			    const uint32_t *__restrict__ aoff, uint32_t *__restrict__ cursor, uint32_t *__restrict__ apos,
@@ -100,27 +96,20 @@ __global__ void k_arc_place(uint32_t NA, uint32_t nblack_arcs, const uint32_t *_
 	apos[a] = q;
 	sarc[q] = a;
 }
-__global__ void k_arc_bounds(uint32_t nS, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ afirst,
-			     uint32_t *__restrict__ alast)
-{
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	afirst[S] = aoff[S];
-	alast[S] = aoff[S + 1] - 1;
-}
 // Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
+// (side w's arcs sit at [aoff[w], aoff[w+1])); also draws the random splitters of the tour ranking
 __global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
-			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ afirst,
-			   const uint32_t *__restrict__ alast, uint32_t *__restrict__ nxt, uint32_t *__restrict__ cnt)
+			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ nxt,
+			   uint32_t *__restrict__ cnt, uint32_t *__restrict__ flag)
 {
 	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= NA)
 		return;
 	uint32_t t = a ^ 1, w = arc_src[t], q = apos[t];
-	uint32_t qn = (q == alast[w]) ? afirst[w] : q + 1;
+	uint32_t qn = (q + 1 == aoff[w + 1]) ? aoff[w] : q + 1;
 	nxt[a] = sarc[qn];
 	cnt[a] = 1;
+	flag[a] = is_random_splitter(a) ? 1u : 0u;
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -128,17 +117,20 @@ __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *sta
 	unsigned long long k = start_key[c];
 	return k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
 }
-__global__ void k_tour_cut(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
-			   const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ alast, uint32_t *__restrict__ nxt,
-			   uint32_t *__restrict__ cnt)
+// per component: cut its tour open behind the arc that returns to the root for the last time, and make the
+// first arc out of the root a (forced) splitter -- the head of the component's list
+__global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
+			    const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ nxt,
+			    uint32_t *__restrict__ cnt, uint32_t *__restrict__ flag)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= C)
 		return;
 	uint32_t r = comp_root_side(start_key, voff, c);
-	uint32_t a_end = sarc[alast[r]] ^ 1; // the arc that returns to the root for the last time
+	uint32_t a_end = sarc[aoff[r + 1] - 1] ^ 1;
 	nxt[a_end] = NIL;
 	cnt[a_end] = 0;
+	flag[sarc[aoff[r]]] = 1;
 }
 // one launch = two rounds of pointer jumping (three hops: every pointer then spans 4x as far), with two
 // accumulators (suffix sums along the list)
@@ -183,35 +175,7 @@ static int list_rank(uint32_t n, unsigned bits, uint32_t *nxtA, uint32_t *nxtB, 
 // ---- work-efficient list ranking: random splitters cut every list into short segments, each
 // splitter walks its segment (sums), the splitter list is ranked by pointer jumping, a second walk
 // hands every element its suffix sum.  Heads (elements nobody points to) are forced splitters.
-static constexpr uint32_t SPLIT_SHIFT = 29; // 1 element in 8 is a random splitter
-static constexpr uint32_t PK_END = 0x1FFFFFFFu;
-__device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
-
-// splitter flags: the random ones, plus every list head (the caller knows where its lists start, so no
-// "who has a predecessor" pass is needed)
-__global__ void k_rank_flags_tours(uint32_t n, uint32_t *__restrict__ flag)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n)
-		flag[i] = is_random_splitter(i) ? 1u : 0u;
-}
-__global__ void k_rank_heads_tours(uint32_t C, const uint32_t *__restrict__ voff,
-				   const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ sarc,
-				   const uint32_t *__restrict__ afirst, uint32_t *__restrict__ flag)
-{
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C)
-		return;
-	unsigned long long k = start_key[c];
-	uint32_t r = k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
-	flag[sarc[afirst[r]]] = 1; // the tour of component c starts with the first arc out of its root side
-}
-__global__ void k_rank_flags_events(uint32_t n, const uint32_t *__restrict__ dpar, uint32_t *__restrict__ flag)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) // event 2S = enter S heads a list iff S has no DFS parent
-		flag[i] = (is_random_splitter(i) || (!(i & 1) && dpar[i >> 1] == NIL)) ? 1u : 0u;
-}
+// (SPLIT_SHIFT / PK_END / is_random_splitter are defined at the top of the file.)
 // one word per element so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
 // bit 29 = the element's 0/1 weight, bit 31 = stop after this element (successor is a splitter / end)
 __global__ void k_rank_pack(uint32_t n, const uint32_t *__restrict__ nxt, const uint32_t *__restrict__ w1,
@@ -313,9 +277,16 @@ static void list_rank_splitters(uint32_t n, const uint32_t *nxt, const uint32_t 
 __global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
 			     const uint32_t *__restrict__ arc_dst, const uint32_t *__restrict__ arc_le,
 			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff, uint32_t *__restrict__ par0,
-			     uint32_t *__restrict__ size0, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ tourflag)
+			     uint32_t *__restrict__ size0, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ tourflag,
+			     uint32_t C, const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ P0)
 {
 	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a < C) { // the DFS start of component a roots its tree (no advance arc ever enters it)
+		uint32_t r = comp_root_side(start_key, voff, a);
+		par0[r] = NIL;
+		size0[r] = 2 * (voff[a + 1] - voff[a]);
+		P0[r] = 2 * voff[a];
+	}
 	if (a >= NA)
 		return;
 	uint32_t da = dist[a], dt = dist[a ^ 1];
@@ -331,17 +302,6 @@ __global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, con
 	} else {
 		tourflag[tix] = 0;
 	}
-}
-__global__ void k_t0_roots(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
-			   uint32_t *__restrict__ par0, uint32_t *__restrict__ size0, uint32_t *__restrict__ P0)
-{
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C)
-		return;
-	uint32_t r = comp_root_side(start_key, voff, c);
-	par0[r] = NIL;
-	size0[r] = 2 * (voff[c + 1] - voff[c]);
-	P0[r] = 2 * voff[c];
 }
 __global__ void k_t0_pre(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
 			 const uint32_t *__restrict__ arc_dst, const uint32_t *__restrict__ ckey,
@@ -380,11 +340,13 @@ __global__ void k_lowhigh(uint32_t nS, const uint32_t *__restrict__ loff, const 
 }
 __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ size0,
 			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ segLo, uint32_t PLo,
-			  const uint32_t *__restrict__ segHi, uint32_t PHi, uint32_t *__restrict__ isbridge)
+			  const uint32_t *__restrict__ segHi, uint32_t PHi, uint32_t *__restrict__ isbridge,
+			  uint32_t *__restrict__ ecc)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
+	ecc[S] = S; // every side starts as its own 2-edge-connected class
 	if (par0[S] == NIL) {
 		isbridge[S] = 0;
 		return;
@@ -451,12 +413,13 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const 
 			  const uint32_t *__restrict__ pe_le0, const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ cproc, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
-			  uint8_t *__restrict__ dvis, uint32_t *__restrict__ entry_flag)
+			  uint8_t *__restrict__ dvis, uint32_t *__restrict__ entry_flag, uint32_t *__restrict__ cur)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	dpar[S] = NIL;
+	cur[S] = 0; // scan position of the class DFS
 	cslot[S] = 0;
 	dvis[S] = 0;
 	entry_flag[S] = 0;
@@ -575,7 +538,7 @@ __global__ void k_child_link(uint32_t nS, const uint32_t *__restrict__ loff, con
 // events: 2S = enter S, 2S+1 = leave S
 __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
 			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ nxt, uint32_t *__restrict__ cnt,
-			 uint32_t *__restrict__ dep)
+			 uint32_t *__restrict__ dep, uint32_t *__restrict__ flag)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -585,6 +548,9 @@ __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const u
 	cnt[2 * S] = 1;
 	dep[2 * S] = 1;
 	uint32_t ns = nsib[S], p = dpar[S];
+	// splitters of the event ranking: the random ones, and "enter S" heads a list iff S has no DFS parent
+	flag[2 * S] = (is_random_splitter(2 * S) || p == NIL) ? 1u : 0u;
+	flag[2 * S + 1] = is_random_splitter(2 * S + 1) ? 1u : 0u;
 	nxt[2 * S + 1] = ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL);
 	cnt[2 * S + 1] = 0;
 	dep[2 * S + 1] = 0xFFFFFFFFu; // -1
@@ -596,9 +562,25 @@ __global__ void k_tree_emit(uint32_t nS, const uint32_t *__restrict__ cnt, const
 			    const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
 			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
 			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
-			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx)
+			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx,
+			    uint32_t C, uint32_t *__restrict__ c_ntree)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S < C) { // tree size of component S and its dummy root (spanning_tree.cpp:397-402)
+		if (!cproc[S]) {
+			c_ntree[S] = 0;
+		} else {
+			const uint32_t Nr = 2 * (voff[S + 1] - voff[S]), hr = start_key[S] != ~0ull ? 1u : 0u, tr = 2 * voff[S] + S;
+			c_ntree[S] = Nr + hr;
+			if (hr) {
+				t_gid[tr] = NIL;
+				t_flags[tr] = 2;
+				t_par[tr] = NIL;
+				t_size[tr] = Nr + 1;
+				t_depth[tr] = 0;
+			}
+		}
+	}
 	if (S >= nS)
 		return;
 	uint32_t c = ckey[S >> 1];
@@ -618,28 +600,6 @@ __global__ void k_tree_emit(uint32_t nS, const uint32_t *__restrict__ cnt, const
 	t_size[t] = size;
 	t_depth[t] = depth + hd;
 	side_tidx[S] = t;
-}
-__global__ void k_tree_roots(uint32_t C, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
-			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ t_gid,
-			     uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par, uint32_t *__restrict__ t_size,
-			     uint32_t *__restrict__ t_depth, uint32_t *__restrict__ c_ntree)
-{
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C)
-		return;
-	if (!cproc[c]) {
-		c_ntree[c] = 0;
-		return;
-	}
-	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u, tb = 2 * voff[c] + c;
-	c_ntree[c] = Nh + hd;
-	if (hd) { // dummy root, spanning_tree.cpp:397-402
-		t_gid[tb] = NIL;
-		t_flags[tb] = 2;
-		t_par[tb] = NIL;
-		t_size[tb] = Nh + 1;
-		t_depth[tb] = 0;
-	}
 }
 // back edges of from_bd out of side S, in scan order (process_edge, spanning_tree.cpp:360-398):
 //  - a side without links points back at the root unless the root is its tree parent (:433-438)
@@ -753,7 +713,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
 	take((void **)&tw.arc_le, NA * 2);
-	for (uint32_t **p : {&tw.afirst, &tw.alast, &tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.isbridge,
+	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.isbridge,
 			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_flag, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
 			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
@@ -797,29 +757,21 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	scan(cs.tgray, tw.tg_ps, (size_t)E + 1);
 	const uint32_t NTG = V - C; // a spanning forest; k_arcs_gray raises err[2] if the hooks disagree
 	const uint32_t NA = 2 * (V + NTG);
-	LAUNCH(k_arcs_black, V, s, V, tw.arc_src, tw.arc_dst, tw.arc_le);
+	uint32_t *acnt = tw.k1, *aoff = tw.k2, *cursor = tw.v1; // [nS+1] each fits the 4V+8 buffers
+	LAUNCH(k_arcs_black, V, s, V, tw.arc_src, tw.arc_dst, tw.arc_le, acnt, cursor);
 	LAUNCH(k_arcs_gray, E, s, E, V, cs.tgray, tw.tg_ps, cs.la, cs.lb, tw.arc_src, tw.arc_dst, tw.arc_le, NTG, pw.err + 2);
-	{
-		uint32_t *acnt = tw.k1, *aoff = tw.k2, *cursor = tw.v1; // [nS+1] each fits the 4V+8 buffers
-		LAUNCH(k_arc_init_count, nS, s, nS, acnt);
-		LAUNCH(k_arc_count, E, s, E, cs.tgray, cs.la, cs.lb, acnt);
-		scan(acnt, aoff, (size_t)nS + 1);
-		HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)nS * 4, s));
-		LAUNCH(k_arc_place, NA, s, NA, 2 * V, tw.arc_src, aoff, cursor, tw.apos, tw.v2);
-		LAUNCH(k_arc_bounds, nS, s, nS, aoff, tw.afirst, tw.alast);
-	}
-	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, tw.afirst, tw.alast, tw.nxtA, tw.cntA);
-	LAUNCH(k_tour_cut, C, s, C, cs.voff, start_key, tw.v2, tw.alast, tw.nxtA, tw.cntA);
+	LAUNCH(k_arc_count, E, s, E, cs.tgray, cs.la, cs.lb, acnt);
+	scan(acnt, aoff, (size_t)nS + 1);
+	LAUNCH(k_arc_place, NA, s, NA, 2 * V, tw.arc_src, aoff, cursor, tw.apos, tw.v2);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
-	LAUNCH(k_rank_flags_tours, NA, s, NA, rb.flag);
-	LAUNCH(k_rank_heads_tours, C, s, C, cs.voff, start_key, tw.v2, tw.afirst, rb.flag);
+	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, tw.nxtA, tw.cntA, rb.flag);
+	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, tw.nxtA, tw.cntA, rb.flag);
 	list_rank_splitters<false>(NA, tw.nxtA, tw.cntA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
-	LAUNCH(k_t0_parents, NA, s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0, tw.pe_le0,
-	       tw.tourflag);
+	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
+	       tw.pe_le0, tw.tourflag, C, start_key, tw.P0);
 	scan(tw.tourflag, tw.tour_ps, (size_t)NA + 1);
-	LAUNCH(k_t0_roots, C, s, C, cs.voff, start_key, tw.par0, tw.size0, tw.P0);
 	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, tw.arc_dst, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
 	tm.end(40);
 
@@ -828,8 +780,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_lowhigh, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.P0, tw.lowP, tw.highP);
 	seg_build(tw.segLo, tw.lowP, nS, s);
 	seg_build(tw.segHi, tw.highP, nS, s);
-	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, tw.segLo.tree, tw.segLo.P, tw.segHi.tree, tw.segHi.P, tw.isbridge);
-	LAUNCH(k_iota, nS, s, nS, tw.ecc);
+	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, tw.segLo.tree, tw.segLo.P, tw.segHi.tree, tw.segHi.P, tw.isbridge,
+	       tw.ecc);
 	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc);
 	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc);
@@ -838,11 +790,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, tw.dpar, tw.cslot,
-	       tw.dvis, tw.entry_flag);
+	       tw.dvis, tw.entry_flag, sw.cur);
 	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
 	const uint32_t n_entry = tw.host->read_u32(tw.entry_ps + nS, s);
-	HIP_CHECK(hipMemsetAsync(sw.cur, 0, (size_t)nS * 4, s));
 	if (n_entry)
 		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj,
 				   tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
@@ -858,9 +809,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		LAUNCH(k_child_link, nS, s, nS, cs.loff, slot_child, tw.dpar, tw.fc, tw.nsib);
 		(void)max_side_links;
 	}
-	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA);
 	// one list per processed component, one two-event list per side of an unprocessed one
-	LAUNCH(k_rank_flags_events, 2 * nS, s, 2 * nS, tw.dpar, rb.flag);
+	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA, rb.flag);
 	list_rank_splitters<true>(2 * nS, tw.nxtA, tw.cntA, tw.cntB, tw.depB, event_lists, rb, s);
 	const uint32_t *cnt = tw.cntB, *dep = tw.depB;
 	tm.end(40);
@@ -868,9 +818,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
 	LAUNCH(k_tree_emit, nS, s, nS, cnt, dep, tw.dpar, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
-	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx);
-	LAUNCH(k_tree_roots, C, s, C, tw.cproc, cs.voff, start_key, sw.t_gid, sw.t_flags, sw.t_par, sw.t_size, sw.t_depth,
-	       sw.c_ntree);
+	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree);
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
 		const uint32_t n_slots = 2 * E;

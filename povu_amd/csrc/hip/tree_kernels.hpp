@@ -14,7 +14,7 @@ struct TreeWs {
 	uint32_t *tg_ps;				  // [E+1] rank of tree-gray links
 	uint32_t *arc_src, *arc_dst, *arc_le;		  // [NA], arc_le per tree edge [NA/2]
 	uint32_t *k1, *k2, *v1, *v2;			  // [4V+4] sort buffers
-	uint32_t *apos, *afirst, *alast;		  // [NA], [2V], [2V]
+	uint32_t *apos;					  // [NA] position of an arc in its side's arc list
 	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
 	uint32_t *tourflag, *tour_ps;			  // [4V+4]
 	uint32_t *par0, *size0, *P0, *pe_le0;		  // [2V]

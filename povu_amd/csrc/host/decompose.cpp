@@ -47,7 +47,8 @@ void do_decompose(const Config &cfg)
 	}
 	if (ll > 1)
 		info("Finding components");
-	povu_hip_opts opts{0, 1, cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u};
+	// per-stage HIP events only when the stage-cost lines will be printed
+	povu_hip_opts opts{0, 1, (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | (ll ? 0u : POVU_HIP_F_NO_STAGE_TIMES)};
 	const double t2 = now_ms();
 	povu_hip_forest *f = povu_hip_decompose(ctx, &opts, err, sizeof err);
 	const double t3 = now_ms();

@@ -43,6 +43,7 @@ F_SEQUENTIAL = 2
 F_SEQ_TREE = 4
 F_FORCE_REDO = 8
 F_SORTED_ADJ = 16
+F_NO_STAGE_TIMES = 32
 
 _lib = None
 
