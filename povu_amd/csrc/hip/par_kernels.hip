@@ -33,7 +33,10 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 	} while (0)
 
 // ------------------------------------------------------------- T-space setup
-__global__ void k_tcomp_vertices(uint32_t V, const uint32_t *__restrict__ ckey, uint32_t *__restrict__ t_comp)
+// component c owns the tree-vertex slots [2 voff[c] + c, 2 voff[c+1] + c]: two per segment and one more
+// (the dummy root, when it exists, shifts the sides up by one); t_comp[T] = NIL closes the array
+__global__ void k_tcomp_vertices(uint32_t V, uint32_t T, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
+				 uint32_t *__restrict__ t_comp)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= V)
@@ -41,21 +44,22 @@ __global__ void k_tcomp_vertices(uint32_t V, const uint32_t *__restrict__ ckey, 
 	uint32_t c = ckey[i];
 	t_comp[2 * i + c] = c;
 	t_comp[2 * i + 1 + c] = c;
-}
-__global__ void k_tcomp_last(uint32_t C, const uint32_t *__restrict__ voff, uint32_t *__restrict__ t_comp)
-{
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c < C)
-		t_comp[2 * voff[c + 1] + c] = c;
+	if (i + 1 == voff[c + 1])
+		t_comp[2 * i + 2 + c] = c;
+	if (i == V - 1)
+		t_comp[T] = NIL;
 }
 __global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ voff,
 			    const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ t_par,
 			    const uint32_t *__restrict__ t_size, uint32_t *__restrict__ gpar, uint32_t *__restrict__ gsize,
-			    uint32_t *__restrict__ t_root)
+			    uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi0)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
+	hi0[t] = NIL; // k_hi0 takes minima into it
+	if (t == T - 1)
+		hi0[T] = NIL;
 	uint32_t c = t_comp[t];
 	uint32_t base = 2 * voff[c] + c, l = t - base;
 	t_root[t] = base;
@@ -181,11 +185,15 @@ __global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const 
 // mpre(v) = depth(v) + N - v - size(v)  (local indices, N = tree vertices of the component).
 __global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ depth,
 		       const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ t_comp,
-		       const uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ mpre)
+		       const uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
+		       uint32_t *__restrict__ srccnt)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
 		return;
+	incnt[v] = srccnt[v] = 0; // bracket counters of the next kernels, [T+2] each
+	if (v == T - 1)
+		incnt[T] = incnt[T + 1] = srccnt[T] = srccnt[T + 1] = 0;
 	uint32_t sz = gsize[v];
 	if (!sz) {
 		mpre[v] = NIL;
@@ -329,11 +337,14 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
 __global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-			      const uint32_t *__restrict__ lsz, uint32_t *__restrict__ flag)
+			      const uint32_t *__restrict__ lsz, uint32_t *__restrict__ flag, uint32_t *__restrict__ dlt)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
 		return;
+	dlt[q] = 0; // row E's difference array, [T+2]
+	if (q == T - 1)
+		dlt[T] = dlt[T + 1] = 0;
 	uint32_t k = skey[q];
 	if (k == NIL) {
 		flag[q] = 0;
@@ -345,15 +356,14 @@ __global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restr
 }
 __global__ void k_class_scatter(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 				const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
-				uint32_t *__restrict__ gcls)
+				uint32_t *__restrict__ gcls, uint32_t *__restrict__ t_cls)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
 		return;
-	if (skey[q] == NIL)
-		gcls[sval[q]] = NIL;
-	else
-		gcls[sval[q]] = ps[q] + flag[q] - 1; // inclusive scan - 1
+	const uint32_t cls = skey[q] == NIL ? NIL : ps[q] + flag[q] - 1; // inclusive scan - 1
+	gcls[sval[q]] = cls;
+	t_cls[sval[q]] = cls; // the per-component layout the debug hooks / sequential kernels read
 }
 
 // ------------------------------------------------------------- row E
@@ -395,9 +405,11 @@ __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const
 			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
 			     const uint32_t *__restrict__ t_comp, uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls,
 			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns,
-			     uint32_t *__restrict__ prev)
+			     uint32_t *__restrict__ prev, uint32_t C, const uint32_t *__restrict__ voff, uint32_t *__restrict__ soff)
 {
 	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m <= C) // first candidate-stack entry of component m
+		soff[m] = m == C ? ps[T] : ps[2 * voff[m] + m];
 	if (m >= T || !flag[m])
 		return;
 	uint32_t v = inv[m], i = ps[m];
@@ -408,15 +420,6 @@ __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const
 	ns[i] = i; // "no later occurrence" until k_next_from_runs says otherwise (flubbles.cpp:391-399)
 	prev[i] = NIL;
 }
-__global__ void k_stack_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ ps,
-				uint32_t T, uint32_t *__restrict__ soff)
-{
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c > C)
-		return;
-	soff[c] = c == C ? ps[T] : ps[2 * voff[c] + c];
-}
-
 // ------------------------------------------------------------- row F
 // next_seen without another sort.  The class stage already grouped the tree vertices by top bracket
 // with every group ordered from the deepest vertex up, and a class is a run inside a group.  The
@@ -454,28 +457,23 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 // flubble and descends (D).  When the (prev, i) intervals are laminar the class is open iff it
 // occurred before, so U/D are known per entry; a crossing pair sends the component to the
 // sequential kernel instead.
-__global__ void k_laminar(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
-			  const uint32_t *__restrict__ s_comp, uint32_t *__restrict__ comp_bad)
+// one kernel: the laminarity check of the (prev, i) intervals and the +-1 walk of the stack machine
+__global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
+			       const uint32_t *__restrict__ s_comp, uint32_t *__restrict__ comp_bad,
+			       const uint32_t *__restrict__ ns, uint32_t *__restrict__ walk, uint32_t *__restrict__ dflag)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S)
 		return;
-	uint32_t p = prev[i];
+	const uint32_t p = prev[i];
+	uint32_t d = (i + 1 < ns[i]) ? 1u : 0u;
+	walk[2 * i] = p != NIL ? 0xFFFFFFFFu : 0u; // -1
+	walk[2 * i + 1] = d;
+	dflag[i] = d;
 	if (p == NIL || p + 1 >= i)
 		return;
 	if (seg_min(segP, P, p + 1, i) < p)
 		comp_bad[s_comp[i]] = 1;
-}
-__global__ void k_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ ns,
-		       uint32_t *__restrict__ walk, uint32_t *__restrict__ dflag)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= S)
-		return;
-	uint32_t d = (i + 1 < ns[i]) ? 1u : 0u;
-	walk[2 * i] = prev[i] != NIL ? 0xFFFFFFFFu : 0u; // -1
-	walk[2 * i + 1] = d;
-	dflag[i] = d;
 }
 __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const uint32_t *__restrict__ ps,
 			    uint32_t *__restrict__ out)
@@ -574,13 +572,6 @@ __global__ void k_export_stack(uint32_t S, const uint32_t *__restrict__ s_comp, 
 	o_cls[voff[c] + l] = s_cls[i];
 	o_ns[voff[c] + l] = ns[i] - soff[c];
 }
-__global__ void k_export_cls(uint32_t T, const uint32_t *__restrict__ gcls, uint32_t *__restrict__ t_cls)
-{
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t < T)
-		t_cls[t] = gcls[t];
-}
-
 // ------------------------------------------------------------- hairpin boundaries
 // The reverse pre-order sweep opens a hairpin at every simplifying vertex (b1 = its segment), extends
 // b2 while the top bracket is a simplifying edge, and closes it at the next leaf (or the root)
@@ -775,10 +766,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- T-space + dense back edges
 	tm.begin("par_setup");
-	fill_u32(pw.t_comp, (size_t)T + 1, NIL, s);
-	LAUNCH(k_tcomp_vertices, V, s, V, cs.ckey, pw.t_comp);
-	LAUNCH(k_tcomp_last, C, s, C, cs.voff, pw.t_comp);
-	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root);
+	LAUNCH(k_tcomp_vertices, V, s, V, T, cs.ckey, cs.voff, pw.t_comp);
+	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0);
 	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
@@ -793,7 +782,6 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- row D
 	tm.begin("par_classes");
 	uint32_t launches = 0;
-	fill_u32(pw.hi0, (size_t)T + 1, NIL, s);
 	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0);
 	seg_build(pw.segA, pw.hi0, T, s);
 	uint32_t *bridge = pw.flagA, *psb = pw.psA, *simp = pw.flagB, *pssimp = pw.psB, *capf = pw.flagC, *pscap = pw.psC;
@@ -803,15 +791,13 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi, pw.hi0, pw.cap_tgt, capf);
 	scan(simp, pssimp, (size_t)T + 1);
 	scan(capf, pscap, (size_t)T + 1);
-	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre);
+	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
+	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre, pw.incnt, srccnt);
 	uint32_t *extra = pw.host->take<uint32_t>(2);
 	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
-	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)T + 2) * 4, s));
-	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
-	HIP_CHECK(hipMemsetAsync(srccnt, 0, ((size_t)T + 2) * 4, s));
 	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt);
 	if (dense_nb0 >= 0) { // ranks inside every source are known: place directly
 		LAUNCH(k_bracket_count, NB, s, NB, pw.b_src, pw.b_tgt, pw.mpre, pw.incnt, srccnt);
@@ -834,16 +820,14 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, T, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 	uint32_t *cflag = pw.flagA, *cps = pw.psA; // bridge flags are dead by now
-	LAUNCH(k_class_flags, T, s, T, 0u, ck2, pw.vals_t2, pw.lsz, cflag);
+	LAUNCH(k_class_flags, T, s, T, 0u, ck2, pw.vals_t2, pw.lsz, cflag, pw.dlt);
 	scan(cflag, cps, (size_t)T + 1);
-	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls);
-	LAUNCH(k_export_cls, T, s, T, pw.gcls, sw.t_cls);
+	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls, sw.t_cls);
 	launches = 30 + 2 * 22;
 	tm.end(launches);
 
 	// ---- row E
 	tm.begin("par_stack");
-	HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)T + 2) * 4, s));
 	LAUNCH(k_shift_delta, T, s, T, pw.gsize, pw.gpar, sw.t_flags, pw.dlt);
 	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
 	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.inv);
@@ -851,8 +835,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
 	scan(bflag, bps, (size_t)T + 1);
 	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
-	       pw.prev);
-	LAUNCH(k_stack_offsets, (size_t)C + 1, s, C, cs.voff, bps, T, pw.soff);
+	       pw.prev, C, cs.voff, pw.soff);
 	const uint32_t S = pw.host->read_u32(bps + T, s);
 	tm.end(9);
 
@@ -869,9 +852,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- row G
 	tm.begin("par_pvst");
 	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
-	LAUNCH(k_laminar, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.comp_bad);
 	uint32_t *dflag = pw.s_key; // scratch
-	LAUNCH(k_walk, S, s, S, pw.prev, pw.ns, pw.walk, dflag);
+	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.comp_bad, pw.ns, pw.walk, dflag);
 	scan(dflag, pw.erank, (size_t)S + 1);
 	scan(pw.walk, pw.walk_ps, (size_t)2 * S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
