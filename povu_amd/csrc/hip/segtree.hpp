@@ -95,48 +95,49 @@ __device__ __forceinline__ uint32_t seg_descend_last(const uint32_t *__restrict_
 		node = tree[2 * node + 1] < x ? 2 * node + 1 : 2 * node;
 	return node - P;
 }
-// first idx in [l, r) whose value is < x, NIL if none
+// first idx in [l, r) whose value is < x, NIL if none.  Walks the disjoint subtrees to the right of l (leaf, then
+// right siblings going up), descends into the first one whose minimum is < x; no per-thread node stack.
 static __device__ uint32_t seg_first_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
 {
 	if (l >= r)
 		return NIL;
-	uint32_t right[32];
-	int nr = 0;
-	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
-		if (l & 1) {
-			if (tree[l] < x)
-				return seg_descend_first(tree, P, l, x);
-			l++;
+	uint32_t node = l + P;
+	for (;;) {
+		if (tree[node] < x) {
+			uint32_t i = seg_descend_first(tree, P, node, x);
+			return i < r ? i : NIL;
 		}
-		if (r & 1)
-			right[nr++] = --r;
+		while (node & 1) // a right child: everything under its parent is either rejected or left of l
+			node >>= 1;
+		if (node == 0)
+			return NIL; // ran off the right edge
+		node += 1;
+		// leftmost leaf under `node` is already >= r: nothing left to find (keeps the walk inside the query)
+		const uint32_t first = node << (__clz(node) - __clz(P)); // P is a power of two
+		if (first - P >= r)
+			return NIL;
 	}
-	for (int k = nr - 1; k >= 0; k--)
-		if (tree[right[k]] < x)
-			return seg_descend_first(tree, P, right[k], x);
-	return NIL;
 }
-// last idx in [l, r) whose value is < x, NIL if none
+// last idx in [l, r) whose value is < x, NIL if none (mirror image of seg_first_less)
 static __device__ uint32_t seg_last_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
 {
 	if (l >= r)
 		return NIL;
-	uint32_t left[32];
-	int nl = 0;
-	for (l += P, r += P; l < r; l >>= 1, r >>= 1) {
-		if (r & 1) {
-			--r;
-			if (tree[r] < x)
-				return seg_descend_last(tree, P, r, x);
+	uint32_t node = r - 1 + P;
+	for (;;) {
+		if (tree[node] < x) {
+			uint32_t i = seg_descend_last(tree, P, node, x);
+			return i >= l ? i : NIL;
 		}
-		if (l & 1)
-			left[nl++] = l++;
+		while (!(node & 1)) // a left child
+			node >>= 1;
+		if (node == 1)
+			return NIL; // ran off the left edge
+		node -= 1;
+		const uint32_t last = ((node + 1) << (__clz(node) - __clz(P))) - 1;
+		if (last - P < l)
+			return NIL;
 	}
-	for (int k = nl - 1; k >= 0; k--)
-		if (tree[left[k]] < x)
-			return seg_descend_last(tree, P, left[k], x);
-	return NIL;
 }
-
 
 } // namespace povu_hip
