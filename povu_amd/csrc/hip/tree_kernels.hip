@@ -40,61 +40,57 @@ static constexpr uint32_t PK_END = 0x1FFFFFFFu;
 __device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
 
 // ------------------------------------------------------------------ 1. arcs of the spanning forest
-// also: every side starts with one arc (the black one) and an empty cursor for its gray arcs
-__global__ void k_arcs_black(uint32_t V, uint32_t *__restrict__ arc_src, uint32_t *__restrict__ arc_dst,
-			     uint32_t *__restrict__ arc_le, uint32_t *__restrict__ acnt, uint32_t *__restrict__ cursor)
+// Arcs: 2i / 2i+1 = the black edge of segment i seen from its l / r side (so the black arc of side S is
+// arc S); 2k / 2k+1 with k = V + rank of the link among the tree-gray links = la -> lb / lb -> la.
+// The arcs leaving a side are grouped (any cyclic order of a side's arcs gives a valid Euler tour): slot 0
+// = the black arc, then the side's tree-gray links in adjacency order.  No atomics: a side counts and
+// places its own arcs.
+__global__ void k_arc_count(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
+			    const uint32_t *__restrict__ tgray, uint32_t *__restrict__ acnt)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= V)
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
 		return;
-	arc_src[2 * i] = 2 * i;
-	arc_dst[2 * i] = 2 * i + 1;
-	arc_src[2 * i + 1] = 2 * i + 1;
-	arc_dst[2 * i + 1] = 2 * i;
-	arc_le[i] = NIL;
-	acnt[2 * i] = acnt[2 * i + 1] = 1;
-	cursor[2 * i] = cursor[2 * i + 1] = 0;
+	uint32_t n = 1;
+	for (uint32_t k = loff[S]; k < loff[S + 1]; k++)
+		n += tgray[lle[k]] ? 1u : 0u;
+	acnt[S] = n;
 }
-__global__ void k_arcs_gray(uint32_t E, uint32_t V, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
-			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ lb, uint32_t *__restrict__ arc_src,
-			    uint32_t *__restrict__ arc_dst, uint32_t *__restrict__ arc_le, uint32_t expect, uint32_t *err)
+__global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t *__restrict__ loff,
+			    const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
+			    const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
+			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ arc_src,
+			    uint32_t *__restrict__ arc_dst, uint32_t *__restrict__ arc_le, uint32_t *__restrict__ apos,
+			    uint32_t *__restrict__ sarc, uint32_t expect, uint32_t *err)
 {
-	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
-	if (le == 0 && tg_ps[E] != expect)
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S == 0 && tg_ps[E] != expect) // the hooks of the union-find are not a spanning forest
 		atomicExch(err, 1u);
-	if (le >= E || !tgray[le])
+	if (S >= nS)
 		return;
-	uint32_t k = V + tg_ps[le];
-	if (tg_ps[le] >= expect) // never write past the arcs the launch was sized for
-		return;
-	arc_src[2 * k] = la[le];
-	arc_dst[2 * k] = lb[le];
-	arc_src[2 * k + 1] = lb[le];
-	arc_dst[2 * k + 1] = la[le];
-	arc_le[k] = le;
-}
-// Arc lists per side WITHOUT a sort: any cyclic order of a side's arcs gives a valid Euler tour, so
-// the arcs are only grouped: slot 0 of side S = its black arc, the gray tree arcs follow (atomic cursor).
-__global__ void k_arc_count(uint32_t E, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ la,
-			    const uint32_t *__restrict__ lb, uint32_t *__restrict__ acnt)
-{
-	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
-	if (le >= E || !tgray[le])
-		return;
-	atomicAdd(&acnt[la[le]], 1u);
-	atomicAdd(&acnt[lb[le]], 1u);
-}
-__global__ void k_arc_place(uint32_t NA, uint32_t nblack_arcs, const uint32_t *__restrict__ arc_src,
-			    const uint32_t *__restrict__ aoff, uint32_t *__restrict__ cursor, uint32_t *__restrict__ apos,
-			    uint32_t *__restrict__ sarc)
-{
-	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= NA)
-		return;
-	uint32_t S = arc_src[a];
-	uint32_t q = a < nblack_arcs ? aoff[S] : aoff[S] + 1 + atomicAdd(&cursor[S], 1u);
-	apos[a] = q;
-	sarc[q] = a;
+	uint32_t q = aoff[S];
+	sarc[q] = S;
+	apos[S] = q;
+	arc_src[S] = S;
+	arc_dst[S] = S ^ 1u;
+	if (!(S & 1u))
+		arc_le[S >> 1] = NIL;
+	for (uint32_t k = loff[S]; k < loff[S + 1]; k++) {
+		const uint32_t le = lle[k];
+		if (!tgray[le])
+			continue;
+		const uint32_t t = tg_ps[le];
+		if (t >= expect) // never write past the arcs the launch was sized for
+			continue;
+		const uint32_t dir = la[le] == S ? 0u : 1u, a = 2 * (V + t) + dir;
+		q++;
+		sarc[q] = a;
+		apos[a] = q;
+		arc_src[a] = S;
+		arc_dst[a] = ladj[k];
+		if (!dir)
+			arc_le[V + t] = le;
+	}
 }
 // Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
 // (side w's arcs sit at [aoff[w], aoff[w+1])); also draws the random splitters of the tour ranking
@@ -755,14 +751,13 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
 	scan(cs.tgray, tw.tg_ps, (size_t)E + 1);
-	const uint32_t NTG = V - C; // a spanning forest; k_arcs_gray raises err[2] if the hooks disagree
+	const uint32_t NTG = V - C; // a spanning forest; k_arc_lists raises err[2] if the hooks disagree
 	const uint32_t NA = 2 * (V + NTG);
-	uint32_t *acnt = tw.k1, *aoff = tw.k2, *cursor = tw.v1; // [nS+1] each fits the 4V+8 buffers
-	LAUNCH(k_arcs_black, V, s, V, tw.arc_src, tw.arc_dst, tw.arc_le, acnt, cursor);
-	LAUNCH(k_arcs_gray, E, s, E, V, cs.tgray, tw.tg_ps, cs.la, cs.lb, tw.arc_src, tw.arc_dst, tw.arc_le, NTG, pw.err + 2);
-	LAUNCH(k_arc_count, E, s, E, cs.tgray, cs.la, cs.lb, acnt);
+	uint32_t *acnt = tw.k1, *aoff = tw.k2; // [nS+1] each fits the 4V+8 buffers
+	LAUNCH(k_arc_count, nS, s, nS, cs.loff, cs.lle, cs.tgray, acnt);
 	scan(acnt, aoff, (size_t)nS + 1);
-	LAUNCH(k_arc_place, NA, s, NA, 2 * V, tw.arc_src, aoff, cursor, tw.apos, tw.v2);
+	LAUNCH(k_arc_lists, nS, s, nS, V, E, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.tg_ps, cs.la, aoff, tw.arc_src, tw.arc_dst,
+	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
 	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, tw.nxtA, tw.cntA, rb.flag);
