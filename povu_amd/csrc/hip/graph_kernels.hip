@@ -232,13 +232,18 @@ __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint32_t *__restrict_
 }
 
 __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const uint32_t *__restrict__ crank,
-			  uint32_t *__restrict__ comp_of, uint32_t *__restrict__ iota)
+			  uint32_t *__restrict__ comp_of, uint32_t *__restrict__ iota, uint32_t C,
+			  unsigned long long *__restrict__ start_key)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= V)
 		return;
 	comp_of[v] = crank[label[v]];
 	iota[v] = v;
+	if (v <= C) // "no tip yet" for k_sorted_vertices' atomicMin; C <= V, and the last lane closes the array
+		start_key[v] = ~0ull;
+	if (v == V - 1)
+		start_key[C] = ~0ull;
 }
 
 // after the stable sort by component: sorted position i holds global vertex perm[i]
@@ -247,11 +252,13 @@ __global__ void k_sorted_vertices(uint32_t V, uint32_t C, const uint32_t *__rest
 				  const uint32_t *__restrict__ vid, const uint8_t *__restrict__ tip,
 				  uint32_t *__restrict__ pos, uint32_t *__restrict__ voff, uint32_t *__restrict__ vdeg,
 				  uint32_t *__restrict__ gid_s, uint8_t *__restrict__ tip_s,
-				  unsigned long long *__restrict__ start_key)
+				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= V)
 		return;
+	if (i < 4)
+		stats[i] = 0; // stats[0] = most links on one side (k_mark_first2 / k_max_u32)
 	uint32_t v = perm[i], c = ckey[i];
 	pos[v] = i;
 	if (i == 0 || ckey[i - 1] != c)
@@ -363,6 +370,8 @@ __global__ void k_mark_first2(uint32_t V, const uint32_t *__restrict__ perm, con
 			if ((aoth[k] >> 1) == v && first[adj[k]] == P)
 				cnt++;
 		ldeg[S] = cnt;
+		if (S == 2 * V - 1)
+			ldeg[2 * V] = 0; // closes the array the scan turns into loff
 	}
 	uint32_t m = cnt;
 	for (int o = 32; o; o >>= 1)
@@ -566,7 +575,8 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	uint32_t launches = 0;
 	// stable sort of vertices by component rank: local vertex idx = rank inside the component,
 	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
-	hipLaunchKernelGGL(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a);
+	hipLaunchKernelGGL(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a, C,
+			   (unsigned long long *)st.start_key);
 	if (C == 1) { // one component: the order is already (component, idx); the key / permutation arrays
 		      // simply alias what k_comp_of wrote (all-zero component ranks, identity permutation)
 		st.ckey = st.comp_of;
@@ -574,22 +584,18 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	} else {
 		sort_pairs_u32(st.comp_of, st.ckey, st.tmp_a, st.perm, V, bits_for(C), st.sort_tmp, st.sort_tmp_bytes, s);
 	}
-	hipLaunchKernelGGL(k_fill_u64, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, (size_t)C + 1,
-			   (unsigned long long *)st.start_key, ~0ull);
 	hipLaunchKernelGGL(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
-			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key);
+			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats);
 	scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	launches += 5;
 	// first-encounter rank of every edge
 	fill_u32(st.first, E, POVU_NIL, s);
 	hipLaunchKernelGGL(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
 	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
-		HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
 		hipLaunchKernelGGL(k_mark_first2, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, g.aoth, st.sbase,
 				   st.first, st.flag, st.ldeg, st.stats);
-		scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);
-		HIP_CHECK(hipMemsetAsync(st.ldeg + nS, 0, 4, s));
-		scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+		scan_exclusive_u32_pair(st.flag, st.erank, (size_t)g.n_slots + 1, st.ldeg, st.loff, nS + 1, st.scan_tmp,
+					st.scan_tmp_bytes, s);
 		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, g.aoth, st.sbase,
 				   st.first, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
 		hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,

@@ -763,6 +763,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
 		scan_exclusive_u32(in, out, n, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	};
+	auto scan2 = [&](const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1) {
+		scan_exclusive_u32_pair(in0, out0, n0, in1, out1, n1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	};
 
 	// ---- T-space + dense back edges
 	tm.begin("par_setup");
@@ -789,8 +792,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan(bridge, psb, (size_t)T + 1);
 	LAUNCH(k_hi_simp, T, s, T, pw.gsize, pw.hiA, bridge, psb, pw.t_root, pw.hi, simp, want_hp ? pw.hpf : nullptr);
 	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi, pw.hi0, pw.cap_tgt, capf);
-	scan(simp, pssimp, (size_t)T + 1);
-	scan(capf, pscap, (size_t)T + 1);
+	scan2(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre, pw.incnt, srccnt);
 	uint32_t *extra = pw.host->take<uint32_t>(2);
@@ -801,15 +803,13 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt);
 	if (dense_nb0 >= 0) { // ranks inside every source are known: place directly
 		LAUNCH(k_bracket_count, NB, s, NB, pw.b_src, pw.b_tgt, pw.mpre, pw.incnt, srccnt);
-		scan(pw.incnt, pw.psin, (size_t)T + 1);
-		scan(srccnt, bstart, (size_t)T + 1);
+		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
 		LAUNCH(k_bracket_place, NB, s, NB, NB0, ncap, pw.b_src, pw.b_tgt, pw.b_ord, pw.mpre, bstart, capf, simp, pw.tgtR,
 		       pw.b_val2);
 	} else {
 		uint32_t *bk = (uint32_t *)pw.b_key, *bk2 = (uint32_t *)pw.b_key2;
 		LAUNCH(k_bracket_order, NB, s, NB, NB0, ncap, nsimp, pw.b_src, pw.b_tgt, pw.mpre, bk, pw.b_val, pw.incnt, srccnt);
-		scan(pw.incnt, pw.psin, (size_t)T + 1);
-		scan(srccnt, bstart, (size_t)T + 1);
+		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
 		sort_pairs_u32(bk, bk2, pw.b_val, pw.b_val2, NB, bits_for(T), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
 	}
@@ -854,8 +854,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
 	uint32_t *dflag = pw.s_key; // scratch
 	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.comp_bad, pw.ns, pw.walk, dflag);
-	scan(dflag, pw.erank, (size_t)S + 1);
-	scan(pw.walk, pw.walk_ps, (size_t)2 * S);
+	scan2(dflag, pw.erank, (size_t)S + 1, pw.walk, pw.walk_ps, (size_t)2 * S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb);
 	seg_build(pw.segW, wb, (size_t)2 * S, s);

@@ -30,11 +30,28 @@ __device__ __forceinline__ uint32_t sc_block_reduce(uint32_t v, uint32_t *sh)
 	__syncthreads();
 	return r;
 }
+// One scan job; a launch carries one or two of them (blockIdx.y picks) so that independent scans that
+// are due at the same point of the pass share their two launches.
+struct ScanJob {
+	const uint32_t *in;
+	uint32_t *out;
+	size_t n, chunk;
+	uint32_t blocks;
+	uint32_t *partial;
+};
+struct ScanJobs {
+	ScanJob j[2];
+};
 template <bool MAX>
-__global__ void __launch_bounds__(SC_TPB) k_scan_partials(const uint32_t *__restrict__ in, size_t n, size_t chunk,
-							  uint32_t *__restrict__ partial)
+__global__ void __launch_bounds__(SC_TPB) k_scan_partials(const ScanJobs jobs)
 {
 	__shared__ uint32_t sh[4];
+	const ScanJob &J = jobs.j[blockIdx.y];
+	if (blockIdx.x >= J.blocks)
+		return;
+	const uint32_t *__restrict__ in = J.in;
+	uint32_t *__restrict__ partial = J.partial;
+	const size_t n = J.n, chunk = J.chunk;
 	const size_t b0 = (size_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
 	uint32_t acc = 0;
 	for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
@@ -44,11 +61,17 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_partials(const uint32_t *__rest
 		partial[blockIdx.x] = acc;
 }
 template <bool MAX>
-__global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
-							size_t chunk, const uint32_t *__restrict__ partial)
+__global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 {
 	__shared__ uint32_t sh[4];
 	__shared__ uint32_t wave_tot[4];
+	const ScanJob &J = jobs.j[blockIdx.y];
+	if (blockIdx.x >= J.blocks)
+		return;
+	const uint32_t *__restrict__ in = J.in;
+	uint32_t *__restrict__ out = J.out;
+	const uint32_t *__restrict__ partial = J.partial;
+	const size_t n = J.n, chunk = J.chunk;
 	uint32_t base = 0;
 	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += SC_TPB)
 		base = sc_op<MAX>(base, partial[k]);
@@ -105,7 +128,20 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const uint32_t *__restri
 
 size_t scan_tmp_bytes(size_t)
 {
-	return SC_MAX_BLOCKS * sizeof(uint32_t) + 256;
+	return 2 * SC_MAX_BLOCKS * sizeof(uint32_t) + 256;
+}
+
+static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial)
+{
+	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)
+		throw HipError("scan: operands must be 16-byte aligned");
+	size_t blocks = (n + SC_TILE - 1) / SC_TILE;
+	if (blocks > SC_MAX_BLOCKS)
+		blocks = SC_MAX_BLOCKS;
+	size_t chunk = (n + blocks - 1) / blocks;
+	chunk = (chunk + SC_TILE - 1) / SC_TILE * SC_TILE; // whole tiles: every tile base stays 16-byte aligned
+	blocks = (n + chunk - 1) / chunk;
+	return ScanJob{in, out, n, chunk, (uint32_t)blocks, partial};
 }
 
 template <bool MAX>
@@ -115,22 +151,33 @@ static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tm
 		return;
 	if (tmp_bytes < SC_MAX_BLOCKS * sizeof(uint32_t))
 		throw HipError("scan: temporary storage too small");
-	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)
-		throw HipError("scan: operands must be 16-byte aligned");
-	size_t blocks = (n + SC_TILE - 1) / SC_TILE;
-	if (blocks > SC_MAX_BLOCKS)
-		blocks = SC_MAX_BLOCKS;
-	size_t chunk = (n + blocks - 1) / blocks;
-	chunk = (chunk + SC_TILE - 1) / SC_TILE * SC_TILE; // whole tiles: every tile base stays 16-byte aligned
-	blocks = (n + chunk - 1) / chunk;
-	uint32_t *partial = static_cast<uint32_t *>(tmp);
-	hipLaunchKernelGGL(k_scan_partials<MAX>, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, in, n, chunk, partial);
-	hipLaunchKernelGGL(k_scan_chunks<MAX>, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, in, out, n, chunk, partial);
+	ScanJobs jobs{};
+	jobs.j[0] = make_scan_job(in, out, n, static_cast<uint32_t *>(tmp));
+	hipLaunchKernelGGL(k_scan_partials<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
+	hipLaunchKernelGGL(k_scan_chunks<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 }
 
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
 	scan_exclusive<false>(in, out, n, tmp, tmp_bytes, s);
+}
+
+void scan_exclusive_u32_pair(const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1,
+			     void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	if (n0 == 0 || n1 == 0) {
+		scan_exclusive<false>(in0, out0, n0, tmp, tmp_bytes, s);
+		scan_exclusive<false>(in1, out1, n1, tmp, tmp_bytes, s);
+		return;
+	}
+	if (tmp_bytes < 2 * SC_MAX_BLOCKS * sizeof(uint32_t))
+		throw HipError("scan: temporary storage too small");
+	ScanJobs jobs{};
+	jobs.j[0] = make_scan_job(in0, out0, n0, static_cast<uint32_t *>(tmp));
+	jobs.j[1] = make_scan_job(in1, out1, n1, static_cast<uint32_t *>(tmp) + SC_MAX_BLOCKS);
+	const unsigned gx = std::max(jobs.j[0].blocks, jobs.j[1].blocks);
+	hipLaunchKernelGGL(k_scan_partials<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
+	hipLaunchKernelGGL(k_scan_chunks<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
 }
 
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
