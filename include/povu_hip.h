@@ -179,6 +179,11 @@ int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint
 int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t *tree_vtx, uint32_t *cls,
 			 uint32_t *next_seen);
 
+/* unit-test hook for the device-wide scans of the path: exclusive scan of in[0..n) (op 0 = sum mod 2^32,
+ * 1 = running maximum) and, when in2 is given, an independent sum scan of in2[0..n2) in the same launch */
+int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t *out, size_t n, const uint32_t *in2,
+			uint32_t *out2, size_t n2);
+
 /* device workspace (bytes) one povu_hip_decompose call reserves for a graph of this size, excluding the
  * resident graph itself (~42 B/link + 13 B/segment) and the sequential kernels' lists; n_components = 0
  * assumes the worst case (every segment its own component); 0 when it cannot be computed */

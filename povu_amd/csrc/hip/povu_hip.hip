@@ -945,6 +945,40 @@ extern "C" uint32_t povu_hip_last_seq_redo(const povu_hip_ctx *ctx) { return ctx
 
 extern "C" uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx) { return ctx ? ctx->last_links : 0; }
 
+// ---- unit-test hook for the scans
+extern "C" int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t *out, size_t n, const uint32_t *in2,
+				   uint32_t *out2, size_t n2)
+{
+	if (!ctx || !in || !out || (in2 && !out2))
+		return 1;
+	try {
+		HIP_CHECK(hipSetDevice(ctx->device));
+		hipStream_t s = ctx->stream;
+		Arena ar;
+		const size_t tb = scan_tmp_bytes(std::max(n, n2));
+		ar.reserve(2 * Arena::padded(n + 16, 4) + 2 * Arena::padded(n2 + 16, 4) + tb + 4096);
+		uint32_t *di = ar.take<uint32_t>(n + 16), *dout = ar.take<uint32_t>(n + 16);
+		uint32_t *di2 = ar.take<uint32_t>(n2 + 16), *dout2 = ar.take<uint32_t>(n2 + 16);
+		void *tmp = ar.take<char>(tb);
+		HIP_CHECK(hipMemcpyAsync(di, in, n * 4, hipMemcpyHostToDevice, s));
+		if (in2)
+			HIP_CHECK(hipMemcpyAsync(di2, in2, n2 * 4, hipMemcpyHostToDevice, s));
+		if (in2 && op == 0)
+			scan_exclusive_u32_pair(di, dout, n, di2, dout2, n2, tmp, tb, s);
+		else if (op == 0)
+			scan_exclusive_u32(di, dout, n, tmp, tb, s);
+		else
+			scan_exclusive_max_u32(di, dout, n, tmp, tb, s);
+		HIP_CHECK(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, s));
+		if (in2 && op == 0)
+			HIP_CHECK(hipMemcpyAsync(out2, dout2, n2 * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		return 0;
+	} catch (const std::exception &) {
+		return 2;
+	}
+}
+
 // ---- stage-level parity hooks
 extern "C" int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *local_idx)
 {

@@ -96,6 +96,9 @@ def load_lib():
     l.povu_hip_debug_stack.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
                                        C.c_void_p]
     l.povu_hip_version.restype = C.c_char_p
+    l.povu_hip_debug_scan.restype = C.c_int
+    l.povu_hip_debug_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_size_t]
     l.povu_hip_workspace_estimate.restype = C.c_uint64
     l.povu_hip_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     _lib = l
@@ -244,6 +247,24 @@ class HipDecomposer:
         return int(self._lib.povu_hip_last_links_processed(self._ctx))
 
     # ---- parity hooks
+    def debug_scan(self, a, op: int = 0, b=None):
+        """Unit-test hook: exclusive scan of `a` on the device (op 0 sum, 1 running max); with `b`, an
+        independent sum scan of `b` in the same launch."""
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        out = np.empty_like(a)
+        if b is None:
+            rc = self._lib.povu_hip_debug_scan(self._ctx, op, a.ctypes.data, out.ctypes.data, a.size, None, None, 0)
+            if rc:
+                raise RuntimeError(f"debug_scan failed ({rc})")
+            return out
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        out2 = np.empty_like(b)
+        rc = self._lib.povu_hip_debug_scan(self._ctx, op, a.ctypes.data, out.ctypes.data, a.size, b.ctypes.data,
+                                           out2.ctypes.data, b.size)
+        if rc:
+            raise RuntimeError(f"debug_scan failed ({rc})")
+        return out, out2
+
     def debug_components(self, n_vtx: int):
         comp = np.zeros(n_vtx, dtype=np.uint32)
         loc = np.zeros(n_vtx, dtype=np.uint32)

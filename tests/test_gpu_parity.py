@@ -183,6 +183,24 @@ def test_both_local_adjacency_builders(hip, seed):
     assert hip.decompose(flags=F_SORTED_ADJ).texts() == want
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 8192, 100003, 4 * 1024 * 1024 + 5, 30_000_001])
+def test_single_pass_scans(hip, n):
+    """The device-wide exclusive scans against numpy: sum mod 2^32, running maximum, and two independent
+    scans sharing their launches."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 7, max(1, n // 3), dtype=np.uint64).astype(np.uint32)
+    z = np.zeros(1, dtype=np.uint64)  # (a python 0 would promote the concatenation to float64)
+    want_sum = np.concatenate([z, np.cumsum(a.astype(np.uint64))[:-1]]) & np.uint64(0xFFFFFFFF)
+    want_max = np.concatenate([z.astype(np.uint32), np.maximum.accumulate(a)[:-1]])
+    want_b = np.concatenate([z, np.cumsum(b.astype(np.uint64))[:-1]])
+    for _ in range(2):
+        assert np.array_equal(hip.debug_scan(a, 0), want_sum.astype(np.uint32))
+        assert np.array_equal(hip.debug_scan(a, 1), want_max.astype(np.uint32))
+        got_a, got_b = hip.debug_scan(a, 0, b)
+        assert np.array_equal(got_a, want_sum.astype(np.uint32)) and np.array_equal(got_b, want_b.astype(np.uint32))
+
+
 # ---- BASELINE.json full-size configurations
 def test_config2_chain_1m_nodes_bit_exact_vs_reference_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))

@@ -4,13 +4,16 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
-from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE
+from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 hip = HipDecomposer(0)
 rng = np.random.default_rng(12345)
 t0 = time.time(); n_graphs = 0; n_links = 0
+last = t0
 while time.time() - t0 < budget:
+    if time.time() - last > 60:
+        last = time.time(); print('...', n_graphs, 'graphs', flush=True)
     seed = int(rng.integers(1 << 30))
     kind = n_graphs % 6
     if kind == 0:
@@ -25,7 +28,7 @@ while time.time() - t0 < budget:
         n = int(rng.integers(10, 200)); g = W.random_bidirected(n, int(n * rng.uniform(1.5, 4.0)), seed, self_loops=True, connected=True)
     else:
         # chains with random extra links (long bridge chains + local tangles)
-        base = W.chain_of_bubbles(int(rng.integers(5, 300)))
+        base = W.chain_of_bubbles(int(rng.integers(5, 3000)))
         extra = W.random_bidirected(base.n_vtx, int(base.n_vtx * rng.uniform(0.0, 0.3)), seed)
         g = W._mk(base.vid, np.concatenate([base.v1, extra.v1]), np.concatenate([base.s1, extra.s1]),
                   np.concatenate([base.v2, extra.v2]), np.concatenate([base.s2, extra.s2]))
@@ -34,7 +37,7 @@ while time.time() - t0 < budget:
         tips = np.zeros(g.n_vtx, dtype=np.uint8)  # builder-style graphs without tips
     want = O.decompose(g, tips=tips)
     hip.upload(g, tips)
-    flags = [0, F_SEQ_TREE, F_HAIRPINS][n_graphs % 3]
+    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES][n_graphs % 5]
     got = hip.decompose(flags=flags).texts()
     if got != want:
         print('MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', flags, 'tips', tips is not None)
