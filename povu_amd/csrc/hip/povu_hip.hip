@@ -645,7 +645,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				launch_seq_components(sw, s);
 				tm.end(1);
 			} else {
-				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0], tm, s);
+				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0],
+							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0, tm, s);
 			}
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, dense_nb0, tm, s);
 			sum = read_summary(true);

@@ -337,12 +337,13 @@ __global__ void k_lowhigh(uint32_t nS, const uint32_t *__restrict__ loff, const 
 __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ size0,
 			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ segLo, uint32_t PLo,
 			  const uint32_t *__restrict__ segHi, uint32_t PHi, uint32_t *__restrict__ isbridge,
-			  uint32_t *__restrict__ ecc)
+			  uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	ecc[S] = S; // every side starts as its own 2-edge-connected class
+	csamp[S] = 0;
 	if (par0[S] == NIL) {
 		isbridge[S] = 0;
 		return;
@@ -393,7 +394,11 @@ __global__ void k_ecc_nontree(uint32_t E, const uint32_t *__restrict__ tgray, co
 		return;
 	uf_union2(ecc, la[le], lb[le]);
 }
-__global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc)
+// Also samples the class sizes: every 64th side counts itself at its class root, and the largest count
+// seen (>= CLASS_SAMPLE_MIN) lands in *big -- a class of a few thousand sides or more is walked by the
+// class DFS with the short dependent chain (k_class_adj), at the price of a filtering pass.
+static constexpr uint32_t CLASS_SAMPLE_MIN = 16; // ~1000 sides
+__global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc, uint32_t *__restrict__ csamp, uint32_t *__restrict__ big)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -402,6 +407,11 @@ __global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc)
 	while (ecc[r] != r)
 		r = ecc[r];
 	ecc[S] = r;
+	if ((S & 63u) == 0) {
+		const uint32_t c = atomicAdd(&csamp[r], 1u) + 1;
+		if (c >= CLASS_SAMPLE_MIN)
+			atomicMax(big, c);
+	}
 }
 
 // ------------------------------------------------------------------ 5. class entries
@@ -415,7 +425,7 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const 
 	if (S >= nS)
 		return;
 	dpar[S] = NIL;
-	cur[S] = 0; // scan position of the class DFS
+	cur[S] = 0; // scan position of the plain class DFS
 	cslot[S] = 0;
 	dvis[S] = 0;
 	entry_flag[S] = 0;
@@ -455,11 +465,36 @@ __global__ void k_compact(uint32_t n, const uint32_t *__restrict__ flag, const u
 }
 
 // ------------------------------------------------------------------ 6. the DFS inside every class
-// Stackless: cur[] holds the scan position of every side (0 = black edge, k = k-th gray link),
-// dpar[] is the way back.  Classes are disjoint, so lanes never touch each other's sides.
-__global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
-			    const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ecc, uint32_t *__restrict__ dpar,
-			    uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis, uint32_t *__restrict__ cur)
+// One lane walks one class, so a step costs its chain of dependent loads (HBM / Infinity-Cache latency):
+// keep that chain short.  k_class_adj filters every side's scan list [black edge, links by local edge idx]
+// down to the neighbours of its own class (entry = {side, scan slot}) and packs {begin, count} per side;
+// the walk then needs per tree edge: one entry load, one {visited, packed side} load going down, and ONE
+// 16-byte load coming back (the child keeps its parent's scan state: {parent, begin, count, next}).
+__global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+			    const uint32_t *__restrict__ ecc, const uint32_t *__restrict__ ckey,
+			    const uint32_t *__restrict__ cproc, uint2 *__restrict__ cadj, uint2 *__restrict__ rb)
+{
+	uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+	if (u >= nS)
+		return;
+	const uint32_t lo = loff[u], hi = loff[u + 1], base = lo + u; // deg + 1 slots per side
+	uint32_t n = 0;
+	if (cproc[ckey[u >> 1]]) {
+		const uint32_t cls = ecc[u];
+		if (ecc[u ^ 1u] == cls)
+			cadj[base + n++] = make_uint2(u ^ 1u, 0u);
+		for (uint32_t k = lo; k < hi; k++) {
+			const uint32_t o = ladj[k];
+			if (ecc[o] == cls)
+				cadj[base + n++] = make_uint2(o, k - lo + 1);
+		}
+	}
+	rb[u] = make_uint2(base, n);
+}
+// the plain walk (small classes only: five or six dependent loads per tree edge, but no filtering pass)
+__global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
+				  const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ecc, uint32_t *__restrict__ dpar,
+				  uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis, uint32_t *__restrict__ cur)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_entry)
@@ -489,6 +524,43 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 		if (u == s)
 			break;
 		u = dpar[u];
+	}
+}
+__global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
+			    const uint2 *__restrict__ rb, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
+			    uint8_t *__restrict__ dvis, uint4 *__restrict__ ret)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_entry)
+		return;
+	const uint32_t s = entry_list[i];
+	uint32_t u = s, k = 0;
+	uint2 r = rb[u];
+	for (;;) {
+		bool down = false;
+		while (k < r.y) {
+			const uint2 e = cadj[r.x + k];
+			k++;
+			if (!dvis[e.x]) {
+				dvis[e.x] = 1;
+				dpar[e.x] = u;
+				cslot[e.x] = e.y;
+				ret[e.x] = make_uint4(u, r.x, r.y, k);
+				u = e.x;
+				r = rb[u];
+				k = 0;
+				down = true;
+				break;
+			}
+		}
+		if (down)
+			continue;
+		if (u == s)
+			break;
+		const uint4 back = ret[u];
+		u = back.x;
+		r = make_uint2(back.y, back.z);
+		k = back.w;
 	}
 }
 
@@ -716,6 +788,9 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.ckey, (nS + 2 * E + 8) * 4); // scan-slot -> child table of the child ordering
 	take((void **)&tw.ckey2, 64);
+	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
+	take((void **)&tw.crb, nS * 8);
+	take((void **)&tw.cret, nS * 16);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	for (uint32_t **p : {&tw.rk_has_pred, &tw.rk_flag, &tw.rk_ps})
 		take((void **)p, NA * 4);
@@ -740,7 +815,7 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax)
 
 // ------------------------------------------------------------------ driver
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
-			   uint32_t max_side_links, StageTimer &tm, hipStream_t s)
+			   uint32_t max_side_links, bool force_big_class_dfs, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = sw.V, E = sw.E, nS = 2 * V;
 	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
@@ -775,11 +850,12 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_lowhigh, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.P0, tw.lowP, tw.highP);
 	seg_build(tw.segLo, tw.lowP, nS, s);
 	seg_build(tw.segHi, tw.highP, nS, s);
+	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
 	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, tw.segLo.tree, tw.segLo.P, tw.segHi.tree, tw.segHi.P, tw.isbridge,
-	       tw.ecc);
+	       tw.ecc, csamp);
 	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc);
 	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc);
-	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc);
+	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
@@ -788,10 +864,20 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       tw.dvis, tw.entry_flag, sw.cur);
 	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
-	const uint32_t n_entry = tw.host->read_u32(tw.entry_ps + nS, s);
-	if (n_entry)
-		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj,
-				   tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
+	uint32_t *hb = tw.host->take<uint32_t>(2);
+	HIP_CHECK(hipMemcpyAsync(hb, tw.entry_ps + nS, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(hb + 1, pw.err + 4, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	const uint32_t n_entry = hb[0];
+	const bool big_classes = hb[1] != 0 || force_big_class_dfs;
+	if (n_entry && big_classes) {
+		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.ecc, cs.ckey, tw.cproc, tw.cadj, tw.crb);
+		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
+				   tw.dpar, tw.cslot, tw.dvis, tw.cret);
+	} else if (n_entry) {
+		hipLaunchKernelGGL(k_class_dfs_small, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff,
+				   cs.ladj, tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
+	}
 	tm.end(5);
 
 	// ---- 7. pre-order, sizes, depths

@@ -21,6 +21,8 @@ struct TreeWs {
 	uint32_t *lowP, *highP;				  // [2V]
 	uint32_t *isbridge, *ecc, *dpar, *cslot;	  // [2V]
 	uint8_t *dvis;					  // [2V]
+	uint2 *cadj, *crb;				  // [2V + 2E] class-filtered scan lists {side, slot}; [2V] {begin, count}
+	uint4 *cret;					  // [2V] scan state of the DFS parent at the moment it descended
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint32_t *entry_flag, *entry_ps, *entry_list;	  // [2V+1]
 	uint64_t *ckey, *ckey2;				  // [2V]
@@ -38,6 +40,6 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax);
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
-			   uint32_t max_side_links, StageTimer &tm, hipStream_t s);
+			   uint32_t max_side_links, bool force_big_class_dfs, StageTimer &tm, hipStream_t s);
 
 } // namespace povu_hip

@@ -44,6 +44,7 @@ F_SEQ_TREE = 4
 F_FORCE_REDO = 8
 F_SORTED_ADJ = 16
 F_NO_STAGE_TIMES = 32
+F_BIG_CLASS_DFS = 64
 
 _lib = None
 

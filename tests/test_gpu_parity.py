@@ -161,6 +161,28 @@ def test_forced_sequential_redo(hip, seed):
 
 
 @pytest.mark.parametrize("seed", range(10))
+def test_both_class_walks(hip, seed):
+    """The per-class DFS has two walks: the plain one (small classes) and the one over class-filtered scan
+    lists that is chosen when the sampled class sizes report a large class; POVU_HIP_F_BIG_CLASS_DFS forces
+    the latter.  Dense random graphs = few large 2-edge-connected classes with many in-class back edges."""
+    from povu_amd.hip import F_BIG_CLASS_DFS
+    n = 60 + 37 * seed
+    g = W.random_bidirected(n, int(n * (1.2 + 0.25 * (seed % 5))), 8800 + seed, connected=(seed % 2 == 0), self_loops=(seed % 3 == 0))
+    want = O.decompose(g)
+    hip.upload(g)
+    assert hip.decompose(flags=F_BIG_CLASS_DFS).texts() == want
+    assert hip.decompose().texts() == want
+
+
+def test_large_class_takes_the_filtered_walk(hip):
+    """One 2-edge-connected class of ~6000 sides (a random connected multigraph): the size sample must pick
+    the filtered walk by itself, and the result equals the oracle's."""
+    g = W.random_bidirected(3000, 4200, 77, connected=True)
+    hip.upload(g)
+    assert hip.decompose().texts() == O.decompose(g)
+
+
+@pytest.mark.parametrize("seed", range(10))
 def test_both_local_adjacency_builders(hip, seed):
     """Row B's per-side adjacency: insertion sort per side (default) and the radix-sort builder hub graphs
     take (POVU_HIP_F_SORTED_ADJ) give the same forest; graphs here are rich in self loops of every kind

@@ -4,7 +4,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
-from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES
+from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 hip = HipDecomposer(0)
@@ -37,7 +37,7 @@ while time.time() - t0 < budget:
         tips = np.zeros(g.n_vtx, dtype=np.uint8)  # builder-style graphs without tips
     want = O.decompose(g, tips=tips)
     hip.upload(g, tips)
-    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES][n_graphs % 5]
+    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS][n_graphs % 7]
     got = hip.decompose(flags=flags).texts()
     if got != want:
         print('MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', flags, 'tips', tips is not None)

@@ -4,7 +4,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 md5 = lambda s: hashlib.md5(s.encode()).hexdigest()
-n = int(sys.argv[1])
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 g = W.random_bidirected(n, int(n * 1.6), 5, connected=True)
 h = HipDecomposer(0)
 h.upload(g)
