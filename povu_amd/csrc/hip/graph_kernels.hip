@@ -373,11 +373,19 @@ __global__ void k_mark_first2(uint32_t V, const uint32_t *__restrict__ perm, con
 		if (S == 2 * V - 1)
 			ldeg[2 * V] = 0; // closes the array the scan turns into loff
 	}
+	__shared__ uint32_t sh[TPB / 64];
 	uint32_t m = cnt;
 	for (int o = 32; o; o >>= 1)
 		m = max(m, __shfl_down(m, o));
-	if ((threadIdx.x & 63) == 0 && m > *(volatile uint32_t *)stats)
-		atomicMax(stats, m);
+	if ((threadIdx.x & 63) == 0)
+		sh[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < TPB / 64; w++)
+			m = max(m, sh[w]);
+		if (m > __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) // few blocks ever need the atomic
+			atomicMax(stats, m);
+	}
 }
 
 // every side gathers its (local edge, other side) pairs and keeps them ascending by local edge with an

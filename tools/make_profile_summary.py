@@ -10,7 +10,7 @@ fetch = json.load(open(os.path.join(F, "fetch_summary.json")))
 write = json.load(open(os.path.join(F, "write_summary.json")))
 shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{tag}_bench_final.json"))
 shutil.copy(os.path.join(F, "bench_under_rocprof.json"), os.path.join(P, f"{tag}_bench_under_rocprof.json"))
-ks = sorted(glob.glob(os.path.join(F, "kt", "*", "*kernel_stats.csv")))[-1]
+ks = sorted(glob.glob(os.path.join(F, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
 shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats_bench_chain1M.csv"))
 E, V = bench["config"]["links_per_gpu"], bench["config"]["segments_per_gpu"]
 hbm = (fetch["per_pass"] + write["per_pass"]) * 1024.0
