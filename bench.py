@@ -32,8 +32,8 @@ def algorithmic_bytes(E, V, F):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--units", type=int, default=333333, help="bubble units per component (K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="chain", choices=["chain", "nest", "hprc"])
