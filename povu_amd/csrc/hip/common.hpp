@@ -47,7 +47,21 @@ public:
 		if (bytes > cap_) {
 			release();
 			size_t want = bytes + bytes / 8 + (1u << 20);
-			HIP_CHECK(hipMalloc(&base_, want));
+			if (hipMalloc(&base_, want) != hipSuccess) {
+				(void)hipGetLastError();
+				base_ = nullptr;
+				want = bytes + 4096; // no head room: retry with exactly what this graph needs
+				if (hipMalloc(&base_, want) != hipSuccess) {
+					(void)hipGetLastError();
+					base_ = nullptr;
+					size_t free_b = 0, total_b = 0;
+					(void)hipMemGetInfo(&free_b, &total_b);
+					throw HipError("not enough device memory for the decompose workspace: need " +
+						       std::to_string(want >> 20) + " MiB in one arena, " + std::to_string(free_b >> 20) +
+						       " MiB free of " + std::to_string(total_b >> 20) +
+						       " MiB (povu_hip_workspace_estimate gives the total for a graph)");
+				}
+			}
 			cap_ = want;
 		}
 		top_ = 0;

@@ -405,11 +405,14 @@ __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const
 			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
 			     const uint32_t *__restrict__ t_comp, uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls,
 			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns,
-			     uint32_t *__restrict__ prev, uint32_t C, const uint32_t *__restrict__ voff, uint32_t *__restrict__ soff)
+			     uint32_t *__restrict__ prev, uint32_t C, const uint32_t *__restrict__ voff, uint32_t *__restrict__ soff,
+			     uint32_t expect_total, uint32_t *err)
 {
 	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
 	if (m <= C) // first candidate-stack entry of component m
 		soff[m] = m == C ? ps[T] : ps[2 * voff[m] + m];
+	if (m == 0 && ps[T] != expect_total)
+		atomicExch(err, 1u);
 	if (m >= T || !flag[m])
 		return;
 	uint32_t v = inv[m], i = ps[m];
@@ -731,7 +734,7 @@ __global__ void k_summary(uint32_t C, const uint32_t *__restrict__ err, const ui
 		out[0] = err ? err[0] : 0;
 		out[1] = err ? err[1] : 0;
 		out[2] = err ? err[2] : 0;
-		out[3] = 0;
+		out[3] = err ? err[3] : 0;
 	}
 	uint32_t *o = out + 4;
 	if (i < C) {
@@ -751,8 +754,8 @@ void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_o
 	       sw.c_nbry, pw ? pw->doff : nullptr, dev_out);
 }
 
-void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, int64_t dense_nb0,
-		     StageTimer &tm, hipStream_t s)
+void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
+		     int64_t dense_nb0, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const bool want_hp = sw.hairpins != nullptr;
@@ -835,8 +838,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
 	scan(bflag, bps, (size_t)T + 1);
 	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
-	       pw.prev, C, cs.voff, pw.soff);
-	const uint32_t S = pw.host->read_u32(bps + T, s);
+	       pw.prev, C, cs.voff, pw.soff, n_stack, pw.err + 3);
+	// one candidate-stack entry per black tree edge = per segment of a processed component: the host knows the
+	// total (k_stack_emit raises err[3] if the device count disagrees)
+	const uint32_t S = n_stack;
 	tm.end(9);
 
 	// ---- row F

@@ -61,15 +61,15 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
 // Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
 // left in `sw`.  Components whose candidate stack is not laminar are flagged in pw.comp_bad (see pass_summary).
 // dense_nb0 < 0: densify the back edges the sequential tree stage wrote; otherwise b_src/b_tgt hold them.
-void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, int64_t dense_nb0,
-		     StageTimer &tm, hipStream_t s);
+void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
+		     int64_t dense_nb0, StageTimer &tm, hipStream_t s);
 
 // Hairpin boundaries (`--hairpins`, flubbles.cpp:531-535, 621-656, 712-717) from the parallel class stage's
 // per-vertex flags; writes sw.hairpins / sw.c_nbry like the sequential kernels do.
 void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s);
 
 // One launch that writes the outcome of a pass into page-locked host memory (5*C + 8 words):
-// [0..2] error words of the parallel stages, then bad[C], status[C], npvst[C], nbry[C], doff[C+1].
+// [0..3] error words of the parallel stages, then bad[C], status[C], npvst[C], nbry[C], doff[C+1].
 // pw == nullptr (sequential-only pass): error words, bad and doff read as 0.  The caller synchronises.
 void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_out, hipStream_t s);
 

@@ -577,7 +577,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		ctx->last_links = links;
 		// processed components (>= 3 vertices, owned by this shard), their running count = where a component
 		// starts in the dense PVST output, and the number of event lists of the pre-order ranking
-		uint32_t event_lists = 0;
+		uint32_t event_lists = 0, n_stack = 0;
 		order[C] = owner[C] = cproc[C] = 0;
 		pc[0] = 0;
 		for (uint32_t c = 0; c < C; c++) {
@@ -585,6 +585,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
 			pc[c + 1] = pc[c] + cproc[c];
 			event_lists += cproc[c] ? 1u : 2 * nv;
+			n_stack += cproc[c] ? nv : 0u; // one candidate-stack entry per segment (its black tree edge)
 		}
 		const uint32_t n_processed = pc[C];
 		HIP_CHECK(hipMemcpyAsync(sw.tables, tab_h, 4 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
@@ -648,7 +649,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0],
 							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0, tm, s);
 			}
-			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, dense_nb0, tm, s);
+			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, tm, s);
 			sum = read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
@@ -656,6 +657,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				throw HipError("list ranking: splitter capacity exceeded (internal sizing bug)");
 			if (sum[2])
 				throw HipError("spanning forest of the links has the wrong size (internal)");
+			if (sum[3])
+				throw HipError("candidate stack has the wrong size (internal)");
 			uint32_t nbad = 0;
 			for (uint32_t c = 0; c < C; c++)
 				nbad += sum[4 + c] ? 1 : 0;
