@@ -688,7 +688,6 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
 	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
 	take((void **)&pw.doff, (Cmax + 2) * 4);
-	take((void **)&pw.d_block, (V + Cmax + 2) * 14 + 5 * 64);
 	take((void **)&pw.err, 64);
 	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
@@ -755,7 +754,7 @@ void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_o
 }
 
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
-		     int64_t dense_nb0, StageTimer &tm, hipStream_t s)
+		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const bool want_hp = sw.hairpins != nullptr;
@@ -864,9 +863,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb);
 	seg_build(pw.segW, wb, (size_t)2 * S, s);
 	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
-	{ // the five PVST arrays back to back, laid out like the host's result block: one exact-size copy brings them over
+	{ // the five PVST arrays back to back in the forest's page-locked result block (povu_hip_forest::alloc has the
+	  // same layout): the emit kernels write over PCIe directly, nothing is copied afterwards
 		const size_t total = (size_t)NE + n_processed, p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
-		char *blk = static_cast<char *>(pw.d_block);
+		char *blk = static_cast<char *>(alloc_result_block(total));
 		pw.d_a = reinterpret_cast<uint32_t *>(blk);
 		pw.d_z = reinterpret_cast<uint32_t *>(blk + p4);
 		pw.d_parent = reinterpret_cast<uint32_t *>(blk + 2 * p4);

@@ -4,6 +4,8 @@
 #include "graph_kernels.hpp"
 #include "seq_kernels.hpp"
 
+#include <functional>
+
 namespace povu_hip
 {
 
@@ -41,9 +43,8 @@ struct ParWs {
 	uint32_t *comp_bad;		 // [C+1] components that must be redone sequentially
 	// dense PVST output (all processed components back to back): what goes over PCIe
 	uint32_t *cproc_ps, *doff;	 // [C+1] processed components before c; first dense PVST slot of c
-	void *d_block;			 // dense PVST output: a | z | parent | a_or | z_or, each padded to 64 bytes
-	size_t d_total;			 // PVST vertices in d_block (all processed components)
-	uint32_t *d_a, *d_z, *d_parent;	 // [d_total] views into d_block
+	size_t d_total;			 // PVST vertices of all processed components (dense output)
+	uint32_t *d_a, *d_z, *d_parent;	 // [d_total] device views into the forest's page-locked result block
 	uint8_t *d_aor, *d_zor;		 // [d_total] 0 forward, 1 reverse
 	uint32_t *err;			 // [4] internal error words
 	SegTree segA, segB, segP, segW, segL;
@@ -61,8 +62,10 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
 // Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
 // left in `sw`.  Components whose candidate stack is not laminar are flagged in pw.comp_bad (see pass_summary).
 // dense_nb0 < 0: densify the back edges the sequential tree stage wrote; otherwise b_src/b_tgt hold them.
+// alloc_result_block(total) returns the device view of a page-locked host block laid out a | z | parent | a_or |
+// z_or (each padded to 64 B) for `total` PVST vertices; the emit kernels write into it.
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
-		     int64_t dense_nb0, StageTimer &tm, hipStream_t s);
+		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s);
 
 // Hairpin boundaries (`--hairpins`, flubbles.cpp:531-535, 621-656, 712-717) from the parallel class stage's
 // per-vertex flags; writes sw.hairpins / sw.c_nbry like the sequential kernels do.

@@ -86,11 +86,14 @@ struct povu_hip_forest {
 		z_or.p = (uint8_t *)carve(total);
 		block_bytes = (size_t)(q - static_cast<char *>(block));
 	}
-	~povu_hip_forest()
+	void release_block()
 	{
 		if (block && pool)
 			pool->put(block, block_cap);
+		block = nullptr;
+		block_cap = block_bytes = total_entries = 0;
 	}
+	~povu_hip_forest() { release_block(); }
 	struct Tree {
 		uint32_t component_id, n_vtx, n_links, n_pvst;
 		size_t off;	// into the flat arrays below
@@ -616,10 +619,22 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			HIP_CHECK(hipMemsetAsync(sw.last, 0xFF, (B + T) * 4, s));
 			HIP_CHECK(hipMemsetAsync(sw.in_s, 0, B + T, s));
 		};
+		// the result block is allocated as soon as the number of PVST vertices is known (before the emit kernel):
+		// the parallel stages write it straight into pinned host memory, there is no device-to-host copy
+		auto f = std::make_unique<povu_hip_forest>();
+		f->pool = ctx->pool;
+		auto alloc_result_block = [&](size_t total) -> void * {
+			f->release_block();
+			f->alloc(total);
+			void *dev = nullptr;
+			HIP_CHECK(hipHostGetDevicePointer(&dev, f->block, 0));
+			return dev;
+		};
 		const uint32_t *sum = nullptr; // outcome of the pass in pinned memory (pass_summary)
 		auto read_summary = [&](bool with_par) -> const uint32_t * {
 			uint32_t *h = ctx->host.take<uint32_t>(5 * (size_t)C + 8);
 			pass_summary(sw, with_par ? &ctx->pw : nullptr, C, h, s);
+			HIP_CHECK(hipEventRecord(ev_all1, s)); // (recorded again if more work follows)
 			HIP_CHECK(hipStreamSynchronize(s));
 			return h;
 		};
@@ -649,7 +664,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0],
 							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0, tm, s);
 			}
-			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, tm, s);
+			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s);
 			sum = read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
@@ -696,7 +711,6 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			if (cstat[c] == 2)
 				throw HipError("internal error: the spanning tree of component " + std::to_string(c + 1) +
 					       " did not reach every side");
-		auto f = std::make_unique<povu_hip_forest>();
 		f->total_components = C;
 		size_t total = 0, total_hp = 0;
 		for (uint32_t c = 0; c < C; c++) {
@@ -714,10 +728,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			total_hp += t.n_hairpins;
 			f->trees.push_back(t);
 		}
-		f->pool = ctx->pool;
-		f->alloc(total);
-		f->hairpins.resize(2 * total_hp);
 		const bool dense_out = !all_seq && ctx->last_seq_redo == 0;
+		if (f->block && (!dense_out || f->total_entries != total))
+			f->release_block();
+		if (!f->block)
+			f->alloc(total);
+		f->hairpins.resize(2 * total_hp);
 		std::vector<uint8_t> ors(dense_out ? 0 : total);
 		if (dense_out) { // the parallel stages wrote every PVST back to back: one exact-size copy per array
 			if (doff[C] != total)
@@ -726,17 +742,20 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				t.off = doff[t.component_id - 1];
 			if (total != ctx->pw.d_total)
 				throw HipError("internal error: dense PVST layout mismatch");
-			if (total) // the device block has the layout of the host block (povu_hip_forest::alloc)
-				HIP_CHECK(hipMemcpyAsync(f->block, ctx->pw.d_block, f->block_bytes, hipMemcpyDeviceToHost, s));
+			// the PVST arrays are already in f->block (written by k_pvst_emit / k_pvst_roots)
+			bool more = false;
 			for (const auto &t : f->trees)
 				if (t.n_hairpins) {
 					const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
 					HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t.hp_off, sw.hairpins + 2 * pb,
 								 (size_t)t.n_hairpins * 16, hipMemcpyDeviceToHost, s));
+					more = true;
 				}
 			tm.end(0);
-			HIP_CHECK(hipEventRecord(ev_all1, s));
-			HIP_CHECK(hipStreamSynchronize(s));
+			if (more || tm.enabled) { // (the stage events themselves have to complete before they are read)
+				HIP_CHECK(hipEventRecord(ev_all1, s));
+				HIP_CHECK(hipStreamSynchronize(s));
+			}
 		} else if (f->trees.size() <= 32) { // few trees: copy exactly their spans
 			for (const auto &t : f->trees) {
 				const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
