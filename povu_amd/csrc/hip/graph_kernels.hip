@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 // parent pointers in LDS and unions every link whose both ends fall inside the tile there (LDS CAS,
 // no global atomics, no long global pointer chains); only the links that leave a tile go through
 // the global lock-free union-find afterwards.
-static constexpr uint32_t UF_TILE = 4096;
+static constexpr uint32_t UF_TILE = 8192, UF_TPB = 1024;
 
 __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 {
@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 	return x;
 }
 
-__global__ void __launch_bounds__(512) k_uf_tiles(uint32_t V, uint32_t E, const uint32_t *__restrict__ e_lo,
+__global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, uint32_t E, const uint32_t *__restrict__ e_lo,
 						  const uint32_t *__restrict__ e_hi, const uint32_t *__restrict__ eperm,
 						  uint32_t *__restrict__ label, uint32_t *__restrict__ hook)
 {
@@ -559,7 +559,7 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
-	hipLaunchKernelGGL(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(512), 0, s, V, E, g.e_lo, g.e_hi, g.eperm, st.label,
+	hipLaunchKernelGGL(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, E, g.e_lo, g.e_hi, g.eperm, st.label,
 			   st.hook);
 	if (g.n_cross)
 		hipLaunchKernelGGL(k_uf_cross, dim3(nblk(g.n_cross)), dim3(TPB), 0, s, g.n_cross, g.xlist, g.e_lo, g.e_hi, g.eperm,

@@ -128,8 +128,11 @@ __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const
 	cnt[a_end] = 0;
 	flag[sarc[aoff[r]]] = 1;
 }
-// one launch = two rounds of pointer jumping (three hops: every pointer then spans 4x as far), with two
-// accumulators (suffix sums along the list)
+// one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
+// HOPS = 3 covers two rounds (every pointer then spans 4x as far), HOPS = 7 three rounds (8x).  More
+// hops per launch mean fewer launches but more loads in total, which pays only while the launches are
+// dispatch-bound (short splitter lists).
+template <int HOPS>
 __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const uint32_t *__restrict__ a_in,
 			 const uint32_t *__restrict__ b_in, uint32_t *__restrict__ nxt_out, uint32_t *__restrict__ a_out,
 			 uint32_t *__restrict__ b_out, const uint32_t *__restrict__ n_dev)
@@ -139,7 +142,7 @@ __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const 
 		return;
 	uint32_t nx = nxt_in[i], a = a_in[i], b = b_in ? b_in[i] : 0;
 #pragma unroll
-	for (int hop = 0; hop < 3; hop++) {
+	for (int hop = 0; hop < HOPS; hop++) {
 		if (nx == NIL)
 			break;
 		a += a_in[nx];
@@ -157,12 +160,15 @@ static int list_rank(uint32_t n, unsigned bits, uint32_t *nxtA, uint32_t *nxtB, 
 		     uint32_t *bB, hipStream_t s, const uint32_t *n_dev = nullptr)
 {
 	int cur = 0;
-	const unsigned launches = (bits + 1) / 2;
+	const bool small = n < (1u << 21);
+	const unsigned launches = small ? (bits + 2) / 3 : (bits + 1) / 2;
 	for (unsigned r = 0; r < launches; r++) {
-		if (cur == 0)
-			LAUNCH(k_wyllie, n, s, n, nxtA, aA, bA, nxtB, aB, bB, n_dev);
+		uint32_t *ni = cur ? nxtB : nxtA, *no = cur ? nxtA : nxtB, *ai = cur ? aB : aA, *ao = cur ? aA : aB;
+		uint32_t *bi = cur ? bB : bA, *bo = cur ? bA : bB;
+		if (small)
+			LAUNCH(k_wyllie<7>, n, s, n, ni, ai, bi, no, ao, bo, n_dev);
 		else
-			LAUNCH(k_wyllie, n, s, n, nxtB, aB, bB, nxtA, aA, bA, n_dev);
+			LAUNCH(k_wyllie<3>, n, s, n, ni, ai, bi, no, ao, bo, n_dev);
 		cur ^= 1;
 	}
 	return cur;
