@@ -38,6 +38,17 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 static constexpr uint32_t SPLIT_SHIFT = 29;
 static constexpr uint32_t PK_END = 0x1FFFFFFFu;
 __device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
+// One word per list element, so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
+// bit 29 = the element's 0/1 weight, bit 31 = stop after this element (the successor is a splitter, or there is
+// none).  A list head never is anybody's successor, so the successor's splitter flag is its hash alone.
+__device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w)
+{
+	uint32_t p = nx == NIL ? PK_END : nx;
+	p |= (w & 1u) << 29;
+	if (nx == NIL || is_random_splitter(nx))
+		p |= 0x80000000u;
+	return p;
+}
 
 // ------------------------------------------------------------------ 1. arcs of the spanning forest
 // Arcs: 2i / 2i+1 = the black edge of segment i seen from its l / r side (so the black arc of side S is
@@ -95,16 +106,15 @@ __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t 
 // Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
 // (side w's arcs sit at [aoff[w], aoff[w+1])); also draws the random splitters of the tour ranking
 __global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
-			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ nxt,
-			   uint32_t *__restrict__ cnt, uint32_t *__restrict__ flag)
+			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk,
+			   uint32_t *__restrict__ flag)
 {
 	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= NA)
 		return;
 	uint32_t t = a ^ 1, w = arc_src[t], q = apos[t];
 	uint32_t qn = (q + 1 == aoff[w + 1]) ? aoff[w] : q + 1;
-	nxt[a] = sarc[qn];
-	cnt[a] = 1;
+	pk[a] = rank_pack(sarc[qn], 1u); // every arc counts 1 (k_tour_ends fixes the closing arc)
 	flag[a] = is_random_splitter(a) ? 1u : 0u;
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
@@ -116,16 +126,15 @@ __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *sta
 // per component: cut its tour open behind the arc that returns to the root for the last time, and make the
 // first arc out of the root a (forced) splitter -- the head of the component's list
 __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
-			    const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ nxt,
-			    uint32_t *__restrict__ cnt, uint32_t *__restrict__ flag)
+			    const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk,
+			    uint32_t *__restrict__ flag)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= C)
 		return;
 	uint32_t r = comp_root_side(start_key, voff, c);
 	uint32_t a_end = sarc[aoff[r + 1] - 1] ^ 1;
-	nxt[a_end] = NIL;
-	cnt[a_end] = 0;
+	pk[a_end] = rank_pack(NIL, 0u); // no successor, weight 0
 	flag[sarc[aoff[r]]] = 1;
 }
 // one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
@@ -178,21 +187,6 @@ static int list_rank(uint32_t n, unsigned bits, uint32_t *nxtA, uint32_t *nxtB, 
 // splitter walks its segment (sums), the splitter list is ranked by pointer jumping, a second walk
 // hands every element its suffix sum.  Heads (elements nobody points to) are forced splitters.
 // (SPLIT_SHIFT / PK_END / is_random_splitter are defined at the top of the file.)
-// one word per element so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
-// bit 29 = the element's 0/1 weight, bit 31 = stop after this element (successor is a splitter / end)
-__global__ void k_rank_pack(uint32_t n, const uint32_t *__restrict__ nxt, const uint32_t *__restrict__ w1,
-			    const uint32_t *__restrict__ flag, uint32_t *__restrict__ pk)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
-		return;
-	uint32_t nx = nxt[i];
-	uint32_t w = nx == NIL ? PK_END : nx;
-	w |= (w1[i] & 1u) << 29;
-	if (nx == NIL || flag[nx])
-		w |= 0x80000000u;
-	pk[i] = w;
-}
 // TWO: second weight = +1 where the first is 1, -1 where it is 0 (enter / leave events)
 template <bool TWO>
 __global__ void k_rank_walk1(uint32_t n, const uint32_t *__restrict__ pk, const uint32_t *__restrict__ flag,
@@ -248,25 +242,23 @@ __global__ void k_rank_walk2(uint32_t n, const uint32_t *__restrict__ pk, const 
 }
 
 struct RankBufs {
-	uint32_t *has_pred, *flag, *ps;		       // [n+1]
+	uint32_t *pk, *flag, *ps;		       // [n+1] packed list words (rank_pack), splitter flags, their scan
 	uint32_t *nA, *nB, *aA, *aB, *bA, *bB;	       // [m_cap] splitter list ping-pong
 	uint32_t *err;
 	void *scan_tmp;
 	size_t scan_tmp_bytes;
 };
-// suffix sums (inclusive) along the lists given by nxt: out1 of the 0/1 weights w1 and, when TWO,
+// suffix sums (inclusive) along the lists packed in rb.pk: out1 of the 0/1 weights and, when TWO,
 // out2 of the +-1 weights derived from them
 template <bool TWO>
-static void list_rank_splitters(uint32_t n, const uint32_t *nxt, const uint32_t *w1, uint32_t *out1, uint32_t *out2,
-				uint32_t max_heads, RankBufs &rb, hipStream_t s)
+static void list_rank_splitters(uint32_t n, uint32_t *out1, uint32_t *out2, uint32_t max_heads, RankBufs &rb, hipStream_t s)
 {
 	if (n >= PK_END)
 		throw HipError("list ranking: more than 2^29 elements (graph too large for the packed walk)");
 	const uint32_t m_cap = n / 4 + max_heads + 4096; // expected n/8 random splitters + the heads
 	// rb.flag[0..n) was filled by the caller (random splitters + list heads)
 	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
-	uint32_t *pk = rb.has_pred; // has_pred is dead once the flags exist
-	LAUNCH(k_rank_pack, n, s, n, nxt, w1, rb.flag, pk);
+	const uint32_t *pk = rb.pk;
 	LAUNCH(k_rank_walk1<TWO>, n, s, n, pk, rb.flag, rb.ps, m_cap, rb.nA, rb.aA, rb.bA, rb.err);
 	const unsigned rounds = bits_for(m_cap) + 1;
 	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s,
@@ -611,23 +603,18 @@ __global__ void k_child_link(uint32_t nS, const uint32_t *__restrict__ loff, con
 }
 // events: 2S = enter S, 2S+1 = leave S
 __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
-			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ nxt, uint32_t *__restrict__ cnt,
-			 uint32_t *__restrict__ dep, uint32_t *__restrict__ flag)
+			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ pk, uint32_t *__restrict__ flag)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	uint32_t c = fc[S];
-	nxt[2 * S] = c != NIL ? 2 * c : 2 * S + 1;
-	cnt[2 * S] = 1;
-	dep[2 * S] = 1;
+	pk[2 * S] = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u); // enter: counts 1, depth +1
 	uint32_t ns = nsib[S], p = dpar[S];
 	// splitters of the event ranking: the random ones, and "enter S" heads a list iff S has no DFS parent
 	flag[2 * S] = (is_random_splitter(2 * S) || p == NIL) ? 1u : 0u;
 	flag[2 * S + 1] = is_random_splitter(2 * S + 1) ? 1u : 0u;
-	nxt[2 * S + 1] = ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL);
-	cnt[2 * S + 1] = 0;
-	dep[2 * S + 1] = 0xFFFFFFFFu; // -1
+	pk[2 * S + 1] = rank_pack(ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL), 0u); // leave: counts 0, depth -1
 }
 
 // ------------------------------------------------------------------ 8. tree arrays + back edges
@@ -841,9 +828,9 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
-	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, tw.nxtA, tw.cntA, rb.flag);
-	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, tw.nxtA, tw.cntA, rb.flag);
-	list_rank_splitters<false>(NA, tw.nxtA, tw.cntA, tw.cntB, nullptr, C, rb, s);
+	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, rb.flag);
+	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.flag);
+	list_rank_splitters<false>(NA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
 	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
 	       tw.pe_le0, tw.tourflag, C, start_key, tw.P0);
@@ -897,8 +884,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		(void)max_side_links;
 	}
 	// one list per processed component, one two-event list per side of an unprocessed one
-	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, tw.nxtA, tw.cntA, tw.depA, rb.flag);
-	list_rank_splitters<true>(2 * nS, tw.nxtA, tw.cntA, tw.cntB, tw.depB, event_lists, rb, s);
+	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, rb.pk, rb.flag);
+	list_rank_splitters<true>(2 * nS, tw.cntB, tw.depB, event_lists, rb, s);
 	const uint32_t *cnt = tw.cntB, *dep = tw.depB;
 	tm.end(40);
 
