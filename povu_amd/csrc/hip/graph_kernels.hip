@@ -252,13 +252,19 @@ __global__ void k_sorted_vertices(uint32_t V, uint32_t C, const uint32_t *__rest
 				  const uint32_t *__restrict__ vid, const uint8_t *__restrict__ tip,
 				  uint32_t *__restrict__ pos, uint32_t *__restrict__ voff, uint32_t *__restrict__ vdeg,
 				  uint32_t *__restrict__ gid_s, uint8_t *__restrict__ tip_s,
-				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats)
+				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats,
+				  uint32_t *__restrict__ sbase_identity)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= V)
 		return;
 	if (i < 4)
 		stats[i] = 0; // stats[0] = most links on one side (k_mark_first2 / k_max_u32)
+	if (sbase_identity) { // one component: sorted order = global order, slot bases are the CSR offsets themselves
+		sbase_identity[i] = off[2 * i];
+		if (i == V - 1)
+			sbase_identity[V] = off[2 * V];
+	}
 	uint32_t v = perm[i], c = ckey[i];
 	pos[v] = i;
 	if (i == 0 || ckey[i - 1] != c)
@@ -593,8 +599,10 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		sort_pairs_u32(st.comp_of, st.ckey, st.tmp_a, st.perm, V, bits_for(C), st.sort_tmp, st.sort_tmp_bytes, s);
 	}
 	hipLaunchKernelGGL(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
-			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats);
-	scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats,
+			   C == 1 ? st.sbase : nullptr);
+	if (C != 1)
+		scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	launches += 5;
 	// first-encounter rank of every edge
 	fill_u32(st.first, E, POVU_NIL, s);
