@@ -465,29 +465,37 @@ __global__ void k_compact(uint32_t n, const uint32_t *__restrict__ flag, const u
 // ------------------------------------------------------------------ 6. the DFS inside every class
 // One lane walks one class, so a step costs its chain of dependent loads (HBM / Infinity-Cache latency):
 // keep that chain short.  k_class_adj filters every side's scan list [black edge, links by local edge idx]
-// down to the neighbours of its own class (entry = {side, scan slot}) and packs {begin, count} per side;
-// the walk then needs per tree edge: one entry load, one {visited, packed side} load going down, and ONE
-// 16-byte load coming back (the child keeps its parent's scan state: {parent, begin, count, next}).
+// down to the neighbours of its own class (entry = {side, scan slot}) and packs {begin, count, first entry}
+// per side.  Going down then costs ONE load level (the candidate's visited byte and its packed record, which
+// already carries ITS first candidate), coming back one 16-byte load (the child keeps its parent's scan
+// state: {parent, begin, count, next}) plus one entry load when the parent has candidates left.
 __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			    const uint32_t *__restrict__ ecc, const uint32_t *__restrict__ ckey,
-			    const uint32_t *__restrict__ cproc, uint2 *__restrict__ cadj, uint2 *__restrict__ rb)
+			    const uint32_t *__restrict__ cproc, uint2 *__restrict__ cadj, uint4 *__restrict__ rb)
 {
 	uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
 	if (u >= nS)
 		return;
 	const uint32_t lo = loff[u], hi = loff[u + 1], base = lo + u; // deg + 1 slots per side
 	uint32_t n = 0;
+	uint2 first = make_uint2(NIL, 0u);
 	if (cproc[ckey[u >> 1]]) {
 		const uint32_t cls = ecc[u];
-		if (ecc[u ^ 1u] == cls)
-			cadj[base + n++] = make_uint2(u ^ 1u, 0u);
+		if (ecc[u ^ 1u] == cls) {
+			first = make_uint2(u ^ 1u, 0u);
+			cadj[base + n++] = first;
+		}
 		for (uint32_t k = lo; k < hi; k++) {
 			const uint32_t o = ladj[k];
-			if (ecc[o] == cls)
-				cadj[base + n++] = make_uint2(o, k - lo + 1);
+			if (ecc[o] == cls) {
+				const uint2 e = make_uint2(o, k - lo + 1);
+				if (!n)
+					first = e;
+				cadj[base + n++] = e;
+			}
 		}
 	}
-	rb[u] = make_uint2(base, n);
+	rb[u] = make_uint4(base, n, first.x, first.y);
 }
 // the plain walk (small classes only: five or six dependent loads per tree edge, but no filtering pass)
 __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
@@ -525,7 +533,7 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 	}
 }
 __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
-			    const uint2 *__restrict__ rb, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
+			    const uint4 *__restrict__ rb, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
 			    uint8_t *__restrict__ dvis, uint4 *__restrict__ ret)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,23 +541,27 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 		return;
 	const uint32_t s = entry_list[i];
 	uint32_t u = s, k = 0;
-	uint2 r = rb[u];
+	uint4 r = rb[u];			 // {begin, count, candidate 0}
+	uint2 e = make_uint2(r.z, r.w);		 // candidate k of u (valid while k < count)
 	for (;;) {
 		bool down = false;
 		while (k < r.y) {
-			const uint2 e = cadj[r.x + k];
-			k++;
+			const uint4 rn = rb[e.x]; // speculative: issued together with the visited byte
 			if (!dvis[e.x]) {
 				dvis[e.x] = 1;
 				dpar[e.x] = u;
 				cslot[e.x] = e.y;
-				ret[e.x] = make_uint4(u, r.x, r.y, k);
+				ret[e.x] = make_uint4(u, r.x, r.y, k + 1);
 				u = e.x;
-				r = rb[u];
+				r = rn;
 				k = 0;
+				e = make_uint2(r.z, r.w);
 				down = true;
 				break;
 			}
+			k++;
+			if (k < r.y)
+				e = cadj[r.x + k];
 		}
 		if (down)
 			continue;
@@ -557,8 +569,11 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 			break;
 		const uint4 back = ret[u];
 		u = back.x;
-		r = make_uint2(back.y, back.z);
+		r.x = back.y;
+		r.y = back.z;
 		k = back.w;
+		if (k < r.y)
+			e = cadj[r.x + k];
 	}
 }
 
@@ -782,7 +797,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.ckey, (nS + 2 * E + 8) * 4); // scan-slot -> child table of the child ordering
 	take((void **)&tw.ckey2, 64);
 	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
-	take((void **)&tw.crb, nS * 8);
+	take((void **)&tw.crb, nS * 16);
 	take((void **)&tw.cret, nS * 16);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	for (uint32_t **p : {&tw.rk_has_pred, &tw.rk_flag, &tw.rk_ps})

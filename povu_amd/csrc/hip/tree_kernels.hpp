@@ -21,7 +21,8 @@ struct TreeWs {
 	uint32_t *lowP, *highP;				  // [2V]
 	uint32_t *isbridge, *ecc, *dpar, *cslot;	  // [2V]
 	uint8_t *dvis;					  // [2V]
-	uint2 *cadj, *crb;				  // [2V + 2E] class-filtered scan lists {side, slot}; [2V] {begin, count}
+	uint2 *cadj;					  // [2V + 2E] class-filtered scan lists {side, slot}
+	uint4 *crb;					  // [2V] {begin, count, first entry} of a side's filtered list
 	uint4 *cret;					  // [2V] scan state of the DFS parent at the moment it descended
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint32_t *entry_flag, *entry_ps, *entry_list;	  // [2V+1]
