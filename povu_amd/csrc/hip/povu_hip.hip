@@ -560,7 +560,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		std::iota(order, order + C, 0u);
 		std::fill(owner, owner + C, 0u);
 		auto weight = [&](uint32_t c) { return (uint64_t)(eoff[c + 1] - eoff[c]) + (voff[c + 1] - voff[c]); };
-		std::stable_sort(order, order + C, [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
+		// heaviest first: the shard assignment below and the launch order of the one-lane kernels (the parallel
+		// stages do not care, so a single-shard parallel pass skips the sort)
+		if (o.world > 1 || (o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE | POVU_HIP_F_FORCE_REDO)))
+			std::stable_sort(order, order + C, [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
 		if (o.world > 1) { // greedy longest-processing-time assignment, deterministic on every rank
 			std::vector<uint64_t> load(o.world, 0);
 			for (uint32_t k = 0; k < C; k++) {
