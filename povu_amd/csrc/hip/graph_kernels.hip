@@ -497,12 +497,6 @@ __global__ void k_fill_u32(size_t n, uint32_t *p, uint32_t val)
 	if (i < n)
 		p[i] = val;
 }
-__global__ void k_fill_u64(size_t n, unsigned long long *p, unsigned long long val)
-{
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n)
-		p[i] = val;
-}
 
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s)
 {
