@@ -5,8 +5,10 @@ One "step" = one full pass of the hot path (rows B-G: component labelling, re-in
 tree, cycle classes, candidate stack, PVST) over the workload, from "graph resident in HBM as CSR"
 to "PVST arrays on the host" (SURVEY.md 8d).  At N=1 the workload is BASELINE.json configs[1]:
 the synthetic chain-of-bubbles GFA, 1 000 000 segments / 1 999 998 links, one component.  At N>1
-every rank owns one such component (components are the sharding unit; weak scaling) and the
-timed region also contains the PVST gather to rank 0 over RCCL.
+every rank owns one such component (components are the sharding unit; weak scaling; no data-path
+collective: like the reference's threads, every rank ends with the PVST arrays of its own components
+in host memory and would write their files).  `--gather` adds the pipelined PVST gather to rank 0 over
+RCCL to the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,6 +39,7 @@ def main():
     ap.add_argument("--units", type=int, default=333333, help="bubble units per component (K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="chain", choices=["chain", "nest", "hprc"])
+    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every rank's PVST arrays to rank 0 (pipelined)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,7 +84,7 @@ def main():
 
     # N > 1: the PVST gather to rank 0 of step k overlaps with the kernels of step k+1 (separate streams);
     # sync() drains it, so the timed region contains every transfer of its K steps
-    gather = PipelinedGather(rank, world, comm_dev) if world > 1 else None
+    gather = PipelinedGather(rank, world, comm_dev) if (world > 1 and args.gather) else None
 
     from povu_amd.hip import F_NO_STAGE_TIMES
 
@@ -158,7 +161,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": wl, "links_per_gpu": E, "segments_per_gpu": V, "flubbles_per_gpu": n_flub,
-                       "sharding": "one weakly-connected component per GPU; PVST gather to rank 0 over RCCL"
+                       "sharding": ("one weakly-connected component per GPU; "
+                                    + ("pipelined PVST gather to rank 0 over RCCL inside the timed region" if gather else
+                                       "every rank keeps (and would write) the PVST of its own components, no data-path collective"))
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "decompose pass (all kernels of rows B-G, one HIP stream)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -15,7 +15,7 @@ while time.time() - t0 < budget:
     if time.time() - last > 60:
         last = time.time(); print('...', n_graphs, 'graphs', flush=True)
     seed = int(rng.integers(1 << 30))
-    kind = n_graphs % 6
+    kind = n_graphs % 8
     if kind == 0:
         n = int(rng.integers(3, 40)); g = W.random_bidirected(n, int(n * rng.uniform(0.8, 3.5)), seed)
     elif kind == 1:
@@ -26,6 +26,11 @@ while time.time() - t0 < budget:
         g = W.hprc_shaped([int(rng.integers(50, 3000)) for _ in range(int(rng.integers(1, 5)))], seed=seed, tiny=int(rng.integers(0, 20)))
     elif kind == 4:
         n = int(rng.integers(10, 200)); g = W.random_bidirected(n, int(n * rng.uniform(1.5, 4.0)), seed, self_loops=True, connected=True)
+    elif kind == 6:
+        # several union-find tiles (8192 vertices each), multi-block scans, many components
+        n = int(rng.integers(9000, 60000)); g = W.random_bidirected(n, int(n * rng.uniform(0.9, 1.5)), seed)
+    elif kind == 7:
+        g = W.hprc_shaped([int(rng.integers(9000, 40000)), int(rng.integers(50, 9000))], seed=seed, tiny=int(rng.integers(0, 300)))
     else:
         # chains with random extra links (long bridge chains + local tangles)
         base = W.chain_of_bubbles(int(rng.integers(5, 3000)))
