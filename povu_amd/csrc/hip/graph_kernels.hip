@@ -52,6 +52,31 @@ __global__ void k_slot_other(uint32_t nS, const uint32_t *__restrict__ off, cons
 		aoth[k] = a == S ? b : a; // same-side self loop: a == b == S
 	}
 }
+// twin slot of every adjacency slot: where the same link sits in the list of its other end (lists are ascending by
+// link idx, so a binary search finds it)
+__global__ void k_slot_twin(uint32_t E, const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
+			    const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
+			    const uint8_t *__restrict__ s2, uint32_t *__restrict__ atwin)
+{
+	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= E)
+		return;
+	const uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
+	auto find = [&](uint32_t side) {
+		uint32_t lo = off[side], hi = off[side + 1];
+		while (lo < hi) {
+			uint32_t mid = (lo + hi) >> 1;
+			if (adj[mid] < e)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo;
+	};
+	const uint32_t ka = find(a), kb = a == b ? ka : find(b);
+	atwin[ka] = kb;
+	atwin[kb] = ka;
+}
 __global__ void k_vertex_degree(uint32_t V, const uint32_t *__restrict__ off, uint32_t *__restrict__ deg)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,11 +379,20 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 // ---- sort-free variant (vertices with few links): a side's local adjacency holds the links of its global
 // slots, plus the self loops of the opposite side -- a self loop is stored as (ve, complement(ve)) from the
 // side that met it first, so it owns one slot on either side of its vertex (bidirected.cpp:529-531).
-// k_mark_first2 = k_mark_first + the local degree of every side (no atomics) + the largest of them.
-__global__ void k_mark_first2(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ off,
-			      const uint32_t *__restrict__ adj, const uint32_t *__restrict__ aoth,
-			      const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ first,
-			      uint32_t *__restrict__ flag, uint32_t *__restrict__ ldeg, uint32_t *__restrict__ stats)
+// Which of a link's two slots componetize meets first needs no search either: slots are visited by sorted
+// vertex, l side before r side, so it is the slot of the smaller sorted vertex (for a loop: the l side, or
+// its only slot).  P = sbase[i] + rank of the slot inside vertex i, as in k_first_slot.
+__device__ __forceinline__ bool slot_is_first(uint32_t i, uint32_t s, uint32_t v, uint32_t o, const uint32_t *__restrict__ pos)
+{
+	if ((o >> 1) == v) // self loop: same side (one slot) or l-r (the l slot comes first)
+		return (o & 1u) == s || s == 0;
+	return i < pos[o >> 1];
+}
+// first-encounter flags + the local degree of every side (no atomics) + the largest of them
+__global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
+			      const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
+			      const uint32_t *__restrict__ sbase, uint32_t *__restrict__ flag, uint32_t *__restrict__ ldeg,
+			      uint32_t *__restrict__ stats)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t cnt = 0;
@@ -367,14 +401,17 @@ __global__ void k_mark_first2(uint32_t V, const uint32_t *__restrict__ perm, con
 		uint32_t b0 = off[2 * v], lo = off[2 * v + s], hi = off[2 * v + s + 1];
 		uint32_t P = sbase[i] + (lo - b0);
 		for (uint32_t k = lo; k < hi; k++, P++) {
-			bool f = first[adj[k]] == P;
+			const uint32_t o = aoth[k];
+			const bool f = slot_is_first(i, s, v, o, pos);
 			flag[P] = f ? 1u : 0u;
-			cnt += ((aoth[k] >> 1) == v) ? (f ? 1u : 0u) : 1u;
+			cnt += ((o >> 1) == v) ? (f ? 1u : 0u) : 1u;
 		}
-		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sbase[i] + (lo - b0);
-		for (uint32_t k = lo; k < hi; k++, P++)
-			if ((aoth[k] >> 1) == v && first[adj[k]] == P)
+		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1];
+		for (uint32_t k = lo; k < hi; k++) {
+			const uint32_t o = aoth[k];
+			if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
 				cnt++;
+		}
 		ldeg[S] = cnt;
 		if (S == 2 * V - 1)
 			ldeg[2 * V] = 0; // closes the array the scan turns into loff
@@ -396,11 +433,12 @@ __global__ void k_mark_first2(uint32_t V, const uint32_t *__restrict__ perm, con
 
 // every side gathers its (local edge, other side) pairs and keeps them ascending by local edge with an
 // insertion sort in place (std::set order of the per-side edge lists); the first-encounter slot also
-// writes the local edge itself
+// writes the local edge itself.  The local edge of a slot that is not the first encounter is the rank of its
+// twin slot (atwin, built at upload).
 __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
 			    const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
-			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ sbase,
-			    const uint32_t *__restrict__ first, const uint32_t *__restrict__ erank,
+			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ atwin,
+			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ erank,
 			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ hook, uint32_t *__restrict__ la,
 			    uint32_t *__restrict__ lb, uint32_t *__restrict__ tgray, uint32_t *ladj, uint32_t *lle)
 {
@@ -423,23 +461,35 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 		ladj[base + j] = other;
 	};
 	for (uint32_t k = lo; k < hi; k++, P++) {
-		uint32_t e = adj[k], o = aoth[k], Pf = first[e];
-		bool loop = (o >> 1) == v;
-		if (loop && Pf != P)
+		const uint32_t o = aoth[k], vo = o >> 1;
+		const bool loop = vo == v;
+		if (loop) {
+			if (!slot_is_first(i, s, v, o, pos))
+				continue; // the l-r loop's r slot: the l side owns the edge, this side gets it below
+			const uint32_t le = erank[P];
+			la[le] = S;
+			lb[le] = S ^ 1u;
+			tgray[le] = hook[adj[k]];
+			insert(le, S ^ 1u);
 			continue;
-		uint32_t le = erank[Pf];
-		uint32_t other = loop ? (S ^ 1u) : 2 * pos[o >> 1] + (o & 1u);
-		if (Pf == P) {
+		}
+		const uint32_t io = pos[vo], other = 2 * io + (o & 1u);
+		if (i < io) { // first encounter
+			const uint32_t le = erank[P];
 			la[le] = S;
 			lb[le] = other;
-			tgray[le] = hook[e];
+			tgray[le] = hook[adj[k]];
+			insert(le, other);
+		} else {
+			insert(erank[sbase[io] + (atwin[k] - off[2 * vo])], other);
 		}
-		insert(le, other);
 	}
 	lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sbase[i] + (lo - b0);
-	for (uint32_t k = lo; k < hi; k++, P++)
-		if ((aoth[k] >> 1) == v && first[adj[k]] == P)
+	for (uint32_t k = lo; k < hi; k++, P++) {
+		const uint32_t o = aoth[k];
+		if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
 			insert(erank[P], S ^ 1u);
+	}
 }
 
 // after the stable sort by side: other side and local edge of every adjacency slot
@@ -535,6 +585,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	if (V && E) {
 		hipLaunchKernelGGL(k_slot_other, dim3(nblk(nS)), dim3(TPB), 0, s, (uint32_t)nS, g.off, g.adj, g.v1, g.s1, g.v2, g.s2,
 				   g.aoth);
+		hipLaunchKernelGGL(k_slot_twin, dim3(nblk(E)), dim3(TPB), 0, s, E, g.off, g.adj, g.v1, g.s1, g.v2, g.s2, g.atwin);
 		uint32_t *mx = tmp_arena.take<uint32_t>(4);
 		HIP_CHECK(hipMemsetAsync(mx, 0, 16, s));
 		hipLaunchKernelGGL(k_vertex_degree, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, deg);
@@ -599,20 +650,20 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	launches += 5;
 	// first-encounter rank of every edge
-	fill_u32(st.first, E, POVU_NIL, s);
-	hipLaunchKernelGGL(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
 	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
-		hipLaunchKernelGGL(k_mark_first2, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, g.aoth, st.sbase,
-				   st.first, st.flag, st.ldeg, st.stats);
+		hipLaunchKernelGGL(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.aoth, st.sbase, st.flag,
+				   st.ldeg, st.stats);
 		scan_exclusive_u32_pair(st.flag, st.erank, (size_t)g.n_slots + 1, st.ldeg, st.loff, nS + 1, st.scan_tmp,
 					st.scan_tmp_bytes, s);
-		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, g.aoth, st.sbase,
-				   st.first, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
+		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, g.aoth, g.atwin,
+				   st.sbase, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
 		hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
 				   st.eoff, st.stats, st.host_pub);
-		tm.end(launches + 11);
+		tm.end(launches + 7);
 		return;
 	}
+	fill_u32(st.first, E, POVU_NIL, s);
+	hipLaunchKernelGGL(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
 	HIP_CHECK(hipMemsetAsync(st.flag, 0, ((size_t)g.n_slots + 1) * 4, s));
 	hipLaunchKernelGGL(k_mark_first, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first,
 			   st.flag);

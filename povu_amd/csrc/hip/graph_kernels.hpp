@@ -18,6 +18,7 @@ struct ResidentGraph {
 	uint32_t *adj = nullptr;		    // [n_slots] incident link idx, ascending per side
 	uint32_t *aoth = nullptr;		    // [n_slots] global side id (2 * vertex idx + end) at the other end of the slot's
 						    //           link; a self loop points back into its own vertex
+	uint32_t *atwin = nullptr;		    // [n_slots] the slot of the same link at its other end (itself for a same-side self loop)
 	uint32_t max_vdeg = 0;			    // most links on one vertex (both sides)
 	// links sorted by their smaller endpoint (built at upload): tile-local union-find input
 	uint32_t *eperm = nullptr, *e_lo = nullptr, *e_hi = nullptr; // [E] link idx, min / max endpoint

@@ -215,7 +215,7 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		g.tips_given = tips != nullptr;
 		const size_t V = n_vtx, E = n_links;
 		size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
-			       Arena::padded(2 * V + 2, 4) + 2 * Arena::padded(2 * E + 2, 4) + 4 * Arena::padded(E + 1, 4) + 4096;
+			       Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 2, 4) + 4 * Arena::padded(E + 1, 4) + 4096;
 		HIP_CHECK(hipMalloc(&g.block, bytes));
 		char *p = static_cast<char *>(g.block);
 		auto carve = [&](size_t n, size_t elem) {
@@ -232,6 +232,7 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		g.off = (uint32_t *)carve(2 * V + 2, 4);
 		g.adj = (uint32_t *)carve(2 * E + 2, 4);
 		g.aoth = (uint32_t *)carve(2 * E + 2, 4);
+		g.atwin = (uint32_t *)carve(2 * E + 2, 4);
 		g.eperm = (uint32_t *)carve(E + 1, 4);
 		g.e_lo = (uint32_t *)carve(E + 1, 4);
 		g.e_hi = (uint32_t *)carve(E + 1, 4);
