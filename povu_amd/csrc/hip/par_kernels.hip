@@ -485,10 +485,15 @@ __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const
 	if (k < n)
 		out[k] = ps[k] + walk[k] + 0x80000000u; // inclusive prefix sum, biased so that u32 order = int order
 }
+// level of every emitted flubble, and -- so that the PCIe writes of the result overlap with the level
+// queries -- its endpoints and orientations straight into the (page-locked host) PVST arrays
 __global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
 			 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
 			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ segW, uint32_t P,
-			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i)
+			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i, const uint32_t *__restrict__ ns,
+			 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
+			 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
+			 uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S || !dflag[i])
@@ -502,38 +507,35 @@ __global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const u
 	uint32_t j = erank[i];
 	lev[j] = (uint32_t)(cur - mn); // depth of the new flubble (>= 1)
 	e_i[j] = i;
+	// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
+	const uint64_t q = (uint64_t)j + cproc_ps[c] + 1;
+	uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
+	uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
+	if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
+		p_a[q] = t_gid[vz];
+		p_z[q] = t_gid[va];
+		p_aor[q] = 0;
+		p_zor[q] = 0;
+	} else {
+		p_a[q] = t_gid[va];
+		p_z[q] = t_gid[vz];
+		p_aor[q] = (uint8_t)ra;
+		p_zor[q] = (uint8_t)rz;
+	}
 }
+// PVST parent of every flubble = nearest earlier flubble of its component with a smaller level
 __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const uint32_t *__restrict__ e_i,
 			    const uint32_t *__restrict__ segL, uint32_t P, const uint32_t *__restrict__ s_comp,
 			    const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
-			    const uint32_t *__restrict__ voff, const uint32_t *__restrict__ ns,
-			    const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
-			    const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps,
-			    uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
-			    uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
+			    const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_parent)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= NE)
 		return;
 	uint32_t i = e_i[j], c = s_comp[i], jb = erank[soff[c]];
 	uint32_t jp = seg_last_less(segL, P, jb, j, lev[j]);
-	(void)voff;
 	uint64_t pb = (uint64_t)jb + cproc_ps[c]; // dense: flubbles emitted before + one root per earlier component
-	uint32_t k = 1 + (j - jb);
-	uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
-	uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
-	if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
-		p_a[pb + k] = t_gid[vz];
-		p_z[pb + k] = t_gid[va];
-		p_aor[pb + k] = 0;
-		p_zor[pb + k] = 0;
-	} else {
-		p_a[pb + k] = t_gid[va];
-		p_z[pb + k] = t_gid[vz];
-		p_aor[pb + k] = (uint8_t)ra;
-		p_zor[pb + k] = (uint8_t)rz;
-	}
-	p_parent[pb + k] = jp == NIL ? 0u : 1 + (jp - jb);
+	p_parent[pb + 1 + (j - jb)] = jp == NIL ? 0u : 1 + (jp - jb);
 }
 __global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ c_ntree,
 			     const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
@@ -874,10 +876,11 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
 		pw.d_total = total;
 	}
-	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i);
+	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i, pw.ns, pw.s_vtx,
+	       sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	seg_build(pw.segL, pw.lev, NE, s);
-	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, cs.voff, pw.ns,
-	       pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_parent, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
+	       pw.d_parent);
 	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
 	       pw.d_a, pw.d_z, pw.d_aor, pw.d_zor, sw.c_npvst, sw.c_nstack);
 	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
