@@ -883,9 +883,15 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	       pw.d_parent);
 	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
 	       pw.d_a, pw.d_z, pw.d_aor, pw.d_zor, sw.c_npvst, sw.c_nstack);
+	pw.n_stack = S; // export_parallel_stack copies the stack into the per-component layout when a debug hook asks
+	tm.end(12 + 3 * 22);
+}
+
+void export_parallel_stack(const CompState &cs, SeqWs &sw, ParWs &pw, hipStream_t s)
+{
+	const uint32_t S = pw.n_stack;
 	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
 	       sw.next_seen);
-	tm.end(12 + 3 * 22);
 }
 
 } // namespace povu_hip

@@ -44,6 +44,7 @@ struct ParWs {
 	// dense PVST output (all processed components back to back): what goes over PCIe
 	uint32_t *cproc_ps, *doff;	 // [C+1] processed components before c; first dense PVST slot of c
 	size_t d_total;			 // PVST vertices of all processed components (dense output)
+	uint32_t n_stack;		 // candidate-stack entries of the last pass
 	uint32_t *d_a, *d_z, *d_parent;	 // [d_total] device views into the forest's page-locked result block
 	uint8_t *d_aor, *d_zor;		 // [d_total] 0 forward, 1 reverse
 	uint32_t *err;			 // [4] internal error words
@@ -70,6 +71,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 // Hairpin boundaries (`--hairpins`, flubbles.cpp:531-535, 621-656, 712-717) from the parallel class stage's
 // per-vertex flags; writes sw.hairpins / sw.c_nbry like the sequential kernels do.
 void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, StageTimer &tm, hipStream_t s);
+
+// Copies the candidate stack / classes / next_seen of the last parallel pass into the per-component layout the
+// debug hooks (and the sequential kernels) use; not needed by the pass itself.
+void export_parallel_stack(const CompState &cs, SeqWs &sw, ParWs &pw, hipStream_t s);
 
 // One launch that writes the outcome of a pass into page-locked host memory (5*C + 8 words):
 // [0..3] error words of the parallel stages, then bad[C], status[C], npvst[C], nbry[C], doff[C+1].

@@ -124,6 +124,7 @@ struct povu_hip_ctx {
 	ParWs pw{};
 	TreeWs tw{};
 	uint32_t last_seq_redo = 0;
+	bool stack_export_pending = false; // the parallel stages' candidate stack is still in its dense layout
 };
 
 static void set_err(char *err, size_t errlen, const std::string &msg)
@@ -514,6 +515,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
+		ctx->stack_export_pending = false;
 		ctx->host.reset();
 		cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
@@ -669,6 +671,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0, tm, s);
 			}
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s);
+			ctx->stack_export_pending = true;
 			sum = read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
@@ -1059,6 +1062,11 @@ extern "C" int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *
 		return 1;
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
+		if (ctx->stack_export_pending && ctx->last_seq_redo == 0) {
+			export_parallel_stack(ctx->cs, ctx->sw, ctx->pw, ctx->stream);
+			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			ctx->stack_export_pending = false;
+		}
 		uint32_t voff = 0, ns = 0;
 		HIP_CHECK(hipMemcpy(&voff, ctx->cs.voff + comp, 4, hipMemcpyDeviceToHost));
 		HIP_CHECK(hipMemcpy(&ns, ctx->sw.c_nstack + comp, 4, hipMemcpyDeviceToHost));
