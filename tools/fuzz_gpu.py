@@ -7,6 +7,7 @@ from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
 hip = HipDecomposer(0)
 rng = np.random.default_rng(12345)
 t0 = time.time(); n_graphs = 0; n_links = 0
@@ -16,6 +17,8 @@ while time.time() - t0 < budget:
         last = time.time(); print('...', n_graphs, 'graphs', flush=True)
     seed = int(rng.integers(1 << 30))
     kind = n_graphs % 8
+    if big:
+        kind = 6 + n_graphs % 2
     if kind == 0:
         n = int(rng.integers(3, 40)); g = W.random_bidirected(n, int(n * rng.uniform(0.8, 3.5)), seed)
     elif kind == 1:
@@ -28,9 +31,10 @@ while time.time() - t0 < budget:
         n = int(rng.integers(10, 200)); g = W.random_bidirected(n, int(n * rng.uniform(1.5, 4.0)), seed, self_loops=True, connected=True)
     elif kind == 6:
         # several union-find tiles (8192 vertices each), multi-block scans, many components
-        n = int(rng.integers(9000, 60000)); g = W.random_bidirected(n, int(n * rng.uniform(0.9, 1.5)), seed)
+        n = int(rng.integers(9000, 60000)) * (10 if big else 1); g = W.random_bidirected(n, int(n * rng.uniform(0.9, 1.2 if big else 1.5)), seed)
     elif kind == 7:
-        g = W.hprc_shaped([int(rng.integers(9000, 40000)), int(rng.integers(50, 9000))], seed=seed, tiny=int(rng.integers(0, 300)))
+        m = 10 if big else 1
+        g = W.hprc_shaped([int(rng.integers(9000, 40000)) * m, int(rng.integers(50, 9000)) * m], seed=seed, tiny=int(rng.integers(0, 300)) * m)
     else:
         # chains with random extra links (long bridge chains + local tangles)
         base = W.chain_of_bubbles(int(rng.integers(5, 3000)))
