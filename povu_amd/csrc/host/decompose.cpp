@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <future>
 #include <iostream>
 #include <stdexcept>
 #include <thread>
@@ -33,13 +34,22 @@ void do_decompose(const Config &cfg)
 	if (cfg.subflubbles)
 		throw std::runtime_error("-s/--subflubbles is not part of the MI355X decompose path yet (flubbles only)");
 	const double t0 = now_ms();
-	GfaGraph g = load_gfa(cfg.input_gfa);
+	// the HIP runtime comes up (~0.1 s) while the GFA is being parsed
+	char err[512] = {0}, cerr_buf[512] = {0};
+	std::future<povu_hip_ctx *> ctx_f =
+		std::async(std::launch::async, [&]() { return povu_hip_create(cfg.device, cerr_buf, sizeof cerr_buf); });
+	GfaGraph g;
+	try {
+		g = load_gfa(cfg.input_gfa, false, false, cfg.threads);
+	} catch (...) {
+		if (povu_hip_ctx *c = ctx_f.get())
+			povu_hip_destroy(c);
+		throw;
+	}
 	const double t1 = now_ms();
-
-	char err[512] = {0};
-	povu_hip_ctx *ctx = povu_hip_create(cfg.device, err, sizeof err);
+	povu_hip_ctx *ctx = ctx_f.get();
 	if (!ctx)
-		throw std::runtime_error(std::string("povu_hip: ") + err);
+		throw std::runtime_error(std::string("povu_hip: ") + cerr_buf);
 	if (povu_hip_graph_upload(ctx, (uint32_t)g.vid.size(), g.vid.data(), (uint32_t)g.v1.size(), g.v1.data(), g.s1.data(),
 				  g.v2.data(), g.s2.data(), nullptr, err, sizeof err) != 0) {
 		povu_hip_destroy(ctx);

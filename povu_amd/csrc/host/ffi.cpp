@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <filesystem>
+#include <thread>
 #include <fstream>
 #include <string>
 #include <unordered_map>
@@ -80,7 +81,8 @@ PovuGraph *povu_graph_from_gfa(const char *gfa_path, PovuError *error) // povu_f
 			set_error(error, 1, m.c_str());
 			return nullptr;
 		}
-		povu_host::GfaGraph gg = povu_host::load_gfa(gfa_path, true, true);
+		const int threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+		povu_host::GfaGraph gg = povu_host::load_gfa(gfa_path, true, true, threads);
 		auto *g = new PovuGraph();
 		g->from_gfa = true;
 		g->ids.assign(gg.vid.begin(), gg.vid.end());

@@ -6,6 +6,7 @@
 #include <stdexcept>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 
 namespace povu_host
@@ -65,20 +66,51 @@ struct Mapped {
 };
 } // namespace
 
-GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths)
+namespace
 {
-	Mapped f(fp);
-	struct Seg {
-		uint32_t id;
-		uint32_t order;
-		const char *sb, *se;
-	};
+struct Seg {
+	uint32_t id;
+	const char *sb, *se;
+};
+// what one tokenizer thread found in its slice of the file (whole lines, in file order)
+struct Slice {
 	std::vector<Seg> segs;
 	std::vector<uint32_t> la, lb;
 	std::vector<uint8_t> sa, sb;
-	GfaGraph g;
-	const char *p = f.p, *end = f.p + f.n;
+	std::vector<GfaPath> paths;
+	size_t lines = 0;	  // lines seen (all of the slice unless an error stopped it)
+	size_t err_line = 0;	  // 1-based line inside the slice of the first malformed record, 0 = none
+	int err_kind = 0;	  // see slice_error
+	char err_char = 0;
+};
+
+std::string slice_error(const std::string &fp, int kind, size_t line, char c)
+{
+	const std::string ln = std::to_string(line);
+	switch (kind) {
+	case 1:
+		return invalid(fp, "S record on line " + ln + " is missing a segment id and sequence");
+	case 2:
+		return invalid(fp, "S record on line " + ln + " is missing a sequence");
+	case 3:
+		return invalid(fp, "S record on line " + ln + " has an empty sequence");
+	case 4:
+		return invalid(fp, "S record on line " + ln + " has a non-numeric segment id");
+	case 5:
+		return invalid(fp, "malformed L record on line " + ln);
+	default:
+		return invalid(fp, "unsupported record type '" + std::string(1, c) + "' on line " + ln);
+	}
+}
+
+void tokenize_slice(const char *p, const char *end, bool want_paths, Slice &out)
+{
 	size_t line_no = 1;
+	auto fail = [&](int kind, char c = 0) {
+		out.err_kind = kind;
+		out.err_line = line_no;
+		out.err_char = c;
+	};
 	while (p < end) {
 		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
 		const char *le = nl ? nl : end, *next = nl ? nl + 1 : end;
@@ -103,28 +135,27 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths)
 		case 'H':
 			break;
 		case 'S': {
-			const std::string ln = std::to_string(line_no);
 			if (nf < 2)
-				throw std::runtime_error(invalid(fp, "S record on line " + ln + " is missing a segment id and sequence"));
+				return fail(1);
 			if (nf < 3)
-				throw std::runtime_error(invalid(fp, "S record on line " + ln + " is missing a sequence"));
+				return fail(2);
 			if (fe[2] == fb[2])
-				throw std::runtime_error(invalid(fp, "S record on line " + ln + " has an empty sequence"));
+				return fail(3);
 			uint32_t id;
 			if (!parse_id(fb[1], fe[1], id))
-				throw std::runtime_error(invalid(fp, "S record on line " + ln + " has a non-numeric segment id"));
-			segs.push_back({id, (uint32_t)segs.size(), fb[2], fe[2]});
+				return fail(4);
+			out.segs.push_back({id, fb[2], fe[2]});
 			break;
 		}
 		case 'L': {
 			uint32_t a, b;
 			if (nf < 5 || !parse_id(fb[1], fe[1], a) || !parse_id(fb[3], fe[3], b) || fe[2] - fb[2] != 1 ||
 			    fe[4] - fb[4] != 1 || (*fb[2] != '+' && *fb[2] != '-') || (*fb[4] != '+' && *fb[4] != '-'))
-				throw std::runtime_error(invalid(fp, "malformed L record on line " + std::to_string(line_no)));
-			la.push_back(a);
-			lb.push_back(b);
-			sa.push_back(*fb[2] == '+' ? 1 : 0);
-			sb.push_back(*fb[4] == '+' ? 0 : 1);
+				return fail(5);
+			out.la.push_back(a);
+			out.lb.push_back(b);
+			out.sa.push_back(*fb[2] == '+' ? 1 : 0);
+			out.sb.push_back(*fb[4] == '+' ? 0 : 1);
 			break;
 		}
 		case 'P':
@@ -143,7 +174,7 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths)
 					}
 					q = c ? c + 1 : fe[2];
 				}
-				g.paths.push_back(std::move(pa));
+				out.paths.push_back(std::move(pa));
 			}
 			break;
 		case 'W':
@@ -162,15 +193,71 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths)
 						pa.step_rev.push_back(o == '<' ? 1 : 0);
 					}
 				}
-				g.paths.push_back(std::move(pa));
+				out.paths.push_back(std::move(pa));
 			}
 			break;
 		default:
-			throw std::runtime_error(invalid(fp, "unsupported record type '" + std::string(1, *p) + "' on line " +
-								     std::to_string(line_no)));
+			return fail(6, *p);
 		}
 		line_no++;
 		p = next;
+	}
+	out.lines = line_no - 1;
+}
+} // namespace
+
+GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int threads)
+{
+	Mapped f(fp);
+	GfaGraph g;
+	// slices of whole lines, one tokenizer thread each; results are stitched together in file order
+	size_t T = (size_t)std::max(1, threads);
+	T = std::min<size_t>(T, std::max<size_t>(1, f.n >> 22)); // at least 4 MiB per thread
+	std::vector<const char *> cut(T + 1);
+	cut[0] = f.p;
+	cut[T] = f.p + f.n;
+	for (size_t t = 1; t < T; t++) {
+		const char *q = f.p + f.n / T * t;
+		if (q < cut[t - 1])
+			q = cut[t - 1];
+		const char *nl = (const char *)memchr(q, '\n', (size_t)(cut[T] - q));
+		cut[t] = nl ? nl + 1 : cut[T];
+	}
+	std::vector<Slice> slices(T);
+	if (T == 1) {
+		tokenize_slice(cut[0], cut[1], want_paths, slices[0]);
+	} else {
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < T; t++)
+			pool.emplace_back([&, t]() { tokenize_slice(cut[t], cut[t + 1], want_paths, slices[t]); });
+		for (auto &th : pool)
+			th.join();
+	}
+	size_t lines_before = 0, n_seg = 0, n_link = 0;
+	for (const Slice &sl : slices) { // the first malformed record in file order
+		if (sl.err_kind)
+			throw std::runtime_error(slice_error(fp, sl.err_kind, lines_before + sl.err_line, sl.err_char));
+		lines_before += sl.lines;
+		n_seg += sl.segs.size();
+		n_link += sl.la.size();
+	}
+	std::vector<Seg> segs;
+	std::vector<uint32_t> la, lb;
+	std::vector<uint8_t> sa, sb;
+	segs.reserve(n_seg);
+	la.reserve(n_link);
+	lb.reserve(n_link);
+	sa.reserve(n_link);
+	sb.reserve(n_link);
+	for (Slice &sl : slices) {
+		segs.insert(segs.end(), sl.segs.begin(), sl.segs.end());
+		la.insert(la.end(), sl.la.begin(), sl.la.end());
+		lb.insert(lb.end(), sl.lb.begin(), sl.lb.end());
+		sa.insert(sa.end(), sl.sa.begin(), sl.sa.end());
+		sb.insert(sb.end(), sl.sb.begin(), sl.sb.end());
+		for (auto &pa : sl.paths)
+			g.paths.push_back(std::move(pa));
+		sl = Slice{};
 	}
 	if (segs.empty())
 		throw std::runtime_error(invalid(fp, "liteseq returned no vertices"));

@@ -27,7 +27,8 @@ struct GfaGraph {
 	std::vector<GfaPath> paths;	 // only with want_paths (P and W records)
 };
 
-// throws std::runtime_error("Invalid GFA '<path>': ...")
-GfaGraph load_gfa(const std::string &path, bool want_labels = false, bool want_paths = false);
+// throws std::runtime_error("Invalid GFA '<path>': ...") for the first malformed record in file order;
+// `threads` tokenizer threads share the file (slices of whole lines, >= 4 MiB each)
+GfaGraph load_gfa(const std::string &path, bool want_labels = false, bool want_paths = false, int threads = 1);
 
 } // namespace povu_host

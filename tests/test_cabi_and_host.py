@@ -177,6 +177,38 @@ def test_ffi_gfa_errors(tmp_path):
     assert err.message == f"Invalid GFA '{bad}': unsupported record type 'X' on line 2".encode()
 
 
+def test_gfa_loader_with_several_tokenizer_threads(tmp_path):
+    """A file large enough for several tokenizer slices (>= 4 MiB each): same graph as the generator's, and the
+    first malformed record in FILE order is the one reported, with its global line number."""
+    lib = _ffi()
+    g = W.chain_of_bubbles(60000)  # ~10 MB of GFA text
+    path = tmp_path / "big.gfa"
+    text = g.to_gfa()
+    path.write_text(text)
+    assert len(text) > 3 * (4 << 20) // 2
+    err = _Err(0, None)
+    h = lib.povu_graph_from_gfa(str(path).encode(), C.byref(err))
+    assert h, err.message
+    assert lib.povu_graph_vertex_count(h) == g.n_vtx and lib.povu_graph_edge_count(h) == g.n_links
+    ne = C.c_size_t(0)
+    e = lib.povu_graph_get_edges(h, C.byref(ne))
+    step = 997
+    got = [(e[i].from_id, e[i].from_o, e[i].to_id, e[i].to_o) for i in range(0, ne.value, step)]
+    exp = [(int(g.vid[g.v1[i]]), int(g.s1[i]), int(g.vid[g.v2[i]]), int(g.s2[i])) for i in range(0, g.n_links, step)]
+    assert got == exp
+    lib.povu_edges_free(e, ne)
+    lib.povu_graph_free(h)
+    lines = text.split("\n")
+    for bad_line in (len(lines) // 5, len(lines) - 10):  # in the first slice / in the last one
+        broken = list(lines)
+        broken[bad_line - 1] = "L\t1\t+\t2"
+        broken[len(lines) - 5] = "Q\tlater error that must not win"
+        path.write_text("\n".join(broken))
+        err = _Err(0, None)
+        assert not lib.povu_graph_from_gfa(str(path).encode(), C.byref(err))
+        assert err.message == f"Invalid GFA '{path}': malformed L record on line {bad_line}".encode(), err.message
+
+
 def test_compute_entry_points_fail_loudly_without_gpu():
     lib = _ffi()
     hl = H.load_lib()
