@@ -141,7 +141,7 @@ namespace
 {
 povu_hip_components *components_of(const Config &cfg, povu_hip_ctx **ctx_out)
 {
-	GfaGraph g = load_gfa(cfg.input_gfa);
+	GfaGraph g = load_gfa(cfg.input_gfa, false, false, cfg.threads);
 	char err[512] = {0};
 	povu_hip_ctx *ctx = povu_hip_create(cfg.device, err, sizeof err);
 	if (!ctx)
