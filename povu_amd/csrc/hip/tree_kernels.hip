@@ -188,20 +188,30 @@ static int list_rank(uint32_t n, unsigned bits, uint32_t *nxtA, uint32_t *nxtB, 
 // hands every element its suffix sum.  Heads (elements nobody points to) are forced splitters.
 // (SPLIT_SHIFT / PK_END / is_random_splitter are defined at the top of the file.)
 // TWO: second weight = +1 where the first is 1, -1 where it is 0 (enter / leave events)
-template <bool TWO>
-__global__ void k_rank_walk1(uint32_t n, const uint32_t *__restrict__ pk, const uint32_t *__restrict__ flag,
-			     const uint32_t *__restrict__ ps, uint32_t m_cap, uint32_t *__restrict__ sp_next,
-			     uint32_t *__restrict__ sp_a, uint32_t *__restrict__ sp_b, uint32_t *__restrict__ err)
+// splitter idx -> element, so that the walks run one lane per SPLITTER (full waves) instead of one lane per
+// element with 1 in 8 active: at scale the walks are bound by how many dependent loads are in flight
+__global__ void k_rank_compact(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps, uint32_t m_cap,
+			       uint32_t *__restrict__ splist, uint32_t *__restrict__ err)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n || !flag[i])
 		return;
-	uint32_t sid = ps[i];
+	const uint32_t sid = ps[i];
 	if (sid >= m_cap) {
 		atomicAdd(err, 1u);
 		return;
 	}
-	uint32_t a = 0, b = 0, x = i, p;
+	splist[sid] = i;
+}
+template <bool TWO>
+__global__ void k_rank_walk1(uint32_t m_cap, const uint32_t *__restrict__ m_dev, const uint32_t *__restrict__ pk,
+			     const uint32_t *__restrict__ splist, const uint32_t *__restrict__ ps, uint32_t *__restrict__ sp_next,
+			     uint32_t *__restrict__ sp_a, uint32_t *__restrict__ sp_b)
+{
+	uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sid >= m_cap || sid >= *m_dev)
+		return;
+	uint32_t a = 0, b = 0, x = splist[sid], p;
 	do {
 		p = pk[x];
 		uint32_t w = (p >> 29) & 1u;
@@ -217,17 +227,14 @@ __global__ void k_rank_walk1(uint32_t n, const uint32_t *__restrict__ pk, const 
 		sp_b[sid] = b;
 }
 template <bool TWO>
-__global__ void k_rank_walk2(uint32_t n, const uint32_t *__restrict__ pk, const uint32_t *__restrict__ flag,
-			     const uint32_t *__restrict__ ps, uint32_t m_cap, const uint32_t *__restrict__ sp_a,
+__global__ void k_rank_walk2(uint32_t m_cap, const uint32_t *__restrict__ m_dev, const uint32_t *__restrict__ pk,
+			     const uint32_t *__restrict__ splist, const uint32_t *__restrict__ sp_a,
 			     const uint32_t *__restrict__ sp_b, uint32_t *__restrict__ out1, uint32_t *__restrict__ out2)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n || !flag[i])
+	uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sid >= m_cap || sid >= *m_dev)
 		return;
-	uint32_t sid = ps[i];
-	if (sid >= m_cap)
-		return;
-	uint32_t a = sp_a[sid], b = TWO ? sp_b[sid] : 0, x = i, p;
+	uint32_t a = sp_a[sid], b = TWO ? sp_b[sid] : 0, x = splist[sid], p;
 	do {
 		p = pk[x];
 		uint32_t w = (p >> 29) & 1u;
@@ -244,6 +251,7 @@ __global__ void k_rank_walk2(uint32_t n, const uint32_t *__restrict__ pk, const 
 struct RankBufs {
 	uint32_t *pk, *flag, *ps;		       // [n+1] packed list words (rank_pack), splitter flags, their scan
 	uint32_t *nA, *nB, *aA, *aB, *bA, *bB;	       // [m_cap] splitter list ping-pong
+	uint32_t *splist;			       // [m_cap] element of every splitter
 	uint32_t *err;
 	void *scan_tmp;
 	size_t scan_tmp_bytes;
@@ -258,12 +266,12 @@ static void list_rank_splitters(uint32_t n, uint32_t *out1, uint32_t *out2, uint
 	const uint32_t m_cap = n / 4 + max_heads + 4096; // expected n/8 random splitters + the heads
 	// rb.flag[0..n) was filled by the caller (random splitters + list heads)
 	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
-	const uint32_t *pk = rb.pk;
-	LAUNCH(k_rank_walk1<TWO>, n, s, n, pk, rb.flag, rb.ps, m_cap, rb.nA, rb.aA, rb.bA, rb.err);
+	const uint32_t *pk = rb.pk, *m_dev = rb.ps + n; // number of splitters, on the device
+	LAUNCH(k_rank_compact, n, s, n, rb.flag, rb.ps, m_cap, rb.splist, rb.err);
+	LAUNCH(k_rank_walk1<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, rb.ps, rb.nA, rb.aA, rb.bA);
 	const unsigned rounds = bits_for(m_cap) + 1;
-	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s,
-			     rb.ps + n);
-	LAUNCH(k_rank_walk2<TWO>, n, s, n, pk, rb.flag, rb.ps, m_cap, side ? rb.aB : rb.aA, side ? rb.bB : rb.bA, out1, out2);
+	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s, m_dev);
+	LAUNCH(k_rank_walk2<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, side ? rb.aB : rb.aA, side ? rb.bB : rb.bA, out1, out2);
 }
 
 // ------------------------------------------------------------------ 2. rooted forest T0
@@ -802,7 +810,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	for (uint32_t **p : {&tw.rk_has_pred, &tw.rk_flag, &tw.rk_ps})
 		take((void **)p, NA * 4);
-	for (uint32_t **p : {&tw.rk_nA, &tw.rk_nB, &tw.rk_aA, &tw.rk_aB, &tw.rk_bA, &tw.rk_bB})
+	for (uint32_t **p : {&tw.rk_nA, &tw.rk_nB, &tw.rk_aA, &tw.rk_aB, &tw.rk_bA, &tw.rk_bB, &tw.rk_list})
 		take((void **)p, (NA / 4 + nS + 8192) * 4);
 	take((void **)&tw.segLo.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
 	take((void **)&tw.segHi.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
@@ -841,7 +849,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	scan(acnt, aoff, (size_t)nS + 1);
 	LAUNCH(k_arc_lists, nS, s, nS, V, E, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.tg_ps, cs.la, aoff, tw.arc_src, tw.arc_dst,
 	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
-	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, pw.err + 1,
+	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, tw.rk_list, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
 	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, rb.flag);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.flag);
