@@ -35,17 +35,20 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 	} while (0)
 
 // list-ranking splitters (section "work-efficient list ranking" below): 1 element in 8, by a multiplicative hash
-static constexpr uint32_t SPLIT_SHIFT = 29;
+// density: element i is a random splitter iff the top (32 - shift) bits of its hash are zero -- shift 29 = 1 in 8
+// (short lists: the walks are bound by their longest sub-list), shift 28 = 1 in 16 (long lists: the walks are
+// throughput-bound either way and the pointer jumping on the splitter list halves).
+static uint32_t rank_split_shift(size_t n) { return n < (size_t(1) << 26) ? 29u : 28u; }
 static constexpr uint32_t PK_END = 0x1FFFFFFFu;
-__device__ __forceinline__ bool is_random_splitter(uint32_t i) { return ((i * 0x9E3779B1u) >> SPLIT_SHIFT) == 0; }
+__device__ __forceinline__ bool is_random_splitter(uint32_t i, uint32_t shift) { return ((i * 0x9E3779B1u) >> shift) == 0; }
 // One word per list element, so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
 // bit 29 = the element's 0/1 weight, bit 31 = stop after this element (the successor is a splitter, or there is
 // none).  A list head never is anybody's successor, so the successor's splitter flag is its hash alone.
-__device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w)
+__device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, uint32_t shift)
 {
 	uint32_t p = nx == NIL ? PK_END : nx;
 	p |= (w & 1u) << 29;
-	if (nx == NIL || is_random_splitter(nx))
+	if (nx == NIL || is_random_splitter(nx, shift))
 		p |= 0x80000000u;
 	return p;
 }
@@ -107,15 +110,15 @@ __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t 
 // (side w's arcs sit at [aoff[w], aoff[w+1])); also draws the random splitters of the tour ranking
 __global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
 			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk,
-			   uint32_t *__restrict__ flag)
+			   uint32_t *__restrict__ flag, uint32_t shift)
 {
 	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= NA)
 		return;
 	uint32_t t = a ^ 1, w = arc_src[t], q = apos[t];
 	uint32_t qn = (q + 1 == aoff[w + 1]) ? aoff[w] : q + 1;
-	pk[a] = rank_pack(sarc[qn], 1u); // every arc counts 1 (k_tour_ends fixes the closing arc)
-	flag[a] = is_random_splitter(a) ? 1u : 0u;
+	pk[a] = rank_pack(sarc[qn], 1u, shift); // every arc counts 1 (k_tour_ends fixes the closing arc)
+	flag[a] = is_random_splitter(a, shift) ? 1u : 0u;
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -134,7 +137,7 @@ __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const
 		return;
 	uint32_t r = comp_root_side(start_key, voff, c);
 	uint32_t a_end = sarc[aoff[r + 1] - 1] ^ 1;
-	pk[a_end] = rank_pack(NIL, 0u); // no successor, weight 0
+	pk[a_end] = rank_pack(NIL, 0u, 29u); // no successor, weight 0
 	flag[sarc[aoff[r]]] = 1;
 }
 // one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
@@ -259,11 +262,12 @@ struct RankBufs {
 // suffix sums (inclusive) along the lists packed in rb.pk: out1 of the 0/1 weights and, when TWO,
 // out2 of the +-1 weights derived from them
 template <bool TWO>
-static void list_rank_splitters(uint32_t n, uint32_t *out1, uint32_t *out2, uint32_t max_heads, RankBufs &rb, hipStream_t s)
+static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint32_t *out2, uint32_t max_heads, RankBufs &rb,
+				hipStream_t s)
 {
 	if (n >= PK_END)
 		throw HipError("list ranking: more than 2^29 elements (graph too large for the packed walk)");
-	const uint32_t m_cap = n / 4 + max_heads + 4096; // expected n/8 random splitters + the heads
+	const uint32_t m_cap = 2 * (n >> (32 - shift)) + max_heads + 4096; // twice the expected random splitters + the heads
 	// rb.flag[0..n) was filled by the caller (random splitters + list heads)
 	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
 	const uint32_t *pk = rb.pk, *m_dev = rb.ps + n; // number of splitters, on the device
@@ -626,18 +630,18 @@ __global__ void k_child_link(uint32_t nS, const uint32_t *__restrict__ loff, con
 }
 // events: 2S = enter S, 2S+1 = leave S
 __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
-			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ pk, uint32_t *__restrict__ flag)
+			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ pk, uint32_t *__restrict__ flag, uint32_t shift)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	uint32_t c = fc[S];
-	pk[2 * S] = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u); // enter: counts 1, depth +1
+	pk[2 * S] = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u, shift); // enter: counts 1, depth +1
 	uint32_t ns = nsib[S], p = dpar[S];
 	// splitters of the event ranking: the random ones, and "enter S" heads a list iff S has no DFS parent
-	flag[2 * S] = (is_random_splitter(2 * S) || p == NIL) ? 1u : 0u;
-	flag[2 * S + 1] = is_random_splitter(2 * S + 1) ? 1u : 0u;
-	pk[2 * S + 1] = rank_pack(ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL), 0u); // leave: counts 0, depth -1
+	flag[2 * S] = (is_random_splitter(2 * S, shift) || p == NIL) ? 1u : 0u;
+	flag[2 * S + 1] = is_random_splitter(2 * S + 1, shift) ? 1u : 0u;
+	pk[2 * S + 1] = rank_pack(ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL), 0u, shift); // leave: counts 0, depth -1
 }
 
 // ------------------------------------------------------------------ 8. tree arrays + back edges
@@ -851,9 +855,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, tw.rk_list, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
-	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, rb.flag);
+	const uint32_t shiftA = rank_split_shift(NA);
+	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, rb.flag, shiftA);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.flag);
-	list_rank_splitters<false>(NA, tw.cntB, nullptr, C, rb, s);
+	list_rank_splitters<false>(NA, shiftA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
 	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
 	       tw.pe_le0, tw.tourflag, C, start_key, tw.P0);
@@ -907,8 +912,9 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		(void)max_side_links;
 	}
 	// one list per processed component, one two-event list per side of an unprocessed one
-	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, rb.pk, rb.flag);
-	list_rank_splitters<true>(2 * nS, tw.cntB, tw.depB, event_lists, rb, s);
+	const uint32_t shiftE = rank_split_shift(2 * (size_t)nS);
+	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, rb.pk, rb.flag, shiftE);
+	list_rank_splitters<true>(2 * nS, shiftE, tw.cntB, tw.depB, event_lists, rb, s);
 	const uint32_t *cnt = tw.cntB, *dep = tw.depB;
 	tm.end(40);
 
