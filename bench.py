@@ -179,12 +179,17 @@ def main():
             import oracle_lib  # CPU oracle: reported baseline only, never the product path
             k = min(args.units, 333333)
             sample = workloads.chain_of_bubbles(k) if args.workload == "chain" else g
+            # repeat the one-core port until ~6 s of CPU work have been spent; report the mean pass
             t1 = time.perf_counter()
-            _, info = oracle_lib.decompose(sample, want_text=False, timings=True)
-            cpu_dt = info["t_componetize"] + info["t_tree"] + info["t_classes"] + info["t_stack"] + info["t_pvst"]
-            out["cpu_baseline"] = {"value": sample.n_links / cpu_dt, "unit": "edges/s", "cores": 1, "kind": "port",
-                                   "sample": f"{sample.n_links} links of the same workload, one pass "
-                                             f"(componetize..add_flubbles {cpu_dt:.2f} s, wall {time.perf_counter() - t1:.2f} s)"}
+            reps, cpu_dt = 0, 0.0
+            while reps < 3 or (cpu_dt < 6.0 and reps < 50):
+                _, info = oracle_lib.decompose(sample, want_text=False, timings=True)
+                cpu_dt += info["t_componetize"] + info["t_tree"] + info["t_classes"] + info["t_stack"] + info["t_pvst"]
+                reps += 1
+            out["cpu_baseline"] = {"value": sample.n_links * reps / cpu_dt, "unit": "edges/s", "cores": 1, "kind": "port",
+                                   "sample": f"{sample.n_links} links of the same workload (one component = one thread in the "
+                                             f"reference's scheme), {reps} passes, componetize..add_flubbles "
+                                             f"{cpu_dt / reps:.2f} s per pass (wall incl. graph build {time.perf_counter() - t1:.1f} s)"}
         print(json.dumps(out))
     hip.close()
     if world > 1:
