@@ -232,7 +232,7 @@ __global__ void k_rank_walk1(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
 template <bool TWO>
 __global__ void k_rank_walk2(uint32_t m_cap, const uint32_t *__restrict__ m_dev, const uint32_t *__restrict__ pk,
 			     const uint32_t *__restrict__ splist, const uint32_t *__restrict__ sp_a,
-			     const uint32_t *__restrict__ sp_b, uint32_t *__restrict__ out1, uint32_t *__restrict__ out2)
+			     const uint32_t *__restrict__ sp_b, uint32_t *__restrict__ out1, uint2 *__restrict__ out12)
 {
 	uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sid >= m_cap || sid >= *m_dev)
@@ -241,12 +241,13 @@ __global__ void k_rank_walk2(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
 	do {
 		p = pk[x];
 		uint32_t w = (p >> 29) & 1u;
-		out1[x] = a;
-		a -= w;
-		if (TWO) {
-			out2[x] = b;
+		if (TWO) { // both sums in one 8-byte store: the writes follow the list, i.e. they are scattered
+			out12[x] = make_uint2(a, b);
 			b -= w ? 1u : 0xFFFFFFFFu;
+		} else {
+			out1[x] = a;
 		}
+		a -= w;
 		x = p & PK_END;
 	} while (!(p >> 31));
 }
@@ -259,10 +260,10 @@ struct RankBufs {
 	void *scan_tmp;
 	size_t scan_tmp_bytes;
 };
-// suffix sums (inclusive) along the lists packed in rb.pk: out1 of the 0/1 weights and, when TWO,
-// out2 of the +-1 weights derived from them
+// suffix sums (inclusive) along the lists packed in rb.pk: out1 of the 0/1 weights or, when TWO, out12 = {that sum,
+// the sum of the +-1 weights derived from them}
 template <bool TWO>
-static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint32_t *out2, uint32_t max_heads, RankBufs &rb,
+static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint2 *out12, uint32_t max_heads, RankBufs &rb,
 				hipStream_t s)
 {
 	if (n >= PK_END)
@@ -275,7 +276,7 @@ static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint
 	LAUNCH(k_rank_walk1<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, rb.ps, rb.nA, rb.aA, rb.bA);
 	const unsigned rounds = bits_for(m_cap) + 1;
 	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s, m_dev);
-	LAUNCH(k_rank_walk2<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, side ? rb.aB : rb.aA, side ? rb.bB : rb.bA, out1, out2);
+	LAUNCH(k_rank_walk2<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, side ? rb.aB : rb.aA, side ? rb.bB : rb.bA, out1, out12);
 }
 
 // ------------------------------------------------------------------ 2. rooted forest T0
@@ -645,7 +646,7 @@ __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const u
 }
 
 // ------------------------------------------------------------------ 8. tree arrays + back edges
-__global__ void k_tree_emit(uint32_t nS, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ dep,
+__global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd,
 			    const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ ckey,
 			    const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
 			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
@@ -677,14 +678,15 @@ __global__ void k_tree_emit(uint32_t nS, const uint32_t *__restrict__ cnt, const
 		return;
 	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u;
 	const uint32_t tb = 2 * voff[c] + c;
-	// suffix sums from the enter event: cnt = enters from here to the end, dep = net depth change
-	const uint32_t pre = Nh - cnt[2 * S], size = cnt[2 * S] - cnt[2 * S + 1];
-	const uint32_t depth = 0u - dep[2 * S];
+	// cd[event] = {enters from this event to the end of the list, net depth change from here to the end}
+	const uint2 ent = cd[2 * S];
+	const uint32_t pre = Nh - ent.x, size = ent.x - cd[2 * S + 1].x;
+	const uint32_t depth = 0u - ent.y;
 	const uint32_t t = tb + hd + pre;
 	t_gid[t] = gid_s[S >> 1];
 	const uint32_t p = dpar[S];
 	t_flags[t] = (uint8_t)((S & 1) | ((p == (S ^ 1)) ? TF_BLACK : 0));
-	t_par[t] = p == NIL ? (hd ? 0u : NIL) : hd + (Nh - cnt[2 * p]);
+	t_par[t] = p == NIL ? (hd ? 0u : NIL) : hd + (Nh - cd[2 * p].x);
 	t_size[t] = size;
 	t_depth[t] = depth + hd;
 	side_tidx[S] = t;
@@ -801,6 +803,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
 	take((void **)&tw.arc_le, NA * 2);
+	take((void **)&tw.evt, NA * 8);
 	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.isbridge,
 			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_flag, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
 			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
@@ -914,13 +917,12 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// one list per processed component, one two-event list per side of an unprocessed one
 	const uint32_t shiftE = rank_split_shift(2 * (size_t)nS);
 	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, rb.pk, rb.flag, shiftE);
-	list_rank_splitters<true>(2 * nS, shiftE, tw.cntB, tw.depB, event_lists, rb, s);
-	const uint32_t *cnt = tw.cntB, *dep = tw.depB;
+	list_rank_splitters<true>(2 * nS, shiftE, nullptr, tw.evt, event_lists, rb, s);
 	tm.end(40);
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
-	LAUNCH(k_tree_emit, nS, s, nS, cnt, dep, tw.dpar, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
+	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, tw.dpar, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
 	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree);
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags

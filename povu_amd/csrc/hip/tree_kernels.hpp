@@ -31,6 +31,7 @@ struct TreeWs {
 	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]
 	uint32_t *be_cnt, *be_ps;			  // [2V+1]
 	uint32_t *rk_has_pred, *rk_flag, *rk_ps, *rk_nA, *rk_nB, *rk_aA, *rk_aB, *rk_bA, *rk_bB; // splitter list ranking
+	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
 	uint32_t *rk_list;				  // element of every list-ranking splitter
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
 	SegTree segLo, segHi;
