@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t seg_descend_last(const uint32_t *__restrict_
 }
 // first idx in [l, r) whose value is < x, NIL if none.  Walks the disjoint subtrees to the right of l (leaf, then
 // right siblings going up), descends into the first one whose minimum is < x; no per-thread node stack.
-static __device__ uint32_t seg_first_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
+__device__ __forceinline__ uint32_t seg_first_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
 {
 	if (l >= r)
 		return NIL;
@@ -119,7 +119,7 @@ static __device__ uint32_t seg_first_less(const uint32_t *__restrict__ tree, uin
 	}
 }
 // last idx in [l, r) whose value is < x, NIL if none (mirror image of seg_first_less)
-static __device__ uint32_t seg_last_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
+__device__ __forceinline__ uint32_t seg_last_less(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r, uint32_t x)
 {
 	if (l >= r)
 		return NIL;
