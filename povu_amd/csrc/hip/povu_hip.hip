@@ -668,7 +668,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				tm.end(1);
 			} else {
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0],
-							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0, tm, s);
+							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0,
+							      (o.flags & POVU_HIP_F_SPARSE_SPLITTERS) != 0, tm, s);
 			}
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s);
 			ctx->stack_export_pending = true;

@@ -838,7 +838,8 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax)
 
 // ------------------------------------------------------------------ driver
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
-			   uint32_t max_side_links, bool force_big_class_dfs, StageTimer &tm, hipStream_t s)
+			   uint32_t max_side_links, bool force_big_class_dfs, bool force_sparse_splitters, StageTimer &tm,
+			   hipStream_t s)
 {
 	const uint32_t V = sw.V, E = sw.E, nS = 2 * V;
 	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
@@ -858,7 +859,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, tw.rk_list, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
-	const uint32_t shiftA = rank_split_shift(NA);
+	const uint32_t shiftA = force_sparse_splitters ? 28u : rank_split_shift(NA);
 	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, rb.flag, shiftA);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.flag);
 	list_rank_splitters<false>(NA, shiftA, tw.cntB, nullptr, C, rb, s);
@@ -915,7 +916,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		(void)max_side_links;
 	}
 	// one list per processed component, one two-event list per side of an unprocessed one
-	const uint32_t shiftE = rank_split_shift(2 * (size_t)nS);
+	const uint32_t shiftE = force_sparse_splitters ? 28u : rank_split_shift(2 * (size_t)nS);
 	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, rb.pk, rb.flag, shiftE);
 	list_rank_splitters<true>(2 * nS, shiftE, nullptr, tw.evt, event_lists, rb, s);
 	tm.end(40);

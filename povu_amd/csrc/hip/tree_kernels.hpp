@@ -43,6 +43,7 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax);
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
-			   uint32_t max_side_links, bool force_big_class_dfs, StageTimer &tm, hipStream_t s);
+			   uint32_t max_side_links, bool force_big_class_dfs, bool force_sparse_splitters, StageTimer &tm,
+			   hipStream_t s);
 
 } // namespace povu_hip

@@ -45,6 +45,7 @@ F_FORCE_REDO = 8
 F_SORTED_ADJ = 16
 F_NO_STAGE_TIMES = 32
 F_BIG_CLASS_DFS = 64
+F_SPARSE_SPLITTERS = 128
 
 _lib = None
 

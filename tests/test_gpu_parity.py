@@ -174,6 +174,17 @@ def test_both_class_walks(hip, seed):
     assert hip.decompose().texts() == want
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_sparse_list_ranking_splitters(hip, seed):
+    """Lists of 2^26+ elements are ranked with 1-in-16 instead of 1-in-8 random splitters; the flag forces that
+    density on small inputs (many components = many lists, long chains = long lists)."""
+    from povu_amd.hip import F_SPARSE_SPLITTERS
+    g = W.hprc_shaped([3000 + 700 * seed, 40 + seed], seed=60 + seed, tiny=30) if seed % 2 else \
+        W.random_bidirected(500 + 300 * seed, 700 + 400 * seed, 6100 + seed)
+    hip.upload(g)
+    assert hip.decompose(flags=F_SPARSE_SPLITTERS).texts() == O.decompose(g)
+
+
 def test_large_class_takes_the_filtered_walk(hip):
     """One 2-edge-connected class of ~6000 sides (a random connected multigraph): the size sample must pick
     the filtered walk by itself, and the result equals the oracle's."""

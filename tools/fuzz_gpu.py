@@ -4,7 +4,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
-from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS
+from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_SPARSE_SPLITTERS
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
@@ -46,7 +46,7 @@ while time.time() - t0 < budget:
         tips = np.zeros(g.n_vtx, dtype=np.uint8)  # builder-style graphs without tips
     want = O.decompose(g, tips=tips)
     hip.upload(g, tips)
-    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS][n_graphs % 7]
+    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS, F_SPARSE_SPLITTERS][(n_graphs + n_graphs // 8) % 8]
     got = hip.decompose(flags=flags).texts()
     if got != want:
         print('MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', flags, 'tips', tips is not None)
