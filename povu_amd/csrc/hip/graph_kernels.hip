@@ -376,6 +376,8 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 	}
 }
 
+static constexpr uint32_t NIL32 = 0xFFFFFFFFu;
+
 // ---- sort-free variant (vertices with few links): a side's local adjacency holds the links of its global
 // slots, plus the self loops of the opposite side -- a self loop is stored as (ve, complement(ve)) from the
 // side that met it first, so it owns one slot on either side of its vertex (bidirected.cpp:529-531).
@@ -450,7 +452,32 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 	uint32_t P = sbase[i] + (lo - b0);
 	const uint32_t base = loff[S];
 	uint32_t n = 0;
+	// the first four entries of a side are kept sorted in registers (almost every side has fewer) and written once;
+	// a fifth entry flushes them and the insertion sort continues in place in global memory
+	uint32_t l0 = NIL32, l1 = NIL32, l2 = NIL32, l3 = NIL32, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
 	auto insert = [&](uint32_t le, uint32_t other) {
+		if (n < 4) {
+			l3 = le, o3 = other; // slot 3 is free while n < 4 (free slots hold NIL32 = +inf)
+			uint32_t t;
+			if (l3 < l2) {
+				t = l2, l2 = l3, l3 = t;
+				t = o2, o2 = o3, o3 = t;
+			}
+			if (l2 < l1) {
+				t = l1, l1 = l2, l2 = t;
+				t = o1, o1 = o2, o2 = t;
+			}
+			if (l1 < l0) {
+				t = l0, l0 = l1, l1 = t;
+				t = o0, o0 = o1, o1 = t;
+			}
+			n++;
+			return;
+		}
+		if (n == 4) {
+			lle[base] = l0, lle[base + 1] = l1, lle[base + 2] = l2, lle[base + 3] = l3;
+			ladj[base] = o0, ladj[base + 1] = o1, ladj[base + 2] = o2, ladj[base + 3] = o3;
+		}
 		uint32_t j = n++;
 		while (j > 0 && lle[base + j - 1] > le) {
 			lle[base + j] = lle[base + j - 1];
@@ -489,6 +516,16 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 		const uint32_t o = aoth[k];
 		if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
 			insert(erank[P], S ^ 1u);
+	}
+	if (n <= 4) { // never flushed: write the registers
+		if (n > 0)
+			lle[base] = l0, ladj[base] = o0;
+		if (n > 1)
+			lle[base + 1] = l1, ladj[base + 1] = o1;
+		if (n > 2)
+			lle[base + 2] = l2, ladj[base + 2] = o2;
+		if (n > 3)
+			lle[base + 3] = l3, ladj[base + 3] = o3;
 	}
 }
 
