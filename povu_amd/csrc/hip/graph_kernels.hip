@@ -388,7 +388,7 @@ __device__ __forceinline__ bool slot_is_first(uint32_t i, uint32_t s, uint32_t v
 {
 	if ((o >> 1) == v) // self loop: same side (one slot) or l-r (the l slot comes first)
 		return (o & 1u) == s || s == 0;
-	return i < pos[o >> 1];
+	return i < (pos ? pos[o >> 1] : (o >> 1)); // pos == nullptr: one component, sorted order = global order
 }
 // first-encounter flags + the local degree of every side (no atomics) + the largest of them
 __global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
@@ -500,7 +500,7 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 			insert(le, S ^ 1u);
 			continue;
 		}
-		const uint32_t io = pos[vo], other = 2 * io + (o & 1u);
+		const uint32_t io = pos ? pos[vo] : vo, other = 2 * io + (o & 1u);
 		if (i < io) { // first encounter
 			const uint32_t le = erank[P];
 			la[le] = S;
@@ -688,11 +688,12 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	launches += 5;
 	// first-encounter rank of every edge
 	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
-		hipLaunchKernelGGL(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.aoth, st.sbase, st.flag,
-				   st.ldeg, st.stats);
+		const uint32_t *pos_or_identity = C == 1 ? nullptr : st.pos; // one component: no vertex is renumbered
+		hipLaunchKernelGGL(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.aoth, st.sbase,
+				   st.flag, st.ldeg, st.stats);
 		scan_exclusive_u32_pair(st.flag, st.erank, (size_t)g.n_slots + 1, st.ldeg, st.loff, nS + 1, st.scan_tmp,
 					st.scan_tmp_bytes, s);
-		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, g.aoth, g.atwin,
+		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin,
 				   st.sbase, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
 		hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
 				   st.eoff, st.stats, st.host_pub);
