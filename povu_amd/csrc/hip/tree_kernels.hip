@@ -54,6 +54,7 @@ __device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, uint32_t 
 }
 
 // ------------------------------------------------------------------ 1. arcs of the spanning forest
+// (An arc stores only its tail, arc_src; its head is the tail of its twin a ^ 1.)
 // Arcs: 2i / 2i+1 = the black edge of segment i seen from its l / r side (so the black arc of side S is
 // arc S); 2k / 2k+1 with k = V + rank of the link among the tree-gray links = la -> lb / lb -> la.
 // The arcs leaving a side are grouped (any cyclic order of a side's arcs gives a valid Euler tour): slot 0
@@ -74,7 +75,7 @@ __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t 
 			    const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
 			    const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
 			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ arc_src,
-			    uint32_t *__restrict__ arc_dst, uint32_t *__restrict__ arc_le, uint32_t *__restrict__ apos,
+			    uint32_t *__restrict__ arc_le, uint32_t *__restrict__ apos,
 			    uint32_t *__restrict__ sarc, uint32_t expect, uint32_t *err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,7 +87,6 @@ __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t 
 	sarc[q] = S;
 	apos[S] = q;
 	arc_src[S] = S;
-	arc_dst[S] = S ^ 1u;
 	if (!(S & 1u))
 		arc_le[S >> 1] = NIL;
 	for (uint32_t k = loff[S]; k < loff[S + 1]; k++) {
@@ -101,7 +101,6 @@ __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t 
 		sarc[q] = a;
 		apos[a] = q;
 		arc_src[a] = S;
-		arc_dst[a] = ladj[k];
 		if (!dir)
 			arc_le[V + t] = le;
 	}
@@ -282,7 +281,7 @@ static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint
 // ------------------------------------------------------------------ 2. rooted forest T0
 // dist[a] = arcs after a in its tour.  u->w is the advance arc of tree edge {u,w} iff it comes first.
 __global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
-			     const uint32_t *__restrict__ arc_dst, const uint32_t *__restrict__ arc_le,
+			     const uint32_t *__restrict__ arc_le,
 			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff, uint32_t *__restrict__ par0,
 			     uint32_t *__restrict__ size0, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ tourflag,
 			     uint32_t C, const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ P0)
@@ -301,7 +300,7 @@ __global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, con
 	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
 	uint32_t tix = abase + (L - 1 - da);
 	if (da > dt) {
-		uint32_t w = arc_dst[a];
+		uint32_t w = arc_src[a ^ 1]; // head of a = tail of its twin
 		par0[w] = u;
 		size0[w] = (da - dt + 1) / 2;
 		pe_le0[w] = arc_le[a >> 1];
@@ -311,7 +310,7 @@ __global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, con
 	}
 }
 __global__ void k_t0_pre(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
-			 const uint32_t *__restrict__ arc_dst, const uint32_t *__restrict__ ckey,
+			 const uint32_t *__restrict__ ckey,
 			 const uint32_t *__restrict__ voff, const uint32_t *__restrict__ tour_ps, uint32_t *__restrict__ P0)
 {
 	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -323,7 +322,7 @@ __global__ void k_t0_pre(uint32_t NA, const uint32_t *__restrict__ dist, const u
 	uint32_t u = arc_src[a], c = ckey[u >> 1];
 	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
 	uint32_t tix = abase + (L - 1 - da);
-	P0[arc_dst[a]] = 2 * voff[c] + 1 + (tour_ps[tix] - tour_ps[abase]);
+	P0[arc_src[a ^ 1]] = 2 * voff[c] + 1 + (tour_ps[tix] - tour_ps[abase]);
 }
 
 // ------------------------------------------------------------------ 3. bridges
@@ -799,7 +798,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // list-ranking buffers double as slot buffers
 	take((void **)&tw.tg_ps, (E + 2) * 4);
 	take((void **)&tw.dvis_slots, 2 * E + 8);
-	for (uint32_t **p : {&tw.arc_src, &tw.arc_dst, &tw.k1, &tw.k2, &tw.v1, &tw.v2, &tw.apos, &tw.nxtA, &tw.nxtB, &tw.cntA,
+	for (uint32_t **p : {&tw.arc_src, &tw.k1, &tw.k2, &tw.v1, &tw.v2, &tw.apos, &tw.nxtA, &tw.nxtB, &tw.cntA,
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
 	take((void **)&tw.arc_le, NA * 2);
@@ -855,7 +854,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint32_t *acnt = tw.k1, *aoff = tw.k2; // [nS+1] each fits the 4V+8 buffers
 	LAUNCH(k_arc_count, nS, s, nS, cs.loff, cs.lle, cs.tgray, acnt);
 	scan(acnt, aoff, (size_t)nS + 1);
-	LAUNCH(k_arc_lists, nS, s, nS, V, E, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.tg_ps, cs.la, aoff, tw.arc_src, tw.arc_dst,
+	LAUNCH(k_arc_lists, nS, s, nS, V, E, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.tg_ps, cs.la, aoff, tw.arc_src,
 	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
 	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, tw.rk_list, pw.err + 1,
 		    pw.scan_tmp, pw.scan_tmp_bytes};
@@ -864,10 +863,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.flag);
 	list_rank_splitters<false>(NA, shiftA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
-	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_dst, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
+	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
 	       tw.pe_le0, tw.tourflag, C, start_key, tw.P0);
 	scan(tw.tourflag, tw.tour_ps, (size_t)NA + 1);
-	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, tw.arc_dst, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
+	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes

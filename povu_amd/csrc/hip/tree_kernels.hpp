@@ -12,7 +12,7 @@ struct TreeWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	// unrooted spanning forest of the biedged graph H, as arcs
 	uint32_t *tg_ps;				  // [E+1] rank of tree-gray links
-	uint32_t *arc_src, *arc_dst, *arc_le;		  // [NA], arc_le per tree edge [NA/2]
+	uint32_t *arc_src, *arc_le;			  // [NA] tail of an arc (head = tail of the twin a ^ 1); local edge per tree edge [NA/2]
 	uint32_t *k1, *k2, *v1, *v2;			  // [4V+4] sort buffers
 	uint32_t *apos;					  // [NA] position of an arc in its side's arc list
 	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong

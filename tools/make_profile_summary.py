@@ -53,6 +53,23 @@ L.append(f"`rocprofv3 --pmc FETCH_SIZE ...` and `--pmc WRITE_SIZE ...` (separate
 L.append("| kernel | fetch MB/pass | | kernel | write MB/pass |\n|---|---|---|---|---|")
 for (a, b), (c, d) in zip(fetch["top"][:10], write["top"][:10]):
     L.append(f"| `{a[:40]}` | {b*1024/1e6:.0f} | | `{c[:40]}` | {d*1024/1e6:.0f} |")
+# per kernel: counted bytes / time it runs = how close each kernel is to the HBM roofline (6.3 TB/s achievable)
+fmap = {k: v for k, v in fetch["top"]}; wmap = {k: v for k, v in write["top"]}
+dur = {}
+for r in rows:
+    k = short(r["Name"]).replace("rocprim radix_sort_onesweep_iteration", "rocprim:radix_sort").replace("rocprim radix_sort_onesweep_global_offsets", "rocprim:radix_sort")
+    dur[k] = dur.get(k, 0.0) + int(r["TotalDurationNs"]) / passes / 1e3
+L.append("\nBytes moved per kernel against the time it runs (both per pass; FETCH_SIZE + WRITE_SIZE as counted):\n")
+L.append("| kernel | us/pass | MB/pass | TB/s | |\n|---|---|---|---|---|")
+tbl = []
+for k, us in dur.items():
+    mb = (fmap.get(k, 0.0) + wmap.get(k, 0.0)) * 1024 / 1e6
+    if us > 15 and mb > 0:
+        tbl.append((us, k, mb))
+for us, k, mb in sorted(tbl, reverse=True)[:18]:
+    tbs = mb / us  # MB per microsecond = TB/s
+    note = "bandwidth (of its amplified traffic)" if tbs > 3.0 else ("latency / dependent loads" if tbs < 1.0 else "")
+    L.append(f"| `{k[:40]}` | {us:.0f} | {mb:.0f} | {tbs:.2f} | {note} |")
 extra = os.path.join(P, f"{tag}_other_workloads.md")
 if os.path.exists(extra):
     L.append("\n" + open(extra).read())

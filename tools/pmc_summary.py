@@ -14,5 +14,5 @@ for r in rows:
         nm = 'rocprim:radix_sort'
     per[nm] += v
 out = {"counter": ctr, "total": tot, "per_pass": tot / passes,
-       "top": [[k, v / passes] for k, v in per.most_common(12)]}
+       "top": [[k, v / passes] for k, v in per.most_common(60)]}
 print(json.dumps(out))
