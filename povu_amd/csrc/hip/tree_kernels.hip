@@ -19,6 +19,8 @@
 // tests/test_parallel_tree_model.py checks this formulation against the oracle on the CPU.
 #include "tree_kernels.hpp"
 
+#include <cstdlib>
+
 #include "segtree.hpp"
 
 #include <algorithm>
@@ -233,24 +235,28 @@ __global__ void k_rank_walk2(uint32_t m_cap, const uint32_t *__restrict__ m_dev,
 			     const uint32_t *__restrict__ splist, const uint32_t *__restrict__ sp_a,
 			     const uint32_t *__restrict__ sp_b, uint32_t *__restrict__ out1, uint2 *__restrict__ out12)
 {
-	uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
-	if (sid >= m_cap || sid >= *m_dev)
-		return;
-	uint32_t a = sp_a[sid], b = TWO ? sp_b[sid] : 0, x = splist[sid], p;
-	do {
-		p = pk[x];
-		uint32_t w = (p >> 29) & 1u;
-		if (TWO) { // both sums in one 8-byte store: the writes follow the list, i.e. they are scattered
-			out12[x] = make_uint2(a, b);
-			b -= w ? 1u : 0xFFFFFFFFu;
-		} else {
-			out1[x] = a;
-		}
-		a -= w;
-		x = p & PK_END;
-	} while (!(p >> 31));
+	// grid-stride over the splitters (they are in index order): the lanes in flight then work on one window of
+	// the element arrays at a time, so the scattered 4/8-byte rank stores meet again in L2 instead of each
+	// costing a partial line in HBM
+	const uint32_t m = min(m_cap, *m_dev);
+	for (uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x; sid < m; sid += gridDim.x * blockDim.x) {
+		uint32_t a = sp_a[sid], b = TWO ? sp_b[sid] : 0, x = splist[sid], p;
+		do {
+			p = pk[x];
+			uint32_t w = (p >> 29) & 1u;
+			if (TWO) { // both sums in one 8-byte store
+				out12[x] = make_uint2(a, b);
+				b -= w ? 1u : 0xFFFFFFFFu;
+			} else {
+				out1[x] = a;
+			}
+			a -= w;
+			x = p & PK_END;
+		} while (!(p >> 31));
+	}
 }
 
+static constexpr unsigned WALK2_BLOCKS = 512; // x 256 lanes in flight (see k_rank_walk2)
 struct RankBufs {
 	uint32_t *pk, *flag, *ps;		       // [n+1] packed list words (rank_pack), splitter flags, their scan
 	uint32_t *nA, *nB, *aA, *aB, *bA, *bB;	       // [m_cap] splitter list ping-pong
@@ -275,7 +281,11 @@ static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint
 	LAUNCH(k_rank_walk1<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, rb.ps, rb.nA, rb.aA, rb.bA);
 	const unsigned rounds = bits_for(m_cap) + 1;
 	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s, m_dev);
-	LAUNCH(k_rank_walk2<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, side ? rb.aB : rb.aA, side ? rb.bB : rb.bA, out1, out12);
+	{
+		const unsigned blocks = std::min<unsigned>(nblk(m_cap), WALK2_BLOCKS);
+		hipLaunchKernelGGL(k_rank_walk2<TWO>, dim3(blocks), dim3(TPB), 0, s, m_cap, m_dev, pk, rb.splist, side ? rb.aB : rb.aA,
+				   side ? rb.bB : rb.bA, out1, out12);
+	}
 }
 
 // ------------------------------------------------------------------ 2. rooted forest T0
@@ -514,34 +524,34 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 				  const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ecc, uint32_t *__restrict__ dpar,
 				  uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis, uint32_t *__restrict__ cur)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_entry)
-		return;
-	const uint32_t s = entry_list[i], cls = ecc[s];
-	uint32_t u = s;
-	while (true) {
-		const uint32_t lo = loff[u], n = loff[u + 1] - lo;
-		uint32_t k = cur[u];
-		bool adv = false;
-		while (k <= n) {
-			const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
-			const uint32_t slot = k++;
-			if (ecc[o] == cls && !dvis[o]) {
-				dvis[o] = 1;
-				dpar[o] = u;
-				cslot[o] = slot;
-				cur[u] = k;
-				u = o;
-				adv = true;
-				break;
+	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
+		const uint32_t s = entry_list[i], cls = ecc[s];
+		uint32_t u = s;
+		while (true) {
+			const uint32_t lo = loff[u], n = loff[u + 1] - lo;
+			uint32_t k = cur[u];
+			bool adv = false;
+			while (k <= n) {
+				const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
+				const uint32_t slot = k++;
+				if (ecc[o] == cls && !dvis[o]) {
+					dvis[o] = 1;
+					dpar[o] = u;
+					cslot[o] = slot;
+					cur[u] = k;
+					u = o;
+					adv = true;
+					break;
+				}
 			}
+			if (adv)
+				continue;
+			cur[u] = k;
+			if (u == s)
+				break;
+			u = dpar[u];
 		}
-		if (adv)
-			continue;
-		cur[u] = k;
-		if (u == s)
-			break;
-		u = dpar[u];
 	}
 }
 __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
@@ -899,7 +909,12 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
 				   tw.dpar, tw.cslot, tw.dvis, tw.cret);
 	} else if (n_entry) {
-		hipLaunchKernelGGL(k_class_dfs_small, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff,
+		// Lanes in flight = a window of sides whose scattered stores meet again in L2 (2048 x 64 lanes measured best
+		// for a few hundred thousand small classes); with millions of classes the walk is latency-bound and wants
+		// every lane the device can hold, so the cap never goes below 40 % of the classes.
+		const unsigned all_blocks = (n_entry + 63) / 64;
+		const unsigned dfs_blocks = std::min(all_blocks, std::max(2048u, (unsigned)(0.4 * all_blocks)));
+		hipLaunchKernelGGL(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff,
 				   cs.ladj, tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
 	}
 	tm.end(5);
