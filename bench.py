@@ -3,18 +3,24 @@
 
 One "step" = one full pass of the hot path (rows B-G: component labelling, re-indexing, spanning
 tree, cycle classes, candidate stack, PVST) over the workload, from "graph resident in HBM as CSR"
-to "PVST arrays on the host" (SURVEY.md 8d).  At N=1 the workload is BASELINE.json configs[1]:
-the synthetic chain-of-bubbles GFA, 1 000 000 segments / 1 999 998 links, one component.  At N>1
-every rank owns one such component (components are the sharding unit; weak scaling; no data-path
-collective: like the reference's threads, every rank ends with the PVST arrays of its own components
-in host memory and would write their files).  `--gather` adds the pipelined PVST gather to rank 0 over
-RCCL to the timed region.
+to "PVST arrays on the host" (SURVEY.md 8d).
+
+N = 1   the workload is the configuration BASELINE.json's metric is quoted on: the HPRC-shaped
+        whole-genome graph (configs[3]) at full size -- 24 chromosome-sized components + 2 000 tiny
+        ones, 99.9 M segments / 122.4 M links; it fits one MI355X (~190 GB of the 288 GB).  Configs
+        2 / 3 / 5 are timed briefly afterwards and reported as secondary keys of the same line.
+N > 1   STRONG scaling of the same graph (`povu_amd/sharded.py`): rank 0 holds the graph; every step
+        it labels the components on its GPU, bin-packs them over the ranks (LPT), partitions the
+        links on the device and scatters the shards (RCCL send/recv over xGMI); every rank builds the
+        CSR of its shard and decomposes it; the PVST arrays are gathered to rank 0.  Scatter and
+        gather are inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,28 +33,111 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 
 
 def algorithmic_bytes(E, V, F):
-    """whole path 48E + 108V + 16F; traversal kernels (rows C-G) 24E + 80V + 16F."""
-    return 48 * E + 108 * V + 16 * F, 24 * E + 80 * V + 16 * F
+    """whole path 48E + 108V + 16F bytes."""
+    return 48 * E + 108 * V + 16 * F
+
+
+def kernel_source_digest():
+    """sha256 over the HIP sources: profiles/pmc_traffic.json records the digest it was measured with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "povu_amd", "csrc", "hip")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_workload(name, scale):
+    from povu_amd import workloads as W
+    if name == "hprc-wg":
+        g = W.hprc_whole_genome(1e8 * scale)
+        return g, (f"BASELINE config 4 at full size: HPRC-shaped whole genome, 24 chromosome-sized components + 2000 tiny, "
+                   f"{g.n_vtx} segments / {g.n_links} links" + ("" if scale == 1.0 else f" (scale {scale})"))
+    if name == "chain":
+        k = max(1, int(333333 * scale))
+        g = W.chain_of_bubbles(k)
+        return g, f"BASELINE config 2: chain-of-bubbles K={k}, {g.n_vtx} segments / {g.n_links} links, 1 component"
+    if name == "hprc-chr":
+        n = max(8, int(4e6 * scale))
+        g = W.hprc_shaped([n], seed=20260612)
+        return g, f"BASELINE config 3 shape: HPRC-shaped single component, backbone {n}, {g.n_vtx} segments / {g.n_links} links"
+    if name == "nest":
+        t = max(1, int(3333 * scale))
+        g = W.nested_towers(1000, t)
+        return g, f"BASELINE config 5: nested towers depth 1000 x {t}, {g.n_vtx} segments / {g.n_links} links"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def count_flubbles(forest):
+    _, total, _, hdr = forest.raw()
+    return int(total) - int(hdr.shape[0])
+
+
+def time_single(hip, g, steps, warmup, flags):
+    """warmup + `steps` timed passes on one context; returns (seconds, HIP-event ms per pass, last forest)."""
+    import torch
+    f = None
+    for _ in range(warmup):
+        f = hip.decompose(flags=flags)
+    torch.cuda.synchronize()
+    ev = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        f = hip.decompose(flags=flags)
+        ev += next(st["ms"] for st in hip.stage_times() if st["name"] == "total")
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, ev / max(1, steps), f
+
+
+def cpu_baseline(scale_note_full_links):
+    """The CPU port (oracle) on all host cores, on a bounded sample of the same workload shape."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib  # CPU oracle: reported baseline only, never the product path
+    from povu_amd import workloads as W
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sample = W.hprc_whole_genome(1e7)  # 1/10 of the workload: same shape, same component structure
+    t0 = time.perf_counter()
+    _, ref = oracle_lib.decompose(sample, want_text=False, timings=True, threads=cores, lpt=False)
+    t_ref = ref["t_componetize"] + ref["t_wall_components"]
+    _, lpt = oracle_lib.decompose(sample, want_text=False, timings=True, threads=cores, lpt=True)
+    t_lpt = lpt["t_componetize"] + lpt["t_wall_components"]
+    _, one = oracle_lib.decompose(sample, want_text=False, timings=True, threads=1)
+    t_one = one["t_componetize"] + one["t_wall_components"]
+    return {"value": sample.n_links / t_ref, "unit": "edges/s", "cores": int(ref["threads"]), "kind": "port",
+            "sample": (f"HPRC-shaped whole genome at 1/10 size ({sample.n_vtx} segments / {sample.n_links} links, 2024 components; "
+                       f"the full workload has {scale_note_full_links} links), componetize..add_flubbles, one run per scheme: "
+                       f"the reference's own threading (contiguous chunks of n_components/threads components per thread, "
+                       f"decompose.cpp:78-92,116-157 -- all 24 large components land on thread 0) {t_ref:.2f} s; "
+                       f"components bin-packed by size over the same threads {t_lpt:.2f} s; one thread {t_one:.2f} s "
+                       f"(wall incl. sample generation {time.perf_counter() - t0:.1f} s)"),
+            "value_lpt_threads": sample.n_links / t_lpt, "value_one_thread": sample.n_links / t_one}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--units", type=int, default=333333, help="bubble units per component (K)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="hprc-wg", choices=["hprc-wg", "chain", "hprc-chr", "nest"])
+    ap.add_argument("--scale", type=float, default=1.0, help="size factor of the workload (1.0 = BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="chain", choices=["chain", "nest", "hprc"])
-    ap.add_argument("--gather", action="store_true", help="N > 1: also gather every rank's PVST arrays to rank 0 (pipelined)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs 2 / 3 / 5")
     args = ap.parse_args()
-
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # never report a 1-GPU number as an N-GPU one: the launcher provides the ranks
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"bench.py --gpus {args.gpus} ...`")
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+
     # POVU_BENCH_BACKEND=gloo + POVU_BENCH_ONE_DEVICE=1 rehearse the N>1 path on a single-GPU box
     backend = os.environ.get("POVU_BENCH_BACKEND", "nccl")
     if os.environ.get("POVU_BENCH_ONE_DEVICE"):
@@ -62,134 +151,122 @@ def main():
     torch.cuda.set_device(local_rank)
     comm_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
-    from povu_amd import HipDecomposer, workloads
-    from povu_amd.sharded import PipelinedGather
-
-    if args.workload == "chain":
-        g = workloads.chain_of_bubbles(args.units)
-        wl = f"chain-of-bubbles K={args.units}: {g.n_vtx} segments / {g.n_links} links, 1 component per GPU"
-    elif args.workload == "nest":
-        g = workloads.nested_towers(1000, max(1, args.units // 100))
-        wl = f"nested towers depth 1000 x {max(1, args.units // 100)}: {g.n_vtx} segments / {g.n_links} links"
-    else:
-        g = workloads.hprc_shaped([args.units * 3], seed=20260612 + rank)
-        wl = f"HPRC-shaped backbone {args.units * 3}: {g.n_vtx} segments / {g.n_links} links"
-
-    hip = HipDecomposer(local_rank)
-    t_up = time.perf_counter()
-    hip.upload(g)  # inputs resident in HBM before the timed region
-    upload_s = time.perf_counter() - t_up
-    # every rank holds ONE component of the job: its global component id is rank + 1
-    id_map = np.array([rank + 1], dtype=np.int64)
-
-    # N > 1: the PVST gather to rank 0 of step k overlaps with the kernels of step k+1 (separate streams);
-    # sync() drains it, so the timed region contains every transfer of its K steps
-    gather = PipelinedGather(rank, world, comm_dev) if (world > 1 and args.gather) else None
-
+    from povu_amd import HipDecomposer
     from povu_amd.hip import F_NO_STAGE_TIMES
 
-    def step():
-        # timed passes record only the pass-total HIP events; the per-stage breakdown comes from one extra pass
-        f = hip.decompose(flags=F_NO_STAGE_TIMES)
-        if gather:
-            gather.submit(f, id_map=id_map)
-        return f
-
-    def sync():
-        if gather:
-            gather.finish()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    f = None
-    for _ in range(args.warmup):
-        f = step()
-    stage_acc = {}
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        f = step()
-        for st in hip.stage_times():
-            a = stage_acc.setdefault(st["name"], [0.0, 0])
-            a[0] += st["ms"]
-            a[1] += 1
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    pass_ms_timed = stage_acc["total"][0] / max(1, stage_acc["total"][1]) if "total" in stage_acc else None
-    hip.decompose()  # untimed: per-stage HIP events (a few microseconds each) for the breakdown below
-    stage_acc = {st["name"]: [st["ms"], 1] for st in hip.stage_times()}
-    if pass_ms_timed is not None:
-        stage_acc["total"] = [pass_ms_timed, 1]
-    n_flub = sum(f.tree(i).a_id.shape[0] - 1 for i in range(len(f)))
-    E, V = g.n_links, g.n_vtx
-    total_links = E * world * args.steps
-    value = total_links / dt
-
-    if rank == 0:
-        stages = {k: v[0] / max(1, v[1]) for k, v in stage_acc.items()}
+    hip = HipDecomposer(local_rank)
+    out = None
+    if world == 1:
+        g, wl = build_workload(args.workload, args.scale)
+        t_up = time.perf_counter()
+        hip.upload(g)  # inputs resident in HBM before the timed region
+        upload_s = time.perf_counter() - t_up
+        up = hip.upload_times()
+        dt, pass_ms, f = time_single(hip, g, args.steps, args.warmup, F_NO_STAGE_TIMES)
+        E, V, F = g.n_links, g.n_vtx, count_flubbles(f)
+        n_trees = len(f)
+        del f
+        hip.decompose()  # untimed: per-stage HIP events for the breakdown
+        stages = {st["name"]: st["ms"] for st in hip.stage_times()}
+        stages["total"] = pass_ms
         dom = max((k for k in stages if k != "total"), key=lambda k: stages[k])
-        whole_b, trav_b = algorithmic_bytes(E, V, n_flub)
-        # the "kernel" of this path is one decompose pass = ~330 short launches; its duration is the HIP-event
-        # time around the whole pass on the library's stream (sum of kernel durations in profiles/ agrees)
-        pass_ms = stages.get("total", dt / args.steps * 1e3)
-        achieved = whole_b / (pass_ms * 1e-3) / 1e9
-        traffic = None
+        alg = algorithmic_bytes(E, V, F)
+        achieved = alg / (pass_ms * 1e-3) / 1e9
+        traffic, traffic_note = None, "no PMC run of this workload under profiles/"
         try:  # HBM bytes per pass from the committed rocprofv3 --pmc runs of this workload (profiles/)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pm.get("links") == E and world == 1:
-                traffic = pm["hbm_bytes_per_pass"]
+            if pm.get("links") == E and pm.get("segments") == V:
+                if pm.get("kernel_source_digest") == kernel_source_digest():
+                    traffic, traffic_note = pm["hbm_bytes_per_pass"], "profiles/pmc_traffic.json (same kernels, same workload)"
+                else:
+                    traffic_note = "profiles/pmc_traffic.json is stale: the kernels changed since it was collected"
         except Exception:
-            traffic = None
+            pass
+        step_s = dt / args.steps
         out = {
             "metric": "edges/sec decomposed (flubble+PVST)",
-            "value": value,
+            "value": E * args.steps / dt,
             "unit": "edges/s",
-            "n_gpus": world,
+            "n_gpus": 1,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": wl, "links_per_gpu": E, "segments_per_gpu": V, "flubbles_per_gpu": n_flub,
-                       "sharding": ("one weakly-connected component per GPU; "
-                                    + ("pipelined PVST gather to rank 0 over RCCL inside the timed region" if gather else
-                                       "every rank keeps (and would write) the PVST of its own components, no data-path collective"))
-                       if world > 1 else "single GPU"},
+            "config": {"workload": wl, "links": E, "segments": V, "components": n_trees, "flubbles": F, "sharding": "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "decompose pass (all kernels of rows B-G, one HIP stream)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": whole_b, "ms_per_launch": pass_ms,
-                         "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d)",
+                         "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg,
+                         "ms_per_launch": pass_ms, "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d)",
                          "dominant_stage": {"name": dom, "ms": stages[dom]}},
             "stage_ms": stages,
-            "upload_ms": upload_s * 1e3,
-            "pcie_inclusive_value": E * world / (dt / args.steps + upload_s),
+            # what happens before the timed region (povu_hip_graph_upload), split by HIP events:
+            "upload": {"wall_ms": upload_s * 1e3, "h2d_ms": up["h2d_ms"], "csr_build_ms": up["csr_ms"],
+                       "twin_index_ms": up["twin_ms"],
+                       "note": "csr_build = side degrees, offsets, adjacency sorted per side, other-end table, tips; "
+                               "twin_index = reverse-slot table (atwin); both device time"},
+            "value_incl_index_build": E / (step_s + (up["csr_ms"] + up["twin_ms"]) * 1e-3),
+            "pcie_inclusive_value": E / (step_s + upload_s),
         }
-        if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib  # CPU oracle: reported baseline only, never the product path
-            k = min(args.units, 333333)
-            sample = workloads.chain_of_bubbles(k) if args.workload == "chain" else g
-            # repeat the one-core port until ~6 s of CPU work have been spent; report the mean pass
-            t1 = time.perf_counter()
-            reps, cpu_dt = 0, 0.0
-            while reps < 3 or (cpu_dt < 6.0 and reps < 50):
-                _, info = oracle_lib.decompose(sample, want_text=False, timings=True)
-                cpu_dt += info["t_componetize"] + info["t_tree"] + info["t_classes"] + info["t_stack"] + info["t_pvst"]
-                reps += 1
-            out["cpu_baseline"] = {"value": sample.n_links * reps / cpu_dt, "unit": "edges/s", "cores": 1, "kind": "port",
-                                   "sample": f"{sample.n_links} links of the same workload (one component = one thread in the "
-                                             f"reference's scheme), {reps} passes, componetize..add_flubbles "
-                                             f"{cpu_dt / reps:.2f} s per pass (wall incl. graph build {time.perf_counter() - t1:.1f} s)"}
+        if not args.no_secondary and args.workload == "hprc-wg":
+            sec = {}
+            for key, name in (("config2_chain_1M", "chain"), ("config3_hprc_chr", "hprc-chr"), ("config5_nest_10M", "nest")):
+                g2, wl2 = build_workload(name, 1.0)
+                hip.upload(g2)
+                dt2, ms2, f2 = time_single(hip, g2, 5, 2, F_NO_STAGE_TIMES)
+                a2 = algorithmic_bytes(g2.n_links, g2.n_vtx, count_flubbles(f2))
+                sec[key] = {"workload": wl2, "value": g2.n_links * 5 / dt2, "ms_per_step": dt2 / 5 * 1e3, "ms_per_launch": ms2,
+                            "roofline_frac": a2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del f2, g2
+            out["secondary"] = sec
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(E)
+    else:
+        from povu_amd.sharded import ShardedBench
+        sb = ShardedBench(hip, rank, world, comm_dev, lambda: build_workload(args.workload, args.scale))
+        for _ in range(args.warmup):
+            sb.step()
+        sb.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sb.step()
+        sb.sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        info = sb.summary()  # collective: per-rank loads and phase times
+        if rank == 0:
+            E, V, F = info["links"], info["segments"], info["flubbles"]
+            alg = algorithmic_bytes(E, V, F)
+            step_s = dt / args.steps
+            achieved = alg / step_s / 1e9
+            out = {
+                "metric": "edges/sec decomposed (flubble+PVST)",
+                "value": E * args.steps / dt,
+                "unit": "edges/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": step_s * 1e3,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "u32",
+                "data": "synthetic",
+                "config": {"workload": info["workload"], "links": E, "segments": V, "components": info["components"], "flubbles": F,
+                           "sharding": info["sharding"]},
+                "roofline": {"bound": "hbm", "kernel": "whole job: label + partition + scatter + per-shard decompose + gather",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
+                             "traffic": None, "algorithmic_bytes_per_launch": alg, "ms_per_launch": step_s * 1e3,
+                             "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d) over the aggregate peak of all GPUs"},
+                "shards": info["shards"],
+                "phase_ms": info["phase_ms"],
+            }
+    if rank == 0:
         print(json.dumps(out))
     hip.close()
     if world > 1:

@@ -62,6 +62,10 @@ int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid
 			  const uint32_t *v1, const uint8_t *s1, const uint32_t *v2, const uint8_t *s2,
 			  const uint8_t *tips, char *err, size_t errlen);
 
+/* device time of the last upload by HIP events, milliseconds: [0] host-to-device copies, [1] CSR build (side
+ * degrees, offsets, per-side sorted adjacency, other-end table, tips), [2] reverse-slot table */
+int povu_hip_last_upload_times(const povu_hip_ctx *ctx, double out_ms[3]);
+
 typedef struct {
 	uint32_t rank;	/* this process' shard (component sharding, 0-based) */
 	uint32_t world; /* number of shards; 0 or 1 = everything */

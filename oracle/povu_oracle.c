@@ -11,6 +11,7 @@
 
 #include <errno.h>
 #include <inttypes.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1240,7 +1241,60 @@ char *orc_pvst_text(const orc_pvst *p, size_t *len)
  * do_decompose, app/subcommand/decompose.cpp:94-160: component id = position
  * + 1 (:129), components with < 3 vertices are skipped (:135-142). */
 
-static orc_forest *decompose_graph(const orc_graph *g, int want_text)
+/* one component through from_bd .. add_flubbles (decompose_component, decompose.cpp:30-76); the
+ * stage seconds are added to t[0..3] (tree, classes, stack + next_seen, pvst) */
+static void decompose_one(const orc_graph *cg, uint32_t c, orc_forest *f, int want_text, double *t)
+{
+	double a = now_s();
+	orc_tree *tr = orc_from_bd(cg);
+	double b = now_s();
+	orc_cycle_equiv(tr);
+	double d = now_s();
+	orc_oic *st = NULL;
+	uint32_t n = orc_eq_class_stack(tr, &st);
+	uint32_t *ns = xmalloc((size_t)(n + 1) * 4);
+	orc_next_seen(st, n, tr->n_class, ns);
+	double e = now_s();
+	orc_pvst *p = orc_add_flubbles(tr, st, ns, n);
+	double h = now_s();
+	t[0] += b - a;
+	t[1] += d - b;
+	t[2] += e - d;
+	t[3] += h - e;
+	f->n_pvst[c] = p->n;
+	if (want_text)
+		f->text[c] = orc_pvst_text(p, &f->text_len[c]);
+	free(st);
+	free(ns);
+	orc_pvst_free(p);
+	orc_tree_free(tr);
+}
+
+typedef struct {
+	orc_graph **cs;
+	orc_forest *f;
+	const uint32_t *list; /* components of this thread, in order */
+	uint32_t n_list;
+	int want_text;
+	double t[4];
+} mt_job;
+
+static void *mt_worker(void *arg)
+{
+	mt_job *j = arg;
+	for (uint32_t k = 0; k < j->n_list; k++) {
+		const uint32_t c = j->list[k];
+		if (j->cs[c]->nv >= 3) /* decompose.cpp:135-142 */
+			decompose_one(j->cs[c], c, j->f, j->want_text, j->t);
+	}
+	return NULL;
+}
+
+/* do_decompose, decompose.cpp:94-160.  threads <= 1: the plain loop.  threads > 1, lpt == 0: the
+ * reference's own scheme -- chunk_size = n_components / threads contiguous components per thread,
+ * the last thread takes the remainder (thread_count, :78-92, :116-123).  lpt != 0: components
+ * bin-packed by (segments + links), heaviest first (what the HIP path's sharding does). */
+static orc_forest *decompose_graph_mt(const orc_graph *g, int want_text, int threads, int lpt)
 {
 	orc_forest *f = xcalloc(1, sizeof *f);
 	double t0 = now_s();
@@ -1256,41 +1310,105 @@ static orc_forest *decompose_graph(const orc_graph *g, int want_text)
 	for (uint32_t c = 0; c < nc; c++) {
 		f->comp_nv[c] = cs[c]->nv;
 		f->comp_ne[c] = cs[c]->ne;
-		if (cs[c]->nv >= 3) {
-			double a = now_s();
-			orc_tree *t = orc_from_bd(cs[c]);
-			double b = now_s();
-			orc_cycle_equiv(t);
-			double d = now_s();
-			orc_oic *st = NULL;
-			uint32_t n = orc_eq_class_stack(t, &st);
-			uint32_t *ns = xmalloc((size_t)(n + 1) * 4);
-			orc_next_seen(st, n, t->n_class, ns);
-			double e = now_s();
-			orc_pvst *p = orc_add_flubbles(t, st, ns, n);
-			double h = now_s();
-			f->t_tree += b - a;
-			f->t_classes += d - b;
-			f->t_stack += e - d;
-			f->t_pvst += h - e;
-			f->n_pvst[c] = p->n;
-			f->total_flubbles += p->n - 1;
-			if (want_text)
-				f->text[c] = orc_pvst_text(p, &f->text_len[c]);
-			free(st);
-			free(ns);
-			orc_pvst_free(p);
-			orc_tree_free(t);
+	}
+	if (threads < 1)
+		threads = 1;
+	if ((uint32_t)threads > nc)
+		threads = nc ? (int)nc : 1;
+	uint32_t *order = xmalloc(((size_t)nc + 1) * 4);
+	uint32_t *first = xcalloc((size_t)threads + 1, 4);
+	if (!lpt) {
+		const uint32_t chunk = nc / (uint32_t)threads;
+		for (uint32_t c = 0; c < nc; c++)
+			order[c] = c;
+		for (int t = 0; t < threads; t++)
+			first[t] = (uint32_t)t * chunk;
+		first[threads] = nc;
+	} else {
+		/* heaviest first (stable), each to the least loaded thread */
+		uint32_t *byw = xmalloc(((size_t)nc + 1) * 4), *owner = xmalloc(((size_t)nc + 1) * 4);
+		uint64_t *load = xcalloc((size_t)threads, 8);
+		for (uint32_t c = 0; c < nc; c++)
+			byw[c] = c;
+		/* insertion into a bucket sort would be overkill: components are few next to their size */
+		for (uint32_t i = 1; i < nc; i++) {
+			uint32_t c = byw[i];
+			uint64_t w = (uint64_t)cs[c]->nv + cs[c]->ne;
+			uint32_t j = i;
+			while (j > 0 && (uint64_t)cs[byw[j - 1]]->nv + cs[byw[j - 1]]->ne < w) {
+				byw[j] = byw[j - 1];
+				j--;
+			}
+			byw[j] = c;
 		}
+		for (uint32_t k = 0; k < nc; k++) {
+			int best = 0;
+			for (int t = 1; t < threads; t++)
+				if (load[t] < load[best])
+					best = t;
+			owner[byw[k]] = (uint32_t)best;
+			load[best] += (uint64_t)cs[byw[k]]->nv + cs[byw[k]]->ne + 1;
+			first[best + 1]++;
+		}
+		for (int t = 0; t < threads; t++)
+			first[t + 1] += first[t];
+		uint32_t *cur = xmalloc(((size_t)threads + 1) * 4);
+		memcpy(cur, first, ((size_t)threads + 1) * 4);
+		for (uint32_t k = 0; k < nc; k++)
+			order[cur[owner[byw[k]]]++] = byw[k];
+		free(cur);
+		free(byw);
+		free(owner);
+		free(load);
+	}
+	mt_job *jobs = xcalloc((size_t)threads, sizeof *jobs);
+	pthread_t *th = xcalloc((size_t)threads, sizeof *th);
+	double w0 = now_s();
+	for (int t = 0; t < threads; t++) {
+		jobs[t].cs = cs;
+		jobs[t].f = f;
+		jobs[t].list = order + first[t];
+		jobs[t].n_list = first[t + 1] - first[t];
+		jobs[t].want_text = want_text;
+		if (threads == 1)
+			mt_worker(&jobs[t]);
+		else if (pthread_create(&th[t], NULL, mt_worker, &jobs[t]) != 0) {
+			fprintf(stderr, "povu_oracle: pthread_create failed\n");
+			abort();
+		}
+	}
+	if (threads > 1)
+		for (int t = 0; t < threads; t++)
+			pthread_join(th[t], NULL);
+	f->t_wall_components = now_s() - w0;
+	f->threads = (uint32_t)threads;
+	for (int t = 0; t < threads; t++) {
+		f->t_tree += jobs[t].t[0];
+		f->t_classes += jobs[t].t[1];
+		f->t_stack += jobs[t].t[2];
+		f->t_pvst += jobs[t].t[3];
+	}
+	for (uint32_t c = 0; c < nc; c++) {
+		if (f->n_pvst[c])
+			f->total_flubbles += f->n_pvst[c] - 1;
 		orc_graph_free(cs[c]);
 	}
+	free(jobs);
+	free(th);
+	free(order);
+	free(first);
 	free(cs);
 	return f;
 }
 
-orc_forest *orc_decompose_arrays(uint32_t nv, const uint32_t *vid, uint32_t ne, const uint32_t *ev1,
-				 const uint8_t *es1, const uint32_t *ev2, const uint8_t *es2,
-				 const uint8_t *tips, int want_text)
+static orc_forest *decompose_graph(const orc_graph *g, int want_text)
+{
+	return decompose_graph_mt(g, want_text, 1, 0);
+}
+
+orc_forest *orc_decompose_arrays_mt(uint32_t nv, const uint32_t *vid, uint32_t ne, const uint32_t *ev1,
+				    const uint8_t *es1, const uint32_t *ev2, const uint8_t *es2,
+				    const uint8_t *tips, int want_text, int threads, int lpt)
 {
 	orc_graph *g = orc_graph_new(nv, ne);
 	memcpy(g->vid, vid, (size_t)nv * 4);
@@ -1303,9 +1421,16 @@ orc_forest *orc_decompose_arrays(uint32_t nv, const uint32_t *vid, uint32_t ne, 
 		memcpy(g->tip, tips, nv);
 	else
 		orc_graph_infer_tips(g);
-	orc_forest *f = decompose_graph(g, want_text);
+	orc_forest *f = decompose_graph_mt(g, want_text, threads, lpt);
 	orc_graph_free(g);
 	return f;
+}
+
+orc_forest *orc_decompose_arrays(uint32_t nv, const uint32_t *vid, uint32_t ne, const uint32_t *ev1,
+				 const uint8_t *es1, const uint32_t *ev2, const uint8_t *es2,
+				 const uint8_t *tips, int want_text)
+{
+	return orc_decompose_arrays_mt(nv, vid, ne, ev1, es1, ev2, es2, tips, want_text, 1, 0);
 }
 
 void orc_forest_free(orc_forest *f)

@@ -132,7 +132,9 @@ typedef struct {
 	size_t *text_len;      /* [n_comp] */
 	uint32_t *n_pvst;      /* [n_comp] PVST vertex count (0 when skipped) */
 	uint64_t total_flubbles;
-	double t_componetize, t_tree, t_classes, t_stack, t_pvst; /* seconds */
+	double t_componetize, t_tree, t_classes, t_stack, t_pvst; /* seconds (summed over threads) */
+	double t_wall_components; /* wall seconds of the per-component part (all threads) */
+	uint32_t threads;
 } orc_forest;
 
 /* edges given by vertex IDX (not id). tips: NULL = infer as the GFA loader does,
@@ -140,6 +142,11 @@ typedef struct {
 orc_forest *orc_decompose_arrays(uint32_t nv, const uint32_t *vid, uint32_t ne, const uint32_t *ev1,
 				 const uint8_t *es1, const uint32_t *ev2, const uint8_t *es2,
 				 const uint8_t *tips, int want_text);
+/* the same with the per-component part on `threads` threads: lpt == 0 = the reference's contiguous
+ * chunks of components (decompose.cpp:78-92,116-157), lpt != 0 = components bin-packed by size */
+orc_forest *orc_decompose_arrays_mt(uint32_t nv, const uint32_t *vid, uint32_t ne, const uint32_t *ev1,
+				    const uint8_t *es1, const uint32_t *ev2, const uint8_t *es2,
+				    const uint8_t *tips, int want_text, int threads, int lpt);
 void orc_forest_free(orc_forest *f);
 
 /* intermediate dumps for stage-level parity tests (single component graphs) */

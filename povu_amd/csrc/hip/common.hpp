@@ -27,6 +27,14 @@ struct HipError : std::runtime_error {
 						 __FILE__ + ":" + std::to_string(__LINE__) + ")");   \
 	} while (0)
 
+// kernel launch + launch-configuration check (a bad grid / LDS size / missing code object is not reported by the
+// stream synchronisation that follows)
+#define KLAUNCH(kernel, grid, block, shmem, stream, ...)                                          \
+	do {                                                                                      \
+		hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);              \
+		HIP_CHECK(hipGetLastError());                                                     \
+	} while (0)
+
 // One growable device arena per context: stages carve typed spans with a bump
 // pointer, nothing is hipMalloc'd inside the timed path once the arena is warm.
 class Arena

@@ -16,14 +16,21 @@ static constexpr int TPB = 256;
 static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 
 // ---------------------------------------------------------------- row A: CSR
-__global__ void k_side_degree(uint32_t E, const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1,
+// (also validates the operands: the first link that names an unknown vertex or side lands in *bad)
+__global__ void k_side_degree(uint32_t E, uint32_t V, const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1,
 			      const uint32_t *__restrict__ v2, const uint8_t *__restrict__ s2,
 			      uint32_t *__restrict__ deg, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-			      uint32_t sentinel)
+			      uint32_t sentinel, uint32_t *__restrict__ bad)
 {
 	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= E)
 		return;
+	if (v1[e] >= V || v2[e] >= V || s1[e] > 1 || s2[e] > 1) {
+		atomicMin(bad, e);
+		keys[2 * e] = keys[2 * e + 1] = sentinel;
+		vals[2 * e] = vals[2 * e + 1] = e;
+		return;
+	}
 	uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
 	atomicAdd(&deg[a], 1u);
 	keys[2 * e] = a;
@@ -93,6 +100,12 @@ __global__ void k_infer_tips(uint32_t V, const uint32_t *__restrict__ off, uint8
 	bool le = off[2 * v + 1] == off[2 * v], re = off[2 * v + 2] == off[2 * v + 1];
 	tip[v] = le ? 1 : (re ? 2 : 0);
 }
+__global__ void k_check_tips(uint32_t V, const uint8_t *__restrict__ tip, uint32_t *__restrict__ bad)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V && tip[v] > 2)
+		atomicMin(bad, v);
+}
 
 // ---------------------------------------------------------------- row B: WCC
 // Lock-free union-find over the links (k_uf_tiles in LDS, k_uf_cross in global memory): roots are
@@ -112,12 +125,13 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 	return x;
 }
 
-// ---- tile-local union-find.  Pangenome GFAs are (mostly) sorted along the genome, so almost every
-// link joins two segments of nearby idx.  A workgroup owns UF_TILE consecutive vertices, keeps their
-// parent pointers in LDS and unions every link whose both ends fall inside the tile there (LDS CAS,
-// no global atomics, no long global pointer chains); only the links that leave a tile go through
-// the global lock-free union-find afterwards.
-static constexpr uint32_t UF_TILE = 8192, UF_TPB = 1024;
+// ---- tile-local union-find straight from the CSR.  Pangenome GFAs are (mostly) sorted along the genome,
+// so almost every link joins two segments of nearby idx.  A workgroup owns UF_TILE consecutive vertices, keeps
+// their parent pointers in LDS and walks the adjacency slots of its sides (contiguous in aoth): a link is
+// handled from its smaller endpoint; when both ends fall inside the tile it is united there (LDS CAS, no
+// global atomics, no long global pointer chains), otherwise the slot goes onto the cross list -- wave ballot +
+// prefix popcount, one atomic per wave -- and k_uf_cross unites it in global memory afterwards.
+static constexpr uint32_t UF_TILE = 8192, UF_TPB = 1024, UF_HEAVY = 128, UF_HEAVY_CAP = 256;
 
 __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 {
@@ -131,52 +145,89 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 	}
 	return x;
 }
+__device__ __forceinline__ bool lds_union(uint32_t *par, uint32_t a, uint32_t b)
+{
+	uint32_t ra = lds_find(par, a), rb = lds_find(par, b);
+	while (ra != rb) {
+		const uint32_t hi = max(ra, rb), lo = min(ra, rb);
+		const uint32_t old = atomicCAS(&par[hi], hi, lo);
+		if (old == hi)
+			return true;
+		ra = lds_find(par, old);
+		rb = lds_find(par, lo);
+	}
+	return false;
+}
+// appends (v, slot) of every lane with `take` to the cross list: one atomic per wave
+__device__ __forceinline__ void wave_append(bool take, uint32_t v, uint32_t k, uint32_t *__restrict__ xcount,
+					    uint2 *__restrict__ xlist)
+{
+	const unsigned long long m = __ballot(take);
+	if (!m)
+		return;
+	const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
+	uint32_t base = 0;
+	if (lane == leader)
+		base = atomicAdd(xcount, (uint32_t)__popcll(m));
+	base = __shfl(base, (int)leader);
+	if (take)
+		xlist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, k);
+}
 
-__global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, uint32_t E, const uint32_t *__restrict__ e_lo,
-						  const uint32_t *__restrict__ e_hi, const uint32_t *__restrict__ eperm,
-						  uint32_t *__restrict__ label, uint32_t *__restrict__ hook)
+__global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
+						  const uint32_t *__restrict__ adj, uint32_t *__restrict__ label,
+						  uint32_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist)
 {
 	__shared__ uint32_t par[UF_TILE];
-	__shared__ uint32_t kb, ke;
+	__shared__ uint32_t heavy[UF_HEAVY_CAP];
+	__shared__ uint32_t n_heavy;
 	const uint32_t v0 = blockIdx.x * UF_TILE, v1 = min(V, v0 + UF_TILE);
 	for (uint32_t i = threadIdx.x; i < UF_TILE; i += blockDim.x)
 		par[i] = i;
-	if (threadIdx.x < 2) { // first sorted link position with e_lo >= v0 (thread 0) / v1 (thread 1)
-		const uint32_t x = threadIdx.x ? v1 : v0;
-		uint32_t lo = 0, hi = E;
-		while (lo < hi) {
-			uint32_t mid = (lo + hi) >> 1;
-			if (e_lo[mid] < x)
-				lo = mid + 1;
-			else
-				hi = mid;
-		}
-		if (threadIdx.x)
-			ke = lo;
-		else
-			kb = lo;
-	}
+	if (threadIdx.x == 0)
+		n_heavy = 0;
 	__syncthreads();
-	for (uint32_t k = kb + threadIdx.x; k < ke; k += blockDim.x) {
-		const uint32_t bg = e_hi[k];
-		if (bg >= v1)
-			continue; // leaves the tile: k_uf_cross
-		const uint32_t a = e_lo[k] - v0, b = bg - v0;
-		uint32_t merged = 0;
-		if (a != b) {
-			uint32_t ra = lds_find(par, a), rb = lds_find(par, b);
-			while (ra != rb) {
-				const uint32_t hi = max(ra, rb), lo = min(ra, rb);
-				const uint32_t old = atomicCAS(&par[hi], hi, lo);
-				if (old == hi) {
-					merged = 1;
-					break;
+	auto handle = [&](uint32_t v, uint32_t k) -> bool { // true: the slot leaves the tile upwards
+		const uint32_t vo = aoth[k] >> 1;
+		if (vo <= v)
+			return false; // handled from the other end (or a self loop: never a forest link)
+		if (vo >= v1)
+			return true;
+		if (lds_union(par, v - v0, vo - v0))
+			hook[adj[k]] = 1u;
+		return false;
+	};
+	const uint32_t S0 = 2 * v0, S1 = 2 * v1;
+	for (uint32_t base = S0; base < S1; base += blockDim.x) { // uniform trip count: the ballots below need whole waves
+		const uint32_t S = base + threadIdx.x;
+		uint32_t k = 0, hi = 0;
+		if (S < S1) {
+			k = off[S];
+			hi = off[S + 1];
+			if (hi - k > UF_HEAVY) { // a hub side: the whole workgroup walks it below
+				const uint32_t q = atomicAdd(&n_heavy, 1u);
+				if (q < UF_HEAVY_CAP) {
+					heavy[q] = S;
+					hi = k;
 				}
-				ra = lds_find(par, old);
-				rb = lds_find(par, lo);
 			}
 		}
-		hook[eperm[k]] = merged;
+		while (__any(k < hi)) {
+			const bool live = k < hi;
+			const bool cross = live && handle(S >> 1, k);
+			wave_append(cross, S >> 1, k, xcount, xlist);
+			k++;
+		}
+	}
+	__syncthreads();
+	const uint32_t nh = min(n_heavy, UF_HEAVY_CAP);
+	for (uint32_t q = 0; q < nh; q++) {
+		const uint32_t S = heavy[q], lo = off[S], hi = off[S + 1];
+		for (uint32_t kb = lo; kb < hi; kb += blockDim.x) {
+			const uint32_t k = kb + threadIdx.x;
+			const bool cross = k < hi && handle(S >> 1, k);
+			wave_append(cross, S >> 1, k, xcount, xlist);
+		}
 	}
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < v1 - v0; i += blockDim.x) {
@@ -187,51 +238,28 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, uint32_t E, con
 	}
 }
 
-__global__ void k_uf_cross(uint32_t NX, const uint32_t *__restrict__ xlist, const uint32_t *__restrict__ e_lo,
-			   const uint32_t *__restrict__ e_hi, const uint32_t *__restrict__ eperm, uint32_t *parent,
+// the links that leave their tile, in global memory (grid-stride: their number only exists on the device)
+__global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__restrict__ xlist,
+			   const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ adj, uint32_t *parent,
 			   uint32_t *__restrict__ hook)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= NX)
-		return;
-	const uint32_t k = xlist[i];
-	uint32_t merged = 0;
-	uint32_t ra = uf_find(parent, e_lo[k]), rb = uf_find(parent, e_hi[k]);
-	while (ra != rb) {
-		uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
-		uint32_t old = atomicCAS(&parent[hi], hi, lo);
-		if (old == hi) {
-			merged = 1;
-			break;
+	const uint32_t NX = *xcount;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NX; i += gridDim.x * blockDim.x) {
+		const uint2 x = xlist[i];
+		uint32_t ra = uf_find(parent, x.x), rb = uf_find(parent, aoth[x.y] >> 1);
+		while (ra != rb) {
+			uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+			uint32_t old = atomicCAS(&parent[hi], hi, lo);
+			if (old == hi) {
+				hook[adj[x.y]] = 1u;
+				break;
+			}
+			ra = uf_find(parent, old);
+			rb = uf_find(parent, lo);
 		}
-		ra = uf_find(parent, old);
-		rb = uf_find(parent, lo);
 	}
-	hook[eperm[k]] = merged;
 }
 
-// upload-time helpers: links keyed by their smaller endpoint
-__global__ void k_edge_min(uint32_t E, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
-			   uint32_t *__restrict__ key, uint32_t *__restrict__ val)
-{
-	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= E)
-		return;
-	key[e] = min(v1[e], v2[e]);
-	val[e] = e;
-}
-__global__ void k_edge_sorted(uint32_t E, const uint32_t *__restrict__ eperm, const uint32_t *__restrict__ v1,
-			      const uint32_t *__restrict__ v2, uint32_t *__restrict__ e_lo, uint32_t *__restrict__ e_hi,
-			      uint32_t *__restrict__ xflag)
-{
-	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= E)
-		return;
-	uint32_t e = eperm[k], a = v1[e], b = v2[e], lo = min(a, b), hi = max(a, b);
-	e_lo[k] = lo;
-	e_hi[k] = hi;
-	xflag[k] = (lo / UF_TILE != hi / UF_TILE) ? 1u : 0u;
-}
 __global__ void k_compact_pos(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 			      uint32_t *__restrict__ out)
 {
@@ -588,7 +616,7 @@ __global__ void k_fill_u32(size_t n, uint32_t *p, uint32_t val)
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s)
 {
 	if (n)
-		hipLaunchKernelGGL(k_fill_u32, dim3(nblk(n)), dim3(TPB), 0, s, n, p, val);
+		KLAUNCH(k_fill_u32, dim3(nblk(n)), dim3(TPB), 0, s, n, p, val);
 }
 
 // ------------------------------------------------------------------ host side
@@ -603,58 +631,79 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	uint32_t *deg = tmp_arena.take<uint32_t>(nS + 1);
 	size_t sb = sort_tmp_bytes(2 * (size_t)E), cb = scan_tmp_bytes(std::max<size_t>(nS, E) + 2);
 	void *stmp = tmp_arena.take<char>(sb), *ctmp = tmp_arena.take<char>(cb);
+	uint32_t *word = tmp_arena.take<uint32_t>(8); // [0] max degree, [1] first bad link, [2] first bad tip
+	hipEvent_t ev[3];
+	for (auto &e : ev)
+		HIP_CHECK(hipEventCreate(&e));
+	struct EvGuard {
+		hipEvent_t *e;
+		~EvGuard()
+		{
+			for (int i = 0; i < 3; i++)
+				(void)hipEventDestroy(e[i]);
+		}
+	} guard{ev};
+	HIP_CHECK(hipEventRecord(ev[0], s));
 	HIP_CHECK(hipMemsetAsync(deg, 0, (nS + 1) * 4, s));
+	HIP_CHECK(hipMemsetAsync(word, 0, 4, s));
+	HIP_CHECK(hipMemsetAsync(word + 1, 0xFF, 8, s));
 	if (E) {
-		hipLaunchKernelGGL(k_side_degree, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.s1, g.v2, g.s2, deg, keys, vals,
-				   (uint32_t)nS);
+		KLAUNCH(k_side_degree, dim3(nblk(E)), dim3(TPB), 0, s, E, V, g.v1, g.s1, g.v2, g.s2, deg, keys, vals,
+				   (uint32_t)nS, word + 1);
+	}
+	if (g.tips_given) {
+		KLAUNCH(k_check_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.tip, word + 2);
 	}
 	scan_exclusive_u32(deg, g.off, nS + 1, ctmp, cb, s);
 	sort_pairs_u32(keys, keys2, vals, vals2, 2 * (size_t)E, bits_for(nS), stmp, sb, s);
-	uint32_t n_slots = 0;
-	HIP_CHECK(hipMemcpyAsync(&n_slots, g.off + nS, 4, hipMemcpyDeviceToHost, s));
+	uint32_t hw[4] = {0, 0, 0, 0};
+	HIP_CHECK(hipMemcpyAsync(&hw[0], g.off + nS, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&hw[1], word + 1, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	g.n_slots = n_slots;
-	if (n_slots)
-		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)n_slots * 4, hipMemcpyDeviceToDevice, s));
-	if (!g.tips_given && V)
-		hipLaunchKernelGGL(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
+	if (hw[1] != POVU_NIL)
+		throw HipError("link " + std::to_string(hw[1]) + " references an unknown vertex or side");
+	if (hw[2] != POVU_NIL)
+		throw HipError("bad tip mark");
+	g.n_slots = hw[0];
+	if (g.n_slots)
+		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)g.n_slots * 4, hipMemcpyDeviceToDevice, s));
+	if (!g.tips_given && V) {
+		KLAUNCH(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
+	}
 	g.max_vdeg = 0;
 	if (V && E) {
-		hipLaunchKernelGGL(k_slot_other, dim3(nblk(nS)), dim3(TPB), 0, s, (uint32_t)nS, g.off, g.adj, g.v1, g.s1, g.v2, g.s2,
+		KLAUNCH(k_slot_other, dim3(nblk(nS)), dim3(TPB), 0, s, (uint32_t)nS, g.off, g.adj, g.v1, g.s1, g.v2, g.s2,
 				   g.aoth);
-		hipLaunchKernelGGL(k_slot_twin, dim3(nblk(E)), dim3(TPB), 0, s, E, g.off, g.adj, g.v1, g.s1, g.v2, g.s2, g.atwin);
-		uint32_t *mx = tmp_arena.take<uint32_t>(4);
-		HIP_CHECK(hipMemsetAsync(mx, 0, 16, s));
-		hipLaunchKernelGGL(k_vertex_degree, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, deg);
-		hipLaunchKernelGGL(k_max_u32, dim3(std::min<unsigned>(nblk(V), 1024)), dim3(TPB), 0, s, V, deg, mx);
-		HIP_CHECK(hipMemcpyAsync(&g.max_vdeg, mx, 4, hipMemcpyDeviceToHost, s));
+		KLAUNCH(k_vertex_degree, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, deg);
+		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(V), 1024)), dim3(TPB), 0, s, V, deg, word);
+		HIP_CHECK(hipMemcpyAsync(&g.max_vdeg, word, 4, hipMemcpyDeviceToHost, s));
 	}
-	// links sorted by smaller endpoint + the list of links that cross a union-find tile
-	g.n_cross = 0;
-	if (E) {
-		hipLaunchKernelGGL(k_edge_min, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.v2, keys, vals);
-		sort_pairs_u32(keys, keys2, vals, g.eperm, E, bits_for(V), stmp, sb, s);
-		uint32_t *xflag = keys, *xps = vals; // reuse (2E+1 entries each)
-		hipLaunchKernelGGL(k_edge_sorted, dim3(nblk(E)), dim3(TPB), 0, s, E, g.eperm, g.v1, g.v2, g.e_lo, g.e_hi, xflag);
-		scan_exclusive_u32(xflag, xps, (size_t)E + 1, ctmp, cb, s);
-		hipLaunchKernelGGL(k_compact_pos, dim3(nblk(E)), dim3(TPB), 0, s, E, xflag, xps, g.xlist);
-		HIP_CHECK(hipMemcpyAsync(&g.n_cross, xps + E, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipEventRecord(ev[1], s));
+	if (V && E) { // reverse-slot table: where the same link sits in the list of its other end
+		KLAUNCH(k_slot_twin, dim3(nblk(E)), dim3(TPB), 0, s, E, g.off, g.adj, g.v1, g.s1, g.v2, g.s2, g.atwin);
 	}
+	HIP_CHECK(hipEventRecord(ev[2], s));
 	HIP_CHECK(hipStreamSynchronize(s));
+	HIP_CHECK(hipEventElapsedTime(&g.csr_ms, ev[0], ev[1]));
+	HIP_CHECK(hipEventElapsedTime(&g.twin_ms, ev[1], ev[2]));
 }
 
 uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
-	hipLaunchKernelGGL(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, E, g.e_lo, g.e_hi, g.eperm, st.label,
-			   st.hook);
-	if (g.n_cross)
-		hipLaunchKernelGGL(k_uf_cross, dim3(nblk(g.n_cross)), dim3(TPB), 0, s, g.n_cross, g.xlist, g.e_lo, g.e_hi, g.eperm,
+	// hook[E] doubles as the length of the cross list
+	HIP_CHECK(hipMemsetAsync(st.hook, 0, ((size_t)E + 1) * 4, s));
+	uint2 *xlist = reinterpret_cast<uint2 *>(st.keys); // [E] pairs fit the 2E+2 words; free until the re-index
+	KLAUNCH(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, g.off, g.aoth, g.adj, st.label,
+			   st.hook, st.hook + E, xlist);
+	if (E) {
+		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, st.hook + E, xlist, g.aoth, g.adj,
 				   st.label, st.hook);
-	hipLaunchKernelGGL(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
+	}
+	KLAUNCH(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
 	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
-	tm.end(4);
+	tm.end(6);
 	return st.host->read_u32(st.crank + V, s);
 }
 
@@ -671,7 +720,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	uint32_t launches = 0;
 	// stable sort of vertices by component rank: local vertex idx = rank inside the component,
 	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
-	hipLaunchKernelGGL(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a, C,
+	KLAUNCH(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a, C,
 			   (unsigned long long *)st.start_key);
 	if (C == 1) { // one component: the order is already (component, idx); the key / permutation arrays
 		      // simply alias what k_comp_of wrote (all-zero component ranks, identity permutation)
@@ -680,7 +729,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	} else {
 		sort_pairs_u32(st.comp_of, st.ckey, st.tmp_a, st.perm, V, bits_for(C), st.sort_tmp, st.sort_tmp_bytes, s);
 	}
-	hipLaunchKernelGGL(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
+	KLAUNCH(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
 			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats,
 			   C == 1 ? st.sbase : nullptr);
 	if (C != 1)
@@ -689,36 +738,36 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	// first-encounter rank of every edge
 	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
 		const uint32_t *pos_or_identity = C == 1 ? nullptr : st.pos; // one component: no vertex is renumbered
-		hipLaunchKernelGGL(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.aoth, st.sbase,
+		KLAUNCH(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.aoth, st.sbase,
 				   st.flag, st.ldeg, st.stats);
 		scan_exclusive_u32_pair(st.flag, st.erank, (size_t)g.n_slots + 1, st.ldeg, st.loff, nS + 1, st.scan_tmp,
 					st.scan_tmp_bytes, s);
-		hipLaunchKernelGGL(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin,
+		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin,
 				   st.sbase, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
-		hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
+		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
 				   st.eoff, st.stats, st.host_pub);
 		tm.end(launches + 7);
 		return;
 	}
 	fill_u32(st.first, E, POVU_NIL, s);
-	hipLaunchKernelGGL(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
+	KLAUNCH(k_first_slot, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first);
 	HIP_CHECK(hipMemsetAsync(st.flag, 0, ((size_t)g.n_slots + 1) * 4, s));
-	hipLaunchKernelGGL(k_mark_first, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first,
+	KLAUNCH(k_mark_first, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, g.off, g.adj, st.sbase, st.first,
 			   st.flag);
 	scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	HIP_CHECK(hipMemsetAsync(st.ldeg, 0, (nS + 1) * 4, s));
-	hipLaunchKernelGGL(k_local_edges, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, st.sbase,
+	KLAUNCH(k_local_edges, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, st.sbase,
 			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg, st.hook, st.la, st.lb,
 			   st.tgray);
 	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
-	hipLaunchKernelGGL(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
-	hipLaunchKernelGGL(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
+	KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
+	KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
 			   st.eoff, st.stats, st.host_pub);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	// local per-side adjacency (other side ids), ascending local edge idx
 	sort_pairs_u32(st.keys, st.keys2, st.vals, st.vals2, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);
 	if (E)
-		hipLaunchKernelGGL(k_local_slots, dim3(nblk(2 * (size_t)E)), dim3(TPB), 0, s, 2 * E, st.vals2, st.la, st.lb,
+		KLAUNCH(k_local_slots, dim3(nblk(2 * (size_t)E)), dim3(TPB), 0, s, 2 * E, st.vals2, st.la, st.lb,
 				   st.ladj, st.lle);
 	launches += 10;
 	tm.end(launches);

@@ -20,10 +20,8 @@ struct ResidentGraph {
 						    //           link; a self loop points back into its own vertex
 	uint32_t *atwin = nullptr;		    // [n_slots] the slot of the same link at its other end (itself for a same-side self loop)
 	uint32_t max_vdeg = 0;			    // most links on one vertex (both sides)
-	// links sorted by their smaller endpoint (built at upload): tile-local union-find input
-	uint32_t *eperm = nullptr, *e_lo = nullptr, *e_hi = nullptr; // [E] link idx, min / max endpoint
-	uint32_t *xlist = nullptr;		    // [n_cross] sorted positions of links that leave their tile
-	uint32_t n_cross = 0;
+	// device time of the last upload, by HIP events: host-to-device copies, CSR build, reverse-slot table
+	float h2d_ms = 0, csr_ms = 0, twin_ms = 0;
 	void *block = nullptr;			    // one allocation backing all of the above
 };
 
@@ -49,6 +47,8 @@ struct CompState {
 };
 
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s);
+// Builds off / adj / aoth / atwin / tip from the link arrays already in g (device memory).  Throws when a link names
+// an unknown vertex or side (validated on the device).
 void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);
 uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,

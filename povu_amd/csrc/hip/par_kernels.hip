@@ -28,8 +28,10 @@ static constexpr int TPB = 256;
 static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 #define LAUNCH(k, n, s, ...)                                                                     \
 	do {                                                                                     \
-		if ((n) > 0)                                                                     \
+		if ((n) > 0) {                                                                   \
 			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
+			HIP_CHECK(hipGetLastError());                                            \
+		}                                                                                \
 	} while (0)
 
 // ------------------------------------------------------------- T-space setup

@@ -186,59 +186,68 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	delete ctx;
 }
 
+// device block of a resident graph: the link arrays + CSR (off / adj / aoth / atwin)
+static void alloc_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given)
+{
+	g.V = n_vtx;
+	g.E = n_links;
+	g.tips_given = tips_given;
+	const size_t V = n_vtx, E = n_links;
+	size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
+		       Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 2, 4) + 4096;
+	if (hipMalloc(&g.block, bytes) != hipSuccess) {
+		(void)hipGetLastError();
+		g.block = nullptr;
+		throw HipError("not enough device memory for the resident graph (" + std::to_string(bytes >> 20) + " MiB)");
+	}
+	char *p = static_cast<char *>(g.block);
+	auto carve = [&](size_t n, size_t elem) {
+		void *r = p;
+		p += Arena::padded(n, elem);
+		return r;
+	};
+	g.vid = (uint32_t *)carve(V, 4);
+	g.v1 = (uint32_t *)carve(E + 1, 4);
+	g.v2 = (uint32_t *)carve(E + 1, 4);
+	g.s1 = (uint8_t *)carve(E + 1, 1);
+	g.s2 = (uint8_t *)carve(E + 1, 1);
+	g.tip = (uint8_t *)carve(V, 1);
+	g.off = (uint32_t *)carve(2 * V + 2, 4);
+	g.adj = (uint32_t *)carve(2 * E + 2, 4);
+	g.aoth = (uint32_t *)carve(2 * E + 2, 4);
+	g.atwin = (uint32_t *)carve(2 * E + 2, 4);
+}
+
+static void check_graph_size(uint32_t n_vtx, uint32_t n_links)
+{
+	if (n_vtx == 0)
+		throw HipError("graph has no vertices");
+	// 32-bit index spaces: 4 arcs / events per segment must stay below 2^29 (packed list-ranking
+	// words), links below 2^31.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
+	if (n_vtx >= (1u << 27) || n_links > 0x7FFFFFF0u)
+		throw HipError("graph too large for this build: at most 134 217 727 segments and 2 147 483 632 links");
+}
+
 extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links,
 				     const uint32_t *v1, const uint8_t *s1, const uint32_t *v2, const uint8_t *s2,
 				     const uint8_t *tips, char *err, size_t errlen)
 {
+	ResidentGraph g; // built on the side: the context keeps its old graph unless everything succeeds
 	try {
 		if (!ctx)
 			throw HipError("null context");
-		if (n_vtx == 0)
-			throw HipError("graph has no vertices");
-		// 32-bit index spaces: 4 arcs / events per segment must stay below 2^29 (packed list-ranking
-		// words), links below 2^31.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
-		if (n_vtx >= (1u << 27) || n_links > 0x7FFFFFF0u)
-			throw HipError("graph too large for this build: at most 134 217 727 segments and 2 147 483 632 links");
-		// operand validation on the host: the kernels index by these values unchecked
-		for (uint32_t e = 0; e < n_links; e++)
-			if (v1[e] >= n_vtx || v2[e] >= n_vtx || s1[e] > 1 || s2[e] > 1)
-				throw HipError("link " + std::to_string(e) + " references an unknown vertex or side");
-		if (tips)
-			for (uint32_t v = 0; v < n_vtx; v++)
-				if (tips[v] > 2)
-					throw HipError("bad tip mark");
+		check_graph_size(n_vtx, n_links);
 		HIP_CHECK(hipSetDevice(ctx->device));
+		// the old graph goes first: two whole-genome graphs do not fit side by side
 		free_graph(ctx->g);
 		ctx->have_state = false;
-		ResidentGraph &g = ctx->g;
-		g.V = n_vtx;
-		g.E = n_links;
-		g.tips_given = tips != nullptr;
+		alloc_graph(g, n_vtx, n_links, tips != nullptr);
 		const size_t V = n_vtx, E = n_links;
-		size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
-			       Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 2, 4) + 4 * Arena::padded(E + 1, 4) + 4096;
-		HIP_CHECK(hipMalloc(&g.block, bytes));
-		char *p = static_cast<char *>(g.block);
-		auto carve = [&](size_t n, size_t elem) {
-			void *r = p;
-			p += Arena::padded(n, elem);
-			return r;
-		};
-		g.vid = (uint32_t *)carve(V, 4);
-		g.v1 = (uint32_t *)carve(E + 1, 4);
-		g.v2 = (uint32_t *)carve(E + 1, 4);
-		g.s1 = (uint8_t *)carve(E + 1, 1);
-		g.s2 = (uint8_t *)carve(E + 1, 1);
-		g.tip = (uint8_t *)carve(V, 1);
-		g.off = (uint32_t *)carve(2 * V + 2, 4);
-		g.adj = (uint32_t *)carve(2 * E + 2, 4);
-		g.aoth = (uint32_t *)carve(2 * E + 2, 4);
-		g.atwin = (uint32_t *)carve(2 * E + 2, 4);
-		g.eperm = (uint32_t *)carve(E + 1, 4);
-		g.e_lo = (uint32_t *)carve(E + 1, 4);
-		g.e_hi = (uint32_t *)carve(E + 1, 4);
-		g.xlist = (uint32_t *)carve(E + 1, 4);
 		hipStream_t s = ctx->stream;
+		hipEvent_t e0, e1;
+		HIP_CHECK(hipEventCreate(&e0));
+		HIP_CHECK(hipEventCreate(&e1));
+		HIP_CHECK(hipEventRecord(e0, s));
 		HIP_CHECK(hipMemcpyAsync(g.vid, vid, V * 4, hipMemcpyHostToDevice, s));
 		if (E) {
 			HIP_CHECK(hipMemcpyAsync(g.v1, v1, E * 4, hipMemcpyHostToDevice, s));
@@ -248,13 +257,32 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		}
 		if (tips)
 			HIP_CHECK(hipMemcpyAsync(g.tip, tips, V, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipEventRecord(e1, s));
 		HIP_CHECK(hipStreamSynchronize(s));
-		build_global_csr(g, ctx->upload_tmp, s);
+		(void)hipEventElapsedTime(&g.h2d_ms, e0, e1);
+		(void)hipEventDestroy(e0);
+		(void)hipEventDestroy(e1);
+		build_global_csr(g, ctx->upload_tmp, s); // validates the operands on the device
+		ctx->g = g;
 		return 0;
 	} catch (const std::exception &e) {
+		if (ctx) {
+			(void)hipStreamSynchronize(ctx->stream);
+			free_graph(g);
+		}
 		set_err(err, errlen, e.what());
 		return 1;
 	}
+}
+
+extern "C" int povu_hip_last_upload_times(const povu_hip_ctx *ctx, double out_ms[3])
+{
+	if (!ctx || !out_ms || !ctx->g.block)
+		return 1;
+	out_ms[0] = ctx->g.h2d_ms;
+	out_ms[1] = ctx->g.csr_ms;
+	out_ms[2] = ctx->g.twin_ms;
+	return 0;
 }
 
 namespace
@@ -490,6 +518,9 @@ extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links
 
 extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip_opts *opts, char *err, size_t errlen)
 {
+	// declared outside the try block: on a failure the stream is drained BEFORE the forest returns its pinned
+	// result block to the pool (kernels that write into it may still be queued)
+	std::unique_ptr<povu_hip_forest> f;
 	try {
 		if (!ctx || !ctx->g.block)
 			throw HipError("no graph resident: call povu_hip_graph_upload first");
@@ -627,7 +658,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		};
 		// the result block is allocated as soon as the number of PVST vertices is known (before the emit kernel):
 		// the parallel stages write it straight into pinned host memory, there is no device-to-host copy
-		auto f = std::make_unique<povu_hip_forest>();
+		f = std::make_unique<povu_hip_forest>();
 		f->pool = ctx->pool;
 		auto alloc_result_block = [&](size_t total) -> void * {
 			f->release_block();
@@ -833,6 +864,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		ctx->have_state = true;
 		return f.release();
 	} catch (const std::exception &e) {
+		if (ctx && ctx->stream)
+			(void)hipStreamSynchronize(ctx->stream);
+		f.reset();
 		set_err(err, errlen, e.what());
 		return nullptr;
 	}

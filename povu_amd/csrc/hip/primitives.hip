@@ -153,8 +153,8 @@ static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tm
 		throw HipError("scan: temporary storage too small");
 	ScanJobs jobs{};
 	jobs.j[0] = make_scan_job(in, out, n, static_cast<uint32_t *>(tmp));
-	hipLaunchKernelGGL(k_scan_partials<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
-	hipLaunchKernelGGL(k_scan_chunks<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_partials<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_chunks<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 }
 
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
@@ -176,8 +176,8 @@ void scan_exclusive_u32_pair(const uint32_t *in0, uint32_t *out0, size_t n0, con
 	jobs.j[0] = make_scan_job(in0, out0, n0, static_cast<uint32_t *>(tmp));
 	jobs.j[1] = make_scan_job(in1, out1, n1, static_cast<uint32_t *>(tmp) + SC_MAX_BLOCKS);
 	const unsigned gx = std::max(jobs.j[0].blocks, jobs.j[1].blocks);
-	hipLaunchKernelGGL(k_scan_partials<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
-	hipLaunchKernelGGL(k_scan_chunks<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_partials<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_chunks<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
 }
 
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)

@@ -65,9 +65,9 @@ static void seg_build(SegTree &st, const uint32_t *val, size_t n, hipStream_t s)
 	st.P = SegTree::pow2(std::max<size_t>(n, 1));
 	const uint32_t W = 2 * SEG_TPB;
 	const uint32_t blocks = (st.P + W - 1) / W;
-	hipLaunchKernelGGL(k_seg_bottom, dim3(blocks), dim3(SEG_TPB), 0, s, st.P, (uint32_t)n, val, st.tree);
+	KLAUNCH(k_seg_bottom, dim3(blocks), dim3(SEG_TPB), 0, s, st.P, (uint32_t)n, val, st.tree);
 	if (st.P > W) // levels above the per-block subtrees: nodes [1, P/W)
-		hipLaunchKernelGGL(k_seg_top, dim3(1), dim3(1024), 0, s, st.P / W, st.tree);
+		KLAUNCH(k_seg_top, dim3(1), dim3(1024), 0, s, st.P / W, st.tree);
 }
 
 __device__ __forceinline__ uint32_t seg_min(const uint32_t *__restrict__ tree, uint32_t P, uint32_t l, uint32_t r)

@@ -533,7 +533,7 @@ __global__ void k_zero_counters(uint32_t n, uint32_t *a, uint32_t *b, uint32_t *
 
 void zero_component_counters(const SeqWs &ws, uint32_t C, uint32_t *comp_bad, uint32_t *err, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_zero_counters, dim3((C + 256) / 256), dim3(256), 0, s, C + 1, ws.c_ntree, ws.c_nbe0, ws.c_nbe,
+	KLAUNCH(k_zero_counters, dim3((C + 256) / 256), dim3(256), 0, s, C + 1, ws.c_ntree, ws.c_nbe0, ws.c_nbe,
 			   ws.c_nstack, ws.c_npvst, ws.c_nclass, ws.c_nbry, ws.c_status, comp_bad, err);
 }
 
@@ -542,7 +542,7 @@ void launch_seq_components(const SeqWs &ws, hipStream_t s)
 	if (ws.C == 0)
 		return;
 	unsigned grid = (unsigned)std::min<uint64_t>(ws.C, 2048);
-	hipLaunchKernelGGL(k_seq_components, dim3(grid), dim3(64), 0, s, ws);
+	KLAUNCH(k_seq_components, dim3(grid), dim3(64), 0, s, ws);
 }
 
 } // namespace povu_hip

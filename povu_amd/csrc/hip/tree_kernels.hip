@@ -32,26 +32,32 @@ static constexpr int TPB = 256;
 static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 #define LAUNCH(k, n, s, ...)                                                                     \
 	do {                                                                                     \
-		if ((n) > 0)                                                                     \
+		if ((n) > 0) {                                                                   \
 			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
+			HIP_CHECK(hipGetLastError());                                            \
+		}                                                                                \
 	} while (0)
 
-// list-ranking splitters (section "work-efficient list ranking" below): 1 element in 8, by a multiplicative hash
-// density: element i is a random splitter iff the top (32 - shift) bits of its hash are zero -- shift 29 = 1 in 8
-// (short lists: the walks are bound by their longest sub-list), shift 28 = 1 in 16 (long lists: the walks are
-// throughput-bound either way and the pointer jumping on the splitter list halves).
-static uint32_t rank_split_shift(size_t n) { return n < (size_t(1) << 26) ? 29u : 28u; }
-static constexpr uint32_t PK_END = 0x1FFFFFFFu;
-__device__ __forceinline__ bool is_random_splitter(uint32_t i, uint32_t shift) { return ((i * 0x9E3779B1u) >> shift) == 0; }
+// ---- list-ranking words and splitters (section "work-efficient list ranking" below).
+// Splitters cut every list into short segments.  The index space of a list level is cut into buckets of 2^b
+// consecutive elements and every bucket names exactly ONE of its elements as a splitter, pseudo-randomly
+// (multiplicative hash of the bucket idx).  So the splitter of bucket q is computed, not looked up; a splitter's id on
+// the next level IS its bucket idx (dense, no flag array, no scan, no compaction), and lane q of a walk kernel works
+// near element q * 2^b (the scattered rank stores of neighbouring lanes meet again in L2).
+// b = 3 (1 in 8) for short lists, whose walks are bound by their longest segment; b = 4 for lists of 2^26+ elements.
+static unsigned rank_bucket_bits(size_t n) { return n < (size_t(1) << 26) ? 3u : 4u; }
+static constexpr uint32_t PK_END = 0x1FFFFFFFu, PK_HEAD = 0x40000000u, PK_STOP = 0x80000000u;
+__device__ __forceinline__ uint32_t bucket_splitter(uint32_t q, unsigned b) { return (q << b) | ((q * 0x9E3779B1u) >> (32u - b)); }
+__device__ __forceinline__ bool is_splitter(uint32_t i, unsigned b) { return bucket_splitter(i >> b, b) == i; }
 // One word per list element, so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
-// bit 29 = the element's 0/1 weight, bit 31 = stop after this element (the successor is a splitter, or there is
-// none).  A list head never is anybody's successor, so the successor's splitter flag is its hash alone.
-__device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, uint32_t shift)
+// bit 29 = the element's 0/1 weight, bit 30 = the element heads a list (nobody's successor; set by the kernels that
+// know the heads), bit 31 = stop after this element (the successor is a splitter, or there is none).
+__device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, unsigned b)
 {
 	uint32_t p = nx == NIL ? PK_END : nx;
 	p |= (w & 1u) << 29;
-	if (nx == NIL || is_random_splitter(nx, shift))
-		p |= 0x80000000u;
+	if (nx == NIL || is_splitter(nx, b))
+		p |= PK_STOP;
 	return p;
 }
 
@@ -108,18 +114,16 @@ __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t 
 	}
 }
 // Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
-// (side w's arcs sit at [aoff[w], aoff[w+1])); also draws the random splitters of the tour ranking
+// (side w's arcs sit at [aoff[w], aoff[w+1]))
 __global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
-			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk,
-			   uint32_t *__restrict__ flag, uint32_t shift)
+			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk, unsigned b)
 {
 	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
 	if (a >= NA)
 		return;
 	uint32_t t = a ^ 1, w = arc_src[t], q = apos[t];
 	uint32_t qn = (q + 1 == aoff[w + 1]) ? aoff[w] : q + 1;
-	pk[a] = rank_pack(sarc[qn], 1u, shift); // every arc counts 1 (k_tour_ends fixes the closing arc)
-	flag[a] = is_random_splitter(a, shift) ? 1u : 0u;
+	pk[a] = rank_pack(sarc[qn], 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -127,19 +131,21 @@ __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *sta
 	unsigned long long k = start_key[c];
 	return k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
 }
-// per component: cut its tour open behind the arc that returns to the root for the last time, and make the
-// first arc out of the root a (forced) splitter -- the head of the component's list
+// per component: cut its tour open behind the arc that returns to the root for the last time; the first arc out of
+// the root heads the component's list
 __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
 			    const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk,
-			    uint32_t *__restrict__ flag)
+			    uint32_t *__restrict__ heads)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= C)
 		return;
 	uint32_t r = comp_root_side(start_key, voff, c);
-	uint32_t a_end = sarc[aoff[r + 1] - 1] ^ 1;
-	pk[a_end] = rank_pack(NIL, 0u, 29u); // no successor, weight 0
-	flag[sarc[aoff[r]]] = 1;
+	uint32_t a_end = sarc[aoff[r + 1] - 1] ^ 1, a_first = sarc[aoff[r]];
+	pk[a_end] = PK_END | PK_STOP | (a_end == a_first ? PK_HEAD : 0u); // no successor, weight 0
+	if (a_end != a_first)
+		atomicOr(&pk[a_first], PK_HEAD); // (k_arc_succ wrote the word in an earlier launch)
+	heads[c] = a_first;
 }
 // one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
 // HOPS = 3 covers two rounds (every pointer then spans 4x as far), HOPS = 7 three rounds (8x).  More
@@ -187,104 +193,245 @@ static int list_rank(uint32_t n, unsigned bits, uint32_t *nxtA, uint32_t *nxtB, 
 	return cur;
 }
 
-// ---- work-efficient list ranking: random splitters cut every list into short segments, each
-// splitter walks its segment (sums), the splitter list is ranked by pointer jumping, a second walk
-// hands every element its suffix sum.  Heads (elements nobody points to) are forced splitters.
-// (SPLIT_SHIFT / PK_END / is_random_splitter are defined at the top of the file.)
-// TWO: second weight = +1 where the first is 1, -1 where it is 0 (enter / leave events)
-// splitter idx -> element, so that the walks run one lane per SPLITTER (full waves) instead of one lane per
-// element with 1 in 8 active: at scale the walks are bound by how many dependent loads are in flight
-__global__ void k_rank_compact(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps, uint32_t m_cap,
-			       uint32_t *__restrict__ splist, uint32_t *__restrict__ err)
+// ---- work-efficient list ranking, recursive.  Level 0 is the list itself (packed words, 0/1 weights).  One lane per
+// splitter (= per bucket, plus one per list head) walks its segment and leaves {next splitter, segment sums} -- the
+// element of the next level, whose index is the bucket idx.  Levels shrink by 2^b until one workgroup ranks the top in
+// LDS (pointer jumping); then every level hands its elements their suffix sums on the way back down.  A list of n
+// elements costs about n(1 + 2^-b + ...) dependent loads up and the same down.
+// Heads: an element that heads a list is never reached through its bucket (its lane stays idle); head h of the caller's
+// head array is element m + h of every level above 0 (m = buckets of the level below) and is walked by its own lane.
+// TWO: second weight = +1 where the first is 1, -1 where it is 0 (enter / leave events).
+static constexpr uint32_t RANK_TOP = 8192; // elements one workgroup ranks in LDS
+struct RankLevelArgs {
+	uint32_t n;	// elements of this level
+	uint32_t m;	// buckets of this level = hash lanes of the walk
+	uint32_t hbase; // first head element of this level (level 0: unused, heads come from the array)
+	uint32_t M;	// lanes of the walk = elements of the next level = m + heads
+};
+// start element of lane `id`, NIL when the lane has nothing to walk
+template <bool L0>
+__device__ __forceinline__ uint32_t rank_lane_start(uint32_t id, const RankLevelArgs &A, unsigned b, const uint32_t *__restrict__ pk0,
+						    const uint32_t *__restrict__ heads)
+{
+	if (id < A.m) {
+		const uint32_t x = bucket_splitter(id, b);
+		if (x >= A.n)
+			return NIL;
+		if (L0)
+			return (pk0[x] & PK_HEAD) ? NIL : x;
+		return x >= A.hbase ? NIL : x;
+	}
+	return L0 ? heads[id - A.m] : A.hbase + (id - A.m);
+}
+template <bool L0, bool TWO>
+__global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restrict__ nx_in, const uint32_t *__restrict__ a_in,
+			  const uint32_t *__restrict__ b_in, const uint32_t *__restrict__ heads, uint32_t *__restrict__ nx_out,
+			  uint32_t *__restrict__ a_out, uint32_t *__restrict__ b_out)
+{
+	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= A.M)
+		return;
+	uint32_t x = rank_lane_start<L0>(id, A, b, nx_in, heads);
+	uint32_t sa = 0, sb = 0, out = PK_END | PK_STOP;
+	if (x != NIL) {
+		uint32_t p;
+		do {
+			p = nx_in[x];
+			if (L0) {
+				const uint32_t w = (p >> 29) & 1u;
+				sa += w;
+				if (TWO)
+					sb += w ? 1u : 0xFFFFFFFFu;
+			} else {
+				sa += a_in[x];
+				if (TWO)
+					sb += b_in[x];
+			}
+			x = p & PK_END;
+		} while (!(p & PK_STOP));
+		if (x != PK_END) { // the successor is the splitter of its bucket: that bucket is its idx one level up
+			const uint32_t q = x >> b;
+			out = q | (is_splitter(q, b) ? PK_STOP : 0u);
+		}
+	}
+	nx_out[id] = out;
+	a_out[id] = sa;
+	if (TWO)
+		b_out[id] = sb;
+}
+// the way back: lane `id` knows the suffix sums at its splitter (ra / rb of the level above) and hands every element of
+// its segment its own.  Level 0 writes the caller's arrays, the levels above overwrite their weights in place.
+template <bool L0, bool TWO>
+__global__ void k_rank_down(RankLevelArgs A, unsigned b, const uint32_t *__restrict__ nx_in, uint32_t *a_io, uint32_t *b_io,
+			    const uint32_t *__restrict__ heads, const uint32_t *__restrict__ ra, const uint32_t *__restrict__ rb,
+			    uint32_t *__restrict__ out1, uint2 *__restrict__ out12)
+{
+	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= A.M)
+		return;
+	uint32_t x = rank_lane_start<L0>(id, A, b, nx_in, heads);
+	if (x == NIL)
+		return;
+	uint32_t sa = ra[id], sb = TWO ? rb[id] : 0, p;
+	do {
+		p = nx_in[x];
+		if (L0) {
+			const uint32_t w = (p >> 29) & 1u;
+			if (TWO) { // both sums in one 8-byte store
+				out12[x] = make_uint2(sa, sb);
+				sb -= w ? 1u : 0xFFFFFFFFu;
+			} else {
+				out1[x] = sa;
+			}
+			sa -= w;
+		} else {
+			const uint32_t wa = a_io[x];
+			a_io[x] = sa;
+			sa -= wa;
+			if (TWO) {
+				const uint32_t wb = b_io[x];
+				b_io[x] = sb;
+				sb -= wb;
+			}
+		}
+		x = p & PK_END;
+	} while (!(p & PK_STOP));
+}
+// top level: inclusive suffix sums of at most RANK_TOP elements by pointer jumping in LDS, one workgroup
+template <bool TWO>
+__global__ void __launch_bounds__(1024) k_rank_top(uint32_t n, const uint32_t *__restrict__ nx_in, uint32_t *a_io, uint32_t *b_io)
+{
+	__shared__ uint32_t nx[RANK_TOP], sa[RANK_TOP], sb[TWO ? RANK_TOP : 1];
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+		const uint32_t p = nx_in[i] & PK_END;
+		nx[i] = p == PK_END ? NIL : p;
+		sa[i] = a_io[i];
+		if (TWO)
+			sb[i] = b_io[i];
+	}
+	__syncthreads();
+	constexpr int PER = RANK_TOP / 1024;
+	for (uint32_t span = 1; span < n; span <<= 1) {
+		uint32_t tn[PER], ta[PER], tb[PER];
+#pragma unroll
+		for (int k = 0; k < PER; k++) {
+			const uint32_t i = threadIdx.x + k * 1024;
+			tn[k] = NIL, ta[k] = 0, tb[k] = 0;
+			if (i < n && nx[i] != NIL) {
+				const uint32_t j = nx[i];
+				tn[k] = nx[j];
+				ta[k] = sa[j];
+				if (TWO)
+					tb[k] = sb[j];
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < PER; k++) {
+			const uint32_t i = threadIdx.x + k * 1024;
+			if (i < n && nx[i] != NIL) {
+				nx[i] = tn[k];
+				sa[i] += ta[k];
+				if (TWO)
+					sb[i] += tb[k];
+			}
+		}
+		__syncthreads();
+	}
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+		a_io[i] = sa[i];
+		if (TWO)
+			b_io[i] = sb[i];
+	}
+}
+// (top level too large for one workgroup -- graphs with very many tiny components: the old pointer jumping in global memory)
+__global__ void k_rank_unpack_next(uint32_t n, const uint32_t *__restrict__ nx_in, uint32_t *__restrict__ out)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n || !flag[i])
-		return;
-	const uint32_t sid = ps[i];
-	if (sid >= m_cap) {
-		atomicAdd(err, 1u);
-		return;
-	}
-	splist[sid] = i;
-}
-template <bool TWO>
-__global__ void k_rank_walk1(uint32_t m_cap, const uint32_t *__restrict__ m_dev, const uint32_t *__restrict__ pk,
-			     const uint32_t *__restrict__ splist, const uint32_t *__restrict__ ps, uint32_t *__restrict__ sp_next,
-			     uint32_t *__restrict__ sp_a, uint32_t *__restrict__ sp_b)
-{
-	uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x;
-	if (sid >= m_cap || sid >= *m_dev)
-		return;
-	uint32_t a = 0, b = 0, x = splist[sid], p;
-	do {
-		p = pk[x];
-		uint32_t w = (p >> 29) & 1u;
-		a += w;
-		if (TWO)
-			b += w ? 1u : 0xFFFFFFFFu;
-		x = p & PK_END;
-	} while (!(p >> 31));
-	uint32_t nx = x == PK_END ? NIL : ps[x];
-	sp_next[sid] = (nx != NIL && nx >= m_cap) ? NIL : nx;
-	sp_a[sid] = a;
-	if (TWO)
-		sp_b[sid] = b;
-}
-template <bool TWO>
-__global__ void k_rank_walk2(uint32_t m_cap, const uint32_t *__restrict__ m_dev, const uint32_t *__restrict__ pk,
-			     const uint32_t *__restrict__ splist, const uint32_t *__restrict__ sp_a,
-			     const uint32_t *__restrict__ sp_b, uint32_t *__restrict__ out1, uint2 *__restrict__ out12)
-{
-	// grid-stride over the splitters (they are in index order): the lanes in flight then work on one window of
-	// the element arrays at a time, so the scattered 4/8-byte rank stores meet again in L2 instead of each
-	// costing a partial line in HBM
-	const uint32_t m = min(m_cap, *m_dev);
-	for (uint32_t sid = blockIdx.x * blockDim.x + threadIdx.x; sid < m; sid += gridDim.x * blockDim.x) {
-		uint32_t a = sp_a[sid], b = TWO ? sp_b[sid] : 0, x = splist[sid], p;
-		do {
-			p = pk[x];
-			uint32_t w = (p >> 29) & 1u;
-			if (TWO) { // both sums in one 8-byte store
-				out12[x] = make_uint2(a, b);
-				b -= w ? 1u : 0xFFFFFFFFu;
-			} else {
-				out1[x] = a;
-			}
-			a -= w;
-			x = p & PK_END;
-		} while (!(p >> 31));
+	if (i < n) {
+		const uint32_t p = nx_in[i] & PK_END;
+		out[i] = p == PK_END ? NIL : p;
 	}
 }
 
-static constexpr unsigned WALK2_BLOCKS = 512; // x 256 lanes in flight (see k_rank_walk2)
 struct RankBufs {
-	uint32_t *pk, *flag, *ps;		       // [n+1] packed list words (rank_pack), splitter flags, their scan
-	uint32_t *nA, *nB, *aA, *aB, *bA, *bB;	       // [m_cap] splitter list ping-pong
-	uint32_t *splist;			       // [m_cap] element of every splitter
-	uint32_t *err;
-	void *scan_tmp;
-	size_t scan_tmp_bytes;
+	uint32_t *pk;			 // [n+1] packed list words of level 0 (rank_pack)
+	uint32_t *heads;		 // [max heads] level-0 element that heads list h, NIL for none
+	uint32_t *nx, *wa, *wb;		 // pools for the levels above 0 (next words, sums), rank_pool_words() each
+	uint32_t *tA, *tB, *tC;		 // three more pools: ping-pong of the global-memory fallback of the top level
 };
+static constexpr int RANK_MAX_LEVELS = 12;
+// words every pool needs for lists of n elements in total with nh heads: the first level above the list has
+// M = n / 2^b + nh elements (b >= 3), the following ones at least halve until the last, which may be as large as
+// the one before it again -- < 3.2 M in all
+static size_t rank_pool_words(size_t n, size_t nh) { return n / 2 + 4 * nh + 64; }
+
 // suffix sums (inclusive) along the lists packed in rb.pk: out1 of the 0/1 weights or, when TWO, out12 = {that sum,
 // the sum of the +-1 weights derived from them}
 template <bool TWO>
-static void list_rank_splitters(uint32_t n, uint32_t shift, uint32_t *out1, uint2 *out12, uint32_t max_heads, RankBufs &rb,
-				hipStream_t s)
+static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *out12, uint32_t nh, RankBufs &rb, hipStream_t s)
 {
 	if (n >= PK_END)
 		throw HipError("list ranking: more than 2^29 elements (graph too large for the packed walk)");
-	const uint32_t m_cap = 2 * (n >> (32 - shift)) + max_heads + 4096; // twice the expected random splitters + the heads
-	// rb.flag[0..n) was filled by the caller (random splitters + list heads)
-	scan_exclusive_u32(rb.flag, rb.ps, (size_t)n + 1, rb.scan_tmp, rb.scan_tmp_bytes, s);
-	const uint32_t *pk = rb.pk, *m_dev = rb.ps + n; // number of splitters, on the device
-	LAUNCH(k_rank_compact, n, s, n, rb.flag, rb.ps, m_cap, rb.splist, rb.err);
-	LAUNCH(k_rank_walk1<TWO>, m_cap, s, m_cap, m_dev, pk, rb.splist, rb.ps, rb.nA, rb.aA, rb.bA);
-	const unsigned rounds = bits_for(m_cap) + 1;
-	int side = list_rank(m_cap, rounds, rb.nA, rb.nB, rb.aA, rb.aB, TWO ? rb.bA : nullptr, TWO ? rb.bB : nullptr, s, m_dev);
-	{
-		const unsigned blocks = std::min<unsigned>(nblk(m_cap), WALK2_BLOCKS);
-		hipLaunchKernelGGL(k_rank_walk2<TWO>, dim3(blocks), dim3(TPB), 0, s, m_cap, m_dev, pk, rb.splist, side ? rb.aB : rb.aA,
-				   side ? rb.bB : rb.bA, out1, out12);
+	// plan: level L has lv[L].n elements; its walk has lv[L].M lanes = the elements of level L + 1
+	RankLevelArgs lv[RANK_MAX_LEVELS];
+	uint32_t *nxp[RANK_MAX_LEVELS + 1], *wap[RANK_MAX_LEVELS + 1], *wbp[RANK_MAX_LEVELS + 1];
+	int levels = 0;
+	size_t used = 0;
+	const size_t pool = rank_pool_words(n, nh);
+	nxp[0] = rb.pk, wap[0] = wbp[0] = nullptr;
+	uint32_t cur_n = n, hbase = 0;
+	for (;;) {
+		RankLevelArgs &A = lv[levels];
+		A.n = cur_n;
+		A.m = (cur_n + (1u << b) - 1) >> b;
+		A.hbase = hbase;
+		A.M = A.m + nh;
+		if (used + A.M > pool)
+			throw HipError("list ranking: level pool exhausted (internal sizing bug)");
+		nxp[levels + 1] = rb.nx + used, wap[levels + 1] = rb.wa + used, wbp[levels + 1] = rb.wb + used;
+		used += A.M;
+		levels++;
+		hbase = A.m;
+		const uint32_t next_n = A.M;
+		// stop when one workgroup can finish, or when the heads keep the levels from shrinking
+		if (next_n <= RANK_TOP || next_n > cur_n / 2 || levels == RANK_MAX_LEVELS) {
+			cur_n = next_n;
+			break;
+		}
+		cur_n = next_n;
+	}
+	for (int L = 0; L < levels; L++) {
+		const RankLevelArgs &A = lv[L];
+		if (L == 0)
+			LAUNCH((k_rank_up<true, TWO>), A.M, s, A, b, nxp[0], nullptr, nullptr, rb.heads, nxp[1], wap[1], wbp[1]);
+		else
+			LAUNCH((k_rank_up<false, TWO>), A.M, s, A, b, nxp[L], wap[L], wbp[L], nullptr, nxp[L + 1], wap[L + 1], wbp[L + 1]);
+	}
+	const uint32_t nt = cur_n; // elements of the top level
+	if (nt <= RANK_TOP) {
+		KLAUNCH((k_rank_top<TWO>), dim3(1), dim3(1024), 0, s, nt, nxp[levels], wap[levels], wbp[levels]);
+	} else {
+		LAUNCH(k_rank_unpack_next, nt, s, nt, nxp[levels], rb.tA);
+		HIP_CHECK(hipMemcpyAsync(rb.tB, wap[levels], (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+		if (TWO)
+			HIP_CHECK(hipMemcpyAsync(rb.tC, wbp[levels], (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+		// ping-pong partners: the level's own arrays (their contents were just copied out)
+		uint32_t *nA = rb.tA, *nB = nxp[levels], *aA = rb.tB, *aB = wap[levels], *bA = rb.tC, *bB = wbp[levels];
+		const int side = list_rank(nt, bits_for(nt) + 1, nA, nB, aA, aB, TWO ? bA : nullptr, TWO ? bB : nullptr, s);
+		if (side == 0) { // result in the A set: bring it home
+			HIP_CHECK(hipMemcpyAsync(wap[levels], aA, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+			if (TWO)
+				HIP_CHECK(hipMemcpyAsync(wbp[levels], bA, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+		}
+	}
+	for (int L = levels - 1; L >= 0; L--) {
+		const RankLevelArgs &A = lv[L];
+		if (L == 0)
+			LAUNCH((k_rank_down<true, TWO>), A.M, s, A, b, nxp[0], nullptr, nullptr, rb.heads, wap[1], wbp[1], out1, out12);
+		else
+			LAUNCH((k_rank_down<false, TWO>), A.M, s, A, b, nxp[L], wap[L], wbp[L], nullptr, wap[L + 1], wbp[L + 1], nullptr,
+			       nullptr);
 	}
 }
 
@@ -638,20 +785,26 @@ __global__ void k_child_link(uint32_t nS, const uint32_t *__restrict__ loff, con
 	if (dpar[P] == NIL)
 		nsib[P] = NIL; // roots (and sides of unprocessed components) have no siblings
 }
-// events: 2S = enter S, 2S+1 = leave S
+// events: 2S = enter S, 2S+1 = leave S.  "enter S" heads the list of its component iff S is the DFS start of a
+// processed component (sides of other components keep their two-event lists, which nobody reads)
 __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
-			 const uint32_t *__restrict__ nsib, uint32_t *__restrict__ pk, uint32_t *__restrict__ flag, uint32_t shift)
+			 const uint32_t *__restrict__ nsib, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc,
+			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	uint32_t c = fc[S];
-	pk[2 * S] = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u, shift); // enter: counts 1, depth +1
-	uint32_t ns = nsib[S], p = dpar[S];
-	// splitters of the event ranking: the random ones, and "enter S" heads a list iff S has no DFS parent
-	flag[2 * S] = (is_random_splitter(2 * S, shift) || p == NIL) ? 1u : 0u;
-	flag[2 * S + 1] = is_random_splitter(2 * S + 1, shift) ? 1u : 0u;
-	pk[2 * S + 1] = rank_pack(ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL), 0u, shift); // leave: counts 0, depth -1
+	const uint32_t c = fc[S], ns = nsib[S], p = dpar[S];
+	uint32_t enter = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u, b); // enter: counts 1, depth +1
+	if (p == NIL) {
+		const uint32_t comp = ckey[S >> 1];
+		if (cproc[comp]) {
+			enter |= PK_HEAD;
+			heads[comp] = 2 * S;
+		}
+	}
+	pk[2 * S] = enter;
+	pk[2 * S + 1] = rank_pack(ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL), 0u, b); // leave: counts 0, depth -1
 }
 
 // ------------------------------------------------------------------ 8. tree arrays + back edges
@@ -824,10 +977,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.crb, nS * 16);
 	take((void **)&tw.cret, nS * 16);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
-	for (uint32_t **p : {&tw.rk_has_pred, &tw.rk_flag, &tw.rk_ps})
-		take((void **)p, NA * 4);
-	for (uint32_t **p : {&tw.rk_nA, &tw.rk_nB, &tw.rk_aA, &tw.rk_aB, &tw.rk_bA, &tw.rk_bB, &tw.rk_list})
-		take((void **)p, (NA / 4 + nS + 8192) * 4);
+	take((void **)&tw.rk_pk, NA * 4);
+	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
+	for (uint32_t **p : {&tw.rk_nx, &tw.rk_wa, &tw.rk_wb, &tw.rk_tA, &tw.rk_tB, &tw.rk_tC})
+		take((void **)p, rank_pool_words(NA, Cmax + 1) * 4);
 	take((void **)&tw.segLo.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
 	take((void **)&tw.segHi.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
 }
@@ -866,12 +1019,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	scan(acnt, aoff, (size_t)nS + 1);
 	LAUNCH(k_arc_lists, nS, s, nS, V, E, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.tg_ps, cs.la, aoff, tw.arc_src,
 	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
-	RankBufs rb{tw.rk_has_pred, tw.rk_flag, tw.rk_ps, tw.rk_nA, tw.rk_nB, tw.rk_aA, tw.rk_aB, tw.rk_bA, tw.rk_bB, tw.rk_list, pw.err + 1,
-		    pw.scan_tmp, pw.scan_tmp_bytes};
-	const uint32_t shiftA = force_sparse_splitters ? 28u : rank_split_shift(NA);
-	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, rb.flag, shiftA);
-	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.flag);
-	list_rank_splitters<false>(NA, shiftA, tw.cntB, nullptr, C, rb, s);
+	RankBufs rb{tw.rk_pk, tw.rk_heads, tw.rk_nx, tw.rk_wa, tw.rk_wb, tw.rk_tA, tw.rk_tB, tw.rk_tC};
+	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(NA);
+	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, bitsA);
+	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.heads);
+	list_rank_splitters<false>(NA, bitsA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
 	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
 	       tw.pe_le0, tw.tourflag, C, start_key, tw.P0);
@@ -906,7 +1058,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const bool big_classes = hb[1] != 0 || force_big_class_dfs;
 	if (n_entry && big_classes) {
 		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.ecc, cs.ckey, tw.cproc, tw.cadj, tw.crb);
-		hipLaunchKernelGGL(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
+		KLAUNCH(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
 				   tw.dpar, tw.cslot, tw.dvis, tw.cret);
 	} else if (n_entry) {
 		// Lanes in flight = a window of sides whose scattered stores meet again in L2 (2048 x 64 lanes measured best
@@ -914,7 +1066,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		// every lane the device can hold, so the cap never goes below 40 % of the classes.
 		const unsigned all_blocks = (n_entry + 63) / 64;
 		const unsigned dfs_blocks = std::min(all_blocks, std::max(2048u, (unsigned)(0.4 * all_blocks)));
-		hipLaunchKernelGGL(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff,
+		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff,
 				   cs.ladj, tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
 	}
 	tm.end(5);
@@ -930,9 +1082,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		(void)max_side_links;
 	}
 	// one list per processed component, one two-event list per side of an unprocessed one
-	const uint32_t shiftE = force_sparse_splitters ? 28u : rank_split_shift(2 * (size_t)nS);
-	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, rb.pk, rb.flag, shiftE);
-	list_rank_splitters<true>(2 * nS, shiftE, nullptr, tw.evt, event_lists, rb, s);
+	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(2 * (size_t)nS);
+	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
+	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE);
+	list_rank_splitters<true>(2 * nS, bitsE, nullptr, tw.evt, C, rb, s);
+	(void)event_lists;
 	tm.end(40);
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges

@@ -30,9 +30,9 @@ struct TreeWs {
 	uint32_t *cval, *cval2, *fc, *nsib;		  // [2V]
 	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]
 	uint32_t *be_cnt, *be_ps;			  // [2V+1]
-	uint32_t *rk_has_pred, *rk_flag, *rk_ps, *rk_nA, *rk_nB, *rk_aA, *rk_aB, *rk_bA, *rk_bB; // splitter list ranking
+	uint32_t *rk_pk, *rk_heads;			  // list ranking: packed list words [4V+8], list heads [C]
+	uint32_t *rk_nx, *rk_wa, *rk_wb, *rk_tA, *rk_tB, *rk_tC; // pools of the levels above the list itself
 	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
-	uint32_t *rk_list;				  // element of every list-ranking splitter
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
 	SegTree segLo, segHi;
 };

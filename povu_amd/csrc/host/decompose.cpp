@@ -94,6 +94,11 @@ void do_decompose(const Config &cfg)
 				info("Handling component: " + std::to_string(t.component_id));
 			size_t len = 0;
 			char *txt = povu_hip_forest_pvst_text(f, i, &len);
+			if (!txt) {
+				std::cerr << "ERR Could not serialise the PVST of component " << t.component_id << std::endl;
+				failed = true;
+				break;
+			}
 			const std::string fn = cfg.output_dir + "/" + std::to_string(t.component_id) + ".pvst";
 			FILE *o = fopen(fn.c_str(), "wb");
 			if (!o) {
@@ -102,8 +107,11 @@ void do_decompose(const Config &cfg)
 				povu_hip_buffer_free(txt);
 				break;
 			}
-			fwrite(txt, 1, len, o);
-			fclose(o);
+			const bool short_write = fwrite(txt, 1, len, o) != len;
+			if ((fclose(o) != 0) | short_write) {
+				std::cerr << "ERR Could not write file " << fn << std::endl;
+				failed = true;
+			}
 			povu_hip_buffer_free(txt);
 		}
 	};

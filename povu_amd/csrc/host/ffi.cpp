@@ -262,6 +262,10 @@ static povu_hip_forest *run_decompose(PovuGraph *g, int device, int hairpins, Po
 			set_error(error, 1, "segment id does not fit 32 bits (pt::id_t is u32, core.hpp:20-21)");
 			return nullptr;
 		}
+	if (g->ids.size() >= 0xFFFFFFFFull || g->v1.size() >= 0xFFFFFFFFull) { // the C ABI below takes 32-bit counts
+		set_error(error, 1, "graph too large: vertex and edge counts must fit 32 bits");
+		return nullptr;
+	}
 	char err[512] = {0};
 	povu_hip_ctx *ctx = povu_hip_create(device, err, sizeof err);
 	if (!ctx) {

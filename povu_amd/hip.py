@@ -66,6 +66,8 @@ def load_lib():
     l.povu_hip_graph_upload.restype = C.c_int
     l.povu_hip_graph_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_last_upload_times.restype = C.c_int
+    l.povu_hip_last_upload_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     l.povu_hip_decompose.restype = C.c_void_p
     l.povu_hip_decompose.argtypes = [C.c_void_p, C.POINTER(_Opts), C.c_char_p, C.c_size_t]
     l.povu_hip_forest_total_components.restype = C.c_uint32
@@ -228,6 +230,13 @@ class HipDecomposer:
                                              s1.ctypes.data, v2.ctypes.data, s2.ctypes.data, tp, err, 512)
         if rc != 0:
             raise RuntimeError(err.value.decode())
+
+    def upload_times(self) -> dict:
+        """Device time of the last upload (HIP events, ms): host-to-device copies, CSR build, reverse-slot table."""
+        t = (C.c_double * 3)()
+        if self._lib.povu_hip_last_upload_times(self._ctx, t) != 0:
+            raise RuntimeError("no graph resident")
+        return dict(h2d_ms=t[0], csr_ms=t[1], twin_ms=t[2])
 
     def decompose(self, rank: int = 0, world: int = 1, flags: int = 0) -> Forest:
         o = _Opts(rank, world, flags)

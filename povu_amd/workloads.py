@@ -186,6 +186,19 @@ def hprc_shaped(backbone_sizes, seed: int = 20260612, tiny: int = 0) -> Links:
                np.concatenate(s2_all))
 
 
+# chr1..22, X, Y lengths in Mbp: the relative sizes of the 24 large components of a whole-genome pangenome
+CHR_MBP = (248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57)
+
+
+def hprc_whole_genome(total_segments: float = 1e8, tiny: int = 2000, seed: int = 20260612) -> Links:
+    """BASELINE config 4: 24 HPRC-shaped components with sizes proportional to chr1..22,X,Y
+    summing to ~`total_segments` segments, plus `tiny` components of < 50 segments.  At the default size:
+    99 860 187 segments / 122 435 438 links / 2 024 components."""
+    # the generator emits ~1.675 segments per backbone segment
+    sizes = [max(8, int(total_segments / 1.675 * m / sum(CHR_MBP))) for m in CHR_MBP]
+    return hprc_shaped(sizes, seed=seed, tiny=tiny)
+
+
 def random_bidirected(n_vtx: int, n_links: int, seed: int, self_loops: bool = True,
                       connected: bool = False) -> Links:
     """Differential-fuzz input: random sides, parallel links, self loops, several components."""

@@ -16,7 +16,8 @@ class Forest(C.Structure):
                 ("text", C.POINTER(C.c_void_p)), ("text_len", C.POINTER(C.c_size_t)),
                 ("n_pvst", C.POINTER(C.c_uint32)), ("total_flubbles", C.c_uint64),
                 ("t_componetize", C.c_double), ("t_tree", C.c_double), ("t_classes", C.c_double),
-                ("t_stack", C.c_double), ("t_pvst", C.c_double)]
+                ("t_stack", C.c_double), ("t_pvst", C.c_double), ("t_wall_components", C.c_double),
+                ("threads", C.c_uint32)]
 
 
 _lib = None
@@ -32,6 +33,9 @@ def lib():
         _lib.orc_decompose_arrays.restype = C.POINTER(Forest)
         _lib.orc_decompose_arrays.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_decompose_arrays_mt.restype = C.POINTER(Forest)
+        _lib.orc_decompose_arrays_mt.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib.orc_forest_free.argtypes = [C.POINTER(Forest)]
         _lib.orc_decompose_gfa.restype = C.c_int
         _lib.orc_decompose_gfa.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
@@ -39,9 +43,11 @@ def lib():
     return _lib
 
 
-def decompose(links, tips=None, want_text=True, timings=False):
+def decompose(links, tips=None, want_text=True, timings=False, threads=1, lpt=False):
     """Run the oracle on a workloads.Links. Returns {component_id: pvst_text}
-    (component ids are 1-based, skipped components absent)."""
+    (component ids are 1-based, skipped components absent).  threads > 1 runs the per-component part
+    on that many threads: the reference's contiguous chunks (decompose.cpp:78-92,116-157) or, with
+    lpt, components bin-packed by size."""
     l = lib()
     vid = np.ascontiguousarray(links.vid, dtype=np.uint32)
     v1 = np.ascontiguousarray(links.v1, dtype=np.uint32)
@@ -52,8 +58,9 @@ def decompose(links, tips=None, want_text=True, timings=False):
     if tips is not None:
         tips = np.ascontiguousarray(tips, dtype=np.uint8)
         tp = tips.ctypes.data
-    f = l.orc_decompose_arrays(len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
-                               v2.ctypes.data, s2.ctypes.data, tp, 1 if want_text else 0)
+    f = l.orc_decompose_arrays_mt(len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
+                                  v2.ctypes.data, s2.ctypes.data, tp, 1 if want_text else 0, int(threads),
+                                  1 if lpt else 0)
     fo = f.contents
     out = {}
     for c in range(fo.n_comp):
@@ -62,7 +69,8 @@ def decompose(links, tips=None, want_text=True, timings=False):
     info = dict(n_comp=fo.n_comp, comp_nv=[fo.comp_nv[c] for c in range(min(fo.n_comp, 100000))],
                 n_pvst=[fo.n_pvst[c] for c in range(min(fo.n_comp, 100000))],
                 total_flubbles=fo.total_flubbles, t_componetize=fo.t_componetize, t_tree=fo.t_tree,
-                t_classes=fo.t_classes, t_stack=fo.t_stack, t_pvst=fo.t_pvst)
+                t_classes=fo.t_classes, t_stack=fo.t_stack, t_pvst=fo.t_pvst,
+                t_wall_components=fo.t_wall_components, threads=fo.threads)
     l.orc_forest_free(f)
     return (out, info) if timings else out
 

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from povu_amd import HipDecomposer, workloads as W
 
-CHR_MBP = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
+CHR_MBP = list(W.CHR_MBP)
 total = float(sys.argv[1]) if len(sys.argv) > 1 else 1e8
 check = (sys.argv[2] if len(sys.argv) > 2 else "oracle")
 # backbone -> segments ratio of the generator is ~1.675
