@@ -194,6 +194,9 @@ void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, 
 // two independent scans that are due at the same point of the pass, in the same two launches
 void scan_exclusive_u32_pair(const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1,
 			     void *tmp, size_t tmp_bytes, hipStream_t s);
+// exclusive running xor of two arrays of the same length (the two halves of 64-bit words), in the same two launches
+void scan_exclusive_xor_u32_pair(const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, size_t n, void *tmp,
+				 size_t tmp_bytes, hipStream_t s);
 size_t scan_tmp_bytes(size_t n);
 // exclusive running maximum (identity 0)
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);

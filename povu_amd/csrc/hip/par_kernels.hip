@@ -54,14 +54,17 @@ __global__ void k_tcomp_vertices(uint32_t V, uint32_t T, const uint32_t *__restr
 __global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ voff,
 			    const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ t_par,
 			    const uint32_t *__restrict__ t_size, uint32_t *__restrict__ gpar, uint32_t *__restrict__ gsize,
-			    uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi0)
+			    uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	hi0[t] = NIL; // k_hi0 takes minima into it
-	if (t == T - 1)
+	cov[t] = 0;   // ... and counts back-edge ends here
+	if (t == T - 1) {
 		hi0[T] = NIL;
+		cov[T] = 0;
+	}
 	uint32_t c = t_comp[t];
 	uint32_t base = 2 * voff[c] + c, l = t - base;
 	t_root[t] = base;
@@ -96,61 +99,56 @@ __global__ void k_dense_be(uint32_t NB0, uint32_t C, const uint32_t *__restrict_
 }
 
 // ------------------------------------------------------------- row D
+// hi0(v) = min target of v's own back edges; cov(v) = back edges leaving v minus back edges arriving at v.  A back
+// edge runs from a descendant to an ancestor, so the sum of cov over subtree(v) counts exactly the back edges that
+// leave subtree(v) upwards past v.
 __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
-		      uint32_t *__restrict__ hi0)
+		      uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < NB0)
-		atomicMin(&hi0[b_src[j]], b_tgt[j]);
+	if (j >= NB0)
+		return;
+	const uint32_t sv = b_src[j], tv = b_tgt[j];
+	atomicMin(&hi0[sv], tv);
+	if (sv != tv) {
+		atomicAdd(&cov[sv], 1u);
+		atomicSub(&cov[tv], 1u);
+	}
 }
-// hiA(v) = min target of the ordinary back edges leaving subtree(v); bridge(v): none of them
-// reaches a proper ancestor of v (the bracket list of v would be empty but for simplifying edges)
-__global__ void k_hiA(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
-		      const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ hiA,
-		      uint32_t *__restrict__ bridge)
+// bridge(v): no ordinary back edge out of subtree(v) reaches a proper ancestor of v (the bracket list of v would be
+// empty but for simplifying edges): the subtree sum of cov is zero
+__global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+			       const uint32_t *__restrict__ pscov, uint32_t *__restrict__ bridge)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
-	uint32_t sz = gsize[t];
-	if (sz == 0) {
-		hiA[t] = NIL;
-		bridge[t] = 0;
-		return;
-	}
-	uint32_t m = seg_min(segA, P, t, t + sz);
-	hiA[t] = m;
-	bridge[t] = (gpar[t] != NIL && (m == NIL || m >= t)) ? 1u : 0u;
+	const uint32_t sz = gsize[t];
+	bridge[t] = (sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1u : 0u;
+	if (t == T - 1)
+		bridge[T] = 0;
 }
 // simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
-// the root, flubbles.cpp:621-643); hi(v) = root as soon as subtree(v) holds a simplifying edge
-__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hiA,
-			  const uint32_t *__restrict__ bridge, const uint32_t *__restrict__ psb,
-			  const uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi, uint32_t *__restrict__ simp,
-			  uint8_t *__restrict__ hpf)
+// the root, flubbles.cpp:621-643)
+__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ bridge,
+			  const uint32_t *__restrict__ psb, uint32_t *__restrict__ simp, uint8_t *__restrict__ hpf)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	uint32_t sz = gsize[t];
-	if (sz == 0) {
-		hi[t] = NIL;
-		simp[t] = 0;
-		if (hpf)
-			hpf[t] = 0;
-		return;
-	}
-	uint32_t cnt = psb[t + sz] - psb[t];
-	hi[t] = cnt > 0 ? t_root[t] : hiA[t];
-	const uint32_t sm = (bridge[t] && cnt == 1) ? 1u : 0u;
+	const uint32_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1u : 0u;
 	simp[t] = sm;
 	if (hpf)
 		hpf[t] = (uint8_t)sm;
 }
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
-// ascending idx are v+1, then each next sibling at c + size(c).
-__global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi,
-			  const uint32_t *__restrict__ hi0, uint32_t *__restrict__ cap_tgt, uint32_t *__restrict__ capf)
+// ascending idx are v+1, then each next sibling at c + size(c).  hi(c) = min target of the back edges leaving
+// subtree(c) -- the root as soon as subtree(c) holds a simplifying edge -- is only ever compared between siblings,
+// so it is evaluated on demand, for the children of branching vertices alone (range-min over hi0).
+__global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
+			  const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ segA,
+			  uint32_t P, uint32_t *__restrict__ cap_tgt, uint32_t *__restrict__ capf)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
@@ -161,21 +159,37 @@ __global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const 
 	if (sz <= 1)
 		return;
 	const uint32_t end = v + sz;
-	uint32_t hi_1 = NIL;
-	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u))
-		hi_1 = min(hi_1, hi[c]);
-	uint32_t hi_child = NIL;
-	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u))
-		if (hi[c] == hi_1) {
+	if (v + 1 + max(gsize[v + 1], 1u) >= end)
+		return; // a single child: there is no hi_2
+	auto hi_of = [&](uint32_t c) {
+		const uint32_t cs = max(gsize[c], 1u);
+		if (psb[c + cs] != psb[c])
+			return t_root[c];
+		if (cs <= 8) { // a small branch: its hi0 values share a cache line or two
+			uint32_t m = NIL;
+			for (uint32_t k = c; k < c + cs; k++)
+				m = min(m, hi0[k]);
+			return m;
+		}
+		return seg_min(segA, P, c, c + cs);
+	};
+	// one sweep over the children: the first child that attains the minimum (hi_child), and the first two children
+	// whose hi lies above v in the tree -- hi_2 belongs to the first of them that is not hi_child
+	uint32_t hi_1 = NIL, hi_child = NIL, lt_c[2] = {NIL, NIL}, lt_h[2] = {NIL, NIL};
+	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u)) {
+		const uint32_t h = hi_of(c);
+		if (h < hi_1 || hi_child == NIL) {
+			hi_1 = h;
 			hi_child = c;
-			break;
 		}
-	uint32_t hi_2 = NIL;
-	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u))
-		if (c != hi_child && hi[c] < v) {
-			hi_2 = hi[c];
-			break;
+		if (h < v) {
+			if (lt_c[0] == NIL)
+				lt_c[0] = c, lt_h[0] = h;
+			else if (lt_c[1] == NIL)
+				lt_c[1] = c, lt_h[1] = h;
 		}
+	}
+	const uint32_t hi_2 = lt_c[0] != hi_child ? lt_h[0] : lt_h[1];
 	if (hi_2 < hi0[v]) {
 		cap_tgt[v] = hi_2;
 		capf[v] = 1;
@@ -462,9 +476,12 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 // flubble and descends (D).  When the (prev, i) intervals are laminar the class is open iff it
 // occurred before, so U/D are known per entry; a crossing pair sends the component to the
 // sequential kernel instead.
-// one kernel: the laminarity check of the (prev, i) intervals and the +-1 walk of the stack machine
+// one kernel: the laminarity check of the (prev, i) intervals and the +-1 walk of the stack machine.
+// The walks of all components sit back to back in one array.  So that ONE unsegmented running minimum serves every
+// component, the first step of component c also drops by B_c = 2 * (entries of the component before it) + 2: further
+// than that component's walk can have climbed or fallen, so nothing in front of c ever is the minimum again.
 __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
-			       const uint32_t *__restrict__ s_comp, uint32_t *__restrict__ comp_bad,
+			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint32_t *__restrict__ comp_bad,
 			       const uint32_t *__restrict__ ns, uint32_t *__restrict__ walk, uint32_t *__restrict__ dflag)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,7 +489,13 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 		return;
 	const uint32_t p = prev[i];
 	uint32_t d = (i + 1 < ns[i]) ? 1u : 0u;
-	walk[2 * i] = p != NIL ? 0xFFFFFFFFu : 0u; // -1
+	uint32_t first = p != NIL ? 0xFFFFFFFFu : 0u; // -1
+	if (i > 0) {
+		const uint32_t cp = s_comp[i - 1];
+		if (cp != s_comp[i])
+			first -= 2 * (i - soff[cp]) + 2;
+	}
+	walk[2 * i] = first;
 	walk[2 * i + 1] = d;
 	dflag[i] = d;
 	if (p == NIL || p + 1 >= i)
@@ -480,18 +503,23 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 	if (seg_min(segP, P, p + 1, i) < p)
 		comp_bad[s_comp[i]] = 1;
 }
+// inclusive prefix sums of the walk, biased so that u32 order = int order; neg = their complement (a running
+// maximum of the complement is the running minimum of the walk)
 __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const uint32_t *__restrict__ ps,
-			    uint32_t *__restrict__ out)
+			    uint32_t *__restrict__ out, uint32_t *__restrict__ neg)
 {
 	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k < n)
-		out[k] = ps[k] + walk[k] + 0x80000000u; // inclusive prefix sum, biased so that u32 order = int order
+	if (k < n) {
+		const uint32_t w = ps[k] + walk[k] + 0x80000000u;
+		out[k] = w;
+		neg[k] = ~w;
+	}
 }
 // level of every emitted flubble, and -- so that the PCIe writes of the result overlap with the level
 // queries -- its endpoints and orientations straight into the (page-locked host) PVST arrays
 __global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
 			 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
-			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ segW, uint32_t P,
+			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ negmax,
 			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i, const uint32_t *__restrict__ ns,
 			 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
 			 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
@@ -500,14 +528,17 @@ __global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const u
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S || !dflag[i])
 		return;
-	uint32_t c = s_comp[i], k0 = 2 * soff[c], k = 2 * i + 1;
-	int base = k0 ? (int)(wb[k0 - 1] - 0x80000000u) : 0;
-	int cur = (int)(wb[k] - 0x80000000u) - base;
-	int mn = (int)(seg_min(segW, P, k0, k + 1) - 0x80000000u) - base;
-	if (mn > 0)
-		mn = 0;
+	const uint32_t c = s_comp[i], i0 = soff[c], k0 = 2 * i0, k = 2 * i + 1;
+	// zero of this component's walk = the value in front of its first step, less the drop B_c of that step
+	uint32_t zero = 0x80000000u;
+	if (k0) {
+		const uint32_t cp = s_comp[i0 - 1];
+		zero = wb[k0 - 1] - (2 * (i0 - soff[cp]) + 2);
+	}
+	// running minimum up to k (negmax = exclusive running maximum of ~wb): everything in front of k0 lies above `zero`
+	const uint32_t cur = wb[k], run = min(cur, ~negmax[k]);
 	uint32_t j = erank[i];
-	lev[j] = (uint32_t)(cur - mn); // depth of the new flubble (>= 1)
+	lev[j] = cur - min(zero, run); // depth of the new flubble (>= 1)
 	e_i[j] = i;
 	// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
 	const uint64_t q = (uint64_t)j + cproc_ps[c] + 1;
@@ -672,7 +703,7 @@ template <typename F>
 static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 {
 	const size_t T = 2 * V + Cmax, NB = E + V + 2 * T, S = V + 1;
-	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.hiA, &pw.hi, &pw.flagA, &pw.psA,
+	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.cov, &pw.flagA, &pw.psA,
 			     &pw.flagB, &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
 			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.inv, &pw.vals_t, &pw.vals_t2})
 		take((void **)p, (T + 2) * 4);
@@ -689,6 +720,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.soff, (Cmax + 2) * 4);
 	take((void **)&pw.walk, (2 * S + 4) * 4);
 	take((void **)&pw.walk_ps, (2 * S + 4) * 4);
+	take((void **)&pw.wrun, (2 * S + 4) * 4);
 	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
 	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
 	take((void **)&pw.doff, (Cmax + 2) * 4);
@@ -696,7 +728,6 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
 	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
 	take((void **)&pw.segP.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
-	take((void **)&pw.segW.tree, 2 * (size_t)SegTree::pow2(2 * S + 2) * 4);
 	take((void **)&pw.segL.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
 	take((void **)&pw.hpf, T + 2);
 	for (uint32_t **p : {&pw.hp1, &pw.hp2, &pw.hp3})
@@ -776,7 +807,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- T-space + dense back edges
 	tm.begin("par_setup");
 	LAUNCH(k_tcomp_vertices, V, s, V, T, cs.ckey, cs.voff, pw.t_comp);
-	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0);
+	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0, pw.cov);
 	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
@@ -791,13 +822,15 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- row D
 	tm.begin("par_classes");
 	uint32_t launches = 0;
-	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0);
+	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov);
 	seg_build(pw.segA, pw.hi0, T, s);
 	uint32_t *bridge = pw.flagA, *psb = pw.psA, *simp = pw.flagB, *pssimp = pw.psB, *capf = pw.flagC, *pscap = pw.psC;
-	LAUNCH(k_hiA, T, s, T, pw.gsize, pw.gpar, pw.segA.tree, pw.segA.P, pw.hiA, bridge);
+	uint32_t *pscov = pw.psB; // (free until the simplifying flags are scanned)
+	scan(pw.cov, pscov, (size_t)T + 1);
+	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan(bridge, psb, (size_t)T + 1);
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, pw.hiA, bridge, psb, pw.t_root, pw.hi, simp, want_hp ? pw.hpf : nullptr);
-	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi, pw.hi0, pw.cap_tgt, capf);
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr);
+	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf);
 	scan2(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre, pw.incnt, srccnt);
@@ -861,11 +894,12 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	tm.begin("par_pvst");
 	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
 	uint32_t *dflag = pw.s_key; // scratch
-	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.comp_bad, pw.ns, pw.walk, dflag);
+	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.soff, pw.comp_bad, pw.ns, pw.walk, dflag);
 	scan2(dflag, pw.erank, (size_t)S + 1, pw.walk, pw.walk_ps, (size_t)2 * S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
-	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb);
-	seg_build(pw.segW, wb, (size_t)2 * S, s);
+	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
+	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb, wneg);
+	scan_exclusive_max_u32(wneg, wrun, (size_t)2 * S, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
 	{ // the five PVST arrays back to back in the forest's page-locked result block (povu_hip_forest::alloc has the
 	  // same layout): the emit kernels write over PCIe directly, nothing is copied afterwards
@@ -878,7 +912,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
 		pw.d_total = total;
 	}
-	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, pw.segW.tree, pw.segW.P, pw.lev, pw.e_i, pw.ns, pw.s_vtx,
+	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i, pw.ns, pw.s_vtx,
 	       sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,

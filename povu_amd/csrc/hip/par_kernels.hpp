@@ -27,7 +27,7 @@ struct ParWs {
 	uint32_t V, E, C, T;
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
-	uint32_t *hi0, *hiA, *hi, *flagA, *psA, *flagB, *psB, *flagC, *psC; // flags + their exclusive scans [T+1]
+	uint32_t *hi0, *cov, *flagA, *psA, *flagB, *psB, *flagC, *psC; // flags + their exclusive scans [T+1]
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
 	uint32_t *inv, *vals_t, *vals_t2;
 	uint64_t *keys_t, *keys_t2; // [T]
@@ -38,7 +38,7 @@ struct ParWs {
 	// candidate stack space
 	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev, *soff; // [V+1] / soff [C+1]
 	uint32_t *s_key, *s_key2, *s_val, *s_val2;
-	uint32_t *walk, *walk_ps;	 // [2V+2]
+	uint32_t *walk, *walk_ps, *wrun; // [2V+2] steps of the stack machine, their prefix sums, running minimum (complemented)
 	uint32_t *erank, *lev, *e_i;	 // [V+1]
 	uint32_t *comp_bad;		 // [C+1] components that must be redone sequentially
 	// dense PVST output (all processed components back to back): what goes over PCIe
@@ -48,7 +48,7 @@ struct ParWs {
 	uint32_t *d_a, *d_z, *d_parent;	 // [d_total] device views into the forest's page-locked result block
 	uint8_t *d_aor, *d_zor;		 // [d_total] 0 forward, 1 reverse
 	uint32_t *err;			 // [4] internal error words
-	SegTree segA, segB, segP, segW, segL;
+	SegTree segA, segB, segP, segL;
 	// --hairpins on the parallel path
 	uint8_t *hpf;			 // [T] bit0 simplifying vertex, bit1 top bracket is a simplifying edge
 	uint32_t *hp1, *hp2, *hp3;	 // [T+1] segment-tree inputs / push flags

@@ -13,12 +13,13 @@ namespace povu_hip
 // from L2 / Infinity Cache.
 static constexpr int SC_TPB = 256, SC_ITEMS = 8, SC_TILE = SC_TPB * SC_ITEMS, SC_MAX_BLOCKS = 1024;
 
-template <bool MAX>
+// MAX: 0 = sum (mod 2^32), 1 = maximum, 2 = xor; the identity of all three is 0
+template <int MAX>
 __device__ __forceinline__ uint32_t sc_op(uint32_t a, uint32_t b)
 {
-	return MAX ? (a > b ? a : b) : a + b;
+	return MAX == 1 ? (a > b ? a : b) : (MAX == 2 ? (a ^ b) : a + b);
 }
-template <bool MAX>
+template <int MAX>
 __device__ __forceinline__ uint32_t sc_block_reduce(uint32_t v, uint32_t *sh)
 {
 	for (int off = 32; off; off >>= 1)
@@ -42,7 +43,7 @@ struct ScanJob {
 struct ScanJobs {
 	ScanJob j[2];
 };
-template <bool MAX>
+template <int MAX>
 __global__ void __launch_bounds__(SC_TPB) k_scan_partials(const ScanJobs jobs)
 {
 	__shared__ uint32_t sh[4];
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_partials(const ScanJobs jobs)
 	if (threadIdx.x == 0)
 		partial[blockIdx.x] = acc;
 }
-template <bool MAX>
+template <int MAX>
 __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 {
 	__shared__ uint32_t sh[4];
@@ -144,7 +145,7 @@ static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32
 	return ScanJob{in, out, n, chunk, (uint32_t)blocks, partial};
 }
 
-template <bool MAX>
+template <int MAX>
 static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
 	if (n == 0)
@@ -159,15 +160,16 @@ static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tm
 
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
-	scan_exclusive<false>(in, out, n, tmp, tmp_bytes, s);
+	scan_exclusive<0>(in, out, n, tmp, tmp_bytes, s);
 }
 
-void scan_exclusive_u32_pair(const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1,
-			     void *tmp, size_t tmp_bytes, hipStream_t s)
+template <int OP>
+static void scan_exclusive_pair(const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1,
+				void *tmp, size_t tmp_bytes, hipStream_t s)
 {
 	if (n0 == 0 || n1 == 0) {
-		scan_exclusive<false>(in0, out0, n0, tmp, tmp_bytes, s);
-		scan_exclusive<false>(in1, out1, n1, tmp, tmp_bytes, s);
+		scan_exclusive<OP>(in0, out0, n0, tmp, tmp_bytes, s);
+		scan_exclusive<OP>(in1, out1, n1, tmp, tmp_bytes, s);
 		return;
 	}
 	if (tmp_bytes < 2 * SC_MAX_BLOCKS * sizeof(uint32_t))
@@ -176,13 +178,25 @@ void scan_exclusive_u32_pair(const uint32_t *in0, uint32_t *out0, size_t n0, con
 	jobs.j[0] = make_scan_job(in0, out0, n0, static_cast<uint32_t *>(tmp));
 	jobs.j[1] = make_scan_job(in1, out1, n1, static_cast<uint32_t *>(tmp) + SC_MAX_BLOCKS);
 	const unsigned gx = std::max(jobs.j[0].blocks, jobs.j[1].blocks);
-	KLAUNCH(k_scan_partials<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
-	KLAUNCH(k_scan_chunks<false>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_partials<OP>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_chunks<OP>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
+}
+
+void scan_exclusive_u32_pair(const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1,
+			     void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	scan_exclusive_pair<0>(in0, out0, n0, in1, out1, n1, tmp, tmp_bytes, s);
+}
+
+void scan_exclusive_xor_u32_pair(const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, size_t n, void *tmp,
+				 size_t tmp_bytes, hipStream_t s)
+{
+	scan_exclusive_pair<2>(in0, out0, n, in1, out1, n, tmp, tmp_bytes, s);
 }
 
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
-	scan_exclusive<true>(in, out, n, tmp, tmp_bytes, s);
+	scan_exclusive<1>(in, out, n, tmp, tmp_bytes, s);
 }
 
 size_t sort_tmp_bytes(size_t n)

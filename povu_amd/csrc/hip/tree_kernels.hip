@@ -21,13 +21,14 @@
 
 #include <cstdlib>
 
-#include "segtree.hpp"
-
 #include <algorithm>
 
 namespace povu_hip
 {
 
+#ifndef NIL
+#define NIL POVU_NIL
+#endif
 static constexpr int TPB = 256;
 static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 #define LAUNCH(k, n, s, ...)                                                                     \
@@ -483,28 +484,43 @@ __global__ void k_t0_pre(uint32_t NA, const uint32_t *__restrict__ dist, const u
 }
 
 // ------------------------------------------------------------------ 3. bridges
-__global__ void k_lowhigh(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ P0,
-			  uint32_t *__restrict__ lowP, uint32_t *__restrict__ highP)
+// A tree edge (parent(w), w) of the rooted forest is a bridge of H iff no non-tree link has exactly one end inside
+// subtree(w).  Every non-tree link gets a 64-bit hash of its local edge idx; a side's value is the xor of the hashes
+// of its non-tree links; the xor over subtree(w) -- two look-ups into the running xor over the forest's pre-order,
+// since subtree(w) is the interval [P0(w), P0(w) + size0(w)) -- cancels every link with both ends inside and keeps
+// the ones that cross.  A bridge always xors to 0; a non-bridge xors to 0 only if the hashes of its crossing links
+// cancel by accident (probability 2^-64 per tree edge, i.e. ~1e-11 per pass over 2e8 tree edges; the hash is a fixed
+// function of the edge idx, so a result is reproducible).  This replaces two range-min queries per side over
+// segment trees of the far ends' pre-order numbers.
+__device__ __forceinline__ unsigned long long link_hash(uint32_t le)
+{
+	unsigned long long z = ((unsigned long long)le + 1ull) * 0x9E3779B97F4A7C15ull; // splitmix64 finaliser
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+__global__ void k_xor_vals(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
+			   const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ P0, uint32_t *__restrict__ vlo,
+			   uint32_t *__restrict__ vhi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	uint32_t me = P0[S], lo = me, hi = me;
+	unsigned long long h = 0;
 	for (uint32_t k = loff[S]; k < loff[S + 1]; k++) {
-		if (tgray[lle[k]])
-			continue;
-		uint32_t o = P0[ladj[k]];
-		lo = min(lo, o);
-		hi = max(hi, o);
+		const uint32_t le = lle[k];
+		if (!tgray[le])
+			h ^= link_hash(le); // (a link is in the lists of both its ends, also when they are l and r of one segment)
 	}
-	lowP[me] = lo;
-	highP[me] = ~hi;
+	const uint32_t me = P0[S];
+	vlo[me] = (uint32_t)h;
+	vhi[me] = (uint32_t)(h >> 32);
+	if (S == nS - 1)
+		vlo[nS] = vhi[nS] = 0;
 }
 __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ size0,
-			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ segLo, uint32_t PLo,
-			  const uint32_t *__restrict__ segHi, uint32_t PHi, uint32_t *__restrict__ isbridge,
-			  uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp)
+			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ xlo, const uint32_t *__restrict__ xhi,
+			  uint32_t *__restrict__ isbridge, uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -515,9 +531,8 @@ __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const 
 		isbridge[S] = 0;
 		return;
 	}
-	uint32_t a = P0[S], b = a + size0[S];
-	uint32_t mn = seg_min(segLo, PLo, a, b), mx = ~seg_min(segHi, PHi, a, b);
-	isbridge[S] = (mn >= a && mx < b) ? 1u : 0u;
+	const uint32_t a = P0[S], b = a + size0[S];
+	isbridge[S] = (((xlo[a] ^ xlo[b]) | (xhi[a] ^ xhi[b])) == 0) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
@@ -966,7 +981,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 		take((void **)p, NA * 4);
 	take((void **)&tw.arc_le, NA * 2);
 	take((void **)&tw.evt, NA * 8);
-	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.isbridge,
+	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.xlo, &tw.xhi, &tw.isbridge,
 			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_flag, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
 			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
@@ -981,8 +996,6 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
 	for (uint32_t **p : {&tw.rk_nx, &tw.rk_wa, &tw.rk_wb, &tw.rk_tA, &tw.rk_tB, &tw.rk_tC})
 		take((void **)p, rank_pool_words(NA, Cmax + 1) * 4);
-	take((void **)&tw.segLo.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
-	take((void **)&tw.segHi.tree, 2 * (size_t)SegTree::pow2(nS) * 4);
 }
 
 size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax)
@@ -1033,12 +1046,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
-	LAUNCH(k_lowhigh, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.P0, tw.lowP, tw.highP);
-	seg_build(tw.segLo, tw.lowP, nS, s);
-	seg_build(tw.segHi, tw.highP, nS, s);
+	uint32_t *vlo = tw.lowP, *vhi = tw.highP, *xlo = tw.xlo, *xhi = tw.xhi; // [nS+1] each
+	LAUNCH(k_xor_vals, nS, s, nS, cs.loff, cs.lle, cs.tgray, tw.P0, vlo, vhi);
+	scan_exclusive_xor_u32_pair(vlo, xlo, vhi, xhi, (size_t)nS + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
-	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, tw.segLo.tree, tw.segLo.P, tw.segHi.tree, tw.segHi.P, tw.isbridge,
-	       tw.ecc, csamp);
+	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, xlo, xhi, tw.isbridge, tw.ecc, csamp);
 	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc);
 	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);

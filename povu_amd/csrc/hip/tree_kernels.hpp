@@ -18,7 +18,7 @@ struct TreeWs {
 	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
 	uint32_t *tourflag, *tour_ps;			  // [4V+4]
 	uint32_t *par0, *size0, *P0, *pe_le0;		  // [2V]
-	uint32_t *lowP, *highP;				  // [2V]
+	uint32_t *lowP, *highP, *xlo, *xhi;		  // [2V+1] per-side xor of non-tree link hashes (by pre-order), running xor
 	uint32_t *isbridge, *ecc, *dpar, *cslot;	  // [2V]
 	uint8_t *dvis;					  // [2V]
 	uint2 *cadj;					  // [2V + 2E] class-filtered scan lists {side, slot}
@@ -34,7 +34,6 @@ struct TreeWs {
 	uint32_t *rk_nx, *rk_wa, *rk_wb, *rk_tA, *rk_tB, *rk_tC; // pools of the levels above the list itself
 	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
-	SegTree segLo, segHi;
 };
 
 size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax);
