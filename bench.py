@@ -226,10 +226,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(E)
     else:
         from povu_amd.sharded import ShardedBench
-        sb = ShardedBench(hip, rank, world, comm_dev, lambda: build_workload(args.workload, args.scale))
+        sb = ShardedBench(hip, rank, world, comm_dev, lambda: build_workload(args.workload, args.scale), device_index=local_rank)
         for _ in range(args.warmup):
             sb.step()
         sb.sync()
+        sb.reset_phases()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             sb.step()
@@ -264,8 +265,10 @@ def main():
                              "traffic": None, "algorithmic_bytes_per_launch": alg, "ms_per_launch": step_s * 1e3,
                              "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d) over the aggregate peak of all GPUs"},
                 "shards": info["shards"],
+                "lpt_max_over_mean": info["lpt_max_over_mean"],
                 "phase_ms": info["phase_ms"],
             }
+        sb.close()
     if rank == 0:
         print(json.dumps(out))
     hip.close()

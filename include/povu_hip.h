@@ -109,6 +109,68 @@ typedef struct {
 povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *err, size_t errlen);
 void povu_hip_components_free(povu_hip_components *c);
 
+/* ---- multi-GPU: component sharding, one process per GPU ----
+ * Replaces the static per-thread chunks of do_decompose (app/subcommand/decompose.cpp:78-92,116-157): the
+ * components of the graph resident on the ROOT rank are labelled there (row B's union-find kernels), bin-packed
+ * over the ranks (greedy longest-processing-time on links + segments), the links are partitioned on the device and
+ * every rank receives the sub-graph of its components; ranks decompose independently; the PVST arrays are gathered
+ * on the root.  No collective touches the traversal itself. */
+typedef struct povu_hip_shards povu_hip_shards;
+typedef struct {
+	uint32_t n_vtx, n_links, n_components; /* of this shard */
+	uint64_t weight;		       /* LPT load: links + segments (+1 per component) */
+	size_t bytes;			       /* size of the packed shard */
+	const void *device_ptr;		       /* packed shard in the root's HBM */
+} povu_hip_shard_info;
+/* LPT assignment of `n` weights to `world` ranks: heaviest first (stable), each to the least loaded rank (lowest
+ * rank on ties), every placed item also costs 1.  Host only -- no GPU needed. */
+int povu_hip_lpt_assign(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner_out);
+/* Partitions the graph resident in `ctx` into `world` packed shards in device memory.  Vertices keep their
+ * ascending global order inside a shard and links their L-line order, so a shard's own component numbering
+ * preserves the global order. */
+povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t world, char *err, size_t errlen);
+uint32_t povu_hip_shards_world(const povu_hip_shards *s);
+uint32_t povu_hip_shards_total_components(const povu_hip_shards *s);
+int povu_hip_shards_get(const povu_hip_shards *s, uint32_t rank, povu_hip_shard_info *out);
+/* device time of the partition (HIP events, ms): [0] labelling, [1] weights + LPT, [2] partition kernels */
+int povu_hip_shards_times(const povu_hip_shards *s, double out_ms[3]);
+/* copies packed shard `rank` to host memory (`dst` holds info.bytes) -- for transports other than RCCL */
+int povu_hip_shards_export(const povu_hip_shards *s, povu_hip_ctx *ctx, uint32_t rank, void *dst);
+void povu_hip_shards_free(povu_hip_shards *s);
+/* Makes a packed shard the resident graph of `ctx` (CSR built on the device).  `packed` is host memory
+ * (on_device = 0) or memory of ctx's device (on_device = 1).  The shard's component ids (1-based ids in the whole
+ * graph, ascending) are kept in the context for povu_hip_forest_globalize / the gather. */
+int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed, size_t bytes, int on_device, char *err, size_t errlen);
+/* number of components of the WHOLE graph the resident shard was cut from (0: the resident graph is no shard) */
+uint32_t povu_hip_shard_total_components(const povu_hip_ctx *ctx);
+/* rewrites the component ids of a forest computed on a shard to the ids of the whole graph */
+int povu_hip_forest_globalize(povu_hip_forest *f, const povu_hip_ctx *ctx);
+/* Wire format of a forest: [u64 n_trees, u64 total_entries, u64 total_components | per tree u32 component id, n_vtx,
+ * n_links, n_pvst | a_id | z_id | parent (u32 x total) | a_or | z_or (u8 x total)], every section padded to 64 B. */
+size_t povu_hip_forest_pack_size(const povu_hip_forest *f);
+int povu_hip_forest_pack(const povu_hip_forest *f, void *dst, size_t cap);
+/* merges packed forests (host memory) into one forest, trees ordered by component id */
+povu_hip_forest *povu_hip_forest_merge(povu_hip_ctx *ctx, const void *const *packed, const size_t *bytes, uint32_t n,
+				       char *err, size_t errlen);
+
+/* RCCL communicator owned by the library (ncclSend / ncclRecv over xGMI on the context's stream).  The unique id
+ * is created on one rank (povu_hip_comm_unique_id) and handed to the others by the launcher. */
+typedef struct povu_hip_comm povu_hip_comm;
+#define POVU_HIP_COMM_ID_BYTES 128
+int povu_hip_comm_unique_id(char id[POVU_HIP_COMM_ID_BYTES], char *err, size_t errlen);
+povu_hip_comm *povu_hip_comm_create(povu_hip_ctx *ctx, const char id[POVU_HIP_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+				    char *err, size_t errlen);
+void povu_hip_comm_destroy(povu_hip_comm *c);
+/* Scatter: on the root (rank 0) `shards` is the partition of its resident graph, elsewhere NULL.  On return every
+ * rank's context holds its shard as resident graph (the root's graph is replaced by its own shard unless
+ * keep_root_graph, in which case the root decomposes through a second context). */
+int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *shards, povu_hip_ctx *dst_ctx, char *err, size_t errlen);
+/* Gather: every rank passes the (globalized) forest of its shard; the root gets the merged forest, the others an
+ * empty one. */
+povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen);
+/* wall time of the last scatter / gather on this rank, milliseconds */
+int povu_hip_comm_times(const povu_hip_comm *c, double out_ms[2]);
+
 /* components of the WHOLE graph (all shards), including skipped ones */
 uint32_t povu_hip_forest_total_components(const povu_hip_forest *f);
 /* PVSTs held by this forest (this shard's components with >= 3 vertices) */

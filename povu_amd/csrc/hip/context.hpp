@@ -1,0 +1,175 @@
+// context.hpp -- the objects behind the opaque handles of include/povu_hip.h (shared by the .hip files that
+// implement the C ABI).
+#pragma once
+#include "../../../include/povu_hip.h"
+
+#include "graph_kernels.hpp"
+#include "par_kernels.hpp"
+#include "seq_kernels.hpp"
+#include "tree_kernels.hpp"
+
+#include <memory>
+#include <mutex>
+
+using namespace povu_hip;
+
+// Pinned host blocks for the PVST arrays: D2H into page-locked memory runs at PCIe speed, and a
+// block returns to its context's pool when the forest is freed (steady state: no allocation).
+struct PinnedPool {
+	std::mutex m;
+	std::vector<std::pair<void *, size_t>> free_blocks;
+	~PinnedPool()
+	{
+		for (auto &b : free_blocks)
+			(void)hipHostFree(b.first);
+	}
+	void *get(size_t bytes, size_t &cap)
+	{
+		{
+			std::lock_guard<std::mutex> g(m);
+			for (size_t i = 0; i < free_blocks.size(); i++)
+				if (free_blocks[i].second >= bytes) {
+					void *p = free_blocks[i].first;
+					cap = free_blocks[i].second;
+					free_blocks.erase(free_blocks.begin() + i);
+					return p;
+				}
+		}
+		void *p = nullptr;
+		cap = bytes + bytes / 4 + 4096;
+		if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
+			throw HipError("hipHostMalloc failed for the PVST result block");
+		return p;
+	}
+	void put(void *p, size_t cap)
+	{
+		std::lock_guard<std::mutex> g(m);
+		if (free_blocks.size() < 24) // (a gather on 8+ ranks cycles through one block per rank)
+			free_blocks.emplace_back(p, cap);
+		else
+			(void)hipHostFree(p);
+	}
+};
+
+template <typename T>
+struct Span { // just enough of std::vector's surface for the code below
+	T *p = nullptr;
+	T *data() const { return p; }
+	T *begin() const { return p; }
+	T &operator[](size_t i) const { return p[i]; }
+};
+
+struct povu_hip_forest {
+	uint32_t total_components = 0;
+	std::shared_ptr<PinnedPool> pool;
+	void *block = nullptr;
+	size_t block_cap = 0, block_bytes = 0, total_entries = 0;
+	void alloc(size_t total)
+	{
+		total_entries = total;
+		const size_t bytes = ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64;
+		block = pool->get(bytes, block_cap);
+		char *q = static_cast<char *>(block);
+		auto carve = [&](size_t b) {
+			char *r = q;
+			q += (b + 63) & ~size_t(63);
+			return r;
+		};
+		a_id.p = (uint32_t *)carve(total * 4);
+		z_id.p = (uint32_t *)carve(total * 4);
+		parent.p = (uint32_t *)carve(total * 4);
+		a_or.p = (uint8_t *)carve(total);
+		z_or.p = (uint8_t *)carve(total);
+		block_bytes = (size_t)(q - static_cast<char *>(block));
+	}
+	void release_block()
+	{
+		if (block && pool)
+			pool->put(block, block_cap);
+		block = nullptr;
+		block_cap = block_bytes = total_entries = 0;
+	}
+	// more page-locked blocks with the same five arrays: taken over from other forests or received from other ranks
+	// (povu_hip_forest_merge / povu_hip_comm_gather), so that merging never copies a PVST array
+	struct ExtraBlock {
+		void *p = nullptr;
+		size_t cap = 0, total = 0;
+		std::shared_ptr<PinnedPool> pool;
+		uint32_t *a = nullptr, *z = nullptr, *parent = nullptr;
+		uint8_t *aor = nullptr, *zor = nullptr;
+		void carve(size_t total_entries)
+		{
+			total = total_entries;
+			char *q = static_cast<char *>(p);
+			auto take = [&](size_t b) {
+				char *r = q;
+				q += (b + 63) & ~size_t(63);
+				return r;
+			};
+			a = (uint32_t *)take(total * 4);
+			z = (uint32_t *)take(total * 4);
+			parent = (uint32_t *)take(total * 4);
+			aor = (uint8_t *)take(total);
+			zor = (uint8_t *)take(total);
+		}
+		static size_t bytes_for(size_t total) { return ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64; }
+	};
+	std::vector<ExtraBlock> extra;
+	~povu_hip_forest()
+	{
+		release_block();
+		for (auto &b : extra)
+			if (b.p && b.pool)
+				b.pool->put(b.p, b.cap);
+	}
+	struct Tree {
+		uint32_t component_id, n_vtx, n_links, n_pvst;
+		size_t off;	// into the flat arrays below
+		size_t hp_off;	// into hairpins (pairs)
+		uint32_t n_hairpins;
+		int blk = -1;	// -1: the arrays of this forest's own block, else extra[blk]
+	};
+	std::vector<Tree> trees;
+	Span<uint32_t> a_id, z_id, parent;
+	Span<uint8_t> a_or, z_or;
+	std::vector<uint64_t> hairpins;
+};
+
+struct povu_hip_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	ResidentGraph g;
+	Arena ws, ws2, ws_seq, upload_tmp;
+	HostScratch host;
+	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
+	StageTimer timer;
+	std::vector<povu_hip_stage_time> last_times;
+	uint64_t last_links = 0;
+	// device state of the last decompose (debug / parity hooks)
+	bool have_state = false;
+	uint32_t C = 0;
+	CompState cs{};
+	SeqWs sw{};
+	ParWs pw{};
+	TreeWs tw{};
+	uint32_t last_seq_redo = 0;
+	bool stack_export_pending = false; // the parallel stages' candidate stack is still in its dense layout
+	// when the resident graph is a shard (povu_hip_graph_upload_shard): ids of its components in the whole graph
+	// (1-based, ascending = the shard's own component order) and the component count of the whole graph
+	std::vector<uint32_t> shard_comp_ids;
+	uint32_t shard_total_components = 0;
+	Arena shard_buf; // a shard received from another rank
+};
+
+
+// device block of a resident graph (link arrays + CSR); build_global_csr fills the CSR part
+void alloc_resident_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given);
+void free_resident_graph(ResidentGraph &g);
+void check_graph_size(uint32_t n_vtx, uint32_t n_links);
+void set_err(char *err, size_t errlen, const std::string &msg);
+
+struct Sizes {
+	size_t V, E, Cmax, T, B, nS, slots;
+};
+// Workspace carving (or just measuring when `ar` is null); part 0 = rows A/B state (CompState), see povu_hip.hip
+size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs &sw, bool hairpins);

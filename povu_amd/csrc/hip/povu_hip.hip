@@ -1,12 +1,7 @@
 // povu_hip.hip -- C ABI (include/povu_hip.h) and host orchestration of the gfx950
 // decompose path.  Mirrors povu::subcommands::decompose::do_decompose
 // (app/subcommand/decompose.cpp:94-160) from "graph built" to "PVST ready to write".
-#include "../../../include/povu_hip.h"
-
-#include "graph_kernels.hpp"
-#include "seq_kernels.hpp"
-#include "par_kernels.hpp"
-#include "tree_kernels.hpp"
+#include "context.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -17,117 +12,7 @@
 
 using namespace povu_hip;
 
-// Pinned host blocks for the PVST arrays: D2H into page-locked memory runs at PCIe speed, and a
-// block returns to its context's pool when the forest is freed (steady state: no allocation).
-struct PinnedPool {
-	std::mutex m;
-	std::vector<std::pair<void *, size_t>> free_blocks;
-	~PinnedPool()
-	{
-		for (auto &b : free_blocks)
-			(void)hipHostFree(b.first);
-	}
-	void *get(size_t bytes, size_t &cap)
-	{
-		{
-			std::lock_guard<std::mutex> g(m);
-			for (size_t i = 0; i < free_blocks.size(); i++)
-				if (free_blocks[i].second >= bytes) {
-					void *p = free_blocks[i].first;
-					cap = free_blocks[i].second;
-					free_blocks.erase(free_blocks.begin() + i);
-					return p;
-				}
-		}
-		void *p = nullptr;
-		cap = bytes + bytes / 4 + 4096;
-		if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
-			throw HipError("hipHostMalloc failed for the PVST result block");
-		return p;
-	}
-	void put(void *p, size_t cap)
-	{
-		std::lock_guard<std::mutex> g(m);
-		if (free_blocks.size() < 4)
-			free_blocks.emplace_back(p, cap);
-		else
-			(void)hipHostFree(p);
-	}
-};
-
-template <typename T>
-struct Span { // just enough of std::vector's surface for the code below
-	T *p = nullptr;
-	T *data() const { return p; }
-	T *begin() const { return p; }
-	T &operator[](size_t i) const { return p[i]; }
-};
-
-struct povu_hip_forest {
-	uint32_t total_components = 0;
-	std::shared_ptr<PinnedPool> pool;
-	void *block = nullptr;
-	size_t block_cap = 0, block_bytes = 0, total_entries = 0;
-	void alloc(size_t total)
-	{
-		total_entries = total;
-		const size_t bytes = ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64;
-		block = pool->get(bytes, block_cap);
-		char *q = static_cast<char *>(block);
-		auto carve = [&](size_t b) {
-			char *r = q;
-			q += (b + 63) & ~size_t(63);
-			return r;
-		};
-		a_id.p = (uint32_t *)carve(total * 4);
-		z_id.p = (uint32_t *)carve(total * 4);
-		parent.p = (uint32_t *)carve(total * 4);
-		a_or.p = (uint8_t *)carve(total);
-		z_or.p = (uint8_t *)carve(total);
-		block_bytes = (size_t)(q - static_cast<char *>(block));
-	}
-	void release_block()
-	{
-		if (block && pool)
-			pool->put(block, block_cap);
-		block = nullptr;
-		block_cap = block_bytes = total_entries = 0;
-	}
-	~povu_hip_forest() { release_block(); }
-	struct Tree {
-		uint32_t component_id, n_vtx, n_links, n_pvst;
-		size_t off;	// into the flat arrays below
-		size_t hp_off;	// into hairpins (pairs)
-		uint32_t n_hairpins;
-	};
-	std::vector<Tree> trees;
-	Span<uint32_t> a_id, z_id, parent;
-	Span<uint8_t> a_or, z_or;
-	std::vector<uint64_t> hairpins;
-};
-
-struct povu_hip_ctx {
-	int device = 0;
-	hipStream_t stream = nullptr;
-	ResidentGraph g;
-	Arena ws, ws2, ws_seq, upload_tmp;
-	HostScratch host;
-	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
-	StageTimer timer;
-	std::vector<povu_hip_stage_time> last_times;
-	uint64_t last_links = 0;
-	// device state of the last decompose (debug / parity hooks)
-	bool have_state = false;
-	uint32_t C = 0;
-	CompState cs{};
-	SeqWs sw{};
-	ParWs pw{};
-	TreeWs tw{};
-	uint32_t last_seq_redo = 0;
-	bool stack_export_pending = false; // the parallel stages' candidate stack is still in its dense layout
-};
-
-static void set_err(char *err, size_t errlen, const std::string &msg)
+void set_err(char *err, size_t errlen, const std::string &msg)
 {
 	if (err && errlen) {
 		snprintf(err, errlen, "%s", msg.c_str());
@@ -164,7 +49,7 @@ extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
 	}
 }
 
-static void free_graph(ResidentGraph &g)
+void free_resident_graph(ResidentGraph &g)
 {
 	if (g.block)
 		(void)hipFree(g.block);
@@ -176,18 +61,19 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	if (!ctx)
 		return;
 	(void)hipSetDevice(ctx->device);
-	free_graph(ctx->g);
+	free_resident_graph(ctx->g);
 	ctx->ws.release();
 	ctx->ws2.release();
 	ctx->ws_seq.release();
 	ctx->upload_tmp.release();
+	ctx->shard_buf.release();
 	if (ctx->stream)
 		(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
 
 // device block of a resident graph: the link arrays + CSR (off / adj / aoth / atwin)
-static void alloc_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given)
+void alloc_resident_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given)
 {
 	g.V = n_vtx;
 	g.E = n_links;
@@ -218,7 +104,7 @@ static void alloc_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool
 	g.atwin = (uint32_t *)carve(2 * E + 2, 4);
 }
 
-static void check_graph_size(uint32_t n_vtx, uint32_t n_links)
+void check_graph_size(uint32_t n_vtx, uint32_t n_links)
 {
 	if (n_vtx == 0)
 		throw HipError("graph has no vertices");
@@ -239,9 +125,11 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		check_graph_size(n_vtx, n_links);
 		HIP_CHECK(hipSetDevice(ctx->device));
 		// the old graph goes first: two whole-genome graphs do not fit side by side
-		free_graph(ctx->g);
+		free_resident_graph(ctx->g);
 		ctx->have_state = false;
-		alloc_graph(g, n_vtx, n_links, tips != nullptr);
+		ctx->shard_comp_ids.clear();
+		ctx->shard_total_components = 0;
+		alloc_resident_graph(g, n_vtx, n_links, tips != nullptr);
 		const size_t V = n_vtx, E = n_links;
 		hipStream_t s = ctx->stream;
 		hipEvent_t e0, e1;
@@ -268,7 +156,7 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 	} catch (const std::exception &e) {
 		if (ctx) {
 			(void)hipStreamSynchronize(ctx->stream);
-			free_graph(g);
+			free_resident_graph(g);
 		}
 		set_err(err, errlen, e.what());
 		return 1;
@@ -285,11 +173,6 @@ extern "C" int povu_hip_last_upload_times(const povu_hip_ctx *ctx, double out_ms
 	return 0;
 }
 
-namespace
-{
-struct Sizes {
-	size_t V, E, Cmax, T, B, nS, slots;
-};
 
 // Workspace carving (or just measuring when `ar` is null), in three parts with different life times:
 //   part 0  rows A/B state (CompState), sized before the component count is known (C <= V)
@@ -411,7 +294,6 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 	}
 	return total + (1 << 20);
 }
-} // namespace
 
 namespace
 {
@@ -522,6 +404,14 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 	// result block to the pool (kernels that write into it may still be queued)
 	std::unique_ptr<povu_hip_forest> f;
 	try {
+		if (ctx && !ctx->g.block && ctx->shard_total_components) { // a shard without components: nothing to do
+			f = std::make_unique<povu_hip_forest>();
+			f->pool = ctx->pool;
+			f->total_components = ctx->shard_total_components;
+			ctx->last_times.clear();
+			ctx->last_links = 0;
+			return f.release();
+		}
 		if (!ctx || !ctx->g.block)
 			throw HipError("no graph resident: call povu_hip_graph_upload first");
 		HIP_CHECK(hipSetDevice(ctx->device));
@@ -884,11 +774,20 @@ extern "C" int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hi
 	out->n_vtx = t.n_vtx;
 	out->n_links = t.n_links;
 	out->n_pvst = t.n_pvst;
-	out->a_id = f->a_id.data() + t.off;
-	out->z_id = f->z_id.data() + t.off;
-	out->a_or = f->a_or.data() + t.off;
-	out->z_or = f->z_or.data() + t.off;
-	out->parent = f->parent.data() + t.off;
+	if (t.blk < 0) {
+		out->a_id = f->a_id.data() + t.off;
+		out->z_id = f->z_id.data() + t.off;
+		out->a_or = f->a_or.data() + t.off;
+		out->z_or = f->z_or.data() + t.off;
+		out->parent = f->parent.data() + t.off;
+	} else {
+		const auto &b = f->extra[(size_t)t.blk];
+		out->a_id = b.a + t.off;
+		out->z_id = b.z + t.off;
+		out->a_or = b.aor + t.off;
+		out->z_or = b.zor + t.off;
+		out->parent = b.parent + t.off;
+	}
 	out->n_hairpins = t.n_hairpins;
 	out->hairpins = t.n_hairpins ? f->hairpins.data() + 2 * t.hp_off : nullptr;
 	return 0;
@@ -897,8 +796,8 @@ extern "C" int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hi
 extern "C" int povu_hip_forest_raw(const povu_hip_forest *f, const void **block, size_t *bytes, uint64_t *total,
 				   uint64_t offsets[5])
 {
-	if (!f || !block || !bytes || !total || !offsets)
-		return 1;
+	if (!f || !block || !bytes || !total || !offsets || !f->extra.empty())
+		return 1; // (a merged forest has one block per rank: no single raw view)
 	*block = f->block;
 	*bytes = f->block_bytes;
 	*total = f->total_entries;

@@ -1,0 +1,875 @@
+// shard.hip -- multi-GPU component sharding (replaces the per-thread chunks of
+// do_decompose, app/subcommand/decompose.cpp:78-92,116-157): device-side partition of the resident graph into
+// per-rank sub-graphs, the packed shard format and its loader, forest packing / merging, and the RCCL
+// communicator (ncclSend / ncclRecv over xGMI) behind povu_hip_comm_*.
+#include "context.hpp"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <dlfcn.h>
+#include <numeric>
+#include <thread>
+
+namespace
+{
+constexpr int TPB = 256;
+inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+constexpr uint64_t SHARD_MAGIC = 0x31647268735F7670ull; // "pv_shrd1"
+
+inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
+
+// packed shard: [header 8 x u64 | vid | v1 | v2 | s1 | s2 | tip | comp ids], every section padded to 256 B
+struct ShardLayout {
+	size_t vid, v1, v2, s1, s2, tip, ids, bytes;
+	ShardLayout(size_t nv, size_t ne, size_t nc)
+	{
+		size_t o = 256;
+		vid = o, o += pad256(nv * 4);
+		v1 = o, o += pad256(ne * 4);
+		v2 = o, o += pad256(ne * 4);
+		s1 = o, o += pad256(ne);
+		s2 = o, o += pad256(ne);
+		tip = o, o += pad256(nv);
+		ids = o, o += pad256(nc * 4);
+		bytes = o;
+	}
+};
+
+double now_ms()
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ void k_shard_comp_of(uint32_t V, const uint32_t *__restrict__ label, const uint32_t *__restrict__ crank,
+				uint32_t *__restrict__ comp_of)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v < V)
+		comp_of[v] = crank[label[v]];
+}
+// items per component (vertices: idx == nullptr; links: by their first endpoint).  Neighbouring lanes mostly share a
+// component, so every run of equal components inside a wave adds its length with ONE atomic.
+__global__ void k_comp_count(uint32_t n, const uint32_t *__restrict__ comp_of, const uint32_t *__restrict__ idx,
+			     uint32_t *__restrict__ cnt)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool valid = i < n;
+	const uint32_t c = valid ? comp_of[idx ? idx[i] : i] : POVU_NIL;
+	const uint32_t prev = __shfl_up(c, 1);
+	const bool head = lane == 0 || prev != c;
+	const unsigned long long heads = __ballot(head);
+	if (head && valid) {
+		const unsigned long long above = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
+		const uint32_t next = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
+		atomicAdd(&cnt[c], next - lane);
+	}
+}
+__global__ void k_owner_keys(uint32_t n, const uint32_t *__restrict__ comp_of, const uint32_t *__restrict__ idx,
+			     const uint32_t *__restrict__ owner, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		key[i] = owner[comp_of[idx ? idx[i] : i]];
+		val[i] = i;
+	}
+}
+struct PartTable { // per rank: first sorted position and the device address of every output section
+	uint32_t vbase, ebase;
+	uint32_t *vid, *v1, *v2;
+	uint8_t *s1, *s2, *tip;
+};
+__global__ void k_part_vertices(uint32_t V, const uint32_t *__restrict__ key, const uint32_t *__restrict__ perm,
+				const PartTable *__restrict__ tab, const uint32_t *__restrict__ vid, const uint8_t *__restrict__ tip,
+				uint32_t *__restrict__ newidx)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= V)
+		return;
+	const PartTable t = tab[key[i]];
+	const uint32_t v = perm[i], li = i - t.vbase;
+	newidx[v] = li;
+	t.vid[li] = vid[v];
+	t.tip[li] = tip[v];
+}
+__global__ void k_part_links(uint32_t E, const uint32_t *__restrict__ key, const uint32_t *__restrict__ eperm,
+			     const PartTable *__restrict__ tab, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ v2,
+			     const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2, const uint32_t *__restrict__ newidx)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= E)
+		return;
+	const PartTable t = tab[key[i]];
+	const uint32_t e = eperm[i], li = i - t.ebase;
+	t.v1[li] = newidx[v1[e]];
+	t.v2[li] = newidx[v2[e]];
+	t.s1[li] = s1[e];
+	t.s2[li] = s2[e];
+}
+} // namespace
+
+// ---------------------------------------------------------------- LPT (host)
+extern "C" int povu_hip_lpt_assign(const uint64_t *weights, uint32_t n, uint32_t world, uint32_t *owner_out)
+{
+	if ((!weights && n) || !owner_out || world == 0)
+		return 1;
+	std::vector<uint32_t> order(n);
+	std::iota(order.begin(), order.end(), 0u);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weights[a] > weights[b]; });
+	std::vector<uint64_t> load(world, 0);
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t c = order[k];
+		uint32_t best = 0;
+		for (uint32_t r = 1; r < world; r++)
+			if (load[r] < load[best])
+				best = r;
+		owner_out[c] = best;
+		load[best] += weights[c] + 1;
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------- partition
+struct povu_hip_shards {
+	uint32_t world = 0, C = 0;
+	int device = 0;
+	void *block = nullptr;
+	struct Part {
+		uint32_t nv = 0, ne = 0, nc = 0;
+		uint64_t weight = 0;
+		size_t off = 0, bytes = 0;
+	};
+	std::vector<Part> parts;
+	double ms[3] = {0, 0, 0};
+	~povu_hip_shards()
+	{
+		if (block) {
+			(void)hipSetDevice(device);
+			(void)hipFree(block);
+		}
+	}
+};
+
+extern "C" povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t world, char *err, size_t errlen)
+{
+	std::unique_ptr<povu_hip_shards> sh;
+	try {
+		if (!ctx || !ctx->g.block)
+			throw HipError("no graph resident: call povu_hip_graph_upload first");
+		if (world == 0 || world > 4096)
+			throw HipError("bad world size");
+		HIP_CHECK(hipSetDevice(ctx->device));
+		const ResidentGraph &g = ctx->g;
+		hipStream_t s = ctx->stream;
+		const uint32_t V = g.V, E = g.E;
+		Sizes z;
+		z.V = V;
+		z.E = E;
+		z.Cmax = V;
+		z.nS = 2 * z.V;
+		z.slots = g.n_slots;
+		z.T = z.B = 0;
+		CompState &cs = ctx->cs;
+		ctx->have_state = false;
+		ctx->host.reset();
+		cs.host = &ctx->host;
+		cs.host_pub = nullptr;
+		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, ctx->sw, false));
+		carve_workspace(&ctx->ws, 0, z, cs, ctx->sw, false);
+		StageTimer &tm = ctx->timer;
+		tm.reset();
+		tm.enabled = false;
+		hipEvent_t ev[4];
+		for (auto &e : ev)
+			e = tm.get();
+		HIP_CHECK(hipEventRecord(ev[0], s));
+		// ---- components (row B's union-find kernels) and their sizes
+		const uint32_t C = label_components(g, cs, tm, s);
+		HIP_CHECK(hipEventRecord(ev[1], s));
+		uint32_t *comp_of = cs.comp_of, *cntv = cs.voff, *cnte = cs.eoff; // [V+1], [C+2] each
+		KLAUNCH(k_shard_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, cs.label, cs.crank, comp_of);
+		HIP_CHECK(hipMemsetAsync(cntv, 0, (size_t)C * 4, s));
+		HIP_CHECK(hipMemsetAsync(cnte, 0, (size_t)C * 4, s));
+		KLAUNCH(k_comp_count, dim3(nblk(V)), dim3(TPB), 0, s, V, comp_of, (const uint32_t *)nullptr, cntv);
+		if (E)
+			KLAUNCH(k_comp_count, dim3(nblk(E)), dim3(TPB), 0, s, E, comp_of, g.v1, cnte);
+		uint32_t *hcnt = ctx->host.take<uint32_t>(2 * (size_t)C);
+		HIP_CHECK(hipMemcpyAsync(hcnt, cntv, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(hcnt + C, cnte, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		// ---- bin packing on the host (components are few next to their size)
+		std::vector<uint64_t> w(C);
+		for (uint32_t c = 0; c < C; c++)
+			w[c] = (uint64_t)hcnt[c] + hcnt[C + c];
+		uint32_t *howner = ctx->host.take<uint32_t>((size_t)C + 1);
+		povu_hip_lpt_assign(w.data(), C, world, howner);
+		sh = std::make_unique<povu_hip_shards>();
+		sh->world = world;
+		sh->C = C;
+		sh->device = ctx->device;
+		sh->parts.resize(world);
+		std::vector<std::vector<uint32_t>> ids(world);
+		for (uint32_t c = 0; c < C; c++) {
+			auto &p = sh->parts[howner[c]];
+			p.nv += hcnt[c];
+			p.ne += hcnt[C + c];
+			p.nc++;
+			p.weight += w[c] + 1;
+			ids[howner[c]].push_back(c + 1); // component ids are 1-based (decompose.cpp:129)
+		}
+		size_t total = pad256((size_t)world * sizeof(PartTable)); // the partition table sits in front of the shards
+		for (auto &p : sh->parts) {
+			p.off = total;
+			p.bytes = ShardLayout(p.nv, p.ne, p.nc).bytes;
+			total += p.bytes;
+		}
+		if (hipMalloc(&sh->block, total) != hipSuccess) {
+			(void)hipGetLastError();
+			sh->block = nullptr;
+			throw HipError("not enough device memory for the packed shards (" + std::to_string(total >> 20) + " MiB)");
+		}
+		HIP_CHECK(hipMemsetAsync(sh->block, 0, total, s)); // (section padding travels too: keep it defined)
+		char *blk = static_cast<char *>(sh->block);
+		PartTable *htab = ctx->host.take<PartTable>(world);
+		uint64_t *hhdr = ctx->host.take<uint64_t>(8 * (size_t)world);
+		uint32_t vb = 0, eb = 0;
+		for (uint32_t r = 0; r < world; r++) {
+			const auto &p = sh->parts[r];
+			const ShardLayout L(p.nv, p.ne, p.nc);
+			char *b = blk + p.off;
+			htab[r] = PartTable{vb,
+					    eb,
+					    (uint32_t *)(b + L.vid),
+					    (uint32_t *)(b + L.v1),
+					    (uint32_t *)(b + L.v2),
+					    (uint8_t *)(b + L.s1),
+					    (uint8_t *)(b + L.s2),
+					    (uint8_t *)(b + L.tip)};
+			vb += p.nv;
+			eb += p.ne;
+			uint64_t *h = hhdr + 8 * (size_t)r;
+			h[0] = SHARD_MAGIC, h[1] = p.nv, h[2] = p.ne, h[3] = p.nc, h[4] = C, h[5] = h[6] = h[7] = 0;
+			HIP_CHECK(hipMemcpyAsync(b, h, 64, hipMemcpyHostToDevice, s));
+			if (p.nc)
+				HIP_CHECK(hipMemcpyAsync(b + L.ids, ids[r].data(), (size_t)p.nc * 4, hipMemcpyHostToDevice, s));
+		}
+		HIP_CHECK(hipEventRecord(ev[2], s));
+		// ---- partition on the device: a stable 1-pass radix sort by owner keeps vertex and link order
+		uint32_t *owner = cs.tmp_a; // [V+1] >= C
+		HIP_CHECK(hipMemcpyAsync(owner, howner, (size_t)C * 4, hipMemcpyHostToDevice, s));
+		PartTable *tab = reinterpret_cast<PartTable *>(sh->block);
+		HIP_CHECK(hipMemcpyAsync(tab, htab, (size_t)world * sizeof(PartTable), hipMemcpyHostToDevice, s));
+		const unsigned kbits = bits_for(world - 1);
+		uint32_t *kv = cs.ckey, *iv = cs.perm, *kv2 = cs.vdeg, *perm = cs.sbase, *newidx = cs.pos; // [V+1] each
+		KLAUNCH(k_owner_keys, dim3(nblk(V)), dim3(TPB), 0, s, V, comp_of, (const uint32_t *)nullptr, owner, kv, iv);
+		sort_pairs_u32(kv, kv2, iv, perm, V, kbits, cs.sort_tmp, cs.sort_tmp_bytes, s);
+		KLAUNCH(k_part_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, kv2, perm, tab, g.vid, g.tip, newidx);
+		if (E) {
+			KLAUNCH(k_owner_keys, dim3(nblk(E)), dim3(TPB), 0, s, E, comp_of, g.v1, owner, cs.keys, cs.vals);
+			sort_pairs_u32(cs.keys, cs.keys2, cs.vals, cs.vals2, E, kbits, cs.sort_tmp, cs.sort_tmp_bytes, s);
+			KLAUNCH(k_part_links, dim3(nblk(E)), dim3(TPB), 0, s, E, cs.keys2, cs.vals2, tab, g.v1, g.v2, g.s1, g.s2, newidx);
+		}
+		HIP_CHECK(hipEventRecord(ev[3], s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		for (int i = 0; i < 3; i++) {
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+			sh->ms[i] = ms;
+		}
+		return sh.release();
+	} catch (const std::exception &e) {
+		if (ctx && ctx->stream)
+			(void)hipStreamSynchronize(ctx->stream);
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+extern "C" uint32_t povu_hip_shards_world(const povu_hip_shards *s) { return s ? s->world : 0; }
+extern "C" uint32_t povu_hip_shards_total_components(const povu_hip_shards *s) { return s ? s->C : 0; }
+extern "C" int povu_hip_shards_get(const povu_hip_shards *s, uint32_t rank, povu_hip_shard_info *out)
+{
+	if (!s || !out || rank >= s->world)
+		return 1;
+	const auto &p = s->parts[rank];
+	out->n_vtx = p.nv;
+	out->n_links = p.ne;
+	out->n_components = p.nc;
+	out->weight = p.weight;
+	out->bytes = p.bytes;
+	out->device_ptr = static_cast<const char *>(s->block) + p.off;
+	return 0;
+}
+extern "C" int povu_hip_shards_times(const povu_hip_shards *s, double out_ms[3])
+{
+	if (!s || !out_ms)
+		return 1;
+	out_ms[0] = s->ms[0], out_ms[1] = s->ms[1], out_ms[2] = s->ms[2];
+	return 0;
+}
+extern "C" int povu_hip_shards_export(const povu_hip_shards *s, povu_hip_ctx *ctx, uint32_t rank, void *dst)
+{
+	if (!s || !ctx || !dst || rank >= s->world)
+		return 1;
+	if (hipSetDevice(s->device) != hipSuccess)
+		return 2;
+	const auto &p = s->parts[rank];
+	return hipMemcpy(dst, static_cast<const char *>(s->block) + p.off, p.bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+extern "C" void povu_hip_shards_free(povu_hip_shards *s) { delete s; }
+
+// ---------------------------------------------------------------- shard loader
+extern "C" int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed, size_t bytes, int on_device, char *err, size_t errlen)
+{
+	ResidentGraph g;
+	try {
+		if (!ctx || !packed || bytes < 256)
+			throw HipError("bad shard");
+		HIP_CHECK(hipSetDevice(ctx->device));
+		hipStream_t s = ctx->stream;
+		const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+		uint64_t h[8];
+		if (on_device)
+			HIP_CHECK(hipMemcpy(h, packed, 64, hipMemcpyDeviceToHost));
+		else
+			memcpy(h, packed, 64);
+		if (h[0] != SHARD_MAGIC)
+			throw HipError("not a packed shard");
+		const uint32_t nv = (uint32_t)h[1], ne = (uint32_t)h[2], nc = (uint32_t)h[3];
+		const ShardLayout L(nv, ne, nc);
+		if (L.bytes != bytes)
+			throw HipError("packed shard has the wrong size");
+		if (nv == 0) { // a rank that owns no component: nothing resident, decompose returns an empty forest
+			free_resident_graph(ctx->g);
+			ctx->have_state = false;
+			ctx->shard_comp_ids.clear();
+			ctx->shard_total_components = (uint32_t)h[4];
+			return 0;
+		}
+		check_graph_size(nv, ne);
+		free_resident_graph(ctx->g);
+		ctx->have_state = false;
+		alloc_resident_graph(g, nv, ne, true);
+		const char *b = static_cast<const char *>(packed);
+		hipEvent_t e0, e1;
+		HIP_CHECK(hipEventCreate(&e0));
+		HIP_CHECK(hipEventCreate(&e1));
+		HIP_CHECK(hipEventRecord(e0, s));
+		HIP_CHECK(hipMemcpyAsync(g.vid, b + L.vid, (size_t)nv * 4, kind, s));
+		if (ne) {
+			HIP_CHECK(hipMemcpyAsync(g.v1, b + L.v1, (size_t)ne * 4, kind, s));
+			HIP_CHECK(hipMemcpyAsync(g.v2, b + L.v2, (size_t)ne * 4, kind, s));
+			HIP_CHECK(hipMemcpyAsync(g.s1, b + L.s1, ne, kind, s));
+			HIP_CHECK(hipMemcpyAsync(g.s2, b + L.s2, ne, kind, s));
+		}
+		HIP_CHECK(hipMemcpyAsync(g.tip, b + L.tip, nv, kind, s));
+		std::vector<uint32_t> ids(nc);
+		if (nc)
+			HIP_CHECK(hipMemcpyAsync(ids.data(), b + L.ids, (size_t)nc * 4, on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, s));
+		HIP_CHECK(hipEventRecord(e1, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		(void)hipEventElapsedTime(&g.h2d_ms, e0, e1);
+		(void)hipEventDestroy(e0);
+		(void)hipEventDestroy(e1);
+		build_global_csr(g, ctx->upload_tmp, s);
+		ctx->g = g;
+		ctx->shard_comp_ids = std::move(ids);
+		ctx->shard_total_components = (uint32_t)h[4];
+		return 0;
+	} catch (const std::exception &e) {
+		if (ctx) {
+			(void)hipStreamSynchronize(ctx->stream);
+			free_resident_graph(g);
+		}
+		set_err(err, errlen, e.what());
+		return 1;
+	}
+}
+
+extern "C" uint32_t povu_hip_shard_total_components(const povu_hip_ctx *ctx) { return ctx ? ctx->shard_total_components : 0; }
+
+extern "C" int povu_hip_forest_globalize(povu_hip_forest *f, const povu_hip_ctx *ctx)
+{
+	if (!f || !ctx || ctx->shard_total_components == 0)
+		return 1;
+	for (auto &t : f->trees) {
+		if (t.component_id == 0 || t.component_id > ctx->shard_comp_ids.size())
+			return 2;
+		t.component_id = ctx->shard_comp_ids[t.component_id - 1];
+	}
+	f->total_components = ctx->shard_total_components;
+	return 0;
+}
+
+// ---------------------------------------------------------------- forest wire format
+namespace
+{
+inline size_t pad64(size_t b) { return (b + 63) & ~size_t(63); }
+struct ForestLayout {
+	size_t meta, a, z, parent, aor, zor, bytes;
+	ForestLayout(size_t n_trees, size_t total)
+	{
+		size_t o = 64;
+		meta = o, o += pad64(n_trees * 16);
+		a = o, o += pad64(total * 4);
+		z = o, o += pad64(total * 4);
+		parent = o, o += pad64(total * 4);
+		aor = o, o += pad64(total);
+		zor = o, o += pad64(total);
+		bytes = o;
+	}
+};
+// copies `n` bytes with a few threads when the block is large (page-locked host memory on both sides)
+void big_copy(void *dst, const void *src, size_t n)
+{
+	if (n < (size_t(8) << 20)) {
+		memcpy(dst, src, n);
+		return;
+	}
+	const unsigned nt = 4;
+	std::vector<std::thread> th;
+	const size_t chunk = (n / nt + 4095) & ~size_t(4095);
+	for (unsigned t = 0; t < nt; t++) {
+		const size_t b = (size_t)t * chunk, e = std::min(n, b + chunk);
+		if (b < e)
+			th.emplace_back([=] { memcpy((char *)dst + b, (const char *)src + b, e - b); });
+	}
+	for (auto &x : th)
+		x.join();
+}
+} // namespace
+
+extern "C" size_t povu_hip_forest_pack_size(const povu_hip_forest *f)
+{
+	if (!f)
+		return 0;
+	size_t total = 0;
+	for (const auto &t : f->trees)
+		total += t.n_pvst;
+	return ForestLayout(f->trees.size(), total).bytes;
+}
+
+extern "C" int povu_hip_forest_pack(const povu_hip_forest *f, void *dst, size_t cap)
+{
+	if (!f || !dst)
+		return 1;
+	size_t total = 0;
+	for (const auto &t : f->trees)
+		total += t.n_pvst;
+	const ForestLayout L(f->trees.size(), total);
+	if (cap < L.bytes)
+		return 2;
+	char *b = static_cast<char *>(dst);
+	uint64_t *h = reinterpret_cast<uint64_t *>(b);
+	memset(h, 0, 64);
+	h[0] = f->trees.size(), h[1] = total, h[2] = f->total_components;
+	uint32_t *meta = reinterpret_cast<uint32_t *>(b + L.meta);
+	size_t at = 0;
+	for (size_t i = 0; i < f->trees.size(); i++) {
+		povu_hip_tree t;
+		if (povu_hip_forest_get(f, (uint32_t)i, &t) != 0)
+			return 3;
+		meta[4 * i] = t.component_id, meta[4 * i + 1] = t.n_vtx, meta[4 * i + 2] = t.n_links, meta[4 * i + 3] = t.n_pvst;
+		memcpy(b + L.a + at * 4, t.a_id, (size_t)t.n_pvst * 4);
+		memcpy(b + L.z + at * 4, t.z_id, (size_t)t.n_pvst * 4);
+		memcpy(b + L.parent + at * 4, t.parent, (size_t)t.n_pvst * 4);
+		memcpy(b + L.aor + at, t.a_or, t.n_pvst);
+		memcpy(b + L.zor + at, t.z_or, t.n_pvst);
+		at += t.n_pvst;
+	}
+	return 0;
+}
+
+// one packed forest -> an extra block of `out` + its trees
+static void adopt_packed(povu_hip_forest &out, std::shared_ptr<PinnedPool> pool, const char *b, size_t bytes)
+{
+	if (bytes < 64)
+		throw HipError("packed forest too short");
+	const uint64_t *h = reinterpret_cast<const uint64_t *>(b);
+	const size_t n_trees = h[0], total = h[1];
+	const ForestLayout L(n_trees, total);
+	if (L.bytes > bytes)
+		throw HipError("packed forest has the wrong size");
+	out.total_components = std::max<uint32_t>(out.total_components, (uint32_t)h[2]);
+	if (n_trees == 0)
+		return;
+	povu_hip_forest::ExtraBlock blk;
+	blk.pool = pool;
+	blk.p = pool->get(povu_hip_forest::ExtraBlock::bytes_for(total), blk.cap);
+	blk.carve(total);
+	big_copy(blk.a, b + L.a, total * 4);
+	big_copy(blk.z, b + L.z, total * 4);
+	big_copy(blk.parent, b + L.parent, total * 4);
+	big_copy(blk.aor, b + L.aor, total);
+	big_copy(blk.zor, b + L.zor, total);
+	const int bi = (int)out.extra.size();
+	out.extra.push_back(blk);
+	const uint32_t *meta = reinterpret_cast<const uint32_t *>(b + L.meta);
+	size_t at = 0;
+	for (size_t i = 0; i < n_trees; i++) {
+		povu_hip_forest::Tree t{};
+		t.component_id = meta[4 * i], t.n_vtx = meta[4 * i + 1], t.n_links = meta[4 * i + 2], t.n_pvst = meta[4 * i + 3];
+		t.off = at;
+		t.hp_off = 0;
+		t.n_hairpins = 0;
+		t.blk = bi;
+		at += t.n_pvst;
+		out.trees.push_back(t);
+	}
+	if (at != total)
+		throw HipError("packed forest: tree sizes do not add up");
+}
+
+static void sort_trees(povu_hip_forest &f)
+{
+	std::stable_sort(f.trees.begin(), f.trees.end(),
+			 [](const povu_hip_forest::Tree &a, const povu_hip_forest::Tree &b) { return a.component_id < b.component_id; });
+}
+
+extern "C" povu_hip_forest *povu_hip_forest_merge(povu_hip_ctx *ctx, const void *const *packed, const size_t *bytes, uint32_t n,
+						  char *err, size_t errlen)
+{
+	try {
+		if (!ctx || (n && (!packed || !bytes)))
+			throw HipError("bad arguments");
+		auto f = std::make_unique<povu_hip_forest>();
+		f->pool = ctx->pool;
+		for (uint32_t i = 0; i < n; i++)
+			adopt_packed(*f, ctx->pool, static_cast<const char *>(packed[i]), bytes[i]);
+		sort_trees(*f);
+		return f.release();
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+// ---------------------------------------------------------------- RCCL (loaded on first use)
+namespace
+{
+struct Rccl {
+	void *h = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl &rccl()
+{
+	static Rccl r = [] {
+		Rccl x;
+		// inside a process that already loaded RCCL (PyTorch) the soname resolves to that copy
+		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (x.h)
+				break;
+		}
+		if (!x.h)
+			return x;
+		auto sym = [&](const char *n) { return dlsym(x.h, n); };
+		x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
+		x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+		x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+		x.Send = (decltype(x.Send))sym("ncclSend");
+		x.Recv = (decltype(x.Recv))sym("ncclRecv");
+		x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+		x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+		x.Broadcast = (decltype(x.Broadcast))sym("ncclBroadcast");
+		x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+		x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+		return x;
+	}();
+	if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd ||
+	    !r.Broadcast || !r.AllGather || !r.GetErrorString)
+		throw HipError("RCCL (librccl.so.1) could not be loaded");
+	return r;
+}
+#define NCCL_CHECK(expr)                                                                                   \
+	do {                                                                                               \
+		ncclResult_t r__ = (expr);                                                                 \
+		if (r__ != ncclSuccess)                                                                    \
+			throw HipError(std::string(#expr) + ": " + rccl().GetErrorString(r__));            \
+	} while (0)
+static_assert(sizeof(ncclUniqueId) == POVU_HIP_COMM_ID_BYTES, "ncclUniqueId size");
+} // namespace
+
+struct povu_hip_comm {
+	ncclComm_t comm = nullptr;
+	povu_hip_ctx *ctx = nullptr;
+	uint32_t rank = 0, world = 1;
+	hipStream_t side = nullptr; // the root's sends / receives run beside its own kernels
+	uint64_t *dsmall = nullptr; // device scratch for the size tables
+	uint64_t *hsmall = nullptr; // pinned
+	Arena stage;		    // device staging of forest blocks
+	double ms[2] = {0, 0};
+};
+
+extern "C" int povu_hip_comm_unique_id(char id[POVU_HIP_COMM_ID_BYTES], char *err, size_t errlen)
+{
+	try {
+		ncclUniqueId u;
+		NCCL_CHECK(rccl().GetUniqueId(&u));
+		memcpy(id, &u, sizeof u);
+		return 0;
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return 1;
+	}
+}
+
+extern "C" povu_hip_comm *povu_hip_comm_create(povu_hip_ctx *ctx, const char id[POVU_HIP_COMM_ID_BYTES], uint32_t rank, uint32_t world,
+					       char *err, size_t errlen)
+{
+	std::unique_ptr<povu_hip_comm> c;
+	try {
+		if (!ctx || !id || world == 0 || rank >= world || world > 512)
+			throw HipError("bad communicator arguments");
+		HIP_CHECK(hipSetDevice(ctx->device));
+		c = std::make_unique<povu_hip_comm>();
+		c->ctx = ctx;
+		c->rank = rank;
+		c->world = world;
+		ncclUniqueId u;
+		memcpy(&u, id, sizeof u);
+		NCCL_CHECK(rccl().CommInitRank(&c->comm, (int)world, u, (int)rank));
+		HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c->dsmall), 8 * 8 * (size_t)world + 64));
+		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->hsmall), 8 * 8 * (size_t)world + 64, hipHostMallocDefault));
+		return c.release();
+	} catch (const std::exception &e) {
+		if (c)
+			povu_hip_comm_destroy(c.release());
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+extern "C" void povu_hip_comm_destroy(povu_hip_comm *c)
+{
+	if (!c)
+		return;
+	if (c->ctx)
+		(void)hipSetDevice(c->ctx->device);
+	if (c->comm) {
+		try {
+			(void)rccl().CommDestroy(c->comm);
+		} catch (...) {
+		}
+	}
+	if (c->side)
+		(void)hipStreamDestroy(c->side);
+	if (c->dsmall)
+		(void)hipFree(c->dsmall);
+	if (c->hsmall)
+		(void)hipHostFree(c->hsmall);
+	c->stage.release();
+	delete c;
+}
+
+extern "C" int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *shards, povu_hip_ctx *dst, char *err, size_t errlen)
+{
+	try {
+		if (!c || !dst || dst != c->ctx)
+			throw HipError("scatter: the destination context must be the communicator's");
+		const bool root = c->rank == 0;
+		if (root && (!shards || shards->world != c->world))
+			throw HipError("scatter: the root needs a partition for exactly `world` ranks");
+		HIP_CHECK(hipSetDevice(dst->device));
+		Rccl &R = rccl();
+		hipStream_t s = dst->stream;
+		const double t0 = now_ms();
+		// sizes first (one broadcast), then every rank's shard point to point, all transfers in one group
+		uint64_t *h = c->hsmall;
+		if (root)
+			for (uint32_t r = 0; r < c->world; r++)
+				h[r] = shards->parts[r].bytes;
+		HIP_CHECK(hipMemcpyAsync(c->dsmall, h, 8 * (size_t)c->world, hipMemcpyHostToDevice, s));
+		NCCL_CHECK(R.Broadcast(c->dsmall, c->dsmall, c->world, ncclUint64, 0, c->comm, s));
+		HIP_CHECK(hipMemcpyAsync(h, c->dsmall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		const size_t my_bytes = h[c->rank];
+		const void *mine = nullptr;
+		if (root) {
+			const char *blk = static_cast<const char *>(shards->block);
+			NCCL_CHECK(R.GroupStart());
+			for (uint32_t r = 1; r < c->world; r++)
+				NCCL_CHECK(R.Send(blk + shards->parts[r].off, shards->parts[r].bytes, ncclChar, (int)r, c->comm, c->side));
+			NCCL_CHECK(R.GroupEnd());
+			mine = blk + shards->parts[0].off; // same device: loaded straight from the partition
+		} else {
+			dst->shard_buf.reserve(my_bytes + 256);
+			char *buf = dst->shard_buf.take<char>(my_bytes);
+			NCCL_CHECK(R.Recv(buf, my_bytes, ncclChar, 0, c->comm, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			mine = buf;
+		}
+		char e2[512] = {0};
+		if (povu_hip_graph_upload_shard(dst, mine, my_bytes, 1, e2, sizeof e2) != 0)
+			throw HipError(std::string("scatter: ") + e2);
+		if (root)
+			HIP_CHECK(hipStreamSynchronize(c->side)); // the partition may be freed once this returns
+		c->ms[0] = now_ms() - t0;
+		return 0;
+	} catch (const std::exception &e) {
+		if (c && c->ctx) {
+			(void)hipStreamSynchronize(c->ctx->stream);
+			if (c->side)
+				(void)hipStreamSynchronize(c->side);
+		}
+		set_err(err, errlen, e.what());
+		return 1;
+	}
+}
+
+extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen)
+{
+	try {
+		if (!c || !mine)
+			throw HipError("gather: bad arguments");
+		if (!mine->extra.empty() || !mine->hairpins.empty())
+			throw HipError("gather: expects the forest of one decompose call (no hairpins)");
+		povu_hip_ctx *ctx = c->ctx;
+		HIP_CHECK(hipSetDevice(ctx->device));
+		Rccl &R = rccl();
+		hipStream_t s = ctx->stream;
+		const double t0 = now_ms();
+		const bool root = c->rank == 0;
+		// what this rank contributes: [n_trees, total entries, total components] + tree table + its result block
+		const size_t nt = mine->trees.size(), total = mine->total_entries;
+		uint64_t *h = c->hsmall;
+		h[0] = nt, h[1] = nt ? total : 0, h[2] = mine->total_components, h[3] = 0;
+		uint64_t *dmy = c->dsmall, *dall = c->dsmall + 4;
+		HIP_CHECK(hipMemcpyAsync(dmy, h, 32, hipMemcpyHostToDevice, s));
+		NCCL_CHECK(R.AllGather(dmy, dall, 4, ncclUint64, c->comm, s));
+		HIP_CHECK(hipMemcpyAsync(h + 4, dall, 32 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		const uint64_t *all = h + 4;
+		auto out = std::make_unique<povu_hip_forest>();
+		out->pool = ctx->pool;
+		if (!root) {
+			if (nt) { // tree table + block through device staging, one message each
+				const size_t mb = nt * 32, bb = povu_hip_forest::ExtraBlock::bytes_for(total); // 8 words per tree
+				c->stage.reserve(mb + bb + 512);
+				uint32_t *dmeta = c->stage.take<uint32_t>(mb / 4);
+				char *dblk = c->stage.take<char>(bb);
+				uint32_t *hmeta = ctx->host.take<uint32_t>(8 * nt);
+				for (size_t i = 0; i < nt; i++) {
+					const auto &t = mine->trees[i];
+					if (t.blk >= 0)
+						throw HipError("gather: unexpected merged forest");
+					if (t.off + t.n_pvst > total)
+						throw HipError("gather: tree outside its block");
+					uint32_t *q = hmeta + 8 * i;
+					q[0] = t.component_id, q[1] = t.n_vtx, q[2] = t.n_links, q[3] = t.n_pvst, q[4] = (uint32_t)t.off, q[5] = q[6] = q[7] = 0;
+				}
+				HIP_CHECK(hipMemcpyAsync(dmeta, hmeta, nt * 32, hipMemcpyHostToDevice, s));
+				HIP_CHECK(hipMemcpyAsync(dblk, mine->block, bb, hipMemcpyHostToDevice, s));
+				NCCL_CHECK(R.GroupStart());
+				NCCL_CHECK(R.Send(dmeta, mb, ncclChar, 0, c->comm, s));
+				NCCL_CHECK(R.Send(dblk, bb, ncclChar, 0, c->comm, s));
+				NCCL_CHECK(R.GroupEnd());
+				HIP_CHECK(hipStreamSynchronize(s));
+			}
+			c->ms[1] = now_ms() - t0;
+			return out.release(); // empty
+		}
+		// root: receive every rank's table + block into device staging, land the blocks in page-locked memory
+		size_t need = 1024;
+		for (uint32_t r = 1; r < c->world; r++)
+			if (all[4 * r])
+				need += pad256(all[4 * r] * 32) + pad256(povu_hip_forest::ExtraBlock::bytes_for(all[4 * r + 1])) + 512;
+		c->stage.reserve(need);
+		struct In {
+			uint32_t rank;
+			size_t nt, total, mb, bb;
+			uint32_t *dmeta;
+			char *dblk;
+		};
+		std::vector<In> in;
+		NCCL_CHECK(R.GroupStart());
+		for (uint32_t r = 1; r < c->world; r++) {
+			if (!all[4 * r])
+				continue;
+			In x{r, (size_t)all[4 * r], (size_t)all[4 * r + 1], 0, 0, nullptr, nullptr};
+			x.mb = x.nt * 32;
+			x.bb = povu_hip_forest::ExtraBlock::bytes_for(x.total);
+			x.dmeta = c->stage.take<uint32_t>(x.mb / 4);
+			x.dblk = c->stage.take<char>(x.bb);
+			NCCL_CHECK(R.Recv(x.dmeta, x.mb, ncclChar, (int)r, c->comm, s));
+			NCCL_CHECK(R.Recv(x.dblk, x.bb, ncclChar, (int)r, c->comm, s));
+			in.push_back(x);
+		}
+		NCCL_CHECK(R.GroupEnd());
+		uint32_t tc = mine->total_components;
+		std::vector<uint32_t *> hmeta;
+		for (auto &x : in) {
+			povu_hip_forest::ExtraBlock blk;
+			blk.pool = ctx->pool;
+			blk.p = ctx->pool->get(x.bb, blk.cap);
+			blk.carve(x.total);
+			out->extra.push_back(blk);
+			uint32_t *hm = ctx->host.take<uint32_t>(8 * x.nt);
+			hmeta.push_back(hm);
+			HIP_CHECK(hipMemcpyAsync(hm, x.dmeta, x.nt * 32, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(blk.p, x.dblk, x.bb, hipMemcpyDeviceToHost, s)); // same layout as the sender's block
+			tc = std::max<uint32_t>(tc, (uint32_t)all[4 * x.rank + 2]);
+		}
+		// the root's own trees stay where they are: the merged forest takes over the block of `mine`
+		povu_hip_forest *m = const_cast<povu_hip_forest *>(mine);
+		if (m->block) {
+			povu_hip_forest::ExtraBlock own;
+			own.pool = m->pool;
+			own.p = m->block;
+			own.cap = m->block_cap;
+			own.carve(m->total_entries);
+			const int bi = (int)out->extra.size();
+			out->extra.push_back(own);
+			for (auto t : m->trees) {
+				t.blk = bi;
+				out->trees.push_back(t);
+			}
+			m->block = nullptr;
+			m->block_cap = m->block_bytes = m->total_entries = 0;
+			m->trees.clear();
+		}
+		HIP_CHECK(hipStreamSynchronize(s));
+		for (size_t k = 0; k < in.size(); k++) {
+			for (size_t i = 0; i < in[k].nt; i++) {
+				povu_hip_forest::Tree t{};
+				const uint32_t *q = hmeta[k] + 8 * i;
+				t.component_id = q[0], t.n_vtx = q[1], t.n_links = q[2], t.n_pvst = q[3];
+				t.off = q[4];
+				t.blk = (int)k;
+				if (t.off + t.n_pvst > in[k].total)
+					throw HipError("gather: a rank's tree lies outside its block");
+				out->trees.push_back(t);
+			}
+		}
+		out->total_components = tc;
+		sort_trees(*out);
+		c->ms[1] = now_ms() - t0;
+		return out.release();
+	} catch (const std::exception &e) {
+		if (c && c->ctx)
+			(void)hipStreamSynchronize(c->ctx->stream);
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
+extern "C" int povu_hip_comm_times(const povu_hip_comm *c, double out_ms[2])
+{
+	if (!c || !out_ms)
+		return 1;
+	out_ms[0] = c->ms[0], out_ms[1] = c->ms[1];
+	return 0;
+}

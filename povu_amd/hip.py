@@ -34,6 +34,11 @@ class _Tree(C.Structure):
                 ("n_hairpins", C.c_uint32), ("hairpins", C.POINTER(C.c_uint64))]
 
 
+class _ShardInfo(C.Structure):
+    _fields_ = [("n_vtx", C.c_uint32), ("n_links", C.c_uint32), ("n_components", C.c_uint32), ("weight", C.c_uint64),
+                ("bytes", C.c_size_t), ("device_ptr", C.c_void_p)]
+
+
 class _StageTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32)]
 
@@ -105,8 +110,57 @@ def load_lib():
                                       C.c_size_t]
     l.povu_hip_workspace_estimate.restype = C.c_uint64
     l.povu_hip_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    # ---- multi-GPU sharding
+    l.povu_hip_lpt_assign.restype = C.c_int
+    l.povu_hip_lpt_assign.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    l.povu_hip_shard_partition.restype = C.c_void_p
+    l.povu_hip_shard_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+    l.povu_hip_shards_world.restype = C.c_uint32
+    l.povu_hip_shards_world.argtypes = [C.c_void_p]
+    l.povu_hip_shards_total_components.restype = C.c_uint32
+    l.povu_hip_shards_total_components.argtypes = [C.c_void_p]
+    l.povu_hip_shards_get.restype = C.c_int
+    l.povu_hip_shards_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_ShardInfo)]
+    l.povu_hip_shards_times.restype = C.c_int
+    l.povu_hip_shards_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    l.povu_hip_shards_export.restype = C.c_int
+    l.povu_hip_shards_export.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    l.povu_hip_shards_free.argtypes = [C.c_void_p]
+    l.povu_hip_graph_upload_shard.restype = C.c_int
+    l.povu_hip_graph_upload_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
+    l.povu_hip_shard_total_components.restype = C.c_uint32
+    l.povu_hip_shard_total_components.argtypes = [C.c_void_p]
+    l.povu_hip_forest_globalize.restype = C.c_int
+    l.povu_hip_forest_globalize.argtypes = [C.c_void_p, C.c_void_p]
+    l.povu_hip_forest_pack_size.restype = C.c_size_t
+    l.povu_hip_forest_pack_size.argtypes = [C.c_void_p]
+    l.povu_hip_forest_pack.restype = C.c_int
+    l.povu_hip_forest_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    l.povu_hip_forest_merge.restype = C.c_void_p
+    l.povu_hip_forest_merge.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_uint32, C.c_char_p,
+                                        C.c_size_t]
+    l.povu_hip_comm_unique_id.restype = C.c_int
+    l.povu_hip_comm_unique_id.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_comm_create.restype = C.c_void_p
+    l.povu_hip_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    l.povu_hip_comm_destroy.argtypes = [C.c_void_p]
+    l.povu_hip_comm_scatter.restype = C.c_int
+    l.povu_hip_comm_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_comm_gather.restype = C.c_void_p
+    l.povu_hip_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_comm_times.restype = C.c_int
+    l.povu_hip_comm_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     _lib = l
     return l
+
+
+def lpt_assign(weights, world: int) -> np.ndarray:
+    """The library's LPT rule (host only): heaviest first (stable), least loaded rank, +1 per item."""
+    w = np.ascontiguousarray(weights, dtype=np.uint64)
+    out = np.zeros(len(w), dtype=np.uint32)
+    if load_lib().povu_hip_lpt_assign(w.ctypes.data, len(w), world, out.ctypes.data) != 0:
+        raise ValueError("bad LPT arguments")
+    return out
 
 
 @dataclass
@@ -174,6 +228,22 @@ class Forest:
             block = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_uint8)), shape=(nb.value,))
         return block, int(tot.value), [int(x) for x in offs], hdr
 
+    def pack(self) -> np.ndarray:
+        """The forest in its wire format (host bytes): what a transport other than RCCL ships."""
+        n = self._lib.povu_hip_forest_pack_size(self._h)
+        buf = np.zeros(n, dtype=np.uint8)
+        if self._lib.povu_hip_forest_pack(self._h, buf.ctypes.data, n) != 0:
+            raise RuntimeError("forest pack failed")
+        return buf
+
+    def component_ids(self) -> List[int]:
+        t = _Tree()
+        out = []
+        for i in range(len(self)):
+            self._lib.povu_hip_forest_get(self._h, i, C.byref(t))
+            out.append(int(t.component_id))
+        return out
+
     def text(self, i: int) -> str:
         ln = C.c_size_t(0)
         p = self._lib.povu_hip_forest_pvst_text(self._h, i, C.byref(ln))
@@ -191,6 +261,45 @@ class Forest:
             self._lib.povu_hip_forest_get(self._h, i, C.byref(t))
             out[t.component_id] = self.text(i)
         return out
+
+
+class Shards:
+    """Device-resident partition of a resident graph into per-rank packed shards (povu_hip_shard_partition)."""
+
+    def __init__(self, lib, handle, owner):
+        self._lib, self._h, self._owner = lib, handle, owner
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.povu_hip_shards_free(self._h)
+            self._h = None
+
+    @property
+    def world(self) -> int:
+        return self._lib.povu_hip_shards_world(self._h)
+
+    @property
+    def total_components(self) -> int:
+        return self._lib.povu_hip_shards_total_components(self._h)
+
+    def info(self, rank: int) -> dict:
+        i = _ShardInfo()
+        if self._lib.povu_hip_shards_get(self._h, rank, C.byref(i)) != 0:
+            raise IndexError(rank)
+        return dict(n_vtx=i.n_vtx, n_links=i.n_links, n_components=i.n_components, weight=int(i.weight), bytes=int(i.bytes),
+                    device_ptr=i.device_ptr)
+
+    def times(self) -> dict:
+        t = (C.c_double * 3)()
+        self._lib.povu_hip_shards_times(self._h, t)
+        return dict(label_ms=t[0], lpt_ms=t[1], partition_ms=t[2])
+
+    def export(self, rank: int) -> np.ndarray:
+        """Packed shard `rank` as host bytes."""
+        buf = np.zeros(self.info(rank)["bytes"], dtype=np.uint8)
+        if self._lib.povu_hip_shards_export(self._h, self._owner._ctx, rank, buf.ctypes.data) != 0:
+            raise RuntimeError("shard export failed")
+        return buf
 
 
 class HipDecomposer:
@@ -237,6 +346,57 @@ class HipDecomposer:
         if self._lib.povu_hip_last_upload_times(self._ctx, t) != 0:
             raise RuntimeError("no graph resident")
         return dict(h2d_ms=t[0], csr_ms=t[1], twin_ms=t[2])
+
+    # ---- multi-GPU sharding
+    def partition(self, world: int) -> Shards:
+        """Labels the resident graph's components, bin-packs them over `world` ranks and partitions the links on the
+        device (povu_hip_shard_partition)."""
+        err = C.create_string_buffer(512)
+        h = self._lib.povu_hip_shard_partition(self._ctx, world, err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return Shards(self._lib, h, self)
+
+    def upload_shard(self, packed, nbytes: Optional[int] = None, on_device: bool = False):
+        """Makes a packed shard the resident graph: host bytes (numpy uint8) or a device pointer (int) + size."""
+        err = C.create_string_buffer(512)
+        if on_device:
+            ptr, n = int(packed), int(nbytes)
+        else:
+            packed = np.ascontiguousarray(packed, dtype=np.uint8)
+            ptr, n = packed.ctypes.data, packed.size
+        if self._lib.povu_hip_graph_upload_shard(self._ctx, ptr, n, 1 if on_device else 0, err, 512) != 0:
+            raise RuntimeError(err.value.decode())
+
+    def shard_total_components(self) -> int:
+        return int(self._lib.povu_hip_shard_total_components(self._ctx))
+
+    def merge_forests(self, packed_list) -> Forest:
+        """Merges packed forests (Forest.pack() bytes) into one forest ordered by component id."""
+        bufs = [np.ascontiguousarray(b, dtype=np.uint8) for b in packed_list]
+        n = len(bufs)
+        ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+        sizes = (C.c_size_t * max(n, 1))(*[b.size for b in bufs])
+        err = C.create_string_buffer(512)
+        h = self._lib.povu_hip_forest_merge(self._ctx, ptrs, sizes, n, err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return Forest(self._lib, h)
+
+    def decompose_shard(self, flags: int = 0) -> Forest:
+        """Decomposes the resident shard and rewrites the component ids to those of the whole graph; a rank that
+        owns no component gets an empty forest."""
+        if self.shard_total_components() == 0:
+            raise RuntimeError("the resident graph is not a shard")
+        err = C.create_string_buffer(512)
+        o = _Opts(0, 1, flags)
+        h = self._lib.povu_hip_decompose(self._ctx, C.byref(o), err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        f = Forest(self._lib, h)
+        if self._lib.povu_hip_forest_globalize(h, self._ctx) != 0:
+            raise RuntimeError("forest globalize failed")
+        return f
 
     def decompose(self, rank: int = 0, world: int = 1, flags: int = 0) -> Forest:
         o = _Opts(rank, world, flags)

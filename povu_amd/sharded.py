@@ -1,318 +1,318 @@
 """Component sharding across GPUs: one process per GPU, components are the unit.
 
-* :func:`assign_owners` -- greedy longest-processing-time bin packing of components over ranks
-  (replaces the reference's static contiguous chunks, app/subcommand/decompose.cpp:78-92,116-157).
-* :func:`partition_links` -- the link slice a rank needs for its components (the "scatter").
-* :func:`scatter_links` / :func:`gather_forest` -- torch.distributed exchange (RCCL on GPUs, gloo
-  in the CPU tests): sizes are all-gathered first, payloads move point to point to/from rank 0.
-No collective runs inside the traversal itself.
+The work is done by the C library (`povu_amd/csrc/hip/shard.hip`, declared in `include/povu_hip.h`):
+
+* `povu_hip_shard_partition`  -- the root labels the components of its resident graph on the GPU (row B's
+  union-find kernels), bin-packs them over the ranks (LPT, `povu_hip_lpt_assign`) and partitions vertices and
+  links on the device into one packed shard per rank;
+* `povu_hip_comm_scatter` / `povu_hip_comm_gather` -- RCCL `ncclSend` / `ncclRecv` over xGMI from C++ on the
+  context's own stream: shards out, PVST blocks back to the root (replaces the reference's static contiguous
+  chunks per thread, app/subcommand/decompose.cpp:78-92,116-157).  No collective runs inside the traversal.
+
+This module is the launcher-side plumbing: it hands the RCCL unique id around with `torch.distributed`, offers
+the same scatter / gather over any `torch.distributed` backend through host memory (`*_over_dist`, what the
+gloo tests and single-GPU rehearsals use), and a numpy model of the partition for the tests.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+import ctypes as C
+import time
+from typing import List, Optional
 
 import numpy as np
 
+from . import hip as _hip
 from .workloads import Links
 
 
-def assign_owners(weights: Sequence[int], world: int) -> np.ndarray:
-    """LPT: components by weight descending (stable), each to the least loaded rank (lowest rank
-    on ties).  Same rule as the C ABI uses for `povu_hip_opts.rank/world`."""
-    w = np.asarray(weights, dtype=np.int64)
-    order = np.argsort(-w, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
-    owner = np.zeros(len(w), dtype=np.int32)
-    for c in order.tolist():
-        r = int(np.argmin(load))
-        owner[c] = r
-        load[r] += int(w[c]) + 1
-    return owner
+# ---------------------------------------------------------------- planning (host)
+def assign_owners(weights, world: int) -> np.ndarray:
+    """LPT: components by weight descending (stable), each to the least loaded rank (lowest rank on ties) --
+    the library's own rule (`povu_hip_lpt_assign`; `povu_hip_opts.rank/world` uses the same)."""
+    return _hip.lpt_assign(weights, world).astype(np.int32)
 
 
 def component_labels(links: Links) -> np.ndarray:
-    """Host-side union-find labelling used only to plan the scatter (component rank by min vertex)."""
+    """Component rank (by minimum vertex idx) of every vertex -- numpy/scipy model used by the tests only."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
     n = links.n_vtx
-    parent = np.arange(n, dtype=np.int64)
-
-    def find(x):
-        while parent[x] != x:
-            parent[x] = parent[parent[x]]
-            x = parent[x]
-        return x
-
-    for a, b in zip(links.v1.tolist(), links.v2.tolist()):
-        ra, rb = find(a), find(b)
-        if ra != rb:
-            if ra < rb:
-                parent[rb] = ra
-            else:
-                parent[ra] = rb
-    root = np.array([find(v) for v in range(n)], dtype=np.int64)
-    _, comp = np.unique(root, return_inverse=True)  # roots are minima => rank by min vertex idx
-    return comp.astype(np.int64)
+    a = coo_matrix((np.ones(links.n_links, dtype=np.int8), (links.v1.astype(np.int64), links.v2.astype(np.int64))), shape=(n, n))
+    _, lab = connected_components(a, directed=False)
+    first = np.full(lab.max() + 1, n, dtype=np.int64)
+    np.minimum.at(first, lab, np.arange(n))
+    rank_of = np.empty_like(first)
+    rank_of[np.argsort(first, kind="stable")] = np.arange(len(first))
+    return rank_of[lab].astype(np.int64)
 
 
 def partition_links(links: Links, comp: np.ndarray, owner: np.ndarray, rank: int):
-    """Sub-graph of the components owned by `rank`, vertices kept in ascending global idx (so the
-    shard's own component numbering preserves the global order) + the global ids of its components."""
+    """Model of the device partition: sub-graph of the components owned by `rank`, vertices in ascending global
+    idx, links in L-line order, + the global ids (1-based) of its components."""
     keep_v = owner[comp] == rank
     new_idx = np.cumsum(keep_v) - 1
     keep_e = keep_v[links.v1]
     sub = Links(links.vid[keep_v], new_idx[links.v1[keep_e]].astype(np.uint32), links.s1[keep_e],
                 new_idx[links.v2[keep_e]].astype(np.uint32), links.s2[keep_e])
-    comp_ids = np.unique(comp[keep_v]) + 1  # 1-based global component ids, ascending
+    comp_ids = np.unique(comp[keep_v]) + 1
     return sub, comp_ids
 
 
-def _flat(forest, id_map=None):
-    """Forest -> (header int32 [n_trees, 2] = (component id, n_pvst), payload int32 bit-view of
-    [a_id | z_id | parent | orientation bits] per tree)."""
-    hdr, pay = [], []
-    for i in range(len(forest)):
-        t = forest.tree(i)
-        cid = t.component_id if id_map is None else int(id_map[t.component_id - 1])
-        n = t.a_id.shape[0]
-        hdr.append((cid, n))
-        pay += [t.a_id.astype(np.uint32, copy=False), t.z_id.astype(np.uint32, copy=False),
-                t.parent.astype(np.uint32, copy=False),
-                t.a_or.astype(np.uint32) | (t.z_or.astype(np.uint32) << 1)]
-    h = np.array(hdr, dtype=np.int32).reshape(-1, 2)
-    p = np.concatenate(pay) if pay else np.zeros(0, dtype=np.uint32)
-    return h, np.ascontiguousarray(p).view(np.int32)
+SHARD_MAGIC = 0x31647268735F7670  # "pv_shrd1"
 
 
-def _unpack(out, hh, pp):
-    pp = pp.view(np.uint32)
-    off = 0
-    for cid, n in hh.reshape(-1, 2).tolist():
-        blk = pp[off:off + 4 * n]
-        out[int(cid)] = dict(a_id=blk[:n], z_id=blk[n:2 * n], parent=blk[2 * n:3 * n],
-                             a_or=(blk[3 * n:] & 1).astype(np.uint8), z_or=((blk[3 * n:] >> 1) & 1).astype(np.uint8))
-        off += 4 * n
-
-
-def _views(out, hdr, block, total, offs, id_map=None):
-    """Slice one rank's raw block (numpy uint8) into per-component array views (no copies)."""
-    a = block[offs[0]:offs[0] + 4 * total].view(np.uint32)
-    z = block[offs[1]:offs[1] + 4 * total].view(np.uint32)
-    p = block[offs[2]:offs[2] + 4 * total].view(np.uint32)
-    ao = block[offs[3]:offs[3] + total]
-    zo = block[offs[4]:offs[4] + total]
-    for cid, n, first in hdr.reshape(-1, 3).tolist():
-        if id_map is not None:
-            cid = int(id_map[cid - 1])
-        sl = slice(first, first + n)
-        out[int(cid)] = dict(a_id=a[sl], z_id=z[sl], parent=p[sl], a_or=ao[sl], z_or=zo[sl])
-
-
-_pinned_cache = {}
-
-
-def _pinned(nbytes: int, key):
-    import torch
-    t = _pinned_cache.get(key)
-    if t is None or t.numel() < nbytes:
-        t = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-        _pinned_cache[key] = t
-    return t[:nbytes]
-
-
-def gather_forest(forest, rank: int, world: int, device, id_map=None) -> Dict[int, dict] | None:
-    """PVST gather to rank 0.  One all-gather of the sizes, then point-to-point payloads (RCCL
-    send/recv over xGMI on GPUs, gloo on CPU); no collective touches the traversal itself.
-    A HIP forest ships its page-locked result block as is (one H2D, one send per rank; rank 0 lands
-    the blocks in pinned memory and slices views); other forest objects go through `_flat`."""
-    import torch
-    import torch.distributed as dist
-
-    if not hasattr(forest, "raw"):
-        return _gather_flat(forest, rank, world, device, id_map)
-    block, total, offs, hdr = forest.raw()
-    if id_map is not None and len(hdr):
-        hdr = hdr.copy()
-        hdr[:, 0] = np.asarray(id_map, dtype=np.int64)[hdr[:, 0] - 1]
-    meta = np.array([hdr.shape[0], block.shape[0], total] + offs, dtype=np.int64)
-    all_meta = torch.zeros(8 * world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(all_meta, torch.from_numpy(meta).to(device))
-    if rank != 0:
-        if hdr.shape[0]:
-            dist.send(torch.from_numpy(hdr.reshape(-1)).to(device), 0)
-            dist.send(torch.from_numpy(block).to(device, non_blocking=True), 0)
-        return None
-    out: Dict[int, dict] = {}
-    _views(out, hdr, block, total, offs)
-    am = all_meta.cpu().numpy().reshape(world, 8)
-    pending = []
-    for r in range(1, world):
-        nh, nb = int(am[r, 0]), int(am[r, 1])
-        if nh == 0:
-            continue
-        hb = torch.empty(3 * nh, dtype=torch.int64, device=device)
-        bb = torch.empty(nb, dtype=torch.uint8, device=device)
-        dist.recv(hb, r)
-        dist.recv(bb, r)
-        pending.append((r, hb, bb))
-    landed = []
-    for r, hb, bb in pending:  # device -> pinned host, all copies in flight before the single sync
-        host = _pinned(bb.numel(), ("blk", r))
-        host.copy_(bb, non_blocking=True)
-        landed.append((r, hb.cpu().numpy(), host))
-    if device.type == "cuda":
-        torch.cuda.current_stream().synchronize()
-    for r, h, host in landed:
-        _views(out, h, host.numpy(), int(am[r, 2]), [int(x) for x in am[r, 3:8]])
+def pack_shard(sub: Links, tips: np.ndarray, comp_ids, total_components: int) -> np.ndarray:
+    """Model of the packed shard format of shard.hip (the bytes `Shards.export` returns): header of 8 u64
+    [magic, n_vtx, n_links, n_components, components of the whole graph, 0, 0, 0], then vid | v1 | v2 | s1 | s2 |
+    tip | component ids, every section padded to 256 bytes."""
+    nv, ne, nc = sub.n_vtx, sub.n_links, len(comp_ids)
+    pad = lambda b: (b + 255) & ~255  # noqa: E731
+    secs = [np.ascontiguousarray(sub.vid, dtype=np.uint32).view(np.uint8), np.ascontiguousarray(sub.v1, dtype=np.uint32).view(np.uint8),
+            np.ascontiguousarray(sub.v2, dtype=np.uint32).view(np.uint8), np.ascontiguousarray(sub.s1, dtype=np.uint8),
+            np.ascontiguousarray(sub.s2, dtype=np.uint8), np.ascontiguousarray(tips, dtype=np.uint8),
+            np.ascontiguousarray(comp_ids, dtype=np.uint32).view(np.uint8)]
+    out = np.zeros(256 + sum(pad(x.size) for x in secs), dtype=np.uint8)
+    out[:64].view(np.uint64)[:5] = (SHARD_MAGIC, nv, ne, nc, total_components)
+    o = 256
+    for x in secs:
+        out[o:o + x.size] = x
+        o += pad(x.size)
     return out
 
 
-class PipelinedGather:
-    """PVST gather to rank 0 that overlaps with the next decompose (one process per GPU).
+def infer_tips(links: Links) -> np.ndarray:
+    """Tips as the loader infers them (src/mto/from_gfa.cpp:262-277): 1 = no link on the l side, else 2 = none on r."""
+    has = np.zeros(2 * links.n_vtx, dtype=bool)
+    has[2 * links.v1.astype(np.int64) + links.s1] = True
+    has[2 * links.v2.astype(np.int64) + links.s2] = True
+    l, r = has[0::2], has[1::2]
+    return np.where(~l, 1, np.where(~r, 2, 0)).astype(np.uint8)
 
-    submit() posts this step's transfers and returns at once: senders `isend` their forest's pinned
-    block (kept alive until the send has completed), rank 0 posts `irecv`s into device buffers and
-    queues the device-to-pinned-host copies behind them on the current stream.  Buffers are double
-    buffered by step parity, so step k's traffic runs under step k+1's kernels.  finish() drains
-    everything and returns the component views of the LAST submitted step (rank 0) / None.
-    """
 
-    def __init__(self, rank: int, world: int, device):
-        self.rank, self.world, self.device = rank, world, device
-        self.step = 0
-        self.inflight = []          # per step: list of (work, keep-alive objects)
-        self.landed = None          # rank 0: what the last step put into host memory
-        self._dev = {}              # (parity, peer, kind) -> device buffer
+def unpack_shard(buf: np.ndarray):
+    """Packed shard bytes -> (Links, tips, component ids, total components): the layout of shard.hip."""
+    h = buf[:64].view(np.uint64)
+    nv, ne, nc, total = int(h[1]), int(h[2]), int(h[3]), int(h[4])
+    pad = lambda b: (b + 255) & ~255  # noqa: E731
+    o = 256
+    sec = {}
+    for name, nb in (("vid", nv * 4), ("v1", ne * 4), ("v2", ne * 4), ("s1", ne), ("s2", ne), ("tip", nv), ("ids", nc * 4)):
+        sec[name] = buf[o:o + nb]
+        o += pad(nb)
+    u32 = lambda x: x.view(np.uint32).copy()  # noqa: E731
+    return (Links(u32(sec["vid"]), u32(sec["v1"]), sec["s1"].copy(), u32(sec["v2"]), sec["s2"].copy()), sec["tip"].copy(),
+            u32(sec["ids"]), total)
 
-    def _buf(self, key, n, dtype):
-        import torch
-        t = self._dev.get(key)
-        if t is None or t.numel() < n:
-            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
-            self._dev[key] = t
-        return t[:n]
 
-    def _drain(self, keep_last: int):
-        while len(self.inflight) > keep_last:
-            for work, _keep in self.inflight.pop(0):
-                work.wait()
+# ---------------------------------------------------------------- RCCL path (C++)
+class ShardComm:
+    """RCCL communicator owned by the C library, bound to one HipDecomposer (its stream carries the transfers).
+    The unique id is created on rank 0 and broadcast with torch.distributed (any backend)."""
 
-    def submit(self, forest, id_map=None):
-        import torch
+    def __init__(self, hip: "_hip.HipDecomposer", rank: int, world: int):
         import torch.distributed as dist
 
-        par = self.step & 1
-        self.step += 1
-        self._drain(1)  # the buffers of this parity were used two steps ago: make sure they are free
-        block, total, offs, hdr = forest.raw()
-        if id_map is not None and len(hdr):
-            hdr = hdr.copy()
-            hdr[:, 0] = np.asarray(id_map, dtype=np.int64)[hdr[:, 0] - 1]
-        meta = np.array([hdr.shape[0], block.shape[0], total] + offs, dtype=np.int64)
-        all_meta = torch.zeros(8 * self.world, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(all_meta, torch.from_numpy(meta).to(self.device))
-        works = []
-        if self.rank != 0:
-            if hdr.shape[0]:
-                ht = torch.from_numpy(hdr.reshape(-1)).to(self.device)
-                bt = torch.from_numpy(block).to(self.device, non_blocking=True)
-                works.append((dist.isend(ht, 0), (ht, forest)))
-                works.append((dist.isend(bt, 0), (bt, forest)))
-            self.inflight.append(works)
-            return
-        am = all_meta.cpu().numpy().reshape(self.world, 8)
-        landed = [(0, hdr, block, total, offs, forest)]
-        for r in range(1, self.world):
-            nh, nb = int(am[r, 0]), int(am[r, 1])
-            if nh == 0:
-                continue
-            hb = self._buf((par, r, "h"), 3 * nh, torch.int64)
-            bb = self._buf((par, r, "b"), nb, torch.uint8)
-            wh, wb = dist.irecv(hb, r), dist.irecv(bb, r)
-            wh.wait()   # NCCL: orders the current stream behind the transfer, the host does not block
-            wb.wait()
-            hh = _pinned(3 * nh * 8, ("ph", par, r)).view(torch.int64)
-            host = _pinned(nb, ("pb", par, r))
-            hh.copy_(hb, non_blocking=True)
-            host.copy_(bb, non_blocking=True)
-            landed.append((r, hh, host, int(am[r, 2]), [int(x) for x in am[r, 3:8]], None))
-        self.inflight.append(works)
-        self.landed = landed
+        self._lib = _hip.load_lib()
+        self.hip, self.rank, self.world = hip, rank, world
+        err = C.create_string_buffer(512)
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            if self._lib.povu_hip_comm_unique_id(buf, err, 512) != 0:
+                raise RuntimeError(err.value.decode())
+            ident[0] = buf.raw
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self._h = self._lib.povu_hip_comm_create(hip._ctx, ident[0], rank, world, err, 512)
+        if not self._h:
+            raise RuntimeError(err.value.decode())
 
-    def finish(self) -> Dict[int, dict] | None:
-        import torch
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.povu_hip_comm_destroy(self._h)
+            self._h = None
 
-        self._drain(0)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize()
-        if self.rank != 0 or self.landed is None:
-            return None
-        out: Dict[int, dict] = {}
-        for r, h, blk, total, offs, _keep in self.landed:
-            hn = h if isinstance(h, np.ndarray) else h.numpy()
-            bn = blk if isinstance(blk, np.ndarray) else blk.numpy()
-            _views(out, hn, bn, total, offs)
-        return out
+    def __del__(self):
+        self.close()
+
+    def scatter(self, shards: Optional["_hip.Shards"]):
+        """Root: `shards` = the partition of its full graph; others: None.  Afterwards every rank's decomposer
+        holds its shard as resident graph."""
+        err = C.create_string_buffer(512)
+        if self._lib.povu_hip_comm_scatter(self._h, shards._h if shards is not None else None, self.hip._ctx, err, 512) != 0:
+            raise RuntimeError(err.value.decode())
+
+    def gather(self, forest: "_hip.Forest") -> "_hip.Forest":
+        """Every rank passes the forest of its shard (global component ids); the root gets the merged forest (it
+        takes over the arrays of the root's own forest), the others an empty one."""
+        err = C.create_string_buffer(512)
+        h = self._lib.povu_hip_comm_gather(self._h, forest._h, err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return _hip.Forest(self._lib, h)
+
+    def times(self) -> dict:
+        t = (C.c_double * 2)()
+        self._lib.povu_hip_comm_times(self._h, t)
+        return dict(scatter_ms=t[0], gather_ms=t[1])
 
 
-def _gather_flat(forest, rank: int, world: int, device, id_map=None) -> Dict[int, dict] | None:
-    import torch
-    import torch.distributed as dist
-
-    h, p = _flat(forest, id_map)
-    sizes = torch.tensor([h.shape[0], p.shape[0]], dtype=torch.int64, device=device)
-    all_sizes = torch.zeros(2 * world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(all_sizes, sizes)
-    if rank != 0:
-        if h.shape[0]:
-            buf = torch.from_numpy(np.concatenate([h.reshape(-1), p])).to(device)
-            dist.send(buf, 0)
-        return None
-    out: Dict[int, dict] = {}
-    _unpack(out, h, p)
-    szs = all_sizes.cpu().numpy().reshape(world, 2)
-    bufs = []
-    for r in range(1, world):
-        nh, npay = int(szs[r, 0]), int(szs[r, 1])
-        if nh == 0:
-            continue
-        b = torch.empty(2 * nh + npay, dtype=torch.int32, device=device)
-        dist.recv(b, r)
-        bufs.append((nh, b))
-    for nh, b in bufs:
-        a = b.cpu().numpy()
-        _unpack(out, a[:2 * nh], a[2 * nh:])
-    return out
-
-
-def scatter_links(links: Links | None, rank: int, world: int, device):
-    """Initial component scatter: rank 0 labels components, bin-packs them and sends every rank the
-    link slice of its components.  Returns (sub-graph, global component ids of the shard)."""
+# ---------------------------------------------------------------- the same over torch.distributed, through host memory
+def scatter_over_dist(full: Optional["_hip.HipDecomposer"], work: "_hip.HipDecomposer", rank: int, world: int, device):
+    """Scatter with any torch.distributed backend (gloo in the CPU-side tests, single-GPU rehearsals): the root
+    partitions on its GPU, exports every packed shard to host memory and sends it; receivers load it."""
     import torch
     import torch.distributed as dist
 
     if rank == 0:
-        comp = component_labels(links)
-        nc = int(comp.max()) + 1
-        wv = np.bincount(comp, minlength=nc)
-        we = np.bincount(comp[links.v1], minlength=nc)
-        owner = assign_owners(wv + we, world)
-        parts = [partition_links(links, comp, owner, r) for r in range(world)]
+        shards = full.partition(world)
+        sizes = torch.tensor([shards.info(r)["bytes"] for r in range(world)], dtype=torch.int64, device=device)
+    else:
+        shards = None
+        sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.broadcast(sizes, src=0)
+    if rank == 0:
+        pending = []
         for r in range(1, world):
-            sub, ids = parts[r]
-            meta = torch.tensor([sub.n_vtx, sub.n_links, len(ids)], dtype=torch.int64, device=device)
-            dist.send(meta, r)
-            for arr in (sub.vid, sub.v1, sub.s1, sub.v2, sub.s2, ids):
-                if len(arr):
-                    dist.send(torch.from_numpy(np.asarray(arr).astype(np.int64)).to(device), r)
-        return parts[0]
-    meta = torch.zeros(3, dtype=torch.int64, device=device)
-    dist.recv(meta, 0)
-    nv, ne, nid = (int(x) for x in meta.tolist())
-    got = []
-    for n in (nv, ne, ne, ne, ne, nid):
-        t = torch.zeros(n, dtype=torch.int64, device=device)
-        if n:
-            dist.recv(t, 0)
-        got.append(t.cpu().numpy())
-    sub = Links(got[0].astype(np.uint32), got[1].astype(np.uint32), got[2].astype(np.uint8),
-                got[3].astype(np.uint32), got[4].astype(np.uint8))
-    return sub, got[5].astype(np.int64)
+            t = torch.from_numpy(shards.export(r)).to(device)
+            pending.append((dist.isend(t, r), t))
+        i0 = shards.info(0)
+        work.upload_shard(i0["device_ptr"], i0["bytes"], on_device=True)
+        for w, _t in pending:
+            w.wait()
+        return shards
+    buf = torch.zeros(int(sizes[rank].item()), dtype=torch.uint8, device=device)
+    dist.recv(buf, 0)
+    work.upload_shard(buf.cpu().numpy())
+    return None
+
+
+def gather_over_dist(work: "_hip.HipDecomposer", forest: "_hip.Forest", rank: int, world: int, device):
+    """PVST gather to rank 0 over torch.distributed: packed forests through host memory, merged by the library."""
+    import torch
+    import torch.distributed as dist
+
+    mine = forest.pack()
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    sizes[rank] = mine.size
+    dist.all_reduce(sizes)
+    if rank != 0:
+        dist.send(torch.from_numpy(mine).to(device), 0)
+        return None
+    parts = [mine]
+    for r in range(1, world):
+        b = torch.zeros(int(sizes[r].item()), dtype=torch.uint8, device=device)
+        dist.recv(b, r)
+        parts.append(b.cpu().numpy())
+    return work.merge_forests(parts)
+
+
+# ---------------------------------------------------------------- strong-scaling bench driver
+class ShardedBench:
+    """bench.py --gpus N: the SAME graph every step, sharded over N ranks.  Rank 0 keeps the whole graph resident in
+    a context of its own (`full`); a step = partition on rank 0's GPU, scatter, per-shard CSR build + decompose on
+    every rank, gather of the PVST arrays to rank 0 -- all inside the timed region."""
+
+    def __init__(self, work: "_hip.HipDecomposer", rank: int, world: int, comm_device, build_workload, device_index: int = 0):
+        import torch.distributed as dist
+
+        self.work, self.rank, self.world, self.dev = work, rank, world, comm_device
+        self.native = comm_device.type == "cuda"  # RCCL from C++; otherwise torch.distributed through host memory
+        self.full = None
+        self.meta = None
+        if rank == 0:
+            g, wl = build_workload()
+            self.full = _hip.HipDecomposer(device_index)
+            self.full.upload(g)
+            self.meta = dict(workload=wl, links=g.n_links, segments=g.n_vtx)
+            del g
+        self.comm = ShardComm(work, rank, world) if self.native else None
+        self.phase = dict(partition=0.0, scatter=0.0, decompose=0.0, gather=0.0)
+        self.steps = 0
+        self.last = None
+        self.last_shards = None
+        dist.barrier()
+
+    def step(self):
+        import torch
+
+        t0 = time.perf_counter()
+        shards = None
+        if self.native:
+            if self.rank == 0:
+                shards = self.full.partition(self.world)
+            t1 = time.perf_counter()
+            self.comm.scatter(shards)
+        else:
+            t1 = t0
+            shards = scatter_over_dist(self.full, self.work, self.rank, self.world, self.dev)
+        t2 = time.perf_counter()
+        f = self.work.decompose_shard(flags=_hip.F_NO_STAGE_TIMES)
+        t3 = time.perf_counter()
+        merged = self.comm.gather(f) if self.native else gather_over_dist(self.work, f, self.rank, self.world, self.dev)
+        t4 = time.perf_counter()
+        self.phase["partition"] += t1 - t0
+        self.phase["scatter"] += t2 - t1
+        self.phase["decompose"] += t3 - t2
+        self.phase["gather"] += t4 - t3
+        self.steps += 1
+        if self.rank == 0:
+            self.last, self.last_shards = merged, shards
+        del f
+        return merged
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def reset_phases(self):
+        self.phase = {k: 0.0 for k in self.phase}
+        self.steps = 0
+
+    def summary(self) -> Optional[dict]:
+        """Collective: per-rank phase times; rank 0 returns the description of the job."""
+        import torch
+        import torch.distributed as dist
+
+        n = max(1, self.steps)
+        mine = torch.tensor([self.phase[k] / n * 1e3 for k in ("partition", "scatter", "decompose", "gather")], dtype=torch.float64,
+                            device=self.dev)
+        allp = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allp, mine)
+        if self.rank != 0:
+            return None
+        sh = self.last_shards
+        shards = [sh.info(r) for r in range(self.world)]
+        for s in shards:
+            s.pop("device_ptr", None)
+        mean_w = sum(s["weight"] for s in shards) / self.world
+        flub = 0
+        f = self.last
+        ids = f.component_ids()
+        lib = f._lib
+        t = _hip._Tree()
+        for i in range(len(f)):
+            lib.povu_hip_forest_get(f._h, i, C.byref(t))
+            flub += t.n_pvst - 1
+        out = dict(self.meta)
+        out.update(components=len(ids), flubbles=flub, shards=shards,
+                   lpt_max_over_mean=max(s["weight"] for s in shards) / mean_w,
+                   sharding=("strong scaling: rank 0 labels the components on its GPU, LPT bin-packing, device partition, "
+                             + ("RCCL ncclSend/ncclRecv scatter of the packed shards and gather of the PVST blocks (C++, shard.hip)"
+                                if self.native else "scatter / gather over torch.distributed through host memory (rehearsal)")
+                             + "; all inside the timed region"),
+                   phase_ms={"per_rank": [dict(zip(("partition", "scatter", "decompose", "gather"), [float(x) for x in p.tolist()]))
+                                          for p in allp],
+                             "partition_device": sh.times()})
+        return out
+
+    def close(self):
+        if self.comm:
+            self.comm.close()
+        if self.full:
+            self.full.close()

@@ -1,6 +1,10 @@
-"""Two ranks on the one GPU of the test box (gloo for the exchange, HIP for the decompose): component
-scatter from rank 0, per-rank HIP decompose, PVST gather of the raw pinned blocks to rank 0."""
-import hashlib
+"""Component sharding on the GPU (povu_amd/csrc/hip/shard.hip):
+* the device partition against the numpy model of tests/test_sharding_gloo.py, byte for byte;
+* every shard loaded and decomposed in turn, forests packed and merged = the whole-graph oracle (also with more
+  ranks than components);
+* two processes on the one GPU of the test box, shards and forests moved over gloo through host memory;
+* the RCCL communicator of the library with a world of one rank (dlopen, ncclCommInitRank, broadcast /
+  all-gather of the size tables on the context's stream, scatter and gather degenerate to the root's own shard)."""
 import os
 import socket
 
@@ -28,55 +32,139 @@ def _graph():
     return W.hprc_shaped([4000, 1500, 2500, 900], seed=17, tiny=30)
 
 
+def _model_shards(g, world):
+    comp = sharded.component_labels(g)
+    nc = int(comp.max()) + 1
+    w = np.bincount(comp, minlength=nc) + np.bincount(comp[g.v1], minlength=nc)
+    owner = sharded.assign_owners(w, world)
+    tips = sharded.infer_tips(g)
+    out = []
+    for r in range(world):
+        sub, ids = sharded.partition_links(g, comp, owner, r)
+        out.append(sharded.pack_shard(sub, tips[owner[comp] == r], ids, nc))
+    return out, nc
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("kind", ["hprc", "random", "isolated"])
+def test_device_partition_matches_model(world, kind):
+    from povu_amd import HipDecomposer
+    if kind == "hprc":
+        g = _graph()
+    elif kind == "random":
+        g = W.random_bidirected(3000, 3300, seed=4)
+    else:  # mostly isolated vertices and tiny components
+        g = W.random_bidirected(2000, 300, seed=9)
+    hip = HipDecomposer(0)
+    hip.upload(g)
+    sh = hip.partition(world)
+    want, nc = _model_shards(g, world)
+    assert sh.world == world and sh.total_components == nc
+    for r in range(world):
+        got = sh.export(r)
+        assert got.size == want[r].size, (r, got.size, want[r].size)
+        assert np.array_equal(got, want[r]), r
+    hip.close()
+
+
+@pytest.mark.parametrize("world", [2, 5, 64])
+def test_shards_decomposed_in_turn_merge_to_the_whole(world):
+    from povu_amd import HipDecomposer
+    g = _graph() if world != 64 else W.hprc_shaped([700, 300], seed=2, tiny=12)  # 64 ranks > components: empty shards
+    full, work = HipDecomposer(0), HipDecomposer(0)
+    full.upload(g)
+    sh = full.partition(world)
+    packed = []
+    for r in range(world):
+        i = sh.info(r)
+        work.upload_shard(i["device_ptr"], i["bytes"], on_device=True)
+        assert work.shard_total_components() == sh.total_components
+        f = work.decompose_shard()
+        packed.append(f.pack())
+        del f
+    merged = work.merge_forests(packed)
+    # the merged forest owns its blocks: later work on the context must not disturb it
+    work.upload(W.chain_of_bubbles(500))
+    for _ in range(3):
+        work.decompose()
+    assert merged.total_components == sh.total_components
+    ids = merged.component_ids()
+    assert ids == sorted(ids)
+    assert merged.texts() == O.decompose(g)
+    # the host-memory route (what another transport ships) loads the same shard
+    work.upload_shard(sh.export(0))
+    assert work.decompose_shard().texts() == {k: v for k, v in O.decompose(g).items() if k in set(
+        sharded.unpack_shard(sh.export(0))[2].tolist())}
+    full.close()
+    work.close()
+
+
 def _worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     from povu_amd import HipDecomposer
-    g = _graph() if rank == 0 else None
-    sub, comp_ids = sharded.scatter_links(g, rank, world, dev)
-    hip = HipDecomposer(0)
-    hip.upload(sub)
-    pg = sharded.PipelinedGather(rank, world, dev)
-    for _ in range(3):  # the gather of one step runs under the next decompose
-        pg.submit(hip.decompose(), id_map=comp_ids)
-    got = pg.finish()
-    again = sharded.gather_forest(hip.decompose(), rank, world, dev, id_map=comp_ids)
+    work = HipDecomposer(0)
+    full = None
     if rank == 0:
-        assert sorted(got) == sorted(again)
-        for k in got:
-            for f in ("a_id", "z_id", "parent", "a_or", "z_or"):
-                assert np.array_equal(np.array(got[k][f]), np.array(again[k][f]))
+        full = HipDecomposer(0)
+        full.upload(_graph())
+    merged = None
+    for _ in range(2):  # a second round reuses every buffer
+        sharded.scatter_over_dist(full, work, rank, world, dev)
+        f = work.decompose_shard()
+        merged = sharded.gather_over_dist(work, f, rank, world, dev)
     if rank == 0:
-        torch.save({k: {kk: torch.from_numpy(np.array(vv).astype(np.int64)) for kk, vv in v.items()} for k, v in got.items()},
-                   out_path)
+        work.decompose_shard()  # more work on the context after the gather: the merged forest keeps its own blocks
+        torch.save(merged.texts(), out_path)
     dist.barrier()
-    hip.close()
+    work.close()
+    if full:
+        full.close()
     dist.destroy_process_group()
 
 
 def test_two_ranks_scatter_hip_decompose_gather(tmp_path):
-    import ctypes as C
-    from povu_amd import hip as H
     out = str(tmp_path / "gathered.pt")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    got = torch.load(out)
-    want = O.decompose(_graph())
-    assert sorted(got) == sorted(want)
-    hl = H.load_lib()
-    hl.povu_hip_pvst_format.restype = C.c_void_p
-    hl.povu_hip_pvst_format.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.POINTER(C.c_size_t)]
-    for cid, arrs in got.items():
-        a = arrs["a_id"].numpy().astype(np.uint32)
-        z = arrs["z_id"].numpy().astype(np.uint32)
-        p = arrs["parent"].numpy().astype(np.uint32)
-        ao = arrs["a_or"].numpy().astype(np.uint8)
-        zo = arrs["z_or"].numpy().astype(np.uint8)
-        ln = C.c_size_t(0)
-        ptr = hl.povu_hip_pvst_format(len(a), a.ctypes.data, z.ctypes.data, ao.ctypes.data, zo.ctypes.data, p.ctypes.data,
-                                      C.byref(ln))
-        text = C.string_at(ptr, ln.value).decode()
-        hl.povu_hip_buffer_free(ptr)
-        assert text == want[cid], cid
+    assert torch.load(out) == O.decompose(_graph())
+
+
+def test_rccl_communicator_world_of_one():
+    from povu_amd import HipDecomposer
+    g = _graph()
+    full, work = HipDecomposer(0), HipDecomposer(0)
+    full.upload(g)
+    comm = sharded.ShardComm(work, 0, 1)
+    for _ in range(2):
+        sh = full.partition(1)
+        comm.scatter(sh)
+        del sh  # the partition may go once the scatter has returned
+        f = work.decompose_shard()
+        merged = comm.gather(f)
+        assert len(f) == 0  # the root's arrays moved into the merged forest
+        assert merged.texts() == O.decompose(g)
+    t = comm.times()
+    assert t["scatter_ms"] > 0 and t["gather_ms"] > 0
+    comm.close()
+    full.close()
+    work.close()
+
+
+def test_bench_rehearsal_two_ranks_one_gpu(tmp_path):
+    """bench.py --gpus 2 on one GPU (gloo through host memory): the strong-scaling driver end to end."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POVU_BENCH_BACKEND="gloo", POVU_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--scale", "0.002"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["components"] == 2024 and len(line["shards"]) == 2
+    assert sum(s["n_links"] for s in line["shards"]) == line["config"]["links"]

@@ -1,6 +1,8 @@
-"""Multi-process path on CPU (gloo, world_size 2): component scatter from rank 0, per-rank decompose,
-PVST gather to rank 0.  The per-rank decompose is the oracle here (no GPU in this container); on the
-GPU box the same glue drives HipDecomposer (bench.py, tests/test_gpu_sharded.py)."""
+"""Multi-process path on CPU (gloo): the component scatter / PVST gather protocol of povu_amd/sharded.py without
+a GPU.  What runs here: the library's LPT rule (povu_hip_lpt_assign, host only), the numpy model of the device
+partition, the packed shard wire format, world_size 2 and 4 exchanges over gloo with the oracle standing in for
+the per-shard decompose.  On the GPU box tests/test_gpu_sharded.py checks the device partition against the same
+model byte for byte and drives the HIP path."""
 import os
 import socket
 
@@ -12,59 +14,6 @@ import torch.multiprocessing as mp
 
 import oracle_lib as O
 from povu_amd import sharded, workloads as W
-from test_oracle import dump_component
-
-
-class _Tree:
-    def __init__(self, cid, d):
-        self.component_id = cid
-        self.a_id, self.z_id, self.parent = d["p_a_id"], d["p_z_id"], d["p_parent"]
-        n = len(self.parent)
-        self.a_or, self.z_or = d["p_a_or"], d["p_z_or"]
-        assert len(self.a_or) == n
-
-
-class OracleForest:
-    """Same surface as povu_amd.hip.Forest (len / tree(i)), backed by the oracle."""
-
-    def __init__(self, links):
-        self.trees = []
-        c = 0
-        while True:
-            d = dump_component(links, c)
-            if d is None:
-                break
-            if len(d["p_parent"]):
-                self.trees.append(_Tree(c + 1, d))
-            c += 1
-
-    def __len__(self):
-        return len(self.trees)
-
-    def tree(self, i):
-        return self.trees[i]
-
-
-class OracleForestRaw(OracleForest):
-    """... plus the raw-block surface of povu_amd.hip.Forest (one contiguous result block)."""
-
-    def raw(self):
-        total = sum(len(t.parent) for t in self.trees)
-        pad = lambda n: (n + 63) // 64 * 64  # noqa: E731
-        offs = [0, pad(4 * total), 2 * pad(4 * total), 3 * pad(4 * total), 3 * pad(4 * total) + pad(total)]
-        block = np.zeros(offs[4] + pad(total) + 64, dtype=np.uint8)
-        hdr = np.zeros((len(self.trees), 3), dtype=np.int64)
-        first = 0
-        for k, t in enumerate(self.trees):
-            n = len(t.parent)
-            hdr[k] = (t.component_id, n, first)
-            block[offs[0] + 4 * first:offs[0] + 4 * (first + n)] = t.a_id.astype(np.uint32).view(np.uint8)
-            block[offs[1] + 4 * first:offs[1] + 4 * (first + n)] = t.z_id.astype(np.uint32).view(np.uint8)
-            block[offs[2] + 4 * first:offs[2] + 4 * (first + n)] = t.parent.astype(np.uint32).view(np.uint8)
-            block[offs[3] + first:offs[3] + first + n] = t.a_or
-            block[offs[4] + first:offs[4] + first + n] = t.z_or
-            first += n
-        return block, total, offs, hdr
 
 
 def _free_port():
@@ -75,90 +24,110 @@ def _free_port():
     return p
 
 
-def _worker_pipelined(rank, world, port, out_path):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu")
-    g = W.hprc_shaped([300, 120, 500, 80], seed=9, tiny=12) if rank == 0 else None
-    sub, comp_ids = sharded.scatter_links(g, rank, world, dev)
-    pg = sharded.PipelinedGather(rank, world, dev)
-    for _ in range(4):  # several steps in flight, as bench.py does
-        pg.submit(OracleForestRaw(sub), id_map=comp_ids)
-    got = pg.finish()
-    if rank == 0:
-        torch.save({k: {kk: torch.from_numpy(np.array(vv).astype(np.int64)) for kk, vv in v.items()} for k, v in got.items()},
-                   out_path)
-    dist.barrier()
-    dist.destroy_process_group()
+def _graph(kind):
+    if kind == "skewed":  # a few large components of very different sizes + many tiny ones
+        return W.hprc_shaped([3000, 300, 2500, 2800, 700, 1800, 120, 2900, 1500, 2200, 900], seed=5, tiny=60)
+    return W.hprc_shaped([1200, 400, 800, 300], seed=11, tiny=25)
 
 
-def test_pipelined_gather_world2(tmp_path):
-    out = str(tmp_path / "gathered.pt")
-    mp.spawn(_worker_pipelined, args=(2, _free_port(), out), nprocs=2, join=True)
-    got = torch.load(out)
-    whole = OracleForest(W.hprc_shaped([300, 120, 500, 80], seed=9, tiny=12))
-    assert sorted(got) == [t.component_id for t in whole.trees]
-    for t in whole.trees:
-        r = got[t.component_id]
-        assert np.array_equal(r["a_id"].numpy(), t.a_id) and np.array_equal(r["z_id"].numpy(), t.z_id)
-        assert np.array_equal(r["parent"].numpy(), t.parent)
-        assert np.array_equal(r["a_or"].numpy(), t.a_or) and np.array_equal(r["z_or"].numpy(), t.z_or)
-
-
-def _worker(rank, world, port, out_path):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu")
-    g = W.hprc_shaped([300, 120, 500, 80], seed=9, tiny=12) if rank == 0 else None
-    sub, comp_ids = sharded.scatter_links(g, rank, world, dev)
-    forest = OracleForest(sub)
-    # shard-local component numbering -> global ids
-    got = sharded.gather_forest(forest, rank, world, dev, id_map=comp_ids)
-    if rank == 0:
-        torch.save({k: {kk: torch.from_numpy(vv.astype(np.int64)) for kk, vv in v.items()} for k, v in got.items()},
-                   out_path)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_scatter_decompose_gather_world2(tmp_path):
-    out = str(tmp_path / "gathered.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    got = torch.load(out)
-    g = W.hprc_shaped([300, 120, 500, 80], seed=9, tiny=12)
-    whole = OracleForest(g)
-    assert sorted(got) == [t.component_id for t in whole.trees]
-    for t in whole.trees:
-        r = got[t.component_id]
-        assert np.array_equal(r["a_id"].numpy(), t.a_id) and np.array_equal(r["z_id"].numpy(), t.z_id)
-        assert np.array_equal(r["parent"].numpy(), t.parent)
-        assert np.array_equal(r["a_or"].numpy(), t.a_or) and np.array_equal(r["z_or"].numpy(), t.z_or)
-
-
-def test_lpt_assignment_balances_and_is_deterministic():
-    w = [800, 10, 10, 700, 650, 5, 300, 300, 40, 40, 40]
-    o = sharded.assign_owners(w, 3)
-    assert o.tolist() == sharded.assign_owners(w, 3).tolist()
-    load = np.bincount(o, weights=np.asarray(w, dtype=float), minlength=3)
-    assert load.max() <= 1.25 * sum(w) / 3
-    assert sharded.assign_owners(w, 1).tolist() == [0] * len(w)
-
-
-def test_partition_keeps_global_component_order():
-    g = W.hprc_shaped([60, 40, 50], seed=2, tiny=6)
+def plan(g, world):
     comp = sharded.component_labels(g)
     nc = int(comp.max()) + 1
-    owner = sharded.assign_owners(np.bincount(comp, minlength=nc), 2)
-    seen = []
+    w = np.bincount(comp, minlength=nc) + np.bincount(comp[g.v1], minlength=nc)
+    return comp, nc, sharded.assign_owners(w, world), w
+
+
+def _worker(rank, world, port, kind, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # scatter: rank 0 plans and ships packed shards; everybody unpacks its own
+    if rank == 0:
+        g = _graph(kind)
+        comp, nc, owner, _ = plan(g, world)
+        tips = sharded.infer_tips(g)
+        packed = []
+        for r in range(world):
+            sub, ids = sharded.partition_links(g, comp, owner, r)
+            packed.append(sharded.pack_shard(sub, tips[owner[comp] == r], ids, nc))
+        sizes = torch.tensor([p.size for p in packed], dtype=torch.int64)
+    else:
+        sizes = torch.zeros(world, dtype=torch.int64)
+    dist.broadcast(sizes, src=0)
+    if rank == 0:
+        for r in range(1, world):
+            dist.send(torch.from_numpy(packed[r]), r)
+        mine = packed[0]
+    else:
+        buf = torch.zeros(int(sizes[rank]), dtype=torch.uint8)
+        dist.recv(buf, 0)
+        mine = buf.numpy()
+    sub, tips, ids, total = sharded.unpack_shard(mine)
+    # per-shard decompose (the oracle stands in for the HIP path), ids rewritten to those of the whole graph
+    local = O.decompose(sub, tips=tips) if sub.n_vtx else {}
+    texts = {int(ids[k - 1]): v for k, v in local.items()}
+    gathered = [None] * world
+    dist.gather_object((total, texts), gathered if rank == 0 else None, dst=0)
+    if rank == 0:
+        merged = {}
+        for tot, t in gathered:
+            assert tot == nc
+            assert not (set(t) & set(merged))
+            merged.update(t)
+        torch.save(merged, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "plain"), (4, "skewed")])
+def test_scatter_decompose_gather_over_gloo(tmp_path, world, kind):
+    out = str(tmp_path / "merged.pt")
+    mp.spawn(_worker, args=(world, _free_port(), kind, out), nprocs=world, join=True)
+    got = torch.load(out)
+    want = O.decompose(_graph(kind))
+    assert got == want
+
+
+def test_lpt_is_deterministic_and_balanced():
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 1000, size=200)
+    o = sharded.assign_owners(w, 3)
+    assert o.tolist() == sharded.assign_owners(w, 3).tolist()
+    loads = np.bincount(o, weights=w, minlength=3)
+    assert loads.max() - loads.min() <= w.max()
+    assert sharded.assign_owners(w, 1).tolist() == [0] * len(w)
+    # ties go to the lowest rank, heaviest first
+    assert sharded.assign_owners([5, 3, 9, 1, 1, 7], 3).tolist() == [2, 2, 0, 1, 0, 1]
+
+
+def test_lpt_load_on_skewed_components_world4():
+    """Skewed component sizes over 4 ranks: the busiest rank stays within 1.25x of the mean load."""
+    g = _graph("skewed")
+    comp, nc, owner, w = plan(g, 4)
+    loads = np.bincount(owner, weights=w + 1, minlength=4)
+    assert loads.max() <= 1.25 * loads.mean(), loads
+    assert loads.max() <= loads.mean() + (w + 1).max()  # the list-scheduling bound, whatever the sizes
+    # whole-genome shape (chromosome-sized components), 8 ranks
+    sizes = np.array(W.CHR_MBP, dtype=np.int64) * 400000
+    o8 = sharded.assign_owners(sizes, 8)
+    l8 = np.bincount(o8, weights=sizes + 1, minlength=8)
+    assert l8.max() <= 1.25 * l8.mean(), l8
+
+
+def test_partition_model_preserves_order_and_ids():
+    g = _graph("plain")
+    comp, nc, owner, _ = plan(g, 2)
+    whole = O.decompose(g)
+    seen = {}
     for r in range(2):
         sub, ids = sharded.partition_links(g, comp, owner, r)
-        assert np.all(np.diff(ids) > 0)
-        seen += ids.tolist()
-        # the shard decomposed alone gives the same PVSTs as those components of the whole graph
-        whole = O.decompose(g)
-        part = O.decompose(sub)
-        for k, text in part.items():
-            assert whole[int(ids[k - 1])] == text
-    assert sorted(seen) == list(range(1, nc + 1))
+        assert np.all(np.diff(sub.vid.astype(np.int64)) > 0)  # ascending global order kept
+        tips = sharded.infer_tips(g)[owner[comp] == r]
+        assert np.array_equal(tips, sharded.infer_tips(sub))  # a shard's tips are its own links' tips
+        back, tips2, ids2, total = sharded.unpack_shard(sharded.pack_shard(sub, tips, ids, nc))
+        assert total == nc and np.array_equal(ids2, ids) and np.array_equal(tips2, tips)
+        for f in ("vid", "v1", "v2", "s1", "s2"):
+            assert np.array_equal(getattr(back, f), getattr(sub, f))
+        for k, v in O.decompose(sub).items():
+            seen[int(ids[k - 1])] = v
+    assert seen == whole
