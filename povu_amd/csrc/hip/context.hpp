@@ -158,12 +158,13 @@ struct povu_hip_ctx {
 	// (1-based, ascending = the shard's own component order) and the component count of the whole graph
 	std::vector<uint32_t> shard_comp_ids;
 	uint32_t shard_total_components = 0;
-	Arena shard_buf; // a shard received from another rank
+	Arena shard_buf;   // a shard received from another rank
+	Arena graph_arena; // backs the resident graph
 };
 
 
 // device block of a resident graph (link arrays + CSR); build_global_csr fills the CSR part
-void alloc_resident_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given);
+void alloc_resident_graph(Arena &arena, ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given);
 void free_resident_graph(ResidentGraph &g);
 void check_graph_size(uint32_t n_vtx, uint32_t n_links);
 void set_err(char *err, size_t errlen, const std::string &msg);

@@ -51,9 +51,7 @@ extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
 
 void free_resident_graph(ResidentGraph &g)
 {
-	if (g.block)
-		(void)hipFree(g.block);
-	g = ResidentGraph{};
+	g = ResidentGraph{}; // the block belongs to the context's graph arena, which keeps it for the next graph
 }
 
 extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
@@ -67,41 +65,34 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	ctx->ws_seq.release();
 	ctx->upload_tmp.release();
 	ctx->shard_buf.release();
+	ctx->graph_arena.release();
 	if (ctx->stream)
 		(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
 
-// device block of a resident graph: the link arrays + CSR (off / adj / aoth / atwin)
-void alloc_resident_graph(ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given)
+// device block of a resident graph: the link arrays + CSR (off / adj / aoth / atwin), carved from the context's graph
+// arena (which only reallocates when a graph is larger than every one before it; the previous graph is gone afterwards)
+void alloc_resident_graph(Arena &arena, ResidentGraph &g, uint32_t n_vtx, uint32_t n_links, bool tips_given)
 {
 	g.V = n_vtx;
 	g.E = n_links;
 	g.tips_given = tips_given;
 	const size_t V = n_vtx, E = n_links;
-	size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
-		       Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 2, 4) + 4096;
-	if (hipMalloc(&g.block, bytes) != hipSuccess) {
-		(void)hipGetLastError();
-		g.block = nullptr;
-		throw HipError("not enough device memory for the resident graph (" + std::to_string(bytes >> 20) + " MiB)");
-	}
-	char *p = static_cast<char *>(g.block);
-	auto carve = [&](size_t n, size_t elem) {
-		void *r = p;
-		p += Arena::padded(n, elem);
-		return r;
-	};
-	g.vid = (uint32_t *)carve(V, 4);
-	g.v1 = (uint32_t *)carve(E + 1, 4);
-	g.v2 = (uint32_t *)carve(E + 1, 4);
-	g.s1 = (uint8_t *)carve(E + 1, 1);
-	g.s2 = (uint8_t *)carve(E + 1, 1);
-	g.tip = (uint8_t *)carve(V, 1);
-	g.off = (uint32_t *)carve(2 * V + 2, 4);
-	g.adj = (uint32_t *)carve(2 * E + 2, 4);
-	g.aoth = (uint32_t *)carve(2 * E + 2, 4);
-	g.atwin = (uint32_t *)carve(2 * E + 2, 4);
+	const size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
+			     Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 2, 4) + 16 * 256;
+	arena.reserve(bytes);
+	g.vid = arena.take<uint32_t>(V);
+	g.block = g.vid;
+	g.v1 = arena.take<uint32_t>(E + 1);
+	g.v2 = arena.take<uint32_t>(E + 1);
+	g.s1 = arena.take<uint8_t>(E + 1);
+	g.s2 = arena.take<uint8_t>(E + 1);
+	g.tip = arena.take<uint8_t>(V);
+	g.off = arena.take<uint32_t>(2 * V + 2);
+	g.adj = arena.take<uint32_t>(2 * E + 2);
+	g.aoth = arena.take<uint32_t>(2 * E + 2);
+	g.atwin = arena.take<uint32_t>(2 * E + 2);
 }
 
 void check_graph_size(uint32_t n_vtx, uint32_t n_links)
@@ -118,18 +109,18 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 				     const uint32_t *v1, const uint8_t *s1, const uint32_t *v2, const uint8_t *s2,
 				     const uint8_t *tips, char *err, size_t errlen)
 {
-	ResidentGraph g; // built on the side: the context keeps its old graph unless everything succeeds
+	ResidentGraph g;
 	try {
 		if (!ctx)
 			throw HipError("null context");
 		check_graph_size(n_vtx, n_links);
 		HIP_CHECK(hipSetDevice(ctx->device));
-		// the old graph goes first: two whole-genome graphs do not fit side by side
+		// the old graph goes first (the new one reuses its memory); a failed upload leaves the context without a graph
 		free_resident_graph(ctx->g);
 		ctx->have_state = false;
 		ctx->shard_comp_ids.clear();
 		ctx->shard_total_components = 0;
-		alloc_resident_graph(g, n_vtx, n_links, tips != nullptr);
+		alloc_resident_graph(ctx->graph_arena, g, n_vtx, n_links, tips != nullptr);
 		const size_t V = n_vtx, E = n_links;
 		hipStream_t s = ctx->stream;
 		hipEvent_t e0, e1;
@@ -154,10 +145,8 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		ctx->g = g;
 		return 0;
 	} catch (const std::exception &e) {
-		if (ctx) {
+		if (ctx)
 			(void)hipStreamSynchronize(ctx->stream);
-			free_resident_graph(g);
-		}
 		set_err(err, errlen, e.what());
 		return 1;
 	}

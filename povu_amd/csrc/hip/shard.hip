@@ -50,23 +50,26 @@ __global__ void k_shard_comp_of(uint32_t V, const uint32_t *__restrict__ label, 
 	if (v < V)
 		comp_of[v] = crank[label[v]];
 }
-// items per component (vertices: idx == nullptr; links: by their first endpoint).  Neighbouring lanes mostly share a
-// component, so every run of equal components inside a wave adds its length with ONE atomic.
+// items per component (vertices: idx == nullptr; links: by their first endpoint).  The items of a component mostly
+// sit next to one another, so the count is taken from the RUN BOUNDARIES: a run [b, e) of component c adds e - b, i.e.
+// "+e" at its end and "-b" at its start (mod 2^32).  Two atomics per boundary -- a handful for a sorted graph, and
+// spread over all components when it is not -- instead of one hot counter per chromosome-sized component.
 __global__ void k_comp_count(uint32_t n, const uint32_t *__restrict__ comp_of, const uint32_t *__restrict__ idx,
 			     uint32_t *__restrict__ cnt)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t lane = threadIdx.x & 63u;
-	const bool valid = i < n;
-	const uint32_t c = valid ? comp_of[idx ? idx[i] : i] : POVU_NIL;
-	const uint32_t prev = __shfl_up(c, 1);
-	const bool head = lane == 0 || prev != c;
-	const unsigned long long heads = __ballot(head);
-	if (head && valid) {
-		const unsigned long long above = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
-		const uint32_t next = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
-		atomicAdd(&cnt[c], next - lane);
+	if (i >= n)
+		return;
+	const uint32_t c = comp_of[idx ? idx[i] : i];
+	if (i > 0) {
+		const uint32_t p = comp_of[idx ? idx[i - 1] : i - 1];
+		if (p != c) {
+			atomicAdd(&cnt[p], i);
+			atomicSub(&cnt[c], i);
+		}
 	}
+	if (i == n - 1)
+		atomicAdd(&cnt[c], n);
 }
 __global__ void k_owner_keys(uint32_t n, const uint32_t *__restrict__ comp_of, const uint32_t *__restrict__ idx,
 			     const uint32_t *__restrict__ owner, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -352,7 +355,7 @@ extern "C" int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed
 		check_graph_size(nv, ne);
 		free_resident_graph(ctx->g);
 		ctx->have_state = false;
-		alloc_resident_graph(g, nv, ne, true);
+		alloc_resident_graph(ctx->graph_arena, g, nv, ne, true);
 		const char *b = static_cast<const char *>(packed);
 		hipEvent_t e0, e1;
 		HIP_CHECK(hipEventCreate(&e0));
@@ -380,10 +383,8 @@ extern "C" int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed
 		ctx->shard_total_components = (uint32_t)h[4];
 		return 0;
 	} catch (const std::exception &e) {
-		if (ctx) {
+		if (ctx)
 			(void)hipStreamSynchronize(ctx->stream);
-			free_resident_graph(g);
-		}
 		set_err(err, errlen, e.what());
 		return 1;
 	}
