@@ -261,7 +261,8 @@ def test_config5_deep_nest_10m_links_vs_oracle(hip):
 
 
 def test_config3_hprc_shaped_component_vs_oracle(hip):
-    g = W.hprc_shaped([1_000_000], seed=20260612)
+    g = W.hprc_shaped([4_000_000], seed=20260612)  # one component, backbone N = 4e6
+    assert g.n_links > 8_000_000
     got = gpu_texts(hip, g)
     want = O.decompose(g)
     assert {k: md5(v) for k, v in got.items()} == {k: md5(v) for k, v in want.items()}
@@ -277,6 +278,50 @@ def test_config4_many_components_sharded_vs_oracle(hip):
         part = hip.decompose(rank=r, world=8).texts()
         got.update({k: md5(v) for k, v in part.items()})
     assert got == want
+
+
+def test_config4_whole_genome_full_size_vs_oracle():
+    """BASELINE config 4 at FULL size (99.9 M segments / 122.4 M links / 2 024 components): every PVST of the HIP path
+    against the oracle (md5 per tree), on one GPU and through the sharded path (partition for 8 ranks, every shard
+    decomposed in turn, forests merged).  The oracle runs its components on the host's cores (LPT threads)."""
+    from povu_amd import HipDecomposer
+    g = W.hprc_whole_genome(1e8)
+    assert g.n_links == 122435438 and g.n_vtx == 99860187
+    cores = min(32, len(os.sched_getaffinity(0)))
+    want = {k: md5(v) for k, v in O.decompose(g, threads=cores, lpt=True).items()}
+    assert len(want) == 2024
+    d = HipDecomposer(0)
+    d.upload(g)
+    f = d.decompose()
+    assert d.seq_redo_count() == 0
+    got = {k: md5(v) for k, v in f.texts().items()}
+    del f
+    assert got == want
+    # the strong-scaling path of bench.py --gpus 8 on the same graph
+    work = HipDecomposer(0)
+    sh = d.partition(8)
+    loads = [sh.info(r)["weight"] for r in range(8)]
+    assert max(loads) <= 1.05 * (sum(loads) / 8)
+    packed = []
+    for r in range(8):
+        i = sh.info(r)
+        work.upload_shard(i["device_ptr"], i["bytes"], on_device=True)
+        packed.append(work.decompose_shard().pack())
+    merged = work.merge_forests(packed)
+    del packed
+    assert {k: md5(v) for k, v in merged.texts().items()} == want
+    del merged, sh
+    work.close()
+    d.close()
+
+
+def test_extracted_reference_structures_on_gpu(hip, golden_dir):
+    """The structure expectations of the reference's conformance suite (tests/golden/reference_vectors.json)."""
+    from test_oracle import check_structure, links_of_vector, reference_vectors
+    for fid, want in sorted(reference_vectors(golden_dir).items()):
+        t = gpu_texts(hip, links_of_vector(want))
+        assert list(t) == [1], fid
+        check_structure(t[1], want)
 
 
 def test_cli_and_ffi_on_gpu(tmp_path, golden_dir):

@@ -34,6 +34,68 @@ def test_reference_fixture_known_answers(golden_dir, tmp_path):
         assert got == want, name
 
 
+def parse_pvst(text):
+    """PVST text (src/mto/to_pvst.cpp:23-109) -> rows {idx, kind, label, children} in file order."""
+    rows = []
+    for ln in text.splitlines()[1:]:
+        typ, idx, label, children, _route = ln.split("\t")
+        rows.append(dict(idx=int(idx), kind=typ, label=label, children=[] if children == "." else [int(x) for x in children.split(", ")]))
+    return rows
+
+
+def reference_vectors(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "reference_vectors.json")))["fixtures"]
+
+
+def check_structure(text, want):
+    """One PVST against the structure the reference's conformance suite expects for the fixture
+    (lean_reference.lean fixtureStructureOutput?, extracted by tests/golden/extract_reference_vectors.py):
+    node ids `1:<idx>`, endpoints, parents, children, depths, and the boundary candidates in emission order."""
+    rows = parse_pvst(text)
+    nodes = want["pvst_nodes"]
+    assert len(rows) == len(nodes)
+    parent, depth = {0: None}, {0: 0}
+    for r in rows:
+        for c in r["children"]:
+            parent[c], depth[c] = r["idx"], depth[r["idx"]] + 1
+    for r, n in zip(rows, nodes):
+        assert f"1:{r['idx']}" == n["node_id"]
+        assert r["kind"] == ("D" if n["kind"] == "dummy" else "F")
+        assert r["label"] == ("." if n["kind"] == "dummy" else n["start"] + n["stop"])
+        assert [f"1:{c}" for c in r["children"]] == n["children"]
+        assert (None if parent[r["idx"]] is None else f"1:{parent[r['idx']]}") == n["parent"]
+        assert depth[r["idx"]] == n["depth"]
+    flub = [r for r in rows if r["kind"] == "F"]
+    assert [(f"1:{r['idx']}", r["label"]) for r in flub] == [(b["node_id"], b["start"] + b["stop"]) for b in
+                                                            sorted(want["boundary_candidates"], key=lambda b: b["order"])]
+
+
+def links_of_vector(v):
+    """The input graph of an extracted fixture (segment names + links), under the loader contract of DESIGN.md."""
+    ids = sorted(name for _i, name, _s in v["segments"])
+    idx = {n: k for k, n in enumerate(ids)}
+    v1 = [idx[a] for _i, a, _sa, _b, _sb in v["links"]]
+    v2 = [idx[b] for _i, _a, _sa, b, _sb in v["links"]]
+    s1 = [1 if sa == "+" else 0 for _i, _a, sa, _b, _sb in v["links"]]
+    s2 = [0 if sb == "+" else 1 for _i, _a, _sa, _b, sb in v["links"]]
+    return W.Links(np.array(ids, dtype=np.uint32), np.array(v1, dtype=np.uint32), np.array(s1, dtype=np.uint8),
+                   np.array(v2, dtype=np.uint32), np.array(s2, dtype=np.uint8))
+
+
+def test_extracted_reference_structures(golden_dir, tmp_path):
+    """Every structure expectation of the reference's conformance suite (11 fixtures): from the GFA file and from
+    the segment / link rows the suite lists next to it."""
+    vec = reference_vectors(golden_dir)
+    assert len(vec) == 11
+    for fid, want in sorted(vec.items()):
+        out = tmp_path / fid
+        out.mkdir()
+        assert O.decompose_gfa(os.path.join(golden_dir, "gfa", want["gfa"]), str(out)) == 1
+        text = (out / "1.pvst").read_text()
+        check_structure(text, want)
+        assert O.decompose(links_of_vector(want)) == {1: text}, fid
+
+
 def test_gfa_md5_anchors(golden_dir, tmp_path):
     a = _anchors(golden_dir)
     for name in ("LPA.gfa", "pvst_tests_graph.gfa"):
