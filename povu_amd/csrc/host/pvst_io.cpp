@@ -133,11 +133,29 @@ extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *er
 			pos = comma + 1;
 		}
 	}
-	// comp_heights: distance from the root (vertices always follow their parent in this format)
-	if (root != POVU_HIP_NIL)
+	// comp_heights (pvst.hpp:807-836): distance from the root by a traversal over the child lists -- a file may
+	// list a vertex before its parent; vertices the root does not reach keep height 0
+	if (root != POVU_HIP_NIL) {
+		std::vector<uint32_t> coff(n + 1, 0), cadj(n), stack;
 		for (uint32_t i = 0; i < n; i++)
-			if (d->parent[i] != POVU_HIP_NIL && d->parent[i] < i)
-				d->height[i] = d->height[d->parent[i]] + 1;
+			if (d->parent[i] != POVU_HIP_NIL)
+				coff[d->parent[i] + 1]++;
+		for (uint32_t i = 0; i < n; i++)
+			coff[i + 1] += coff[i];
+		std::vector<uint32_t> cur(coff.begin(), coff.end() - 1);
+		for (uint32_t i = 0; i < n; i++)
+			if (d->parent[i] != POVU_HIP_NIL)
+				cadj[cur[d->parent[i]]++] = i;
+		stack.push_back(root);
+		while (!stack.empty()) {
+			const uint32_t v = stack.back();
+			stack.pop_back();
+			for (uint32_t k = coff[v]; k < coff[v + 1]; k++) {
+				d->height[cadj[k]] = d->height[v] + 1;
+				stack.push_back(cadj[k]);
+			}
+		}
+	}
 	return d;
 }
 

@@ -313,3 +313,46 @@ def test_pvst_write_read_round_trip(golden_dir):
     err = C.create_string_buffer(256)
     assert not hl.povu_pvst_parse(b"H\t0.0.2\t.\t.\t.\n", 16, err, 256) and b"Unsupported PVST version" in err.value
     assert not hl.povu_pvst_parse(b"H\t0.0.3\t.\t.\n", 12, err, 256) and b"invalid number of columns" in err.value
+
+
+def test_pvst_reader_subflubble_lines():
+    """A PVST as `decompose -s` writes it (src/mto/to_pvst.cpp:50-105): every vertex family of the wire format --
+    D dummy, F flubble, T tiny, O parallel ("overlap"), C concealed, M midi, S smothered -- with both routes, file
+    ids that are not the line order, a vertex listed before its parent and `, `-separated children.  Expected values
+    follow read_pvst (src/mto/from_pvst.cpp:136-158 label and route, :284-297 children by FILE id) and comp_heights
+    (include/povu/graph/pvst.hpp:807-836)."""
+    hl = H.load_lib()
+    hl.povu_pvst_parse.restype = C.POINTER(_Doc)
+    hl.povu_pvst_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    hl.povu_pvst_doc_free.argtypes = [C.POINTER(_Doc)]
+    text = ("H\t0.0.3\t.\t.\t.\n"
+            "D\t0\t.\t1, 9\t.\n"
+            "F\t1\t>1>40\t2, 3, 5\tL\n"
+            "T\t2\t>2>4\t.\tL\n"
+            "O\t3\t>5<7\t.\tR\n"
+            "S\t8\t<12>13\t.\tR\n"          # listed before its parent (file id 6)
+            "C\t5\t>10>20\t6,7\tL\n"        # children without the blank after the comma
+            "S\t6\t>11>14\t8\tL\n"
+            "M\t7\t<15<18\t.\tR\n"
+            "F\t9\t<4294967294>50\t.\tL\n").encode()
+    err = C.create_string_buffer(256)
+    d = hl.povu_pvst_parse(text, len(text), err, 256)
+    assert d, err.value
+    doc = d.contents
+    n = doc.n
+    assert n == 9
+    col = lambda name: [getattr(doc, name)[i] for i in range(n)]  # noqa: E731
+    assert b"".join(col("type")) == b"DFTOSCSMF"
+    assert col("file_id") == [0, 1, 2, 3, 8, 5, 6, 7, 9]
+    NIL = 0xFFFFFFFF
+    #            D    F1  T2  O3  S8  C5  S6  M7  F9        (vertex idx = line order)
+    assert col("parent") == [NIL, 0, 1, 1, 6, 1, 5, 5, 0]
+    assert col("height") == [0, 1, 2, 2, 4, 2, 3, 3, 1]
+    assert col("a_id")[1:] == [1, 2, 5, 12, 10, 11, 15, 4294967294]
+    assert col("z_id")[1:] == [40, 4, 7, 13, 20, 14, 18, 50]
+    assert col("a_or")[1:] == [0, 0, 0, 1, 0, 0, 1, 1]
+    assert col("z_or")[1:] == [0, 0, 1, 0, 0, 0, 1, 0]
+    assert col("route")[1:] == [0, 0, 1, 1, 0, 0, 1, 0]
+    hl.povu_pvst_doc_free(d)
+    assert not hl.povu_pvst_parse(b"X\t1\t>1>2\t.\tL\n", 13, err, 256) and b"Unknown vertex type" in err.value
+    assert not hl.povu_pvst_parse(b"T\t1\t12\t.\tL\n", 11, err, 256) and b"malformed vertex label" in err.value
