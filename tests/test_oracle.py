@@ -23,7 +23,7 @@ def _anchors(golden_dir):
 
 def test_reference_fixture_known_answers(golden_dir, tmp_path):
     names = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(golden_dir, "pvst", "*.pvst")))
-    assert len(names) == 12
+    assert len(names) == 13  # 12 reference-held answers + the hand-derived hi_2 vector (test below)
     for name in names:
         out = tmp_path / name
         out.mkdir()
@@ -94,6 +94,48 @@ def test_extracted_reference_structures(golden_dir, tmp_path):
         text = (out / "1.pvst").read_text()
         check_structure(text, want)
         assert O.decompose(links_of_vector(want)) == {1: text}, fid
+
+
+def test_hi2_literal_rule_hand_derived(golden_dir):
+    """The `hi_2` quirk of handle_vertex (flubbles.cpp:555-574): hi_2 is the hi of the FIRST child, in ascending idx,
+    that is not hi_child and has hi < v -- not the second-smallest hi.  tests/golden/gfa/hi2_literal_rule.gfa makes the
+    two differ; the expected tree, back edges, classes, candidate stack and PVST below were worked out BY HAND from
+    spanning_tree.cpp:262-463 and flubbles.cpp:295-367,412-501,503-687 (they are not an output of the oracle).
+
+    Graph (all links `+ +`): backbone 1>2>9>4; 4 fans out to 5, 6, 7; 5>4, 6>2, 7>8, 8>4, 8>9 close three cycles that
+    end at different heights.  Segment 9 carries the highest id so that, in componetize's first-encounter order, link
+    8>4 gets a smaller local idx than 8>9: side 8.r then scans 4.l before 9.l.
+    from_bd (start = tip 1.l, black edge first, then links by local idx): tree vertices 0 dummy, 1 1.l, 2 1.r, 3 2.l,
+    4 2.r, 5 9.l, 6 9.r, 7 4.l, 8 4.r, 9 5.l, 10 5.r, 11 6.l (child of 8), 12 6.r, 13 7.l (child of 8), 14 7.r, 15 8.l,
+    16 8.r; back edges in creation order 10>7, 12>3, 16>7, 16>5.
+    handle_vertex, v = 16 .. 0: list(16) = [16>5, 16>7] (later pushed on top), class k0 for 16, 15, 14, 13; 12, 11: k1
+    (12>3); 10, 9: k2 (10>7).  At v = 8 (side 4.r) the children are 9 (hi 7), 11 (hi 3), 13 (hi 5): hi_1 = 3,
+    hi_child = 11, and the first other child with hi < 8 is 9, so hi_2 = 7 (the second-smallest hi would be 5).  hi_0 is
+    unset, so a capping edge 8>7 goes on top: [8>7, 16>5, 16>7, 12>3, 10>7], class k3.  At v = 7 the brackets that end
+    there go (10>7, 16>7 and the capping edge): [16>5, 12>3], top 16>5 with size 2 = the size it last saw at 13, so
+    vertex 7 and then 6 (the black edge of segment 9) join class k0.  (With hi_2 = 5 the capping edge would still be on
+    top here and segment 9 would get a class of its own.)  v = 5 drops 16>5: [12>3], class k1 for 5 and 4; v = 3 drops
+    12>3, the list is empty: simplifying edge 3>0, class k6 for 3, 2, 1.
+    Candidate stack (black edges; under the three-way branch at 8 the gray children in ascending idx): >1 k6, >2 k1,
+    >9 k0, >4 k3, >5 k2, >6 k1, >7 k0, >8 k0; next_seen = 0 5 6 3 4 5 7 7.
+    add_flubbles: i = 1 opens >2>6 (next_seen 5), i = 2 opens >9>7 under it (next_seen 6); nothing else is non-adjacent."""
+    g = _load_gfa_links(os.path.join(golden_dir, "gfa", "hi2_literal_rule.gfa"))
+    d = dump_component(g, 0)
+    NIL = 0xFFFFFFFF
+    assert d["par"].tolist() == [NIL, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 8, 11, 8, 13, 14, 15]
+    assert d["gid"].tolist() == [NIL, 1, 1, 2, 2, 9, 9, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8]
+    assert d["typ"].tolist() == [2] + [0, 1] * 8
+    be = list(zip(d["be_src"].tolist(), d["be_tgt"].tolist(), d["be_type"].tolist()))
+    assert be == [(10, 7, 0), (12, 3, 0), (16, 7, 0), (16, 5, 0), (8, 7, 1), (3, 0, 2), (0, 0, 2)]
+    # classes up to renaming: k0 = {6, 7, 13..16}, k1 = {4, 5, 11, 12}, k2 = {9, 10}, k3 = {8}, k6 = {1, 2, 3}
+    cls = d["cls"].tolist()
+    groups = {}
+    for t in range(1, 17):
+        groups.setdefault(cls[t], set()).add(t)
+    assert sorted(map(sorted, groups.values())) == sorted(map(sorted, [{6, 7, 13, 14, 15, 16}, {4, 5, 11, 12}, {9, 10}, {8}, {1, 2, 3}]))
+    assert d["s_id"].tolist() == [1, 2, 9, 4, 5, 6, 7, 8]
+    assert d["next_seen"].tolist() == [0, 5, 6, 3, 4, 5, 7, 7]
+    assert O.decompose(g)[1] == "H\t0.0.3\t.\t.\t.\nD\t0\t.\t1\t.\nF\t1\t>2>6\t2\tL\nF\t2\t>9>7\t.\tL\n"
 
 
 def test_gfa_md5_anchors(golden_dir, tmp_path):
