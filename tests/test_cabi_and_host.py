@@ -356,3 +356,21 @@ def test_pvst_reader_subflubble_lines():
     hl.povu_pvst_doc_free(d)
     assert not hl.povu_pvst_parse(b"X\t1\t>1>2\t.\tL\n", 13, err, 256) and b"Unknown vertex type" in err.value
     assert not hl.povu_pvst_parse(b"T\t1\t12\t.\tL\n", 11, err, 256) and b"malformed vertex label" in err.value
+
+
+def test_host_code_under_address_and_ub_sanitizers(golden_dir, tmp_path):
+    """The tokenizer and the PVST reader under -fsanitize=address,undefined (CPU build; the GPU pool has no sanitizer
+    runs) over every golden input, the malformed fixtures and truncated PVST texts."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "povu_amd", "csrc"), "asan", "-s"])
+    exe = os.path.join(root, "build", "obj", "host_asan_check")
+    big = tmp_path / "chain.gfa"
+    big.write_text(W.chain_of_bubbles(3000).to_gfa())
+    bad = tmp_path / "bad.gfa"
+    bad.write_text("S\t1\nL\t1\t+\t2\n")
+    files = sorted(glob.glob(os.path.join(golden_dir, "gfa", "*.gfa")) + glob.glob(os.path.join(golden_dir, "pvst", "*.pvst")))
+    r = subprocess.run([exe] + files + [str(big), str(bad)], capture_output=True, text=True,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert "parsed" in r.stdout
