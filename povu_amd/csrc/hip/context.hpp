@@ -138,6 +138,7 @@ struct povu_hip_forest {
 struct povu_hip_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	SideStream side; // PCIe-bound result writes run beside the main stream's kernels
 	ResidentGraph g;
 	Arena ws, ws2, ws_seq, upload_tmp;
 	HostScratch host;

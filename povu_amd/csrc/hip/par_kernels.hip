@@ -25,6 +25,7 @@ namespace povu_hip
 
 #define NIL POVU_NIL
 static constexpr int TPB = 256;
+static constexpr size_t PVST_STAGE_MIN = size_t(1) << 20; // PVST vertices from which the result goes through a device block
 static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
 #define LAUNCH(k, n, s, ...)                                                                     \
 	do {                                                                                     \
@@ -482,7 +483,7 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 // than that component's walk can have climbed or fallen, so nothing in front of c ever is the minimum again.
 __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
 			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint32_t *__restrict__ comp_bad,
-			       const uint32_t *__restrict__ ns, uint32_t *__restrict__ walk, uint32_t *__restrict__ dflag)
+			       const uint32_t *__restrict__ ns, uint32_t *__restrict__ walk)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S)
@@ -497,7 +498,6 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 	}
 	walk[2 * i] = first;
 	walk[2 * i + 1] = d;
-	dflag[i] = d;
 	if (p == NIL || p + 1 >= i)
 		return;
 	if (seg_min(segP, P, p + 1, i) < p)
@@ -515,15 +515,50 @@ __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const
 		neg[k] = ~w;
 	}
 }
-// level of every emitted flubble, and -- so that the PCIe writes of the result overlap with the level
-// queries -- its endpoints and orientations straight into the (page-locked host) PVST arrays
+// entry i opens a flubble iff its class comes back later than at the next entry (flubbles.cpp:344)
+__global__ void k_dflag(uint32_t S, const uint32_t *__restrict__ ns, uint32_t *__restrict__ dflag)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < S)
+		dflag[i] = (i + 1 < ns[i]) ? 1u : 0u;
+	if (i == S)
+		dflag[S] = 0;
+}
+// Endpoints and orientations of every flubble straight into the (page-locked host) PVST arrays.  They only depend on
+// the candidate stack and next_seen, so this kernel runs on the context's side stream while the main stream still
+// computes levels and parents: the PCIe writes (10 of the 14 bytes per PVST vertex) hide behind that work.  A small
+// grid-stride launch: a few ten thousand lanes keep the link busy and leave the CUs to the main stream.
+__global__ void k_emit_endpoints(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
+				 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ ns,
+				 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
+				 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
+				 uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
+{
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+		if (!dflag[i])
+			continue;
+		// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
+		const uint64_t q = (uint64_t)erank[i] + cproc_ps[s_comp[i]] + 1;
+		uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
+		uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
+		if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
+			p_a[q] = t_gid[vz];
+			p_z[q] = t_gid[va];
+			p_aor[q] = 0;
+			p_zor[q] = 0;
+		} else {
+			p_a[q] = t_gid[va];
+			p_z[q] = t_gid[vz];
+			p_aor[q] = (uint8_t)ra;
+			p_zor[q] = (uint8_t)rz;
+		}
+	}
+}
+// level of every emitted flubble
 __global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
 			 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
 			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ negmax,
-			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i, const uint32_t *__restrict__ ns,
-			 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
-			 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
-			 uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
+			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S || !dflag[i])
@@ -540,21 +575,6 @@ __global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const u
 	uint32_t j = erank[i];
 	lev[j] = cur - min(zero, run); // depth of the new flubble (>= 1)
 	e_i[j] = i;
-	// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
-	const uint64_t q = (uint64_t)j + cproc_ps[c] + 1;
-	uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
-	uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
-	if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
-		p_a[q] = t_gid[vz];
-		p_z[q] = t_gid[va];
-		p_aor[q] = 0;
-		p_zor[q] = 0;
-	} else {
-		p_a[q] = t_gid[va];
-		p_z[q] = t_gid[vz];
-		p_aor[q] = (uint8_t)ra;
-		p_zor[q] = (uint8_t)rz;
-	}
 }
 // PVST parent of every flubble = nearest earlier flubble of its component with a smaller level
 __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const uint32_t *__restrict__ e_i,
@@ -729,6 +749,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
 	take((void **)&pw.segP.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
 	take((void **)&pw.segL.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
+	take((void **)&pw.stage, ((S + Cmax + 2) * 4 + 64) * 3 + ((S + Cmax + 2) + 64) * 2 + 256);
 	take((void **)&pw.hpf, T + 2);
 	for (uint32_t **p : {&pw.hp1, &pw.hp2, &pw.hp3})
 		take((void **)p, (T + 2) * 4);
@@ -789,7 +810,8 @@ void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_o
 }
 
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
-		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s)
+		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s,
+		     const SideStream &side)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const bool want_hp = sw.hairpins != nullptr;
@@ -892,33 +914,56 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row G
 	tm.begin("par_pvst");
-	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
 	uint32_t *dflag = pw.s_key; // scratch
-	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.soff, pw.comp_bad, pw.ns, pw.walk, dflag);
-	scan2(dflag, pw.erank, (size_t)S + 1, pw.walk, pw.walk_ps, (size_t)2 * S);
+	LAUNCH(k_dflag, (size_t)S + 1, s, S, pw.ns, dflag);
+	scan(dflag, pw.erank, (size_t)S + 1);
+	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
+	// The five PVST arrays back to back (povu_hip_forest::alloc has the same layout).  Small results are written by the
+	// emit kernels straight into the forest's page-locked host block (no copy, no extra launch).  Large ones go
+	// through a device block of the same layout: the scattered 4- and 1-byte stores of the emit kernels make poor PCIe
+	// packets (~25 GB/s measured), the copy engine moves the finished arrays at link speed -- endpoints and
+	// orientations on the side stream while this one still works out levels and parents.
+	const size_t total = (size_t)NE + n_processed, p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
+	char *host_blk = static_cast<char *>(alloc_result_block(total));
+	const bool staged = total >= PVST_STAGE_MIN && side.stream != nullptr;
+	char *blk = staged ? reinterpret_cast<char *>(pw.stage) : host_blk;
+	pw.d_a = reinterpret_cast<uint32_t *>(blk);
+	pw.d_z = reinterpret_cast<uint32_t *>(blk + p4);
+	pw.d_parent = reinterpret_cast<uint32_t *>(blk + 2 * p4);
+	pw.d_aor = reinterpret_cast<uint8_t *>(blk + 3 * p4);
+	pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
+	pw.d_total = total;
+	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
+	       pw.d_a, pw.d_z, pw.d_aor, pw.d_zor, sw.c_npvst, sw.c_nstack);
+	if (S && side.stream) {
+		HIP_CHECK(hipEventRecord(side.fork, s));
+		HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork, 0));
+		KLAUNCH(k_emit_endpoints, dim3(staged ? nblk(S) : std::min<unsigned>(nblk(S), 160)), dim3(TPB), 0, side.stream, S, dflag, pw.erank,
+			pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+		if (staged) {
+			HIP_CHECK(hipMemcpyAsync(host_blk, blk, 2 * p4, hipMemcpyDeviceToHost, side.stream));
+			HIP_CHECK(hipMemcpyAsync(host_blk + 3 * p4, blk + 3 * p4, 2 * p1, hipMemcpyDeviceToHost, side.stream));
+		}
+		HIP_CHECK(hipEventRecord(side.join, side.stream));
+	} else if (S) {
+		KLAUNCH(k_emit_endpoints, dim3(nblk(S)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
+			sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+	}
+	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
+	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.soff, pw.comp_bad, pw.ns, pw.walk);
+	scan(pw.walk, pw.walk_ps, (size_t)2 * S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
 	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb, wneg);
 	scan_exclusive_max_u32(wneg, wrun, (size_t)2 * S, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
-	{ // the five PVST arrays back to back in the forest's page-locked result block (povu_hip_forest::alloc has the
-	  // same layout): the emit kernels write over PCIe directly, nothing is copied afterwards
-		const size_t total = (size_t)NE + n_processed, p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
-		char *blk = static_cast<char *>(alloc_result_block(total));
-		pw.d_a = reinterpret_cast<uint32_t *>(blk);
-		pw.d_z = reinterpret_cast<uint32_t *>(blk + p4);
-		pw.d_parent = reinterpret_cast<uint32_t *>(blk + 2 * p4);
-		pw.d_aor = reinterpret_cast<uint8_t *>(blk + 3 * p4);
-		pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
-		pw.d_total = total;
-	}
-	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i, pw.ns, pw.s_vtx,
-	       sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
 	       pw.d_parent);
-	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
-	       pw.d_a, pw.d_z, pw.d_aor, pw.d_zor, sw.c_npvst, sw.c_nstack);
+	if (staged)
+		HIP_CHECK(hipMemcpyAsync(host_blk + 2 * p4, blk + 2 * p4, p4, hipMemcpyDeviceToHost, s));
+	if (S && side.stream)
+		HIP_CHECK(hipStreamWaitEvent(s, side.join, 0)); // the pass is complete when both streams are
 	pw.n_stack = S; // export_parallel_stack copies the stack into the per-component layout when a debug hook asks
 	tm.end(12 + 3 * 22);
 }

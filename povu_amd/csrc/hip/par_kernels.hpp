@@ -47,6 +47,7 @@ struct ParWs {
 	uint32_t n_stack;		 // candidate-stack entries of the last pass
 	uint32_t *d_a, *d_z, *d_parent;	 // [d_total] device views into the forest's page-locked result block
 	uint8_t *d_aor, *d_zor;		 // [d_total] 0 forward, 1 reverse
+	void *stage;			 // device block with the layout of the result block (large results are copied out by the DMA engine)
 	uint32_t *err;			 // [4] internal error words
 	SegTree segA, segB, segP, segL;
 	// --hairpins on the parallel path
@@ -55,6 +56,12 @@ struct ParWs {
 	SegTree segH1, segH2, segH3;
 	void *scan_tmp, *sort_tmp;
 	size_t scan_tmp_bytes, sort_tmp_bytes;
+};
+
+// second stream of a context + the two events that fork it from / join it to the main stream
+struct SideStream {
+	hipStream_t stream = nullptr;
+	hipEvent_t fork = nullptr, join = nullptr;
 };
 
 size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax);
@@ -66,7 +73,8 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
 // alloc_result_block(total) returns the device view of a page-locked host block laid out a | z | parent | a_or |
 // z_or (each padded to 64 B) for `total` PVST vertices; the emit kernels write into it.
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
-		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s);
+		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s,
+		     const SideStream &side);
 
 // Hairpin boundaries (`--hairpins`, flubbles.cpp:531-535, 621-656, 712-717) from the parallel class stage's
 // per-vertex flags; writes sw.hairpins / sw.c_nbry like the sequential kernels do.

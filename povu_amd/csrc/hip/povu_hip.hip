@@ -41,6 +41,9 @@ extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
 		auto ctx = std::make_unique<povu_hip_ctx>();
 		ctx->device = device;
 		HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+		HIP_CHECK(hipStreamCreateWithFlags(&ctx->side.stream, hipStreamNonBlocking));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming));
 		ctx->timer.stream = ctx->stream;
 		return ctx.release();
 	} catch (const std::exception &e) {
@@ -68,6 +71,12 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	ctx->graph_arena.release();
 	if (ctx->stream)
 		(void)hipStreamDestroy(ctx->stream);
+	if (ctx->side.stream)
+		(void)hipStreamDestroy(ctx->side.stream);
+	if (ctx->side.fork)
+		(void)hipEventDestroy(ctx->side.fork);
+	if (ctx->side.join)
+		(void)hipEventDestroy(ctx->side.join);
 	delete ctx;
 }
 
@@ -581,7 +590,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0,
 							      (o.flags & POVU_HIP_F_SPARSE_SPLITTERS) != 0, tm, s);
 			}
-			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s);
+			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
 			ctx->stack_export_pending = true;
 			sum = read_summary(true);
 			if (sum[0])
@@ -745,6 +754,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 	} catch (const std::exception &e) {
 		if (ctx && ctx->stream)
 			(void)hipStreamSynchronize(ctx->stream);
+		if (ctx && ctx->side.stream)
+			(void)hipStreamSynchronize(ctx->side.stream);
 		f.reset();
 		set_err(err, errlen, e.what());
 		return nullptr;

@@ -520,13 +520,15 @@ __global__ void k_xor_vals(uint32_t nS, const uint32_t *__restrict__ loff, const
 }
 __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ size0,
 			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ xlo, const uint32_t *__restrict__ xhi,
-			  uint32_t *__restrict__ isbridge, uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp)
+			  uint32_t *__restrict__ isbridge, uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp,
+			  uint8_t *__restrict__ multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	ecc[S] = S; // every side starts as its own 2-edge-connected class
 	csamp[S] = 0;
+	multi[S] = 0; // ... and alone in it until a non-bridge edge says otherwise
 	if (par0[S] == NIL) {
 		isbridge[S] = 0;
 		return;
@@ -560,21 +562,29 @@ __device__ __forceinline__ void uf_union2(uint32_t *parent, uint32_t a, uint32_t
 		rb = uf_find2(parent, lo);
 	}
 }
+// (multi[S] = 1: side S shares its class with another side.  Most sides of a pangenome graph sit on bridges only and
+// are classes of their own; those need no walk at all.)
 __global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
-			   uint32_t *ecc)
+			   uint32_t *ecc, uint8_t *__restrict__ multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS || par0[S] == NIL || isbridge[S])
 		return;
-	uf_union2(ecc, S, par0[S]);
+	const uint32_t p = par0[S];
+	uf_union2(ecc, S, p);
+	multi[S] = 1;
+	multi[p] = 1;
 }
 __global__ void k_ecc_nontree(uint32_t E, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ la,
-			      const uint32_t *__restrict__ lb, uint32_t *ecc)
+			      const uint32_t *__restrict__ lb, uint32_t *ecc, uint8_t *__restrict__ multi)
 {
 	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
 	if (le >= E || tgray[le])
 		return;
-	uf_union2(ecc, la[le], lb[le]);
+	const uint32_t a = la[le], b = lb[le];
+	uf_union2(ecc, a, b);
+	multi[a] = 1;
+	multi[b] = 1;
 }
 // Also samples the class sizes: every 64th side counts itself at its class root, and the largest count
 // seen (>= CLASS_SAMPLE_MIN) lands in *big -- a class of a few thousand sides or more is walked by the
@@ -597,32 +607,40 @@ __global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc, uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------ 5. class entries
+static constexpr uint32_t CS_VISITED = 0x80000000u; // (class ids are side ids < 2^28)
 __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
 			  const uint32_t *__restrict__ pe_le0, const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
-			  const uint32_t *__restrict__ cproc, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
-			  uint8_t *__restrict__ dvis, uint32_t *__restrict__ entry_flag, uint32_t *__restrict__ cur)
+			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ecc,
+			  uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis,
+			  uint32_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	dpar[S] = NIL;
-	cur[S] = 0; // scan position of the plain class DFS
 	cslot[S] = 0;
 	dvis[S] = 0;
 	entry_flag[S] = 0;
-	if (!cproc[ckey[S >> 1]])
+	// class and visited bit of a side in ONE word: the walk tests "same class and not yet visited" with one load
+	const bool proc = cproc[ckey[S >> 1]] != 0;
+	const uint32_t p0 = proc ? par0[S] : 0u;
+	const bool entry = proc && (p0 == NIL || isbridge[S]);
+	cstate[S] = proc ? (ecc[S] | (entry ? CS_VISITED : 0u)) : NIL;
+	if (!proc)
 		return;
+	// a class is walked from its entry side; a side that is alone in its class has nothing to walk
+	const uint32_t walk = multi[S] ? 1u : 0u;
 	uint32_t p = par0[S];
 	if (p == NIL) { // DFS start of the component
 		dvis[S] = 1;
-		entry_flag[S] = 1;
+		entry_flag[S] = walk;
 		return;
 	}
 	if (!isbridge[S])
 		return;
 	dvis[S] = 1;
-	entry_flag[S] = 1;
+	entry_flag[S] = walk;
 	dpar[S] = p;
 	if (p == (S ^ 1)) {
 		cslot[S] = 0; // black edge: scanned first
@@ -681,38 +699,42 @@ __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, cons
 	}
 	rb[u] = make_uint4(base, n, first.x, first.y);
 }
-// the plain walk (small classes only: five or six dependent loads per tree edge, but no filtering pass)
+// the plain walk (small classes only; no filtering pass).  Dependent loads per tree edge: the candidate's adjacency
+// entry and its state word on the way down; {parent, slot} of the finished side and the parent's list bounds on the way
+// back -- the parent resumes its scan behind the slot the child was found through, so no cursor is stored.
 __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
-				  const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ecc, uint32_t *__restrict__ dpar,
-				  uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis, uint32_t *__restrict__ cur)
+				  const uint32_t *__restrict__ ladj, uint32_t *__restrict__ cstate, uint32_t *__restrict__ dpar,
+				  uint32_t *__restrict__ cslot)
 {
 	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
-		const uint32_t s = entry_list[i], cls = ecc[s];
-		uint32_t u = s;
-		while (true) {
-			const uint32_t lo = loff[u], n = loff[u + 1] - lo;
-			uint32_t k = cur[u];
+		const uint32_t s = entry_list[i], cls = cstate[s] & ~CS_VISITED;
+		uint32_t u = s, k = 0, lo = loff[u], n = loff[u + 1] - lo;
+		for (;;) {
 			bool adv = false;
 			while (k <= n) {
 				const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
 				const uint32_t slot = k++;
-				if (ecc[o] == cls && !dvis[o]) {
-					dvis[o] = 1;
+				if (cstate[o] == cls) { // same class, not visited yet
+					cstate[o] = cls | CS_VISITED;
 					dpar[o] = u;
 					cslot[o] = slot;
-					cur[u] = k;
 					u = o;
+					k = 0;
+					lo = loff[u];
+					n = loff[u + 1] - lo;
 					adv = true;
 					break;
 				}
 			}
 			if (adv)
 				continue;
-			cur[u] = k;
 			if (u == s)
 				break;
+			k = cslot[u] + 1;
 			u = dpar[u];
+			lo = loff[u];
+			n = loff[u + 1] - lo;
 		}
 	}
 }
@@ -975,7 +997,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 {
 	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // list-ranking buffers double as slot buffers
 	take((void **)&tw.tg_ps, (E + 2) * 4);
-	take((void **)&tw.dvis_slots, 2 * E + 8);
+	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
 	for (uint32_t **p : {&tw.arc_src, &tw.k1, &tw.k2, &tw.v1, &tw.v2, &tw.apos, &tw.nxtA, &tw.nxtB, &tw.cntA,
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
@@ -1050,16 +1072,18 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_xor_vals, nS, s, nS, cs.loff, cs.lle, cs.tgray, tw.P0, vlo, vhi);
 	scan_exclusive_xor_u32_pair(vlo, xlo, vhi, xhi, (size_t)nS + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
-	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, xlo, xhi, tw.isbridge, tw.ecc, csamp);
-	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc);
-	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc);
+	uint8_t *multi = tw.dvis_slots; // [2E+8] >= ... see tree_spans: sized for max(2E, 2V) + 8
+	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, xlo, xhi, tw.isbridge, tw.ecc, csamp, multi);
+	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc, multi);
+	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc, multi);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
-	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, tw.dpar, tw.cslot,
-	       tw.dvis, tw.entry_flag, sw.cur);
+	uint32_t *cstate = sw.cur; // [nS+1]
+	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dpar,
+	       tw.cslot, tw.dvis, tw.entry_flag, cstate);
 	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
 	uint32_t *hb = tw.host->take<uint32_t>(2);
@@ -1073,13 +1097,15 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		KLAUNCH(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
 				   tw.dpar, tw.cslot, tw.dvis, tw.cret);
 	} else if (n_entry) {
-		// Lanes in flight = a window of sides whose scattered stores meet again in L2 (2048 x 64 lanes measured best
-		// for a few hundred thousand small classes); with millions of classes the walk is latency-bound and wants
-		// every lane the device can hold, so the cap never goes below 40 % of the classes.
+		// Lanes in flight = a window of sides whose scattered stores meet again in L2: ~3000 x 64 lanes measured best
+		// from a few hundred thousand to twenty million small classes (wider windows thrash the caches, narrower
+		// ones leave latency uncovered).
 		const unsigned all_blocks = (n_entry + 63) / 64;
-		const unsigned dfs_blocks = std::min(all_blocks, std::max(2048u, (unsigned)(0.4 * all_blocks)));
-		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff,
-				   cs.ladj, tw.ecc, tw.dpar, tw.cslot, tw.dvis, sw.cur);
+		unsigned dfs_blocks = std::min(all_blocks, 3072u);
+		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
+			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
+		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dpar,
+			tw.cslot);
 	}
 	tm.end(5);
 
