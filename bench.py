@@ -218,8 +218,10 @@ def main():
                 hip.upload(g2)
                 dt2, ms2, f2 = time_single(hip, g2, 5, 2, F_NO_STAGE_TIMES)
                 a2 = algorithmic_bytes(g2.n_links, g2.n_vtx, count_flubbles(f2))
+                hip.decompose()  # untimed: per-stage HIP events
                 sec[key] = {"workload": wl2, "value": g2.n_links * 5 / dt2, "ms_per_step": dt2 / 5 * 1e3, "ms_per_launch": ms2,
-                            "roofline_frac": a2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                            "roofline_frac": a2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "stage_ms": {st["name"]: round(st["ms"], 4) for st in hip.stage_times()}}
                 del f2, g2
             out["secondary"] = sec
         if not args.no_cpu_baseline:

@@ -230,12 +230,26 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		}
 	}
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < v1 - v0; i += blockDim.x) {
-		uint32_t r = i;
-		while (par[r] != r)
-			r = par[r];
-		label[v0 + i] = v0 + r;
+	// flatten by pointer doubling (a long chain of segments leaves a parent chain as long: walking it once per
+	// vertex would be quadratic); a round without a change ends it
+	for (int round = 0; round < 14; round++) {
+		uint32_t pp[UF_TILE / UF_TPB];
+		int changed = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < UF_TILE / UF_TPB; k++) {
+			const uint32_t i = threadIdx.x + k * UF_TPB, p = par[i];
+			pp[k] = par[p];
+			changed |= pp[k] != p;
+		}
+		if (!__syncthreads_or(changed))
+			break;
+#pragma unroll
+		for (uint32_t k = 0; k < UF_TILE / UF_TPB; k++)
+			par[threadIdx.x + k * UF_TPB] = pp[k];
+		__syncthreads();
 	}
+	for (uint32_t i = threadIdx.x; i < v1 - v0; i += blockDim.x)
+		label[v0 + i] = v0 + par[i];
 }
 
 // the links that leave their tile, in global memory (grid-stride: their number only exists on the device)

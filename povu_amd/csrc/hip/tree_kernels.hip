@@ -436,62 +436,18 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 	}
 }
 
-// ------------------------------------------------------------------ 2. rooted forest T0
-// dist[a] = arcs after a in its tour.  u->w is the advance arc of tree edge {u,w} iff it comes first.
-__global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
-			     const uint32_t *__restrict__ arc_le,
-			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff, uint32_t *__restrict__ par0,
-			     uint32_t *__restrict__ size0, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ tourflag,
-			     uint32_t C, const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ P0)
-{
-	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a < C) { // the DFS start of component a roots its tree (no advance arc ever enters it)
-		uint32_t r = comp_root_side(start_key, voff, a);
-		par0[r] = NIL;
-		size0[r] = 2 * (voff[a + 1] - voff[a]);
-		P0[r] = 2 * voff[a];
-	}
-	if (a >= NA)
-		return;
-	uint32_t da = dist[a], dt = dist[a ^ 1];
-	uint32_t u = arc_src[a], c = ckey[u >> 1];
-	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
-	uint32_t tix = abase + (L - 1 - da);
-	if (da > dt) {
-		uint32_t w = arc_src[a ^ 1]; // head of a = tail of its twin
-		par0[w] = u;
-		size0[w] = (da - dt + 1) / 2;
-		pe_le0[w] = arc_le[a >> 1];
-		tourflag[tix] = 1;
-	} else {
-		tourflag[tix] = 0;
-	}
-}
-__global__ void k_t0_pre(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
-			 const uint32_t *__restrict__ ckey,
-			 const uint32_t *__restrict__ voff, const uint32_t *__restrict__ tour_ps, uint32_t *__restrict__ P0)
-{
-	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= NA)
-		return;
-	uint32_t da = dist[a], dt = dist[a ^ 1];
-	if (da <= dt)
-		return;
-	uint32_t u = arc_src[a], c = ckey[u >> 1];
-	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
-	uint32_t tix = abase + (L - 1 - da);
-	P0[arc_src[a ^ 1]] = 2 * voff[c] + 1 + (tour_ps[tix] - tour_ps[abase]);
-}
-
-// ------------------------------------------------------------------ 3. bridges
+// ------------------------------------------------------------------ 2. rooted forest T0 and 3. its bridges
+// dist[a] = arcs after a in its tour.  u->w is the advance arc of tree edge {u,w} iff it comes first; subtree(w) is the
+// stretch of the tour from that arc (position tin) to its twin (position tout).
+//
 // A tree edge (parent(w), w) of the rooted forest is a bridge of H iff no non-tree link has exactly one end inside
 // subtree(w).  Every non-tree link gets a 64-bit hash of its local edge idx; a side's value is the xor of the hashes
-// of its non-tree links; the xor over subtree(w) -- two look-ups into the running xor over the forest's pre-order,
-// since subtree(w) is the interval [P0(w), P0(w) + size0(w)) -- cancels every link with both ends inside and keeps
-// the ones that cross.  A bridge always xors to 0; a non-bridge xors to 0 only if the hashes of its crossing links
-// cancel by accident (probability 2^-64 per tree edge, i.e. ~1e-11 per pass over 2e8 tree edges; the hash is a fixed
-// function of the edge idx, so a result is reproducible).  This replaces two range-min queries per side over
-// segment trees of the far ends' pre-order numbers.
+// of its non-tree links, placed at the tour position of the arc that enters the side (0 at all other positions); the
+// xor over subtree(w) -- two look-ups into the running xor over the tour positions -- cancels every link with both
+// ends inside and keeps the ones that cross.  A bridge always xors to 0; a non-bridge xors to 0 only if the hashes of
+// its crossing links cancel by accident (probability 2^-64 per tree edge, i.e. ~1e-11 per pass over 2e8 tree edges;
+// the hash is a fixed function of the edge idx, so a result is reproducible).  This replaces two range-min queries
+// per side over segment trees of the far ends' pre-order numbers, and the forest needs no pre-order numbering at all.
 __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 {
 	unsigned long long z = ((unsigned long long)le + 1ull) * 0x9E3779B97F4A7C15ull; // splitmix64 finaliser
@@ -499,27 +455,42 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 	return z ^ (z >> 31);
 }
-__global__ void k_xor_vals(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
-			   const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ P0, uint32_t *__restrict__ vlo,
-			   uint32_t *__restrict__ vhi)
+__global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
+			     const uint32_t *__restrict__ arc_le, const uint32_t *__restrict__ ckey,
+			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
+			     const uint32_t *__restrict__ tgray, uint32_t *__restrict__ par0, uint32_t *__restrict__ tin,
+			     uint32_t *__restrict__ tout, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ vlo,
+			     uint32_t *__restrict__ vhi, uint32_t C, const unsigned long long *__restrict__ start_key)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
+	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+	if (a < C) // the DFS start of component a roots its tree (no advance arc ever enters it)
+		par0[comp_root_side(start_key, voff, a)] = NIL;
+	if (a == 0)
+		vlo[NA] = vhi[NA] = 0;
+	if (a >= NA)
 		return;
+	uint32_t da = dist[a], dt = dist[a ^ 1];
+	uint32_t u = arc_src[a], c = ckey[u >> 1];
+	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
+	uint32_t tix = abase + (L - 1 - da);
 	unsigned long long h = 0;
-	for (uint32_t k = loff[S]; k < loff[S + 1]; k++) {
-		const uint32_t le = lle[k];
-		if (!tgray[le])
-			h ^= link_hash(le); // (a link is in the lists of both its ends, also when they are l and r of one segment)
+	if (da > dt) {
+		uint32_t w = arc_src[a ^ 1]; // head of a = tail of its twin
+		par0[w] = u;
+		pe_le0[w] = arc_le[a >> 1];
+		tin[w] = tix;
+		tout[w] = abase + (L - 1 - dt);
+		for (uint32_t k = loff[w]; k < loff[w + 1]; k++) {
+			const uint32_t le = lle[k];
+			if (!tgray[le])
+				h ^= link_hash(le); // (a link is in the lists of both its ends, also when they are l and r of one segment)
+		}
 	}
-	const uint32_t me = P0[S];
-	vlo[me] = (uint32_t)h;
-	vhi[me] = (uint32_t)(h >> 32);
-	if (S == nS - 1)
-		vlo[nS] = vhi[nS] = 0;
+	vlo[tix] = (uint32_t)h;
+	vhi[tix] = (uint32_t)(h >> 32);
 }
-__global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ size0,
-			  const uint32_t *__restrict__ P0, const uint32_t *__restrict__ xlo, const uint32_t *__restrict__ xhi,
+__global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ tin,
+			  const uint32_t *__restrict__ tout, const uint32_t *__restrict__ xlo, const uint32_t *__restrict__ xhi,
 			  uint32_t *__restrict__ isbridge, uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp,
 			  uint8_t *__restrict__ multi)
 {
@@ -533,7 +504,7 @@ __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const 
 		isbridge[S] = 0;
 		return;
 	}
-	const uint32_t a = P0[S], b = a + size0[S];
+	const uint32_t a = tin[S], b = tout[S] + 1;
 	isbridge[S] = (((xlo[a] ^ xlo[b]) | (xhi[a] ^ xhi[b])) == 0) ? 1u : 0u;
 }
 
@@ -562,6 +533,9 @@ __device__ __forceinline__ void uf_union2(uint32_t *parent, uint32_t a, uint32_t
 		rb = uf_find2(parent, lo);
 	}
 }
+// The 2-edge-connected classes are the pieces the rooted forest falls into when its bridges are cut (every bridge of H is
+// a tree edge, and a class stays connected inside any spanning tree): uniting child and parent over every non-bridge
+// tree edge is enough, the non-tree links add nothing.
 // (multi[S] = 1: side S shares its class with another side.  Most sides of a pangenome graph sit on bridges only and
 // are classes of their own; those need no walk at all.)
 __global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
@@ -574,17 +548,6 @@ __global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ par0, const
 	uf_union2(ecc, S, p);
 	multi[S] = 1;
 	multi[p] = 1;
-}
-__global__ void k_ecc_nontree(uint32_t E, const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ la,
-			      const uint32_t *__restrict__ lb, uint32_t *ecc, uint8_t *__restrict__ multi)
-{
-	uint32_t le = blockIdx.x * blockDim.x + threadIdx.x;
-	if (le >= E || tgray[le])
-		return;
-	const uint32_t a = la[le], b = lb[le];
-	uf_union2(ecc, a, b);
-	multi[a] = 1;
-	multi[b] = 1;
 }
 // Also samples the class sizes: every 64th side counts itself at its class root, and the largest count
 // seen (>= CLASS_SAMPLE_MIN) lands in *big -- a class of a few thousand sides or more is walked by the
@@ -1060,22 +1023,19 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.heads);
 	list_rank_splitters<false>(NA, bitsA, tw.cntB, nullptr, C, rb, s);
 	const uint32_t *dist = tw.cntB;
-	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_le, cs.ckey, cs.voff, tw.par0, tw.size0,
-	       tw.pe_le0, tw.tourflag, C, start_key, tw.P0);
-	scan(tw.tourflag, tw.tour_ps, (size_t)NA + 1);
-	LAUNCH(k_t0_pre, NA, s, NA, dist, tw.arc_src, cs.ckey, cs.voff, tw.tour_ps, tw.P0);
+	uint32_t *tin = tw.P0, *tout = tw.size0;				      // [nS]
+	uint32_t *vlo = tw.tourflag, *vhi = tw.tour_ps, *xlo = tw.nxtA, *xhi = tw.nxtB; // [NA+1] each
+	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_le, cs.ckey, cs.voff, cs.loff, cs.lle, cs.tgray, tw.par0,
+	       tin, tout, tw.pe_le0, vlo, vhi, C, start_key);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
-	uint32_t *vlo = tw.lowP, *vhi = tw.highP, *xlo = tw.xlo, *xhi = tw.xhi; // [nS+1] each
-	LAUNCH(k_xor_vals, nS, s, nS, cs.loff, cs.lle, cs.tgray, tw.P0, vlo, vhi);
-	scan_exclusive_xor_u32_pair(vlo, xlo, vhi, xhi, (size_t)nS + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	scan_exclusive_xor_u32_pair(vlo, xlo, vhi, xhi, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
-	uint8_t *multi = tw.dvis_slots; // [2E+8] >= ... see tree_spans: sized for max(2E, 2V) + 8
-	LAUNCH(k_bridges, nS, s, nS, tw.par0, tw.size0, tw.P0, xlo, xhi, tw.isbridge, tw.ecc, csamp, multi);
+	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
+	LAUNCH(k_bridges, nS, s, nS, tw.par0, tin, tout, xlo, xhi, tw.isbridge, tw.ecc, csamp, multi);
 	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc, multi);
-	LAUNCH(k_ecc_nontree, E, s, E, cs.tgray, cs.la, cs.lb, tw.ecc, multi);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
 	tm.end(8 + 44);
 
