@@ -75,6 +75,7 @@ typedef struct {
 #define POVU_HIP_F_SEQUENTIAL 2u /* force the one-lane-per-component kernels for every stage */
 #define POVU_HIP_F_SEQ_TREE 4u /* sequential spanning tree, parallel classes/stack/PVST (A/B testing) */
 #define POVU_HIP_F_FORCE_REDO 8u /* treat every component as flagged for the sequential redo (tests) */
+#define POVU_HIP_F_REDO_ODD 256u /* treat every second component as flagged for the sequential redo (tests of the mixed result) */
 #define POVU_HIP_F_NO_STAGE_TIMES 32u /* record only the pass total, not the per-stage HIP events */
 #define POVU_HIP_F_BIG_CLASS_DFS 64u /* always walk the classes with the filtered-scan-list DFS large classes get (A/B testing) */
 #define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with the 1-in-16 splitters lists of 2^26+ elements get (A/B testing) */

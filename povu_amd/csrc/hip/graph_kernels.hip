@@ -627,6 +627,18 @@ __global__ void k_fill_u32(size_t n, uint32_t *p, uint32_t val)
 		p[i] = val;
 }
 
+__global__ void k_mark_odd(size_t n, uint32_t *p)
+{
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && (i & 1))
+		p[i] = 1u;
+}
+void mark_odd_u32(uint32_t *p, size_t n, hipStream_t s)
+{
+	if (n)
+		KLAUNCH(k_mark_odd, dim3(nblk(n)), dim3(TPB), 0, s, n, p);
+}
+
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s)
 {
 	if (n)

@@ -47,6 +47,7 @@ struct CompState {
 };
 
 void fill_u32(uint32_t *p, size_t n, uint32_t val, hipStream_t s);
+void mark_odd_u32(uint32_t *p, size_t n, hipStream_t s); // p[i] = 1 for odd i (test hook)
 // Builds off / adj / aoth / atwin / tip from the link arrays already in g (device memory).  Throws when a link names
 // an unknown vertex or side (validated on the device).
 void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);

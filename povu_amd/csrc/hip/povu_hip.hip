@@ -570,6 +570,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		tm.end(all_seq ? 14 : 1);
 		sw.comp_sel = nullptr;
 		ctx->last_seq_redo = 0;
+		bool mixed = false; // parallel result for most components, sequential redo for the flagged ones
 		if (all_seq) {
 			tm.begin("traversal_seq");
 			sw.stages = SEQ_STAGE_ALL;
@@ -592,6 +593,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			}
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
 			ctx->stack_export_pending = true;
+			if (o.flags & POVU_HIP_F_REDO_ODD) // (tests: flag every other component as if its stack were not laminar)
+				mark_odd_u32(ctx->pw.comp_bad, C, s);
 			sum = read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
@@ -608,11 +611,14 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				run_parallel_hairpins(cs, sw, ctx->pw, C, tm, s);
 				sum = nullptr;
 			}
-			if (nbad || (o.flags & POVU_HIP_F_FORCE_REDO)) {
-				// the parallel stages only keep the dense PVST layout; a (never yet observed) flagged
-				// component sends the whole shard through the sequential kernels
+			if ((o.flags & POVU_HIP_F_FORCE_REDO) || (nbad && hairpins)) {
+				// (tests; and the boundary report, which the parallel path only has for a whole pass)
 				fill_u32(ctx->pw.comp_bad, C, 1u, s);
 				nbad = C;
+			} else if (nbad) {
+				// only the flagged components go through the sequential kernels; the others keep the dense
+				// result the parallel stages wrote
+				mixed = true;
 			}
 			ctx->last_seq_redo = nbad;
 			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
@@ -655,21 +661,70 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			total_hp += t.n_hairpins;
 			f->trees.push_back(t);
 		}
-		const bool dense_out = !all_seq && ctx->last_seq_redo == 0;
-		if (f->block && (!dense_out || f->total_entries != total))
-			f->release_block();
-		if (!f->block)
-			f->alloc(total);
+		const bool dense_out = !all_seq && (ctx->last_seq_redo == 0 || mixed);
+		const uint32_t *bad = sum + 4;
+		// results of the sequential kernels (per-component layout sw.p_*) -> `dst` arrays at every tree's `off`
+		auto fetch_seq = [&](std::vector<povu_hip_forest::Tree *> &ts, uint32_t *da, uint32_t *dz, uint32_t *dp, uint8_t *dao,
+				     uint8_t *dzo, size_t n_total) {
+			std::vector<uint8_t> ors(n_total);
+			if (ts.size() <= 32) { // few trees: copy exactly their spans
+				for (const auto *t : ts) {
+					const size_t pb = (size_t)voff[t->component_id - 1] + (t->component_id - 1);
+					HIP_CHECK(hipMemcpyAsync(da + t->off, sw.p_a + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipMemcpyAsync(dz + t->off, sw.p_z + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipMemcpyAsync(dp + t->off, sw.p_parent + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipMemcpyAsync(ors.data() + t->off, sw.p_or + pb, t->n_pvst, hipMemcpyDeviceToHost, s));
+					if (t->n_hairpins)
+						HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t->hp_off, sw.hairpins + 2 * pb,
+									 (size_t)t->n_hairpins * 16, hipMemcpyDeviceToHost, s));
+				}
+				HIP_CHECK(hipEventRecord(ev_all1, s));
+				HIP_CHECK(hipStreamSynchronize(s));
+			} else { // many trees: one bulk copy per array, sliced on the host
+				const size_t P = (size_t)g.V + C;
+				std::vector<uint32_t> ha(P), hz(P), hp(P);
+				std::vector<uint8_t> ho(P);
+				std::vector<uint64_t> hh(hairpins ? 2 * P : 0);
+				HIP_CHECK(hipMemcpyAsync(ha.data(), sw.p_a, P * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(hz.data(), sw.p_z, P * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(hp.data(), sw.p_parent, P * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipMemcpyAsync(ho.data(), sw.p_or, P, hipMemcpyDeviceToHost, s));
+				if (hairpins)
+					HIP_CHECK(hipMemcpyAsync(hh.data(), sw.hairpins, 2 * P * 8, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(hipEventRecord(ev_all1, s));
+				HIP_CHECK(hipStreamSynchronize(s));
+				for (const auto *t : ts) {
+					const size_t pb = (size_t)voff[t->component_id - 1] + (t->component_id - 1);
+					std::copy_n(ha.begin() + pb, t->n_pvst, da + t->off);
+					std::copy_n(hz.begin() + pb, t->n_pvst, dz + t->off);
+					std::copy_n(hp.begin() + pb, t->n_pvst, dp + t->off);
+					std::copy_n(ho.begin() + pb, t->n_pvst, ors.begin() + t->off);
+					if (t->n_hairpins)
+						std::copy_n(hh.begin() + 2 * pb, 2 * (size_t)t->n_hairpins, f->hairpins.begin() + 2 * t->hp_off);
+				}
+			}
+			for (size_t i = 0; i < n_total; i++) {
+				dao[i] = ors[i] & 1;
+				dzo[i] = (ors[i] >> 1) & 1;
+			}
+		};
 		f->hairpins.resize(2 * total_hp);
-		std::vector<uint8_t> ors(dense_out ? 0 : total);
-		if (dense_out) { // the parallel stages wrote every PVST back to back: one exact-size copy per array
-			if (doff[C] != total)
+		if (dense_out) { // the parallel stages wrote every PVST back to back into f->block
+			if (!mixed && (doff[C] != total || total != ctx->pw.d_total))
 				throw HipError("internal error: dense PVST size mismatch");
-			for (auto &t : f->trees)
-				t.off = doff[t.component_id - 1];
-			if (total != ctx->pw.d_total)
-				throw HipError("internal error: dense PVST layout mismatch");
-			// the PVST arrays are already in f->block (written by k_pvst_emit / k_pvst_roots)
+			if (!f->block)
+				f->alloc(ctx->pw.d_total);
+			std::vector<povu_hip_forest::Tree *> redo;
+			size_t redo_total = 0;
+			for (auto &t : f->trees) {
+				if (mixed && bad[t.component_id - 1]) {
+					t.off = redo_total;
+					redo_total += t.n_pvst;
+					redo.push_back(&t);
+				} else {
+					t.off = doff[t.component_id - 1];
+				}
+			}
 			bool more = false;
 			for (const auto &t : f->trees)
 				if (t.n_hairpins) {
@@ -679,56 +734,30 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 					more = true;
 				}
 			tm.end(0);
-			if (more || tm.enabled) { // (the stage events themselves have to complete before they are read)
+			if (!redo.empty()) { // the redone components get a block of their own
+				povu_hip_forest::ExtraBlock blk;
+				blk.pool = ctx->pool;
+				blk.p = ctx->pool->get(povu_hip_forest::ExtraBlock::bytes_for(redo_total), blk.cap);
+				blk.carve(redo_total);
+				f->extra.push_back(blk);
+				for (auto *t : redo)
+					t->blk = 0;
+				fetch_seq(redo, blk.a, blk.z, blk.parent, blk.aor, blk.zor, redo_total);
+			} else if (more || tm.enabled) { // (the stage events themselves have to complete before they are read)
 				HIP_CHECK(hipEventRecord(ev_all1, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 			}
-		} else if (f->trees.size() <= 32) { // few trees: copy exactly their spans
-			for (const auto &t : f->trees) {
-				const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
-				HIP_CHECK(hipMemcpyAsync(f->a_id.data() + t.off, sw.p_a + pb, (size_t)t.n_pvst * 4,
-							 hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(f->z_id.data() + t.off, sw.p_z + pb, (size_t)t.n_pvst * 4,
-							 hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(f->parent.data() + t.off, sw.p_parent + pb, (size_t)t.n_pvst * 4,
-							 hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(ors.data() + t.off, sw.p_or + pb, t.n_pvst, hipMemcpyDeviceToHost, s));
-				if (t.n_hairpins)
-					HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t.hp_off, sw.hairpins + 2 * pb,
-								 (size_t)t.n_hairpins * 16, hipMemcpyDeviceToHost, s));
-			}
+		} else {
+			if (f->block && f->total_entries != total)
+				f->release_block();
+			if (!f->block)
+				f->alloc(total);
+			std::vector<povu_hip_forest::Tree *> all;
+			for (auto &t : f->trees)
+				all.push_back(&t);
 			tm.end(0);
-			HIP_CHECK(hipEventRecord(ev_all1, s));
-			HIP_CHECK(hipStreamSynchronize(s));
-		} else { // many trees: one bulk copy per array, sliced on the host
-			const size_t P = (size_t)g.V + C;
-			std::vector<uint32_t> ha(P), hz(P), hp(P);
-			std::vector<uint8_t> ho(P);
-			std::vector<uint64_t> hh(hairpins ? 2 * P : 0);
-			HIP_CHECK(hipMemcpyAsync(ha.data(), sw.p_a, P * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(hz.data(), sw.p_z, P * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(hp.data(), sw.p_parent, P * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(ho.data(), sw.p_or, P, hipMemcpyDeviceToHost, s));
-			if (hairpins)
-				HIP_CHECK(hipMemcpyAsync(hh.data(), sw.hairpins, 2 * P * 8, hipMemcpyDeviceToHost, s));
-			tm.end(0);
-			HIP_CHECK(hipEventRecord(ev_all1, s));
-			HIP_CHECK(hipStreamSynchronize(s));
-			for (const auto &t : f->trees) {
-				const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
-				std::copy_n(ha.begin() + pb, t.n_pvst, f->a_id.begin() + t.off);
-				std::copy_n(hz.begin() + pb, t.n_pvst, f->z_id.begin() + t.off);
-				std::copy_n(hp.begin() + pb, t.n_pvst, f->parent.begin() + t.off);
-				std::copy_n(ho.begin() + pb, t.n_pvst, ors.begin() + t.off);
-				if (t.n_hairpins)
-					std::copy_n(hh.begin() + 2 * pb, 2 * (size_t)t.n_hairpins, f->hairpins.begin() + 2 * t.hp_off);
-			}
+			fetch_seq(all, f->a_id.data(), f->z_id.data(), f->parent.data(), f->a_or.data(), f->z_or.data(), total);
 		}
-		if (!dense_out)
-			for (size_t i = 0; i < total; i++) {
-				f->a_or[i] = ors[i] & 1;
-				f->z_or[i] = (ors[i] >> 1) & 1;
-			}
 		// stage times
 		ctx->last_times.clear();
 		for (auto &r : tm.recs) {

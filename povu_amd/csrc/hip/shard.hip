@@ -731,13 +731,47 @@ extern "C" int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *sh
 	}
 }
 
+// a forest whose trees sit in several blocks (sequential redo of some components) -> one block, trees back to back
+static std::unique_ptr<povu_hip_forest> compact_forest(const povu_hip_forest *f)
+{
+	auto out = std::make_unique<povu_hip_forest>();
+	out->pool = f->pool;
+	out->total_components = f->total_components;
+	size_t total = 0;
+	for (const auto &t : f->trees)
+		total += t.n_pvst;
+	out->alloc(total);
+	size_t at = 0;
+	for (size_t i = 0; i < f->trees.size(); i++) {
+		povu_hip_tree t;
+		if (povu_hip_forest_get(f, (uint32_t)i, &t) != 0)
+			throw HipError("gather: bad forest");
+		memcpy(out->a_id.p + at, t.a_id, (size_t)t.n_pvst * 4);
+		memcpy(out->z_id.p + at, t.z_id, (size_t)t.n_pvst * 4);
+		memcpy(out->parent.p + at, t.parent, (size_t)t.n_pvst * 4);
+		memcpy(out->a_or.p + at, t.a_or, t.n_pvst);
+		memcpy(out->z_or.p + at, t.z_or, t.n_pvst);
+		povu_hip_forest::Tree nt = f->trees[i];
+		nt.blk = -1;
+		nt.off = at;
+		out->trees.push_back(nt);
+		at += t.n_pvst;
+	}
+	return out;
+}
+
 extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen)
 {
+	std::unique_ptr<povu_hip_forest> compacted;
 	try {
 		if (!c || !mine)
 			throw HipError("gather: bad arguments");
-		if (!mine->extra.empty() || !mine->hairpins.empty())
-			throw HipError("gather: expects the forest of one decompose call (no hairpins)");
+		if (!mine->hairpins.empty())
+			throw HipError("gather: hairpin boundaries do not travel");
+		if (!mine->extra.empty()) { // (rare: some components went through the sequential redo)
+			compacted = compact_forest(mine);
+			mine = compacted.get();
+		}
 		povu_hip_ctx *ctx = c->ctx;
 		HIP_CHECK(hipSetDevice(ctx->device));
 		Rccl &R = rccl();

@@ -51,6 +51,7 @@ F_SORTED_ADJ = 16
 F_NO_STAGE_TIMES = 32
 F_BIG_CLASS_DFS = 64
 F_SPARSE_SPLITTERS = 128
+F_REDO_ODD = 256
 
 _lib = None
 

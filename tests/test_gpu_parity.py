@@ -160,6 +160,25 @@ def test_forced_sequential_redo(hip, seed):
     assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_partial_sequential_redo_keeps_the_parallel_results_of_the_rest(hip, seed):
+    """Per-component redo: every second component is flagged as if its candidate stack were not laminar; those go
+    through the sequential kernels (a block of their own in the forest), the others keep the dense parallel result."""
+    from povu_amd.hip import F_REDO_ODD, F_SEQ_TREE
+    g = W.hprc_shaped([300 + 40 * seed, 120, 75, 210], seed=seed, tiny=9 + seed)
+    hip.upload(g)
+    want = O.decompose(g)
+    f = hip.decompose(flags=F_REDO_ODD)
+    n_comp = f.total_components
+    assert hip.seq_redo_count() == n_comp // 2
+    assert f.texts() == want
+    packed = f.pack()  # the wire format flattens the two blocks
+    assert hip.merge_forests([packed]).texts() == want
+    assert hip.decompose(flags=F_REDO_ODD | F_SEQ_TREE).texts() == want
+    assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
+    assert f.texts() == want  # the earlier forest still owns its blocks
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_both_class_walks(hip, seed):
     """The per-class DFS has two walks: the plain one (small classes) and the one over class-filtered scan
