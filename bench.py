@@ -174,12 +174,12 @@ def main():
         achieved = alg / (pass_ms * 1e-3) / 1e9
         traffic, traffic_note = None, "no PMC run of this workload under profiles/"
         try:  # HBM bytes per pass from the committed rocprofv3 --pmc runs of this workload (profiles/)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pm.get("links") == E and pm.get("segments") == V:
-                if pm.get("kernel_source_digest") == kernel_source_digest():
-                    traffic, traffic_note = pm["hbm_bytes_per_pass"], "profiles/pmc_traffic.json (same kernels, same workload)"
-                else:
-                    traffic_note = "profiles/pmc_traffic.json is stale: the kernels changed since it was collected"
+            for pm in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))):
+                if pm.get("links") == E and pm.get("segments") == V:
+                    if pm.get("kernel_source_digest") == kernel_source_digest():
+                        traffic, traffic_note = pm["hbm_bytes_per_pass"], "profiles/pmc_traffic.json (same kernels, same workload)"
+                    else:
+                        traffic_note = "profiles/pmc_traffic.json is stale: the kernels changed since it was collected"
         except Exception:
             pass
         step_s = dt / args.steps

@@ -176,7 +176,7 @@ __device__ __forceinline__ void wave_append(bool take, uint32_t v, uint32_t k, u
 
 __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
 						  const uint32_t *__restrict__ adj, uint32_t *__restrict__ label,
-						  uint32_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist)
+						  uint8_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist)
 {
 	__shared__ uint32_t par[UF_TILE];
 	__shared__ uint32_t heavy[UF_HEAVY_CAP];
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		if (vo >= v1)
 			return true;
 		if (lds_union(par, v - v0, vo - v0))
-			hook[adj[k]] = 1u;
+			hook[adj[k]] = 1;
 		return false;
 	};
 	const uint32_t S0 = 2 * v0, S1 = 2 * v1;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 // the links that leave their tile, in global memory (grid-stride: their number only exists on the device)
 __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__restrict__ xlist,
 			   const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ adj, uint32_t *parent,
-			   uint32_t *__restrict__ hook)
+			   uint8_t *__restrict__ hook)
 {
 	const uint32_t NX = *xcount;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NX; i += gridDim.x * blockDim.x) {
@@ -265,7 +265,7 @@ __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__r
 			uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
 			uint32_t old = atomicCAS(&parent[hi], hi, lo);
 			if (old == hi) {
-				hook[adj[x.y]] = 1u;
+				hook[adj[x.y]] = 1;
 				break;
 			}
 			ra = uf_find(parent, old);
@@ -282,7 +282,7 @@ __global__ void k_compact_pos(uint32_t n, const uint32_t *__restrict__ flag, con
 		out[ps[i]] = i;
 }
 
-__global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint32_t *__restrict__ is_root)
+__global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__ is_root)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= V)
@@ -295,7 +295,7 @@ __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint32_t *__restrict_
 		r = p;
 	}
 	parent[v] = r; // readers of parent[] in this kernel only ever walk towards roots
-	is_root[v] = (r == v) ? 1u : 0u;
+	is_root[v] = (r == v) ? 1 : 0;
 }
 
 __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const uint32_t *__restrict__ crank,
@@ -384,8 +384,8 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 			      const uint32_t *__restrict__ erank, const uint32_t *__restrict__ v1,
 			      const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
 			      const uint8_t *__restrict__ s2, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-			      uint32_t *__restrict__ ldeg, const uint32_t *__restrict__ hook, uint32_t *__restrict__ la,
-			      uint32_t *__restrict__ lb, uint32_t *__restrict__ tgray)
+			      uint32_t *__restrict__ ldeg, const uint8_t *__restrict__ hook, uint32_t *__restrict__ la,
+			      uint32_t *__restrict__ lb, uint8_t *__restrict__ tgray)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
@@ -435,7 +435,7 @@ __device__ __forceinline__ bool slot_is_first(uint32_t i, uint32_t s, uint32_t v
 // first-encounter flags + the local degree of every side (no atomics) + the largest of them
 __global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
 			      const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
-			      const uint32_t *__restrict__ sbase, uint32_t *__restrict__ flag, uint32_t *__restrict__ ldeg,
+			      const uint32_t *__restrict__ sbase, uint8_t *__restrict__ flag, uint8_t *__restrict__ ldeg,
 			      uint32_t *__restrict__ stats)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,7 +447,7 @@ __global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, con
 		for (uint32_t k = lo; k < hi; k++, P++) {
 			const uint32_t o = aoth[k];
 			const bool f = slot_is_first(i, s, v, o, pos);
-			flag[P] = f ? 1u : 0u;
+			flag[P] = f ? 1 : 0;
 			cnt += ((o >> 1) == v) ? (f ? 1u : 0u) : 1u;
 		}
 		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1];
@@ -456,7 +456,7 @@ __global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, con
 			if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
 				cnt++;
 		}
-		ldeg[S] = cnt;
+		ldeg[S] = (uint8_t)cnt; // (this path only runs when no vertex has more than SORT_FREE_MAX_VDEG links)
 		if (S == 2 * V - 1)
 			ldeg[2 * V] = 0; // closes the array the scan turns into loff
 	}
@@ -483,8 +483,8 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 			    const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
 			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ atwin,
 			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ erank,
-			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ hook, uint32_t *__restrict__ la,
-			    uint32_t *__restrict__ lb, uint32_t *__restrict__ tgray, uint32_t *ladj, uint32_t *lle)
+			    const uint32_t *__restrict__ loff, const uint8_t *__restrict__ hook, uint32_t *__restrict__ la,
+			    uint32_t *__restrict__ lb, uint8_t *__restrict__ tgray, uint32_t *ladj, uint32_t *lle)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
@@ -718,17 +718,20 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
-	// hook[E] doubles as the length of the cross list
-	HIP_CHECK(hipMemsetAsync(st.hook, 0, ((size_t)E + 1) * 4, s));
+	// one byte per link; the length of the cross list sits behind them (zeroed by the same memset)
+	const size_t xoff = ((size_t)E + 7) & ~size_t(7);
+	HIP_CHECK(hipMemsetAsync(st.hook, 0, xoff + 8, s));
+	uint32_t *xcount = reinterpret_cast<uint32_t *>(st.hook + xoff);
 	uint2 *xlist = reinterpret_cast<uint2 *>(st.keys); // [E] pairs fit the 2E+2 words; free until the re-index
 	KLAUNCH(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, g.off, g.aoth, g.adj, st.label,
-			   st.hook, st.hook + E, xlist);
+			   st.hook, xcount, xlist);
 	if (E) {
-		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, st.hook + E, xlist, g.aoth, g.adj,
+		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, xcount, xlist, g.aoth, g.adj,
 				   st.label, st.hook);
 	}
-	KLAUNCH(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.flag);
-	scan_exclusive_u32(st.flag, st.crank, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+	uint8_t *is_root = reinterpret_cast<uint8_t *>(st.flag);
+	KLAUNCH(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, is_root);
+	scan_exclusive_u8(is_root, st.crank, (size_t)V + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(6);
 	return st.host->read_u32(st.crank + V, s);
 }
@@ -764,10 +767,10 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	// first-encounter rank of every edge
 	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
 		const uint32_t *pos_or_identity = C == 1 ? nullptr : st.pos; // one component: no vertex is renumbered
+		uint8_t *first8 = reinterpret_cast<uint8_t *>(st.flag), *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
 		KLAUNCH(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.aoth, st.sbase,
-				   st.flag, st.ldeg, st.stats);
-		scan_exclusive_u32_pair(st.flag, st.erank, (size_t)g.n_slots + 1, st.ldeg, st.loff, nS + 1, st.scan_tmp,
-					st.scan_tmp_bytes, s);
+				   first8, ldeg8, st.stats);
+		scan_exclusive_u8(first8, st.erank, (size_t)g.n_slots + 1, ldeg8, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin,
 				   st.sbase, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
 		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,

@@ -32,10 +32,10 @@ struct CompState {
 	uint32_t *label, *flag, *crank, *comp_of, *tmp_a, *ckey, *perm, *pos;
 	uint32_t *voff, *eoff, *vdeg, *sbase, *first, *erank, *ldeg, *loff, *ladj;
 	uint32_t *keys, *vals, *keys2, *vals2;
-	uint32_t *hook;	   // [E]  1 = the link merged two union-find trees (spanning forest of the segments)
+	uint8_t *hook;	   // [E]  1 = the link merged two union-find trees (spanning forest of the segments)
 	uint32_t *la, *lb; // [E]  sorted side ids of local edge le (la = first-encounter side)
 	uint32_t *lle;	   // [2E] local edge idx of every adjacency slot
-	uint32_t *tgray;   // [E+1] local edge is in the spanning forest
+	uint8_t *tgray;	   // [E+1] local edge is in the spanning forest
 	uint32_t *stats;   // [4]  stats[0] = max links on one side
 	uint32_t *gid_s;
 	uint8_t *tip_s;

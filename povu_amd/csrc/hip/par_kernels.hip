@@ -119,29 +119,31 @@ __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const ui
 // bridge(v): no ordinary back edge out of subtree(v) reaches a proper ancestor of v (the bracket list of v would be
 // empty but for simplifying edges): the subtree sum of cov is zero
 __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
-			       const uint32_t *__restrict__ pscov, uint32_t *__restrict__ bridge)
+			       const uint32_t *__restrict__ pscov, uint8_t *__restrict__ bridge)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	const uint32_t sz = gsize[t];
-	bridge[t] = (sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1u : 0u;
+	bridge[t] = (sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1 : 0;
 	if (t == T - 1)
 		bridge[T] = 0;
 }
 // simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
 // the root, flubbles.cpp:621-643)
-__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ bridge,
-			  const uint32_t *__restrict__ psb, uint32_t *__restrict__ simp, uint8_t *__restrict__ hpf)
+__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
+			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	uint32_t sz = gsize[t];
-	const uint32_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1u : 0u;
+	const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
 	simp[t] = sm;
+	if (t == T - 1)
+		simp[T] = 0;
 	if (hpf)
-		hpf[t] = (uint8_t)sm;
+		hpf[t] = sm;
 }
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
 // ascending idx are v+1, then each next sibling at c + size(c).  hi(c) = min target of the back edges leaving
@@ -149,7 +151,7 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 // so it is evaluated on demand, for the children of branching vertices alone (range-min over hi0).
 __global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
 			  const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ segA,
-			  uint32_t P, uint32_t *__restrict__ cap_tgt, uint32_t *__restrict__ capf)
+			  uint32_t P, uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
@@ -224,8 +226,8 @@ __global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uin
 // The brackets are laid out in an initial order that already satisfies the second criterion
 // (simplifying | capping | ordinary by DESCENDING dense idx), so ONE stable 32-bit radix sort by the
 // source's mirror pre-order yields the list order.
-__global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ capf,
-				const uint32_t *__restrict__ pscap, const uint32_t *__restrict__ simp,
+__global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
+				const uint32_t *__restrict__ pscap, const uint8_t *__restrict__ simp,
 				const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
 				const uint32_t *__restrict__ t_root, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
 {
@@ -279,7 +281,7 @@ __global__ void k_bracket_count(uint32_t NB, const uint32_t *__restrict__ b_src,
 __global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ b_src,
 				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ b_ord,
 				const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
-				const uint32_t *__restrict__ capf, const uint32_t *__restrict__ simp,
+				const uint8_t *__restrict__ capf, const uint8_t *__restrict__ simp,
 				uint32_t *__restrict__ tgtR, uint32_t *__restrict__ rid)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,7 +356,7 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
 __global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-			      const uint32_t *__restrict__ lsz, uint32_t *__restrict__ flag, uint32_t *__restrict__ dlt)
+			      const uint32_t *__restrict__ lsz, uint8_t *__restrict__ flag, uint32_t *__restrict__ dlt)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
@@ -368,19 +370,18 @@ __global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restr
 		return;
 	}
 	bool fresh = q == 0 || skey[q - 1] != k || lsz[sval[q - 1]] != lsz[sval[q]];
-	flag[q] = fresh ? 1u : 0u;
+	flag[q] = fresh ? 1 : 0;
 	(void)mask;
 }
 __global__ void k_class_scatter(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-				const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
-				uint32_t *__restrict__ gcls, uint32_t *__restrict__ t_cls)
+				const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
+				uint32_t *__restrict__ gcls)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
 		return;
 	const uint32_t cls = skey[q] == NIL ? NIL : ps[q] + flag[q] - 1; // inclusive scan - 1
-	gcls[sval[q]] = cls;
-	t_cls[sval[q]] = cls; // the per-component layout the debug hooks / sequential kernels read
+	gcls[sval[q]] = cls; // (T-space = the per-component layout the debug hook reads)
 }
 
 // ------------------------------------------------------------- row E
@@ -410,15 +411,15 @@ __global__ void k_mpos_scatter(uint32_t T, const uint32_t *__restrict__ dlt, con
 		inv[v + dlt_ps[v] + dlt[v]] = v;
 }
 __global__ void k_black_flag(uint32_t T, const uint32_t *__restrict__ inv, const uint32_t *__restrict__ gsize,
-			     const uint8_t *__restrict__ tf, uint32_t *__restrict__ flag)
+			     const uint8_t *__restrict__ tf, uint8_t *__restrict__ flag)
 {
 	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
 	if (m >= T)
 		return;
 	uint32_t v = inv[m];
-	flag[m] = (gsize[v] && (tf[v] & TF_BLACK)) ? 1u : 0u;
+	flag[m] = (gsize[v] && (tf[v] & TF_BLACK)) ? 1 : 0;
 }
-__global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const uint32_t *__restrict__ flag,
+__global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const uint8_t *__restrict__ flag,
 			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
 			     const uint32_t *__restrict__ t_comp, uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls,
 			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns,
@@ -516,11 +517,11 @@ __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const
 	}
 }
 // entry i opens a flubble iff its class comes back later than at the next entry (flubbles.cpp:344)
-__global__ void k_dflag(uint32_t S, const uint32_t *__restrict__ ns, uint32_t *__restrict__ dflag)
+__global__ void k_dflag(uint32_t S, const uint32_t *__restrict__ ns, uint8_t *__restrict__ dflag)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < S)
-		dflag[i] = (i + 1 < ns[i]) ? 1u : 0u;
+		dflag[i] = (i + 1 < ns[i]) ? 1 : 0;
 	if (i == S)
 		dflag[S] = 0;
 }
@@ -528,7 +529,7 @@ __global__ void k_dflag(uint32_t S, const uint32_t *__restrict__ ns, uint32_t *_
 // the candidate stack and next_seen, so this kernel runs on the context's side stream while the main stream still
 // computes levels and parents: the PCIe writes (10 of the 14 bytes per PVST vertex) hide behind that work.  A small
 // grid-stride launch: a few ten thousand lanes keep the link busy and leave the CUs to the main stream.
-__global__ void k_emit_endpoints(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
+__global__ void k_emit_endpoints(uint32_t S, const uint8_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
 				 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ ns,
 				 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
 				 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
@@ -555,7 +556,7 @@ __global__ void k_emit_endpoints(uint32_t S, const uint32_t *__restrict__ dflag,
 	}
 }
 // level of every emitted flubble
-__global__ void k_levels(uint32_t S, const uint32_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
+__global__ void k_levels(uint32_t S, const uint8_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
 			 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
 			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ negmax,
 			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i)
@@ -653,7 +654,7 @@ __global__ void k_hp_close(uint32_t T, const uint32_t *__restrict__ gsize, const
 			   const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ c_ntree,
 			   const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ a_close,
 			   const uint32_t *__restrict__ s1, uint32_t P1, const uint32_t *__restrict__ s2, uint32_t P2,
-			   const uint32_t *__restrict__ s3, uint32_t P3, uint32_t *__restrict__ push,
+			   const uint32_t *__restrict__ s3, uint32_t P3, uint8_t *__restrict__ push,
 			   unsigned long long *__restrict__ b12)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -677,7 +678,7 @@ __global__ void k_hp_close(uint32_t T, const uint32_t *__restrict__ gsize, const
 	(void)gsize;
 }
 // boundaries are reported in processing order: closers by descending idx inside a component
-__global__ void k_hp_emit(uint32_t T, const uint32_t *__restrict__ push, const uint32_t *__restrict__ ps,
+__global__ void k_hp_emit(uint32_t T, const uint8_t *__restrict__ push, const uint32_t *__restrict__ ps,
 			  const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ t_comp,
 			  const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ voff,
 			  const unsigned long long *__restrict__ b12, unsigned long long *__restrict__ out,
@@ -708,11 +709,12 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 	seg_build(pw.segH1, pw.hp1, T, s);
 	seg_build(pw.segH2, pw.hp2, T, s);
 	seg_build(pw.segH3, pw.hp3, T, s);
-	uint32_t *push = pw.flagA, *pps = pw.psA;
+	uint8_t *push = pw.f8a;
+	uint32_t *pps = pw.psA;
 	unsigned long long *b12 = (unsigned long long *)pw.b_key; // free after the class stage, >= 2T entries
 	LAUNCH(k_hp_close, T, s, T, pw.gsize, pw.t_root, pw.t_comp, sw.c_ntree, sw.t_gid, pw.hp3, pw.segH1.tree, pw.segH1.P,
 	       pw.segH2.tree, pw.segH2.P, pw.segH3.tree, pw.segH3.P, push, b12);
-	scan_exclusive_u32(push, pps, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	scan_exclusive_u8(push, pps, (size_t)T + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_hp_emit, T, s, T, push, pps, pw.t_root, pw.t_comp, sw.c_ntree, cs.voff, b12, (unsigned long long *)sw.hairpins,
 	       sw.c_nbry);
 	tm.end(10);
@@ -723,10 +725,12 @@ template <typename F>
 static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 {
 	const size_t T = 2 * V + Cmax, NB = E + V + 2 * T, S = V + 1;
-	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.cov, &pw.flagA, &pw.psA,
-			     &pw.flagB, &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
+	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.cov, &pw.psA,
+			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
 			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.inv, &pw.vals_t, &pw.vals_t2})
 		take((void **)p, (T + 2) * 4);
+	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c})
+		take((void **)p, T + 32);
 	take((void **)&pw.keys_t, (T + 2) * 8);
 	take((void **)&pw.keys_t2, (T + 2) * 8);
 	take((void **)&pw.dbo, (Cmax + 2) * 4);
@@ -822,6 +826,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
 		scan_exclusive_u32(in, out, n, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	};
+	auto scan8 = [&](const uint8_t *in, uint32_t *out, size_t n) {
+		scan_exclusive_u8(in, out, n, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	};
 	auto scan2 = [&](const uint32_t *in0, uint32_t *out0, size_t n0, const uint32_t *in1, uint32_t *out1, size_t n1) {
 		scan_exclusive_u32_pair(in0, out0, n0, in1, out1, n1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	};
@@ -846,14 +853,15 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint32_t launches = 0;
 	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov);
 	seg_build(pw.segA, pw.hi0, T, s);
-	uint32_t *bridge = pw.flagA, *psb = pw.psA, *simp = pw.flagB, *pssimp = pw.psB, *capf = pw.flagC, *pscap = pw.psC;
+	uint8_t *bridge = pw.f8a, *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
+	uint32_t *psb = pw.psA, *pssimp = pw.psB, *pscap = pw.psC;
 	uint32_t *pscov = pw.psB; // (free until the simplifying flags are scanned)
 	scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
-	scan(bridge, psb, (size_t)T + 1);
+	scan8(bridge, psb, (size_t)T + 1);
 	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr);
 	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf);
-	scan2(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1);
+	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre, pw.incnt, srccnt);
 	uint32_t *extra = pw.host->take<uint32_t>(2);
@@ -880,10 +888,11 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	       pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr);
 	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, T, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
-	uint32_t *cflag = pw.flagA, *cps = pw.psA; // bridge flags are dead by now
+	uint8_t *cflag = pw.f8a; // bridge flags are dead by now
+	uint32_t *cps = pw.psA;
 	LAUNCH(k_class_flags, T, s, T, 0u, ck2, pw.vals_t2, pw.lsz, cflag, pw.dlt);
-	scan(cflag, cps, (size_t)T + 1);
-	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls, sw.t_cls);
+	scan8(cflag, cps, (size_t)T + 1);
+	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls);
 	launches = 30 + 2 * 22;
 	tm.end(launches);
 
@@ -892,9 +901,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_shift_delta, T, s, T, pw.gsize, pw.gpar, sw.t_flags, pw.dlt);
 	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
 	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.inv);
-	uint32_t *bflag = pw.flagB, *bps = pw.psB;
+	uint8_t *bflag = pw.f8b;
+	uint32_t *bps = pw.psB;
 	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
-	scan(bflag, bps, (size_t)T + 1);
+	scan8(bflag, bps, (size_t)T + 1);
 	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
 	       pw.prev, C, cs.voff, pw.soff, n_stack, pw.err + 3);
 	// one candidate-stack entry per black tree edge = per segment of a processed component: the host knows the
@@ -914,9 +924,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row G
 	tm.begin("par_pvst");
-	uint32_t *dflag = pw.s_key; // scratch
+	uint8_t *dflag = pw.f8c; // [S+1] <= [T+1]; capping flags are dead by now
 	LAUNCH(k_dflag, (size_t)S + 1, s, S, pw.ns, dflag);
-	scan(dflag, pw.erank, (size_t)S + 1);
+	scan8(dflag, pw.erank, (size_t)S + 1);
 	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
 	// The five PVST arrays back to back (povu_hip_forest::alloc has the same layout).  Small results are written by the
 	// emit kernels straight into the forest's page-locked host block (no copy, no extra launch).  Large ones go

@@ -27,7 +27,8 @@ struct ParWs {
 	uint32_t V, E, C, T;
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
-	uint32_t *hi0, *cov, *flagA, *psA, *flagB, *psB, *flagC, *psC; // flags + their exclusive scans [T+1]
+	uint32_t *hi0, *cov, *psA, *psB, *flagC, *psC; // exclusive scans of the byte flags below [T+1]; flagC: run marks
+	uint8_t *f8a, *f8b, *f8c;	 // [T+1] one-byte flags (bridge / simplifying / capping vertex, class and stack flags)
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
 	uint32_t *inv, *vals_t, *vals_t2;
 	uint64_t *keys_t, *keys_t2; // [T]

@@ -210,11 +210,11 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take(&cs.vals, 2 * E + 2, 4);
 		take(&cs.keys2, 2 * E + 2, 4);
 		take(&cs.vals2, 2 * E + 2, 4);
-		take(&cs.hook, E + 2, 4);
+		take(&cs.hook, E + 32, 1);
 		take(&cs.la, E + 2, 4);
 		take(&cs.lb, E + 2, 4);
 		take(&cs.lle, 2 * E + 2, 4);
-		take(&cs.tgray, E + 2, 4);
+		take(&cs.tgray, E + 32, 1);
 		take(&cs.stats, 16, 4);
 		take(&cs.gid_s, V + 1, 4);
 		take(&cs.tip_s, V + 1, 1);
@@ -435,6 +435,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
 		ctx->stack_export_pending = false;
+		ctx->classes_in_par = false;
 		ctx->host.reset();
 		cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
@@ -593,6 +594,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			}
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
 			ctx->stack_export_pending = true;
+			ctx->classes_in_par = true;
 			if (o.flags & POVU_HIP_F_REDO_ODD) // (tests: flag every other component as if its stack were not laminar)
 				mark_odd_u32(ctx->pw.comp_bad, C, s);
 			sum = read_summary(true);
@@ -1008,8 +1010,9 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 			HIP_CHECK(hipMemcpy(gid, ctx->sw.t_gid + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
 		if (par)
 			HIP_CHECK(hipMemcpy(par, ctx->sw.t_par + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
-		if (cls)
-			HIP_CHECK(hipMemcpy(cls, ctx->sw.t_cls + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
+		if (cls) // the parallel class stage keeps the classes in its own T-space array
+			HIP_CHECK(hipMemcpy(cls, (ctx->classes_in_par && ctx->last_seq_redo == 0 ? ctx->pw.gcls : ctx->sw.t_cls) + tb,
+					    (size_t)N * 4, hipMemcpyDeviceToHost));
 		if (typ)
 			HIP_CHECK(hipMemcpy(typ, ctx->sw.t_flags + tb, N, hipMemcpyDeviceToHost));
 		return 0;

@@ -35,6 +35,7 @@ __device__ __forceinline__ uint32_t sc_block_reduce(uint32_t v, uint32_t *sh)
 // are due at the same point of the pass share their two launches.
 struct ScanJob {
 	const uint32_t *in;
+	const uint8_t *in8; // when set: the input is one BYTE per element (flags, small counts) -- a quarter of the reads
 	uint32_t *out;
 	size_t n, chunk;
 	uint32_t blocks;
@@ -55,8 +56,19 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_partials(const ScanJobs jobs)
 	const size_t n = J.n, chunk = J.chunk;
 	const size_t b0 = (size_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
 	uint32_t acc = 0;
-	for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
-		acc = sc_op<MAX>(acc, in[i]);
+	if (J.in8) { // chunks start on multiples of the tile: four bytes per load
+		const uint8_t *__restrict__ in8 = J.in8;
+		const size_t w1 = b0 + ((b1 - b0) & ~size_t(3));
+		for (size_t i = b0 + 4 * (size_t)threadIdx.x; i < w1; i += 4 * SC_TPB) {
+			const uint32_t w = *reinterpret_cast<const uint32_t *>(in8 + i);
+			acc = sc_op<MAX>(sc_op<MAX>(sc_op<MAX>(acc, w & 0xFFu), sc_op<MAX>((w >> 8) & 0xFFu, (w >> 16) & 0xFFu)), w >> 24);
+		}
+		for (size_t i = w1 + threadIdx.x; i < b1; i += SC_TPB)
+			acc = sc_op<MAX>(acc, in8[i]);
+	} else {
+		for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
+			acc = sc_op<MAX>(acc, in[i]);
+	}
 	acc = sc_block_reduce<MAX>(acc, sh);
 	if (threadIdx.x == 0)
 		partial[blockIdx.x] = acc;
@@ -82,7 +94,17 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 	for (size_t t0 = b0; t0 < b1; t0 += SC_TILE) {
 		const size_t e0 = t0 + (size_t)threadIdx.x * SC_ITEMS;
 		uint32_t v[SC_ITEMS];
-		if (e0 + SC_ITEMS <= b1) {
+		if (J.in8) {
+			const uint8_t *__restrict__ in8 = J.in8;
+			if (e0 + SC_ITEMS <= b1) {
+				const uint2 a = *reinterpret_cast<const uint2 *>(in8 + e0);
+				v[0] = a.x & 0xFFu, v[1] = (a.x >> 8) & 0xFFu, v[2] = (a.x >> 16) & 0xFFu, v[3] = a.x >> 24;
+				v[4] = a.y & 0xFFu, v[5] = (a.y >> 8) & 0xFFu, v[6] = (a.y >> 16) & 0xFFu, v[7] = a.y >> 24;
+			} else {
+				for (int k = 0; k < SC_ITEMS; k++)
+					v[k] = e0 + k < b1 ? in8[e0 + k] : 0u;
+			}
+		} else if (e0 + SC_ITEMS <= b1) {
 			const uint4 a = *reinterpret_cast<const uint4 *>(in + e0), b = *reinterpret_cast<const uint4 *>(in + e0 + 4);
 			v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
 		} else {
@@ -132,9 +154,9 @@ size_t scan_tmp_bytes(size_t)
 	return 2 * SC_MAX_BLOCKS * sizeof(uint32_t) + 256;
 }
 
-static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial)
+static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial, const uint8_t *in8 = nullptr)
 {
-	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)
+	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(in8) | reinterpret_cast<uintptr_t>(out)) & 15)
 		throw HipError("scan: operands must be 16-byte aligned");
 	size_t blocks = (n + SC_TILE - 1) / SC_TILE;
 	if (blocks > SC_MAX_BLOCKS)
@@ -142,7 +164,7 @@ static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32
 	size_t chunk = (n + blocks - 1) / blocks;
 	chunk = (chunk + SC_TILE - 1) / SC_TILE * SC_TILE; // whole tiles: every tile base stays 16-byte aligned
 	blocks = (n + chunk - 1) / chunk;
-	return ScanJob{in, out, n, chunk, (uint32_t)blocks, partial};
+	return ScanJob{in, in8, out, n, chunk, (uint32_t)blocks, partial};
 }
 
 template <int MAX>
@@ -156,6 +178,30 @@ static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tm
 	jobs.j[0] = make_scan_job(in, out, n, static_cast<uint32_t *>(tmp));
 	KLAUNCH(k_scan_partials<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 	KLAUNCH(k_scan_chunks<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
+}
+
+// byte inputs: one or two independent jobs in the same two launches (in1 may be null)
+void scan_exclusive_u8(const uint8_t *in0, uint32_t *out0, size_t n0, const uint8_t *in1, uint32_t *out1, size_t n1, void *tmp,
+		       size_t tmp_bytes, hipStream_t s)
+{
+	if (tmp_bytes < 2 * SC_MAX_BLOCKS * sizeof(uint32_t))
+		throw HipError("scan: temporary storage too small");
+	ScanJobs jobs{};
+	unsigned gx = 0, gy = 0;
+	if (n0) {
+		jobs.j[gy] = make_scan_job(nullptr, out0, n0, static_cast<uint32_t *>(tmp) + gy * SC_MAX_BLOCKS, in0);
+		gx = std::max(gx, jobs.j[gy].blocks);
+		gy++;
+	}
+	if (in1 && n1) {
+		jobs.j[gy] = make_scan_job(nullptr, out1, n1, static_cast<uint32_t *>(tmp) + gy * SC_MAX_BLOCKS, in1);
+		gx = std::max(gx, jobs.j[gy].blocks);
+		gy++;
+	}
+	if (!gy)
+		return;
+	KLAUNCH(k_scan_partials<0>, dim3(gx, gy), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_chunks<0>, dim3(gx, gy), dim3(SC_TPB), 0, s, jobs);
 }
 
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)

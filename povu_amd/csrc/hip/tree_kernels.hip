@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, unsigned 
 // = the black arc, then the side's tree-gray links in adjacency order.  No atomics: a side counts and
 // places its own arcs.
 __global__ void k_arc_count(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
-			    const uint32_t *__restrict__ tgray, uint32_t *__restrict__ acnt)
+			    const uint8_t *__restrict__ tgray, uint32_t *__restrict__ acnt)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -82,7 +82,7 @@ __global__ void k_arc_count(uint32_t nS, const uint32_t *__restrict__ loff, cons
 }
 __global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t *__restrict__ loff,
 			    const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
-			    const uint32_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
+			    const uint8_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
 			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ arc_src,
 			    uint32_t *__restrict__ arc_le, uint32_t *__restrict__ apos,
 			    uint32_t *__restrict__ sarc, uint32_t expect, uint32_t *err)
@@ -458,7 +458,7 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 __global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
 			     const uint32_t *__restrict__ arc_le, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
-			     const uint32_t *__restrict__ tgray, uint32_t *__restrict__ par0, uint32_t *__restrict__ tin,
+			     const uint8_t *__restrict__ tgray, uint32_t *__restrict__ par0, uint32_t *__restrict__ tin,
 			     uint32_t *__restrict__ tout, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ vlo,
 			     uint32_t *__restrict__ vhi, uint32_t C, const unsigned long long *__restrict__ start_key)
 {
@@ -576,7 +576,7 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const 
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ecc,
 			  uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis,
-			  uint32_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
+			  uint8_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -593,7 +593,7 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const 
 	if (!proc)
 		return;
 	// a class is walked from its entry side; a side that is alone in its class has nothing to walk
-	const uint32_t walk = multi[S] ? 1u : 0u;
+	const uint8_t walk = multi[S] ? 1 : 0;
 	uint32_t p = par0[S];
 	if (p == NIL) { // DFS start of the component
 		dvis[S] = 1;
@@ -619,7 +619,7 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const 
 		cslot[S] = lo - loff[p] + 1;
 	}
 }
-__global__ void k_compact(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
+__global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 			  uint32_t *__restrict__ out)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -967,10 +967,11 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.arc_le, NA * 2);
 	take((void **)&tw.evt, NA * 8);
 	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.xlo, &tw.xhi, &tw.isbridge,
-			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_flag, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
+			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
 			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
+	take((void **)&tw.entry_flag, nS + 16);
 	take((void **)&tw.ckey, (nS + 2 * E + 8) * 4); // scan-slot -> child table of the child ordering
 	take((void **)&tw.ckey2, 64);
 	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
@@ -1009,7 +1010,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
-	scan(cs.tgray, tw.tg_ps, (size_t)E + 1);
+	scan_exclusive_u8(cs.tgray, tw.tg_ps, (size_t)E + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	const uint32_t NTG = V - C; // a spanning forest; k_arc_lists raises err[2] if the hooks disagree
 	const uint32_t NA = 2 * (V + NTG);
 	uint32_t *acnt = tw.k1, *aoff = tw.k2; // [nS+1] each fits the 4V+8 buffers
@@ -1044,7 +1045,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint32_t *cstate = sw.cur; // [nS+1]
 	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dpar,
 	       tw.cslot, tw.dvis, tw.entry_flag, cstate);
-	scan(tw.entry_flag, tw.entry_ps, (size_t)nS + 1);
+	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
 	uint32_t *hb = tw.host->take<uint32_t>(2);
 	HIP_CHECK(hipMemcpyAsync(hb, tw.entry_ps + nS, 4, hipMemcpyDeviceToHost, s));

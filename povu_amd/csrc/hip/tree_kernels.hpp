@@ -25,7 +25,8 @@ struct TreeWs {
 	uint4 *crb;					  // [2V] {begin, count, first entry} of a side's filtered list
 	uint4 *cret;					  // [2V] scan state of the DFS parent at the moment it descended
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
-	uint32_t *entry_flag, *entry_ps, *entry_list;	  // [2V+1]
+	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
+	uint32_t *entry_ps, *entry_list;		  // [2V+1]
 	uint64_t *ckey, *ckey2;				  // [2V]
 	uint32_t *cval, *cval2, *fc, *nsib;		  // [2V]
 	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]

@@ -1,77 +1,95 @@
-"""Turn gpurun_out/final/ (tools/collect_profiles.sh) into the committed files under profiles/."""
+"""Turn gpurun_out/final/<workload>/ (tools/collect_profiles.sh) into the committed files under profiles/:
+<tag>_<workload>_bench.json, _bench_under_rocprof.json, _kernel_stats.csv, pmc_traffic.json and <tag>_summary.md."""
 import csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # kernel_source_digest
 F = os.path.join(ROOT, "gpurun_out", "final")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-bench = json.loads(open(os.path.join(F, "bench.json")).read().strip().splitlines()[-1])
-under = json.loads(open(os.path.join(F, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
-fetch = json.load(open(os.path.join(F, "fetch_summary.json")))
-write = json.load(open(os.path.join(F, "write_summary.json")))
-shutil.copy(os.path.join(F, "bench.json"), os.path.join(P, f"{tag}_bench_final.json"))
-shutil.copy(os.path.join(F, "bench_under_rocprof.json"), os.path.join(P, f"{tag}_bench_under_rocprof.json"))
-ks = sorted(glob.glob(os.path.join(F, "kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1]
-shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats_bench_chain1M.csv"))
-E, V = bench["config"]["links_per_gpu"], bench["config"]["segments_per_gpu"]
-hbm = (fetch["per_pass"] + write["per_pass"]) * 1024.0
-json.dump({"workload": "chain-of-bubbles K=333333", "links": E, "segments": V, "hbm_bytes_per_pass": int(hbm),
-           "fetch_size_kb_per_pass": fetch["per_pass"], "write_size_kb_per_pass": write["per_pass"],
-           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 2 --warmup 1` "
-                   "(4 decompose passes + one upload, divided by 4; tools/collect_profiles.sh). Counter values as reported (KB); "
-                   "FETCH_SIZE is not doubled because the accesses are mostly 4-byte gathers, not 16-byte streams "
-                   "(MI355X_MICROARCH.md: uncalibrated for other widths); Infinity-Cache hits are counted."},
-          open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
-rows = list(csv.DictReader(open(ks)))
-passes = under["steps"] + under["warmup"] + 1  # + the stage-breakdown pass
-tot_ns = sum(int(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+PASSES = 4  # bench.py --steps 2 --warmup 1: 1 warm-up + 2 timed + 1 stage-breakdown pass
+
+
 def short(n):
     n = re.sub(r"\(.*", "", n).replace("povu_hip::", "").replace("void ", "")
     if "rocprim" in n:
-        m = re.search(r"(radix_sort_onesweep_iteration|radix_sort_onesweep_global_offsets|scan_impl|init_lookback\w*)", n)
-        n = "rocprim " + (m.group(1) if m else "?")
+        m = re.search(r"(radix_sort_onesweep|radix_sort_\w+|scan_impl|init_lookback\w*)", n)
+        n = "rocprim:" + (m.group(1) if m else "?")
     return n[:60]
-tl = open(os.path.join(F, "timeline_summary.txt")).read().strip()
-alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-L = []
-L.append(f"# Round 1 profiles (MI355X, ROCm 7.2) -- regenerate with tools/collect_profiles.sh + tools/make_profile_summary.py\n")
-L.append(f"Workload: BASELINE config 2, chain-of-bubbles K=333333 ({V:,} segments / {E:,} links / {bench['config']['flubbles_per_gpu']:,} flubbles).\n")
-L.append(f"Bench line (`{tag}_bench_final.json`, default `python bench.py`): **{bench['value']:.3e} links/s, {bench['ms_per_step']:.2f} ms per pass**, "
-         f"HIP-event time of the pass {bench['roofline']['ms_per_launch']:.2f} ms, roofline frac {bench['roofline']['frac']:.4f} "
-         f"(algorithmic 48E+108V+16F = {alg/1e6:.0f} MB per pass); CPU port on the same box: {bench['cpu_baseline']['value']:.3e} links/s on 1 core.\n")
-L.append("## Kernel trace\n")
-L.append(f"`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 2` ({passes} decompose passes + one upload)\n")
-L.append(f"Sum of kernel durations {tot_ns/1e6:.2f} ms over {calls} launches; the last pass of the trace: `{tl}` "
-         f"(HIP-event time of a pass in that run: {under['roofline']['ms_per_launch']:.2f} ms, `{tag}_bench_under_rocprof.json`).\n")
-L.append("| kernel | calls/pass | us/pass | avg us | % |\n|---|---|---|---|---|")
-for r in sorted(rows, key=lambda r: -int(r["TotalDurationNs"]))[:32]:
-    L.append(f"| `{short(r['Name'])}` | {int(r['Calls'])/passes:.1f} | {int(r['TotalDurationNs'])/passes/1e3:.1f} | {float(r['AverageNs'])/1e3:.2f} | {float(r['Percentage']):.2f} |")
-L.append(f"\nFull table: `{tag}_kernel_stats_bench_chain1M.csv`.\n")
-L.append("## HBM traffic (PMC)\n")
-L.append(f"`rocprofv3 --pmc FETCH_SIZE ...` and `--pmc WRITE_SIZE ...` (separate passes): FETCH_SIZE {fetch['per_pass']*1024/1e9:.2f} GB + WRITE_SIZE "
-         f"{write['per_pass']*1024/1e9:.2f} GB = **{hbm/1e9:.2f} GB per pass** against {alg/1e9:.3f} GB algorithmic: ~{hbm/alg:.0f}x "
-         f"(= {hbm/1e9/bench['roofline']['ms_per_launch']:.2f} TB/s while the pass runs).  Where the bytes go:\n")
-L.append("| kernel | fetch MB/pass | | kernel | write MB/pass |\n|---|---|---|---|---|")
-for (a, b), (c, d) in zip(fetch["top"][:10], write["top"][:10]):
-    L.append(f"| `{a[:40]}` | {b*1024/1e6:.0f} | | `{c[:40]}` | {d*1024/1e6:.0f} |")
-# per kernel: counted bytes / time it runs = how close each kernel is to the HBM roofline (6.3 TB/s achievable)
-fmap = {k: v for k, v in fetch["top"]}; wmap = {k: v for k, v in write["top"]}
-dur = {}
-for r in rows:
-    k = short(r["Name"]).replace("rocprim radix_sort_onesweep_iteration", "rocprim:radix_sort").replace("rocprim radix_sort_onesweep_global_offsets", "rocprim:radix_sort")
-    dur[k] = dur.get(k, 0.0) + int(r["TotalDurationNs"]) / passes / 1e3
-L.append("\nBytes moved per kernel against the time it runs (both per pass; FETCH_SIZE + WRITE_SIZE as counted):\n")
-L.append("| kernel | us/pass | MB/pass | TB/s | |\n|---|---|---|---|---|")
-tbl = []
-for k, us in dur.items():
-    mb = (fmap.get(k, 0.0) + wmap.get(k, 0.0)) * 1024 / 1e6
-    if us > 15 and mb > 0:
-        tbl.append((us, k, mb))
-for us, k, mb in sorted(tbl, reverse=True)[:18]:
-    tbs = mb / us  # MB per microsecond = TB/s
-    note = "bandwidth (of its amplified traffic)" if tbs > 3.0 else ("latency / dependent loads" if tbs < 1.0 else "")
-    L.append(f"| `{k[:40]}` | {us:.0f} | {mb:.0f} | {tbs:.2f} | {note} |")
-extra = os.path.join(P, f"{tag}_other_workloads.md")
+
+
+traffic = []
+L = [f"# Round {tag[1:]} profiles (MI355X, ROCm 7.2) -- regenerate with tools/collect_profiles.sh + tools/make_profile_summary.py\n"]
+for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline workload of bench.py)"), ("chain", "BASELINE config 2")):
+    D = os.path.join(F, wl)
+    if not os.path.isdir(D):
+        continue
+    bench_line = json.loads(open(os.path.join(D, "bench.json")).read().strip().splitlines()[-1])
+    under = json.loads(open(os.path.join(D, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    fetch = json.load(open(os.path.join(D, "fetch_summary.json")))
+    write = json.load(open(os.path.join(D, "write_summary.json")))
+    for src, dst in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("kernel_stats.csv", "kernel_stats.csv")):
+        shutil.copy(os.path.join(D, src), os.path.join(P, f"{tag}_{wl}_{dst}"))
+    E, V = bench_line["config"]["links"], bench_line["config"]["segments"]
+    rows = list(csv.DictReader(open(os.path.join(D, "kernel_stats.csv"))))
+    # calibration of FETCH_SIZE on kernels of this very run whose bytes are known: the two scan kernels read their input
+    # exactly once (k_scan_partials with 4-byte-per-lane loads, k_scan_chunks with 16-byte-per-lane loads) and
+    # k_scan_chunks writes as many bytes as it reads
+    fmap = {k: v for k, v in fetch["top"]}
+    wmap = {k: v for k, v in write["top"]}
+    cal = {}
+    if fmap.get("k_scan_chunks<0>") and wmap.get("k_scan_chunks<0>"):
+        known = wmap["k_scan_chunks<0>"]  # WRITE_SIZE is exact for 16-byte streaming stores (guide) = bytes read as well
+        cal = {"read_16B_per_lane": fmap["k_scan_chunks<0>"] / known, "read_4B_per_lane": fmap.get("k_scan_partials<0>", 0) / known}
+    raw = (fetch["per_pass"] + write["per_pass"]) * 1024.0
+    # corrected: the guide's gfx950 rule doubles FETCH_SIZE of 16-byte-per-lane streams; here only the share of the kernels
+    # that stream with uint4 loads (the scans) is doubled, everything else (4-byte gathers and strided 4-byte loads)
+    # is taken as counted, which the calibration above supports when read_4B_per_lane is ~1
+    wide = sum(v for k, v in fetch["top"] if k.startswith("k_scan_chunks"))
+    corrected = (fetch["per_pass"] + wide + write["per_pass"]) * 1024.0
+    traffic.append({"workload": bench_line["config"]["workload"], "links": E, "segments": V, "hbm_bytes_per_pass": int(corrected),
+                    "raw_counter_bytes_per_pass": int(raw), "fetch_size_kb_per_pass": fetch["per_pass"],
+                    "write_size_kb_per_pass": write["per_pass"], "fetch_calibration": cal,
+                    "kernel_source_digest": bench.kernel_source_digest(),
+                    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --workload " + wl +
+                            " --steps 2 --warmup 1` (4 decompose passes + one upload, divided by 4). Counter values are KB. "
+                            "Correction per MI355X_MICROARCH.md (gfx950 counts 16-byte-per-lane streaming reads at half): the "
+                            "FETCH_SIZE of the uint4-streaming scan kernels is doubled, 4-byte accesses are taken as counted "
+                            "(fetch_calibration = counted / known bytes on the scan kernels of this run); Infinity-Cache hits are counted."})
+    passes = PASSES
+    tot_ns = sum(int(r["TotalDurationNs"]) for r in rows)
+    calls = sum(int(r["Calls"]) for r in rows)
+    alg = bench_line["roofline"]["algorithmic_bytes_per_launch"]
+    L.append(f"## {title}\n")
+    L.append(f"Workload: {bench_line['config']['workload']}.\n")
+    cb = bench_line.get("cpu_baseline")
+    L.append(f"Bench line (`{tag}_{wl}_bench.json`): **{bench_line['value']:.3e} links/s, {bench_line['ms_per_step']:.2f} ms per pass**, HIP-event time of "
+             f"the pass {bench_line['roofline']['ms_per_launch']:.2f} ms, roofline frac {bench_line['roofline']['frac']:.4f} (algorithmic 48E+108V+16F = "
+             f"{alg/1e9:.3f} GB per pass)" + (f"; CPU port on the box: {cb['value']:.3e} links/s on {cb['cores']} threads (reference scheme), "
+                                              f"{cb['value_lpt_threads']:.3e} bin-packed, {cb['value_one_thread']:.3e} on one thread" if cb else "") + ".\n")
+    L.append(f"### Kernel trace\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --no-cpu-baseline --no-secondary --steps 2 --warmup 1` "
+             f"({passes} passes + one upload): sum of kernel durations {tot_ns/1e6:.2f} ms over {calls} launches; the last pass: "
+             f"`{open(os.path.join(D, 'timeline_summary.txt')).read().strip()}` (HIP-event time of a pass in that run: {under['roofline']['ms_per_launch']:.2f} ms).\n")
+    agg = {}
+    for r in rows:
+        k = short(r["Name"])
+        a = agg.setdefault(k, [0, 0])
+        a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
+    T = sum(v[1] for v in agg.values())
+    L.append("| kernel | calls/pass | ms/pass | avg us | % |\n|---|---|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda x: -x[1][1])[:30]:
+        L.append(f"| `{k}` | {v[0]/passes:.1f} | {v[1]/passes/1e6:.3f} | {v[1]/max(1,v[0])/1e3:.1f} | {v[1]/T*100:.1f} |")
+    L.append(f"\nFull table: `{tag}_{wl}_kernel_stats.csv`.\n")
+    L.append(f"### HBM traffic (PMC)\n\nFETCH_SIZE {fetch['per_pass']*1024/1e9:.2f} GB + WRITE_SIZE {write['per_pass']*1024/1e9:.2f} GB = {raw/1e9:.2f} GB per pass as counted; "
+             f"with the wide-load share doubled (see `pmc_traffic.json`) **{corrected/1e9:.2f} GB per pass** against {alg/1e9:.3f} GB algorithmic: "
+             f"{corrected/alg:.1f}x (= {corrected/1e9/bench_line['roofline']['ms_per_launch']:.2f} TB/s while the pass runs).  Calibration on the scan kernels: {json.dumps(cal)}.\n")
+    L.append("| kernel | fetch MB/pass | | kernel | write MB/pass |\n|---|---|---|---|---|")
+    for (a, b), (c, d) in zip(fetch["top"][:12], write["top"][:12]):
+        L.append(f"| `{a[:40]}` | {b*1024/1e6:.0f} | | `{c[:40]}` | {d*1024/1e6:.0f} |")
+    L.append("")
+json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+extra = os.path.join(P, f"{tag}_other.md")
 if os.path.exists(extra):
-    L.append("\n" + open(extra).read())
+    L.append(open(extra).read())
 open(os.path.join(P, f"{tag}_summary.md"), "w").write("\n".join(L) + "\n")
-print("\n".join(L)[:3000])
+print("\n".join(L)[:4000])

@@ -11,8 +11,8 @@ for r in rows:
     v = float(r['Counter_Value']); tot += v
     nm = re.sub(r'\(.*', '', r['Kernel_Name']).replace('povu_hip::', '').replace('void ', '')
     if 'rocprim' in nm:
-        nm = 'rocprim:radix_sort'
+        nm = "rocprim:radix_sort"
     per[nm] += v
 out = {"counter": ctr, "total": tot, "per_pass": tot / passes,
-       "top": [[k, v / passes] for k, v in per.most_common(60)]}
+       "top": [[k, v / passes] for k, v in per.most_common(300)]}
 print(json.dumps(out))
