@@ -62,69 +62,67 @@ __device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, unsigned 
 	return p;
 }
 
-// ------------------------------------------------------------------ 1. arcs of the spanning forest
-// (An arc stores only its tail, arc_src; its head is the tail of its twin a ^ 1.)
-// Arcs: 2i / 2i+1 = the black edge of segment i seen from its l / r side (so the black arc of side S is
-// arc S); 2k / 2k+1 with k = V + rank of the link among the tree-gray links = la -> lb / lb -> la.
-// The arcs leaving a side are grouped (any cyclic order of a side's arcs gives a valid Euler tour): slot 0
-// = the black arc, then the side's tree-gray links in adjacency order.  No atomics: a side counts and
-// places its own arcs.
-__global__ void k_arc_count(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
-			    const uint8_t *__restrict__ tgray, uint32_t *__restrict__ acnt)
+// ------------------------------------------------------------------ 1. Euler tour of the spanning forest
+// The arcs of the tour ARE the scan slots of the sides: side S owns the slots [loff[S] + S, loff[S+1] + S + 1) -- slot 0
+// its black edge, slot k >= 1 its k-th link in adjacency order -- and a slot is an arc iff its edge is in the forest
+// (black edges always, links that won a hook in the union-find).  Nothing is numbered, counted or stored per arc: the
+// twin of a slot is found in the (short, ascending) list of the side at the other end, and the arcs leaving a side are
+// taken in slot order (any cyclic order of a side's arcs gives a valid Euler tour).
+__device__ __forceinline__ uint32_t slot_base(const uint32_t *__restrict__ loff, uint32_t S) { return loff[S] + S; }
+// slot (1-based) of local edge `le` in the list of side w (ascending by local edge idx)
+__device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle, uint32_t w,
+						   uint32_t le)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	uint32_t n = 1;
-	for (uint32_t k = loff[S]; k < loff[S + 1]; k++)
-		n += tgray[lle[k]] ? 1u : 0u;
-	acnt[S] = n;
-}
-__global__ void k_arc_lists(uint32_t nS, uint32_t V, uint32_t E, const uint32_t *__restrict__ loff,
-			    const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
-			    const uint8_t *__restrict__ tgray, const uint32_t *__restrict__ tg_ps,
-			    const uint32_t *__restrict__ la, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ arc_src,
-			    uint32_t *__restrict__ arc_le, uint32_t *__restrict__ apos,
-			    uint32_t *__restrict__ sarc, uint32_t expect, uint32_t *err)
-{
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S == 0 && tg_ps[E] != expect) // the hooks of the union-find are not a spanning forest
-		atomicExch(err, 1u);
-	if (S >= nS)
-		return;
-	uint32_t q = aoff[S];
-	sarc[q] = S;
-	apos[S] = q;
-	arc_src[S] = S;
-	if (!(S & 1u))
-		arc_le[S >> 1] = NIL;
-	for (uint32_t k = loff[S]; k < loff[S + 1]; k++) {
-		const uint32_t le = lle[k];
-		if (!tgray[le])
-			continue;
-		const uint32_t t = tg_ps[le];
-		if (t >= expect) // never write past the arcs the launch was sized for
-			continue;
-		const uint32_t dir = la[le] == S ? 0u : 1u, a = 2 * (V + t) + dir;
-		q++;
-		sarc[q] = a;
-		apos[a] = q;
-		arc_src[a] = S;
-		if (!dir)
-			arc_le[V + t] = le;
+	uint32_t lo = loff[w], hi = loff[w + 1];
+	const uint32_t l0 = lo;
+	if (hi - lo > 8) {
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (lle[mid] < le)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		return lo - l0 + 1;
 	}
+	for (uint32_t j = lo; j < hi; j++)
+		if (lle[j] == le)
+			return j - l0 + 1;
+	return 0; // (not reached: a link sits in the lists of both its ends)
 }
-// Euler tour successor: after u->w comes the arc that follows w->u in w's arc list (cyclically)
-// (side w's arcs sit at [aoff[w], aoff[w+1]))
-__global__ void k_arc_succ(uint32_t NA, const uint32_t *__restrict__ arc_src, const uint32_t *__restrict__ sarc,
-			   const uint32_t *__restrict__ apos, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk, unsigned b)
+// the slot at the other end of slot k of side S: {side, slot}
+__device__ __forceinline__ uint2 slot_twin(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+					   const uint32_t *__restrict__ lle, uint32_t S, uint32_t k)
 {
-	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a >= NA)
+	if (k == 0)
+		return make_uint2(S ^ 1u, 0u);
+	const uint32_t at = loff[S] + k - 1, w = ladj[at];
+	return make_uint2(w, find_link_slot(loff, lle, w, lle[at]));
+}
+// Euler tour successor: after u->w comes the arc that follows w->u among w's arcs (cyclically).  Slots that are no
+// arcs get an inert word (no lane ever walks into them).
+__global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
 		return;
-	uint32_t t = a ^ 1, w = arc_src[t], q = apos[t];
-	uint32_t qn = (q + 1 == aoff[w + 1]) ? aoff[w] : q + 1;
-	pk[a] = rank_pack(sarc[qn], 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
+	const uint32_t lo = loff[S], n = loff[S + 1] - lo, base = lo + S;
+	for (uint32_t k = 0; k <= n; k++) {
+		if (k && !tgray[lle[lo + k - 1]]) {
+			pk[base + k] = PK_END | PK_STOP;
+			continue;
+		}
+		const uint2 t = slot_twin(loff, ladj, lle, S, k);
+		const uint32_t wlo = loff[t.x], wn = loff[t.x + 1] - wlo;
+		uint32_t nxt = 0; // next arc of w behind the twin; its black edge when the links are exhausted
+		for (uint32_t j = t.y + 1; j <= wn; j++)
+			if (tgray[lle[wlo + j - 1]]) {
+				nxt = j;
+				break;
+			}
+		pk[base + k] = rank_pack(wlo + t.x + nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
+	}
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -133,19 +131,25 @@ __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *sta
 	return k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
 }
 // per component: cut its tour open behind the arc that returns to the root for the last time; the first arc out of
-// the root heads the component's list
+// the root (its black edge) heads the component's list
 __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
-			    const uint32_t *__restrict__ sarc, const uint32_t *__restrict__ aoff, uint32_t *__restrict__ pk,
-			    uint32_t *__restrict__ heads)
+			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
+			    const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, uint32_t *__restrict__ heads)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= C)
 		return;
-	uint32_t r = comp_root_side(start_key, voff, c);
-	uint32_t a_end = sarc[aoff[r + 1] - 1] ^ 1, a_first = sarc[aoff[r]];
-	pk[a_end] = PK_END | PK_STOP | (a_end == a_first ? PK_HEAD : 0u); // no successor, weight 0
-	if (a_end != a_first)
-		atomicOr(&pk[a_first], PK_HEAD); // (k_arc_succ wrote the word in an earlier launch)
+	const uint32_t r = comp_root_side(start_key, voff, c), lo = loff[r], n = loff[r + 1] - lo;
+	uint32_t last = 0;
+	for (uint32_t k = n; k >= 1; k--)
+		if (tgray[lle[lo + k - 1]]) {
+			last = k;
+			break;
+		}
+	const uint2 t = slot_twin(loff, ladj, lle, r, last);
+	const uint32_t a_end = slot_base(loff, t.x) + t.y, a_first = lo + r;
+	pk[a_end] = PK_END | PK_STOP; // no successor, weight 0
+	atomicOr(&pk[a_first], PK_HEAD); // (k_tour_words wrote the word in an earlier launch)
 	heads[c] = a_first;
 }
 // one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
@@ -455,39 +459,61 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 	return z ^ (z >> 31);
 }
-__global__ void k_t0_parents(uint32_t NA, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ arc_src,
-			     const uint32_t *__restrict__ arc_le, const uint32_t *__restrict__ ckey,
-			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
-			     const uint8_t *__restrict__ tgray, uint32_t *__restrict__ par0, uint32_t *__restrict__ tin,
-			     uint32_t *__restrict__ tout, uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ vlo,
-			     uint32_t *__restrict__ vhi, uint32_t C, const unsigned long long *__restrict__ start_key)
+__global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
+			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
+			     uint32_t *__restrict__ par0, uint32_t *__restrict__ tin, uint32_t *__restrict__ tout,
+			     uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ vlo, uint32_t *__restrict__ vhi, uint32_t C,
+			     const unsigned long long *__restrict__ start_key, uint32_t n_pos, uint32_t *__restrict__ err)
 {
-	uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-	if (a < C) // the DFS start of component a roots its tree (no advance arc ever enters it)
-		par0[comp_root_side(start_key, voff, a)] = NIL;
-	if (a == 0)
-		vlo[NA] = vhi[NA] = 0;
-	if (a >= NA)
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S < C) { // the DFS start of component S roots its tree (no advance arc ever enters it)
+		const uint32_t r = comp_root_side(start_key, voff, S);
+		par0[r] = NIL;
+		// the tour of the component covers all its 4 nv - 2 arcs iff the hooks of the union-find are a spanning tree
+		if (dist[slot_base(loff, r)] != 4 * (voff[S + 1] - voff[S]) - 3)
+			atomicExch(err, 1u);
+	}
+	if (S == 0)
+		vlo[n_pos] = vhi[n_pos] = 0;
+	if (S >= nS)
 		return;
-	uint32_t da = dist[a], dt = dist[a ^ 1];
-	uint32_t u = arc_src[a], c = ckey[u >> 1];
-	uint32_t L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
-	uint32_t tix = abase + (L - 1 - da);
-	unsigned long long h = 0;
-	if (da > dt) {
-		uint32_t w = arc_src[a ^ 1]; // head of a = tail of its twin
-		par0[w] = u;
-		pe_le0[w] = arc_le[a >> 1];
-		tin[w] = tix;
-		tout[w] = abase + (L - 1 - dt);
+	const uint32_t c = ckey[S >> 1], L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
+	const uint32_t lo = loff[S], n = loff[S + 1] - lo, base = lo + S;
+	auto side_hash = [&](uint32_t w) { // xor of the hashes of w's non-tree links
+		unsigned long long h = 0;
 		for (uint32_t k = loff[w]; k < loff[w + 1]; k++) {
 			const uint32_t le = lle[k];
 			if (!tgray[le])
 				h ^= link_hash(le); // (a link is in the lists of both its ends, also when they are l and r of one segment)
 		}
+		return h;
+	};
+	// every tree edge is handled once, from the side that owns it: its two arcs a (leaving S) and t (coming back)
+	auto edge = [&](uint32_t a, uint32_t w, uint32_t t, uint32_t le) {
+		const uint32_t da = dist[a], dt = dist[t];
+		const uint32_t pa = abase + (L - 1 - da), pt = abase + (L - 1 - dt); // tour positions of the two arcs
+		const bool down = da > dt;					      // a comes first: S is the parent of w
+		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
+		par0[child] = parent;
+		pe_le0[child] = le;
+		tin[child] = p_in;
+		tout[child] = p_out;
+		const unsigned long long h = side_hash(child);
+		vlo[p_in] = (uint32_t)h;
+		vhi[p_in] = (uint32_t)(h >> 32);
+		vlo[p_out] = 0;
+		vhi[p_out] = 0;
+	};
+	if (!(S & 1u)) // the black edge belongs to the l side
+		edge(base, S ^ 1u, slot_base(loff, S ^ 1u), NIL);
+	for (uint32_t k = 1; k <= n; k++) {
+		const uint32_t le = lle[lo + k - 1];
+		if (!tgray[le] || la[le] != S)
+			continue; // a link of the forest belongs to the side that met it first
+		const uint2 t = slot_twin(loff, ladj, lle, S, k);
+		edge(base + k, t.x, slot_base(loff, t.x) + t.y, le);
 	}
-	vlo[tix] = (uint32_t)h;
-	vhi[tix] = (uint32_t)(h >> 32);
 }
 __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ tin,
 			  const uint32_t *__restrict__ tout, const uint32_t *__restrict__ xlo, const uint32_t *__restrict__ xhi,
@@ -959,12 +985,12 @@ template <typename F>
 static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 {
 	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // list-ranking buffers double as slot buffers
-	take((void **)&tw.tg_ps, (E + 2) * 4);
+	const size_t NSL = std::max<size_t>(2 * V + 2 * E, 4 * V) + 16; // scan slots of all sides / events of the second ranking
 	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
-	for (uint32_t **p : {&tw.arc_src, &tw.k1, &tw.k2, &tw.v1, &tw.v2, &tw.apos, &tw.nxtA, &tw.nxtB, &tw.cntA,
+	take((void **)&tw.dist, NSL * 4);
+	for (uint32_t **p : {&tw.nxtA, &tw.nxtB, &tw.cntA,
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
-	take((void **)&tw.arc_le, NA * 2);
 	take((void **)&tw.evt, NA * 8);
 	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.xlo, &tw.xhi, &tw.isbridge,
 			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
@@ -978,10 +1004,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.crb, nS * 16);
 	take((void **)&tw.cret, nS * 16);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
-	take((void **)&tw.rk_pk, NA * 4);
+	take((void **)&tw.rk_pk, NSL * 4);
 	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
 	for (uint32_t **p : {&tw.rk_nx, &tw.rk_wa, &tw.rk_wb, &tw.rk_tA, &tw.rk_tB, &tw.rk_tC})
-		take((void **)p, rank_pool_words(NA, Cmax + 1) * 4);
+		take((void **)p, rank_pool_words(NSL, Cmax + 1) * 4);
 }
 
 size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax)
@@ -1010,24 +1036,20 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
-	scan_exclusive_u8(cs.tgray, tw.tg_ps, (size_t)E + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	const uint32_t NTG = V - C; // a spanning forest; k_arc_lists raises err[2] if the hooks disagree
-	const uint32_t NA = 2 * (V + NTG);
-	uint32_t *acnt = tw.k1, *aoff = tw.k2; // [nS+1] each fits the 4V+8 buffers
-	LAUNCH(k_arc_count, nS, s, nS, cs.loff, cs.lle, cs.tgray, acnt);
-	scan(acnt, aoff, (size_t)nS + 1);
-	LAUNCH(k_arc_lists, nS, s, nS, V, E, cs.loff, cs.ladj, cs.lle, cs.tgray, tw.tg_ps, cs.la, aoff, tw.arc_src,
-	       tw.arc_le, tw.apos, tw.v2, NTG, pw.err + 2);
+	const uint32_t NA = 2 * (2 * V - C); // arcs of the spanning forest = positions of the tours
+	const size_t n_slots = (size_t)nS + 2 * (size_t)E; // >= the scan slots of all sides (loff[nS] + nS)
 	RankBufs rb{tw.rk_pk, tw.rk_heads, tw.rk_nx, tw.rk_wa, tw.rk_wb, tw.rk_tA, tw.rk_tB, tw.rk_tC};
-	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(NA);
-	LAUNCH(k_arc_succ, NA, s, NA, tw.arc_src, tw.v2, tw.apos, aoff, rb.pk, bitsA);
-	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, tw.v2, aoff, rb.pk, rb.heads);
-	list_rank_splitters<false>(NA, bitsA, tw.cntB, nullptr, C, rb, s);
-	const uint32_t *dist = tw.cntB;
+	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA);
+	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
+	if (n_slots >= PK_END) // (every link has two local slots, a self loop one on either side of its segment: loff[nS] = 2E)
+		throw HipError("graph too large for the packed list ranking: 2 * (segments + links) must stay below 2^29");
+	list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
+	const uint32_t *dist = tw.dist;
 	uint32_t *tin = tw.P0, *tout = tw.size0;				      // [nS]
 	uint32_t *vlo = tw.tourflag, *vhi = tw.tour_ps, *xlo = tw.nxtA, *xhi = tw.nxtB; // [NA+1] each
-	LAUNCH(k_t0_parents, std::max(NA, C), s, NA, dist, tw.arc_src, tw.arc_le, cs.ckey, cs.voff, cs.loff, cs.lle, cs.tgray, tw.par0,
-	       tin, tout, tw.pe_le0, vlo, vhi, C, start_key);
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.par0, tin, tout,
+	       tw.pe_le0, vlo, vhi, C, start_key, NA, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes

@@ -11,10 +11,7 @@ namespace povu_hip
 struct TreeWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	// unrooted spanning forest of the biedged graph H, as arcs
-	uint32_t *tg_ps;				  // [E+1] rank of tree-gray links
-	uint32_t *arc_src, *arc_le;			  // [NA] tail of an arc (head = tail of the twin a ^ 1); local edge per tree edge [NA/2]
-	uint32_t *k1, *k2, *v1, *v2;			  // [4V+4] sort buffers
-	uint32_t *apos;					  // [NA] position of an arc in its side's arc list
+	uint32_t *dist;					  // [2V + 2E] arcs behind a slot in its Euler tour (slots = arcs, see tree_kernels.hip)
 	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
 	uint32_t *tourflag, *tour_ps;			  // [4V+4]
 	uint32_t *par0, *size0, *P0, *pe_le0;		  // [2V]
