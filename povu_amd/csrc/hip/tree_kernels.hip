@@ -773,54 +773,41 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 }
 
 // ------------------------------------------------------------------ 7. pre-order of the union tree
-// Children of every side in the order of the parent's scan slots, without a sort: side P owns
-// deg(P)+1 scan slots (black edge, then its links) at [loff[P] + P, ...); every child drops itself
-// into the slot it was discovered through (at most one child per slot), then each parent strings
-// its non-empty slots together.
-__global__ void k_child_scatter(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
-				const uint32_t *__restrict__ loff, uint32_t *__restrict__ slot_child)
-{
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	uint32_t p = dpar[S];
-	if (p != NIL)
-		slot_child[loff[p] + p + cslot[S]] = S;
-}
-__global__ void k_child_link(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ slot_child,
-			     const uint32_t *__restrict__ dpar, uint32_t *__restrict__ fc, uint32_t *__restrict__ nsib)
-{
-	uint32_t P = blockIdx.x * blockDim.x + threadIdx.x;
-	if (P >= nS)
-		return;
-	const uint32_t base = loff[P] + P, n = loff[P + 1] - loff[P] + 1;
-	uint32_t first = NIL, prev = NIL;
-	for (uint32_t k = 0; k < n; k++) {
-		const uint32_t c = slot_child[base + k];
-		if (c == NIL)
-			continue;
-		if (prev == NIL)
-			first = c;
-		else
-			nsib[prev] = c;
-		prev = c;
-	}
-	if (prev != NIL)
-		nsib[prev] = NIL;
-	fc[P] = first;
-	if (dpar[P] == NIL)
-		nsib[P] = NIL; // roots (and sides of unprocessed components) have no siblings
-}
+// Children of a side are ordered by the scan slot they were discovered through (at most one child per slot).  No child
+// table: the first child of S is the first slot of S whose far side names (S, that slot) as its discovery; the next
+// sibling of S is the next such slot of its parent behind S's own.  A parent's list is walked once over all its
+// children, so the work stays linear in the degrees.
 // events: 2S = enter S, 2S+1 = leave S.  "enter S" heads the list of its component iff S is the DFS start of a
 // processed component (sides of other components keep their two-event lists, which nobody reads)
-__global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ fc,
-			 const uint32_t *__restrict__ nsib, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc,
-			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b)
+__global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
+			 const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey,
+			 const uint32_t *__restrict__ cproc, uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	const uint32_t c = fc[S], ns = nsib[S], p = dpar[S];
+	const uint32_t p = dpar[S];
+	uint32_t c = NIL, ns = NIL;
+	{
+		const uint32_t lo = loff[S], n = loff[S + 1] - lo;
+		for (uint32_t k = 0; k <= n; k++) {
+			const uint32_t o = k == 0 ? (S ^ 1u) : ladj[lo + k - 1];
+			if (dpar[o] == S && cslot[o] == k) {
+				c = o;
+				break;
+			}
+		}
+	}
+	if (p != NIL) {
+		const uint32_t lo = loff[p], n = loff[p + 1] - lo;
+		for (uint32_t k = cslot[S] + 1; k <= n; k++) {
+			const uint32_t o = ladj[lo + k - 1];
+			if (dpar[o] == p && cslot[o] == k) {
+				ns = o;
+				break;
+			}
+		}
+	}
 	uint32_t enter = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u, b); // enter: counts 1, depth +1
 	if (p == NIL) {
 		const uint32_t comp = ckey[S >> 1];
@@ -994,12 +981,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.evt, NA * 8);
 	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.xlo, &tw.xhi, &tw.isbridge,
 			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
-			     &tw.fc, &tw.nsib, &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
+			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.entry_flag, nS + 16);
-	take((void **)&tw.ckey, (nS + 2 * E + 8) * 4); // scan-slot -> child table of the child ordering
-	take((void **)&tw.ckey2, 64);
 	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
 	take((void **)&tw.crb, nS * 16);
 	take((void **)&tw.cret, nS * 16);
@@ -1094,18 +1079,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 7. pre-order, sizes, depths
 	tm.begin("tree_preorder");
-	{
-		const size_t n_scan_slots = (size_t)nS + 2 * (size_t)E;
-		uint32_t *slot_child = reinterpret_cast<uint32_t *>(tw.ckey); // [nS + 2E] (see tree_spans)
-		HIP_CHECK(hipMemsetAsync(slot_child, 0xFF, n_scan_slots * 4, s));
-		LAUNCH(k_child_scatter, nS, s, nS, tw.dpar, tw.cslot, cs.loff, slot_child);
-		LAUNCH(k_child_link, nS, s, nS, cs.loff, slot_child, tw.dpar, tw.fc, tw.nsib);
-		(void)max_side_links;
-	}
+	(void)max_side_links;
 	// one list per processed component, one two-event list per side of an unprocessed one
 	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(2 * (size_t)nS);
 	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
-	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.fc, tw.nsib, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE);
+	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.cslot, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE);
 	list_rank_splitters<true>(2 * nS, bitsE, nullptr, tw.evt, C, rb, s);
 	(void)event_lists;
 	tm.end(40);

@@ -24,8 +24,7 @@ struct TreeWs {
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
 	uint32_t *entry_ps, *entry_list;		  // [2V+1]
-	uint64_t *ckey, *ckey2;				  // [2V]
-	uint32_t *cval, *cval2, *fc, *nsib;		  // [2V]
+	uint32_t *cval, *cval2;				  // [2V]
 	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]
 	uint32_t *be_cnt, *be_ps;			  // [2V+1]
 	uint32_t *rk_pk, *rk_heads;			  // list ranking: packed list words [4V+8], list heads [C]
