@@ -462,14 +462,13 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
-			     uint32_t *__restrict__ par0, uint32_t *__restrict__ tin, uint32_t *__restrict__ tout,
-			     uint32_t *__restrict__ pe_le0, uint32_t *__restrict__ vlo, uint32_t *__restrict__ vhi, uint32_t C,
+			     uint4 *__restrict__ t0rec, uint32_t *__restrict__ vlo, uint32_t *__restrict__ vhi, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t n_pos, uint32_t *__restrict__ err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S < C) { // the DFS start of component S roots its tree (no advance arc ever enters it)
 		const uint32_t r = comp_root_side(start_key, voff, S);
-		par0[r] = NIL;
+		t0rec[r] = make_uint4(NIL, NIL, 0u, 0u);
 		// the tour of the component covers all its 4 nv - 2 arcs iff the hooks of the union-find are a spanning tree
 		if (dist[slot_base(loff, r)] != 4 * (voff[S + 1] - voff[S]) - 3)
 			atomicExch(err, 1u);
@@ -495,10 +494,7 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		const uint32_t pa = abase + (L - 1 - da), pt = abase + (L - 1 - dt); // tour positions of the two arcs
 		const bool down = da > dt;					      // a comes first: S is the parent of w
 		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
-		par0[child] = parent;
-		pe_le0[child] = le;
-		tin[child] = p_in;
-		tout[child] = p_out;
+		t0rec[child] = make_uint4(parent, le, p_in, p_out); // ONE scattered 16-byte store: {parent, its link, tour in, tour out}
 		const unsigned long long h = side_hash(child);
 		vlo[p_in] = (uint32_t)h;
 		vhi[p_in] = (uint32_t)(h >> 32);
@@ -515,10 +511,11 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		edge(base + k, t.x, slot_base(loff, t.x) + t.y, le);
 	}
 }
-__global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ tin,
-			  const uint32_t *__restrict__ tout, const uint32_t *__restrict__ xlo, const uint32_t *__restrict__ xhi,
-			  uint32_t *__restrict__ isbridge, uint32_t *__restrict__ ecc, uint32_t *__restrict__ csamp,
-			  uint8_t *__restrict__ multi)
+// pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
+static constexpr uint32_t PB_BRIDGE = 0x80000000u;
+__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0rec, const uint32_t *__restrict__ xlo,
+			  const uint32_t *__restrict__ xhi, uint32_t *__restrict__ pbr, uint32_t *__restrict__ ecc,
+			  uint32_t *__restrict__ csamp, uint8_t *__restrict__ multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -526,12 +523,13 @@ __global__ void k_bridges(uint32_t nS, const uint32_t *__restrict__ par0, const 
 	ecc[S] = S; // every side starts as its own 2-edge-connected class
 	csamp[S] = 0;
 	multi[S] = 0; // ... and alone in it until a non-bridge edge says otherwise
-	if (par0[S] == NIL) {
-		isbridge[S] = 0;
+	const uint4 r = t0rec[S];
+	if (r.x == NIL) {
+		pbr[S] = NIL;
 		return;
 	}
-	const uint32_t a = tin[S], b = tout[S] + 1;
-	isbridge[S] = (((xlo[a] ^ xlo[b]) | (xhi[a] ^ xhi[b])) == 0) ? 1u : 0u;
+	const uint32_t a = r.z, b = r.w + 1;
+	pbr[S] = r.x | ((((xlo[a] ^ xlo[b]) | (xhi[a] ^ xhi[b])) == 0) ? PB_BRIDGE : 0u);
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
@@ -564,13 +562,14 @@ __device__ __forceinline__ void uf_union2(uint32_t *parent, uint32_t a, uint32_t
 // tree edge is enough, the non-tree links add nothing.
 // (multi[S] = 1: side S shares its class with another side.  Most sides of a pangenome graph sit on bridges only and
 // are classes of their own; those need no walk at all.)
-__global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
-			   uint32_t *ecc, uint8_t *__restrict__ multi)
+__global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ pbr, uint32_t *ecc, uint8_t *__restrict__ multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS || par0[S] == NIL || isbridge[S])
+	if (S >= nS)
 		return;
-	const uint32_t p = par0[S];
+	const uint32_t p = pbr[S];
+	if (p & PB_BRIDGE) // (NIL has the bit set too)
+		return;
 	uf_union2(ecc, S, p);
 	multi[S] = 1;
 	multi[p] = 1;
@@ -597,8 +596,8 @@ __global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc, uint32_t *__restrict__
 
 // ------------------------------------------------------------------ 5. class entries
 static constexpr uint32_t CS_VISITED = 0x80000000u; // (class ids are side ids < 2^28)
-__global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const uint32_t *__restrict__ isbridge,
-			  const uint32_t *__restrict__ pe_le0, const uint32_t *__restrict__ loff,
+__global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const uint4 *__restrict__ t0rec,
+			  const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ecc,
 			  uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis,
@@ -613,28 +612,29 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ par0, const 
 	entry_flag[S] = 0;
 	// class and visited bit of a side in ONE word: the walk tests "same class and not yet visited" with one load
 	const bool proc = cproc[ckey[S >> 1]] != 0;
-	const uint32_t p0 = proc ? par0[S] : 0u;
-	const bool entry = proc && (p0 == NIL || isbridge[S]);
+	const uint32_t p0 = proc ? pbr[S] : 0u;
+	const bool entry = proc && (p0 & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
 	cstate[S] = proc ? (ecc[S] | (entry ? CS_VISITED : 0u)) : NIL;
 	if (!proc)
 		return;
 	// a class is walked from its entry side; a side that is alone in its class has nothing to walk
 	const uint8_t walk = multi[S] ? 1 : 0;
-	uint32_t p = par0[S];
+	uint32_t p = p0;
 	if (p == NIL) { // DFS start of the component
 		dvis[S] = 1;
 		entry_flag[S] = walk;
 		return;
 	}
-	if (!isbridge[S])
+	if (!(p & PB_BRIDGE))
 		return;
+	p &= ~PB_BRIDGE;
 	dvis[S] = 1;
 	entry_flag[S] = walk;
 	dpar[S] = p;
 	if (p == (S ^ 1)) {
 		cslot[S] = 0; // black edge: scanned first
 	} else { // gray bridge: its slot in the parent's list (ascending local edge idx)
-		uint32_t le = pe_le0[S], lo = loff[p], hi = loff[p + 1];
+		uint32_t le = t0rec[S].y, lo = loff[p], hi = loff[p + 1];
 		while (lo < hi) {
 			uint32_t mid = (lo + hi) >> 1;
 			if (lle[mid] < le)
@@ -979,7 +979,8 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
 		take((void **)p, NA * 4);
 	take((void **)&tw.evt, NA * 8);
-	for (uint32_t **p : {&tw.par0, &tw.size0, &tw.P0, &tw.pe_le0, &tw.lowP, &tw.highP, &tw.xlo, &tw.xhi, &tw.isbridge,
+	take((void **)&tw.t0rec, nS * 16);
+	for (uint32_t **p : {&tw.pbr,
 			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
 			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
@@ -1031,10 +1032,9 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		throw HipError("graph too large for the packed list ranking: 2 * (segments + links) must stay below 2^29");
 	list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
-	uint32_t *tin = tw.P0, *tout = tw.size0;				      // [nS]
 	uint32_t *vlo = tw.tourflag, *vhi = tw.tour_ps, *xlo = tw.nxtA, *xhi = tw.nxtB; // [NA+1] each
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.par0, tin, tout,
-	       tw.pe_le0, vlo, vhi, C, start_key, NA, pw.err + 2);
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.t0rec, vlo,
+	       vhi, C, start_key, NA, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
@@ -1042,15 +1042,15 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	scan_exclusive_xor_u32_pair(vlo, xlo, vhi, xhi, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
-	LAUNCH(k_bridges, nS, s, nS, tw.par0, tin, tout, xlo, xhi, tw.isbridge, tw.ecc, csamp, multi);
-	LAUNCH(k_ecc_tree, nS, s, nS, tw.par0, tw.isbridge, tw.ecc, multi);
+	LAUNCH(k_bridges, nS, s, nS, tw.t0rec, xlo, xhi, tw.pbr, tw.ecc, csamp, multi);
+	LAUNCH(k_ecc_tree, nS, s, nS, tw.pbr, tw.ecc, multi);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_entries, nS, s, nS, tw.par0, tw.isbridge, tw.pe_le0, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dpar,
+	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0rec, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dpar,
 	       tw.cslot, tw.dvis, tw.entry_flag, cstate);
 	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);

@@ -14,9 +14,9 @@ struct TreeWs {
 	uint32_t *dist;					  // [2V + 2E] arcs behind a slot in its Euler tour (slots = arcs, see tree_kernels.hip)
 	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
 	uint32_t *tourflag, *tour_ps;			  // [4V+4]
-	uint32_t *par0, *size0, *P0, *pe_le0;		  // [2V]
-	uint32_t *lowP, *highP, *xlo, *xhi;		  // [2V+1] per-side xor of non-tree link hashes (by pre-order), running xor
-	uint32_t *isbridge, *ecc, *dpar, *cslot;	  // [2V]
+	uint4 *t0rec;					  // [2V] rooted forest: {parent, link to it (NIL: black edge), tour position in, out}
+	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
+	uint32_t *ecc, *dpar, *cslot;			  // [2V]
 	uint8_t *dvis;					  // [2V]
 	uint2 *cadj;					  // [2V + 2E] class-filtered scan lists {side, slot}
 	uint4 *crb;					  // [2V] {begin, count, first entry} of a side's filtered list

@@ -17,6 +17,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 > $O/bench_under_rocprof.json 2> $O/kt.err || { tail -20 $O/kt.err; exit 3; }
 KS=$(ls $O/kt/*/*kernel_stats.csv | tail -1)
 cp $KS $O/kernel_stats.csv
-python3 $R/tools/trace_timeline.py $(ls $O/kt/*/*kernel_trace.csv | tail -1) x > $O/timeline_summary.txt 2>/dev/null
+python3 $R/tools/trace_timeline.py $(ls $O/kt/*/*kernel_trace.csv | tail -1) > $O/timeline.txt 2>/dev/null; tail -1 $O/timeline.txt > $O/timeline_summary.txt
 rm -f $O/kt/*/*kernel_trace.csv
 head -45 $O/kernel_stats.csv | cut -c1-200

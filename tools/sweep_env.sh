@@ -8,6 +8,6 @@ for b in default "$@"; do
   python - <<PY
 import json
 b=json.loads(open('$O/b_$b.json').read().strip().splitlines()[-1])
-print('$VAR=$b', round(b['ms_per_step'],2), {k:round(v,2) for k,v in b['stage_ms'].items() if k in ('tree_root_forest','tree_preorder','tree_class_dfs')})
+print('$VAR=$b', round(b['ms_per_step'],2), {k:round(v,2) for k,v in b['stage_ms'].items() if k in ('par_classes','tree_preorder','tree_class_dfs')})
 PY
 done
