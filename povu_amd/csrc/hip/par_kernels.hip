@@ -131,39 +131,52 @@ __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, c
 }
 // simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
 // the root, flubbles.cpp:621-643)
+// ... and the list of BRANCHING vertices (two or more children), the only ones that can get a capping edge: compacted
+// per workgroup with wave ballots + prefix popcounts, so that k_capping runs on full waves (followed by empty ones that
+// leave at once) instead of on the one lane in six that has work
 __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
-			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf)
+			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
+			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, uint32_t *__restrict__ branch_list)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= T)
-		return;
-	uint32_t sz = gsize[t];
-	const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
-	simp[t] = sm;
-	if (t == T - 1)
-		simp[T] = 0;
-	if (hpf)
-		hpf[t] = sm;
+	bool branching = false;
+	if (t < T) {
+		uint32_t sz = gsize[t];
+		const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
+		simp[t] = sm;
+		if (t == T - 1)
+			simp[T] = 0;
+		if (hpf)
+			hpf[t] = sm;
+		cap_tgt[t] = NIL;
+		capf[t] = 0;
+		branching = sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz; // the first child does not fill the subtree
+	}
+	// the branching vertices of this workgroup move to the front of its own stretch of the list (no global counter:
+	// millions of waves adding to one word would serialise); the rest of the stretch is marked empty
+	__shared__ uint32_t wcnt[TPB / 64];
+	const unsigned long long m = __ballot(branching);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (lane == 0)
+		wcnt[wave] = (uint32_t)__popcll(m);
+	branch_list[t] = NIL; // (every slot of the stretch, also behind T in the last workgroup; the flagged ones are overwritten below)
+	__syncthreads();
+	uint32_t before = 0;
+	for (uint32_t w = 0; w < wave; w++)
+		before += wcnt[w];
+	if (branching)
+		branch_list[blockIdx.x * TPB + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
 }
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
 // ascending idx are v+1, then each next sibling at c + size(c).  hi(c) = min target of the back edges leaving
 // subtree(c) -- the root as soon as subtree(c) holds a simplifying edge -- is only ever compared between siblings,
 // so it is evaluated on demand, for the children of branching vertices alone (range-min over hi0).
-__global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
-			  const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ segA,
-			  uint32_t P, uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf)
+__device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
+					   const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root,
+					   const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt,
+					   uint8_t *__restrict__ capf)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
-		return;
-	uint32_t sz = gsize[v];
-	cap_tgt[v] = NIL;
-	capf[v] = 0;
-	if (sz <= 1)
-		return;
-	const uint32_t end = v + sz;
-	if (v + 1 + max(gsize[v + 1], 1u) >= end)
-		return; // a single child: there is no hi_2
+	const uint32_t end = v + gsize[v];
 	auto hi_of = [&](uint32_t c) {
 		const uint32_t cs = max(gsize[c], 1u);
 		if (psb[c + cs] != psb[c])
@@ -197,6 +210,17 @@ __global__ void k_capping(uint32_t T, const uint32_t *__restrict__ gsize, const 
 		cap_tgt[v] = hi_2;
 		capf[v] = 1;
 	}
+}
+__global__ void k_capping(uint32_t n_list, const uint32_t *__restrict__ branch_list, const uint32_t *__restrict__ gsize,
+			  const uint32_t *__restrict__ hi0, const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root,
+			  const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_list)
+		return;
+	const uint32_t v = branch_list[i];
+	if (v != NIL)
+		capping_of(v, gsize, hi0, psb, t_root, segA, P, cap_tgt, capf);
 }
 // mirror pre-order (children visited in DESCENDING idx): the order brackets sit in a bracket list,
 // because each child's list is spliced in front of its earlier siblings' (flubbles.cpp:586-588).
@@ -731,6 +755,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 		take((void **)p, (T + 2) * 4);
 	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c})
 		take((void **)p, T + 32);
+	take((void **)&pw.branch_list, ((T + TPB - 1) / TPB * TPB + 64) * 4);
 	take((void **)&pw.keys_t, (T + 2) * 8);
 	take((void **)&pw.keys_t2, (T + 2) * 8);
 	take((void **)&pw.dbo, (Cmax + 2) * 4);
@@ -859,8 +884,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr);
-	LAUNCH(k_capping, T, s, T, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf);
+	uint32_t *branch_list = pw.branch_list; // [nblk(T) * TPB]: one stretch of TPB slots per workgroup of k_hi_simp
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, branch_list);
+	const uint32_t n_list = nblk(T) * TPB;
+	LAUNCH(k_capping, n_list, s, n_list, branch_list, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf);
 	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre, pw.incnt, srccnt);
