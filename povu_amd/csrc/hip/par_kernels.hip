@@ -355,24 +355,38 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 	}
 	uint32_t m = mpre[v];
 	uint32_t lo = bstart[m], hi = bstart[m + sz];
-	// the top bracket is almost always one of the first few of the range: probe them linearly
-	// (one cache line) before falling back to the O(log n) descent
+	// Number of live brackets first (two prefix sums): in a chain of bubbles the brackets of everything below v are closed
+	// inside their bubbles and the few live ones -- a simplifying edge, a tip's edge to the root -- come from the
+	// deepest sources, i.e. sit at the END of the range.  When the last `live` entries are all live they are THE live
+	// ones, and the top bracket is the first of them: no search at all.
+	const uint32_t live = (hi - lo) - (psin[v + sz] - psin[v]);
 	uint32_t i = NIL;
-	const uint32_t probe_end = min(hi, lo + 4);
-	for (uint32_t k = lo; k < probe_end; k++)
-		if (tgtR[k] < v) {
-			i = k;
-			break;
-		}
-	if (i == NIL && probe_end < hi)
-		i = seg_first_less(segB, P, probe_end, hi, v);
+	if (live >= 1 && live <= 4) {
+		bool all = true;
+		for (uint32_t k = hi - live; k < hi; k++)
+			all = all && tgtR[k] < v;
+		if (all)
+			i = hi - live;
+	}
+	// otherwise the top bracket often is one of the first few of the range: probe them linearly
+	// (one cache line) before falling back to the O(log n) descent
+	if (i == NIL) {
+		const uint32_t probe_end = min(hi, lo + 4);
+		for (uint32_t k = lo; k < probe_end; k++)
+			if (tgtR[k] < v) {
+				i = k;
+				break;
+			}
+		if (i == NIL && probe_end < hi)
+			i = seg_first_less(segB, P, probe_end, hi, v);
+	}
 	if (i == NIL) {
 		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
 		ckey[q] = NIL;
 		lsz[v] = 0;
 		return;
 	}
-	lsz[v] = (hi - lo) - (psin[v + sz] - psin[v]);
+	lsz[v] = live;
 	ckey[q] = i;
 	if (hpf && rid[i] >= first_simp_id) // the top bracket is a simplifying edge (flubbles.cpp:644-656)
 		hpf[v] |= 2;
