@@ -282,9 +282,11 @@ __global__ void k_compact_pos(uint32_t n, const uint32_t *__restrict__ flag, con
 		out[ps[i]] = i;
 }
 
-__global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__ is_root)
+__global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__ is_root, uint32_t *__restrict__ unsorted)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v == 0)
+		*unsorted = 0; // (k_labels_sorted, the next launch, raises it)
 	if (v >= V)
 		return;
 	uint32_t r = v;
@@ -296,6 +298,16 @@ __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__
 	}
 	parent[v] = r; // readers of parent[] in this kernel only ever walk towards roots
 	is_root[v] = (r == v) ? 1 : 0;
+}
+
+// Are the vertices already grouped by component, in component order?  Components are ranked by their smallest vertex
+// (= their union-find root), so that is the case iff the roots never decrease along the vertex order -- true for GFAs
+// written chromosome by chromosome, and then the stable sort of the vertices by component is the identity.
+__global__ void k_labels_sorted(uint32_t V, const uint32_t *__restrict__ label, uint32_t *__restrict__ unsorted)
+{
+	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v > 0 && v < V && label[v] < label[v - 1])
+		*unsorted = 1; // (same value from every writer)
 }
 
 __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const uint32_t *__restrict__ crank,
@@ -730,10 +742,16 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 				   st.label, st.hook);
 	}
 	uint8_t *is_root = reinterpret_cast<uint8_t *>(st.flag);
-	KLAUNCH(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, is_root);
+	KLAUNCH(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, is_root, st.stats + 9);
+	KLAUNCH(k_labels_sorted, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.stats + 9);
 	scan_exclusive_u8(is_root, st.crank, (size_t)V + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
-	tm.end(6);
-	return st.host->read_u32(st.crank + V, s);
+	tm.end(7);
+	uint32_t *h = st.host->take<uint32_t>(2); // component count and the order flag in one round trip
+	HIP_CHECK(hipMemcpyAsync(h, st.crank + V, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(h + 1, st.stats + 9, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	st.comp_sorted = h[1] == 0;
+	return h[0];
 }
 
 // vertices with more links than this take the radix-sorted adjacency path (an insertion sort per side is
@@ -751,8 +769,9 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
 	KLAUNCH(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a, C,
 			   (unsigned long long *)st.start_key);
-	if (C == 1) { // one component: the order is already (component, idx); the key / permutation arrays
-		      // simply alias what k_comp_of wrote (all-zero component ranks, identity permutation)
+	const bool identity = C == 1 || st.comp_sorted;
+	if (identity) { // one component, or components one after the other: the order is already (component, idx); the key /
+			// permutation arrays simply alias what k_comp_of wrote (component ranks, identity permutation)
 		st.ckey = st.comp_of;
 		st.perm = st.tmp_a;
 	} else {
@@ -760,13 +779,13 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	}
 	KLAUNCH(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
 			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats,
-			   C == 1 ? st.sbase : nullptr);
-	if (C != 1)
+			   identity ? st.sbase : nullptr);
+	if (!identity)
 		scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	launches += 5;
 	// first-encounter rank of every edge
 	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
-		const uint32_t *pos_or_identity = C == 1 ? nullptr : st.pos; // one component: no vertex is renumbered
+		const uint32_t *pos_or_identity = identity ? nullptr : st.pos; // sorted order = global order: no vertex is renumbered
 		uint8_t *first8 = reinterpret_cast<uint8_t *>(st.flag), *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
 		KLAUNCH(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.aoth, st.sbase,
 				   first8, ldeg8, st.stats);

@@ -42,6 +42,7 @@ struct CompState {
 	uint64_t *start_key; // [C+1] (segment id << 32 | sorted side) of the smallest tip, ~0 if none
 	void *scan_tmp, *sort_tmp;
 	size_t scan_tmp_bytes, sort_tmp_bytes;
+	bool comp_sorted;   // the vertices already are in (component, idx) order: re-indexing keeps every vertex where it is
 	HostScratch *host;  // pinned read-back scratch of the owning context
 	uint32_t *host_pub; // device view of a pinned [voff C+1 | eoff C+1 | stats 4] the re-index publishes into (or null)
 };
