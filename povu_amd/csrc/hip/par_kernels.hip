@@ -55,27 +55,37 @@ __global__ void k_tcomp_vertices(uint32_t V, uint32_t T, const uint32_t *__restr
 __global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ voff,
 			    const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ t_par,
 			    const uint32_t *__restrict__ t_size, uint32_t *__restrict__ gpar, uint32_t *__restrict__ gsize,
-			    uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov)
+			    uint32_t *__restrict__ t_root, uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov,
+			    const uint32_t *__restrict__ depth, uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
+			    uint32_t *__restrict__ srccnt)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	hi0[t] = NIL; // k_hi0 takes minima into it
 	cov[t] = 0;   // ... and counts back-edge ends here
+	incnt[t] = srccnt[t] = 0; // bracket counters of the class stage, [T+2] each
 	if (t == T - 1) {
 		hi0[T] = NIL;
 		cov[T] = 0;
+		incnt[T] = incnt[T + 1] = srccnt[T] = srccnt[T + 1] = 0;
 	}
 	uint32_t c = t_comp[t];
-	uint32_t base = 2 * voff[c] + c, l = t - base;
+	uint32_t base = 2 * voff[c] + c, l = t - base, n = c_ntree[c];
 	t_root[t] = base;
-	if (l < c_ntree[c]) {
-		uint32_t p = t_par[t];
+	if (l < n) {
+		uint32_t p = t_par[t], sz = t_size[t];
 		gpar[t] = p == NIL ? NIL : base + p;
-		gsize[t] = t_size[t];
+		gsize[t] = sz;
+		// mirror pre-order (children visited in DESCENDING idx): the order brackets sit in a bracket list, because each
+		// child's list is spliced in front of its earlier siblings' (flubbles.cpp:586-588).  With q(v) = mpre(v) + v + size(v)
+		// one gets q(child) = q(parent) + 1, hence mpre(v) = depth(v) + N - v - size(v) (local indices, N = tree vertices
+		// of the component)
+		mpre[t] = base + depth[t] + n - l - sz;
 	} else {
 		gpar[t] = NIL;
 		gsize[t] = 0;
+		mpre[t] = NIL;
 	}
 }
 __global__ void k_dense_be(uint32_t NB0, uint32_t C, const uint32_t *__restrict__ dbo, const uint32_t *__restrict__ voff,
@@ -221,29 +231,6 @@ __global__ void k_capping(uint32_t n_list, const uint32_t *__restrict__ branch_l
 	const uint32_t v = branch_list[i];
 	if (v != NIL)
 		capping_of(v, gsize, hi0, psb, t_root, segA, P, cap_tgt, capf);
-}
-// mirror pre-order (children visited in DESCENDING idx): the order brackets sit in a bracket list,
-// because each child's list is spliced in front of its earlier siblings' (flubbles.cpp:586-588).
-// With q(v) = mpre(v) + v + size(v) one gets q(child) = q(parent) + 1, hence
-// mpre(v) = depth(v) + N - v - size(v)  (local indices, N = tree vertices of the component).
-__global__ void k_mpre(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ depth,
-		       const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ t_comp,
-		       const uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
-		       uint32_t *__restrict__ srccnt)
-{
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
-		return;
-	incnt[v] = srccnt[v] = 0; // bracket counters of the next kernels, [T+2] each
-	if (v == T - 1)
-		incnt[T] = incnt[T + 1] = srccnt[T] = srccnt[T + 1] = 0;
-	uint32_t sz = gsize[v];
-	if (!sz) {
-		mpre[v] = NIL;
-		return;
-	}
-	uint32_t r = t_root[v];
-	mpre[v] = r + depth[v] + c_ntree[t_comp[v]] - (v - r) - sz;
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
@@ -393,8 +380,10 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 }
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
-__global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-			      const uint32_t *__restrict__ lsz, uint8_t *__restrict__ flag, uint32_t *__restrict__ dlt)
+// (also row F's marks: q + 1 where the vertex at sorted position q ends a black edge, see k_next_from_runs)
+__global__ void k_class_flags(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+			      const uint32_t *__restrict__ lsz, const uint8_t *__restrict__ tf, uint8_t *__restrict__ flag,
+			      uint32_t *__restrict__ dlt, uint32_t *__restrict__ mark)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= T)
@@ -405,11 +394,13 @@ __global__ void k_class_flags(uint32_t T, uint32_t mask, const uint32_t *__restr
 	uint32_t k = skey[q];
 	if (k == NIL) {
 		flag[q] = 0;
+		mark[q] = 0;
 		return;
 	}
-	bool fresh = q == 0 || skey[q - 1] != k || lsz[sval[q - 1]] != lsz[sval[q]];
+	const uint32_t v = sval[q];
+	bool fresh = q == 0 || skey[q - 1] != k || lsz[sval[q - 1]] != lsz[v];
 	flag[q] = fresh ? 1 : 0;
-	(void)mask;
+	mark[q] = (tf[v] & TF_BLACK) ? q + 1 : 0;
 }
 __global__ void k_class_scatter(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 				const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
@@ -441,21 +432,19 @@ __global__ void k_shift_delta(uint32_t T, const uint32_t *__restrict__ gsize, co
 	atomicAdd(&dlt[b + sb], 0u - g - sb); // the gray subtrees move forward by size(black)
 	atomicAdd(&dlt[a + gsize[a]], sb);
 }
+// stack position of every tree vertex, and whether a candidate-stack entry sits there (the child end of a black edge)
 __global__ void k_mpos_scatter(uint32_t T, const uint32_t *__restrict__ dlt, const uint32_t *__restrict__ dlt_ps,
-			       uint32_t *__restrict__ inv)
+			       const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ tf, uint32_t *__restrict__ inv,
+			       uint8_t *__restrict__ flag)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v < T)
-		inv[v + dlt_ps[v] + dlt[v]] = v;
-}
-__global__ void k_black_flag(uint32_t T, const uint32_t *__restrict__ inv, const uint32_t *__restrict__ gsize,
-			     const uint8_t *__restrict__ tf, uint8_t *__restrict__ flag)
-{
-	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-	if (m >= T)
+	if (v >= T)
 		return;
-	uint32_t v = inv[m];
+	const uint32_t m = v + dlt_ps[v] + dlt[v];
+	inv[m] = v;
 	flag[m] = (gsize[v] && (tf[v] & TF_BLACK)) ? 1 : 0;
+	if (v == T - 1)
+		flag[T] = 0;
 }
 __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const uint8_t *__restrict__ flag,
 			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
@@ -484,14 +473,6 @@ __global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const
 // with every group ordered from the deepest vertex up, and a class is a run inside a group.  The
 // members of a class lie on one root-to-leaf path, so their order in the candidate stack is their
 // order by depth: for consecutive BLACK members (deeper d, shallower u) of a run, next_seen[u] = d.
-__global__ void k_black_marks(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-			      const uint8_t *__restrict__ tf, uint32_t *__restrict__ mark)
-{
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= T)
-		return;
-	mark[q] = (skey[q] != NIL && (tf[sval[q]] & TF_BLACK)) ? q + 1 : 0;
-}
 __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, const uint32_t *__restrict__ lastb,
 				 const uint32_t *__restrict__ sval, const uint32_t *__restrict__ gcls,
 				 const uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
@@ -875,7 +856,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- T-space + dense back edges
 	tm.begin("par_setup");
 	LAUNCH(k_tcomp_vertices, V, s, V, T, cs.ckey, cs.voff, pw.t_comp);
-	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0, pw.cov);
+	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0, pw.cov, sw.t_depth,
+	       pw.mpre, pw.incnt, pw.dlt);
 	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
@@ -904,7 +886,6 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_capping, n_list, s, n_list, branch_list, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf);
 	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
-	LAUNCH(k_mpre, T, s, T, pw.gsize, sw.t_depth, pw.t_root, pw.t_comp, sw.c_ntree, pw.mpre, pw.incnt, srccnt);
 	uint32_t *extra = pw.host->take<uint32_t>(2);
 	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));
@@ -931,7 +912,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 	uint8_t *cflag = pw.f8a; // bridge flags are dead by now
 	uint32_t *cps = pw.psA;
-	LAUNCH(k_class_flags, T, s, T, 0u, ck2, pw.vals_t2, pw.lsz, cflag, pw.dlt);
+	LAUNCH(k_class_flags, T, s, T, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, pw.flagC);
 	scan8(cflag, cps, (size_t)T + 1);
 	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls);
 	launches = 30 + 2 * 22;
@@ -941,10 +922,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	tm.begin("par_stack");
 	LAUNCH(k_shift_delta, T, s, T, pw.gsize, pw.gpar, sw.t_flags, pw.dlt);
 	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
-	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.inv);
 	uint8_t *bflag = pw.f8b;
 	uint32_t *bps = pw.psB;
-	LAUNCH(k_black_flag, T, s, T, pw.inv, pw.gsize, sw.t_flags, bflag);
+	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.gsize, sw.t_flags, pw.inv, bflag);
 	scan8(bflag, bps, (size_t)T + 1);
 	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
 	       pw.prev, C, cs.voff, pw.soff, n_stack, pw.err + 3);
@@ -956,8 +936,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- row F
 	tm.begin("par_next_seen");
 	{
-		uint32_t *mark = pw.flagC, *lastb = pw.psC; // capping flags are dead by now
-		LAUNCH(k_black_marks, T, s, T, ck2, pw.vals_t2, sw.t_flags, mark);
+		uint32_t *mark = pw.flagC, *lastb = pw.psC; // (the marks were written with the class flags)
 		scan_exclusive_max_u32(mark, lastb, T, pw.scan_tmp, pw.scan_tmp_bytes, s);
 		LAUNCH(k_next_from_runs, T, s, T, mark, lastb, pw.vals_t2, pw.gcls, pw.topi, pw.ns, pw.prev);
 	}
