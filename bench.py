@@ -62,6 +62,11 @@ def build_workload(name, scale):
         n = max(8, int(4e6 * scale))
         g = W.hprc_shaped([n], seed=20260612)
         return g, f"BASELINE config 3 shape: HPRC-shaped single component, backbone {n}, {g.n_vtx} segments / {g.n_links} links"
+    if name == "tangled":
+        n = max(1000, int(3e6 * scale))
+        g = W.hprc_tangled(n, tangle_every=100000, max_tangle=300000)
+        return g, (f"HPRC-shaped with heavy-tailed tangles (2-edge-connected blocks of 10^2..3*10^5 segments every ~10^5 backbone "
+                   f"segments, links of a tangle in random order): {g.n_vtx} segments / {g.n_links} links")
     if name == "nest":
         t = max(1, int(3333 * scale))
         g = W.nested_towers(1000, t)
@@ -119,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="hprc-wg", choices=["hprc-wg", "chain", "hprc-chr", "nest"])
+    ap.add_argument("--workload", default="hprc-wg", choices=["hprc-wg", "chain", "hprc-chr", "nest", "tangled"])
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the workload (1.0 = BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs 2 / 3 / 5")
@@ -213,13 +218,14 @@ def main():
         }
         if not args.no_secondary and args.workload == "hprc-wg":
             sec = {}
-            for key, name in (("config2_chain_1M", "chain"), ("config3_hprc_chr", "hprc-chr"), ("config5_nest_10M", "nest")):
+            for key, name, k_steps in (("config2_chain_1M", "chain", 5), ("config3_hprc_chr", "hprc-chr", 5), ("config5_nest_10M", "nest", 5),
+                                      ("tangled_hprc_shape", "tangled", 2)):
                 g2, wl2 = build_workload(name, 1.0)
                 hip.upload(g2)
-                dt2, ms2, f2 = time_single(hip, g2, 5, 2, F_NO_STAGE_TIMES)
+                dt2, ms2, f2 = time_single(hip, g2, k_steps, 1 if k_steps < 5 else 2, F_NO_STAGE_TIMES)
                 a2 = algorithmic_bytes(g2.n_links, g2.n_vtx, count_flubbles(f2))
                 hip.decompose()  # untimed: per-stage HIP events
-                sec[key] = {"workload": wl2, "value": g2.n_links * 5 / dt2, "ms_per_step": dt2 / 5 * 1e3, "ms_per_launch": ms2,
+                sec[key] = {"workload": wl2, "value": g2.n_links * k_steps / dt2, "ms_per_step": dt2 / k_steps * 1e3, "ms_per_launch": ms2,
                             "roofline_frac": a2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "stage_ms": {st["name"]: round(st["ms"], 4) for st in hip.stage_times()}}
                 del f2, g2

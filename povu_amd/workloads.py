@@ -199,6 +199,56 @@ def hprc_whole_genome(total_segments: float = 1e8, tiny: int = 2000, seed: int =
     return hprc_shaped(sizes, seed=seed, tiny=tiny)
 
 
+def hprc_tangled(n_backbone: int, seed: int = 20260612, tangle_every: int = 20000, max_tangle: int = 200000,
+                 shuffle_links: bool = True) -> Links:
+    """HPRC-shaped component with TANGLES: the chain of small bubbles of `hprc_shaped`, and every ~`tangle_every`
+    backbone segments a tangle replaces a bubble -- `n` extra segments (heavy-tailed: n = 100 * 10^(3u), u uniform,
+    capped at `max_tangle`, i.e. 10^2 .. 10^5+ segments) wired by a random spanning path plus 0.6 n random links with
+    random sides (inversions, self loops, parallel links), entered from the backbone segment before it and left to the
+    one behind it.  Each tangle is one large 2-edge-connected class (the case a chain of bubbles never produces); with
+    `shuffle_links` the L lines of a tangle come in random order instead of sorted along the backbone."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base = hprc_shaped([n_backbone], seed=seed)
+    nv = base.n_vtx
+    # backbone vertices of `base`: recover them as the articulation-free spine is not needed -- tangles hang between
+    # two consecutive vertex indices chosen at random positions (a link a -> b of the spine is rerouted through the tangle)
+    v1, v2, s1, s2 = [base.v1.astype(np.int64)], [base.v2.astype(np.int64)], [base.s1], [base.s2]
+    n_t = max(1, n_backbone // tangle_every)
+    # candidate attachment links: plain backbone links (+ +) between consecutive vertices
+    plain = np.flatnonzero((base.v2.astype(np.int64) - base.v1.astype(np.int64) == 1) & (base.s1 == R) & (base.s2 == L))
+    pick = np.sort(rng.choice(plain, size=min(n_t, len(plain)), replace=False))
+    keep = np.ones(base.n_links, dtype=bool)
+    keep[pick] = False
+    nxt = nv
+    ex_v1, ex_v2, ex_s1, ex_s2 = [], [], [], []
+    for e in pick.tolist():
+        n = int(min(max_tangle, 100 * 10 ** (3 * rng.random())))
+        a, b = int(base.v1[e]), int(base.v2[e])
+        ids = np.arange(nxt, nxt + n, dtype=np.int64)
+        nxt += n
+        perm = rng.permutation(ids)
+        # spanning path through the tangle, entered from a and left to b
+        p1 = np.concatenate([[a], perm])
+        p2 = np.concatenate([perm, [b]])
+        m = int(0.6 * n)
+        r1 = rng.choice(ids, size=m)
+        r2 = rng.choice(ids, size=m)
+        t1 = np.concatenate([p1, r1]); t2 = np.concatenate([p2, r2])
+        ts1 = np.concatenate([np.full(len(p1), R), rng.integers(0, 2, size=m)]).astype(np.uint8)
+        ts2 = np.concatenate([np.full(len(p2), L), rng.integers(0, 2, size=m)]).astype(np.uint8)
+        if shuffle_links:
+            o = rng.permutation(len(t1))
+            t1, t2, ts1, ts2 = t1[o], t2[o], ts1[o], ts2[o]
+        ex_v1.append(t1); ex_v2.append(t2); ex_s1.append(ts1); ex_s2.append(ts2)
+    n_all = nxt
+    vid = np.arange(1, n_all + 1, dtype=np.uint32)
+    V1 = np.concatenate([base.v1.astype(np.int64)[keep]] + ex_v1)
+    V2 = np.concatenate([base.v2.astype(np.int64)[keep]] + ex_v2)
+    S1 = np.concatenate([base.s1[keep]] + ex_s1)
+    S2 = np.concatenate([base.s2[keep]] + ex_s2)
+    return _mk(vid, V1, S1, V2, S2)
+
+
 def random_bidirected(n_vtx: int, n_links: int, seed: int, self_loops: bool = True,
                       connected: bool = False) -> Links:
     """Differential-fuzz input: random sides, parallel links, self loops, several components."""

@@ -334,6 +334,19 @@ def test_config4_whole_genome_full_size_vs_oracle():
     d.close()
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_tangled_hprc_shape_vs_oracle(hip, seed):
+    """HPRC-shaped chain of bubbles with heavy-tailed TANGLES (random 2-edge-connected blocks of 10^2 .. 10^4.8 segments,
+    links in random order, random sides): large classes next to millions of small ones, both class walks."""
+    from povu_amd.hip import F_BIG_CLASS_DFS
+    g = W.hprc_tangled(120000, seed=seed, tangle_every=12000, max_tangle=60000)
+    want = {k: md5(v) for k, v in O.decompose(g).items()}
+    hip.upload(g)
+    assert {k: md5(v) for k, v in hip.decompose().texts().items()} == want
+    assert hip.seq_redo_count() == 0
+    assert {k: md5(v) for k, v in hip.decompose(flags=F_BIG_CLASS_DFS).texts().items()} == want
+
+
 def test_extracted_reference_structures_on_gpu(hip, golden_dir):
     """The structure expectations of the reference's conformance suite (tests/golden/reference_vectors.json)."""
     from test_oracle import check_structure, links_of_vector, reference_vectors
