@@ -244,6 +244,10 @@ int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *lo
 /* tree arrays of component `comp` (0-based rank): sizes via n_tree first call with NULLs */
 int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *gid, uint8_t *typ,
 			uint32_t *par, uint32_t *cls);
+/* id of the tree edge into each tree vertex (tree_edge_id[0] = 0xFFFFFFFF): tree and back edges share one counter in
+ * creation order (Tree::add_tree_edge / add_be, spanning_tree.cpp:784-805).  Conformance export only; returns 3 after a
+ * pass that built the tree with the one-lane kernels (POVU_HIP_F_SEQUENTIAL / POVU_HIP_F_SEQ_TREE). */
+int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *tree_edge_id);
 /* candidate stack of component `comp`: tree vertex of each entry, class, next_seen */
 int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t *tree_vtx, uint32_t *cls,
 			 uint32_t *next_seen);

@@ -155,6 +155,7 @@ struct povu_hip_ctx {
 	TreeWs tw{};
 	uint32_t last_seq_redo = 0;
 	bool stack_export_pending = false; // the parallel stages' candidate stack is still in its dense layout
+	bool tree_in_par = false;	   // the tree of the last pass came from the parallel kernels (their per-side state is still there)
 	bool classes_in_par = false;	   // the classes of the last pass sit in the parallel stage's own array (pw.gcls)
 	// when the resident graph is a shard (povu_hip_graph_upload_shard): ids of its components in the whole graph
 	// (1-based, ascending = the shard's own component order) and the component count of the whole graph

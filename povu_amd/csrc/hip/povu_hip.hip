@@ -436,6 +436,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		ctx->have_state = false;
 		ctx->stack_export_pending = false;
 		ctx->classes_in_par = false;
+		ctx->tree_in_par = false;
 		ctx->host.reset();
 		cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
@@ -591,6 +592,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				dense_nb0 = run_parallel_tree(cs, sw, ctx->pw, ctx->tw, C, event_lists, gstats[0],
 							      (o.flags & POVU_HIP_F_BIG_CLASS_DFS) != 0,
 							      (o.flags & POVU_HIP_F_SPARSE_SPLITTERS) != 0, tm, s);
+				ctx->tree_in_par = true;
 			}
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
 			ctx->stack_export_pending = true;
@@ -1017,6 +1019,52 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 			HIP_CHECK(hipMemcpy(typ, ctx->sw.t_flags + tb, N, hipMemcpyDeviceToHost));
 		return 0;
 	} catch (const std::exception &) {
+		return 2;
+	}
+}
+
+extern "C" int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *tree_edge_id)
+{
+	if (!ctx || !ctx->have_state || comp >= ctx->C || !n_tree)
+		return 1;
+	if (!ctx->tree_in_par)
+		return 3; // the one-lane tree kernels keep no per-side scan state
+	uint32_t *dw = nullptr;
+	try {
+		HIP_CHECK(hipSetDevice(ctx->device));
+		uint32_t voff = 0, N = 0;
+		HIP_CHECK(hipMemcpy(&voff, ctx->cs.voff + comp, 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&N, ctx->sw.c_ntree + comp, 4, hipMemcpyDeviceToHost));
+		*n_tree = N;
+		if (!tree_edge_id || N == 0)
+			return 0;
+		const size_t T = 2 * (size_t)ctx->sw.V + ctx->C, tb = 2 * (size_t)voff + comp;
+		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dw), 2 * T * 4));
+		HIP_CHECK(hipMemsetAsync(dw, 0, 2 * T * 4, ctx->stream));
+		debug_edge_id_weights(ctx->cs, ctx->sw, ctx->tw, dw, dw + T, ctx->stream);
+		std::vector<uint32_t> w(N), tail(N), size(N);
+		HIP_CHECK(hipMemcpyAsync(w.data(), dw + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(hipMemcpyAsync(tail.data(), dw + T + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(hipMemcpyAsync(size.data(), ctx->sw.t_size + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		HIP_CHECK(hipFree(dw));
+		dw = nullptr;
+		// back edges created before vertex t is discovered: those in front of every vertex up to t, and the tails of
+		// the vertices whose subtree closed before t
+		std::vector<uint32_t> closed((size_t)N + 1, 0);
+		for (uint32_t t = 0; t < N; t++)
+			closed[std::min<size_t>((size_t)t + size[t], N)] += tail[t];
+		uint32_t before = 0;
+		tree_edge_id[0] = POVU_NIL;
+		for (uint32_t t = 0; t < N; t++) {
+			before += w[t] + closed[t];
+			if (t > 0)
+				tree_edge_id[t] = t - 1 + before;
+		}
+		return 0;
+	} catch (const std::exception &) {
+		if (dw)
+			(void)hipFree(dw);
 		return 2;
 	}
 }

@@ -245,6 +245,97 @@ void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *t
 	scan_exclusive<1>(in, out, n, tmp, tmp_bytes, s);
 }
 
+// ---- exclusive running xor of 64-bit words (the bridge test's hashes): same two-launch scheme, 4 words per lane
+static constexpr int X64_ITEMS = 4, X64_TILE = SC_TPB * X64_ITEMS;
+struct Xor64Job {
+	const unsigned long long *in;
+	unsigned long long *out;
+	size_t n, chunk;
+	uint32_t blocks;
+	unsigned long long *partial;
+};
+__device__ __forceinline__ unsigned long long x64_block_reduce(unsigned long long v, unsigned long long *sh)
+{
+	for (int off = 32; off; off >>= 1)
+		v ^= __shfl_down(v, off);
+	if ((threadIdx.x & 63) == 0)
+		sh[threadIdx.x >> 6] = v;
+	__syncthreads();
+	const unsigned long long r = sh[0] ^ sh[1] ^ sh[2] ^ sh[3];
+	__syncthreads();
+	return r;
+}
+__global__ void __launch_bounds__(SC_TPB) k_xor64_partials(const Xor64Job J)
+{
+	__shared__ unsigned long long sh[4];
+	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < J.n ? b0 + J.chunk : J.n;
+	unsigned long long acc = 0;
+	for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
+		acc ^= J.in[i];
+	acc = x64_block_reduce(acc, sh);
+	if (threadIdx.x == 0)
+		J.partial[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(SC_TPB) k_xor64_chunks(const Xor64Job J)
+{
+	__shared__ unsigned long long sh[4], wave_tot[4];
+	unsigned long long base = 0;
+	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += SC_TPB)
+		base ^= J.partial[k];
+	unsigned long long carry = x64_block_reduce(base, sh);
+	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < J.n ? b0 + J.chunk : J.n;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (size_t t0 = b0; t0 < b1; t0 += X64_TILE) {
+		const size_t e0 = t0 + (size_t)threadIdx.x * X64_ITEMS;
+		unsigned long long v[X64_ITEMS];
+		for (int k = 0; k < X64_ITEMS; k++)
+			v[k] = e0 + k < b1 ? J.in[e0 + k] : 0ull;
+		unsigned long long tot = 0;
+		for (int k = 0; k < X64_ITEMS; k++) {
+			const unsigned long long x = v[k];
+			v[k] = tot;
+			tot ^= x;
+		}
+		unsigned long long inc = tot;
+		for (int off = 1; off < 64; off <<= 1) {
+			const unsigned long long y = __shfl_up(inc, off);
+			if (lane >= off)
+				inc ^= y;
+		}
+		if (lane == 63)
+			wave_tot[wave] = inc;
+		__syncthreads();
+		unsigned long long pre = carry;
+		for (int w = 0; w < wave; w++)
+			pre ^= wave_tot[w];
+		const unsigned long long lane_excl = __shfl_up(inc, 1);
+		if (lane > 0)
+			pre ^= lane_excl;
+		const unsigned long long tile_tot = wave_tot[0] ^ wave_tot[1] ^ wave_tot[2] ^ wave_tot[3];
+		for (int k = 0; k < X64_ITEMS; k++)
+			if (e0 + k < b1)
+				J.out[e0 + k] = pre ^ v[k];
+		carry ^= tile_tot;
+		__syncthreads();
+	}
+}
+void scan_exclusive_xor_u64(const unsigned long long *in, unsigned long long *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	if (n == 0)
+		return;
+	if (tmp_bytes < SC_MAX_BLOCKS * sizeof(unsigned long long))
+		throw HipError("scan: temporary storage too small");
+	size_t blocks = (n + X64_TILE - 1) / X64_TILE;
+	if (blocks > SC_MAX_BLOCKS)
+		blocks = SC_MAX_BLOCKS;
+	size_t chunk = (n + blocks - 1) / blocks;
+	chunk = (chunk + X64_TILE - 1) / X64_TILE * X64_TILE;
+	blocks = (n + chunk - 1) / chunk;
+	const Xor64Job J{in, out, n, chunk, (uint32_t)blocks, static_cast<unsigned long long *>(tmp)};
+	KLAUNCH(k_xor64_partials, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
+	KLAUNCH(k_xor64_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
+}
+
 size_t sort_tmp_bytes(size_t n)
 {
 	size_t bytes = 0;

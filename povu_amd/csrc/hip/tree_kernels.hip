@@ -462,7 +462,7 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
-			     uint4 *__restrict__ t0rec, uint32_t *__restrict__ vlo, uint32_t *__restrict__ vhi, uint32_t C,
+			     uint4 *__restrict__ t0rec, unsigned long long *__restrict__ val, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t n_pos, uint32_t *__restrict__ err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,7 +474,7 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 			atomicExch(err, 1u);
 	}
 	if (S == 0)
-		vlo[n_pos] = vhi[n_pos] = 0;
+		val[n_pos] = 0;
 	if (S >= nS)
 		return;
 	const uint32_t c = ckey[S >> 1], L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
@@ -495,11 +495,8 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		const bool down = da > dt;					      // a comes first: S is the parent of w
 		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
 		t0rec[child] = make_uint4(parent, le, p_in, p_out); // ONE scattered 16-byte store: {parent, its link, tour in, tour out}
-		const unsigned long long h = side_hash(child);
-		vlo[p_in] = (uint32_t)h;
-		vhi[p_in] = (uint32_t)(h >> 32);
-		vlo[p_out] = 0;
-		vhi[p_out] = 0;
+		val[p_in] = side_hash(child);
+		val[p_out] = 0;
 	};
 	if (!(S & 1u)) // the black edge belongs to the l side
 		edge(base, S ^ 1u, slot_base(loff, S ^ 1u), NIL);
@@ -513,8 +510,8 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 }
 // pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
 static constexpr uint32_t PB_BRIDGE = 0x80000000u;
-__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0rec, const uint32_t *__restrict__ xlo,
-			  const uint32_t *__restrict__ xhi, uint32_t *__restrict__ pbr, uint32_t *__restrict__ ecc,
+__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0rec, const unsigned long long *__restrict__ px,
+			  uint32_t *__restrict__ pbr, uint32_t *__restrict__ ecc,
 			  uint32_t *__restrict__ csamp, uint8_t *__restrict__ multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,7 +526,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0rec, const ui
 		return;
 	}
 	const uint32_t a = r.z, b = r.w + 1;
-	pbr[S] = r.x | ((((xlo[a] ^ xlo[b]) | (xhi[a] ^ xhi[b])) == 0) ? PB_BRIDGE : 0u);
+	pbr[S] = r.x | (px[a] == px[b] ? PB_BRIDGE : 0u);
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
@@ -931,6 +928,68 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 		be_cnt[S] = n;
 }
 
+// Conformance export only (povu_hip_debug_edge_ids): the tree and back edges of from_bd share one id counter in
+// creation order (spanning_tree.cpp:784-805), so the id of the tree edge into vertex t is (t - 1) plus the back
+// edges created before t was discovered.  A side creates its back edges while it scans its links between two of
+// its tree children: w[child] = those just before that child, tail[side] = those after its last child.
+__global__ void k_edge_id_weights(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+				  const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
+				  const uint32_t *__restrict__ side_tidx, const uint32_t *__restrict__ ckey,
+				  const uint32_t *__restrict__ voff, const uint32_t *__restrict__ t_par,
+				  const uint8_t *__restrict__ dupflag, uint32_t *__restrict__ w, uint32_t *__restrict__ tail)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	const uint32_t p = side_tidx[S];
+	if (p == NIL)
+		return;
+	const uint32_t c = ckey[S >> 1], root = 2 * voff[c] + c;
+	const uint32_t lo = loff[S], hi = loff[S + 1];
+	uint32_t cnt = 0;
+	if (lo == hi) {
+		cnt = (p == root || t_par[p] != 0) ? 1u : 0u;
+	} else {
+		const uint32_t dp = dpar[S];
+		bool loop_seen = false;
+		for (uint32_t k = lo; k < hi; k++) {
+			const uint32_t o = ladj[k];
+			if (o == (S ^ 1)) {
+				if (dp == o && !loop_seen)
+					cnt++;
+				loop_seen = true;
+				continue;
+			}
+			if (dpar[o] == S && cslot[o] == k - lo + 1) { // the link that discovered o
+				w[side_tidx[o]] = cnt;
+				cnt = 0;
+				continue;
+			}
+			if (side_tidx[o] > p || o == dp)
+				continue;
+			bool dup = false;
+			if (dupflag) {
+				dup = dupflag[k] != 0;
+			} else {
+				for (uint32_t j = lo; j < k; j++)
+					if (ladj[j] == o) {
+						dup = true;
+						break;
+					}
+			}
+			if (!dup)
+				cnt++;
+		}
+	}
+	tail[p] = cnt;
+}
+void debug_edge_id_weights(const CompState &cs, const SeqWs &sw, const TreeWs &tw, uint32_t *w, uint32_t *tail, hipStream_t s)
+{
+	const uint32_t nS = 2 * sw.V;
+	LAUNCH(k_edge_id_weights, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.cslot, tw.side_tidx, cs.ckey, cs.voff, sw.t_par,
+	       tw.last_dupflag, w, tail);
+}
+
 // Repeated links of one side (same far side) beyond the first: only the first can become a back edge.
 // Sides with few links find them by looking back over their own list; when some side has many links
 // the look-back is quadratic, so the flags come from a stable two-key radix sort of all slots instead.
@@ -976,8 +1035,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
 	take((void **)&tw.dist, NSL * 4);
 	for (uint32_t **p : {&tw.nxtA, &tw.nxtB, &tw.cntA,
-			     &tw.cntB, &tw.depA, &tw.depB, &tw.tourflag, &tw.tour_ps})
+			     &tw.cntB, &tw.depA, &tw.depB})
 		take((void **)p, NA * 4);
+	take((void **)&tw.xval, (NA + 2) * 8);
+	take((void **)&tw.xps, (NA + 2) * 8);
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0rec, nS * 16);
 	for (uint32_t **p : {&tw.pbr,
@@ -1032,17 +1093,17 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		throw HipError("graph too large for the packed list ranking: 2 * (segments + links) must stay below 2^29");
 	list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
-	uint32_t *vlo = tw.tourflag, *vhi = tw.tour_ps, *xlo = tw.nxtA, *xhi = tw.nxtB; // [NA+1] each
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.t0rec, vlo,
-	       vhi, C, start_key, NA, pw.err + 2);
+	unsigned long long *val = tw.xval, *px = tw.xps; // [NA+1] each
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.t0rec, val, C,
+	       start_key, NA, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
-	scan_exclusive_xor_u32_pair(vlo, xlo, vhi, xhi, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	scan_exclusive_xor_u64(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
-	LAUNCH(k_bridges, nS, s, nS, tw.t0rec, xlo, xhi, tw.pbr, tw.ecc, csamp, multi);
+	LAUNCH(k_bridges, nS, s, nS, tw.t0rec, px, tw.pbr, tw.ecc, csamp, multi);
 	LAUNCH(k_ecc_tree, nS, s, nS, tw.pbr, tw.ecc, multi);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
 	tm.end(8 + 44);
@@ -1104,6 +1165,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		LAUNCH(k_dup_flags, n_slots, s, n_slots, k2, v1, cs.ladj, tw.dvis_slots);
 		dupflag = tw.dvis_slots;
 	}
+	tw.last_dupflag = dupflag;
 	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
 	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);

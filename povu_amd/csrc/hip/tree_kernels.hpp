@@ -13,7 +13,7 @@ struct TreeWs {
 	// unrooted spanning forest of the biedged graph H, as arcs
 	uint32_t *dist;					  // [2V + 2E] arcs behind a slot in its Euler tour (slots = arcs, see tree_kernels.hip)
 	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
-	uint32_t *tourflag, *tour_ps;			  // [4V+4]
+	unsigned long long *xval, *xps;			  // [4V+4] xor values by tour position, their running xor
 	uint4 *t0rec;					  // [2V] rooted forest: {parent, link to it (NIL: black edge), tour position in, out}
 	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
 	uint32_t *ecc, *dpar, *cslot;			  // [2V]
@@ -31,6 +31,7 @@ struct TreeWs {
 	uint32_t *rk_nx, *rk_wa, *rk_wb, *rk_tA, *rk_tB, *rk_tC; // pools of the levels above the list itself
 	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
+	const uint8_t *last_dupflag;			  // dvis_slots when the last pass filled it, else null
 };
 
 size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax);
@@ -41,5 +42,9 @@ void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax);
 uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   uint32_t max_side_links, bool force_big_class_dfs, bool force_sparse_splitters, StageTimer &tm,
 			   hipStream_t s);
+
+// conformance export: back edges from_bd creates just before each tree vertex (w, T-space) and after the last child of
+// each (tail, T-space); both arrays must be zeroed by the caller.  Reads the state of the last run_parallel_tree.
+void debug_edge_id_weights(const CompState &cs, const SeqWs &sw, const TreeWs &tw, uint32_t *w, uint32_t *tail, hipStream_t s);
 
 } // namespace povu_hip

@@ -1,12 +1,15 @@
 // cli.cpp -- the `povu` command line for the decompose path.
 // Same surface as the reference for this path (app/cli/cli.cpp:14-26,236-262,324-382, app/main.cpp):
 //   povu [--version] [-v <int>] [-t <int>] decompose -i <gfa> [-o <dir>] [-h|--hairpins] [-s|--subflubbles]
+//   povu ... decompose ... --structure-export <json>   (additive: writes the flubble debug sidecar gfa2vcf writes)
+//   povu ... gfa2vcf -i <gfa> [-h] [-s] [--structure-export <json>] <options of `call`>   (app/cli/cli.cpp:154-193)
 #include "decompose.hpp"
 
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <vector>
 
 static const char *VERSION = "0.0.1-alpha"; // app/cli/cli.hpp:10
 
@@ -19,7 +22,8 @@ static void usage(std::ostream &os)
 	      "        decompose                         Find regions of variation\n"
 	      "        info                              Print graph information [uses 1 thread]\n"
 	      "        prune                             Reduce GFA to graph structure\n"
-	      "        gfa2vcf, call, vcf                (not part of the MI355X decompose build)\n"
+	      "        gfa2vcf                           Convert GFA to VCF (decompose here + `call` of $POVU_CALL_EXE)\n"
+	      "        call, vcf                         (not part of the MI355X decompose build)\n"
 	      "      arguments\n"
 	      "        --version                         The current version of povu\n"
 	      "        -v[verbosity],\n"
@@ -31,7 +35,10 @@ static void usage(std::ostream &os)
 	      "        -o[output_dir],\n"
 	      "        --output-dir=[output_dir]         Output directory [default: .]\n"
 	      "        -h, --hairpins                    Find hairpins in the variation graph [default: false]\n"
-	      "        -s, --subflubbles                 Find subflubbles in the variation graph [default: false]\n";
+	      "        -s, --subflubbles                 Find subflubbles in the variation graph [default: false]\n"
+	      "        --structure-export=[structure_json]\n"
+	      "                                          Write the flubble debug sidecar <structure_json>.flubble-debug.jsonl\n"
+	      "                                          [conformance]\n";
 }
 
 int main(int argc, char **argv)
@@ -39,6 +46,7 @@ int main(int argc, char **argv)
 	povu_host::Config cfg;
 	std::string command;
 	bool version = false, help = false, have_input = false, print_tips = false;
+	std::vector<std::string> call_args; // gfa2vcf: everything that belongs to `call`
 	auto value = [&](int &i, const char *a, const char *shortf, const char *longf, std::string &out) -> bool {
 		const size_t ls = strlen(shortf), ll = strlen(longf);
 		if (!strncmp(a, longf, ll) && a[ll] == '=') {
@@ -73,15 +81,29 @@ int main(int argc, char **argv)
 			print_tips = true; // inside `info`, -t means "print the tips" (cli.cpp:220)
 		} else if (value(i, a, "-t", "--threads", v)) {
 			cfg.threads = atoi(v.c_str());
-		} else if ((command == "decompose" || command == "info" || command == "prune") && value(i, a, "-i", "--input-gfa", v)) {
+		} else if ((command == "decompose" || command == "info" || command == "prune" || command == "gfa2vcf") &&
+			   value(i, a, "-i", "--input-gfa", v)) {
 			cfg.input_gfa = v;
 			have_input = true;
 		} else if ((command == "decompose" || command == "prune") && value(i, a, "-o", "--output-dir", v)) {
 			cfg.output_dir = v;
-		} else if (command == "decompose" && (!strcmp(a, "-h") || !strcmp(a, "--hairpins"))) {
+		} else if ((command == "decompose" || command == "gfa2vcf") && (!strcmp(a, "-h") || !strcmp(a, "--hairpins"))) {
 			cfg.hairpins = true;
-		} else if (command == "decompose" && (!strcmp(a, "-s") || !strcmp(a, "--subflubbles"))) {
+		} else if ((command == "decompose" || command == "gfa2vcf") && (!strcmp(a, "-s") || !strcmp(a, "--subflubbles"))) {
 			cfg.subflubbles = true;
+		} else if ((command == "decompose" || command == "gfa2vcf") && !strncmp(a, "--structure-export", 18) &&
+			   (a[18] == 0 || a[18] == '=')) {
+			if (a[18] == '=') {
+				cfg.structure_export = a + 19;
+			} else if (i + 1 < argc) {
+				cfg.structure_export = argv[++i];
+			} else {
+				std::cerr << "Flag '" << a << "' requires an argument but received none" << std::endl;
+				usage(std::cerr);
+				return 1;
+			}
+		} else if (command == "gfa2vcf") {
+			call_args.push_back(a); // streaming / output / reference options of `call` (cli.cpp:28-88)
 		} else if (command.empty() && a[0] != '-') {
 			command = a;
 		} else {
@@ -100,8 +122,8 @@ int main(int argc, char **argv)
 		usage(std::cout);
 		return 0;
 	}
-	if (command != "decompose" && command != "info" && command != "prune") {
-		std::cerr << "povu (MI355X build): only `decompose`, `info` and `prune` are provided; `" << command
+	if (command != "decompose" && command != "info" && command != "prune" && command != "gfa2vcf") {
+		std::cerr << "povu (MI355X build): only `decompose`, `info`, `prune` and `gfa2vcf` are provided; `" << command
 			  << "` belongs to the reference CPU tool" << std::endl;
 		return 1;
 	}
@@ -117,7 +139,11 @@ int main(int argc, char **argv)
 		povu_host::do_info(cfg, print_tips);
 	else if (command == "prune")
 		povu_host::do_prune(cfg);
-	else
+	else if (command == "gfa2vcf")
+		povu_host::do_gfa2vcf(cfg, call_args);
+	else {
+		povu_host::reset_debug_sidecar(cfg);
 		povu_host::do_decompose(cfg);
+	}
 	return 0;
 }

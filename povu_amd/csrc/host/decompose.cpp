@@ -77,6 +77,12 @@ void do_decompose(const Config &cfg)
 			for (uint32_t k = 0; k < t.n_hairpins; k++)
 				std::cerr << "Boundary: " << t.hairpins[2 * k] << " " << t.hairpins[2 * k + 1] << std::endl;
 		}
+	if (!cfg.structure_export.empty()) // one frame per find_flubbles call (flubbles.cpp:733), in component order
+		for (uint32_t i = 0; i < n; i++) {
+			povu_hip_tree t;
+			povu_hip_forest_get(f, i, &t);
+			append_debug_sidecar_frame(cfg, ctx, t.component_id - 1);
+		}
 	// one <id>.pvst per component; formatting + writing spread over -t threads
 	unsigned nt = (unsigned)std::max(1, cfg.threads);
 	nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));

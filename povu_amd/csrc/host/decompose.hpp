@@ -4,6 +4,9 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
+
+struct povu_hip_ctx;
 
 namespace povu_host
 {
@@ -16,6 +19,8 @@ struct Config {
 	bool hairpins = false;
 	bool subflubbles = false;
 	int device = 0;
+	// --structure-export <path>: also write <path>.flubble-debug.jsonl (one frame per decomposed component)
+	std::string structure_export;
 };
 
 // Loads the GFA, decomposes it on the GPU and writes <output_dir>/<component id>.pvst.
@@ -27,6 +32,16 @@ void do_decompose(const Config &cfg);
 // (app/subcommand/prune.cpp:17-41 + mto::to_gfa::write_gfa, src/mto/to_gfa.cpp:13-56): both only need
 // the components of row B.
 void do_info(const Config &cfg, bool print_tips);
+
+// The flubble debug sidecar of --structure-export (src/povu/algorithms/flubbles.cpp:108-231): path, reset, and one
+// frame for the component of 0-based rank `comp_rank` from the device state of the last povu_hip_decompose.
+std::string debug_sidecar_path(const std::string &structure_export_path);
+void reset_debug_sidecar(const Config &cfg);
+void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t comp_rank);
+
+// `povu gfa2vcf` (app/subcommand/gfa2vcf.cpp:18-87): decompose into a temporary forest, then run `call` of the
+// povu binary named by POVU_CALL_EXE on it (a child process); `call_args` are handed to it unchanged.
+void do_gfa2vcf(const Config &cfg, const std::vector<std::string> &call_args);
 void do_prune(const Config &cfg);
 
 } // namespace povu_host

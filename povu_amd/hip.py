@@ -102,6 +102,8 @@ def load_lib():
     l.povu_hip_debug_tree.restype = C.c_int
     l.povu_hip_debug_tree.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
+    l.povu_hip_debug_edge_ids.restype = C.c_int
+    l.povu_hip_debug_edge_ids.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
     l.povu_hip_debug_stack.restype = C.c_int
     l.povu_hip_debug_stack.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
                                        C.c_void_p]
@@ -455,6 +457,17 @@ class HipDecomposer:
         self._lib.povu_hip_debug_tree(self._ctx, comp, C.byref(n), gid.ctypes.data, typ.ctypes.data, par.ctypes.data,
                                       cls.ctypes.data)
         return dict(gid=gid, typ=typ & 3, black=(typ >> 2) & 1, par=par, cls=cls)
+
+    def debug_edge_ids(self, comp: int):
+        """Id of the tree edge into every tree vertex ([0] = 0xFFFFFFFF), Tree::add_tree_edge's shared counter."""
+        n = C.c_uint32(0)
+        rc = self._lib.povu_hip_debug_edge_ids(self._ctx, comp, C.byref(n), None)
+        if rc != 0:
+            raise RuntimeError("no parallel-tree state" if rc == 3 else "no decompose state")
+        ids = np.zeros(n.value, dtype=np.uint32)
+        if self._lib.povu_hip_debug_edge_ids(self._ctx, comp, C.byref(n), ids.ctypes.data) != 0:
+            raise RuntimeError("povu_hip_debug_edge_ids failed")
+        return ids
 
     def debug_stack(self, comp: int):
         n = C.c_uint32(0)

@@ -70,6 +70,28 @@ def test_random_connected_stage_parity(hip, seed):
         m = {}
         return [m.setdefault(v, len(m)) for v in x.tolist()]
     assert canon(s["cls"]) == canon(d["s_cls"])
+    assert np.array_equal(hip.debug_edge_ids(0), d["pe_id"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tree_edge_ids_shared_counter(hip, seed):
+    """Tree::add_tree_edge / add_be draw their ids from one counter in creation order (spanning_tree.cpp:784-805); the
+    conformance export needs the tree-edge ids, which the GPU derives from per-side back-edge counts."""
+    n = 40 + 23 * seed
+    g = W.random_bidirected(n, int(n * (1.0 + 0.08 * (seed % 6))), 9000 + seed)
+    hip.upload(g)
+    hip.decompose()
+    c = 0
+    checked = 0
+    while True:
+        d = dump_component(g, c)
+        if d is None:
+            break
+        if len(d["gid"]):
+            assert np.array_equal(hip.debug_edge_ids(c), d["pe_id"]), (seed, c)
+            checked += 1
+        c += 1
+    assert checked
 
 
 def test_components_and_skips(hip):
@@ -653,6 +675,132 @@ def test_hub_with_many_parallel_links(hip):
     g = _mk(list(range(1, n + 1)), links)
     want = O.decompose(g)
     assert gpu_texts(hip, g) == want
+    assert np.array_equal(hip.debug_edge_ids(0), dump_component(g, 0)["pe_id"])
     from povu_amd.hip import F_SEQ_TREE
     hip.upload(g)
     assert hip.decompose(flags=F_SEQ_TREE).texts() == want
+    with pytest.raises(RuntimeError):
+        hip.debug_edge_ids(0)
+
+
+def _read_sidecar(path):
+    with open(path) as fh:
+        return [json.loads(l) for l in fh if l.strip()]
+
+
+def _harness_checks(frame):
+    """validate_flubble_debug_export, tests/lean4_conformance/src/main.rs:1288-1403 (per frame)."""
+    assert frame["schema"] == "povu.flubble-debug.frame.v1"
+    assert "tree_vertex_count" in frame and "tree_edge_count" in frame
+    st, tb = frame["stack_entries"], frame["next_seen_table"]
+    assert len(st) == len(tb)
+    for e in st:
+        for f in ["order", "tree_edge_index", "tree_edge_id", "boundary_vertex_id", "orientation", "provenance", "color",
+                  "class_id", "parent_tree_vertex", "child_tree_vertex", "next_seen", "expected_next_seen",
+                  "next_seen_in_range", "next_seen_same_class", "diagnostic"]:
+            assert f in e
+        assert e["diagnostic"] == "ok" and e["next_seen_in_range"] is True and e["next_seen_same_class"] is True
+    for r in tb:
+        for f in ["stack_order", "class_id", "next_seen", "expected_next_seen", "diagnostic"]:
+            assert f in r
+        assert r["diagnostic"] == "ok"
+
+
+def test_structure_export_sidecar_and_gfa2vcf_glue(tmp_path, golden_dir):
+    """--structure-export: the flubble debug sidecar (flubbles.cpp:108-231) frame by frame against the oracle's stack,
+    the conformance harness's own checks, its cycle-class oracles by tree_edge_id (main.rs:1594-1622), and the
+    gfa2vcf glue (gfa2vcf.cpp:18-87) handing the forest to the `call` of an external povu binary."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    povu = os.path.join(root, "povu_amd", "bin", "povu")
+    r0 = W.random_bidirected(160, 230, 77)
+    r1 = W.hprc_shaped([120, 60], seed=5, tiny=6)
+    off = r0.n_vtx
+    g = W._mk(np.concatenate([r0.vid, r1.vid + 1000]), np.concatenate([r0.v1, r1.v1 + off]), np.concatenate([r0.s1, r1.s1]),
+              np.concatenate([r0.v2, r1.v2 + off]), np.concatenate([r0.s2, r1.s2]))
+    gfa = tmp_path / "g.gfa"
+    gfa.write_text(g.to_gfa())
+    out = tmp_path / "out"
+    out.mkdir()
+    sx = tmp_path / "structure.json"
+    side = str(sx) + ".flubble-debug.jsonl"
+    with open(side, "w") as fh:
+        fh.write("stale\n")  # reset_debug_sidecar removes an older file
+    r = subprocess.run([povu, "decompose", "-i", str(gfa), "-o", str(out), "--structure-export", str(sx)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = O.decompose(g)
+    assert {int(p.name[:-5]): p.read_text() for p in out.glob("*.pvst")} == want
+    frames = _read_sidecar(side)
+    assert len(frames) == len(want)
+    def canon(x):
+        m = {}
+        return [m.setdefault(v, len(m)) for v in x]
+    for frame, cid in zip(frames, sorted(want)):
+        _harness_checks(frame)
+        d = dump_component(g, cid - 1)
+        assert frame["tree_vertex_count"] == len(d["gid"]) and frame["tree_edge_count"] == len(d["gid"]) - 1
+        st = frame["stack_entries"]
+        assert [e["order"] for e in st] == list(range(len(d["s_id"])))
+        assert [e["tree_edge_index"] for e in st] == d["s_st_idx"].tolist()
+        assert [e["tree_edge_id"] for e in st] == d["s_edge_id"].tolist()
+        assert [e["boundary_vertex_id"] for e in st] == d["s_id"].tolist()
+        assert [e["orientation"] for e in st] == [">" if o == 0 else "<" for o in d["s_orient"].tolist()]
+        assert all(e["color"] == "black" and e["provenance"] == "real" for e in st)
+        assert [e["child_tree_vertex"] for e in st] == (d["s_st_idx"] + 1).tolist()
+        assert [e["parent_tree_vertex"] for e in st] == d["par"][d["s_st_idx"] + 1].tolist()
+        assert [e["next_seen"] for e in st] == d["next_seen"].tolist()
+        assert [e["expected_next_seen"] for e in st] == d["next_seen"].tolist()
+        assert canon([e["class_id"] for e in st]) == canon(d["s_cls"].tolist())
+        assert [(x["stack_order"], x["class_id"], x["next_seen"]) for x in frame["next_seen_table"]] == \
+            [(e["order"], e["class_id"], e["next_seen"]) for e in st]
+    # the harness's cycle-class oracles: groups of tree_edge_ids that must share a class, and only those
+    vec = json.load(open(os.path.join(golden_dir, "reference_vectors.json")))["fixtures"]
+    n_checked = 0
+    for name, fx in vec.items():
+        groups = fx.get("cycle_classes_by_tree_edge_id")
+        if not groups:
+            continue
+        o2 = tmp_path / ("o_" + name)
+        o2.mkdir()
+        s2 = tmp_path / (name + ".json")
+        r = subprocess.run([povu, "decompose", "-i", os.path.join(golden_dir, "gfa", fx["gfa"]), "-o", str(o2),
+                            "--structure-export=" + str(s2)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        fr = _read_sidecar(str(s2) + ".flubble-debug.jsonl")
+        assert len(fr) == 1
+        _harness_checks(fr[0])
+        st = fr[0]["stack_entries"]
+        group_of = {e: k for k, grp in enumerate(groups) for e in grp}
+        for e in st:
+            assert e["tree_edge_id"] in group_of, (name, e)
+        for a in st:
+            for b in st:
+                assert (a["class_id"] == b["class_id"]) == (group_of[a["tree_edge_id"]] == group_of[b["tree_edge_id"]]), name
+        n_checked += 1
+    assert n_checked == 6
+    # gfa2vcf: without a `call` provider it refuses; with one, the child sees the forest and the pass-through options
+    env = {k: v for k, v in os.environ.items() if k != "POVU_CALL_EXE"}
+    r = subprocess.run([povu, "gfa2vcf", "-i", str(gfa), "-p", "HG"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "POVU_CALL_EXE" in r.stderr
+    fake = tmp_path / "fake_povu.sh"
+    log = tmp_path / "call.log"
+    fake.write_text("#!/bin/bash\necho \"$@\" > %s\nwhile [ $# -gt 0 ]; do if [ \"$1\" = -f ]; then ls \"$2\" | sort -n >> %s; fi; shift; done\n"
+                    "echo '##fileformat=VCFv4.2'\nexit 0\n" % (log, log))
+    fake.chmod(0o755)
+    os.remove(side)
+    r = subprocess.run([povu, "-t", "2", "gfa2vcf", "-i", str(gfa), "--structure-export", str(sx), "--stdout", "-p", "HG", "-c", "50"],
+                       capture_output=True, text=True, env=dict(env, POVU_CALL_EXE=str(fake)))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("##fileformat=VCF")
+    lines = log.read_text().splitlines()
+    args = lines[0].split()
+    assert args[:3] == ["-t", "2", "call"] and args[3:5] == ["-i", str(gfa)] and args[5] == "-f"
+    assert args[7:] == ["--structure-export", str(sx), "--stdout", "-p", "HG", "-c", "50"]
+    assert lines[1:] == ["%d.pvst" % c for c in sorted(want)]
+    assert not os.path.exists(args[6])  # the temporary forest is removed afterwards
+    assert len(_read_sidecar(side)) == len(want)
+    # a failing `call` fails gfa2vcf
+    fake.write_text("#!/bin/bash\nexit 7\n")
+    r = subprocess.run([povu, "gfa2vcf", "-i", str(gfa)], capture_output=True, text=True, env=dict(env, POVU_CALL_EXE=str(fake)))
+    assert r.returncode == 7
