@@ -1030,19 +1030,16 @@ __global__ void k_dup_flags(uint32_t n, const uint32_t *__restrict__ skey, const
 template <typename F>
 static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 {
-	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // list-ranking buffers double as slot buffers
+	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // tour positions; the 8-byte arrays double as slot buffers
 	const size_t NSL = std::max<size_t>(2 * V + 2 * E, 4 * V) + 16; // scan slots of all sides / events of the second ranking
 	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
 	take((void **)&tw.dist, NSL * 4);
-	for (uint32_t **p : {&tw.nxtA, &tw.nxtB, &tw.cntA,
-			     &tw.cntB, &tw.depA, &tw.depB})
-		take((void **)p, NA * 4);
 	take((void **)&tw.xval, (NA + 2) * 8);
 	take((void **)&tw.xps, (NA + 2) * 8);
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0rec, nS * 16);
 	for (uint32_t **p : {&tw.pbr,
-			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list, &tw.cval, &tw.cval2,
+			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list,
 			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
@@ -1156,7 +1153,9 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
 		const uint32_t n_slots = 2 * E;
-		uint32_t *k1 = tw.nxtA, *k2 = tw.nxtB, *v1 = tw.cntA, *v2 = tw.cntB, *side_of = tw.depA; // free by now, >= 2E? see tree_spans
+		// the bridge test's value arrays and the event ranks are free by now ([NA] 8-byte words each, NA >= 2E)
+		uint32_t *k1 = (uint32_t *)tw.xval, *k2 = k1 + n_slots, *v1 = (uint32_t *)tw.xps, *v2 = v1 + n_slots;
+		uint32_t *side_of = (uint32_t *)tw.evt;
 		LAUNCH(k_slot_keys, n_slots, s, n_slots, cs.ladj, k1, v1);
 		sort_pairs_u32(k1, k2, v1, v2, n_slots, bits_for(nS), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		LAUNCH(k_slot_side, nS, s, nS, cs.loff, side_of);

@@ -12,7 +12,6 @@ struct TreeWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	// unrooted spanning forest of the biedged graph H, as arcs
 	uint32_t *dist;					  // [2V + 2E] arcs behind a slot in its Euler tour (slots = arcs, see tree_kernels.hip)
-	uint32_t *nxtA, *nxtB, *cntA, *cntB, *depA, *depB; // [4V+4] list ranking ping-pong
 	unsigned long long *xval, *xps;			  // [4V+4] xor values by tour position, their running xor
 	uint4 *t0rec;					  // [2V] rooted forest: {parent, link to it (NIL: black edge), tour position in, out}
 	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
@@ -24,8 +23,7 @@ struct TreeWs {
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
 	uint32_t *entry_ps, *entry_list;		  // [2V+1]
-	uint32_t *cval, *cval2;				  // [2V]
-	uint32_t *pre, *dep, *tsz, *side_tidx;		  // [2V]
+	uint32_t *side_tidx;				  // [2V] tree vertex (T-space) of a side
 	uint32_t *be_cnt, *be_ps;			  // [2V+1]
 	uint32_t *rk_pk, *rk_heads;			  // list ranking: packed list words [4V+8], list heads [C]
 	uint32_t *rk_nx, *rk_wa, *rk_wb, *rk_tA, *rk_tB, *rk_tC; // pools of the levels above the list itself

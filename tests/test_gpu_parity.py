@@ -804,3 +804,48 @@ def test_structure_export_sidecar_and_gfa2vcf_glue(tmp_path, golden_dir):
     fake.write_text("#!/bin/bash\nexit 7\n")
     r = subprocess.run([povu, "gfa2vcf", "-i", str(gfa)], capture_output=True, text=True, env=dict(env, POVU_CALL_EXE=str(fake)))
     assert r.returncode == 7
+
+
+def test_reader_round_trip_on_gpu_output(hip):
+    """SURVEY 8f item 2 on the product path: the PVST text the GPU pass writes goes back through the reader
+    (read_pvst, src/mto/from_pvst.cpp:162-302) and comp_heights (pvst.hpp:807-836) -- what `povu call` does first
+    (call.cpp:36-53) -- and must give the arrays the forest holds."""
+    import ctypes as C
+    from test_cabi_and_host import _Doc
+    from povu_amd import hip as H
+    hl = H.load_lib()
+    hl.povu_pvst_parse.restype = C.POINTER(_Doc)
+    hl.povu_pvst_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    hl.povu_pvst_doc_free.argtypes = [C.POINTER(_Doc)]
+    g = W.hprc_shaped([3000, 800], seed=21, tiny=5)
+    g2 = W.nested_towers(40, 6)
+    for links in (g, g2):
+        hip.upload(links)
+        f = hip.decompose()
+        texts = f.texts()
+        assert texts == O.decompose(links)
+        arrays = {}
+        for i in range(len(f)):
+            pt = f.tree(i)
+            arrays[pt.component_id] = dict(parent=pt.parent, a_id=pt.a_id, z_id=pt.z_id, a_or=pt.a_or, z_or=pt.z_or)
+        for cid, text in texts.items():
+            raw = text.encode()
+            err = C.create_string_buffer(256)
+            d = hl.povu_pvst_parse(raw, len(raw), err, 256)
+            assert d, err.value
+            doc = d.contents
+            t = arrays[cid]
+            n = doc.n
+            assert n == len(t["parent"])
+            assert np.array_equal(np.ctypeslib.as_array(doc.parent, (n,))[1:], t["parent"][1:])
+            assert np.array_equal(np.ctypeslib.as_array(doc.a_id, (n,))[1:], t["a_id"][1:])
+            assert np.array_equal(np.ctypeslib.as_array(doc.z_id, (n,))[1:], t["z_id"][1:])
+            assert np.array_equal(np.ctypeslib.as_array(doc.a_or, (n,))[1:], t["a_or"][1:])
+            assert np.array_equal(np.ctypeslib.as_array(doc.z_or, (n,))[1:], t["z_or"][1:])
+            assert [doc.type[i] for i in range(n)] == [b"D"] + [b"F"] * (n - 1)
+            depth = np.zeros(n, dtype=np.int64)
+            par = t["parent"].astype(np.int64)
+            for i in range(1, n):  # parents precede children (emission order, flubbles.cpp:345-361)
+                depth[i] = depth[par[i]] + 1
+            assert np.array_equal(np.ctypeslib.as_array(doc.height, (n,)), depth)
+            hl.povu_pvst_doc_free(d)
