@@ -79,6 +79,7 @@ typedef struct {
 #define POVU_HIP_F_NO_STAGE_TIMES 32u /* record only the pass total, not the per-stage HIP events */
 #define POVU_HIP_F_BIG_CLASS_DFS 64u /* always walk the classes with the filtered-scan-list DFS large classes get (A/B testing) */
 #define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with the 1-in-16 splitters lists of 2^26+ elements get (A/B testing) */
+#define POVU_HIP_F_ALL_VERTEX_CLASSES 512u /* number the cycle classes of all tree edges, not just the black ones the candidate stack holds (A/B testing) */
 #define POVU_HIP_F_SORTED_ADJ 16u /* build the local adjacency with the radix sort hub graphs use (A/B testing) */
 
 /*
@@ -235,13 +236,18 @@ typedef struct {
 int povu_hip_last_stage_times(const povu_hip_ctx *ctx, povu_hip_stage_time *out, int max);
 /* components the parallel kernels handed to the sequential redo in the last decompose */
 uint32_t povu_hip_last_seq_redo(const povu_hip_ctx *ctx);
+/* 1 when the last decompose numbered the cycle classes of the black tree edges only (the default whenever the
+ * literal hi_2 rule of flubbles.cpp:566-574 picked the second-highest reach everywhere and no hairpins were asked
+ * for), 0 when it went over all tree edges */
+int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx);
 /* number of links in the components this shard processed in the last decompose */
 uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx);
 
 /* ---- stage-level parity hooks (tests only; device state of the last decompose) ---- */
 /* copies comp_of[v] (0-based component rank) and local vertex idx for every GLOBAL vertex idx */
 int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *local_idx);
-/* tree arrays of component `comp` (0-based rank): sizes via n_tree first call with NULLs */
+/* tree arrays of component `comp` (0-based rank): sizes via n_tree first call with NULLs; `cls` is defined for the
+ * child ends of black tree edges, and for the others too only when povu_hip_last_black_only_classes() == 0 */
 int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *gid, uint8_t *typ,
 			uint32_t *par, uint32_t *cls);
 /* id of the tree edge into each tree vertex (tree_edge_id[0] = 0xFFFFFFFF): tree and back edges share one counter in

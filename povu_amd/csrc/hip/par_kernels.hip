@@ -184,7 +184,7 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
 					   const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root,
 					   const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt,
-					   uint8_t *__restrict__ capf)
+					   uint8_t *__restrict__ capf, uint32_t *__restrict__ literal_rule_seen)
 {
 	const uint32_t end = v + gsize[v];
 	auto hi_of = [&](uint32_t c) {
@@ -202,11 +202,15 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 	// one sweep over the children: the first child that attains the minimum (hi_child), and the first two children
 	// whose hi lies above v in the tree -- hi_2 belongs to the first of them that is not hi_child
 	uint32_t hi_1 = NIL, hi_child = NIL, lt_c[2] = {NIL, NIL}, lt_h[2] = {NIL, NIL};
+	uint32_t second = NIL; // the second smallest hi over the children, with multiplicity: what hi_2 "should" be
 	for (uint32_t c = v + 1; c < end; c += max(gsize[c], 1u)) {
 		const uint32_t h = hi_of(c);
 		if (h < hi_1 || hi_child == NIL) {
+			second = hi_1;
 			hi_1 = h;
 			hi_child = c;
+		} else {
+			second = min(second, h);
 		}
 		if (h < v) {
 			if (lt_c[0] == NIL)
@@ -216,6 +220,11 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 		}
 	}
 	const uint32_t hi_2 = lt_c[0] != hi_child ? lt_h[0] : lt_h[1];
+	// The literal rule (first other child in idx order with hi < v, not the one reaching highest) can leave a capping
+	// edge that ends too early; only then can a bracket come back on top with MORE brackets under it than before.
+	// The black-edge-only class pass relies on that never happening (see run_parallel_dg), so say when it might.
+	if (hi_2 != (second < v ? second : NIL))
+		*literal_rule_seen = 1u;
 	if (hi_2 < hi0[v]) {
 		cap_tgt[v] = hi_2;
 		capf[v] = 1;
@@ -223,14 +232,15 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 }
 __global__ void k_capping(uint32_t n_list, const uint32_t *__restrict__ branch_list, const uint32_t *__restrict__ gsize,
 			  const uint32_t *__restrict__ hi0, const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root,
-			  const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf)
+			  const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf,
+			  uint32_t *__restrict__ literal_rule_seen)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_list)
 		return;
 	const uint32_t v = branch_list[i];
 	if (v != NIL)
-		capping_of(v, gsize, hi0, psb, t_root, segA, P, cap_tgt, capf);
+		capping_of(v, gsize, hi0, psb, t_root, segA, P, cap_tgt, capf, literal_rule_seen);
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
@@ -322,17 +332,26 @@ __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const
 // proper ancestor of v; in list order they are the contiguous range [bstart[mpre(v)],
 // bstart[mpre(v)+size(v)]), the top is the first live one.  Output in DESCENDING v order so that a
 // stable sort by top bracket leaves every group ordered from the deepest vertex up.
-__global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+// BLACK: only the child ends of black tree edges take part (n = V of them: segment slot g of component c is tree
+// vertex 2g + c + [dummy root] + 1, the opposite side follows the entered side in pre-order) -- the candidate stack
+// holds no other edge, see run_parallel_dg for when that is enough.
+template <bool BLACK>
+__global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
 			      const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
 			      const uint32_t *__restrict__ segB, uint32_t P, const uint32_t *__restrict__ tgtR,
 			      const uint32_t *__restrict__ psin, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval,
 			      uint32_t *__restrict__ lsz, uint32_t *__restrict__ err, const uint32_t *__restrict__ rid,
-			      uint32_t first_simp_id, uint8_t *__restrict__ hpf)
+			      uint32_t first_simp_id, uint8_t *__restrict__ hpf, const uint32_t *__restrict__ seg_comp,
+			      const uint32_t *__restrict__ c_ntree)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n)
 		return;
-	const uint32_t q = T - 1 - v;
+	uint32_t v = n - 1 - q;
+	if (BLACK) {
+		const uint32_t c = seg_comp[v];
+		v = 2 * v + c + (c_ntree[c] & 1u) + 1;
+	}
 	cval[q] = v;
 	uint32_t sz = gsize[v];
 	if (sz == 0 || gpar[v] == NIL) {
@@ -381,33 +400,47 @@ __global__ void k_top_bracket(uint32_t T, const uint32_t *__restrict__ gsize, co
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
 // (also row F's marks: q + 1 where the vertex at sorted position q ends a black edge, see k_next_from_runs)
-__global__ void k_class_flags(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+// BLACK: n = V sorted entries, all of them black edges (no marks); the T + 2 words of row E's difference array are
+// still cleared here.
+template <bool BLACK>
+__global__ void k_class_flags(uint32_t n, uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 			      const uint32_t *__restrict__ lsz, const uint8_t *__restrict__ tf, uint8_t *__restrict__ flag,
 			      uint32_t *__restrict__ dlt, uint32_t *__restrict__ mark)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= T)
-		return;
-	dlt[q] = 0; // row E's difference array, [T+2]
-	if (q == T - 1)
-		dlt[T] = dlt[T + 1] = 0;
+	if (BLACK) { // T + 2 = 2n + (C + 2)
+		if (q < n)
+			dlt[2 * q] = dlt[2 * q + 1] = 0;
+		if (2 * n + q < T + 2)
+			dlt[2 * n + q] = 0;
+		if (q >= n)
+			return;
+	} else {
+		if (q >= n)
+			return;
+		dlt[q] = 0; // row E's difference array, [T+2]
+		if (q == n - 1)
+			dlt[n] = dlt[n + 1] = 0;
+	}
 	uint32_t k = skey[q];
 	if (k == NIL) {
 		flag[q] = 0;
-		mark[q] = 0;
+		if (!BLACK)
+			mark[q] = 0;
 		return;
 	}
 	const uint32_t v = sval[q];
 	bool fresh = q == 0 || skey[q - 1] != k || lsz[sval[q - 1]] != lsz[v];
 	flag[q] = fresh ? 1 : 0;
-	mark[q] = (tf[v] & TF_BLACK) ? q + 1 : 0;
+	if (!BLACK)
+		mark[q] = (tf[v] & TF_BLACK) ? q + 1 : 0;
 }
-__global__ void k_class_scatter(uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+__global__ void k_class_scatter(uint32_t n, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 				const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 				uint32_t *__restrict__ gcls)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= T)
+	if (q >= n)
 		return;
 	const uint32_t cls = skey[q] == NIL ? NIL : ps[q] + flag[q] - 1; // inclusive scan - 1
 	gcls[sval[q]] = cls; // (T-space = the per-component layout the debug hook reads)
@@ -487,6 +520,20 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 	if (gcls[u] != gcls[d])
 		return;
 	const uint32_t iu = sidx[u], id = sidx[d];
+	ns[iu] = id;
+	prev[id] = iu;
+}
+
+// the same when only black edges were sorted: the previous entry of the sorted order is the previous black member,
+// and "same class" is "not the first of its run"
+__global__ void k_next_from_runs_black(uint32_t n, const uint32_t *__restrict__ skey, const uint8_t *__restrict__ fresh,
+				       const uint32_t *__restrict__ sval, const uint32_t *__restrict__ sidx,
+				       uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n || q == 0 || skey[q] == NIL || fresh[q])
+		return;
+	const uint32_t iu = sidx[sval[q]], id = sidx[sval[q - 1]];
 	ns[iu] = id;
 	prev[id] = iu;
 }
@@ -883,14 +930,26 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint32_t *branch_list = pw.branch_list; // [nblk(T) * TPB]: one stretch of TPB slots per workgroup of k_hi_simp
 	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, branch_list);
 	const uint32_t n_list = nblk(T) * TPB;
-	LAUNCH(k_capping, n_list, s, n_list, branch_list, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf);
+	LAUNCH(k_capping, n_list, s, n_list, branch_list, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf,
+	       pw.err + 5);
 	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
-	uint32_t *extra = pw.host->take<uint32_t>(2);
+	uint32_t *extra = pw.host->take<uint32_t>(3);
 	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&extra[2], pw.err + 5, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
+	// Classes of the black tree edges only (the candidate stack holds no others: half the vertices to look up, sort and
+	// number).  Per top bracket the reference walks ALL vertices that have it on top, deepest first, and opens a class
+	// whenever the list size differs from the one before (recent_size, flubbles.cpp:668-676); leaving the gray edges'
+	// vertices out of that walk gives the same classes on the black ones as long as the sizes seen by one bracket never
+	// grow again on the way up -- which is what capping edges are for (a bracket only resurfaces once every list spliced
+	// under it has ended).  The literal hi_2 rule (flubbles.cpp:566-574) can cap too low; k_capping reports when it
+	// picked another target than the second-highest reach, and hairpin reports want the top bracket of every vertex:
+	// both take the all-vertices pass.
+	const bool black_only = !want_hp && !pw.all_vertex_classes && extra[2] == 0;
+	pw.black_only_used = black_only;
 	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt);
 	if (dense_nb0 >= 0) { // ranks inside every source are known: place directly
 		LAUNCH(k_bracket_count, NB, s, NB, pw.b_src, pw.b_tgt, pw.mpre, pw.incnt, srccnt);
@@ -906,15 +965,24 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	}
 	seg_build(pw.segB, pw.tgtR, NB, s);
 	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
-	LAUNCH(k_top_bracket, T, s, T, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck, pw.vals_t,
-	       pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr);
-	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, T, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
+	const uint32_t NC = black_only ? V : T; // vertices that get a class
+	if (black_only)
+		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
+		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree);
+	else
+		LAUNCH(k_top_bracket<false>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
+		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr, nullptr, nullptr);
+	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 	uint8_t *cflag = pw.f8a; // bridge flags are dead by now
 	uint32_t *cps = pw.psA;
-	LAUNCH(k_class_flags, T, s, T, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, pw.flagC);
-	scan8(cflag, cps, (size_t)T + 1);
-	LAUNCH(k_class_scatter, T, s, T, ck2, pw.vals_t2, cflag, cps, pw.gcls);
+	if (black_only)
+		LAUNCH(k_class_flags<true>, std::max<size_t>(NC, (size_t)C + 2), s, NC, T, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt,
+		       nullptr);
+	else
+		LAUNCH(k_class_flags<false>, NC, s, NC, T, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, pw.flagC);
+	scan8(cflag, cps, (size_t)NC + 1);
+	LAUNCH(k_class_scatter, NC, s, NC, ck2, pw.vals_t2, cflag, cps, pw.gcls);
 	launches = 30 + 2 * 22;
 	tm.end(launches);
 
@@ -935,7 +1003,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row F
 	tm.begin("par_next_seen");
-	{
+	if (pw.black_only_used) {
+		LAUNCH(k_next_from_runs_black, V, s, V, (const uint32_t *)pw.keys_t2, pw.f8a, pw.vals_t2, pw.topi, pw.ns, pw.prev);
+	} else {
 		uint32_t *mark = pw.flagC, *lastb = pw.psC; // (the marks were written with the class flags)
 		scan_exclusive_max_u32(mark, lastb, T, pw.scan_tmp, pw.scan_tmp_bytes, s);
 		LAUNCH(k_next_from_runs, T, s, T, mark, lastb, pw.vals_t2, pw.gcls, pw.topi, pw.ns, pw.prev);

@@ -25,6 +25,8 @@ struct SegTree {
 struct ParWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	uint32_t V, E, C, T;
+	bool all_vertex_classes = false; // in: number the classes of all tree edges even when the black ones would do (A/B tests)
+	bool black_only_used = false;	 // out: the last pass numbered the classes of the black tree edges only
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
 	uint32_t *hi0, *cov, *psA, *psB, *flagC, *psC; // exclusive scans of the byte flags below [T+1]; flagC: run marks

@@ -594,6 +594,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 							      (o.flags & POVU_HIP_F_SPARSE_SPLITTERS) != 0, tm, s);
 				ctx->tree_in_par = true;
 			}
+			ctx->pw.all_vertex_classes = (o.flags & POVU_HIP_F_ALL_VERTEX_CLASSES) != 0;
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
 			ctx->stack_export_pending = true;
 			ctx->classes_in_par = true;
@@ -1021,6 +1022,11 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 	} catch (const std::exception &) {
 		return 2;
 	}
+}
+
+extern "C" int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx)
+{
+	return ctx && ctx->have_state && ctx->classes_in_par && ctx->pw.black_only_used ? 1 : 0;
 }
 
 extern "C" int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *tree_edge_id)

@@ -52,6 +52,7 @@ F_NO_STAGE_TIMES = 32
 F_BIG_CLASS_DFS = 64
 F_SPARSE_SPLITTERS = 128
 F_REDO_ODD = 256
+F_ALL_VERTEX_CLASSES = 512
 
 _lib = None
 
@@ -102,6 +103,8 @@ def load_lib():
     l.povu_hip_debug_tree.restype = C.c_int
     l.povu_hip_debug_tree.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
+    l.povu_hip_last_black_only_classes.restype = C.c_int
+    l.povu_hip_last_black_only_classes.argtypes = [C.c_void_p]
     l.povu_hip_debug_edge_ids.restype = C.c_int
     l.povu_hip_debug_edge_ids.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
     l.povu_hip_debug_stack.restype = C.c_int
@@ -457,6 +460,10 @@ class HipDecomposer:
         self._lib.povu_hip_debug_tree(self._ctx, comp, C.byref(n), gid.ctypes.data, typ.ctypes.data, par.ctypes.data,
                                       cls.ctypes.data)
         return dict(gid=gid, typ=typ & 3, black=(typ >> 2) & 1, par=par, cls=cls)
+
+    def last_black_only_classes(self) -> bool:
+        """True when the last pass numbered the cycle classes of the black tree edges only (the fast path)."""
+        return bool(self._lib.povu_hip_last_black_only_classes(self._ctx))
 
     def debug_edge_ids(self, comp: int):
         """Id of the tree edge into every tree vertex ([0] = 0xFFFFFFFF), Tree::add_tree_edge's shared counter."""

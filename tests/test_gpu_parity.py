@@ -849,3 +849,38 @@ def test_reader_round_trip_on_gpu_output(hip):
                 depth[i] = depth[par[i]] + 1
             assert np.array_equal(np.ctypeslib.as_array(doc.height, (n,)), depth)
             hl.povu_pvst_doc_free(d)
+
+
+def test_black_edge_only_class_pass(hip, golden_dir):
+    """The class pass numbers the black tree edges only (half the vertices to sort) unless the literal hi_2 rule
+    (flubbles.cpp:566-574) capped somewhere else than at the second-highest reach, or hairpins are reported; both
+    passes must give the reference's result."""
+    from povu_amd.hip import F_ALL_VERTEX_CLASSES, F_HAIRPINS
+    fast = 0
+    for g in [W.chain_of_bubbles(4000), W.hprc_shaped([5000, 700], seed=3, tiny=11), W.nested_towers(30, 5),
+              W.hprc_tangled(3000, seed=4, tangle_every=700, max_tangle=400)]:
+        want = O.decompose(g)
+        hip.upload(g)
+        assert hip.decompose().texts() == want
+        fast += hip.last_black_only_classes()
+        assert hip.decompose(flags=F_ALL_VERTEX_CLASSES).texts() == want
+        assert not hip.last_black_only_classes()
+        assert hip.decompose(flags=F_HAIRPINS).texts() == want
+        assert not hip.last_black_only_classes()
+    assert fast >= 3
+    # the hand-derived vector where hi_2 is NOT the second-highest reach: the fast pass must stand down
+    g = _load_gfa_links(os.path.join(golden_dir, "gfa", "hi2_literal_rule.gfa"))
+    hip.upload(g)
+    got = hip.decompose().texts()
+    assert not hip.last_black_only_classes()
+    assert got[1] == open(os.path.join(golden_dir, "pvst", "hi2_literal_rule.pvst")).read()
+    used = [0, 0]
+    for seed in range(40):
+        n = 25 + 3 * seed
+        g = W.random_bidirected(n, int(n * (1.2 + 0.1 * (seed % 8))), 4242 + seed, connected=True)
+        want = O.decompose(g)
+        hip.upload(g)
+        assert hip.decompose().texts() == want, seed
+        used[int(hip.last_black_only_classes())] += 1
+        assert hip.decompose(flags=F_ALL_VERTEX_CLASSES).texts() == want, seed
+    assert used[0] > 0 and used[1] > 0, used

@@ -4,19 +4,20 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
-from povu_amd.hip import F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_SPARSE_SPLITTERS
+from povu_amd.hip import (F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_SPARSE_SPLITTERS,
+                          F_ALL_VERTEX_CLASSES)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
 hip = HipDecomposer(0)
 rng = np.random.default_rng(12345)
-t0 = time.time(); n_graphs = 0; n_links = 0
+t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0
 last = t0
 while time.time() - t0 < budget:
     if time.time() - last > 60:
         last = time.time(); print('...', n_graphs, 'graphs', flush=True)
     seed = int(rng.integers(1 << 30))
-    kind = n_graphs % 8
+    kind = n_graphs % 9
     if big:
         kind = 6 + n_graphs % 2
     if kind == 0:
@@ -29,6 +30,8 @@ while time.time() - t0 < budget:
         g = W.hprc_shaped([int(rng.integers(50, 3000)) for _ in range(int(rng.integers(1, 5)))], seed=seed, tiny=int(rng.integers(0, 20)))
     elif kind == 4:
         n = int(rng.integers(10, 200)); g = W.random_bidirected(n, int(n * rng.uniform(1.5, 4.0)), seed, self_loops=True, connected=True)
+    elif kind == 8:
+        g = W.hprc_tangled(int(rng.integers(500, 20000)), seed=seed, tangle_every=int(rng.integers(200, 3000)), max_tangle=int(rng.integers(50, 3000)))
     elif kind == 6:
         # several union-find tiles (8192 vertices each), multi-block scans, many components
         n = int(rng.integers(9000, 60000)) * (10 if big else 1); g = W.random_bidirected(n, int(n * rng.uniform(0.9, 1.2 if big else 1.5)), seed)
@@ -46,11 +49,12 @@ while time.time() - t0 < budget:
         tips = np.zeros(g.n_vtx, dtype=np.uint8)  # builder-style graphs without tips
     want = O.decompose(g, tips=tips)
     hip.upload(g, tips)
-    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS, F_SPARSE_SPLITTERS][(n_graphs + n_graphs // 8) % 8]
+    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS, F_SPARSE_SPLITTERS, F_ALL_VERTEX_CLASSES][(n_graphs + n_graphs // 9) % 9]
     got = hip.decompose(flags=flags).texts()
     if got != want:
         print('MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', flags, 'tips', tips is not None)
         np.savez('gpurun_out/fuzz_fail.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
         sys.exit(1)
+    n_black_only += int(hip.last_black_only_classes())
     n_graphs += 1; n_links += g.n_links
-print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's')
+print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only')
