@@ -400,28 +400,17 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
 // (also row F's marks: q + 1 where the vertex at sorted position q ends a black edge, see k_next_from_runs)
-// BLACK: n = V sorted entries, all of them black edges (no marks); the T + 2 words of row E's difference array are
-// still cleared here.
+// BLACK: n = V sorted entries, all of them black edges (no marks).
 template <bool BLACK>
-__global__ void k_class_flags(uint32_t n, uint32_t T, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+__global__ void k_class_flags(uint32_t n, uint32_t V, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 			      const uint32_t *__restrict__ lsz, const uint8_t *__restrict__ tf, uint8_t *__restrict__ flag,
 			      uint32_t *__restrict__ dlt, uint32_t *__restrict__ mark)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (BLACK) { // T + 2 = 2n + (C + 2)
-		if (q < n)
-			dlt[2 * q] = dlt[2 * q + 1] = 0;
-		if (2 * n + q < T + 2)
-			dlt[2 * n + q] = 0;
-		if (q >= n)
-			return;
-	} else {
-		if (q >= n)
-			return;
-		dlt[q] = 0; // row E's difference array, [T+2]
-		if (q == n - 1)
-			dlt[n] = dlt[n + 1] = 0;
-	}
+	if (q < V + 2)
+		dlt[q] = 0; // row E's difference array, [V+2] (launched with max(n, V + 2) threads)
+	if (q >= n)
+		return;
 	uint32_t k = skey[q];
 	if (k == NIL) {
 		flag[q] = 0;
@@ -448,56 +437,47 @@ __global__ void k_class_scatter(uint32_t n, const uint32_t *__restrict__ skey, c
 
 // ------------------------------------------------------------- row E
 // candidate-stack order = pre-order, except that under a branching entered side `a` the black
-// child's subtree comes after the gray children's (tree_utils.cpp:47-76, flubbles.cpp:446-457)
-__global__ void k_shift_delta(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
-			      const uint8_t *__restrict__ tf, uint32_t *__restrict__ dlt)
+// child's subtree comes after the gray children's (tree_utils.cpp:47-76, flubbles.cpp:446-457).
+// Only black edges enter the stack, and pre-order puts exactly one black vertex on every other position (segment slot
+// g of component c <-> black vertex b = 2g + c + [dummy root] + 1, its parent a = b - 1): the whole permutation is
+// worked out in units of black vertices, over the V segment slots.  subtree(b) holds (size + 1) / 2 black vertices,
+// the gray children of a (size(a) - 1 - size(b)) / 2.
+__global__ void k_shift_delta(uint32_t V, const uint32_t *__restrict__ seg_comp, const uint32_t *__restrict__ c_ntree,
+			      const uint32_t *__restrict__ gsize, uint32_t *__restrict__ dlt)
 {
-	uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-	if (b >= T)
+	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= V)
 		return;
-	uint32_t sb = gsize[b];
-	if (sb == 0 || !(tf[b] & TF_BLACK))
+	const uint32_t c = seg_comp[g], b = 2 * g + c + (c_ntree[c] & 1u) + 1, sb = gsize[b];
+	if (sb == 0)
 		return;
-	uint32_t a = gpar[b], g = gsize[a] - 1 - sb;
-	if (g == 0)
+	const uint32_t sa = gsize[b - 1], gray = (sa - 1 - sb) / 2, black = (sb + 1) / 2;
+	if (gray == 0)
 		return;
-	atomicAdd(&dlt[b], g);		       // the black subtree moves behind the gray ones
-	atomicAdd(&dlt[b + sb], 0u - g - sb); // the gray subtrees move forward by size(black)
-	atomicAdd(&dlt[a + gsize[a]], sb);
+	atomicAdd(&dlt[g], gray);		       // the black subtree moves behind the gray ones
+	atomicAdd(&dlt[g + black], 0u - gray - black); // the gray subtrees move forward by the black one's entries
+	atomicAdd(&dlt[g + sa / 2], black);
 }
-// stack position of every tree vertex, and whether a candidate-stack entry sits there (the child end of a black edge)
-__global__ void k_mpos_scatter(uint32_t T, const uint32_t *__restrict__ dlt, const uint32_t *__restrict__ dlt_ps,
-			       const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ tf, uint32_t *__restrict__ inv,
-			       uint8_t *__restrict__ flag)
+// the entry of every black edge, straight at its stack position (no flags, no compaction: a processed component's
+// entries start at soff[c], a host-built table)
+__global__ void k_stack_emit(uint32_t V, const uint32_t *__restrict__ seg_comp, const uint32_t *__restrict__ c_ntree,
+			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ soff,
+			     const uint32_t *__restrict__ dlt, const uint32_t *__restrict__ dlt_ps,
+			     const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gcls,
+			     uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls, uint32_t *__restrict__ s_comp,
+			     uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
+	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= V)
 		return;
-	const uint32_t m = v + dlt_ps[v] + dlt[v];
-	inv[m] = v;
-	flag[m] = (gsize[v] && (tf[v] & TF_BLACK)) ? 1 : 0;
-	if (v == T - 1)
-		flag[T] = 0;
-}
-__global__ void k_stack_emit(uint32_t T, const uint32_t *__restrict__ inv, const uint8_t *__restrict__ flag,
-			     const uint32_t *__restrict__ ps, const uint32_t *__restrict__ gcls,
-			     const uint32_t *__restrict__ t_comp, uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls,
-			     uint32_t *__restrict__ s_comp, uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns,
-			     uint32_t *__restrict__ prev, uint32_t C, const uint32_t *__restrict__ voff, uint32_t *__restrict__ soff,
-			     uint32_t expect_total, uint32_t *err)
-{
-	uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-	if (m <= C) // first candidate-stack entry of component m
-		soff[m] = m == C ? ps[T] : ps[2 * voff[m] + m];
-	if (m == 0 && ps[T] != expect_total)
-		atomicExch(err, 1u);
-	if (m >= T || !flag[m])
+	const uint32_t c = seg_comp[g], b = 2 * g + c + (c_ntree[c] & 1u) + 1;
+	if (gsize[b] == 0)
 		return;
-	uint32_t v = inv[m], i = ps[m];
-	s_vtx[i] = v;
-	s_cls[i] = gcls[v];
-	s_comp[i] = t_comp[v];
-	sidx[v] = i;
+	const uint32_t i = soff[c] + (g - voff[c]) + dlt_ps[g] + dlt[g];
+	s_vtx[i] = b;
+	s_cls[i] = gcls[b];
+	s_comp[i] = c;
+	sidx[b] = i;
 	ns[i] = i; // "no later occurrence" until k_next_from_runs says otherwise (flubbles.cpp:391-399)
 	prev[i] = NIL;
 }
@@ -793,7 +773,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	const size_t T = 2 * V + Cmax, NB = E + V + 2 * T, S = V + 1;
 	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.cov, &pw.psA,
 			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
-			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.inv, &pw.vals_t, &pw.vals_t2})
+			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.vals_t, &pw.vals_t2})
 		take((void **)p, (T + 2) * 4);
 	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c})
 		take((void **)p, T + 32);
@@ -808,7 +788,6 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	for (uint32_t **p : {&pw.s_vtx, &pw.s_cls, &pw.s_comp, &pw.ns, &pw.prev, &pw.s_key, &pw.s_key2, &pw.s_val, &pw.s_val2,
 			     &pw.erank, &pw.lev, &pw.e_i})
 		take((void **)p, (S + 2) * 4);
-	take((void **)&pw.soff, (Cmax + 2) * 4);
 	take((void **)&pw.walk, (2 * S + 4) * 4);
 	take((void **)&pw.walk_ps, (2 * S + 4) * 4);
 	take((void **)&pw.wrun, (2 * S + 4) * 4);
@@ -977,10 +956,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint8_t *cflag = pw.f8a; // bridge flags are dead by now
 	uint32_t *cps = pw.psA;
 	if (black_only)
-		LAUNCH(k_class_flags<true>, std::max<size_t>(NC, (size_t)C + 2), s, NC, T, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt,
-		       nullptr);
+		LAUNCH(k_class_flags<true>, (size_t)V + 2, s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, nullptr);
 	else
-		LAUNCH(k_class_flags<false>, NC, s, NC, T, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, pw.flagC);
+		LAUNCH(k_class_flags<false>, std::max<size_t>(NC, (size_t)V + 2), s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt,
+		       pw.flagC);
 	scan8(cflag, cps, (size_t)NC + 1);
 	LAUNCH(k_class_scatter, NC, s, NC, ck2, pw.vals_t2, cflag, cps, pw.gcls);
 	launches = 30 + 2 * 22;
@@ -988,16 +967,12 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row E
 	tm.begin("par_stack");
-	LAUNCH(k_shift_delta, T, s, T, pw.gsize, pw.gpar, sw.t_flags, pw.dlt);
-	scan(pw.dlt, pw.dlt_ps, (size_t)T + 1);
-	uint8_t *bflag = pw.f8b;
-	uint32_t *bps = pw.psB;
-	LAUNCH(k_mpos_scatter, T, s, T, pw.dlt, pw.dlt_ps, pw.gsize, sw.t_flags, pw.inv, bflag);
-	scan8(bflag, bps, (size_t)T + 1);
-	LAUNCH(k_stack_emit, T, s, T, pw.inv, bflag, bps, pw.gcls, pw.t_comp, pw.s_vtx, pw.s_cls, pw.s_comp, pw.topi, pw.ns,
-	       pw.prev, C, cs.voff, pw.soff, n_stack, pw.err + 3);
-	// one candidate-stack entry per black tree edge = per segment of a processed component: the host knows the
-	// total (k_stack_emit raises err[3] if the device count disagrees)
+	LAUNCH(k_shift_delta, V, s, V, cs.ckey, sw.c_ntree, pw.gsize, pw.dlt);
+	scan(pw.dlt, pw.dlt_ps, (size_t)V + 1);
+	// one candidate-stack entry per black tree edge = per segment of a processed component: the host knows where
+	// every component's entries start (pw.soff) and the total
+	LAUNCH(k_stack_emit, V, s, V, cs.ckey, sw.c_ntree, cs.voff, pw.soff, pw.dlt, pw.dlt_ps, pw.gsize, pw.gcls, pw.s_vtx, pw.s_cls,
+	       pw.s_comp, pw.topi, pw.ns, pw.prev);
 	const uint32_t S = n_stack;
 	tm.end(9);
 

@@ -33,14 +33,15 @@ struct ParWs {
 	uint32_t *branch_list;		 // [T rounded up to whole workgroups] branching vertices, compacted per workgroup
 	uint8_t *f8a, *f8b, *f8c;	 // [T+1] one-byte flags (bridge / simplifying / capping vertex, class and stack flags)
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
-	uint32_t *inv, *vals_t, *vals_t2;
+	uint32_t *vals_t, *vals_t2;
 	uint64_t *keys_t, *keys_t2; // [T]
 	// dense back edges / brackets
 	uint32_t *dbo;			 // [C+1]
 	uint32_t *b_src, *b_tgt, *b_val, *b_val2, *tgtR, *b_ord; // [NBmax]; b_ord = rank among the source's ordinary edges, top first
 	uint64_t *b_key, *b_key2;	 // [NBmax]
 	// candidate stack space
-	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev, *soff; // [V+1] / soff [C+1]
+	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev; // [V+1]
+	uint32_t *soff;				     // [C+1] first stack entry of a component (host-built table, set by the caller)
 	uint32_t *s_key, *s_key2, *s_val, *s_val2;
 	uint32_t *walk, *walk_ps, *wrun; // [2V+2] steps of the stack machine, their prefix sums, running minimum (complemented)
 	uint32_t *erank, *lev, *e_i;	 // [V+1]

@@ -224,9 +224,9 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);
 		take((char **)&cs.sort_tmp, cs.sort_tmp_bytes, 1);
 	} else if (part == 1) {
-		// host-built per-component tables, one upload: order | owner | processed-before | processed
+		// host-built per-component tables, one upload: order | owner | processed-before | processed | stack entries before
 		uint32_t *tables = nullptr;
-		take(&tables, 4 * (C + 1), 4);
+		take(&tables, 5 * (C + 1), 4);
 		sw.order = tables;
 		sw.owner = tables + (C + 1);
 		sw.tables = tables;
@@ -478,9 +478,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			seq_ws_ready = true;
 		};
 		// host-built tables live in pinned scratch: their uploads need no synchronisation
-		uint32_t *tab_h = ctx->host.take<uint32_t>(4 * ((size_t)C + 1));
+		uint32_t *tab_h = ctx->host.take<uint32_t>(5 * ((size_t)C + 1));
 		uint32_t *order = tab_h, *owner = tab_h + ((size_t)C + 1), *pc = tab_h + 2 * ((size_t)C + 1),
-			 *cproc = tab_h + 3 * ((size_t)C + 1);
+			 *cproc = tab_h + 3 * ((size_t)C + 1), *stack_off = tab_h + 4 * ((size_t)C + 1);
 		std::iota(order, order + C, 0u);
 		std::fill(owner, owner + C, 0u);
 		auto weight = [&](uint32_t c) { return (uint64_t)(eoff[c + 1] - eoff[c]) + (voff[c + 1] - voff[c]); };
@@ -515,10 +515,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			cproc[c] = (nv >= 3 && (o.world == 1 || owner[c] == o.rank)) ? 1u : 0u;
 			pc[c + 1] = pc[c] + cproc[c];
 			event_lists += cproc[c] ? 1u : 2 * nv;
+			stack_off[c] = n_stack;
 			n_stack += cproc[c] ? nv : 0u; // one candidate-stack entry per segment (its black tree edge)
 		}
+		stack_off[C] = n_stack;
 		const uint32_t n_processed = pc[C];
-		HIP_CHECK(hipMemcpyAsync(sw.tables, tab_h, 4 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(sw.tables, tab_h, 5 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
 
 		// ---- rows C-G
 		sw.V = g.V;
@@ -582,6 +584,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			int64_t dense_nb0 = -1;
 			ctx->pw.cproc_ps = sw.tables + 2 * ((size_t)C + 1);
 			ctx->tw.cproc = sw.tables + 3 * ((size_t)C + 1);
+			ctx->pw.soff = sw.tables + 4 * ((size_t)C + 1);
 			if (o.flags & POVU_HIP_F_SEQ_TREE) {
 				init_seq_workspace();
 				tm.begin("tree_seq");

@@ -31,7 +31,7 @@ struct SeqWs {
 	const uint64_t *start_key;
 	const uint32_t *order; // [C] components by size descending
 	const uint32_t *owner; // [C] shard that owns the component
-	uint32_t *tables;      // [4(C+1)] order | owner | processed-before | processed: one upload per pass
+	uint32_t *tables;      // [5(C+1)] order | owner | processed-before | processed | stack entries before: one upload per pass
 	// spanning tree
 	uint32_t *t_gid, *t_par, *t_cls, *t_hi, *first_child, *next_sib, *last_child; // [T]
 	uint32_t *t_size, *t_depth;						       // [T] subtree sizes, depths
