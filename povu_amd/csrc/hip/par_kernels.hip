@@ -139,44 +139,6 @@ __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, c
 	if (t == T - 1)
 		bridge[T] = 0;
 }
-// simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
-// the root, flubbles.cpp:621-643)
-// ... and the list of BRANCHING vertices (two or more children), the only ones that can get a capping edge: compacted
-// per workgroup with wave ballots + prefix popcounts, so that k_capping runs on full waves (followed by empty ones that
-// leave at once) instead of on the one lane in six that has work
-__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
-			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
-			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, uint32_t *__restrict__ branch_list)
-{
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	bool branching = false;
-	if (t < T) {
-		uint32_t sz = gsize[t];
-		const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
-		simp[t] = sm;
-		if (t == T - 1)
-			simp[T] = 0;
-		if (hpf)
-			hpf[t] = sm;
-		cap_tgt[t] = NIL;
-		capf[t] = 0;
-		branching = sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz; // the first child does not fill the subtree
-	}
-	// the branching vertices of this workgroup move to the front of its own stretch of the list (no global counter:
-	// millions of waves adding to one word would serialise); the rest of the stretch is marked empty
-	__shared__ uint32_t wcnt[TPB / 64];
-	const unsigned long long m = __ballot(branching);
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	if (lane == 0)
-		wcnt[wave] = (uint32_t)__popcll(m);
-	branch_list[t] = NIL; // (every slot of the stretch, also behind T in the last workgroup; the flagged ones are overwritten below)
-	__syncthreads();
-	uint32_t before = 0;
-	for (uint32_t w = 0; w < wave; w++)
-		before += wcnt[w];
-	if (branching)
-		branch_list[blockIdx.x * TPB + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
-}
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
 // ascending idx are v+1, then each next sibling at c + size(c).  hi(c) = min target of the back edges leaving
 // subtree(c) -- the root as soon as subtree(c) holds a simplifying edge -- is only ever compared between siblings,
@@ -230,17 +192,49 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 		capf[v] = 1;
 	}
 }
-__global__ void k_capping(uint32_t n_list, const uint32_t *__restrict__ branch_list, const uint32_t *__restrict__ gsize,
-			  const uint32_t *__restrict__ hi0, const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root,
-			  const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf,
+// simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
+// the root, flubbles.cpp:621-643)
+// ... and the capping edges.  Only BRANCHING vertices (two or more children) can get one, about one lane in six: the
+// workgroup collects its branching vertices in LDS (wave ballots + prefix popcounts) and its first lanes work
+// through that list, so the sweeps over the children run on full waves.
+__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
+			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
+			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, const uint32_t *__restrict__ hi0,
+			  const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ segA, uint32_t P,
 			  uint32_t *__restrict__ literal_rule_seen)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_list)
-		return;
-	const uint32_t v = branch_list[i];
-	if (v != NIL)
-		capping_of(v, gsize, hi0, psb, t_root, segA, P, cap_tgt, capf, literal_rule_seen);
+	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	bool branching = false;
+	if (t < T) {
+		uint32_t sz = gsize[t];
+		const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
+		simp[t] = sm;
+		if (t == T - 1)
+			simp[T] = 0;
+		if (hpf)
+			hpf[t] = sm;
+		cap_tgt[t] = NIL;
+		capf[t] = 0;
+		branching = sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz; // the first child does not fill the subtree
+	}
+	__shared__ uint32_t wcnt[TPB / 64];
+	__shared__ uint32_t list[TPB];
+	const unsigned long long m = __ballot(branching);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (lane == 0)
+		wcnt[wave] = (uint32_t)__popcll(m);
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+	for (uint32_t w = 0; w < TPB / 64; w++) {
+		if (w < wave)
+			before += wcnt[w];
+		total += wcnt[w];
+	}
+	if (branching)
+		list[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
+	__syncthreads(); // (also orders the cap_tgt / capf defaults above before the stores of capping_of)
+	if (threadIdx.x < total)
+		capping_of(list[threadIdx.x], gsize, hi0, psb, t_root, segA, P, cap_tgt, capf, literal_rule_seen);
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
@@ -547,7 +541,15 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 	walk[2 * i + 1] = d;
 	if (p == NIL || p + 1 >= i)
 		return;
-	if (seg_min(segP, P, p + 1, i) < p)
+	uint32_t lowest;
+	if (i - p <= 9) { // a class that comes back within a few entries: its neighbours' words sit next to prev[i]
+		lowest = NIL;
+		for (uint32_t k = p + 1; k < i; k++)
+			lowest = min(lowest, prev[k]);
+	} else {
+		lowest = seg_min(segP, P, p + 1, i);
+	}
+	if (lowest < p)
 		comp_bad[s_comp[i]] = 1;
 }
 // inclusive prefix sums of the walk, biased so that u32 order = int order; neg = their complement (a running
@@ -777,7 +779,6 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 		take((void **)p, (T + 2) * 4);
 	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c})
 		take((void **)p, T + 32);
-	take((void **)&pw.branch_list, ((T + TPB - 1) / TPB * TPB + 64) * 4);
 	take((void **)&pw.keys_t, (T + 2) * 8);
 	take((void **)&pw.keys_t2, (T + 2) * 8);
 	take((void **)&pw.dbo, (Cmax + 2) * 4);
@@ -906,11 +907,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
-	uint32_t *branch_list = pw.branch_list; // [nblk(T) * TPB]: one stretch of TPB slots per workgroup of k_hi_simp
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, branch_list);
-	const uint32_t n_list = nblk(T) * TPB;
-	LAUNCH(k_capping, n_list, s, n_list, branch_list, pw.gsize, pw.hi0, psb, pw.t_root, pw.segA.tree, pw.segA.P, pw.cap_tgt, capf,
-	       pw.err + 5);
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, pw.hi0, pw.t_root,
+	       pw.segA.tree, pw.segA.P, pw.err + 5);
 	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	uint32_t *extra = pw.host->take<uint32_t>(3);

@@ -30,7 +30,6 @@ struct ParWs {
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
 	uint32_t *hi0, *cov, *psA, *psB, *flagC, *psC; // exclusive scans of the byte flags below [T+1]; flagC: run marks
-	uint32_t *branch_list;		 // [T rounded up to whole workgroups] branching vertices, compacted per workgroup
 	uint8_t *f8a, *f8b, *f8c;	 // [T+1] one-byte flags (bridge / simplifying / capping vertex, class and stack flags)
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
 	uint32_t *vals_t, *vals_t2;
