@@ -326,6 +326,11 @@ __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const
 // proper ancestor of v; in list order they are the contiguous range [bstart[mpre(v)],
 // bstart[mpre(v)+size(v)]), the top is the first live one.  Output in DESCENDING v order so that a
 // stable sort by top bracket leaves every group ordered from the deepest vertex up.
+// where the candidate-stack entry of a black vertex goes (row E worked out before the class pass)
+struct StackPlace {
+	const uint32_t *voff, *soff, *dlt, *dlt_ps;
+	uint32_t *s_vtx, *s_comp;
+};
 // BLACK: only the child ends of black tree edges take part (n = V of them: segment slot g of component c is tree
 // vertex 2g + c + [dummy root] + 1, the opposite side follows the entered side in pre-order) -- the candidate stack
 // holds no other edge, see run_parallel_dg for when that is enough.
@@ -336,23 +341,34 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 			      const uint32_t *__restrict__ psin, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval,
 			      uint32_t *__restrict__ lsz, uint32_t *__restrict__ err, const uint32_t *__restrict__ rid,
 			      uint32_t first_simp_id, uint8_t *__restrict__ hpf, const uint32_t *__restrict__ seg_comp,
-			      const uint32_t *__restrict__ c_ntree)
+			      const uint32_t *__restrict__ c_ntree, const StackPlace sp)
 {
 	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n)
 		return;
-	uint32_t v = n - 1 - q;
+	uint32_t v = n - 1 - q, c = 0;
+	const uint32_t g = v;
 	if (BLACK) {
-		const uint32_t c = seg_comp[v];
-		v = 2 * v + c + (c_ntree[c] & 1u) + 1;
+		c = seg_comp[g];
+		v = 2 * g + c + (c_ntree[c] & 1u) + 1;
 	}
-	cval[q] = v;
 	uint32_t sz = gsize[v];
 	if (sz == 0 || gpar[v] == NIL) {
+		cval[q] = v;
 		ckey[q] = NIL;
-		lsz[v] = 0;
+		if (!BLACK)
+			lsz[v] = 0;
 		return;
 	}
+	// BLACK: everything downstream lives in candidate-stack order, so the sort carries the entry's stack index and the
+	// entry itself (its tree vertex, its component) is written here; lsz is indexed by stack position too
+	uint32_t at = v;
+	if (BLACK) {
+		at = sp.soff[c] + (g - sp.voff[c]) + sp.dlt_ps[g] + sp.dlt[g];
+		sp.s_vtx[at] = v;
+		sp.s_comp[at] = c;
+	}
+	cval[q] = at;
 	uint32_t m = mpre[v];
 	uint32_t lo = bstart[m], hi = bstart[m + sz];
 	// Number of live brackets first (two prefix sums): in a chain of bubbles the brackets of everything below v are closed
@@ -383,10 +399,10 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 	if (i == NIL) {
 		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
 		ckey[q] = NIL;
-		lsz[v] = 0;
+		lsz[at] = 0;
 		return;
 	}
-	lsz[v] = live;
+	lsz[at] = live;
 	ckey[q] = i;
 	if (hpf && rid[i] >= first_simp_id) // the top bracket is a simplifying edge (flubbles.cpp:644-656)
 		hpf[v] |= 2;
@@ -401,8 +417,8 @@ __global__ void k_class_flags(uint32_t n, uint32_t V, const uint32_t *__restrict
 			      uint32_t *__restrict__ dlt, uint32_t *__restrict__ mark)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q < V + 2)
-		dlt[q] = 0; // row E's difference array, [V+2] (launched with max(n, V + 2) threads)
+	if (!BLACK && q < V + 2)
+		dlt[q] = 0; // row E's difference array, [V+2] (launched with max(n, V + 2) threads; BLACK: row E ran already)
 	if (q >= n)
 		return;
 	uint32_t k = skey[q];
@@ -498,20 +514,35 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 	prev[id] = iu;
 }
 
-// the same when only black edges were sorted: the previous entry of the sorted order is the previous black member,
-// and "same class" is "not the first of its run"
-__global__ void k_next_from_runs_black(uint32_t n, const uint32_t *__restrict__ skey, const uint8_t *__restrict__ fresh,
-				       const uint32_t *__restrict__ sval, const uint32_t *__restrict__ sidx,
-				       uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
+// BLACK pass, all in one: class id, next_seen / prev and the "opens a flubble" flag of the entry at sorted position q,
+// written at its stack index (the sort's payload).  Consecutive entries of a run are consecutive members of a class
+// (deeper first), so next_seen[u] = the entry before it in the run, prev[u] = the entry after it.
+__global__ void k_class_finish_black(uint32_t n, uint32_t S, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+				     const uint8_t *__restrict__ fresh, const uint32_t *__restrict__ ps,
+				     uint32_t *__restrict__ s_cls, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev,
+				     uint8_t *__restrict__ dflag)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= n || q == 0 || skey[q] == NIL || fresh[q])
+	if (q == 0)
+		dflag[S] = 0;
+	if (q >= n || skey[q] == NIL)
 		return;
-	const uint32_t iu = sidx[sval[q]], id = sidx[sval[q - 1]];
-	ns[iu] = id;
-	prev[id] = iu;
+	const uint32_t u = sval[q];
+	const uint8_t f = fresh[q];
+	s_cls[u] = ps[q] + f - 1; // inclusive scan - 1
+	const uint32_t nx = f ? u : sval[q - 1];
+	ns[u] = nx;
+	prev[u] = (q + 1 < n && skey[q + 1] != NIL && !fresh[q + 1]) ? sval[q + 1] : NIL;
+	dflag[u] = (u + 1 < nx) ? 1 : 0; // entry u opens a flubble iff its class comes back later than at the next entry
 }
-
+// classes of the black tree vertices back in T-space (debug hook after a BLACK pass)
+__global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx, const uint32_t *__restrict__ s_cls,
+				 uint32_t *__restrict__ gcls)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < S)
+		gcls[s_vtx[i]] = s_cls[i];
+}
 // ------------------------------------------------------------- row G
 // add_flubbles as a stack machine: at entry i, "class already open" pops through it and moves the
 // PVST parent one level up (U, saturating at the root); a non-adjacent next occurrence emits a
@@ -898,7 +929,6 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row D
 	tm.begin("par_classes");
-	uint32_t launches = 0;
 	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov);
 	seg_build(pw.segA, pw.hi0, T, s);
 	uint8_t *bridge = pw.f8a, *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
@@ -943,52 +973,65 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	seg_build(pw.segB, pw.tgtR, NB, s);
 	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
 	const uint32_t NC = black_only ? V : T; // vertices that get a class
-	if (black_only)
-		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
-		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree);
-	else
-		LAUNCH(k_top_bracket<false>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
-		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr, nullptr, nullptr);
-	sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
-	// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
+	const uint32_t S = n_stack;
 	uint8_t *cflag = pw.f8a; // bridge flags are dead by now
 	uint32_t *cps = pw.psA;
-	if (black_only)
-		LAUNCH(k_class_flags<true>, (size_t)V + 2, s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, nullptr);
-	else
+	uint8_t *dflag = pw.f8c; // [S+1] <= [T+1]; capping flags are dead by now
+	if (black_only) {
+		// row E first (it only needs the tree): the stack index of every black vertex, so that the class pass can work
+		// in stack order from the start -- the sort carries stack indices, and classes, next_seen and prev are written
+		// where rows F/G read them
+		HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)V + 2) * 4, s)); // (the bracket counts that lived here are dead)
+		LAUNCH(k_shift_delta, V, s, V, cs.ckey, sw.c_ntree, pw.gsize, pw.dlt);
+		uint32_t *shift_ps = pw.topi; // (dlt_ps still holds the bracket range starts; nobody needs vertex -> stack index here)
+		scan(pw.dlt, shift_ps, (size_t)V + 1);
+		const StackPlace sp{cs.voff, pw.soff, pw.dlt, shift_ps, pw.s_vtx, pw.s_comp};
+		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
+		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree, sp);
+		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
+		// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
+		LAUNCH(k_class_flags<true>, NC, s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, nullptr);
+		scan8(cflag, cps, (size_t)NC + 1);
+		tm.end(30 + 2 * 22);
+		tm.begin("par_stack");
+		LAUNCH(k_class_finish_black, std::max<size_t>(NC, 1), s, NC, S, ck2, pw.vals_t2, cflag, cps, pw.s_cls, pw.ns, pw.prev, dflag);
+		tm.end(1);
+		tm.begin("par_next_seen"); // (folded into the kernel above)
+		tm.end(0);
+		pw.gcls_valid = false;
+	} else {
+		const StackPlace none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+		LAUNCH(k_top_bracket<false>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
+		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr, nullptr, nullptr, none);
+		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		LAUNCH(k_class_flags<false>, std::max<size_t>(NC, (size_t)V + 2), s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt,
 		       pw.flagC);
-	scan8(cflag, cps, (size_t)NC + 1);
-	LAUNCH(k_class_scatter, NC, s, NC, ck2, pw.vals_t2, cflag, cps, pw.gcls);
-	launches = 30 + 2 * 22;
-	tm.end(launches);
+		scan8(cflag, cps, (size_t)NC + 1);
+		LAUNCH(k_class_scatter, NC, s, NC, ck2, pw.vals_t2, cflag, cps, pw.gcls);
+		pw.gcls_valid = true;
+		tm.end(30 + 2 * 22);
 
-	// ---- row E
-	tm.begin("par_stack");
-	LAUNCH(k_shift_delta, V, s, V, cs.ckey, sw.c_ntree, pw.gsize, pw.dlt);
-	scan(pw.dlt, pw.dlt_ps, (size_t)V + 1);
-	// one candidate-stack entry per black tree edge = per segment of a processed component: the host knows where
-	// every component's entries start (pw.soff) and the total
-	LAUNCH(k_stack_emit, V, s, V, cs.ckey, sw.c_ntree, cs.voff, pw.soff, pw.dlt, pw.dlt_ps, pw.gsize, pw.gcls, pw.s_vtx, pw.s_cls,
-	       pw.s_comp, pw.topi, pw.ns, pw.prev);
-	const uint32_t S = n_stack;
-	tm.end(9);
+		// ---- row E
+		tm.begin("par_stack");
+		LAUNCH(k_shift_delta, V, s, V, cs.ckey, sw.c_ntree, pw.gsize, pw.dlt);
+		scan(pw.dlt, pw.dlt_ps, (size_t)V + 1);
+		// one candidate-stack entry per black tree edge = per segment of a processed component: the host knows where
+		// every component's entries start (pw.soff) and the total
+		LAUNCH(k_stack_emit, V, s, V, cs.ckey, sw.c_ntree, cs.voff, pw.soff, pw.dlt, pw.dlt_ps, pw.gsize, pw.gcls, pw.s_vtx, pw.s_cls,
+		       pw.s_comp, pw.topi, pw.ns, pw.prev);
+		tm.end(9);
 
-	// ---- row F
-	tm.begin("par_next_seen");
-	if (pw.black_only_used) {
-		LAUNCH(k_next_from_runs_black, V, s, V, (const uint32_t *)pw.keys_t2, pw.f8a, pw.vals_t2, pw.topi, pw.ns, pw.prev);
-	} else {
+		// ---- row F
+		tm.begin("par_next_seen");
 		uint32_t *mark = pw.flagC, *lastb = pw.psC; // (the marks were written with the class flags)
 		scan_exclusive_max_u32(mark, lastb, T, pw.scan_tmp, pw.scan_tmp_bytes, s);
 		LAUNCH(k_next_from_runs, T, s, T, mark, lastb, pw.vals_t2, pw.gcls, pw.topi, pw.ns, pw.prev);
+		tm.end(4);
+		LAUNCH(k_dflag, (size_t)S + 1, s, S, pw.ns, dflag);
 	}
-	tm.end(4);
 
 	// ---- row G
 	tm.begin("par_pvst");
-	uint8_t *dflag = pw.f8c; // [S+1] <= [T+1]; capping flags are dead by now
-	LAUNCH(k_dflag, (size_t)S + 1, s, S, pw.ns, dflag);
 	scan8(dflag, pw.erank, (size_t)S + 1);
 	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
 	// The five PVST arrays back to back (povu_hip_forest::alloc has the same layout).  Small results are written by the
@@ -1039,6 +1082,16 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		HIP_CHECK(hipStreamWaitEvent(s, side.join, 0)); // the pass is complete when both streams are
 	pw.n_stack = S; // export_parallel_stack copies the stack into the per-component layout when a debug hook asks
 	tm.end(12 + 3 * 22);
+}
+
+void classes_to_tree_space(ParWs &pw, hipStream_t s)
+{
+	if (pw.gcls_valid)
+		return;
+	HIP_CHECK(hipMemsetAsync(pw.gcls, 0xFF, (size_t)pw.T * 4, s));
+	if (pw.n_stack)
+		LAUNCH(k_cls_from_stack, pw.n_stack, s, pw.n_stack, pw.s_vtx, pw.s_cls, pw.gcls);
+	pw.gcls_valid = true;
 }
 
 void export_parallel_stack(const CompState &cs, SeqWs &sw, ParWs &pw, hipStream_t s)

@@ -27,6 +27,7 @@ struct ParWs {
 	uint32_t V, E, C, T;
 	bool all_vertex_classes = false; // in: number the classes of all tree edges even when the black ones would do (A/B tests)
 	bool black_only_used = false;	 // out: the last pass numbered the classes of the black tree edges only
+	bool gcls_valid = false;	 // gcls holds the classes in T-space (a black-only pass keeps them in stack order only)
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
 	uint32_t *hi0, *cov, *psA, *psB, *flagC, *psC; // exclusive scans of the byte flags below [T+1]; flagC: run marks
@@ -86,6 +87,8 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 
 // Copies the candidate stack / classes / next_seen of the last parallel pass into the per-component layout the
 // debug hooks (and the sequential kernels) use; not needed by the pass itself.
+// debug hook after a black-only pass: the classes of the black tree vertices into pw.gcls (NIL elsewhere)
+void classes_to_tree_space(ParWs &pw, hipStream_t s);
 void export_parallel_stack(const CompState &cs, SeqWs &sw, ParWs &pw, hipStream_t s);
 
 // One launch that writes the outcome of a pass into page-locked host memory (5*C + 8 words):

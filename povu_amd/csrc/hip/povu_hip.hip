@@ -1016,6 +1016,10 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 			HIP_CHECK(hipMemcpy(gid, ctx->sw.t_gid + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
 		if (par)
 			HIP_CHECK(hipMemcpy(par, ctx->sw.t_par + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
+		if (cls && ctx->classes_in_par && ctx->last_seq_redo == 0) {
+			classes_to_tree_space(ctx->pw, ctx->stream);
+			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		}
 		if (cls) // the parallel class stage keeps the classes in its own T-space array
 			HIP_CHECK(hipMemcpy(cls, (ctx->classes_in_par && ctx->last_seq_redo == 0 ? ctx->pw.gcls : ctx->sw.t_cls) + tb,
 					    (size_t)N * 4, hipMemcpyDeviceToHost));

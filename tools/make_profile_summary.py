@@ -32,18 +32,18 @@ for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline work
         shutil.copy(os.path.join(D, src), os.path.join(P, f"{tag}_{wl}_{dst}"))
     E, V = bench_line["config"]["links"], bench_line["config"]["segments"]
     rows = list(csv.DictReader(open(os.path.join(D, "kernel_stats.csv"))))
-    # calibration of FETCH_SIZE on kernels of this very run whose bytes are known: the xor scan (word inputs) reads its
-    # input exactly once in each of its two kernels (k_scan_partials<2> with 4-byte-per-lane loads, k_scan_chunks<2> with
-    # 16-byte-per-lane loads) and k_scan_chunks<2> writes as many bytes as it reads (WRITE_SIZE is exact for 16-byte
-    # streaming stores, MI355X_MICROARCH.md)
+    # calibration of FETCH_SIZE on kernels of this very run whose bytes are known: the 64-bit xor scan of the bridge
+    # test reads its input exactly once in each of its two kernels (k_xor64_partials with 8-byte-per-lane loads,
+    # k_xor64_chunks with 32-byte-per-lane loads) and k_xor64_chunks writes as many bytes as it reads (WRITE_SIZE is
+    # exact for streaming stores of whole lines, MI355X_MICROARCH.md)
     fmap = {k: v for k, v in fetch["top"]}
     wmap = {k: v for k, v in write["top"]}
     cal = {}
-    if fmap.get("k_scan_chunks<2>") and wmap.get("k_scan_chunks<2>"):
-        known = wmap["k_scan_chunks<2>"]
-        cal = {"read_16B_per_lane": fmap["k_scan_chunks<2>"] / known, "read_4B_per_lane": fmap.get("k_scan_partials<2>", 0) / known}
+    if fmap.get("k_xor64_chunks") and wmap.get("k_xor64_chunks"):
+        known = wmap["k_xor64_chunks"]
+        cal = {"read_32B_per_lane": fmap["k_xor64_chunks"] / known, "read_8B_per_lane": fmap.get("k_xor64_partials", 0) / known}
     raw = (fetch["per_pass"] + write["per_pass"]) * 1024.0
-    # corrected: the guide's gfx950 rule (coalesced reads are counted at one half) holds for 16-byte AND for 4-byte per
+    # corrected: the guide's gfx950 rule (coalesced reads are counted at one half) holds for wide AND for narrow per
     # lane loads here (both calibrate at ~0.5), so FETCH_SIZE is doubled as a whole; scattered 4-byte gathers are
     # uncalibrated and may be over- or under-stated by this
     corrected = (2 * fetch["per_pass"] + write["per_pass"]) * 1024.0
@@ -55,7 +55,7 @@ for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline work
                             " --steps 2 --warmup 1` (4 decompose passes + one upload, divided by 4). Counter values are KB. "
                             "Correction per MI355X_MICROARCH.md (gfx950 counts coalesced streaming reads at half): FETCH_SIZE is "
                             "doubled -- fetch_calibration = counted / known bytes on the xor-scan kernels of this run shows ~0.5 "
-                            "for 16-byte and for 4-byte per lane loads alike; WRITE_SIZE as counted; scattered gathers are "
+                            "for wide and for narrow per lane loads alike; WRITE_SIZE as counted; scattered gathers are "
                             "uncalibrated; Infinity-Cache hits are counted."})
     passes = PASSES
     tot_ns = sum(int(r["TotalDurationNs"]) for r in rows)
