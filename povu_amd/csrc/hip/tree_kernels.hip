@@ -99,18 +99,31 @@ __device__ __forceinline__ uint2 slot_twin(const uint32_t *__restrict__ loff, co
 	const uint32_t at = loff[S] + k - 1, w = ladj[at];
 	return make_uint2(w, find_link_slot(loff, lle, w, lle[at]));
 }
+// (bridge test of step 3, see k_t0_parents) every non-tree link gets a 64-bit hash of its local edge idx
+__device__ __forceinline__ unsigned long long link_hash(uint32_t le)
+{
+	unsigned long long z = ((unsigned long long)le + 1ull) * 0x9E3779B97F4A7C15ull; // splitmix64 finaliser
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
 // Euler tour successor: after u->w comes the arc that follows w->u among w's arcs (cyclically).  Slots that are no
 // arcs get an inert word (no lane ever walks into them).
+// Also, while the side's links are in hand: hside[S] = xor of the hashes of its non-tree links (a link is in the lists
+// of both its ends, also when they are l and r of one segment).
 __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b)
+			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b,
+			     unsigned long long *__restrict__ hside)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	const uint32_t lo = loff[S], n = loff[S + 1] - lo, base = lo + S;
+	unsigned long long h = 0;
 	for (uint32_t k = 0; k <= n; k++) {
 		if (k && !tgray[lle[lo + k - 1]]) {
 			pk[base + k] = PK_END | PK_STOP;
+			h ^= link_hash(lle[lo + k - 1]);
 			continue;
 		}
 		const uint2 t = slot_twin(loff, ladj, lle, S, k);
@@ -123,6 +136,7 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 			}
 		pk[base + k] = rank_pack(wlo + t.x + nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 	}
+	hside[S] = h;
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -452,17 +466,11 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 // its crossing links cancel by accident (probability 2^-64 per tree edge, i.e. ~1e-11 per pass over 2e8 tree edges;
 // the hash is a fixed function of the edge idx, so a result is reproducible).  This replaces two range-min queries
 // per side over segment trees of the far ends' pre-order numbers, and the forest needs no pre-order numbering at all.
-__device__ __forceinline__ unsigned long long link_hash(uint32_t le)
-{
-	unsigned long long z = ((unsigned long long)le + 1ull) * 0x9E3779B97F4A7C15ull; // splitmix64 finaliser
-	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-	return z ^ (z >> 31);
-}
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
-			     uint4 *__restrict__ t0rec, unsigned long long *__restrict__ val, uint32_t C,
+			     const unsigned long long *__restrict__ hside, uint4 *__restrict__ t0rec,
+			     unsigned long long *__restrict__ val, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t n_pos, uint32_t *__restrict__ err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -473,21 +481,10 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		if (dist[slot_base(loff, r)] != 4 * (voff[S + 1] - voff[S]) - 3)
 			atomicExch(err, 1u);
 	}
-	if (S == 0)
-		val[n_pos] = 0;
 	if (S >= nS)
 		return;
 	const uint32_t c = ckey[S >> 1], L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
 	const uint32_t lo = loff[S], n = loff[S + 1] - lo, base = lo + S;
-	auto side_hash = [&](uint32_t w) { // xor of the hashes of w's non-tree links
-		unsigned long long h = 0;
-		for (uint32_t k = loff[w]; k < loff[w + 1]; k++) {
-			const uint32_t le = lle[k];
-			if (!tgray[le])
-				h ^= link_hash(le); // (a link is in the lists of both its ends, also when they are l and r of one segment)
-		}
-		return h;
-	};
 	// every tree edge is handled once, from the side that owns it: its two arcs a (leaving S) and t (coming back)
 	auto edge = [&](uint32_t a, uint32_t w, uint32_t t, uint32_t le) {
 		const uint32_t da = dist[a], dt = dist[t];
@@ -495,8 +492,10 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		const bool down = da > dt;					      // a comes first: S is the parent of w
 		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
 		t0rec[child] = make_uint4(parent, le, p_in, p_out); // ONE scattered 16-byte store: {parent, its link, tour in, tour out}
-		val[p_in] = side_hash(child);
-		val[p_out] = 0;
+		// (val was cleared by the caller: most sides have no non-tree link, and a scattered 8-byte store costs a sector)
+		const unsigned long long h = hside[child];
+		if (h)
+			val[p_in] = h;
 	};
 	if (!(S & 1u)) // the black edge belongs to the l side
 		edge(base, S ^ 1u, slot_base(loff, S ^ 1u), NIL);
@@ -597,50 +596,42 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 			  const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ecc,
-			  uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot, uint8_t *__restrict__ dvis,
+			  uint2 *__restrict__ dps, uint8_t *__restrict__ dvis,
 			  uint8_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	dpar[S] = NIL;
-	cslot[S] = 0;
-	dvis[S] = 0;
-	entry_flag[S] = 0;
+	uint2 rec = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}: one word pair, one store
+	uint8_t vis = 0, ef = 0;
 	// class and visited bit of a side in ONE word: the walk tests "same class and not yet visited" with one load
 	const bool proc = cproc[ckey[S >> 1]] != 0;
 	const uint32_t p0 = proc ? pbr[S] : 0u;
 	const bool entry = proc && (p0 & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
 	cstate[S] = proc ? (ecc[S] | (entry ? CS_VISITED : 0u)) : NIL;
-	if (!proc)
-		return;
-	// a class is walked from its entry side; a side that is alone in its class has nothing to walk
-	const uint8_t walk = multi[S] ? 1 : 0;
-	uint32_t p = p0;
-	if (p == NIL) { // DFS start of the component
-		dvis[S] = 1;
-		entry_flag[S] = walk;
-		return;
-	}
-	if (!(p & PB_BRIDGE))
-		return;
-	p &= ~PB_BRIDGE;
-	dvis[S] = 1;
-	entry_flag[S] = walk;
-	dpar[S] = p;
-	if (p == (S ^ 1)) {
-		cslot[S] = 0; // black edge: scanned first
-	} else { // gray bridge: its slot in the parent's list (ascending local edge idx)
-		uint32_t le = t0rec[S].y, lo = loff[p], hi = loff[p + 1];
-		while (lo < hi) {
-			uint32_t mid = (lo + hi) >> 1;
-			if (lle[mid] < le)
-				lo = mid + 1;
-			else
-				hi = mid;
+	if (entry) {
+		// a class is walked from its entry side; a side that is alone in its class has nothing to walk
+		vis = 1;
+		ef = multi[S] ? 1 : 0;
+		if (p0 != NIL) { // (NIL: DFS start of the component)
+			const uint32_t p = p0 & ~PB_BRIDGE;
+			rec.x = p;
+			if (p != (S ^ 1)) { // (black edge: slot 0, scanned first) gray bridge: its slot in the parent's list (ascending local edge idx)
+				uint32_t le = t0rec[S].y, lo = loff[p], hi = loff[p + 1];
+				while (lo < hi) {
+					uint32_t mid = (lo + hi) >> 1;
+					if (lle[mid] < le)
+						lo = mid + 1;
+					else
+						hi = mid;
+				}
+				rec.y = lo - loff[p] + 1;
+			}
 		}
-		cslot[S] = lo - loff[p] + 1;
 	}
+	dps[S] = rec;
+	dvis[S] = vis;
+	entry_flag[S] = ef;
 }
 __global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 			  uint32_t *__restrict__ out)
@@ -689,8 +680,7 @@ __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, cons
 // entry and its state word on the way down; {parent, slot} of the finished side and the parent's list bounds on the way
 // back -- the parent resumes its scan behind the slot the child was found through, so no cursor is stored.
 __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
-				  const uint32_t *__restrict__ ladj, uint32_t *__restrict__ cstate, uint32_t *__restrict__ dpar,
-				  uint32_t *__restrict__ cslot)
+				  const uint32_t *__restrict__ ladj, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
 {
 	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
@@ -703,8 +693,7 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 				const uint32_t slot = k++;
 				if (cstate[o] == cls) { // same class, not visited yet
 					cstate[o] = cls | CS_VISITED;
-					dpar[o] = u;
-					cslot[o] = slot;
+					dps[o] = make_uint2(u, slot);
 					u = o;
 					k = 0;
 					lo = loff[u];
@@ -717,15 +706,16 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 				continue;
 			if (u == s)
 				break;
-			k = cslot[u] + 1;
-			u = dpar[u];
+			const uint2 up = dps[u];
+			k = up.y + 1;
+			u = up.x;
 			lo = loff[u];
 			n = loff[u + 1] - lo;
 		}
 	}
 }
 __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
-			    const uint4 *__restrict__ rb, uint32_t *__restrict__ dpar, uint32_t *__restrict__ cslot,
+			    const uint4 *__restrict__ rb, uint2 *__restrict__ dps,
 			    uint8_t *__restrict__ dvis, uint4 *__restrict__ ret)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,8 +731,7 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 			const uint4 rn = rb[e.x]; // speculative: issued together with the visited byte
 			if (!dvis[e.x]) {
 				dvis[e.x] = 1;
-				dpar[e.x] = u;
-				cslot[e.x] = e.y;
+				dps[e.x] = make_uint2(u, e.y);
 				ret[e.x] = make_uint4(u, r.x, r.y, k + 1);
 				u = e.x;
 				r = rn;
@@ -776,20 +765,22 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 // children, so the work stays linear in the degrees.
 // events: 2S = enter S, 2S+1 = leave S.  "enter S" heads the list of its component iff S is the DFS start of a
 // processed component (sides of other components keep their two-event lists, which nobody reads)
-__global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
+__global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps,
 			 const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey,
 			 const uint32_t *__restrict__ cproc, uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	const uint32_t p = dpar[S];
+	const uint2 me = dps[S];
+	const uint32_t p = me.x;
 	uint32_t c = NIL, ns = NIL;
 	{
 		const uint32_t lo = loff[S], n = loff[S + 1] - lo;
 		for (uint32_t k = 0; k <= n; k++) {
 			const uint32_t o = k == 0 ? (S ^ 1u) : ladj[lo + k - 1];
-			if (dpar[o] == S && cslot[o] == k) {
+			const uint2 r = dps[o];
+			if (r.x == S && r.y == k) {
 				c = o;
 				break;
 			}
@@ -797,9 +788,10 @@ __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const u
 	}
 	if (p != NIL) {
 		const uint32_t lo = loff[p], n = loff[p + 1] - lo;
-		for (uint32_t k = cslot[S] + 1; k <= n; k++) {
+		for (uint32_t k = me.y + 1; k <= n; k++) {
 			const uint32_t o = ladj[lo + k - 1];
-			if (dpar[o] == p && cslot[o] == k) {
+			const uint2 r = dps[o];
+			if (r.x == p && r.y == k) {
 				ns = o;
 				break;
 			}
@@ -819,7 +811,7 @@ __global__ void k_events(uint32_t nS, const uint32_t *__restrict__ dpar, const u
 
 // ------------------------------------------------------------------ 8. tree arrays + back edges
 __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd,
-			    const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ ckey,
+			    const uint2 *__restrict__ dps, const uint32_t *__restrict__ ckey,
 			    const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
 			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
 			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
@@ -856,7 +848,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd,
 	const uint32_t depth = 0u - ent.y;
 	const uint32_t t = tb + hd + pre;
 	t_gid[t] = gid_s[S >> 1];
-	const uint32_t p = dpar[S];
+	const uint32_t p = dps[S].x;
 	t_flags[t] = (uint8_t)((S & 1) | ((p == (S ^ 1)) ? TF_BLACK : 0));
 	t_par[t] = p == NIL ? (hd ? 0u : NIL) : hd + (Nh - cd[2 * p].x);
 	t_size[t] = size;
@@ -870,7 +862,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd,
 //  - a link to the tree parent, or a repeated link to the same side, is already "connected"
 template <bool EMIT>
 __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			     const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ side_tidx,
+			     const uint2 *__restrict__ dps, const uint32_t *__restrict__ side_tidx,
 			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
 			     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ be_cnt,
 			     const uint32_t *__restrict__ be_ps, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
@@ -896,7 +888,7 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 			if (p == root || t_par[p] != 0)
 				out(root);
 		} else {
-			const uint32_t dp = dpar[S];
+			const uint32_t dp = dps[S].x;
 			bool loop_seen = false;
 			for (uint32_t k = lo; k < hi; k++) {
 				const uint32_t o = ladj[k];
@@ -933,7 +925,7 @@ __global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, con
 // edges created before t was discovered.  A side creates its back edges while it scans its links between two of
 // its tree children: w[child] = those just before that child, tail[side] = those after its last child.
 __global__ void k_edge_id_weights(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-				  const uint32_t *__restrict__ dpar, const uint32_t *__restrict__ cslot,
+				  const uint2 *__restrict__ dps,
 				  const uint32_t *__restrict__ side_tidx, const uint32_t *__restrict__ ckey,
 				  const uint32_t *__restrict__ voff, const uint32_t *__restrict__ t_par,
 				  const uint8_t *__restrict__ dupflag, uint32_t *__restrict__ w, uint32_t *__restrict__ tail)
@@ -950,7 +942,7 @@ __global__ void k_edge_id_weights(uint32_t nS, const uint32_t *__restrict__ loff
 	if (lo == hi) {
 		cnt = (p == root || t_par[p] != 0) ? 1u : 0u;
 	} else {
-		const uint32_t dp = dpar[S];
+		const uint32_t dp = dps[S].x;
 		bool loop_seen = false;
 		for (uint32_t k = lo; k < hi; k++) {
 			const uint32_t o = ladj[k];
@@ -960,7 +952,8 @@ __global__ void k_edge_id_weights(uint32_t nS, const uint32_t *__restrict__ loff
 				loop_seen = true;
 				continue;
 			}
-			if (dpar[o] == S && cslot[o] == k - lo + 1) { // the link that discovered o
+			const uint2 ro = dps[o];
+			if (ro.x == S && ro.y == k - lo + 1) { // the link that discovered o
 				w[side_tidx[o]] = cnt;
 				cnt = 0;
 				continue;
@@ -986,7 +979,7 @@ __global__ void k_edge_id_weights(uint32_t nS, const uint32_t *__restrict__ loff
 void debug_edge_id_weights(const CompState &cs, const SeqWs &sw, const TreeWs &tw, uint32_t *w, uint32_t *tail, hipStream_t s)
 {
 	const uint32_t nS = 2 * sw.V;
-	LAUNCH(k_edge_id_weights, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.cslot, tw.side_tidx, cs.ckey, cs.voff, sw.t_par,
+	LAUNCH(k_edge_id_weights, nS, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey, cs.voff, sw.t_par,
 	       tw.last_dupflag, w, tail);
 }
 
@@ -1039,9 +1032,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0rec, nS * 16);
 	for (uint32_t **p : {&tw.pbr,
-			     &tw.ecc, &tw.dpar, &tw.cslot, &tw.entry_ps, &tw.entry_list,
+			     &tw.ecc, &tw.entry_ps, &tw.entry_list,
 			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
+	take((void **)&tw.dps, nS * 8);
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.entry_flag, nS + 16);
 	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
@@ -1084,14 +1078,15 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const size_t n_slots = (size_t)nS + 2 * (size_t)E; // >= the scan slots of all sides (loff[nS] + nS)
 	RankBufs rb{tw.rk_pk, tw.rk_heads, tw.rk_nx, tw.rk_wa, tw.rk_wb, tw.rk_tA, tw.rk_tB, tw.rk_tC};
 	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
-	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA);
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, tw.xps); // (xps: free until the xor scan)
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
 	if (n_slots >= PK_END) // (every link has two local slots, a self loop one on either side of its segment: loff[nS] = 2E)
 		throw HipError("graph too large for the packed list ranking: 2 * (segments + links) must stay below 2^29");
 	list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
 	unsigned long long *val = tw.xval, *px = tw.xps; // [NA+1] each
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.t0rec, val, C,
+	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 8, s));
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.xps, tw.t0rec, val, C,
 	       start_key, NA, pw.err + 2);
 	tm.end(40);
 
@@ -1108,8 +1103,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0rec, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dpar,
-	       tw.cslot, tw.dvis, tw.entry_flag, cstate);
+	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0rec, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dps,
+	       tw.dvis, tw.entry_flag, cstate);
 	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
 	uint32_t *hb = tw.host->take<uint32_t>(2);
@@ -1121,7 +1116,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	if (n_entry && big_classes) {
 		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.ecc, cs.ckey, tw.cproc, tw.cadj, tw.crb);
 		KLAUNCH(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
-				   tw.dpar, tw.cslot, tw.dvis, tw.cret);
+				   tw.dps, tw.dvis, tw.cret);
 	} else if (n_entry) {
 		// Lanes in flight = a window of sides whose scattered stores meet again in L2: ~3000 x 64 lanes measured best
 		// from a few hundred thousand to twenty million small classes (wider windows thrash the caches, narrower
@@ -1130,8 +1125,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		unsigned dfs_blocks = std::min(all_blocks, 3072u);
 		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
 			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
-		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dpar,
-			tw.cslot);
+		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps);
 	}
 	tm.end(5);
 
@@ -1141,14 +1135,14 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// one list per processed component, one two-event list per side of an unprocessed one
 	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(2 * (size_t)nS);
 	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
-	LAUNCH(k_events, nS, s, nS, tw.dpar, tw.cslot, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE);
+	LAUNCH(k_events, nS, s, nS, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE);
 	list_rank_splitters<true>(2 * nS, bitsE, nullptr, tw.evt, C, rb, s);
 	(void)event_lists;
 	tm.end(40);
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
-	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, tw.dpar, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
+	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
 	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree);
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
@@ -1165,11 +1159,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		dupflag = tw.dvis_slots;
 	}
 	tw.last_dupflag = dupflag;
-	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
+	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
 	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
 	const uint32_t NB0 = tw.host->read_u32(tw.be_ps + nS, s);
-	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dpar, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
+	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
 	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
 	tm.end(6);
 	return NB0;
