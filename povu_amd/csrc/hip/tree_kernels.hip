@@ -63,12 +63,13 @@ __device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, unsigned 
 }
 
 // ------------------------------------------------------------------ 1. Euler tour of the spanning forest
-// The arcs of the tour ARE the scan slots of the sides: side S owns the slots [loff[S] + S, loff[S+1] + S + 1) -- slot 0
-// its black edge, slot k >= 1 its k-th link in adjacency order -- and a slot is an arc iff its edge is in the forest
-// (black edges always, links that won a hook in the union-find).  Nothing is numbered, counted or stored per arc: the
-// twin of a slot is found in the (short, ascending) list of the side at the other end, and the arcs leaving a side are
-// taken in slot order (any cyclic order of a side's arcs gives a valid Euler tour).
-__device__ __forceinline__ uint32_t slot_base(const uint32_t *__restrict__ loff, uint32_t S) { return loff[S] + S; }
+// The forest = every black edge + the links that won a hook in the union-find over the segments.  A black edge never
+// needs rooting (whichever side of a segment the tour enters first is the parent of the other), so the tour runs over
+// the forest of SEGMENTS joined by the hooked links: its arcs ARE the adjacency slots of those links (slot = index
+// into ladj / lle, two per link), half as many list elements as a tour over the sides.  Nothing is numbered, counted
+// or stored per arc: the twin of a slot is found in the (short, ascending) list of the side at the other end, and
+// the arcs around a segment are taken in slot order -- the slots of its l side, then those of its r side, which are
+// one contiguous index range [loff[2w], loff[2w + 2]) -- so the subtrees hanging off ONE side are contiguous in the tour.
 // slot (1-based) of local edge `le` in the list of side w (ascending by local edge idx)
 __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle, uint32_t w,
 						   uint32_t le)
@@ -90,14 +91,12 @@ __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ 
 			return j - l0 + 1;
 	return 0; // (not reached: a link sits in the lists of both its ends)
 }
-// the slot at the other end of slot k of side S: {side, slot}
-__device__ __forceinline__ uint2 slot_twin(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-					   const uint32_t *__restrict__ lle, uint32_t S, uint32_t k)
+// adjacency index of the same link in the list of the side at its other end
+__device__ __forceinline__ uint32_t arc_twin(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+					     const uint32_t *__restrict__ lle, uint32_t at)
 {
-	if (k == 0)
-		return make_uint2(S ^ 1u, 0u);
-	const uint32_t at = loff[S] + k - 1, w = ladj[at];
-	return make_uint2(w, find_link_slot(loff, lle, w, lle[at]));
+	const uint32_t w = ladj[at];
+	return loff[w] + find_link_slot(loff, lle, w, lle[at]) - 1;
 }
 // (bridge test of step 3, see k_t0_parents) every non-tree link gets a 64-bit hash of its local edge idx
 __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
@@ -107,36 +106,42 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
 	return z ^ (z >> 31);
 }
-// Euler tour successor: after u->w comes the arc that follows w->u among w's arcs (cyclically).  Slots that are no
-// arcs get an inert word (no lane ever walks into them).
+// Euler tour successor: after u->w comes the arc that follows w->u among the arcs of w's segment (cyclically; w->u
+// itself when the segment has no other).  Slots that are no arcs get an inert word (no lane ever walks into them).
 // Also, while the side's links are in hand: hside[S] = xor of the hashes of its non-tree links (a link is in the lists
-// of both its ends, also when they are l and r of one segment).
+// of both its ends, also when they are l and r of one segment), ft[S] = its first arc (NIL: none).
 __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b,
-			     unsigned long long *__restrict__ hside)
+			     unsigned long long *__restrict__ hside, uint32_t *__restrict__ ft)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	const uint32_t lo = loff[S], n = loff[S + 1] - lo, base = lo + S;
+	const uint32_t lo = loff[S], hi = loff[S + 1];
 	unsigned long long h = 0;
-	for (uint32_t k = 0; k <= n; k++) {
-		if (k && !tgray[lle[lo + k - 1]]) {
-			pk[base + k] = PK_END | PK_STOP;
-			h ^= link_hash(lle[lo + k - 1]);
+	uint32_t first = NIL;
+	for (uint32_t at = lo; at < hi; at++) {
+		const uint32_t le = lle[at];
+		if (!tgray[le]) {
+			pk[at] = PK_END | PK_STOP;
+			h ^= link_hash(le);
 			continue;
 		}
-		const uint2 t = slot_twin(loff, ladj, lle, S, k);
-		const uint32_t wlo = loff[t.x], wn = loff[t.x + 1] - wlo;
-		uint32_t nxt = 0; // next arc of w behind the twin; its black edge when the links are exhausted
-		for (uint32_t j = t.y + 1; j <= wn; j++)
-			if (tgray[lle[wlo + j - 1]]) {
+		if (first == NIL)
+			first = at;
+		const uint32_t w = ladj[at], t = loff[w] + find_link_slot(loff, lle, w, le) - 1;
+		const uint32_t sb = loff[w & ~1u], se = loff[(w & ~1u) + 2];
+		uint32_t nxt = t;
+		for (uint32_t j = t + 1; j < se && nxt == t; j++)
+			if (tgray[lle[j]])
 				nxt = j;
-				break;
-			}
-		pk[base + k] = rank_pack(wlo + t.x + nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
+		for (uint32_t j = sb; j < t && nxt == t; j++)
+			if (tgray[lle[j]])
+				nxt = j;
+		pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 	}
 	hside[S] = h;
+	ft[S] = first;
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -144,8 +149,9 @@ __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *sta
 	unsigned long long k = start_key[c];
 	return k == ~0ull ? 2 * voff[c] : (uint32_t)(k & 0xFFFFFFFFu);
 }
-// per component: cut its tour open behind the arc that returns to the root for the last time; the first arc out of
-// the root (its black edge) heads the component's list
+// per component: the tour starts with the first arc of the root segment, its slots taken from the DFS start side on
+// (start side, then the other side), and is cut open behind the arc that returns to the root for the last time.
+// A component of one segment has no arc and heads no list.
 __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
 			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
 			    const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, uint32_t *__restrict__ heads)
@@ -153,18 +159,26 @@ __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= C)
 		return;
-	const uint32_t r = comp_root_side(start_key, voff, c), lo = loff[r], n = loff[r + 1] - lo;
-	uint32_t last = 0;
-	for (uint32_t k = n; k >= 1; k--)
-		if (tgray[lle[lo + k - 1]]) {
-			last = k;
-			break;
+	const uint32_t r = comp_root_side(start_key, voff, c), sb = loff[r & ~1u], se = loff[(r & ~1u) + 2], mid = loff[r];
+	// cyclic order from `mid`: [mid, se) then [sb, mid)
+	uint32_t a_first = NIL, a_last = NIL;
+	for (uint32_t j = mid; j < se; j++)
+		if (tgray[lle[j]]) {
+			if (a_first == NIL)
+				a_first = j;
+			a_last = j;
 		}
-	const uint2 t = slot_twin(loff, ladj, lle, r, last);
-	const uint32_t a_end = slot_base(loff, t.x) + t.y, a_first = lo + r;
-	pk[a_end] = PK_END | PK_STOP; // no successor, weight 0
-	atomicOr(&pk[a_first], PK_HEAD); // (k_tour_words wrote the word in an earlier launch)
+	for (uint32_t j = sb; j < mid; j++)
+		if (tgray[lle[j]]) {
+			if (a_first == NIL)
+				a_first = j;
+			a_last = j;
+		}
 	heads[c] = a_first;
+	if (a_first == NIL)
+		return;
+	pk[arc_twin(loff, ladj, lle, a_last)] = PK_END | PK_STOP; // no successor, weight 0
+	atomicOr(&pk[a_first], PK_HEAD);			       // (k_tour_words wrote the word in an earlier launch)
 }
 // one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
 // HOPS = 3 covers two rounds (every pointer then spans 4x as far), HOPS = 7 three rounds (8x).  More
@@ -455,62 +469,69 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 }
 
 // ------------------------------------------------------------------ 2. rooted forest T0 and 3. its bridges
-// dist[a] = arcs after a in its tour.  u->w is the advance arc of tree edge {u,w} iff it comes first; subtree(w) is the
-// stretch of the tour from that arc (position tin) to its twin (position tout).
+// dist[a] = arcs after a in its tour; position of arc a = (arcs of the components before) + L - 1 - dist[a], L = 2 (nv - 1).
+// u->w is the advance arc of the hooked link {u,w} iff it comes first: then w is the side its segment is ENTERED
+// through (parent u), the segment's other side is the child of w over the black edge, and the segment's subtree is the
+// stretch of the tour from that arc (position tin) to its twin (position tout).  One record per segment:
+// t0seg[segment] = {parent side of the entered side, its link | entered side's r/l bit << 31, tin, tout}; the root
+// segment of a component is entered through the DFS start side, from nowhere.
 //
 // A tree edge (parent(w), w) of the rooted forest is a bridge of H iff no non-tree link has exactly one end inside
 // subtree(w).  Every non-tree link gets a 64-bit hash of its local edge idx; a side's value is the xor of the hashes
-// of its non-tree links, placed at the tour position of the arc that enters the side (0 at all other positions); the
-// xor over subtree(w) -- two look-ups into the running xor over the tour positions -- cancels every link with both
-// ends inside and keeps the ones that cross.  A bridge always xors to 0; a non-bridge xors to 0 only if the hashes of
-// its crossing links cancel by accident (probability 2^-64 per tree edge, i.e. ~1e-11 per pass over 2e8 tree edges;
-// the hash is a fixed function of the edge idx, so a result is reproducible).  This replaces two range-min queries
-// per side over segment trees of the far ends' pre-order numbers, and the forest needs no pre-order numbering at all.
+// of its non-tree links, a segment's value (both sides) sits at the tour position of the arc that enters it (0 at all
+// other positions); the xor over a stretch of the tour -- two look-ups into the running xor over the positions --
+// cancels every link with both ends inside and keeps the ones that cross:
+//   hooked link into w:   the stretch [tin, tout] of w's segment;
+//   black edge w -> w^1:  hside[w^1] and the stretch of the subtrees hanging off w^1, which the slot order keeps
+//                         together: from the first arc of w^1 up to the next arc of the segment behind them (the first
+//                         arc of w if that is not the entering one, else the arc that leaves the segment).
+// A bridge always xors to 0; a non-bridge xors to 0 only if the hashes of its crossing links cancel by accident
+// (probability 2^-64 per tree edge, i.e. ~1e-11 per pass over 2e8 tree edges; the hash is a fixed function of the edge
+// idx, so a result is reproducible).  This replaces two range-min queries per side over segment trees of the far ends'
+// pre-order numbers, and the forest needs no pre-order numbering at all.
+static constexpr uint32_t T0_RBIT = 0x80000000u;
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
-			     const unsigned long long *__restrict__ hside, uint4 *__restrict__ t0rec,
-			     unsigned long long *__restrict__ val, uint32_t C,
-			     const unsigned long long *__restrict__ start_key, uint32_t n_pos, uint32_t *__restrict__ err)
+			     const unsigned long long *__restrict__ hside, const uint32_t *__restrict__ heads,
+			     uint4 *__restrict__ t0seg, unsigned long long *__restrict__ val, uint32_t C,
+			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S < C) { // the DFS start of component S roots its tree (no advance arc ever enters it)
-		const uint32_t r = comp_root_side(start_key, voff, S);
-		t0rec[r] = make_uint4(NIL, NIL, 0u, 0u);
-		// the tour of the component covers all its 4 nv - 2 arcs iff the hooks of the union-find are a spanning tree
-		if (dist[slot_base(loff, r)] != 4 * (voff[S + 1] - voff[S]) - 3)
+	if (S < C) { // the DFS start of component S roots its tree (no advance arc ever enters its segment)
+		const uint32_t r = comp_root_side(start_key, voff, S), L = 2 * (voff[S + 1] - voff[S] - 1);
+		t0seg[r >> 1] = make_uint4(NIL, (r & 1u) ? T0_RBIT : 0u, 0u, L ? L - 1 : 0u);
+		// the tour of the component covers all its arcs iff the hooks of the union-find are a spanning tree
+		const uint32_t h = heads[S];
+		if (h == NIL ? L != 0 : dist[h] != L - 1)
 			atomicExch(err, 1u);
 	}
 	if (S >= nS)
 		return;
-	const uint32_t c = ckey[S >> 1], L = 4 * (voff[c + 1] - voff[c]) - 2, abase = 4 * voff[c] - 2 * c;
-	const uint32_t lo = loff[S], n = loff[S + 1] - lo, base = lo + S;
-	// every tree edge is handled once, from the side that owns it: its two arcs a (leaving S) and t (coming back)
-	auto edge = [&](uint32_t a, uint32_t w, uint32_t t, uint32_t le) {
-		const uint32_t da = dist[a], dt = dist[t];
+	const uint32_t c = ckey[S >> 1], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
+	const uint32_t lo = loff[S], hi = loff[S + 1];
+	for (uint32_t at = lo; at < hi; at++) {
+		const uint32_t le = lle[at];
+		if (!tgray[le] || la[le] != S)
+			continue; // a link of the forest is handled once, from the side that met it first
+		const uint32_t w = ladj[at], t = loff[w] + find_link_slot(loff, lle, w, le) - 1;
+		const uint32_t da = dist[at], dt = dist[t];
 		const uint32_t pa = abase + (L - 1 - da), pt = abase + (L - 1 - dt); // tour positions of the two arcs
-		const bool down = da > dt;					      // a comes first: S is the parent of w
+		const bool down = da > dt;					      // `at` comes first: S is the parent of w
 		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
-		t0rec[child] = make_uint4(parent, le, p_in, p_out); // ONE scattered 16-byte store: {parent, its link, tour in, tour out}
-		// (val was cleared by the caller: most sides have no non-tree link, and a scattered 8-byte store costs a sector)
-		const unsigned long long h = hside[child];
+		t0seg[child >> 1] = make_uint4(parent, le | ((child & 1u) ? T0_RBIT : 0u), p_in, p_out); // ONE scattered 16-byte store
+		// (val was cleared by the caller: most segments have no non-tree link, and a scattered 8-byte store costs a sector)
+		const unsigned long long h = hside[child] ^ hside[child ^ 1u];
 		if (h)
 			val[p_in] = h;
-	};
-	if (!(S & 1u)) // the black edge belongs to the l side
-		edge(base, S ^ 1u, slot_base(loff, S ^ 1u), NIL);
-	for (uint32_t k = 1; k <= n; k++) {
-		const uint32_t le = lle[lo + k - 1];
-		if (!tgray[le] || la[le] != S)
-			continue; // a link of the forest belongs to the side that met it first
-		const uint2 t = slot_twin(loff, ladj, lle, S, k);
-		edge(base + k, t.x, slot_base(loff, t.x) + t.y, le);
 	}
 }
 // pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
 static constexpr uint32_t PB_BRIDGE = 0x80000000u;
-__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0rec, const unsigned long long *__restrict__ px,
-			  uint32_t *__restrict__ pbr, uint32_t *__restrict__ ecc,
+__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const unsigned long long *__restrict__ px,
+			  const unsigned long long *__restrict__ hside, const uint32_t *__restrict__ ft,
+			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
+			  const uint32_t *__restrict__ voff, uint32_t *__restrict__ pbr, uint32_t *__restrict__ ecc,
 			  uint32_t *__restrict__ csamp, uint8_t *__restrict__ multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,13 +540,28 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0rec, const un
 	ecc[S] = S; // every side starts as its own 2-edge-connected class
 	csamp[S] = 0;
 	multi[S] = 0; // ... and alone in it until a non-bridge edge says otherwise
-	const uint4 r = t0rec[S];
-	if (r.x == NIL) {
-		pbr[S] = NIL;
+	const uint4 r = t0seg[S >> 1];
+	const uint32_t entered = (S & ~1u) | (r.y >> 31);
+	if (S == entered) {
+		pbr[S] = r.x == NIL ? NIL : (r.x | (px[r.z] == px[r.w + 1] ? PB_BRIDGE : 0u));
 		return;
 	}
-	const uint32_t a = r.z, b = r.w + 1;
-	pbr[S] = r.x | (px[a] == px[b] ? PB_BRIDGE : 0u);
+	// the black edge entered -> S: what leaves subtree(S) = S's own non-tree links and those of the subtrees hanging off S
+	unsigned long long x = hside[S];
+	const uint32_t a1 = ft[S];
+	if (a1 != NIL) {
+		const uint32_t c = ckey[S >> 1], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
+		const uint32_t a3 = ft[entered];
+		uint32_t end; // position behind the last of them
+		if (r.x == NIL) // root segment: the start side's arcs come first, S's are the rest of the tour
+			end = abase + L;
+		else if (a3 != NIL && lle[a3] != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
+			end = abase + (L - 1 - dist[a3]);
+		else
+			end = r.w;
+		x ^= px[abase + (L - 1 - dist[a1])] ^ px[end];
+	}
+	pbr[S] = entered | (x == 0 ? PB_BRIDGE : 0u);
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
@@ -592,7 +628,7 @@ __global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc, uint32_t *__restrict__
 
 // ------------------------------------------------------------------ 5. class entries
 static constexpr uint32_t CS_VISITED = 0x80000000u; // (class ids are side ids < 2^28)
-__global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const uint4 *__restrict__ t0rec,
+__global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const uint4 *__restrict__ t0seg,
 			  const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ecc,
@@ -617,7 +653,7 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 			const uint32_t p = p0 & ~PB_BRIDGE;
 			rec.x = p;
 			if (p != (S ^ 1)) { // (black edge: slot 0, scanned first) gray bridge: its slot in the parent's list (ascending local edge idx)
-				uint32_t le = t0rec[S].y, lo = loff[p], hi = loff[p + 1];
+				uint32_t le = t0seg[S >> 1].y & ~T0_RBIT, lo = loff[p], hi = loff[p + 1];
 				while (lo < hi) {
 					uint32_t mid = (lo + hi) >> 1;
 					if (lle[mid] < le)
@@ -1030,7 +1066,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.xval, (NA + 2) * 8);
 	take((void **)&tw.xps, (NA + 2) * 8);
 	take((void **)&tw.evt, NA * 8);
-	take((void **)&tw.t0rec, nS * 16);
+	take((void **)&tw.t0seg, (V + 2) * 16);
 	for (uint32_t **p : {&tw.pbr,
 			     &tw.ecc, &tw.entry_ps, &tw.entry_list,
 			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
@@ -1074,20 +1110,23 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
 	tm.begin("tree_root_forest");
-	const uint32_t NA = 2 * (2 * V - C); // arcs of the spanning forest = positions of the tours
-	const size_t n_slots = (size_t)nS + 2 * (size_t)E; // >= the scan slots of all sides (loff[nS] + nS)
+	const uint32_t NA = 2 * (V - C); // arcs of the spanning forest of the segments = positions of the tours
+	const size_t n_slots = 2 * (size_t)E; // list elements = adjacency slots (loff[nS] = 2E: every link has one at either end)
 	RankBufs rb{tw.rk_pk, tw.rk_heads, tw.rk_nx, tw.rk_wa, tw.rk_wb, tw.rk_tA, tw.rk_tB, tw.rk_tC};
 	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
-	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, tw.xps); // (xps: free until the xor scan)
+	unsigned long long *hside = reinterpret_cast<unsigned long long *>(tw.evt); // [nS] (evt: free until the second ranking)
+	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
+	if (n_slots >= PK_END || 2 * (size_t)nS >= PK_END) // (the first ranking runs over the 2E slots, the second over 2 nS events)
+		throw HipError("graph too large for the packed list ranking: 2 * links and 4 * segments must stay below 2^29");
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, hside, ft);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
-	if (n_slots >= PK_END) // (every link has two local slots, a self loop one on either side of its segment: loff[nS] = 2E)
-		throw HipError("graph too large for the packed list ranking: 2 * (segments + links) must stay below 2^29");
-	list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
+	if (n_slots)
+		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
 	unsigned long long *val = tw.xval, *px = tw.xps; // [NA+1] each
 	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 8, s));
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, tw.xps, tw.t0rec, val, C,
-	       start_key, NA, pw.err + 2);
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, hside, rb.heads,
+	       tw.t0seg, val, C, start_key, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
@@ -1095,7 +1134,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	scan_exclusive_xor_u64(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
-	LAUNCH(k_bridges, nS, s, nS, tw.t0rec, px, tw.pbr, tw.ecc, csamp, multi);
+	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.lle, cs.ckey, cs.voff, tw.pbr, tw.ecc, csamp, multi);
 	LAUNCH(k_ecc_tree, nS, s, nS, tw.pbr, tw.ecc, multi);
 	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
 	tm.end(8 + 44);
@@ -1103,7 +1142,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0rec, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dps,
+	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dps,
 	       tw.dvis, tw.entry_flag, cstate);
 	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
