@@ -256,7 +256,23 @@ __device__ __forceinline__ uint32_t rank_lane_start(uint32_t id, const RankLevel
 	}
 	return L0 ? heads[id - A.m] : A.hbase + (id - A.m);
 }
-template <bool L0, bool TWO>
+// EVT3 (level 0 only, with TWO): the elements are the events of the pre-order ranking, three per segment, and an
+// element's two weights follow from its index: 3g = enter both sides of segment g (+2 entered, depth +2), 3g + 1 =
+// leave the far side (depth -1, or -2 when bit 29 says the entered side is left with it), 3g + 2 = leave the
+// entered side (depth -1).
+template <bool EVT3>
+__device__ __forceinline__ void rank_l0_weights(uint32_t x, uint32_t p, uint32_t &wa, uint32_t &wb)
+{
+	if (EVT3) {
+		const uint32_t t = x % 3u;
+		wa = t == 0 ? 2u : 0u;
+		wb = t == 0 ? 2u : ((t == 1 && (p & (1u << 29))) ? 0u - 2u : 0u - 1u);
+	} else {
+		wa = (p >> 29) & 1u;
+		wb = wa ? 1u : 0xFFFFFFFFu;
+	}
+}
+template <bool L0, bool TWO, bool EVT3 = false>
 __global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restrict__ nx_in, const uint32_t *__restrict__ a_in,
 			  const uint32_t *__restrict__ b_in, const uint32_t *__restrict__ heads, uint32_t *__restrict__ nx_out,
 			  uint32_t *__restrict__ a_out, uint32_t *__restrict__ b_out)
@@ -271,10 +287,11 @@ __global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restric
 		do {
 			p = nx_in[x];
 			if (L0) {
-				const uint32_t w = (p >> 29) & 1u;
-				sa += w;
+				uint32_t wa, wb;
+				rank_l0_weights<EVT3>(x, p, wa, wb);
+				sa += wa;
 				if (TWO)
-					sb += w ? 1u : 0xFFFFFFFFu;
+					sb += wb;
 			} else {
 				sa += a_in[x];
 				if (TWO)
@@ -294,7 +311,7 @@ __global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restric
 }
 // the way back: lane `id` knows the suffix sums at its splitter (ra / rb of the level above) and hands every element of
 // its segment its own.  Level 0 writes the caller's arrays, the levels above overwrite their weights in place.
-template <bool L0, bool TWO>
+template <bool L0, bool TWO, bool EVT3 = false>
 __global__ void k_rank_down(RankLevelArgs A, unsigned b, const uint32_t *__restrict__ nx_in, uint32_t *a_io, uint32_t *b_io,
 			    const uint32_t *__restrict__ heads, const uint32_t *__restrict__ ra, const uint32_t *__restrict__ rb,
 			    uint32_t *__restrict__ out1, uint2 *__restrict__ out12)
@@ -309,14 +326,15 @@ __global__ void k_rank_down(RankLevelArgs A, unsigned b, const uint32_t *__restr
 	do {
 		p = nx_in[x];
 		if (L0) {
-			const uint32_t w = (p >> 29) & 1u;
+			uint32_t wa, wb;
+			rank_l0_weights<EVT3>(x, p, wa, wb);
 			if (TWO) { // both sums in one 8-byte store
 				out12[x] = make_uint2(sa, sb);
-				sb -= w ? 1u : 0xFFFFFFFFu;
+				sb -= wb;
 			} else {
 				out1[x] = sa;
 			}
-			sa -= w;
+			sa -= wa;
 		} else {
 			const uint32_t wa = a_io[x];
 			a_io[x] = sa;
@@ -401,7 +419,7 @@ static size_t rank_pool_words(size_t n, size_t nh) { return n / 2 + 4 * nh + 64;
 
 // suffix sums (inclusive) along the lists packed in rb.pk: out1 of the 0/1 weights or, when TWO, out12 = {that sum,
 // the sum of the +-1 weights derived from them}
-template <bool TWO>
+template <bool TWO, bool EVT3 = false>
 static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *out12, uint32_t nh, RankBufs &rb, hipStream_t s)
 {
 	if (n >= PK_END)
@@ -437,7 +455,7 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 	for (int L = 0; L < levels; L++) {
 		const RankLevelArgs &A = lv[L];
 		if (L == 0)
-			LAUNCH((k_rank_up<true, TWO>), A.M, s, A, b, nxp[0], nullptr, nullptr, rb.heads, nxp[1], wap[1], wbp[1]);
+			LAUNCH((k_rank_up<true, TWO, EVT3>), A.M, s, A, b, nxp[0], nullptr, nullptr, rb.heads, nxp[1], wap[1], wbp[1]);
 		else
 			LAUNCH((k_rank_up<false, TWO>), A.M, s, A, b, nxp[L], wap[L], wbp[L], nullptr, nxp[L + 1], wap[L + 1], wbp[L + 1]);
 	}
@@ -461,7 +479,7 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 	for (int L = levels - 1; L >= 0; L--) {
 		const RankLevelArgs &A = lv[L];
 		if (L == 0)
-			LAUNCH((k_rank_down<true, TWO>), A.M, s, A, b, nxp[0], nullptr, nullptr, rb.heads, wap[1], wbp[1], out1, out12);
+			LAUNCH((k_rank_down<true, TWO, EVT3>), A.M, s, A, b, nxp[0], nullptr, nullptr, rb.heads, wap[1], wbp[1], out1, out12);
 		else
 			LAUNCH((k_rank_down<false, TWO>), A.M, s, A, b, nxp[L], wap[L], wbp[L], nullptr, wap[L + 1], wbp[L + 1], nullptr,
 			       nullptr);
@@ -799,19 +817,22 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 // table: the first child of S is the first slot of S whose far side names (S, that slot) as its discovery; the next
 // sibling of S is the next such slot of its parent behind S's own.  A parent's list is walked once over all its
 // children, so the work stays linear in the degrees.
-// events: 2S = enter S, 2S+1 = leave S.  "enter S" heads the list of its component iff S is the DFS start of a
-// processed component (sides of other components keep their two-event lists, which nobody reads)
-__global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps,
-			 const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey,
-			 const uint32_t *__restrict__ cproc, uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b)
+// The far side o of a segment always is the first child of the side e it is entered through (black edge first), so a
+// segment needs three events, not four: 3g = enter e and o, 3g + 1 = leave o, 3g + 2 = leave e -- and when e has no
+// other child (the common case) the two leaves are one event (bit 29 of its word) and 3g + 2 stays out of the list.
+// "enter" heads the list of its component iff e is the DFS start of a processed component (segments of other
+// components get inert words).  merged[g] remembers which form the segment took.
+__device__ __forceinline__ uint32_t leave_event(uint32_t p, bool p_is_far) { return 3 * (p >> 1) + (p_is_far ? 1u : 2u); }
+__global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps, const uint32_t *__restrict__ loff,
+			 const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc,
+			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b, uint8_t *__restrict__ merged)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	const uint2 me = dps[S];
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x; // (nS is even and the workgroup size too: S and S ^ 1 are lanes of one wave)
+	const bool live = S < nS;
+	const uint2 me = live ? dps[S] : make_uint2(NIL, 0u);
 	const uint32_t p = me.x;
 	uint32_t c = NIL, ns = NIL;
-	{
+	if (live) {
 		const uint32_t lo = loff[S], n = loff[S + 1] - lo;
 		for (uint32_t k = 0; k <= n; k++) {
 			const uint32_t o = k == 0 ? (S ^ 1u) : ladj[lo + k - 1];
@@ -822,7 +843,7 @@ __global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps,
 			}
 		}
 	}
-	if (p != NIL) {
+	if (live && p != NIL) {
 		const uint32_t lo = loff[p], n = loff[p + 1] - lo;
 		for (uint32_t k = me.y + 1; k <= n; k++) {
 			const uint32_t o = ladj[lo + k - 1];
@@ -833,20 +854,48 @@ __global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps,
 			}
 		}
 	}
-	uint32_t enter = rank_pack(c != NIL ? 2 * c : 2 * S + 1, 1u, b); // enter: counts 1, depth +1
-	if (p == NIL) {
-		const uint32_t comp = ckey[S >> 1];
+	const bool far = live && p == (S ^ 1u); // S is the far side o of its segment (its parent is the entered side)
+	// what follows "leave the entered side": its next sibling, else the leave of its parent, else nothing (DFS start)
+	uint32_t after_e = NIL;
+	if (live && !far) {
+		if (ns != NIL)
+			after_e = 3 * (ns >> 1);
+		else if (p != NIL)
+			after_e = leave_event(p, dps[p].x == (p ^ 1u));
+	}
+	// the far side's lane writes the segment's three words; it gets the entered side's part from the neighbouring lane
+	const uint32_t e_after = __shfl_xor(after_e, 1);
+	const uint32_t e_par = __shfl_xor(p, 1);
+	const bool other_far = __shfl_xor(far ? 1 : 0, 1) != 0;
+	if (live && !far && !other_far && !(S & 1u)) { // a segment outside the decomposed components: three inert words
+		pk[3 * (S >> 1)] = pk[3 * (S >> 1) + 1] = pk[3 * (S >> 1) + 2] = PK_END | PK_STOP;
+		merged[S >> 1] = 1;
+	}
+	if (!far)
+		return;
+	const uint32_t g = S >> 1, A = 3 * g;
+	uint32_t enter = rank_pack(c != NIL ? 3 * (c >> 1) : A + 1, 0u, b);
+	if (e_par == NIL) {
+		const uint32_t comp = ckey[g];
 		if (cproc[comp]) {
 			enter |= PK_HEAD;
-			heads[comp] = 2 * S;
+			heads[comp] = A;
 		}
 	}
-	pk[2 * S] = enter;
-	pk[2 * S + 1] = rank_pack(ns != NIL ? 2 * ns : (p != NIL ? 2 * p + 1 : NIL), 0u, b); // leave: counts 0, depth -1
+	pk[A] = enter;
+	if (ns != NIL) { // the entered side has more children: leave o -> the first of them; leave e on its own
+		pk[A + 1] = rank_pack(3 * (ns >> 1), 0u, b);
+		pk[A + 2] = rank_pack(e_after, 0u, b);
+		merged[g] = 0;
+	} else {
+		pk[A + 1] = rank_pack(e_after, 1u, b); // both leaves in one
+		pk[A + 2] = PK_END | PK_STOP;
+		merged[g] = 1;
+	}
 }
 
 // ------------------------------------------------------------------ 8. tree arrays + back edges
-__global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd,
+__global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uint8_t *__restrict__ merged,
 			    const uint2 *__restrict__ dps, const uint32_t *__restrict__ ckey,
 			    const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
 			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
@@ -877,16 +926,31 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd,
 	if (!cproc[c])
 		return;
 	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u;
-	const uint32_t tb = 2 * voff[c] + c;
-	// cd[event] = {enters from this event to the end of the list, net depth change from here to the end}
-	const uint2 ent = cd[2 * S];
-	const uint32_t pre = Nh - ent.x, size = ent.x - cd[2 * S + 1].x;
-	const uint32_t depth = 0u - ent.y;
-	const uint32_t t = tb + hd + pre;
-	t_gid[t] = gid_s[S >> 1];
+	const uint32_t tb = 2 * voff[c] + c, g = S >> 1;
+	// cd[event] = {sides entered from this event to the end of the list, net depth change from here to the end}
+	const uint2 ent = cd[3 * g], lv_o = cd[3 * g + 1];
 	const uint32_t p = dps[S].x;
-	t_flags[t] = (uint8_t)((S & 1) | ((p == (S ^ 1)) ? TF_BLACK : 0));
-	t_par[t] = p == NIL ? (hd ? 0u : NIL) : hd + (Nh - cd[2 * p].x);
+	const bool far = p == (S ^ 1u);
+	const uint32_t pre_e = Nh - ent.x, depth_e = 0u - ent.y;
+	uint32_t pre, size, depth, par;
+	if (far) {
+		pre = pre_e + 1;
+		size = ent.x - 1 - lv_o.x;
+		depth = depth_e + 1;
+		par = hd + pre_e;
+	} else {
+		pre = pre_e;
+		size = ent.x - (merged[g] ? lv_o.x : cd[3 * g + 2].x);
+		depth = depth_e;
+		if (p == NIL)
+			par = hd ? 0u : NIL;
+		else
+			par = hd + (Nh - cd[3 * (p >> 1)].x) + (dps[p].x == (p ^ 1u) ? 1u : 0u);
+	}
+	const uint32_t t = tb + hd + pre;
+	t_gid[t] = gid_s[g];
+	t_flags[t] = (uint8_t)((S & 1) | (far ? TF_BLACK : 0));
+	t_par[t] = par;
 	t_size[t] = size;
 	t_depth[t] = depth + hd;
 	side_tidx[S] = t;
@@ -1116,8 +1180,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
 	unsigned long long *hside = reinterpret_cast<unsigned long long *>(tw.evt); // [nS] (evt: free until the second ranking)
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
-	if (n_slots >= PK_END || 2 * (size_t)nS >= PK_END) // (the first ranking runs over the 2E slots, the second over 2 nS events)
-		throw HipError("graph too large for the packed list ranking: 2 * links and 4 * segments must stay below 2^29");
+	if (n_slots >= PK_END || 3 * (size_t)V >= PK_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
+		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^29");
 	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, hside, ft);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
 	if (n_slots)
@@ -1172,16 +1236,18 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	tm.begin("tree_preorder");
 	(void)max_side_links;
 	// one list per processed component, one two-event list per side of an unprocessed one
-	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(2 * (size_t)nS);
+	const uint32_t n_events = 3 * V; // three per segment
+	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(n_events);
+	uint8_t *merged = tw.dvis; // [V] (the visited bytes of the class walk are dead)
 	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
-	LAUNCH(k_events, nS, s, nS, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE);
-	list_rank_splitters<true>(2 * nS, bitsE, nullptr, tw.evt, C, rb, s);
+	LAUNCH(k_events, nS, s, nS, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged);
+	list_rank_splitters<true, true>(n_events, bitsE, nullptr, tw.evt, C, rb, s);
 	(void)event_lists;
 	tm.end(40);
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
-	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
+	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
 	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree);
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
