@@ -550,26 +550,29 @@ __global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx,
 // occurred before, so U/D are known per entry; a crossing pair sends the component to the
 // sequential kernel instead.
 // one kernel: the laminarity check of the (prev, i) intervals and the +-1 walk of the stack machine.
+// Entry i takes two steps: U (-1 if its class was seen before) and then D (+1 if it opens a flubble).  The level of a
+// new flubble is the walk's value after its D less the running minimum, and as D never goes down the minimum is
+// always attained right after a U: the walk is kept at those points only, one word per entry, step(i) = D(i-1) + U(i).
 // The walks of all components sit back to back in one array.  So that ONE unsegmented running minimum serves every
 // component, the first step of component c also drops by B_c = 2 * (entries of the component before it) + 2: further
-// than that component's walk can have climbed or fallen, so nothing in front of c ever is the minimum again.
+// than that component's walk can have climbed or fallen, so nothing in front of c ever is the minimum again (and the
+// zero of component c is simply the walk's value at its first entry, whose own U is 0).
 __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
 			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint32_t *__restrict__ comp_bad,
-			       const uint32_t *__restrict__ ns, uint32_t *__restrict__ walk)
+			       const uint8_t *__restrict__ dflag, uint32_t *__restrict__ walk)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S)
 		return;
 	const uint32_t p = prev[i];
-	uint32_t d = (i + 1 < ns[i]) ? 1u : 0u;
-	uint32_t first = p != NIL ? 0xFFFFFFFFu : 0u; // -1
+	uint32_t step = p != NIL ? 0xFFFFFFFFu : 0u; // U: -1
 	if (i > 0) {
+		step += dflag[i - 1]; // D of the entry before
 		const uint32_t cp = s_comp[i - 1];
 		if (cp != s_comp[i])
-			first -= 2 * (i - soff[cp]) + 2;
+			step -= 2 * (i - soff[cp]) + 2;
 	}
-	walk[2 * i] = first;
-	walk[2 * i + 1] = d;
+	walk[i] = step;
 	if (p == NIL || p + 1 >= i)
 		return;
 	uint32_t lowest;
@@ -643,17 +646,13 @@ __global__ void k_levels(uint32_t S, const uint8_t *__restrict__ dflag, const ui
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= S || !dflag[i])
 		return;
-	const uint32_t c = s_comp[i], i0 = soff[c], k0 = 2 * i0, k = 2 * i + 1;
-	// zero of this component's walk = the value in front of its first step, less the drop B_c of that step
-	uint32_t zero = 0x80000000u;
-	if (k0) {
-		const uint32_t cp = s_comp[i0 - 1];
-		zero = wb[k0 - 1] - (2 * (i0 - soff[cp]) + 2);
-	}
-	// running minimum up to k (negmax = exclusive running maximum of ~wb): everything in front of k0 lies above `zero`
-	const uint32_t cur = wb[k], run = min(cur, ~negmax[k]);
+	const uint32_t c = s_comp[i], i0 = soff[c];
+	// zero of this component's walk = its value at the component's first entry (after the drop B_c, before any U or D)
+	const uint32_t zero = wb[i0];
+	// running minimum up to i (negmax = exclusive running maximum of ~wb): everything in front of i0 lies above `zero`
+	const uint32_t cur = wb[i], run = min(cur, ~negmax[i]);
 	uint32_t j = erank[i];
-	lev[j] = cur - min(zero, run); // depth of the new flubble (>= 1)
+	lev[j] = cur + 1 - min(zero, run); // depth of the new flubble (>= 1): the walk after this entry's own D
 	e_i[j] = i;
 }
 // PVST parent of every flubble = nearest earlier flubble of its component with a smaller level
@@ -820,9 +819,9 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	for (uint32_t **p : {&pw.s_vtx, &pw.s_cls, &pw.s_comp, &pw.ns, &pw.prev, &pw.s_key, &pw.s_key2, &pw.s_val, &pw.s_val2,
 			     &pw.erank, &pw.lev, &pw.e_i})
 		take((void **)p, (S + 2) * 4);
-	take((void **)&pw.walk, (2 * S + 4) * 4);
-	take((void **)&pw.walk_ps, (2 * S + 4) * 4);
-	take((void **)&pw.wrun, (2 * S + 4) * 4);
+	take((void **)&pw.walk, (S + 4) * 4);
+	take((void **)&pw.walk_ps, (S + 4) * 4);
+	take((void **)&pw.wrun, (S + 4) * 4);
 	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
 	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
 	take((void **)&pw.doff, (Cmax + 2) * 4);
@@ -1066,12 +1065,12 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 			sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	}
 	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
-	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.soff, pw.comp_bad, pw.ns, pw.walk);
-	scan(pw.walk, pw.walk_ps, (size_t)2 * S);
+	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.soff, pw.comp_bad, dflag, pw.walk);
+	scan(pw.walk, pw.walk_ps, (size_t)S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
-	LAUNCH(k_walk_bias, (size_t)2 * S, s, 2 * S, pw.walk, pw.walk_ps, wb, wneg);
-	scan_exclusive_max_u32(wneg, wrun, (size_t)2 * S, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	LAUNCH(k_walk_bias, (size_t)S, s, S, pw.walk, pw.walk_ps, wb, wneg);
+	scan_exclusive_max_u32(wneg, wrun, (size_t)S, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,

@@ -43,7 +43,7 @@ struct ParWs {
 	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev; // [V+1]
 	uint32_t *soff;				     // [C+1] first stack entry of a component (host-built table, set by the caller)
 	uint32_t *s_key, *s_key2, *s_val, *s_val2;
-	uint32_t *walk, *walk_ps, *wrun; // [2V+2] steps of the stack machine, their prefix sums, running minimum (complemented)
+	uint32_t *walk, *walk_ps, *wrun; // [V+2] steps of the stack machine (one per entry), their prefix sums, running minimum (complemented)
 	uint32_t *erank, *lev, *e_i;	 // [V+1]
 	uint32_t *comp_bad;		 // [C+1] components that must be redone sequentially
 	// dense PVST output (all processed components back to back): what goes over PCIe
