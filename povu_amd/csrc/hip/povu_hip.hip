@@ -108,10 +108,10 @@ void check_graph_size(uint32_t n_vtx, uint32_t n_links)
 {
 	if (n_vtx == 0)
 		throw HipError("graph has no vertices");
-	// 32-bit index spaces: 4 arcs / events per segment must stay below 2^29 (packed list-ranking
-	// words), links below 2^31.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
-	if (n_vtx >= (1u << 27) || n_links > 0x7FFFFFF0u)
-		throw HipError("graph too large for this build: at most 134 217 727 segments and 2 147 483 632 links");
+	// 32-bit index spaces: the packed list-ranking words hold 29-bit successors -- 3 events per segment and 2 adjacency
+	// slots per link must stay below 2^29.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
+	if (3ull * n_vtx >= (1u << 29) || 2ull * n_links >= (1u << 29))
+		throw HipError("graph too large for this build: at most 178 956 969 segments and 268 435 455 links");
 }
 
 extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links,
