@@ -700,8 +700,9 @@ __global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const ui
 // keep that chain short.  k_class_adj filters every side's scan list [black edge, links by local edge idx]
 // down to the neighbours of its own class (entry = {side, scan slot}) and packs {begin, count, first entry}
 // per side.  Going down then costs ONE load level (the candidate's visited byte and its packed record, which
-// already carries ITS first candidate), coming back one 16-byte load (the child keeps its parent's scan
-// state: {parent, begin, count, next}) plus one entry load when the parent has candidates left.
+// already carries ITS first candidate), skipping a visited candidate costs one (the candidate behind it is loaded with
+// it), coming back one (the child keeps its parent's scan state {parent, begin, count, next} and the parent's next
+// candidate).
 __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			    const uint32_t *__restrict__ ecc, const uint32_t *__restrict__ ckey,
 			    const uint32_t *__restrict__ cproc, uint2 *__restrict__ cadj, uint4 *__restrict__ rb)
@@ -746,12 +747,15 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 				const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
 				const uint32_t slot = k++;
 				if (cstate[o] == cls) { // same class, not visited yet
+					// (loads of the next step before the stores of this one: vmcnt counts both in issue order,
+					// and a wait for a load behind a store waits for the store too)
+					const uint32_t nlo = loff[o], nhi = loff[o + 1];
 					cstate[o] = cls | CS_VISITED;
 					dps[o] = make_uint2(u, slot);
 					u = o;
 					k = 0;
-					lo = loff[u];
-					n = loff[u + 1] - lo;
+					lo = nlo;
+					n = nhi - nlo;
 					adv = true;
 					break;
 				}
@@ -768,9 +772,15 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 		}
 	}
 }
+// The loop is software-pipelined by hand.  vmcnt counts loads AND stores of a wave in issue order, so "wait for this
+// load" also waits for every store issued before it: a walk that stores the child's records and then loads the next
+// candidate pays a store round trip per step.  Here the loads for the NEXT step are issued first, the stores of this
+// step behind them, and the loaded registers are pinned (empty asm) at the end of each branch so that the wait the
+// compiler inserts there lets exactly the younger stores stay in flight.
+#define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
 			    const uint4 *__restrict__ rb, uint2 *__restrict__ dps,
-			    uint8_t *__restrict__ dvis, uint4 *__restrict__ ret)
+			    uint8_t *dvis, uint4 *__restrict__ ret, uint2 *__restrict__ retc)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_entry)
@@ -779,36 +789,69 @@ __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry
 	uint32_t u = s, k = 0;
 	uint4 r = rb[u];			 // {begin, count, candidate 0}
 	uint2 e = make_uint2(r.z, r.w);		 // candidate k of u (valid while k < count)
+	// loaded for candidate e: its packed record (speculative), its visited byte, the candidate behind it (one past a
+	// list is the next side's first entry or padding)
+	uint4 rn = make_uint4(0, 0, 0, 0);
+	uint32_t seen = 1;
+	uint2 e2 = make_uint2(NIL, 0u);
+	if (r.y) {
+		rn = rb[e.x];
+		seen = dvis[e.x];
+		e2 = cadj[r.x + 1];
+	}
 	for (;;) {
-		bool down = false;
-		while (k < r.y) {
-			const uint4 rn = rb[e.x]; // speculative: issued together with the visited byte
-			if (!dvis[e.x]) {
-				dvis[e.x] = 1;
-				dps[e.x] = make_uint2(u, e.y);
-				ret[e.x] = make_uint4(u, r.x, r.y, k + 1);
-				u = e.x;
-				r = rn;
-				k = 0;
-				e = make_uint2(r.z, r.w);
-				down = true;
-				break;
+		// a run of descents is a loop of its own: one way in, one way round, so the compiler's wait in front of the next
+		// round counts exactly the four stores behind the loads
+		while (k < r.y && !seen && e.x != u) { // (e.x == u: a link from a side to itself, its visited byte was read before it was set)
+			const uint32_t child = e.x;
+			// next step first: candidate 0 of the child ...
+			const uint2 ne = make_uint2(rn.z, rn.w);
+			uint4 nrn = make_uint4(0, 0, 0, 0);
+			uint32_t nseen = 1;
+			uint2 ne2 = make_uint2(NIL, 0u);
+			if (rn.y) {
+				nrn = rb[ne.x];
+				nseen = dvis[ne.x];
+				ne2 = cadj[rn.x + 1];
 			}
-			k++;
-			if (k < r.y)
-				e = cadj[r.x + k];
+			// ... then the child's records
+			dvis[child] = 1;
+			dps[child] = make_uint2(u, e.y);
+			ret[child] = make_uint4(u, r.x, r.y, k + 1);
+			retc[child] = e2;
+			u = child;
+			r = rn;
+			k = 0;
+			e = ne;
+			rn = nrn;
+			seen = nseen;
+			e2 = ne2;
+			PIN3(rn.x, seen, e2.x);
 		}
-		if (down)
+		if (k < r.y) { // a visited candidate: on to the one behind it
+			k++;
+			e = e2;
+			if (k < r.y) {
+				rn = rb[e.x];
+				seen = dvis[e.x];
+				e2 = cadj[r.x + k + 1];
+			}
 			continue;
+		}
 		if (u == s)
 			break;
-		const uint4 back = ret[u];
+		const uint4 back = ret[u]; // (two loads, one level)
+		const uint2 bc = retc[u];
 		u = back.x;
 		r.x = back.y;
 		r.y = back.z;
 		k = back.w;
-		if (k < r.y)
-			e = cadj[r.x + k];
+		e = bc;
+		if (k < r.y) {
+			rn = rb[e.x];
+			seen = dvis[e.x];
+			e2 = cadj[r.x + k + 1];
+		}
 	}
 }
 
@@ -1141,6 +1184,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
 	take((void **)&tw.crb, nS * 16);
 	take((void **)&tw.cret, nS * 16);
+	take((void **)&tw.cretc, nS * 8);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	take((void **)&tw.rk_pk, NSL * 4);
 	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
@@ -1219,7 +1263,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	if (n_entry && big_classes) {
 		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.ecc, cs.ckey, tw.cproc, tw.cadj, tw.crb);
 		KLAUNCH(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
-				   tw.dps, tw.dvis, tw.cret);
+				   tw.dps, tw.dvis, tw.cret, tw.cretc);
 	} else if (n_entry) {
 		// Lanes in flight = a window of sides whose scattered stores meet again in L2: ~3000 x 64 lanes measured best
 		// from a few hundred thousand to twenty million small classes (wider windows thrash the caches, narrower

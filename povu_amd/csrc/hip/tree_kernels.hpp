@@ -21,6 +21,7 @@ struct TreeWs {
 	uint2 *cadj;					  // [2V + 2E] class-filtered scan lists {side, slot}
 	uint4 *crb;					  // [2V] {begin, count, first entry} of a side's filtered list
 	uint4 *cret;					  // [2V] scan state of the DFS parent at the moment it descended
+	uint2 *cretc;					  // [2V] ... and the parent's next candidate
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
 	uint32_t *entry_ps, *entry_list;		  // [2V+1]
