@@ -549,19 +549,26 @@ static constexpr uint32_t PB_BRIDGE = 0x80000000u;
 __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const unsigned long long *__restrict__ px,
 			  const unsigned long long *__restrict__ hside, const uint32_t *__restrict__ ft,
 			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
-			  const uint32_t *__restrict__ voff, uint32_t *__restrict__ pbr, uint32_t *__restrict__ ecc,
-			  uint32_t *__restrict__ csamp, uint8_t *__restrict__ multi)
+			  const uint32_t *__restrict__ voff, uint32_t *__restrict__ pbr, uint8_t *multi)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	ecc[S] = S; // every side starts as its own 2-edge-connected class
-	csamp[S] = 0;
-	multi[S] = 0; // ... and alone in it until a non-bridge edge says otherwise
+	// multi[S] = 1: side S shares its 2-edge-connected class with another side, i.e. some tree edge at S is no bridge
+	// (cleared by the caller).  Most sides of a pangenome graph sit on bridges only and are classes of their own; those
+	// need no walk at all.
 	const uint4 r = t0seg[S >> 1];
 	const uint32_t entered = (S & ~1u) | (r.y >> 31);
 	if (S == entered) {
-		pbr[S] = r.x == NIL ? NIL : (r.x | (px[r.z] == px[r.w + 1] ? PB_BRIDGE : 0u));
+		if (r.x == NIL) {
+			pbr[S] = NIL;
+		} else if (px[r.z] == px[r.w + 1]) {
+			pbr[S] = r.x | PB_BRIDGE;
+		} else {
+			pbr[S] = r.x;
+			multi[S] = 1;
+			multi[r.x] = 1;
+		}
 		return;
 	}
 	// the black edge entered -> S: what leaves subtree(S) = S's own non-tree links and those of the subtrees hanging off S
@@ -579,77 +586,31 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const un
 			end = r.w;
 		x ^= px[abase + (L - 1 - dist[a1])] ^ px[end];
 	}
-	pbr[S] = entered | (x == 0 ? PB_BRIDGE : 0u);
+	if (x == 0) {
+		pbr[S] = entered | PB_BRIDGE;
+	} else {
+		pbr[S] = entered;
+		multi[S] = 1;
+		multi[entered] = 1;
+	}
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
-__device__ __forceinline__ uint32_t uf_find2(uint32_t *parent, uint32_t x)
-{
-	uint32_t p = parent[x];
-	while (p != x) {
-		uint32_t gp = parent[p];
-		if (gp != p)
-			parent[x] = gp;
-		x = p;
-		p = gp;
-	}
-	return x;
-}
-__device__ __forceinline__ void uf_union2(uint32_t *parent, uint32_t a, uint32_t b)
-{
-	uint32_t ra = uf_find2(parent, a), rb = uf_find2(parent, b);
-	while (ra != rb) {
-		uint32_t hi = max(ra, rb), lo = min(ra, rb);
-		uint32_t old = atomicCAS(&parent[hi], hi, lo);
-		if (old == hi)
-			break;
-		ra = uf_find2(parent, old);
-		rb = uf_find2(parent, lo);
-	}
-}
 // The 2-edge-connected classes are the pieces the rooted forest falls into when its bridges are cut (every bridge of H is
-// a tree edge, and a class stays connected inside any spanning tree): uniting child and parent over every non-bridge
-// tree edge is enough, the non-tree links add nothing.
-// (multi[S] = 1: side S shares its class with another side.  Most sides of a pangenome graph sit on bridges only and
-// are classes of their own; those need no walk at all.)
-__global__ void k_ecc_tree(uint32_t nS, const uint32_t *__restrict__ pbr, uint32_t *ecc, uint8_t *__restrict__ multi)
-{
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	const uint32_t p = pbr[S];
-	if (p & PB_BRIDGE) // (NIL has the bit set too)
-		return;
-	uf_union2(ecc, S, p);
-	multi[S] = 1;
-	multi[p] = 1;
-}
-// Also samples the class sizes: every 64th side counts itself at its class root, and the largest count
-// seen (>= CLASS_SAMPLE_MIN) lands in *big -- a class of a few thousand sides or more is walked by the
-// class DFS with the short dependent chain (k_class_adj), at the price of a filtering pass.
-static constexpr uint32_t CLASS_SAMPLE_MIN = 16; // ~1000 sides
-__global__ void k_ecc_flatten(uint32_t nS, uint32_t *ecc, uint32_t *__restrict__ csamp, uint32_t *__restrict__ big)
-{
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	uint32_t r = S;
-	while (ecc[r] != r)
-		r = ecc[r];
-	ecc[S] = r;
-	if ((S & 63u) == 0) {
-		const uint32_t c = atomicAdd(&csamp[r], 1u) + 1;
-		if (c >= CLASS_SAMPLE_MIN)
-			atomicMax(big, c);
-	}
-}
+// a tree edge, and a class stays connected inside any spanning tree).  They are never numbered: two neighbouring sides
+// are in one class iff the edge between them is no bridge, and a bridge is recognised from pbr alone -- it is the tree
+// edge between a side and its forest parent with the bridge bit set (a bridge has no parallel edge, so "the edge to my
+// parent" and "a link to my parent" are the same thing when the bit is set).  Every class is walked from its ENTRY,
+// the one side whose parent edge is a bridge (or the DFS start); entries are marked visited before any walk starts,
+// so a walk never runs down across a bridge, and only the entry itself has to skip the way up.
 
 // ------------------------------------------------------------------ 5. class entries
-static constexpr uint32_t CS_VISITED = 0x80000000u; // (class ids are side ids < 2^28)
+static constexpr uint32_t CLASS_BUDGET = 256;  // sides a lane walks before it hands its class to the big-class walk
+static constexpr uint32_t CS_VISITED = 0x40000000u; // (side ids stay below 2^29, bit 31 is PB_BRIDGE)
 __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const uint4 *__restrict__ t0seg,
 			  const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
-			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ecc,
+			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi,
 			  uint2 *__restrict__ dps, uint8_t *__restrict__ dvis,
 			  uint8_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
 {
@@ -658,11 +619,12 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 		return;
 	uint2 rec = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}: one word pair, one store
 	uint8_t vis = 0, ef = 0;
-	// class and visited bit of a side in ONE word: the walk tests "same class and not yet visited" with one load
+	// forest parent, bridge bit and visited bit of a side in ONE word: the walk tests "not yet visited" with one load, and
+	// that covers "not across a bridge" too on the way down (see section 4)
 	const bool proc = cproc[ckey[S >> 1]] != 0;
 	const uint32_t p0 = proc ? pbr[S] : 0u;
 	const bool entry = proc && (p0 & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
-	cstate[S] = proc ? (ecc[S] | (entry ? CS_VISITED : 0u)) : NIL;
+	cstate[S] = proc ? (p0 | (entry ? CS_VISITED : 0u)) : NIL;
 	if (entry) {
 		// a class is walked from its entry side; a side that is alone in its class has nothing to walk
 		vis = 1;
@@ -698,13 +660,13 @@ __global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const ui
 // ------------------------------------------------------------------ 6. the DFS inside every class
 // One lane walks one class, so a step costs its chain of dependent loads (HBM / Infinity-Cache latency):
 // keep that chain short.  k_class_adj filters every side's scan list [black edge, links by local edge idx]
-// down to the neighbours of its own class (entry = {side, scan slot}) and packs {begin, count, first entry}
+// down to the neighbours of its own class, i.e. those not across a bridge (entry = {side, scan slot}) and packs {begin, count, first entry}
 // per side.  Going down then costs ONE load level (the candidate's visited byte and its packed record, which
 // already carries ITS first candidate), skipping a visited candidate costs one (the candidate behind it is loaded with
 // it), coming back one (the child keeps its parent's scan state {parent, begin, count, next} and the parent's next
 // candidate).
 __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			    const uint32_t *__restrict__ ecc, const uint32_t *__restrict__ ckey,
+			    const uint32_t *__restrict__ pbr, const uint32_t *__restrict__ ckey,
 			    const uint32_t *__restrict__ cproc, uint2 *__restrict__ cadj, uint4 *__restrict__ rb)
 {
 	uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -714,14 +676,15 @@ __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, cons
 	uint32_t n = 0;
 	uint2 first = make_uint2(NIL, 0u);
 	if (cproc[ckey[u >> 1]]) {
-		const uint32_t cls = ecc[u];
-		if (ecc[u ^ 1u] == cls) {
+		const uint32_t mine = pbr[u];
+		auto same_class = [&](uint32_t o) { return mine != (o | PB_BRIDGE) && pbr[o] != (u | PB_BRIDGE); }; // no bridge between
+		if (same_class(u ^ 1u)) {
 			first = make_uint2(u ^ 1u, 0u);
 			cadj[base + n++] = first;
 		}
 		for (uint32_t k = lo; k < hi; k++) {
 			const uint32_t o = ladj[k];
-			if (ecc[o] == cls) {
+			if (same_class(o)) {
 				const uint2 e = make_uint2(o, k - lo + 1);
 				if (!n)
 					first = e;
@@ -735,33 +698,42 @@ __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, cons
 // entry and its state word on the way down; {parent, slot} of the finished side and the parent's list bounds on the way
 // back -- the parent resumes its scan behind the slot the child was found through, so no cursor is stored.
 __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
-				  const uint32_t *__restrict__ ladj, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
+				  const uint32_t *__restrict__ ladj, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps,
+				  uint32_t budget, uint32_t *__restrict__ n_over, uint32_t *__restrict__ over_list)
 {
 	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
-		const uint32_t s = entry_list[i], cls = cstate[s] & ~CS_VISITED;
-		uint32_t u = s, k = 0, lo = loff[u], n = loff[u + 1] - lo;
+		const uint32_t s = entry_list[i];
+		const uint32_t s_up = cstate[s] & ~(CS_VISITED | PB_BRIDGE); // the entry's parent, across its bridge (root: all ones)
+		uint32_t u = s, k = 0, lo = loff[u], n = loff[u + 1] - lo, sides = 0;
 		for (;;) {
 			bool adv = false;
 			while (k <= n) {
 				const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
 				const uint32_t slot = k++;
-				if (cstate[o] == cls) { // same class, not visited yet
+				const uint32_t w = cstate[o];
+				if (!(w & CS_VISITED) && !(u == s && o == s_up)) { // not visited yet (hence no entry of another class), not the way up
 					// (loads of the next step before the stores of this one: vmcnt counts both in issue order,
 					// and a wait for a load behind a store waits for the store too)
 					const uint32_t nlo = loff[o], nhi = loff[o + 1];
-					cstate[o] = cls | CS_VISITED;
+					cstate[o] = w | CS_VISITED;
 					dps[o] = make_uint2(u, slot);
 					u = o;
 					k = 0;
 					lo = nlo;
 					n = nhi - nlo;
 					adv = true;
+					sides++;
 					break;
 				}
 			}
-			if (adv)
+			if (adv) {
+				if (sides > budget) { // a large class: the walk with the short dependent chain starts it over (k_class_dfs)
+					over_list[atomicAdd(n_over, 1u)] = s;
+					break;
+				}
 				continue;
+			}
 			if (u == s)
 				break;
 			const uint2 up = dps[u];
@@ -780,9 +752,13 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 #define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 __global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
 			    const uint4 *__restrict__ rb, uint2 *__restrict__ dps,
-			    uint8_t *dvis, uint4 *__restrict__ ret, uint2 *__restrict__ retc)
+			    uint8_t *dvis, uint4 *__restrict__ ret, uint2 *__restrict__ retc, uint32_t lane_stride)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	// lane_stride = 64: one class per WAVE (the walks of large classes diverge completely; lanes of one wave would take turns)
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t % lane_stride)
+		return;
+	const uint32_t i = t / lane_stride;
 	if (i >= n_entry)
 		return;
 	const uint32_t s = entry_list[i];
@@ -1175,7 +1151,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0seg, (V + 2) * 16);
 	for (uint32_t **p : {&tw.pbr,
-			     &tw.ecc, &tw.entry_ps, &tw.entry_list,
+			     &tw.entry_ps, &tw.entry_list,
 			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dps, nS * 8);
@@ -1240,31 +1216,25 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
 	scan_exclusive_xor_u64(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	uint32_t *csamp = tw.entry_ps; // [nS], free until the entries are scanned
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
-	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.lle, cs.ckey, cs.voff, tw.pbr, tw.ecc, csamp, multi);
-	LAUNCH(k_ecc_tree, nS, s, nS, tw.pbr, tw.ecc, multi);
-	LAUNCH(k_ecc_flatten, nS, s, nS, tw.ecc, csamp, pw.err + 4);
+	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
+	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.lle, cs.ckey, cs.voff, tw.pbr, multi);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.ecc, tw.dps,
-	       tw.dvis, tw.entry_flag, cstate);
+	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.dps, tw.dvis, tw.entry_flag, cstate);
 	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
-	uint32_t *hb = tw.host->take<uint32_t>(2);
-	HIP_CHECK(hipMemcpyAsync(hb, tw.entry_ps + nS, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(hb + 1, pw.err + 4, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	const uint32_t n_entry = hb[0];
-	const bool big_classes = hb[1] != 0 || force_big_class_dfs;
-	if (n_entry && big_classes) {
-		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.ecc, cs.ckey, tw.cproc, tw.cadj, tw.crb);
-		KLAUNCH(k_class_dfs, dim3((n_entry + 63) / 64), dim3(64), 0, s, n_entry, tw.entry_list, tw.cadj, tw.crb,
-				   tw.dps, tw.dvis, tw.cret, tw.cretc);
-	} else if (n_entry) {
+	const uint32_t n_entry = tw.host->read_u32(tw.entry_ps + nS, s);
+	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
+	// gives up and reports the entry; those classes are then walked from the start by the walk with the short dependent
+	// chain, at the price of a filtering pass over the adjacency (it marks visits in its own bytes and rewrites the same
+	// parents, so the abandoned attempt leaves nothing behind).
+	const uint32_t *big_list = tw.entry_list;
+	uint32_t n_big = force_big_class_dfs ? n_entry : 0;
+	if (n_entry && !force_big_class_dfs) {
 		// Lanes in flight = a window of sides whose scattered stores meet again in L2: ~3000 x 64 lanes measured best
 		// from a few hundred thousand to twenty million small classes (wider windows thrash the caches, narrower
 		// ones leave latency uncovered).
@@ -1272,7 +1242,17 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		unsigned dfs_blocks = std::min(all_blocks, 3072u);
 		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
 			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
-		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps);
+		uint32_t *n_over = pw.err + 4, *over_list = tw.entry_ps; // (the scan of the entry flags is dead once compacted)
+		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps,
+			CLASS_BUDGET, n_over, over_list);
+		n_big = tw.host->read_u32(n_over, s);
+		big_list = over_list;
+	}
+	if (n_big) {
+		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.pbr, cs.ckey, tw.cproc, tw.cadj, tw.crb);
+		const uint32_t stride = n_big <= (1u << 16) ? 64u : 1u; // few large classes: a wave each
+		KLAUNCH(k_class_dfs, dim3((unsigned)(((size_t)n_big * stride + 63) / 64)), dim3(64), 0, s, n_big, big_list, tw.cadj, tw.crb,
+			tw.dps, tw.dvis, tw.cret, tw.cretc, stride);
 	}
 	tm.end(5);
 

@@ -15,7 +15,6 @@ struct TreeWs {
 	unsigned long long *xval, *xps;			  // [4V+4] xor values by tour position, their running xor
 	uint4 *t0seg;					  // [V] rooted forest, per segment: {parent of the entered side, link to it | r bit, tour position in, out}
 	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
-	uint32_t *ecc;					  // [2V] 2-edge-connected class of a side
 	uint2 *dps;					  // [2V] {DFS parent side, scan slot of the parent it was found through}
 	uint8_t *dvis;					  // [2V]
 	uint2 *cadj;					  // [2V + 2E] class-filtered scan lists {side, slot}
