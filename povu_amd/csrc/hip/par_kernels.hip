@@ -213,8 +213,7 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 			simp[T] = 0;
 		if (hpf)
 			hpf[t] = sm;
-		cap_tgt[t] = NIL;
-		capf[t] = 0;
+		capf[t] = 0; // (cap_tgt is only read where capf says so)
 		branching = sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz; // the first child does not fill the subtree
 	}
 	__shared__ uint32_t wcnt[TPB / 64];
