@@ -303,8 +303,8 @@ __global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const 
 		return;
 	const uint32_t v = b_src[j];
 	uint32_t rank;
-	if (j < NB0)
-		rank = capf[v] + simp[v] + b_ord[j];
+	if (j < NB0) // b_ord counts from the bottom of the source's ordinary edges; the list has the later pushed on top
+		rank = bstart[mpre[v] + 1] - bstart[mpre[v]] - 1 - b_ord[j];
 	else if (j < NB0 + ncap)
 		rank = simp[v];
 	else

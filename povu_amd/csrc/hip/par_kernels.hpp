@@ -37,7 +37,7 @@ struct ParWs {
 	uint64_t *keys_t, *keys_t2; // [T]
 	// dense back edges / brackets
 	uint32_t *dbo;			 // [C+1]
-	uint32_t *b_src, *b_tgt, *b_val, *b_val2, *tgtR, *b_ord; // [NBmax]; b_ord = rank among the source's ordinary edges, top first
+	uint32_t *b_src, *b_tgt, *b_val, *b_val2, *tgtR, *b_ord; // [NBmax]; b_ord = rank among the source's ordinary edges, bottom first
 	uint64_t *b_key, *b_key2;	 // [NBmax]
 	// candidate stack space
 	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev; // [V+1]

@@ -979,64 +979,111 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 //  - self-loop links: one back edge per segment, from the black child, at its first loop slot
 //  - a link to a descendant was already turned into a back edge by the descendant
 //  - a link to the tree parent, or a repeated link to the same side, is already "connected"
+// One kernel: a workgroup takes BE_SIDES consecutive sides (BE_ITER per lane, lanes on consecutive sides), every lane
+// counts the back edges of its sides, the workgroup adds the counts up (wave shuffles + LDS) and takes its stretch of the
+// dense list with ONE atomic add (few enough workgroups that the one hot word does not hurt), then every lane walks its
+// sides again (now from cache) and writes them.  The dense list is in no particular order -- nothing downstream needs one:
+// a bracket's place in its list follows from its source and b_ord, its rank among the ordinary edges of that source
+// (bottom first; k_bracket_place turns it round).
+static constexpr uint32_t BE_ITER = 16, BE_SIDES = TPB * BE_ITER;
 template <bool EMIT>
-__global__ void k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			     const uint2 *__restrict__ dps, const uint32_t *__restrict__ side_tidx,
-			     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
-			     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ be_cnt,
-			     const uint32_t *__restrict__ be_ps, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
-			     uint32_t *__restrict__ b_ord, const uint8_t *__restrict__ dupflag)
+__device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint32_t at,
+						    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+						    const uint2 *__restrict__ dps, const uint32_t *__restrict__ side_tidx,
+						    const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
+						    const uint32_t *__restrict__ t_par, uint32_t *__restrict__ b_src,
+						    uint32_t *__restrict__ b_tgt, uint32_t *__restrict__ b_ord,
+						    const uint8_t *__restrict__ dupflag)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
-	if (S >= nS)
-		return;
-	const uint32_t p = side_tidx[S];
-	uint32_t n = 0, at = EMIT ? be_ps[S] : 0;
-	if (p != NIL) {
-		const uint32_t c = ckey[S >> 1], root = 2 * voff[c] + c;
-		const uint32_t lo = loff[S], hi = loff[S + 1];
-		auto out = [&](uint32_t tgt) {
-			if (EMIT) {
-				b_src[at + n] = p;
-				b_tgt[at + n] = tgt;
-				b_ord[at + n] = be_cnt[S] - 1 - n; // later pushed = nearer the top of the bracket list
-			}
-			n++;
-		};
-		if (lo == hi) {
-			if (p == root || t_par[p] != 0)
-				out(root);
-		} else {
-			const uint32_t dp = dps[S].x;
-			bool loop_seen = false;
-			for (uint32_t k = lo; k < hi; k++) {
-				const uint32_t o = ladj[k];
-				if (o == (S ^ 1)) {
-					if (dp == o && !loop_seen)
-						out(side_tidx[o]);
-					loop_seen = true;
-					continue;
-				}
-				const uint32_t x = side_tidx[o];
-				if (x > p || o == dp)
-					continue;
-				bool dup = false;
-				if (dupflag) {
-					dup = dupflag[k] != 0;
-				} else {
-					for (uint32_t j = lo; j < k; j++)
-						if (ladj[j] == o) {
-							dup = true;
-							break;
-						}
-				}
-				if (!dup)
-					out(x);
-			}
+	uint32_t n = 0;
+	const uint32_t c = ckey[S >> 1], root = 2 * voff[c] + c;
+	const uint32_t lo = loff[S], hi = loff[S + 1];
+	auto out = [&](uint32_t tgt) {
+		if (EMIT) {
+			b_src[at + n] = p;
+			b_tgt[at + n] = tgt;
+			b_ord[at + n] = n; // later pushed = nearer the top of the bracket list
 		}
+		n++;
+	};
+	if (lo == hi) {
+		if (p == root || t_par[p] != 0)
+			out(root);
+		return n;
 	}
-	if (!EMIT)
-		be_cnt[S] = n;
+	const uint32_t dp = dps[S].x;
+	bool loop_seen = false;
+	for (uint32_t k = lo; k < hi; k++) {
+		const uint32_t o = ladj[k];
+		if (o == (S ^ 1)) {
+			if (dp == o && !loop_seen)
+				out(side_tidx[o]);
+			loop_seen = true;
+			continue;
+		}
+		const uint32_t x = side_tidx[o];
+		if (x > p || o == dp)
+			continue;
+		bool dup = false;
+		if (dupflag) {
+			dup = dupflag[k] != 0;
+		} else {
+			for (uint32_t j = lo; j < k; j++)
+				if (ladj[j] == o) {
+					dup = true;
+					break;
+				}
+		}
+		if (!dup)
+			out(x);
+	}
+	return n;
+}
+__global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+						     const uint2 *__restrict__ dps, const uint32_t *__restrict__ side_tidx,
+						     const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
+						     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ total_out,
+						     uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
+						     uint32_t *__restrict__ b_ord, const uint8_t *__restrict__ dupflag)
+{
+	const uint32_t S0 = blockIdx.x * BE_SIDES + threadIdx.x;
+	uint32_t n = 0;
+	for (uint32_t it = 0; it < BE_ITER; it++) {
+		const uint32_t S = S0 + it * TPB;
+		const uint32_t p = S < nS ? side_tidx[S] : NIL;
+		if (p != NIL)
+			n += side_back_edges<false>(S, p, 0, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag);
+	}
+	// exclusive prefix of n over the workgroup
+	__shared__ uint32_t wsum[TPB / 64], base;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint32_t inc = n;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(inc, off);
+		if ((int)lane >= off)
+			inc += y;
+	}
+	if (lane == 63)
+		wsum[wave] = inc;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+	for (uint32_t w = 0; w < TPB / 64; w++) {
+		if (w < wave)
+			before += wsum[w];
+		all += wsum[w];
+	}
+	if (threadIdx.x == 0)
+		base = all ? atomicAdd(total_out, all) : 0u;
+	__syncthreads();
+	if (!n)
+		return;
+	uint32_t at = base + before + inc - n;
+	for (uint32_t it = 0; it < BE_ITER; it++) {
+		const uint32_t S = S0 + it * TPB;
+		const uint32_t p = S < nS ? side_tidx[S] : NIL;
+		if (p != NIL)
+			at += side_back_edges<true>(S, p, at, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag);
+	}
 }
 
 // Conformance export only (povu_hip_debug_edge_ids): the tree and back edges of from_bd share one id counter in
@@ -1152,7 +1199,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.t0seg, (V + 2) * 16);
 	for (uint32_t **p : {&tw.pbr,
 			     &tw.entry_ps, &tw.entry_list,
-			     &tw.side_tidx, &tw.be_cnt, &tw.be_ps})
+			     &tw.side_tidx, &tw.be_cnt})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dps, nS * 8);
 	take((void **)&tw.dvis, nS);
@@ -1187,9 +1234,6 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 			   hipStream_t s)
 {
 	const uint32_t V = sw.V, E = sw.E, nS = 2 * V;
-	auto scan = [&](const uint32_t *in, uint32_t *out, size_t n) {
-		scan_exclusive_u32(in, out, n, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	};
 	const unsigned long long *start_key = (const unsigned long long *)cs.start_key;
 
 	// ---- 1-2. spanning forest, rooted at the DFS start by an Euler tour
@@ -1288,12 +1332,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		dupflag = tw.dvis_slots;
 	}
 	tw.last_dupflag = dupflag;
-	LAUNCH(k_back_edges<false>, nS, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
-	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
-	scan(tw.be_cnt, tw.be_ps, (size_t)nS + 1);
-	const uint32_t NB0 = tw.host->read_u32(tw.be_ps + nS, s);
-	LAUNCH(k_back_edges<true>, nS, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey, cs.voff, sw.t_par, tw.be_cnt,
-	       tw.be_ps, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
+	uint32_t *nb0_dev = pw.err + 6; // (cleared with the other counters at the start of the pass)
+	KLAUNCH(k_back_edges, dim3((nS + BE_SIDES - 1) / BE_SIDES), dim3(TPB), 0, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey,
+		cs.voff, sw.t_par, nb0_dev, pw.b_src, pw.b_tgt, pw.b_ord, dupflag);
+	const uint32_t NB0 = tw.host->read_u32(nb0_dev, s);
 	tm.end(6);
 	return NB0;
 }

@@ -25,7 +25,7 @@ struct TreeWs {
 	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
 	uint32_t *entry_ps, *entry_list;		  // [2V+1]
 	uint32_t *side_tidx;				  // [2V] tree vertex (T-space) of a side
-	uint32_t *be_cnt, *be_ps;			  // [2V+1]
+	uint32_t *be_cnt;				  // [2V+1] first arc of a side (tour); free afterwards
 	uint32_t *rk_pk, *rk_heads;			  // list ranking: packed list words [4V+8], list heads [C]
 	uint32_t *rk_nx, *rk_wa, *rk_wb, *rk_tA, *rk_tB, *rk_tC; // pools of the levels above the list itself
 	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
