@@ -513,12 +513,12 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 	prev[id] = iu;
 }
 
-// BLACK pass, all in one: class id, next_seen / prev and the "opens a flubble" flag of the entry at sorted position q,
-// written at its stack index (the sort's payload).  Consecutive entries of a run are consecutive members of a class
-// (deeper first), so next_seen[u] = the entry before it in the run, prev[u] = the entry after it.
+// BLACK pass, all in one: next_seen / prev and the "opens a flubble" flag of the entry at sorted position q, written at
+// its stack index (the sort's payload).  Consecutive entries of a run are consecutive members of a class (deeper
+// first), so next_seen[u] = the entry before it in the run, prev[u] = the entry after it.  Nothing downstream needs the
+// classes as numbers; the debug hooks number them on demand (k_class_ids_black).
 __global__ void k_class_finish_black(uint32_t n, uint32_t S, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-				     const uint8_t *__restrict__ fresh, const uint32_t *__restrict__ ps,
-				     uint32_t *__restrict__ s_cls, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev,
+				     const uint8_t *__restrict__ fresh, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev,
 				     uint8_t *__restrict__ dflag)
 {
 	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,11 +528,17 @@ __global__ void k_class_finish_black(uint32_t n, uint32_t S, const uint32_t *__r
 		return;
 	const uint32_t u = sval[q];
 	const uint8_t f = fresh[q];
-	s_cls[u] = ps[q] + f - 1; // inclusive scan - 1
 	const uint32_t nx = f ? u : sval[q - 1];
 	ns[u] = nx;
 	prev[u] = (q + 1 < n && skey[q + 1] != NIL && !fresh[q + 1]) ? sval[q + 1] : NIL;
 	dflag[u] = (u + 1 < nx) ? 1 : 0; // entry u opens a flubble iff its class comes back later than at the next entry
+}
+__global__ void k_class_ids_black(uint32_t n, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+				  const uint8_t *__restrict__ fresh, const uint32_t *__restrict__ ps, uint32_t *__restrict__ s_cls)
+{
+	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n && skey[q] != NIL)
+		s_cls[sval[q]] = ps[q] + fresh[q] - 1; // inclusive scan - 1
 }
 // classes of the black tree vertices back in T-space (debug hook after a BLACK pass)
 __global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx, const uint32_t *__restrict__ s_cls,
@@ -989,14 +995,14 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 		LAUNCH(k_class_flags<true>, NC, s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, nullptr);
-		scan8(cflag, cps, (size_t)NC + 1);
 		tm.end(30 + 2 * 22);
 		tm.begin("par_stack");
-		LAUNCH(k_class_finish_black, std::max<size_t>(NC, 1), s, NC, S, ck2, pw.vals_t2, cflag, cps, pw.s_cls, pw.ns, pw.prev, dflag);
+		LAUNCH(k_class_finish_black, std::max<size_t>(NC, 1), s, NC, S, ck2, pw.vals_t2, cflag, pw.ns, pw.prev, dflag);
 		tm.end(1);
 		tm.begin("par_next_seen"); // (folded into the kernel above)
 		tm.end(0);
 		pw.gcls_valid = false;
+		pw.s_cls_valid = false; // (cflag, the sorted keys and their stack indices stay where they are for stack_class_ids)
 	} else {
 		const StackPlace none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 		LAUNCH(k_top_bracket<false>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
@@ -1007,6 +1013,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		scan8(cflag, cps, (size_t)NC + 1);
 		LAUNCH(k_class_scatter, NC, s, NC, ck2, pw.vals_t2, cflag, cps, pw.gcls);
 		pw.gcls_valid = true;
+		pw.s_cls_valid = true;
 		tm.end(30 + 2 * 22);
 
 		// ---- row E
@@ -1082,10 +1089,21 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	tm.end(12 + 3 * 22);
 }
 
+// class ids of the stack entries after a black-only pass (debug hooks): the runs of the sorted order, numbered
+static void stack_class_ids(ParWs &pw, hipStream_t s)
+{
+	if (pw.s_cls_valid)
+		return;
+	const uint32_t V = pw.V;
+	scan_exclusive_u8(pw.f8a, pw.psA, (size_t)V + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	LAUNCH(k_class_ids_black, V, s, V, (const uint32_t *)pw.keys_t2, pw.vals_t2, pw.f8a, pw.psA, pw.s_cls);
+	pw.s_cls_valid = true;
+}
 void classes_to_tree_space(ParWs &pw, hipStream_t s)
 {
 	if (pw.gcls_valid)
 		return;
+	stack_class_ids(pw, s);
 	HIP_CHECK(hipMemsetAsync(pw.gcls, 0xFF, (size_t)pw.T * 4, s));
 	if (pw.n_stack)
 		LAUNCH(k_cls_from_stack, pw.n_stack, s, pw.n_stack, pw.s_vtx, pw.s_cls, pw.gcls);
@@ -1094,6 +1112,7 @@ void classes_to_tree_space(ParWs &pw, hipStream_t s)
 
 void export_parallel_stack(const CompState &cs, SeqWs &sw, ParWs &pw, hipStream_t s)
 {
+	stack_class_ids(pw, s);
 	const uint32_t S = pw.n_stack;
 	LAUNCH(k_export_stack, S, s, S, pw.s_comp, pw.soff, cs.voff, pw.s_vtx, pw.s_cls, pw.ns, sw.s_vtx, sw.s_cls,
 	       sw.next_seen);

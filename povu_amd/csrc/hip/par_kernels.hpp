@@ -27,6 +27,7 @@ struct ParWs {
 	uint32_t V, E, C, T;
 	bool all_vertex_classes = false; // in: number the classes of all tree edges even when the black ones would do (A/B tests)
 	bool black_only_used = false;	 // out: the last pass numbered the classes of the black tree edges only
+	bool s_cls_valid = false;	 // s_cls holds class ids (a black-only pass numbers its classes only when a debug hook asks)
 	bool gcls_valid = false;	 // gcls holds the classes in T-space (a black-only pass keeps them in stack order only)
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
