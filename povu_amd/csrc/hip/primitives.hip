@@ -336,12 +336,19 @@ void scan_exclusive_xor_u64(const unsigned long long *in, unsigned long long *ou
 	KLAUNCH(k_xor64_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
 }
 
+// 25..27 key bits (the class sort of a whole-genome graph: ~2^26 brackets) take four 8-bit places with rocPRIM's tuned
+// default; three 9-bit places move a quarter less data (13-bit digits would need more LDS than a CU has)
+using nine = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+					rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 9,
+									    rocprim::block_radix_rank_algorithm::match>>;
 size_t sort_tmp_bytes(size_t n)
 {
-	size_t bytes = 0;
+	size_t bytes = 0, bytes9 = 0;
 	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
 					(const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32);
-	return bytes + 256;
+	(void)rocprim::radix_sort_pairs<nine>(nullptr, bytes9, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+					      (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 27);
+	return std::max(bytes, bytes9) + 256;
 }
 
 void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
@@ -349,7 +356,10 @@ void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, ui
 {
 	if (n == 0)
 		return;
-	HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
+	if ((bits + 8) / 9 < (bits + 7) / 8 && n > (size_t(1) << 22)) // fewer places with 9-bit digits (17-18, 25-27 key bits)
+		HIP_CHECK(rocprim::radix_sort_pairs<nine>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
+	else
+		HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
 }
 
 } // namespace povu_hip
