@@ -113,13 +113,16 @@ __global__ void k_dense_be(uint32_t NB0, uint32_t C, const uint32_t *__restrict_
 // hi0(v) = min target of v's own back edges; cov(v) = back edges leaving v minus back edges arriving at v.  A back
 // edge runs from a descendant to an ancestor, so the sum of cov over subtree(v) counts exactly the back edges that
 // leave subtree(v) upwards past v.
+// (incnt, when given: brackets that end at a vertex -- the ordinary ones are counted here, while their ends are in hand)
 __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
-		      uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov)
+		      uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov, uint32_t *__restrict__ incnt)
 {
 	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= NB0)
 		return;
 	const uint32_t sv = b_src[j], tv = b_tgt[j];
+	if (incnt)
+		atomicAdd(&incnt[tv], 1u);
 	atomicMin(&hi0[sv], tv);
 	if (sv != tv) {
 		atomicAdd(&cov[sv], 1u);
@@ -243,21 +246,31 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 __global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
 				const uint32_t *__restrict__ pscap, const uint8_t *__restrict__ simp,
 				const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
-				const uint32_t *__restrict__ t_root, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
+				const uint32_t *__restrict__ t_root, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
+				const uint32_t *__restrict__ ordcnt, const uint32_t *__restrict__ gsize,
+				const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt, uint32_t *__restrict__ srccnt)
 {
 	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= T)
 		return;
-	if (capf[v]) {
+	const uint32_t c = capf[v], sm = simp[v];
+	if (c) {
 		uint32_t j = NB0 + pscap[v];
 		b_src[j] = v;
 		b_tgt[j] = cap_tgt[v];
+		if (ordcnt)
+			atomicAdd(&incnt[cap_tgt[v]], 1u);
 	}
-	if (simp[v]) {
+	if (sm) {
 		uint32_t j = NB0 + ncap + pssimp[v];
 		b_src[j] = v;
 		b_tgt[j] = t_root[v];
+		if (ordcnt)
+			atomicAdd(&incnt[t_root[v]], 1u);
 	}
+	// (dense path) brackets per source, at its place in the list order: known per vertex, no counting pass over the brackets
+	if (ordcnt && gsize[v])
+		srccnt[mpre[v]] = ordcnt[v] + c + sm;
 }
 __global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32_t nsimp, const uint32_t *__restrict__ b_src,
 				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ mpre,
@@ -283,15 +296,6 @@ __global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32
 // With the per-source rank of every ordinary edge known (parallel tree stage), the list order needs no
 // sort: a bracket's position = (first bracket of its source's mirror pre-order position) + its rank
 // inside the source (simplifying, capping, ordinary edges top first).
-__global__ void k_bracket_count(uint32_t NB, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
-				const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt, uint32_t *__restrict__ srccnt)
-{
-	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= NB)
-		return;
-	atomicAdd(&incnt[b_tgt[j]], 1u);
-	atomicAdd(&srccnt[mpre[b_src[j]]], 1u);
-}
 __global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const uint32_t *__restrict__ b_src,
 				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ b_ord,
 				const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
@@ -933,7 +937,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row D
 	tm.begin("par_classes");
-	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov);
+	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov, dense_nb0 >= 0 ? pw.incnt : nullptr);
 	seg_build(pw.segA, pw.hi0, T, s);
 	uint8_t *bridge = pw.f8a, *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
 	uint32_t *psb = pw.psA, *pssimp = pw.psB, *pscap = pw.psC;
@@ -961,9 +965,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// both take the all-vertices pass.
 	const bool black_only = !want_hp && !pw.all_vertex_classes && extra[2] == 0;
 	pw.black_only_used = black_only;
-	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt);
-	if (dense_nb0 >= 0) { // ranks inside every source are known: place directly
-		LAUNCH(k_bracket_count, NB, s, NB, pw.b_src, pw.b_tgt, pw.mpre, pw.incnt, srccnt);
+	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt,
+	       dense_nb0 >= 0 ? pw.lsz : nullptr, pw.gsize, pw.mpre, pw.incnt, srccnt);
+	if (dense_nb0 >= 0) { // ranks inside every source and the counts per source are known: place directly
 		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
 		LAUNCH(k_bracket_place, NB, s, NB, NB0, ncap, pw.b_src, pw.b_tgt, pw.b_ord, pw.mpre, bstart, capf, simp, pw.tgtR,
 		       pw.b_val2);
