@@ -200,6 +200,9 @@ void scan_exclusive_xor_u32_pair(const uint32_t *in0, uint32_t *out0, const uint
 // exclusive sums of BYTE inputs (flags, counts below 256): one job, or two independent ones in the same two launches
 void scan_exclusive_u8(const uint8_t *in0, uint32_t *out0, size_t n0, const uint8_t *in1, uint32_t *out1, size_t n1, void *tmp,
 		       size_t tmp_bytes, hipStream_t s);
+// exclusive prefix sums of in[i] - sub[i] (mod 2^32)
+void scan_exclusive_diff_u32(const uint32_t *in, const uint32_t *sub, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes,
+			     hipStream_t s);
 // exclusive running xor of 64-bit words
 void scan_exclusive_xor_u64(const unsigned long long *in, unsigned long long *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
 size_t scan_tmp_bytes(size_t n);

@@ -63,11 +63,13 @@ __global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, con
 	if (t >= T)
 		return;
 	hi0[t] = NIL; // k_hi0 takes minima into it
-	cov[t] = 0;   // ... and counts back-edge ends here
+	if (cov)
+		cov[t] = 0; // ... and counts back-edge ends here (not on the dense path)
 	incnt[t] = srccnt[t] = 0; // bracket counters of the class stage, [T+2] each
 	if (t == T - 1) {
 		hi0[T] = NIL;
-		cov[T] = 0;
+		if (cov)
+			cov[T] = 0;
 		incnt[T] = incnt[T + 1] = srccnt[T] = srccnt[T + 1] = 0;
 	}
 	uint32_t c = t_comp[t];
@@ -121,10 +123,10 @@ __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const ui
 	if (j >= NB0)
 		return;
 	const uint32_t sv = b_src[j], tv = b_tgt[j];
-	if (incnt)
-		atomicAdd(&incnt[tv], 1u);
 	atomicMin(&hi0[sv], tv);
-	if (sv != tv) {
+	if (incnt) { // (dense path: cov = edges leaving - edges arriving is read off the two counts, see run_parallel_dg)
+		atomicAdd(&incnt[tv], 1u);
+	} else if (sv != tv) {
 		atomicAdd(&cov[sv], 1u);
 		atomicSub(&cov[tv], 1u);
 	}
@@ -922,7 +924,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- T-space + dense back edges
 	tm.begin("par_setup");
 	LAUNCH(k_tcomp_vertices, V, s, V, T, cs.ckey, cs.voff, pw.t_comp);
-	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0, pw.cov, sw.t_depth,
+	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0,
+	       dense_nb0 >= 0 ? nullptr : pw.cov, sw.t_depth,
 	       pw.mpre, pw.incnt, pw.dlt);
 	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
@@ -942,7 +945,10 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint8_t *bridge = pw.f8a, *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
 	uint32_t *psb = pw.psA, *pssimp = pw.psB, *pscap = pw.psC;
 	uint32_t *pscov = pw.psB; // (free until the simplifying flags are scanned)
-	scan(pw.cov, pscov, (size_t)T + 1);
+	if (dense_nb0 >= 0) // back edges leaving a vertex (counted by the tree stage) minus those arriving (counted by k_hi0)
+		scan_exclusive_diff_u32(pw.lsz, pw.incnt, pscov, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	else
+		scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
 	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, pw.hi0, pw.t_root,

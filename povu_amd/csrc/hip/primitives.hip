@@ -35,6 +35,7 @@ __device__ __forceinline__ uint32_t sc_block_reduce(uint32_t v, uint32_t *sh)
 // are due at the same point of the pass share their two launches.
 struct ScanJob {
 	const uint32_t *in;
+	const uint32_t *sub; // when set (sum scans of words): the element is in[i] - sub[i]
 	const uint8_t *in8; // when set: the input is one BYTE per element (flags, small counts) -- a quarter of the reads
 	uint32_t *out;
 	size_t n, chunk;
@@ -65,6 +66,10 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_partials(const ScanJobs jobs)
 		}
 		for (size_t i = w1 + threadIdx.x; i < b1; i += SC_TPB)
 			acc = sc_op<MAX>(acc, in8[i]);
+	} else if (J.sub) {
+		const uint32_t *__restrict__ sub = J.sub;
+		for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
+			acc = sc_op<MAX>(acc, in[i] - sub[i]);
 	} else {
 		for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
 			acc = sc_op<MAX>(acc, in[i]);
@@ -107,9 +112,13 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 		} else if (e0 + SC_ITEMS <= b1) {
 			const uint4 a = *reinterpret_cast<const uint4 *>(in + e0), b = *reinterpret_cast<const uint4 *>(in + e0 + 4);
 			v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+			if (J.sub) {
+				const uint4 c = *reinterpret_cast<const uint4 *>(J.sub + e0), d = *reinterpret_cast<const uint4 *>(J.sub + e0 + 4);
+				v[0] -= c.x, v[1] -= c.y, v[2] -= c.z, v[3] -= c.w, v[4] -= d.x, v[5] -= d.y, v[6] -= d.z, v[7] -= d.w;
+			}
 		} else {
 			for (int k = 0; k < SC_ITEMS; k++)
-				v[k] = e0 + k < b1 ? in[e0 + k] : 0u;
+				v[k] = e0 + k < b1 ? in[e0 + k] - (J.sub ? J.sub[e0 + k] : 0u) : 0u;
 		}
 		uint32_t tot = 0; // lane-local exclusive scan
 		for (int k = 0; k < SC_ITEMS; k++) {
@@ -154,9 +163,11 @@ size_t scan_tmp_bytes(size_t)
 	return 2 * SC_MAX_BLOCKS * sizeof(uint32_t) + 256;
 }
 
-static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial, const uint8_t *in8 = nullptr)
+static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial, const uint8_t *in8 = nullptr,
+			     const uint32_t *sub = nullptr)
 {
-	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(in8) | reinterpret_cast<uintptr_t>(out)) & 15)
+	if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(in8) | reinterpret_cast<uintptr_t>(out) |
+	     reinterpret_cast<uintptr_t>(sub)) & 15)
 		throw HipError("scan: operands must be 16-byte aligned");
 	size_t blocks = (n + SC_TILE - 1) / SC_TILE;
 	if (blocks > SC_MAX_BLOCKS)
@@ -164,7 +175,7 @@ static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32
 	size_t chunk = (n + blocks - 1) / blocks;
 	chunk = (chunk + SC_TILE - 1) / SC_TILE * SC_TILE; // whole tiles: every tile base stays 16-byte aligned
 	blocks = (n + chunk - 1) / chunk;
-	return ScanJob{in, in8, out, n, chunk, (uint32_t)blocks, partial};
+	return ScanJob{in, sub, in8, out, n, chunk, (uint32_t)blocks, partial};
 }
 
 template <int MAX>
@@ -207,6 +218,18 @@ void scan_exclusive_u8(const uint8_t *in0, uint32_t *out0, size_t n0, const uint
 void scan_exclusive_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
 	scan_exclusive<0>(in, out, n, tmp, tmp_bytes, s);
+}
+void scan_exclusive_diff_u32(const uint32_t *in, const uint32_t *sub, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes,
+			     hipStream_t s)
+{
+	if (n == 0)
+		return;
+	if (tmp_bytes < SC_MAX_BLOCKS * sizeof(uint32_t))
+		throw HipError("scan: temporary storage too small");
+	ScanJobs jobs{};
+	jobs.j[0] = make_scan_job(in, out, n, static_cast<uint32_t *>(tmp), nullptr, sub);
+	KLAUNCH(k_scan_partials<0>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
+	KLAUNCH(k_scan_chunks<0>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 }
 
 template <int OP>
