@@ -62,15 +62,20 @@ __global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, con
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
-	hi0[t] = NIL; // k_hi0 takes minima into it
-	if (cov)
-		cov[t] = 0; // ... and counts back-edge ends here (not on the dense path)
-	incnt[t] = srccnt[t] = 0; // bracket counters of the class stage, [T+2] each
-	if (t == T - 1) {
-		hi0[T] = NIL;
-		if (cov)
+	srccnt[t] = 0; // brackets per source, [T+2]
+	if (t == T - 1)
+		srccnt[T] = srccnt[T + 1] = 0;
+	if (cov) { // (not on the dense path: the tree stage left hi0 and the count of bracket ends, and needs no coverage array)
+		hi0[t] = NIL; // k_hi0 takes minima into it
+		cov[t] = 0;   // ... and counts back-edge ends here
+		incnt[t] = 0; // brackets that end at a vertex, [T+2]
+		if (t == T - 1) {
+			hi0[T] = NIL;
 			cov[T] = 0;
-		incnt[T] = incnt[T + 1] = srccnt[T] = srccnt[T + 1] = 0;
+			incnt[T] = incnt[T + 1] = 0;
+		}
+	} else if (t == T - 1) {
+		hi0[T] = NIL;
 	}
 	uint32_t c = t_comp[t];
 	uint32_t base = 2 * voff[c] + c, l = t - base, n = c_ntree[c];
@@ -940,7 +945,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- row D
 	tm.begin("par_classes");
-	LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov, dense_nb0 >= 0 ? pw.incnt : nullptr);
+	if (dense_nb0 < 0)
+		LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov, nullptr);
 	seg_build(pw.segA, pw.hi0, T, s);
 	uint8_t *bridge = pw.f8a, *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
 	uint32_t *psb = pw.psA, *pssimp = pw.psB, *pscap = pw.psC;

@@ -920,7 +920,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
 			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
 			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx,
-			    uint32_t C, uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ ordcnt)
+			    uint32_t C, uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S < C) { // tree size of component S and its dummy root (spanning_tree.cpp:397-402)
@@ -935,7 +935,8 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 				t_par[tr] = NIL;
 				t_size[tr] = Nr + 1;
 				t_depth[tr] = 0;
-				ordcnt[tr] = 0; // (a dummy root has no back edges of its own; every other tree vertex gets its count from k_back_edges)
+				ordcnt[tr] = 0; // (a dummy root has no back edges of its own; every other tree vertex gets these from k_back_edges)
+				hi0[tr] = NIL;
 			}
 		}
 	}
@@ -994,7 +995,7 @@ __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint
 						    const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
 						    const uint32_t *__restrict__ t_par, uint32_t *__restrict__ b_src,
 						    uint32_t *__restrict__ b_tgt, uint32_t *__restrict__ b_ord,
-						    const uint8_t *__restrict__ dupflag)
+						    const uint8_t *__restrict__ dupflag, uint32_t *__restrict__ incnt, uint32_t &highest)
 {
 	uint32_t n = 0;
 	const uint32_t c = ckey[S >> 1], root = 2 * voff[c] + c;
@@ -1004,6 +1005,9 @@ __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint
 			b_src[at + n] = p;
 			b_tgt[at + n] = tgt;
 			b_ord[at + n] = n; // later pushed = nearer the top of the bracket list
+			atomicAdd(&incnt[tgt], 1u); // brackets that end at tgt
+		} else {
+			highest = min(highest, tgt);
 		}
 		n++;
 	};
@@ -1046,7 +1050,7 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 						     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ total_out,
 						     uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
 						     uint32_t *__restrict__ b_ord, const uint8_t *__restrict__ dupflag,
-						     uint32_t *__restrict__ ordcnt)
+						     uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0, uint32_t *__restrict__ incnt)
 {
 	const uint32_t S0 = blockIdx.x * BE_SIDES + threadIdx.x;
 	uint32_t n = 0;
@@ -1054,8 +1058,13 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 		const uint32_t S = S0 + it * TPB;
 		const uint32_t p = S < nS ? side_tidx[S] : NIL;
 		if (p != NIL) {
-			const uint32_t k = side_back_edges<false>(S, p, 0, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag);
-			ordcnt[p] = k; // ordinary brackets of tree vertex p (the class stage sizes p's stretch of the bracket list with it)
+			uint32_t highest = NIL;
+			const uint32_t k = side_back_edges<false>(S, p, 0, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag,
+								  incnt, highest);
+			// what the class stage needs per tree vertex, known right here: its ordinary brackets (p's stretch of the
+			// bracket list is sized with it) and the highest vertex they reach (hi_0, flubbles.cpp:515-519)
+			ordcnt[p] = k;
+			hi0[p] = highest;
 			n += k;
 		}
 	}
@@ -1086,8 +1095,10 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 	for (uint32_t it = 0; it < BE_ITER; it++) {
 		const uint32_t S = S0 + it * TPB;
 		const uint32_t p = S < nS ? side_tidx[S] : NIL;
+		uint32_t unused = NIL;
 		if (p != NIL)
-			at += side_back_edges<true>(S, p, at, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag);
+			at += side_back_edges<true>(S, p, at, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag, incnt,
+						    unused);
 	}
 }
 
@@ -1321,7 +1332,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
 	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
-	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree, pw.lsz);
+	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0);
+	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
 		const uint32_t n_slots = 2 * E;
@@ -1339,7 +1351,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	tw.last_dupflag = dupflag;
 	uint32_t *nb0_dev = pw.err + 6; // (cleared with the other counters at the start of the pass)
 	KLAUNCH(k_back_edges, dim3((nS + BE_SIDES - 1) / BE_SIDES), dim3(TPB), 0, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey,
-		cs.voff, sw.t_par, nb0_dev, pw.b_src, pw.b_tgt, pw.b_ord, dupflag, pw.lsz);
+		cs.voff, sw.t_par, nb0_dev, pw.b_src, pw.b_tgt, pw.b_ord, dupflag, pw.lsz, pw.hi0, pw.incnt);
 	const uint32_t NB0 = tw.host->read_u32(nb0_dev, s);
 	tm.end(6);
 	return NB0;
