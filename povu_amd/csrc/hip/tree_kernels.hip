@@ -112,7 +112,7 @@ __device__ __forceinline__ unsigned long long link_hash(uint32_t le)
 // of both its ends, also when they are l and r of one segment), ft[S] = its first arc (NIL: none).
 __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b,
-			     unsigned long long *__restrict__ hside, uint32_t *__restrict__ ft)
+			     unsigned long long *__restrict__ hside, uint32_t *__restrict__ ft, uint32_t *__restrict__ twin)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -130,6 +130,7 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 		if (first == NIL)
 			first = at;
 		const uint32_t w = ladj[at], t = loff[w] + find_link_slot(loff, lle, w, le) - 1;
+		twin[at] = t; // (k_t0_parents needs it again)
 		const uint32_t sb = loff[w & ~1u], se = loff[(w & ~1u) + 2];
 		uint32_t nxt = t;
 		for (uint32_t j = t + 1; j < se && nxt == t; j++)
@@ -512,7 +513,7 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
 			     const unsigned long long *__restrict__ hside, const uint32_t *__restrict__ heads,
-			     uint4 *__restrict__ t0seg, unsigned long long *__restrict__ val, uint32_t C,
+			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, unsigned long long *__restrict__ val, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,7 +533,7 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		const uint32_t le = lle[at];
 		if (!tgray[le] || la[le] != S)
 			continue; // a link of the forest is handled once, from the side that met it first
-		const uint32_t w = ladj[at], t = loff[w] + find_link_slot(loff, lle, w, le) - 1;
+		const uint32_t w = ladj[at], t = twin[at];
 		const uint32_t da = dist[at], dt = dist[t];
 		const uint32_t pa = abase + (L - 1 - da), pt = abase + (L - 1 - dt); // tour positions of the two arcs
 		const bool down = da > dt;					      // `at` comes first: S is the parent of w
@@ -1262,7 +1263,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
 	if (n_slots >= PK_END || 3 * (size_t)V >= PK_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
 		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^29");
-	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, hside, ft);
+	uint32_t *twin = reinterpret_cast<uint32_t *>(tw.cadj); // [2E] (the filtered scan lists come much later)
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, hside, ft, twin);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
 	if (n_slots)
 		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
@@ -1270,7 +1272,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	unsigned long long *val = tw.xval, *px = tw.xps; // [NA+1] each
 	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 8, s));
 	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, hside, rb.heads,
-	       tw.t0seg, val, C, start_key, pw.err + 2);
+	       twin, tw.t0seg, val, C, start_key, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
