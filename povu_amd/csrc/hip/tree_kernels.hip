@@ -698,15 +698,21 @@ __global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, cons
 // the plain walk (small classes only; no filtering pass).  Dependent loads per tree edge: the candidate's adjacency
 // entry and its state word on the way down; {parent, slot} of the finished side and the parent's list bounds on the way
 // back -- the parent resumes its scan behind the slot the child was found through, so no cursor is stored.
-__global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint32_t *__restrict__ loff,
-				  const uint32_t *__restrict__ ladj, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps,
-				  uint32_t budget, uint32_t *__restrict__ n_over, uint32_t *__restrict__ over_list)
+static constexpr uint32_t DFS_STK = 8; // levels of a walk whose scan state stays in LDS (most classes are bubbles a few sides deep)
+__global__ void __launch_bounds__(64) k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list,
+							 const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+							 uint32_t *__restrict__ cstate, uint2 *__restrict__ dps, uint32_t budget,
+							 uint32_t *__restrict__ n_over, uint32_t *__restrict__ over_list)
 {
+	// the scan state {side, next slot, list begin, list length} of the upper levels of a walk: coming back to them costs no
+	// memory traffic at all (deeper levels go through dps and loff again)
+	__shared__ uint4 stk[DFS_STK][64];
+	const uint32_t lane = threadIdx.x;
 	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
 		const uint32_t s = entry_list[i];
 		const uint32_t s_up = cstate[s] & ~(CS_VISITED | PB_BRIDGE); // the entry's parent, across its bridge (root: all ones)
-		uint32_t u = s, k = 0, lo = loff[u], n = loff[u + 1] - lo, sides = 0;
+		uint32_t u = s, k = 0, lo = loff[u], n = loff[u + 1] - lo, sides = 0, depth = 0;
 		for (;;) {
 			bool adv = false;
 			while (k <= n) {
@@ -719,6 +725,9 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 					const uint32_t nlo = loff[o], nhi = loff[o + 1];
 					cstate[o] = w | CS_VISITED;
 					dps[o] = make_uint2(u, slot);
+					if (depth < DFS_STK)
+						stk[depth][lane] = make_uint4(u, k, lo, n);
+					depth++;
 					u = o;
 					k = 0;
 					lo = nlo;
@@ -737,11 +746,17 @@ __global__ void k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__
 			}
 			if (u == s)
 				break;
-			const uint2 up = dps[u];
-			k = up.y + 1;
-			u = up.x;
-			lo = loff[u];
-			n = loff[u + 1] - lo;
+			depth--;
+			if (depth < DFS_STK) {
+				const uint4 r = stk[depth][lane];
+				u = r.x, k = r.y, lo = r.z, n = r.w;
+			} else {
+				const uint2 up = dps[u];
+				k = up.y + 1;
+				u = up.x;
+				lo = loff[u];
+				n = loff[u + 1] - lo;
+			}
 		}
 	}
 }
