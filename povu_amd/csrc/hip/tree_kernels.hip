@@ -1011,7 +1011,8 @@ __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint
 						    const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
 						    const uint32_t *__restrict__ t_par, uint32_t *__restrict__ b_src,
 						    uint32_t *__restrict__ b_tgt, uint32_t *__restrict__ b_ord,
-						    const uint8_t *__restrict__ dupflag, uint32_t *__restrict__ incnt, uint32_t &highest)
+						    const uint8_t *__restrict__ dupflag, uint32_t *__restrict__ incnt, uint32_t &highest,
+						    uint32_t *first2)
 {
 	uint32_t n = 0;
 	const uint32_t c = ckey[S >> 1], root = 2 * voff[c] + c;
@@ -1024,6 +1025,8 @@ __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint
 			atomicAdd(&incnt[tgt], 1u); // brackets that end at tgt
 		} else {
 			highest = min(highest, tgt);
+			if (n < 2)
+				first2[n] = tgt; // (LDS: a side with at most two back edges is written from there, without a second walk)
 		}
 		n++;
 	};
@@ -1069,20 +1072,24 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 						     uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0, uint32_t *__restrict__ incnt)
 {
 	const uint32_t S0 = blockIdx.x * BE_SIDES + threadIdx.x;
+	__shared__ uint32_t first2[BE_ITER][TPB][2]; // the first two targets of every side of the chunk
+	__shared__ uint8_t cnt8[BE_ITER][TPB];	     // min(its back edges, 255)
 	uint32_t n = 0;
 	for (uint32_t it = 0; it < BE_ITER; it++) {
 		const uint32_t S = S0 + it * TPB;
 		const uint32_t p = S < nS ? side_tidx[S] : NIL;
+		uint32_t k = 0;
 		if (p != NIL) {
 			uint32_t highest = NIL;
-			const uint32_t k = side_back_edges<false>(S, p, 0, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag,
-								  incnt, highest);
+			k = side_back_edges<false>(S, p, 0, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag, incnt, highest,
+						   first2[it][threadIdx.x]);
 			// what the class stage needs per tree vertex, known right here: its ordinary brackets (p's stretch of the
 			// bracket list is sized with it) and the highest vertex they reach (hi_0, flubbles.cpp:515-519)
 			ordcnt[p] = k;
 			hi0[p] = highest;
 			n += k;
 		}
+		cnt8[it][threadIdx.x] = (uint8_t)min(k, 255u);
 	}
 	// exclusive prefix of n over the workgroup
 	__shared__ uint32_t wsum[TPB / 64], base;
@@ -1109,12 +1116,24 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 		return;
 	uint32_t at = base + before + inc - n;
 	for (uint32_t it = 0; it < BE_ITER; it++) {
-		const uint32_t S = S0 + it * TPB;
-		const uint32_t p = S < nS ? side_tidx[S] : NIL;
-		uint32_t unused = NIL;
-		if (p != NIL)
-			at += side_back_edges<true>(S, p, at, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag, incnt,
-						    unused);
+		const uint32_t k = cnt8[it][threadIdx.x];
+		if (!k)
+			continue;
+		const uint32_t S = S0 + it * TPB, p = side_tidx[S];
+		if (k <= 2) {
+			for (uint32_t j = 0; j < k; j++) {
+				const uint32_t tgt = first2[it][threadIdx.x][j];
+				b_src[at + j] = p;
+				b_tgt[at + j] = tgt;
+				b_ord[at + j] = j;
+				atomicAdd(&incnt[tgt], 1u);
+			}
+			at += k;
+		} else {
+			uint32_t unused = NIL;
+			at += side_back_edges<true>(S, p, at, loff, ladj, dps, side_tidx, ckey, voff, t_par, b_src, b_tgt, b_ord, dupflag, incnt, unused,
+						    nullptr);
+		}
 	}
 }
 
