@@ -364,11 +364,14 @@ void scan_exclusive_xor_u64(const unsigned long long *in, unsigned long long *ou
 using nine = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
 					rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 9,
 									    rocprim::block_radix_rank_algorithm::match>>;
+// rocPRIM merge-sorts up to 2^20 items by default: some twenty launches, which a pass that is bound by its launches on a
+// graph of that size feels more than the radix sort's four or five
+using few_launches = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t(1) << 16)>;
 size_t sort_tmp_bytes(size_t n)
 {
 	size_t bytes = 0, bytes9 = 0;
-	(void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-					(const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32);
+	(void)rocprim::radix_sort_pairs<few_launches>(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+						      (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32);
 	(void)rocprim::radix_sort_pairs<nine>(nullptr, bytes9, (const uint32_t *)nullptr, (uint32_t *)nullptr,
 					      (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 27);
 	return std::max(bytes, bytes9) + 256;
@@ -382,7 +385,7 @@ void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, ui
 	if ((bits + 8) / 9 < (bits + 7) / 8 && n > (size_t(1) << 22)) // fewer places with 9-bit digits (17-18, 25-27 key bits)
 		HIP_CHECK(rocprim::radix_sort_pairs<nine>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
 	else
-		HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
+		HIP_CHECK(rocprim::radix_sort_pairs<few_launches>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
 }
 
 } // namespace povu_hip
