@@ -80,6 +80,7 @@ typedef struct {
 #define POVU_HIP_F_BIG_CLASS_DFS 64u /* always walk the classes with the filtered-scan-list DFS large classes get (A/B testing) */
 #define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with the 1-in-16 splitters lists of 2^26+ elements get (A/B testing) */
 #define POVU_HIP_F_ALL_VERTEX_CLASSES 512u /* number the cycle classes of all tree edges, not just the black ones the candidate stack holds (A/B testing) */
+#define POVU_HIP_F_CHECK_LAMINAR 1024u /* always run the laminarity check of the candidate stack's (prev, i) intervals; by default it only runs when the literal hi_2 rule capped differently from the second-highest reach, DESIGN.md section 4 has the proof for the other case (A/B testing, fuzzing) */
 #define POVU_HIP_F_SORTED_ADJ 16u /* build the local adjacency with the radix sort hub graphs use (A/B testing) */
 
 /*

@@ -318,7 +318,8 @@ __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const 
 	if (v >= V)
 		return;
 	comp_of[v] = crank[label[v]];
-	iota[v] = v;
+	if (iota)
+		iota[v] = v;
 	if (v <= C) // "no tip yet" for k_sorted_vertices' atomicMin; C <= V, and the last lane closes the array
 		start_key[v] = ~0ull;
 	if (v == V - 1)
@@ -326,38 +327,36 @@ __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const 
 }
 
 // after the stable sort by component: sorted position i holds global vertex perm[i]
+// perm == nullptr: the vertices already are in (component, idx) order.  Sorted space then IS the global vertex space:
+// no position, degree, id or tip array is written (the callers read the resident graph's own), only the component
+// boundaries and the DFS starts.
 __global__ void k_sorted_vertices(uint32_t V, uint32_t C, const uint32_t *__restrict__ ckey,
 				  const uint32_t *__restrict__ perm, const uint32_t *__restrict__ off,
 				  const uint32_t *__restrict__ vid, const uint8_t *__restrict__ tip,
 				  uint32_t *__restrict__ pos, uint32_t *__restrict__ voff, uint32_t *__restrict__ vdeg,
 				  uint32_t *__restrict__ gid_s, uint8_t *__restrict__ tip_s,
-				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats,
-				  uint32_t *__restrict__ sbase_identity)
+				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= V)
 		return;
 	if (i < 4)
 		stats[i] = 0; // stats[0] = most links on one side (k_mark_first2 / k_max_u32)
-	if (sbase_identity) { // one component: sorted order = global order, slot bases are the CSR offsets themselves
-		sbase_identity[i] = off[2 * i];
-		if (i == V - 1)
-			sbase_identity[V] = off[2 * V];
-	}
-	uint32_t v = perm[i], c = ckey[i];
-	pos[v] = i;
+	const uint32_t v = perm ? perm[i] : i, c = ckey[i];
 	if (i == 0 || ckey[i - 1] != c)
 		voff[c] = i;
 	if (i == V - 1)
 		voff[C] = V;
-	vdeg[i] = off[2 * v + 2] - off[2 * v];
-	uint32_t id = vid[v];
-	gid_s[i] = id;
-	uint8_t t = tip[v];
-	tip_s[i] = t;
+	const uint8_t t = tip[v];
+	if (perm) {
+		pos[v] = i;
+		vdeg[i] = off[2 * v + 2] - off[2 * v];
+		gid_s[i] = vid[v];
+		tip_s[i] = t;
+	}
 	// start of the spanning tree = *tips().begin(): smallest (id, then l<r), types.cpp:60-68
 	if (t)
-		atomicMin(&start_key[c], ((unsigned long long)id << 32) | (unsigned long long)(2u * i + (t == 1 ? 0u : 1u)));
+		atomicMin(&start_key[c], ((unsigned long long)vid[v] << 32) | (unsigned long long)(2u * i + (t == 1 ? 0u : 1u)));
 }
 
 // slot order of componetize's edge loop: vertices ascending, e_l then e_r ascending
@@ -453,9 +452,9 @@ __global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, con
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t cnt = 0;
 	if (S < 2 * V) {
-		uint32_t i = S >> 1, s = S & 1, v = perm[i];
+		uint32_t i = S >> 1, s = S & 1, v = perm ? perm[i] : i;
 		uint32_t b0 = off[2 * v], lo = off[2 * v + s], hi = off[2 * v + s + 1];
-		uint32_t P = sbase[i] + (lo - b0);
+		uint32_t P = (sbase ? sbase[i] : b0) + (lo - b0); // (no sbase: sorted space = global space, slot bases are the CSR offsets)
 		for (uint32_t k = lo; k < hi; k++, P++) {
 			const uint32_t o = aoth[k];
 			const bool f = slot_is_first(i, s, v, o, pos);
@@ -501,9 +500,10 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
 		return;
-	uint32_t i = S >> 1, s = S & 1, v = perm[i];
+	uint32_t i = S >> 1, s = S & 1, v = perm ? perm[i] : i;
 	uint32_t b0 = off[2 * v], lo = off[2 * v + s], hi = off[2 * v + s + 1];
-	uint32_t P = sbase[i] + (lo - b0);
+	const uint32_t sb = sbase ? sbase[i] : b0; // (no sbase: sorted space = global space)
+	uint32_t P = sb + (lo - b0);
 	const uint32_t base = loff[S];
 	uint32_t n = 0;
 	// the first four entries of a side are kept sorted in registers (almost every side has fewer) and written once;
@@ -562,10 +562,10 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 			tgray[le] = hook[adj[k]];
 			insert(le, other);
 		} else {
-			insert(erank[sbase[io] + (atwin[k] - off[2 * vo])], other);
+			insert(erank[sbase ? sbase[io] + (atwin[k] - off[2 * vo]) : atwin[k]], other);
 		}
 	}
-	lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sbase[i] + (lo - b0);
+	lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sb + (lo - b0);
 	for (uint32_t k = lo; k < hi; k++, P++) {
 		const uint32_t o = aoth[k];
 		if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
@@ -615,14 +615,15 @@ __global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *
 
 // first local edge of every component; also publishes voff / eoff / stats straight into the context's
 // page-locked host buffer [voff C+1 | eoff C+1 | stats 4] when one is given
-__global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ sbase,
+__global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ off,
+				    const uint32_t *__restrict__ sbase,
 				    const uint32_t *__restrict__ erank, uint32_t *__restrict__ eoff,
 				    const uint32_t *__restrict__ stats, uint32_t *__restrict__ host_pub)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c > C)
 		return;
-	const uint32_t vo = voff[c], eo = erank[sbase[vo]];
+	const uint32_t vo = voff[c], eo = erank[sbase ? sbase[vo] : off[2 * vo]];
 	eoff[c] = eo;
 	if (host_pub) {
 		host_pub[c] = vo;
@@ -767,33 +768,41 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	uint32_t launches = 0;
 	// stable sort of vertices by component rank: local vertex idx = rank inside the component,
 	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
-	KLAUNCH(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.tmp_a, C,
-			   (unsigned long long *)st.start_key);
 	const bool identity = C == 1 || st.comp_sorted;
-	if (identity) { // one component, or components one after the other: the order is already (component, idx); the key /
-			// permutation arrays simply alias what k_comp_of wrote (component ranks, identity permutation)
+	const bool sort_free = g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency;
+	// One component, or components one after the other in the vertex order: the order already is (component, idx), sorted
+	// space is the global vertex space.  The sort-free builder then needs no permutation, position, slot-base, id or tip
+	// array at all -- it reads the resident graph's own (slot base of vertex i = off[2 i]).
+	st.lean_identity = identity && sort_free;
+	KLAUNCH(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.lean_identity ? nullptr : st.tmp_a, C,
+			   (unsigned long long *)st.start_key);
+	if (identity) { // the key / permutation arrays simply alias what k_comp_of wrote (component ranks, identity permutation)
 		st.ckey = st.comp_of;
 		st.perm = st.tmp_a;
 	} else {
 		sort_pairs_u32(st.comp_of, st.ckey, st.tmp_a, st.perm, V, bits_for(C), st.sort_tmp, st.sort_tmp_bytes, s);
 	}
-	KLAUNCH(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.perm, g.off, g.vid, g.tip,
-			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats,
-			   identity ? st.sbase : nullptr);
-	if (!identity)
+	if (st.lean_identity) {
+		st.gid_s = g.vid;
+		st.tip_s = g.tip;
+	}
+	KLAUNCH(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.lean_identity ? nullptr : st.perm, g.off, g.vid, g.tip,
+			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats);
+	if (!st.lean_identity)
 		scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	launches += 5;
 	// first-encounter rank of every edge
-	if (g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency) {
+	if (sort_free) {
 		const uint32_t *pos_or_identity = identity ? nullptr : st.pos; // sorted order = global order: no vertex is renumbered
+		const uint32_t *perm = st.lean_identity ? nullptr : st.perm, *sbase = st.lean_identity ? nullptr : st.sbase;
 		uint8_t *first8 = reinterpret_cast<uint8_t *>(st.flag), *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
-		KLAUNCH(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.aoth, st.sbase,
-				   first8, ldeg8, st.stats);
+		KLAUNCH(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, sbase, first8, ldeg8,
+				   st.stats);
 		scan_exclusive_u8(first8, st.erank, (size_t)g.n_slots + 1, ldeg8, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
-		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin,
-				   st.sbase, st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
-		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
-				   st.eoff, st.stats, st.host_pub);
+		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin, sbase,
+				   st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
+		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, g.off, sbase, st.erank, st.eoff,
+				   st.stats, st.host_pub);
 		tm.end(launches + 7);
 		return;
 	}
@@ -809,7 +818,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			   st.tgray);
 	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
 	KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
-	KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.sbase, st.erank,
+	KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, g.off, st.sbase, st.erank,
 			   st.eoff, st.stats, st.host_pub);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	// local per-side adjacency (other side ids), ascending local edge idx

@@ -37,11 +37,12 @@ struct CompState {
 	uint32_t *lle;	   // [2E] local edge idx of every adjacency slot
 	uint8_t *tgray;	   // [E+1] local edge is in the spanning forest
 	uint32_t *stats;   // [4]  stats[0] = max links on one side
-	uint32_t *gid_s;
+	uint32_t *gid_s; // (may alias the resident graph's vid / tip: never written through)
 	uint8_t *tip_s;
 	uint64_t *start_key; // [C+1] (segment id << 32 | sorted side) of the smallest tip, ~0 if none
 	void *scan_tmp, *sort_tmp;
 	size_t scan_tmp_bytes, sort_tmp_bytes;
+	bool lean_identity; // sorted space = global vertex space and no perm / pos / sbase / vdeg was written (gid_s / tip_s alias the graph's)
 	bool comp_sorted;   // the vertices already are in (component, idx) order: re-indexing keeps every vertex where it is
 	HostScratch *host;  // pinned read-back scratch of the owning context
 	uint32_t *host_pub; // device view of a pinned [voff C+1 | eoff C+1 | stats 4] the re-index publishes into (or null)

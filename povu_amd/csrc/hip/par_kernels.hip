@@ -19,6 +19,7 @@
 #include "segtree.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace povu_hip
 {
@@ -153,23 +154,48 @@ __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, c
 // ascending idx are v+1, then each next sibling at c + size(c).  hi(c) = min target of the back edges leaving
 // subtree(c) -- the root as soon as subtree(c) holds a simplifying edge -- is only ever compared between siblings,
 // so it is evaluated on demand, for the children of branching vertices alone (range-min over hi0).
+// Root of the tree that holds tree vertex t.  The all-parallel pass keeps no per-vertex table of it (it is needed at
+// few vertices): component c owns [2 voff[c] + c, 2 voff[c+1] + c], so the component is found by bisection over voff.
+struct RootOf {
+	const uint32_t *t_root; // per-vertex table, or null: bisect
+	const uint32_t *voff;
+	uint32_t C;
+	__device__ __forceinline__ uint32_t operator()(uint32_t t) const
+	{
+		if (t_root)
+			return t_root[t];
+		uint32_t lo = 0, hi = C; // last c with 2 voff[c] + c <= t
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (2 * voff[mid] + mid <= t)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		return 2 * voff[lo] + lo;
+	}
+};
 __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
-					   const uint32_t *__restrict__ psb, const uint32_t *__restrict__ t_root,
-					   const uint32_t *__restrict__ segA, uint32_t P, uint32_t *__restrict__ cap_tgt,
+					   const uint32_t *__restrict__ psb, const RootOf &root_of,
+					   const SegTree &segA, uint32_t *__restrict__ cap_tgt,
 					   uint8_t *__restrict__ capf, uint32_t *__restrict__ literal_rule_seen)
 {
 	const uint32_t end = v + gsize[v];
+	uint32_t root = NIL; // of v's tree, looked up at most once
 	auto hi_of = [&](uint32_t c) {
 		const uint32_t cs = max(gsize[c], 1u);
-		if (psb[c + cs] != psb[c])
-			return t_root[c];
+		if (psb[c + cs] != psb[c]) {
+			if (root == NIL)
+				root = root_of(v);
+			return root;
+		}
 		if (cs <= 8) { // a small branch: its hi0 values share a cache line or two
 			uint32_t m = NIL;
 			for (uint32_t k = c; k < c + cs; k++)
 				m = min(m, hi0[k]);
 			return m;
 		}
-		return seg_min(segA, P, c, c + cs);
+		return seg_min(segA, c, c + cs);
 	};
 	// one sweep over the children: the first child that attains the minimum (hi_child), and the first two children
 	// whose hi lies above v in the tree -- hi_2 belongs to the first of them that is not hi_child
@@ -210,7 +236,7 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
 			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
 			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, const uint32_t *__restrict__ hi0,
-			  const uint32_t *__restrict__ t_root, const uint32_t *__restrict__ segA, uint32_t P,
+			  const RootOf root_of, const SegTree segA,
 			  uint32_t *__restrict__ literal_rule_seen)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,7 +269,7 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 		list[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
 	__syncthreads(); // (also orders the cap_tgt / capf defaults above before the stores of capping_of)
 	if (threadIdx.x < total)
-		capping_of(list[threadIdx.x], gsize, hi0, psb, t_root, segA, P, cap_tgt, capf, literal_rule_seen);
+		capping_of(list[threadIdx.x], gsize, hi0, psb, root_of, segA, cap_tgt, capf, literal_rule_seen);
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
@@ -253,7 +279,7 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 __global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
 				const uint32_t *__restrict__ pscap, const uint8_t *__restrict__ simp,
 				const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
-				const uint32_t *__restrict__ t_root, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
+				const RootOf root_of, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
 				const uint32_t *__restrict__ ordcnt, const uint32_t *__restrict__ gsize,
 				const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt, uint32_t *__restrict__ srccnt)
 {
@@ -270,10 +296,11 @@ __global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const u
 	}
 	if (sm) {
 		uint32_t j = NB0 + ncap + pssimp[v];
+		const uint32_t root = root_of(v);
 		b_src[j] = v;
-		b_tgt[j] = t_root[v];
+		b_tgt[j] = root;
 		if (ordcnt)
-			atomicAdd(&incnt[t_root[v]], 1u);
+			atomicAdd(&incnt[root], 1u);
 	}
 	// (dense path) brackets per source, at its place in the list order: known per vertex, no counting pass over the brackets
 	if (ordcnt && gsize[v])
@@ -347,7 +374,7 @@ struct StackPlace {
 template <bool BLACK>
 __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
 			      const uint32_t *__restrict__ mpre, const uint32_t *__restrict__ bstart,
-			      const uint32_t *__restrict__ segB, uint32_t P, const uint32_t *__restrict__ tgtR,
+			      const SegTree segB, const uint32_t *__restrict__ tgtR,
 			      const uint32_t *__restrict__ psin, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval,
 			      uint32_t *__restrict__ lsz, uint32_t *__restrict__ err, const uint32_t *__restrict__ rid,
 			      uint32_t first_simp_id, uint8_t *__restrict__ hpf, const uint32_t *__restrict__ seg_comp,
@@ -404,7 +431,7 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 				break;
 			}
 		if (i == NIL && probe_end < hi)
-			i = seg_first_less(segB, P, probe_end, hi, v);
+			i = seg_first_less(segB, probe_end, hi, v);
 	}
 	if (i == NIL) {
 		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
@@ -573,7 +600,7 @@ __global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx,
 // component, the first step of component c also drops by B_c = 2 * (entries of the component before it) + 2: further
 // than that component's walk can have climbed or fallen, so nothing in front of c ever is the minimum again (and the
 // zero of component c is simply the walk's value at its first entry, whose own U is 0).
-__global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const uint32_t *__restrict__ segP, uint32_t P,
+__global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const SegTree segP, bool check,
 			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint32_t *__restrict__ comp_bad,
 			       const uint8_t *__restrict__ dflag, uint32_t *__restrict__ walk)
 {
@@ -589,7 +616,7 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 			step -= 2 * (i - soff[cp]) + 2;
 	}
 	walk[i] = step;
-	if (p == NIL || p + 1 >= i)
+	if (!check || p == NIL || p + 1 >= i) // (!check: the class stage was exact, the intervals are laminar by construction)
 		return;
 	uint32_t lowest;
 	if (i - p <= 9) { // a class that comes back within a few entries: its neighbours' words sit next to prev[i]
@@ -597,7 +624,7 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 		for (uint32_t k = p + 1; k < i; k++)
 			lowest = min(lowest, prev[k]);
 	} else {
-		lowest = seg_min(segP, P, p + 1, i);
+		lowest = seg_min(segP, p + 1, i);
 	}
 	if (lowest < p)
 		comp_bad[s_comp[i]] = 1;
@@ -673,7 +700,7 @@ __global__ void k_levels(uint32_t S, const uint8_t *__restrict__ dflag, const ui
 }
 // PVST parent of every flubble = nearest earlier flubble of its component with a smaller level
 __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const uint32_t *__restrict__ e_i,
-			    const uint32_t *__restrict__ segL, uint32_t P, const uint32_t *__restrict__ s_comp,
+			    const SegTree segL, const uint32_t *__restrict__ s_comp,
 			    const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
 			    const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_parent)
 {
@@ -681,7 +708,7 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 	if (j >= NE)
 		return;
 	uint32_t i = e_i[j], c = s_comp[i], jb = erank[soff[c]];
-	uint32_t jp = seg_last_less(segL, P, jb, j, lev[j]);
+	uint32_t jp = seg_last_less(segL, jb, j, lev[j]);
 	uint64_t pb = (uint64_t)jb + cproc_ps[c]; // dense: flubbles emitted before + one root per earlier component
 	p_parent[pb + 1 + (j - jb)] = jp == NIL ? 0u : 1 + (jp - jb);
 }
@@ -747,8 +774,7 @@ __global__ void k_hp_inputs(uint32_t T, const uint32_t *__restrict__ gsize, cons
 __global__ void k_hp_close(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ t_root,
 			   const uint32_t *__restrict__ t_comp, const uint32_t *__restrict__ c_ntree,
 			   const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ a_close,
-			   const uint32_t *__restrict__ s1, uint32_t P1, const uint32_t *__restrict__ s2, uint32_t P2,
-			   const uint32_t *__restrict__ s3, uint32_t P3, uint8_t *__restrict__ push,
+			   const SegTree s1, const SegTree s2, const SegTree s3, uint8_t *__restrict__ push,
 			   unsigned long long *__restrict__ b12)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,13 +785,13 @@ __global__ void k_hp_close(uint32_t T, const uint32_t *__restrict__ gsize, const
 		return;
 	const uint32_t base = t_root[c], end = base + c_ntree[t_comp[c]];
 	// previous closer in processing order = nearest closer with a larger idx
-	const uint32_t cp = seg_first_less(s3, P3, c + 1, end, 1u);
+	const uint32_t cp = seg_first_less(s3, c + 1, end, 1u);
 	const uint32_t hi = cp == NIL ? end : cp + 1; // window (c, hi)
-	const uint32_t smin = seg_first_less(s1, P1, c + 1, hi, 1u);
+	const uint32_t smin = seg_first_less(s1, c + 1, hi, 1u);
 	if (smin == NIL)
 		return; // no simplifying vertex since the previous closer: not in a hairpin
-	const uint32_t smax = seg_last_less(s1, P1, c + 1, hi, 1u);
-	const uint32_t q = seg_first_less(s2, P2, c + 1, smax, 1u);
+	const uint32_t smax = seg_last_less(s1, c + 1, hi, 1u);
+	const uint32_t q = seg_first_less(s2, c + 1, smax, 1u);
 	push[c] = 1;
 	b12[2 * (size_t)c] = t_gid[smin];
 	b12[2 * (size_t)c + 1] = q == NIL ? (unsigned long long)NIL : (unsigned long long)t_gid[q];
@@ -806,8 +832,8 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 	uint8_t *push = pw.f8a;
 	uint32_t *pps = pw.psA;
 	unsigned long long *b12 = (unsigned long long *)pw.b_key; // free after the class stage, >= 2T entries
-	LAUNCH(k_hp_close, T, s, T, pw.gsize, pw.t_root, pw.t_comp, sw.c_ntree, sw.t_gid, pw.hp3, pw.segH1.tree, pw.segH1.P,
-	       pw.segH2.tree, pw.segH2.P, pw.segH3.tree, pw.segH3.P, push, b12);
+	LAUNCH(k_hp_close, T, s, T, pw.gsize, pw.t_root, pw.t_comp, sw.c_ntree, sw.t_gid, pw.hp3, pw.segH1, pw.segH2, pw.segH3, push,
+	       b12);
 	scan_exclusive_u8(push, pps, (size_t)T + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_hp_emit, T, s, T, push, pps, pw.t_root, pw.t_comp, sw.c_ntree, cs.voff, b12, (unsigned long long *)sw.hairpins,
 	       sw.c_nbry);
@@ -842,17 +868,17 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
 	take((void **)&pw.doff, (Cmax + 2) * 4);
 	take((void **)&pw.err, 64);
-	take((void **)&pw.segA.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
-	take((void **)&pw.segB.tree, 2 * (size_t)SegTree::pow2(NB + 1) * 4);
-	take((void **)&pw.segP.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
-	take((void **)&pw.segL.tree, 2 * (size_t)SegTree::pow2(S + 1) * 4);
+	take((void **)&pw.segA.tree, SegTree::tree_words(T + 1) * 4);
+	take((void **)&pw.segB.tree, SegTree::tree_words(NB + 1) * 4);
+	take((void **)&pw.segP.tree, SegTree::tree_words(S + 1) * 4);
+	take((void **)&pw.segL.tree, SegTree::tree_words(S + 1) * 4);
 	take((void **)&pw.stage, ((S + Cmax + 2) * 4 + 64) * 3 + ((S + Cmax + 2) + 64) * 2 + 256);
 	take((void **)&pw.hpf, T + 2);
 	for (uint32_t **p : {&pw.hp1, &pw.hp2, &pw.hp3})
 		take((void **)p, (T + 2) * 4);
-	take((void **)&pw.segH1.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
-	take((void **)&pw.segH2.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
-	take((void **)&pw.segH3.tree, 2 * (size_t)SegTree::pow2(T + 1) * 4);
+	take((void **)&pw.segH1.tree, SegTree::tree_words(T + 1) * 4);
+	take((void **)&pw.segH2.tree, SegTree::tree_words(T + 1) * 4);
+	take((void **)&pw.segH3.tree, SegTree::tree_words(T + 1) * 4);
 	pw.scan_tmp_bytes = scan_tmp_bytes(std::max(T, NB) + 4);
 	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), std::max(4 * V, 2 * E) + 8) + 4);
 	take(&pw.scan_tmp, pw.scan_tmp_bytes);
@@ -884,7 +910,7 @@ __global__ void k_summary(uint32_t C, const uint32_t *__restrict__ err, const ui
 		return;
 	if (i == 0) {
 		out[0] = err ? err[0] : 0;
-		out[1] = err ? err[1] : 0;
+		out[1] = err ? (err[1] | (err[8] << 1)) : 0; // bit 0: list ranking, bit 1: stack pool of the class walk
 		out[2] = err ? err[2] : 0;
 		out[3] = err ? err[3] : 0;
 	}
@@ -928,10 +954,20 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 
 	// ---- T-space + dense back edges
 	tm.begin("par_setup");
-	LAUNCH(k_tcomp_vertices, V, s, V, T, cs.ckey, cs.voff, pw.t_comp);
-	LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0,
-	       dense_nb0 >= 0 ? nullptr : pw.cov, sw.t_depth,
-	       pw.mpre, pw.incnt, pw.dlt);
+	// All-parallel pass: the tree stage wrote sizes (0 = no vertex in this slot), parents (only ever tested against NIL), the
+	// mirror pre-order and the cleared bracket counts in T-space itself; the root of a vertex's tree is looked up where it
+	// is needed.  A sequential tree stage works per component: its arrays are brought into that form here, and the
+	// hairpin report wants the per-vertex tables too.
+	const bool lean = dense_nb0 >= 0 && !want_hp;
+	if (lean) {
+		pw.gsize = sw.t_size;
+		pw.gpar = sw.t_par;
+	} else {
+		LAUNCH(k_tcomp_vertices, V, s, V, T, cs.ckey, cs.voff, pw.t_comp);
+		LAUNCH(k_globalize, T, s, T, pw.t_comp, cs.voff, sw.c_ntree, sw.t_par, sw.t_size, pw.gpar, pw.gsize, pw.t_root, pw.hi0,
+		       dense_nb0 >= 0 ? nullptr : pw.cov, sw.t_depth, pw.mpre, pw.incnt, pw.dlt);
+	}
+	const RootOf root_of{lean ? nullptr : pw.t_root, cs.voff, C};
 	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
@@ -957,8 +993,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, pw.hi0, pw.t_root,
-	       pw.segA.tree, pw.segA.P, pw.err + 5);
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, pw.hi0, root_of,
+	       pw.segA, pw.err + 5);
 	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	uint32_t *extra = pw.host->take<uint32_t>(3);
@@ -977,7 +1013,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// both take the all-vertices pass.
 	const bool black_only = !want_hp && !pw.all_vertex_classes && extra[2] == 0;
 	pw.black_only_used = black_only;
-	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, pw.t_root, pw.b_src, pw.b_tgt,
+	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
 	       dense_nb0 >= 0 ? pw.lsz : nullptr, pw.gsize, pw.mpre, pw.incnt, srccnt);
 	if (dense_nb0 >= 0) { // ranks inside every source and the counts per source are known: place directly
 		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
@@ -1006,7 +1042,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		uint32_t *shift_ps = pw.topi; // (dlt_ps still holds the bracket range starts; nobody needs vertex -> stack index here)
 		scan(pw.dlt, shift_ps, (size_t)V + 1);
 		const StackPlace sp{cs.voff, pw.soff, pw.dlt, shift_ps, pw.s_vtx, pw.s_comp};
-		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
+		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB, pw.tgtR, pw.psin, ck,
 		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree, sp);
 		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
@@ -1021,7 +1057,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		pw.s_cls_valid = false; // (cflag, the sorted keys and their stack indices stay where they are for stack_class_ids)
 	} else {
 		const StackPlace none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-		LAUNCH(k_top_bracket<false>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB.tree, pw.segB.P, pw.tgtR, pw.psin, ck,
+		LAUNCH(k_top_bracket<false>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB, pw.tgtR, pw.psin, ck,
 		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, want_hp ? pw.hpf : nullptr, nullptr, nullptr, none);
 		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		LAUNCH(k_class_flags<false>, std::max<size_t>(NC, (size_t)V + 2), s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt,
@@ -1086,8 +1122,13 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		KLAUNCH(k_emit_endpoints, dim3(nblk(S)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
 			sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	}
-	seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
-	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP.tree, pw.segP.P, pw.s_comp, pw.soff, pw.comp_bad, dflag, pw.walk);
+	// The (prev, i) intervals of exact cycle-equivalence classes never cross ("Row G"): the check is
+	// only needed when the literal hi_2 rule capped differently from the second-highest reach (extra[2]), i.e. when the
+	// classes may not be the exact ones -- or when a caller asks for it.
+	pw.laminar_checked = pw.check_laminar || extra[2] != 0;
+	if (pw.laminar_checked)
+		seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
+	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, pw.comp_bad, dflag, pw.walk);
 	scan(pw.walk, pw.walk_ps, (size_t)S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
@@ -1095,7 +1136,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan_exclusive_max_u32(wneg, wrun, (size_t)S, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
-	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL.tree, pw.segL.P, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
+	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
 	       pw.d_parent);
 	if (staged)
 		HIP_CHECK(hipMemcpyAsync(host_blk + 2 * p4, blk + 2 * p4, p4, hipMemcpyDeviceToHost, s));

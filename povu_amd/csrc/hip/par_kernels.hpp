@@ -9,10 +9,15 @@
 namespace povu_hip
 {
 
-// Array-based min segment tree over n values (padded to a power of two with +inf).
+// Min segment tree over n values, kept COARSE: its leaves are the minima of blocks of SEG_BLK consecutive values, the
+// values themselves stay where they are (val must outlive the queries).  A query reads the one or two blocks at its ends
+// as whole cache lines and walks the tree only over the blocks in between: 1/16 of the writes of a full tree, and the
+// short ranges most queries have never touch it (segtree.hpp).
 struct SegTree {
-	uint32_t *tree = nullptr; // [2P], node 1 = root, leaves at [P, 2P)
-	uint32_t P = 1;
+	uint32_t *tree = nullptr;     // [2P], node 1 = root, block minima at [P, 2P)
+	const uint32_t *val = nullptr; // [n] the values (16-byte aligned, readable up to the next multiple of SEG_BLK)
+	uint32_t P = 1;		      // blocks, padded to a power of two with +inf
+	static constexpr uint32_t BLK = 16;
 	static uint32_t pow2(size_t n)
 	{
 		uint32_t p = 1;
@@ -20,12 +25,15 @@ struct SegTree {
 			p <<= 1;
 		return p;
 	}
+	static size_t tree_words(size_t n) { return 2 * (size_t)pow2((n + BLK - 1) / BLK + 1); }
 };
 
 struct ParWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	uint32_t V, E, C, T;
 	bool all_vertex_classes = false; // in: number the classes of all tree edges even when the black ones would do (A/B tests)
+	bool check_laminar = false;	 // in: run the laminarity check of the candidate stack even when the class stage was exact
+	bool laminar_checked = false;	 // out: the last pass ran it
 	bool black_only_used = false;	 // out: the last pass numbered the classes of the black tree edges only
 	bool s_cls_valid = false;	 // s_cls holds class ids (a black-only pass numbers its classes only when a debug hook asks)
 	bool gcls_valid = false;	 // gcls holds the classes in T-space (a black-only pass keeps them in stack order only)

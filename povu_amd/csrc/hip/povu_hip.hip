@@ -598,6 +598,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				ctx->tree_in_par = true;
 			}
 			ctx->pw.all_vertex_classes = (o.flags & POVU_HIP_F_ALL_VERTEX_CLASSES) != 0;
+			ctx->pw.check_laminar = (o.flags & POVU_HIP_F_CHECK_LAMINAR) != 0;
 			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
 			ctx->stack_export_pending = true;
 			ctx->classes_in_par = true;
@@ -606,8 +607,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			sum = read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
-			if (sum[1])
+			if (sum[1] & 1u)
 				throw HipError("list ranking: splitter capacity exceeded (internal sizing bug)");
+			if (sum[1] & 2u)
+				throw HipError("class walk: stack pool exhausted (internal sizing bug)");
 			if (sum[2])
 				throw HipError("spanning forest of the links has the wrong size (internal)");
 			if (sum[3])
@@ -990,7 +993,10 @@ extern "C" int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, u
 		const uint32_t V = ctx->g.V, C = ctx->C;
 		std::vector<uint32_t> pos(V), voff(C + 1);
 		HIP_CHECK(hipMemcpy(comp_of, ctx->cs.comp_of, (size_t)V * 4, hipMemcpyDeviceToHost));
-		HIP_CHECK(hipMemcpy(pos.data(), ctx->cs.pos, (size_t)V * 4, hipMemcpyDeviceToHost));
+		if (ctx->cs.lean_identity)
+			std::iota(pos.begin(), pos.end(), 0u);
+		else
+			HIP_CHECK(hipMemcpy(pos.data(), ctx->cs.pos, (size_t)V * 4, hipMemcpyDeviceToHost));
 		HIP_CHECK(hipMemcpy(voff.data(), ctx->cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost));
 		for (uint32_t v = 0; v < V; v++)
 			local_idx[v] = pos[v] - voff[comp_of[v]];

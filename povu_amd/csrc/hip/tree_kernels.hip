@@ -612,14 +612,13 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 			  const uint32_t *__restrict__ loff,
 			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi,
-			  uint2 *__restrict__ dps, uint8_t *__restrict__ dvis,
-			  uint8_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
+			  uint2 *__restrict__ dps, uint8_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	uint2 rec = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}: one word pair, one store
-	uint8_t vis = 0, ef = 0;
+	uint8_t ef = 0;
 	// forest parent, bridge bit and visited bit of a side in ONE word: the walk tests "not yet visited" with one load, and
 	// that covers "not across a bridge" too on the way down (see section 4)
 	const bool proc = cproc[ckey[S >> 1]] != 0;
@@ -628,7 +627,6 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 	cstate[S] = proc ? (p0 | (entry ? CS_VISITED : 0u)) : NIL;
 	if (entry) {
 		// a class is walked from its entry side; a side that is alone in its class has nothing to walk
-		vis = 1;
 		ef = multi[S] ? 1 : 0;
 		if (p0 != NIL) { // (NIL: DFS start of the component)
 			const uint32_t p = p0 & ~PB_BRIDGE;
@@ -647,7 +645,6 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 		}
 	}
 	dps[S] = rec;
-	dvis[S] = vis;
 	entry_flag[S] = ef;
 }
 __global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
@@ -659,41 +656,71 @@ __global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const ui
 }
 
 // ------------------------------------------------------------------ 6. the DFS inside every class
-// One lane walks one class, so a step costs its chain of dependent loads (HBM / Infinity-Cache latency):
-// keep that chain short.  k_class_adj filters every side's scan list [black edge, links by local edge idx]
-// down to the neighbours of its own class, i.e. those not across a bridge (entry = {side, scan slot}) and packs {begin, count, first entry}
-// per side.  Going down then costs ONE load level (the candidate's visited byte and its packed record, which
-// already carries ITS first candidate), skipping a visited candidate costs one (the candidate behind it is loaded with
-// it), coming back one (the child keeps its parent's scan state {parent, begin, count, next} and the parent's next
-// candidate).
-__global__ void k_class_adj(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			    const uint32_t *__restrict__ pbr, const uint32_t *__restrict__ ckey,
-			    const uint32_t *__restrict__ cproc, uint2 *__restrict__ cadj, uint4 *__restrict__ rb)
+// Small classes (a bubble: a handful of sides) are walked by ONE LANE each, millions at a time (k_class_dfs_small).
+// A class that turns out larger than CLASS_BUDGET sides is handed to the WAVE-COOPERATIVE walk below, one wave per
+// class: lexicographic DFS is sequential, so the time of a large class is (sides) x (dependent load levels per side)
+// and the wave exists to cut the levels, not to share the sides.
+//
+// k_class_recs filters every side's scan list [black edge, links by local edge idx] down to the neighbours of its own
+// class (those not across a bridge) and packs a 32-byte record {count, overflow begin, first six candidates}.
+//  * going DOWN costs one level: the lanes load the visited word AND the record of every candidate of the current side at
+//    once, a ballot picks the first unvisited one, its record already sits in a lane.  Candidates that are visited
+//    already -- most of them, deep inside a tangle -- cost nothing (the one-lane walk paid a round trip for each).
+//  * a side is only remembered on the stack when the ballot showed ANOTHER unvisited candidate behind the chosen one
+//    (visited is monotone: a side without one never needs a second look), so most returns never happen.
+//  * coming BACK pops up to 64 stack entries at once: every lane re-checks the remaining candidates of one entry, a
+//    ballot finds the nearest entry that still has an unvisited candidate.
+// The top 64 entries of the stack live in LDS together with their records; older ones move out to an array in HBM
+// (chunks that double in size, taken from one pool with an atomic add, so a class needs no size in advance: a stack
+// that ever held d > 64 entries belongs to a class of more than d sides and takes less than 64 + 2 d entries of the pool,
+// under three per side).
+static constexpr uint32_t W_UNVIS = 0xFFFFFFFEu;  // wpar: side not reached yet
+static constexpr uint32_t W_INLINE = 6;		  // candidates inside the record
+static constexpr uint32_t W_CHUNK0 = 64;	  // first chunk of a stack's HBM array (entries); chunk c >= 1 holds W_CHUNK0 << (c - 1)
+struct WalkRec { // 32 bytes
+	uint32_t n, begin, c[W_INLINE];
+};
+__global__ void k_class_recs(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
+			     const uint32_t *__restrict__ pbr, const uint32_t *__restrict__ ckey,
+			     const uint32_t *__restrict__ cproc, uint32_t *__restrict__ wadj, uint4 *__restrict__ wrec,
+			     uint32_t *__restrict__ wpar)
 {
 	uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
 	if (u >= nS)
 		return;
 	const uint32_t lo = loff[u], hi = loff[u + 1], base = lo + u; // deg + 1 slots per side
-	uint32_t n = 0;
-	uint2 first = make_uint2(NIL, 0u);
+	uint32_t n = 0, c[W_INLINE] = {NIL, NIL, NIL, NIL, NIL, NIL};
+	uint32_t vis = W_UNVIS;
 	if (cproc[ckey[u >> 1]]) {
 		const uint32_t mine = pbr[u];
-		auto same_class = [&](uint32_t o) { return mine != (o | PB_BRIDGE) && pbr[o] != (u | PB_BRIDGE); }; // no bridge between
-		if (same_class(u ^ 1u)) {
-			first = make_uint2(u ^ 1u, 0u);
-			cadj[base + n++] = first;
-		}
+		if (mine & PB_BRIDGE)
+			vis = 0u; // the entry of its class (or a DFS start): never walked into
+		auto same_class = [&](uint32_t o) { return o != u && mine != (o | PB_BRIDGE) && pbr[o] != (u | PB_BRIDGE); }; // no bridge between
+		auto put = [&](uint32_t o) {
+			if (n < W_INLINE) {
+#pragma unroll
+				for (uint32_t k = 0; k < W_INLINE; k++)
+					if (k == n)
+						c[k] = o;
+			} else {
+				if (n == W_INLINE) // the list spills: the overflow array holds ALL candidates, in order
+					for (uint32_t k = 0; k < W_INLINE; k++)
+						wadj[base + k] = c[k];
+				wadj[base + n] = o;
+			}
+			n++;
+		};
+		if (same_class(u ^ 1u))
+			put(u ^ 1u);
 		for (uint32_t k = lo; k < hi; k++) {
 			const uint32_t o = ladj[k];
-			if (same_class(o)) {
-				const uint2 e = make_uint2(o, k - lo + 1);
-				if (!n)
-					first = e;
-				cadj[base + n++] = e;
-			}
+			if (same_class(o))
+				put(o);
 		}
 	}
-	rb[u] = make_uint4(base, n, first.x, first.y);
+	wrec[2 * (size_t)u] = make_uint4(n, base, c[0], c[1]);
+	wrec[2 * (size_t)u + 1] = make_uint4(c[2], c[3], c[4], c[5]);
+	wpar[u] = vis;
 }
 // the plain walk (small classes only; no filtering pass).  Dependent loads per tree edge: the candidate's adjacency
 // entry and its state word on the way down; {parent, slot} of the finished side and the parent's list bounds on the way
@@ -760,91 +787,179 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(uint32_t n_entry, const 
 		}
 	}
 }
-// The loop is software-pipelined by hand.  vmcnt counts loads AND stores of a wave in issue order, so "wait for this
-// load" also waits for every store issued before it: a walk that stores the child's records and then loads the next
-// candidate pays a store round trip per step.  Here the loads for the NEXT step are issued first, the stores of this
-// step behind them, and the loaded registers are pinned (empty asm) at the end of each branch so that the wait the
-// compiler inserts there lets exactly the younger stores stay in flight.
-#define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
-__global__ void k_class_dfs(uint32_t n_entry, const uint32_t *__restrict__ entry_list, const uint2 *__restrict__ cadj,
-			    const uint4 *__restrict__ rb, uint2 *__restrict__ dps,
-			    uint8_t *dvis, uint4 *__restrict__ ret, uint2 *__restrict__ retc, uint32_t lane_stride)
+// ---- the wave-cooperative walk (see the head of this section)
+struct WalkStackEntry { // one remembered side: 40 bytes in LDS, {u, j} in HBM
+	uint32_t u, j; // side, first candidate index still to look at
+	uint4 r0, r1;  // its record
+};
+__device__ __forceinline__ uint32_t wstk_addr(uint32_t d, const uint32_t *chunk_base)
 {
-	// lane_stride = 64: one class per WAVE (the walks of large classes diverge completely; lanes of one wave would take turns)
-	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t % lane_stride)
+	const uint32_t c = d < W_CHUNK0 ? 0u : 32u - (uint32_t)__clz(d / W_CHUNK0);
+	return chunk_base[c] + (d - (c ? (W_CHUNK0 << (c - 1)) : 0u));
+}
+__device__ __forceinline__ uint32_t wrec_cand(const uint4 &r0, const uint4 &r1, uint32_t k)
+{
+	return k == 0 ? r0.z : k == 1 ? r0.w : k == 2 ? r1.x : k == 3 ? r1.y : k == 4 ? r1.z : r1.w;
+}
+__global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const uint32_t *__restrict__ entry_list,
+							 const uint4 *__restrict__ wrec, const uint32_t *__restrict__ wadj,
+							 uint32_t *wpar, uint2 *wstk, uint32_t *__restrict__ pool_top, uint32_t pool_cap,
+							 uint32_t *__restrict__ err)
+{
+	__shared__ WalkStackEntry ring[64];
+	__shared__ uint32_t chunk_base[32];
+	const uint32_t lane = threadIdx.x;
+	if (blockIdx.x >= n_entry)
 		return;
-	const uint32_t i = t / lane_stride;
-	if (i >= n_entry)
-		return;
-	const uint32_t s = entry_list[i];
-	uint32_t u = s, k = 0;
-	uint4 r = rb[u];			 // {begin, count, candidate 0}
-	uint2 e = make_uint2(r.z, r.w);		 // candidate k of u (valid while k < count)
-	// loaded for candidate e: its packed record (speculative), its visited byte, the candidate behind it (one past a
-	// list is the next side's first entry or padding)
-	uint4 rn = make_uint4(0, 0, 0, 0);
-	uint32_t seen = 1;
-	uint2 e2 = make_uint2(NIL, 0u);
-	if (r.y) {
-		rn = rb[e.x];
-		seen = dvis[e.x];
-		e2 = cadj[r.x + 1];
-	}
+	uint32_t u = entry_list[blockIdx.x]; // (uniform)
+	uint4 r0 = wrec[2 * (size_t)u], r1 = wrec[2 * (size_t)u + 1];
+	uint32_t j0 = 0;
+	uint32_t depth = 0, lds_lo = 0, n_chunks = 0; // stack entries; first entry cached in LDS; chunks taken from the pool
 	for (;;) {
-		// a run of descents is a loop of its own: one way in, one way round, so the compiler's wait in front of the next
-		// round counts exactly the four stores behind the loads
-		while (k < r.y && !seen && e.x != u) { // (e.x == u: a link from a side to itself, its visited byte was read before it was set)
-			const uint32_t child = e.x;
-			// next step first: candidate 0 of the child ...
-			const uint2 ne = make_uint2(rn.z, rn.w);
-			uint4 nrn = make_uint4(0, 0, 0, 0);
-			uint32_t nseen = 1;
-			uint2 ne2 = make_uint2(NIL, 0u);
-			if (rn.y) {
-				nrn = rb[ne.x];
-				nseen = dvis[ne.x];
-				ne2 = cadj[rn.x + 1];
-			}
-			// ... then the child's records
-			dvis[child] = 1;
-			dps[child] = make_uint2(u, e.y);
-			ret[child] = make_uint4(u, r.x, r.y, k + 1);
-			retc[child] = e2;
-			u = child;
-			r = rn;
-			k = 0;
-			e = ne;
-			rn = nrn;
-			seen = nseen;
-			e2 = ne2;
-			PIN3(rn.x, seen, e2.x);
+		// ---- look at the candidates [j0, j0 + 64) of u: one level for visited words and records together
+		const uint32_t n = r0.x, idx = j0 + lane;
+		uint32_t cand = NIL;
+		if (idx < n)
+			cand = n <= W_INLINE ? wrec_cand(r0, r1, idx) : wadj[r0.y + idx];
+		uint32_t vp = 0;
+		uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+		if (cand != NIL) {
+			vp = wpar[cand];
+			c0 = wrec[2 * (size_t)cand];
+			c1 = wrec[2 * (size_t)cand + 1];
 		}
-		if (k < r.y) { // a visited candidate: on to the one behind it
-			k++;
-			e = e2;
-			if (k < r.y) {
-				rn = rb[e.x];
-				seen = dvis[e.x];
-				e2 = cadj[r.x + k + 1];
+		const unsigned long long m = __ballot(cand != NIL && vp == W_UNVIS);
+		const bool beyond = j0 + 64 < n; // (sides with more than 64 class neighbours: the next window)
+		if (m) {
+			const int f = __ffsll((long long)m) - 1;
+			const uint32_t child = __shfl(cand, f);
+			// another unvisited candidate behind the chosen one (a second slot of the same side counts: harmless)?
+			if ((m & (m - 1)) || beyond) {
+				const uint32_t d = depth;
+				if (d - lds_lo == 64) {
+					// the cache is full: its oldest entry moves out to the HBM array (a stack that never holds more than
+					// 64 entries -- every small class -- never touches the pool)
+					const uint32_t ev = lds_lo;
+					if (ev == (n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : 0u)) { // the array grows into a new chunk
+						uint32_t base = 0;
+						if (lane == 0) {
+							const uint32_t sz = n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : W_CHUNK0;
+							base = atomicAdd(pool_top, sz);
+							if (base + sz > pool_cap || n_chunks >= 31) {
+								atomicExch(err, 1u);
+								base = NIL;
+							}
+							chunk_base[n_chunks] = base;
+						}
+						base = __shfl(base, 0);
+						if (base == NIL)
+							return; // (cannot happen: see the pool's size; the host stops the pass on err)
+						n_chunks++;
+					}
+					if (lane == 0) {
+						const WalkStackEntry &o = ring[ev & 63u];
+						wstk[wstk_addr(ev, chunk_base)] = make_uint2(o.u, o.j);
+					}
+					lds_lo = ev + 1;
+				}
+				if (lane == 0) {
+					WalkStackEntry &e = ring[d & 63u];
+					e.u = u;
+					e.j = j0 + (uint32_t)f + 1u;
+					e.r0 = r0;
+					e.r1 = r1;
+				}
+				depth = d + 1;
 			}
+			if (lane == 0)
+				wpar[child] = u;
+			u = child;
+			r0.x = __shfl(c0.x, f), r0.y = __shfl(c0.y, f), r0.z = __shfl(c0.z, f), r0.w = __shfl(c0.w, f);
+			r1.x = __shfl(c1.x, f), r1.y = __shfl(c1.y, f), r1.z = __shfl(c1.z, f), r1.w = __shfl(c1.w, f);
+			j0 = 0;
 			continue;
 		}
-		if (u == s)
-			break;
-		const uint4 back = ret[u]; // (two loads, one level)
-		const uint2 bc = retc[u];
-		u = back.x;
-		r.x = back.y;
-		r.y = back.z;
-		k = back.w;
-		e = bc;
-		if (k < r.y) {
-			rn = rb[e.x];
-			seen = dvis[e.x];
-			e2 = cadj[r.x + k + 1];
+		if (beyond) {
+			j0 += 64;
+			continue;
+		}
+		// ---- u is finished: back to the nearest remembered side that still has an unvisited candidate
+		bool found = false;
+		while (!found) {
+			if (depth == 0)
+				return; // the class is walked
+			__syncthreads(); // (one wave: orders lane 0's LDS writes of the pushes before the reads below)
+			if (lds_lo >= depth) { // nothing cached: fetch the top entries (two levels per 64 pops)
+				const uint32_t cnt = min(depth, 64u);
+				if (lane < cnt) {
+					const uint32_t d = depth - 1 - lane;
+					const uint2 e = wstk[wstk_addr(d, chunk_base)];
+					WalkStackEntry &w = ring[d & 63u];
+					w.u = e.x;
+					w.j = e.y;
+					w.r0 = wrec[2 * (size_t)e.x];
+					w.r1 = wrec[2 * (size_t)e.x + 1];
+				}
+				lds_lo = depth - cnt;
+				__syncthreads();
+			}
+			const uint32_t cnt = depth - lds_lo; // 1 .. 64 cached entries, lane l looks at entry depth - 1 - l
+			bool has = false;
+			uint32_t eu = 0, ej = 0;
+			uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
+			if (lane < cnt) {
+				const WalkStackEntry &w = ring[(depth - 1 - lane) & 63u];
+				eu = w.u, ej = w.j, e0 = w.r0, e1 = w.r1;
+				if (e0.x > W_INLINE) {
+					has = true; // a long list: let the window scan above decide
+				} else {
+					uint32_t v[W_INLINE];
+#pragma unroll
+					for (uint32_t k = 0; k < W_INLINE; k++)
+						v[k] = (k >= ej && k < e0.x) ? wpar[wrec_cand(e0, e1, k)] : 0u;
+#pragma unroll
+					for (uint32_t k = 0; k < W_INLINE; k++)
+						has = has || v[k] == W_UNVIS;
+				}
+			}
+			const unsigned long long hm = __ballot(has);
+			if (!hm) {
+				depth -= cnt;
+				continue;
+			}
+			const int l = __ffsll((long long)hm) - 1;
+			depth -= (uint32_t)l + 1u; // the entries above it are done for good; it is re-pushed if it keeps a candidate
+			u = __shfl(eu, l);
+			j0 = __shfl(ej, l);
+			r0.x = __shfl(e0.x, l), r0.y = __shfl(e0.y, l), r0.z = __shfl(e0.z, l), r0.w = __shfl(e0.w, l);
+			r1.x = __shfl(e1.x, l), r1.y = __shfl(e1.y, l), r1.z = __shfl(e1.z, l), r1.w = __shfl(e1.w, l);
+			if (lds_lo > depth)
+				lds_lo = depth;
+			found = true;
 		}
 	}
+}
+// the wave walk leaves the DFS parent of every side it reached in wpar; the scan slot the parent found it through is
+// the black edge (slot 0) or the first link of the parent that leads to it
+__global__ void k_walk_finish(uint32_t nS, const uint32_t *__restrict__ wpar, const uint32_t *__restrict__ pbr,
+			      const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, uint2 *__restrict__ dps)
+{
+	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	const uint32_t p = wpar[S];
+	if (p == W_UNVIS || (pbr[S] & PB_BRIDGE))
+		return; // not reached by a wave walk / an entry (k_entries wrote its record)
+	uint32_t slot = 0;
+	if (S != (p ^ 1u)) {
+		const uint32_t lo = loff[p], hi = loff[p + 1];
+		for (uint32_t k = lo; k < hi; k++)
+			if (ladj[k] == S) {
+				slot = k - lo + 1;
+				break;
+			}
+	}
+	dps[S] = make_uint2(p, slot);
 }
 
 // ------------------------------------------------------------------ 7. pre-order of the union tree
@@ -936,14 +1051,29 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			    const unsigned long long *__restrict__ start_key, const uint32_t *__restrict__ gid_s,
 			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
 			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx,
-			    uint32_t C, uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0)
+			    uint32_t C, uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0,
+			    uint32_t *__restrict__ mpre, uint32_t *__restrict__ srccnt)
 {
+	// The class stage works on the tree in T-space (component c owns [2 voff[c] + c, 2 voff[c+1] + c]) and reads, per tree
+	// vertex: t_size (0 marks a slot without a vertex), t_par (NIL = root), mpre = mirror pre-order (children visited in
+	// DESCENDING idx: the order brackets sit in a bracket list, each child's list is spliced in front of its earlier
+	// siblings', flubbles.cpp:586-588; with q(v) = mpre(v) + v + size(v) one gets q(child) = q(parent) + 1, hence
+	// mpre(v) = depth(v) + N - v - size(v) in local indices) and srccnt (brackets per mirror pre-order position, written for
+	// every vertex later: only the slots without a vertex are cleared here).  All of it is written right here.
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	if (S == 0) {
+		const uint32_t T = 2 * (nS >> 1) + C;
+		hi0[T] = NIL;
+		srccnt[T] = srccnt[T + 1] = 0;
+	}
 	if (S < C) { // tree size of component S and its dummy root (spanning_tree.cpp:397-402)
+		const uint32_t Nr = 2 * (voff[S + 1] - voff[S]), tr = 2 * voff[S] + S;
 		if (!cproc[S]) {
 			c_ntree[S] = 0;
+			t_size[tr + Nr] = 0; // the spare slot (the sides clear their own two below)
+			srccnt[tr + Nr] = 0;
 		} else {
-			const uint32_t Nr = 2 * (voff[S + 1] - voff[S]), hr = start_key[S] != ~0ull ? 1u : 0u, tr = 2 * voff[S] + S;
+			const uint32_t hr = start_key[S] != ~0ull ? 1u : 0u;
 			c_ntree[S] = Nr + hr;
 			if (hr) {
 				t_gid[tr] = NIL;
@@ -951,8 +1081,12 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 				t_par[tr] = NIL;
 				t_size[tr] = Nr + 1;
 				t_depth[tr] = 0;
+				mpre[tr] = tr;
 				ordcnt[tr] = 0; // (a dummy root has no back edges of its own; every other tree vertex gets these from k_back_edges)
 				hi0[tr] = NIL;
+			} else {
+				t_size[tr + Nr] = 0;
+				srccnt[tr + Nr] = 0;
 			}
 		}
 	}
@@ -960,10 +1094,14 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 		return;
 	uint32_t c = ckey[S >> 1];
 	side_tidx[S] = NIL;
-	if (!cproc[c])
-		return;
-	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u;
 	const uint32_t tb = 2 * voff[c] + c, g = S >> 1;
+	if (!cproc[c]) {
+		const uint32_t t = tb + (S - 2 * voff[c]);
+		t_size[t] = 0;
+		srccnt[t] = 0;
+		return;
+	}
+	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u;
 	// cd[event] = {sides entered from this event to the end of the list, net depth change from here to the end}
 	const uint2 ent = cd[3 * g], lv_o = cd[3 * g + 1];
 	const uint32_t p = dps[S].x;
@@ -984,12 +1122,13 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 		else
 			par = hd + (Nh - cd[3 * (p >> 1)].x) + (dps[p].x == (p ^ 1u) ? 1u : 0u);
 	}
-	const uint32_t t = tb + hd + pre;
+	const uint32_t l = hd + pre, t = tb + l;
 	t_gid[t] = gid_s[g];
 	t_flags[t] = (uint8_t)((S & 1) | (far ? TF_BLACK : 0));
 	t_par[t] = par;
 	t_size[t] = size;
 	t_depth[t] = depth + hd;
+	mpre[t] = tb + (depth + hd) + (Nh + hd) - l - size;
 	side_tidx[S] = t;
 }
 // back edges of from_bd out of side S, in scan order (process_edge, spanning_tree.cpp:360-398):
@@ -1255,10 +1394,10 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.dps, nS * 8);
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.entry_flag, nS + 16);
-	take((void **)&tw.cadj, (nS + 2 * E + 8) * 8); // per-class scan lists of the class DFS
-	take((void **)&tw.crb, nS * 16);
-	take((void **)&tw.cret, nS * 16);
-	take((void **)&tw.cretc, nS * 8);
+	take((void **)&tw.wadj, (nS + 2 * E + 8) * 8); // wave walk: class-filtered scan lists (4 bytes a slot); earlier in the pass: twin slots [2E]
+	take((void **)&tw.wrec, nS * 32);	       // 32-byte record per side
+	take((void **)&tw.wstk, 3 * nS * 8 + 64);      // stack pool: chunks double in size, a class takes less than three entries per side
+	take((void **)&tw.wpar, nS * 4);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	take((void **)&tw.rk_pk, NSL * 4);
 	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
@@ -1297,7 +1436,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
 	if (n_slots >= PK_END || 3 * (size_t)V >= PK_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
 		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^29");
-	uint32_t *twin = reinterpret_cast<uint32_t *>(tw.cadj); // [2E] (the filtered scan lists come much later)
+	uint32_t *twin = tw.wadj; // [2E] (the filtered scan lists come much later)
 	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, hside, ft, twin);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
 	if (n_slots)
@@ -1320,7 +1459,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.dps, tw.dvis, tw.entry_flag, cstate);
+	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.dps, tw.entry_flag, cstate);
 	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
 	const uint32_t n_entry = tw.host->read_u32(tw.entry_ps + nS, s);
@@ -1344,11 +1483,14 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		n_big = tw.host->read_u32(n_over, s);
 		big_list = over_list;
 	}
-	if (n_big) {
-		LAUNCH(k_class_adj, nS, s, nS, cs.loff, cs.ladj, tw.pbr, cs.ckey, tw.cproc, tw.cadj, tw.crb);
-		const uint32_t stride = n_big <= (1u << 16) ? 64u : 1u; // few large classes: a wave each
-		KLAUNCH(k_class_dfs, dim3((unsigned)(((size_t)n_big * stride + 63) / 64)), dim3(64), 0, s, n_big, big_list, tw.cadj, tw.crb,
-			tw.dps, tw.dvis, tw.cret, tw.cretc, stride);
+	if (n_big) { // large classes: one wave each (see section 6)
+		uint32_t *pool_top = pw.err + 7, *walk_err = pw.err + 8; // (cleared with the other counters at the start of the pass)
+		LAUNCH(k_class_recs, nS, s, nS, cs.loff, cs.ladj, tw.pbr, cs.ckey, tw.cproc, tw.wadj, tw.wrec, tw.wpar);
+		KLAUNCH(k_class_walk_wave, dim3(n_big), dim3(64), 0, s, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top,
+			(uint32_t)std::min<size_t>(3 * (size_t)nS, 0xFFFFFFF0u), walk_err);
+		LAUNCH(k_walk_finish, nS, s, nS, tw.wpar, tw.pbr, cs.loff, cs.ladj, tw.dps);
+		if (tw.host->read_u32(walk_err, s)) // (an unfinished walk leaves a broken tree: nothing downstream may run on it)
+			throw HipError("class walk: stack pool exhausted (internal sizing bug)");
 	}
 	tm.end(5);
 
@@ -1368,7 +1510,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
 	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
-	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0);
+	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
 	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags

@@ -17,10 +17,11 @@ struct TreeWs {
 	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
 	uint2 *dps;					  // [2V] {DFS parent side, scan slot of the parent it was found through}
 	uint8_t *dvis;					  // [2V]
-	uint2 *cadj;					  // [2V + 2E] class-filtered scan lists {side, slot}
-	uint4 *crb;					  // [2V] {begin, count, first entry} of a side's filtered list
-	uint4 *cret;					  // [2V] scan state of the DFS parent at the moment it descended
-	uint2 *cretc;					  // [2V] ... and the parent's next candidate
+	// the wave-cooperative walk of large 2-edge-connected classes
+	uint32_t *wadj;					  // [2V + 2E] class-filtered scan lists (sides), deg + 1 slots per side
+	uint4 *wrec;					  // [2 x 2V] 32-byte record per side: {count, list begin, first six candidates}
+	uint2 *wstk;					  // [3 x 2V] pool of the walks' stacks {side, next candidate}
+	uint32_t *wpar;					  // [2V] DFS parent of a side the walk reached, W_UNVIS before
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
 	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
 	uint32_t *entry_ps, *entry_list;		  // [2V+1]

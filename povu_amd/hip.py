@@ -53,6 +53,7 @@ F_BIG_CLASS_DFS = 64
 F_SPARSE_SPLITTERS = 128
 F_REDO_ODD = 256
 F_ALL_VERTEX_CLASSES = 512
+F_CHECK_LAMINAR = 1024
 
 _lib = None
 
