@@ -165,11 +165,14 @@ povu_hip_comm *povu_hip_comm_create(povu_hip_ctx *ctx, const char id[POVU_HIP_CO
 				    char *err, size_t errlen);
 void povu_hip_comm_destroy(povu_hip_comm *c);
 /* Scatter: on the root (rank 0) `shards` is the partition of its resident graph, elsewhere NULL.  On return every
- * rank's context holds its shard as resident graph (the root's graph is replaced by its own shard unless
- * keep_root_graph, in which case the root decomposes through a second context). */
+ * rank's context holds its shard as resident graph (on the root it replaces the whole graph; a root that wants to
+ * keep the whole graph resident scatters from a second context).  Collective: every rank of the communicator must
+ * call it; a rank that cannot take part (no partition on the root, no room for its shard) makes the call fail on ALL
+ * ranks before any shard moves.  Every RCCL call of a communicator runs on the communicator's own stream. */
 int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *shards, povu_hip_ctx *dst_ctx, char *err, size_t errlen);
 /* Gather: every rank passes the (globalized) forest of its shard; the root gets the merged forest, the others an
- * empty one. */
+ * empty one.  Collective like the scatter: a forest that cannot travel (hairpin boundaries, a merged forest) or a root
+ * without room fails the call on all ranks before any block moves. */
 povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen);
 /* wall time of the last scatter / gather on this rank, milliseconds */
 int povu_hip_comm_times(const povu_hip_comm *c, double out_ms[2]);
@@ -225,6 +228,12 @@ typedef struct {
 	uint32_t *height;   /* distance from the root */
 } povu_pvst_doc;
 povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *err, size_t errlen);
+
+/* GFA v1 text of a whole graph in the arrays povu_hip_graph_upload takes (mto::to_gfa::write_gfa's record shapes,
+ * src/mto/to_gfa.cpp:13-56): `S <id> A` per segment, `L <a> <+|-> <b> <+|-> 0M` per link, `+` = out of a's r side / into
+ * b's l side -- the inverse of the loader contract, so that writing and loading a graph is the identity.  Host only. */
+int povu_hip_gfa_write(const char *path, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links, const uint32_t *v1,
+		       const uint8_t *s1, const uint32_t *v2, const uint8_t *s2, char *err, size_t errlen);
 void povu_pvst_doc_free(povu_pvst_doc *doc);
 
 /* ---- measurement (bench.py, povu-stage-cost lines) ---- */
@@ -244,7 +253,10 @@ int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx);
 /* number of links in the components this shard processed in the last decompose */
 uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx);
 
-/* ---- stage-level parity hooks (tests only; device state of the last decompose) ---- */
+/* ---- stage-level parity hooks (tests only; device state of the last decompose) ----
+ * After a pass that redid SOME components with the one-lane kernels (povu_hip_last_seq_redo() between 1 and the
+ * component count - 1) the classes and candidate stacks sit in two layouts: povu_hip_debug_tree (when `cls` is asked
+ * for), povu_hip_debug_edge_ids and povu_hip_debug_stack then return 4 instead of exporting half-valid state. */
 /* copies comp_of[v] (0-based component rank) and local vertex idx for every GLOBAL vertex idx */
 int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *local_idx);
 /* tree arrays of component `comp` (0-based rank): sizes via n_tree first call with NULLs; `cls` is defined for the

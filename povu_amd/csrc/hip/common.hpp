@@ -203,8 +203,8 @@ void scan_exclusive_u8(const uint8_t *in0, uint32_t *out0, size_t n0, const uint
 // exclusive prefix sums of in[i] - sub[i] (mod 2^32)
 void scan_exclusive_diff_u32(const uint32_t *in, const uint32_t *sub, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes,
 			     hipStream_t s);
-// exclusive running xor of 64-bit words
-void scan_exclusive_xor_u64(const unsigned long long *in, unsigned long long *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
+// exclusive running xor of 128-bit words (two independent 64-bit hashes side by side)
+void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
 size_t scan_tmp_bytes(size_t n);
 // exclusive running maximum (identity 0)
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);

@@ -434,6 +434,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		CompState &cs = ctx->cs;
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
+		ctx->last_mixed = false;
 		ctx->stack_export_pending = false;
 		ctx->classes_in_par = false;
 		ctx->tree_in_par = false;
@@ -632,6 +633,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				mixed = true;
 			}
 			ctx->last_seq_redo = nbad;
+			ctx->last_mixed = mixed;
 			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
 				tm.begin("redo_seq");
 				if (dense_nb0 >= 0) // parallel tree: the one-lane kernels start from scratch
@@ -1011,6 +1013,8 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 {
 	if (!ctx || !ctx->have_state || comp >= ctx->C || !n_tree)
 		return 1;
+	if (cls && ctx->last_mixed)
+		return 4; // classes of a mixed pass sit in two layouts (parallel stage / one-lane kernels): not exported
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
 		uint32_t voff = 0, N = 0;
@@ -1048,6 +1052,8 @@ extern "C" int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_
 		return 1;
 	if (!ctx->tree_in_par)
 		return 3; // the one-lane tree kernels keep no per-side scan state
+	if (ctx->last_mixed)
+		return 4; // (see povu_hip_debug_tree)
 	uint32_t *dw = nullptr;
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
@@ -1093,6 +1099,8 @@ extern "C" int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *
 {
 	if (!ctx || !ctx->have_state || comp >= ctx->C || !n)
 		return 1;
+	if (ctx->last_mixed)
+		return 4; // the candidate stacks of a mixed pass sit in two layouts: not exported (see povu_hip_debug_tree)
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
 		if (ctx->stack_export_pending && ctx->last_seq_redo == 0) {

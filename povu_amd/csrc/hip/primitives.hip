@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 
 size_t scan_tmp_bytes(size_t)
 {
-	return 2 * SC_MAX_BLOCKS * sizeof(uint32_t) + 256;
+	return SC_MAX_BLOCKS * 16 + 256; // (two u32 jobs, or one job of 128-bit words)
 }
 
 static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial, const uint8_t *in8 = nullptr,
@@ -268,95 +268,98 @@ void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *t
 	scan_exclusive<1>(in, out, n, tmp, tmp_bytes, s);
 }
 
-// ---- exclusive running xor of 64-bit words (the bridge test's hashes): same two-launch scheme, 4 words per lane
-static constexpr int X64_ITEMS = 4, X64_TILE = SC_TPB * X64_ITEMS;
-struct Xor64Job {
-	const unsigned long long *in;
-	unsigned long long *out;
+// ---- exclusive running xor of 128-bit words (the bridge test's two hashes): same two-launch scheme, 2 words per lane
+static constexpr int X128_ITEMS = 2, X128_TILE = SC_TPB * X128_ITEMS;
+struct Xor128Job {
+	const ulonglong2 *in;
+	ulonglong2 *out;
 	size_t n, chunk;
 	uint32_t blocks;
-	unsigned long long *partial;
+	ulonglong2 *partial;
 };
-__device__ __forceinline__ unsigned long long x64_block_reduce(unsigned long long v, unsigned long long *sh)
+__device__ __forceinline__ ulonglong2 x128(const ulonglong2 a, const ulonglong2 b) { return make_ulonglong2(a.x ^ b.x, a.y ^ b.y); }
+__device__ __forceinline__ ulonglong2 x128_shfl_down(const ulonglong2 v, int off) { return make_ulonglong2(__shfl_down(v.x, off), __shfl_down(v.y, off)); }
+__device__ __forceinline__ ulonglong2 x128_shfl_up(const ulonglong2 v, int off) { return make_ulonglong2(__shfl_up(v.x, off), __shfl_up(v.y, off)); }
+__device__ __forceinline__ ulonglong2 x128_block_reduce(ulonglong2 v, ulonglong2 *sh)
 {
 	for (int off = 32; off; off >>= 1)
-		v ^= __shfl_down(v, off);
+		v = x128(v, x128_shfl_down(v, off));
 	if ((threadIdx.x & 63) == 0)
 		sh[threadIdx.x >> 6] = v;
 	__syncthreads();
-	const unsigned long long r = sh[0] ^ sh[1] ^ sh[2] ^ sh[3];
+	const ulonglong2 r = x128(x128(sh[0], sh[1]), x128(sh[2], sh[3]));
 	__syncthreads();
 	return r;
 }
-__global__ void __launch_bounds__(SC_TPB) k_xor64_partials(const Xor64Job J)
+__global__ void __launch_bounds__(SC_TPB) k_xor128_partials(const Xor128Job J)
 {
-	__shared__ unsigned long long sh[4];
+	__shared__ ulonglong2 sh[4];
 	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < J.n ? b0 + J.chunk : J.n;
-	unsigned long long acc = 0;
+	ulonglong2 acc = make_ulonglong2(0ull, 0ull);
 	for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
-		acc ^= J.in[i];
-	acc = x64_block_reduce(acc, sh);
+		acc = x128(acc, J.in[i]);
+	acc = x128_block_reduce(acc, sh);
 	if (threadIdx.x == 0)
 		J.partial[blockIdx.x] = acc;
 }
-__global__ void __launch_bounds__(SC_TPB) k_xor64_chunks(const Xor64Job J)
+__global__ void __launch_bounds__(SC_TPB) k_xor128_chunks(const Xor128Job J)
 {
-	__shared__ unsigned long long sh[4], wave_tot[4];
-	unsigned long long base = 0;
+	__shared__ ulonglong2 sh[4], wave_tot[4];
+	ulonglong2 base = make_ulonglong2(0ull, 0ull);
 	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += SC_TPB)
-		base ^= J.partial[k];
-	unsigned long long carry = x64_block_reduce(base, sh);
+		base = x128(base, J.partial[k]);
+	ulonglong2 carry = x128_block_reduce(base, sh);
 	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < J.n ? b0 + J.chunk : J.n;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	for (size_t t0 = b0; t0 < b1; t0 += X64_TILE) {
-		const size_t e0 = t0 + (size_t)threadIdx.x * X64_ITEMS;
-		unsigned long long v[X64_ITEMS];
-		for (int k = 0; k < X64_ITEMS; k++)
-			v[k] = e0 + k < b1 ? J.in[e0 + k] : 0ull;
-		unsigned long long tot = 0;
-		for (int k = 0; k < X64_ITEMS; k++) {
-			const unsigned long long x = v[k];
+	for (size_t t0 = b0; t0 < b1; t0 += X128_TILE) {
+		const size_t e0 = t0 + (size_t)threadIdx.x * X128_ITEMS;
+		ulonglong2 v[X128_ITEMS];
+		for (int k = 0; k < X128_ITEMS; k++)
+			v[k] = e0 + k < b1 ? J.in[e0 + k] : make_ulonglong2(0ull, 0ull);
+		ulonglong2 tot = make_ulonglong2(0ull, 0ull);
+		for (int k = 0; k < X128_ITEMS; k++) {
+			const ulonglong2 x = v[k];
 			v[k] = tot;
-			tot ^= x;
+			tot = x128(tot, x);
 		}
-		unsigned long long inc = tot;
+		ulonglong2 inc = tot;
 		for (int off = 1; off < 64; off <<= 1) {
-			const unsigned long long y = __shfl_up(inc, off);
+			const ulonglong2 y = x128_shfl_up(inc, off);
 			if (lane >= off)
-				inc ^= y;
+				inc = x128(inc, y);
 		}
 		if (lane == 63)
 			wave_tot[wave] = inc;
 		__syncthreads();
-		unsigned long long pre = carry;
+		ulonglong2 pre = carry;
 		for (int w = 0; w < wave; w++)
-			pre ^= wave_tot[w];
-		const unsigned long long lane_excl = __shfl_up(inc, 1);
+			pre = x128(pre, wave_tot[w]);
+		const ulonglong2 lane_excl = x128_shfl_up(inc, 1);
 		if (lane > 0)
-			pre ^= lane_excl;
-		const unsigned long long tile_tot = wave_tot[0] ^ wave_tot[1] ^ wave_tot[2] ^ wave_tot[3];
-		for (int k = 0; k < X64_ITEMS; k++)
+			pre = x128(pre, lane_excl);
+		const ulonglong2 tile_tot = x128(x128(wave_tot[0], wave_tot[1]), x128(wave_tot[2], wave_tot[3]));
+		for (int k = 0; k < X128_ITEMS; k++)
 			if (e0 + k < b1)
-				J.out[e0 + k] = pre ^ v[k];
-		carry ^= tile_tot;
+				J.out[e0 + k] = x128(pre, v[k]);
+		carry = x128(carry, tile_tot);
 		__syncthreads();
 	}
 }
-void scan_exclusive_xor_u64(const unsigned long long *in, unsigned long long *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
+void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
 	if (n == 0)
 		return;
-	if (tmp_bytes < SC_MAX_BLOCKS * sizeof(unsigned long long))
+	if (tmp_bytes < SC_MAX_BLOCKS * sizeof(ulonglong2))
 		throw HipError("scan: temporary storage too small");
-	size_t blocks = (n + X64_TILE - 1) / X64_TILE;
+	size_t blocks = (n + X128_TILE - 1) / X128_TILE;
 	if (blocks > SC_MAX_BLOCKS)
 		blocks = SC_MAX_BLOCKS;
 	size_t chunk = (n + blocks - 1) / blocks;
-	chunk = (chunk + X64_TILE - 1) / X64_TILE * X64_TILE;
+	chunk = (chunk + X128_TILE - 1) / X128_TILE * X128_TILE;
 	blocks = (n + chunk - 1) / chunk;
-	const Xor64Job J{in, out, n, chunk, (uint32_t)blocks, static_cast<unsigned long long *>(tmp)};
-	KLAUNCH(k_xor64_partials, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
-	KLAUNCH(k_xor64_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
+	const Xor128Job J{in, out, n, chunk, (uint32_t)blocks, static_cast<ulonglong2 *>(tmp)};
+	KLAUNCH(k_xor128_partials, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
+	KLAUNCH(k_xor128_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
 }
 
 // 25..27 key bits (the class sort of a whole-genome graph: ~2^26 brackets) take four 8-bit places with rocPRIM's tuned

@@ -643,8 +643,8 @@ extern "C" povu_hip_comm *povu_hip_comm_create(povu_hip_ctx *ctx, const char id[
 		memcpy(&u, id, sizeof u);
 		NCCL_CHECK(rccl().CommInitRank(&c->comm, (int)world, u, (int)rank));
 		HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c->dsmall), 8 * 8 * (size_t)world + 64));
-		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->hsmall), 8 * 8 * (size_t)world + 64, hipHostMallocDefault));
+		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&c->dsmall), 8 * 8 * (size_t)world + 128));
+		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&c->hsmall), 8 * 8 * (size_t)world + 128, hipHostMallocDefault));
 		return c.release();
 	} catch (const std::exception &e) {
 		if (c)
@@ -676,39 +676,66 @@ extern "C" void povu_hip_comm_destroy(povu_hip_comm *c)
 	delete c;
 }
 
+// Every RCCL call of a communicator is issued on ITS stream (c->side): one communicator, one stream.  A rank that finds
+// something wrong BEFORE a transfer says so in the status word all ranks exchange first, so that nobody is left waiting in
+// a send or a receive for a peer that has already given up; a group that was opened is closed on every path.
 extern "C" int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *shards, povu_hip_ctx *dst, char *err, size_t errlen)
 {
+	bool in_group = false;
 	try {
 		if (!c || !dst || dst != c->ctx)
 			throw HipError("scatter: the destination context must be the communicator's");
 		const bool root = c->rank == 0;
-		if (root && (!shards || shards->world != c->world))
-			throw HipError("scatter: the root needs a partition for exactly `world` ranks");
 		HIP_CHECK(hipSetDevice(dst->device));
 		Rccl &R = rccl();
-		hipStream_t s = dst->stream;
+		hipStream_t s = c->side;
 		const double t0 = now_ms();
-		// sizes first (one broadcast), then every rank's shard point to point, all transfers in one group
+		// sizes first (one broadcast; an all-ones size = the root cannot serve this call), then every rank's shard point to
+		// point, all transfers in one group
+		const bool root_ok = !root || (shards && shards->world == c->world);
 		uint64_t *h = c->hsmall;
 		if (root)
 			for (uint32_t r = 0; r < c->world; r++)
-				h[r] = shards->parts[r].bytes;
+				h[r] = root_ok ? shards->parts[r].bytes : ~0ull;
 		HIP_CHECK(hipMemcpyAsync(c->dsmall, h, 8 * (size_t)c->world, hipMemcpyHostToDevice, s));
 		NCCL_CHECK(R.Broadcast(c->dsmall, c->dsmall, c->world, ncclUint64, 0, c->comm, s));
 		HIP_CHECK(hipMemcpyAsync(h, c->dsmall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
+		if (h[c->rank] == ~0ull)
+			throw HipError("scatter: the root needs a partition for exactly `world` ranks");
 		const size_t my_bytes = h[c->rank];
+		// second word of the handshake: can every receiver take its shard?  (a failed reservation must not leave the root
+		// blocked in its sends)
+		char *buf = nullptr;
+		uint64_t ok = 1;
+		if (!root) {
+			try {
+				dst->shard_buf.reserve(my_bytes + 256);
+				buf = dst->shard_buf.take<char>(my_bytes);
+			} catch (const std::exception &) {
+				ok = 0;
+			}
+		}
+		h[0] = ok;
+		uint64_t *dmy = c->dsmall, *dall = c->dsmall + 4;
+		HIP_CHECK(hipMemcpyAsync(dmy, h, 8, hipMemcpyHostToDevice, s));
+		NCCL_CHECK(R.AllGather(dmy, dall, 1, ncclUint64, c->comm, s));
+		HIP_CHECK(hipMemcpyAsync(h + 4, dall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		for (uint32_t r = 0; r < c->world; r++)
+			if (!h[4 + r])
+				throw HipError("scatter: rank " + std::to_string(r) + " has no room for its shard");
 		const void *mine = nullptr;
 		if (root) {
 			const char *blk = static_cast<const char *>(shards->block);
 			NCCL_CHECK(R.GroupStart());
+			in_group = true;
 			for (uint32_t r = 1; r < c->world; r++)
-				NCCL_CHECK(R.Send(blk + shards->parts[r].off, shards->parts[r].bytes, ncclChar, (int)r, c->comm, c->side));
+				NCCL_CHECK(R.Send(blk + shards->parts[r].off, shards->parts[r].bytes, ncclChar, (int)r, c->comm, s));
+			in_group = false;
 			NCCL_CHECK(R.GroupEnd());
-			mine = blk + shards->parts[0].off; // same device: loaded straight from the partition
+			mine = blk + shards->parts[0].off; // same device: loaded straight from the partition, beside the sends
 		} else {
-			dst->shard_buf.reserve(my_bytes + 256);
-			char *buf = dst->shard_buf.take<char>(my_bytes);
 			NCCL_CHECK(R.Recv(buf, my_bytes, ncclChar, 0, c->comm, s));
 			HIP_CHECK(hipStreamSynchronize(s));
 			mine = buf;
@@ -717,10 +744,16 @@ extern "C" int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *sh
 		if (povu_hip_graph_upload_shard(dst, mine, my_bytes, 1, e2, sizeof e2) != 0)
 			throw HipError(std::string("scatter: ") + e2);
 		if (root)
-			HIP_CHECK(hipStreamSynchronize(c->side)); // the partition may be freed once this returns
+			HIP_CHECK(hipStreamSynchronize(s)); // the partition may be freed once this returns
 		c->ms[0] = now_ms() - t0;
 		return 0;
 	} catch (const std::exception &e) {
+		if (in_group) {
+			try {
+				(void)rccl().GroupEnd();
+			} catch (...) {
+			}
+		}
 		if (c && c->ctx) {
 			(void)hipStreamSynchronize(c->ctx->stream);
 			if (c->side)
@@ -763,40 +796,39 @@ static std::unique_ptr<povu_hip_forest> compact_forest(const povu_hip_forest *f)
 extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen)
 {
 	std::unique_ptr<povu_hip_forest> compacted;
+	bool in_group = false;
 	try {
-		if (!c || !mine)
+		if (!c || !c->ctx)
 			throw HipError("gather: bad arguments");
-		if (!mine->hairpins.empty())
-			throw HipError("gather: hairpin boundaries do not travel");
-		if (!mine->extra.empty()) { // (rare: some components went through the sequential redo)
-			compacted = compact_forest(mine);
-			mine = compacted.get();
-		}
 		povu_hip_ctx *ctx = c->ctx;
 		HIP_CHECK(hipSetDevice(ctx->device));
 		Rccl &R = rccl();
-		hipStream_t s = ctx->stream;
+		hipStream_t s = c->side; // (see povu_hip_comm_scatter: one communicator, one stream)
 		const double t0 = now_ms();
 		const bool root = c->rank == 0;
-		// what this rank contributes: [n_trees, total entries, total components] + tree table + its result block
-		const size_t nt = mine->trees.size(), total = mine->total_entries;
-		uint64_t *h = c->hsmall;
-		h[0] = nt, h[1] = nt ? total : 0, h[2] = mine->total_components, h[3] = 0;
-		uint64_t *dmy = c->dsmall, *dall = c->dsmall + 4;
-		HIP_CHECK(hipMemcpyAsync(dmy, h, 32, hipMemcpyHostToDevice, s));
-		NCCL_CHECK(R.AllGather(dmy, dall, 4, ncclUint64, c->comm, s));
-		HIP_CHECK(hipMemcpyAsync(h + 4, dall, 32 * (size_t)c->world, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipStreamSynchronize(s));
-		const uint64_t *all = h + 4;
-		auto out = std::make_unique<povu_hip_forest>();
-		out->pool = ctx->pool;
-		if (!root) {
-			if (nt) { // tree table + block through device staging, one message each
-				const size_t mb = nt * 32, bb = povu_hip_forest::ExtraBlock::bytes_for(total); // 8 words per tree
+		// ---- everything that can go wrong on this rank alone is found out BEFORE the first collective, and travels in the
+		// status word of the size exchange: all ranks then fail together instead of waiting for each other
+		std::string my_error;
+		size_t nt = 0, total = 0;
+		uint32_t *dmeta = nullptr, *hmeta = nullptr;
+		char *dblk = nullptr;
+		size_t mb = 0, bb = 0;
+		try {
+			if (!mine)
+				throw HipError("gather: bad arguments");
+			if (!mine->hairpins.empty())
+				throw HipError("gather: hairpin boundaries do not travel");
+			if (!mine->extra.empty()) { // (rare: some components went through the sequential redo)
+				compacted = compact_forest(mine);
+				mine = compacted.get();
+			}
+			nt = mine->trees.size(), total = mine->total_entries;
+			if (!root && nt) { // tree table + block go through device staging, one message each
+				mb = nt * 32, bb = povu_hip_forest::ExtraBlock::bytes_for(total); // 8 words per tree
 				c->stage.reserve(mb + bb + 512);
-				uint32_t *dmeta = c->stage.take<uint32_t>(mb / 4);
-				char *dblk = c->stage.take<char>(bb);
-				uint32_t *hmeta = ctx->host.take<uint32_t>(8 * nt);
+				dmeta = c->stage.take<uint32_t>(mb / 4);
+				dblk = c->stage.take<char>(bb);
+				hmeta = ctx->host.take<uint32_t>(8 * nt);
 				for (size_t i = 0; i < nt; i++) {
 					const auto &t = mine->trees[i];
 					if (t.blk >= 0)
@@ -806,23 +838,26 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 					uint32_t *q = hmeta + 8 * i;
 					q[0] = t.component_id, q[1] = t.n_vtx, q[2] = t.n_links, q[3] = t.n_pvst, q[4] = (uint32_t)t.off, q[5] = q[6] = q[7] = 0;
 				}
-				HIP_CHECK(hipMemcpyAsync(dmeta, hmeta, nt * 32, hipMemcpyHostToDevice, s));
-				HIP_CHECK(hipMemcpyAsync(dblk, mine->block, bb, hipMemcpyHostToDevice, s));
-				NCCL_CHECK(R.GroupStart());
-				NCCL_CHECK(R.Send(dmeta, mb, ncclChar, 0, c->comm, s));
-				NCCL_CHECK(R.Send(dblk, bb, ncclChar, 0, c->comm, s));
-				NCCL_CHECK(R.GroupEnd());
-				HIP_CHECK(hipStreamSynchronize(s));
 			}
-			c->ms[1] = now_ms() - t0;
-			return out.release(); // empty
+		} catch (const std::exception &e) {
+			my_error = e.what();
+			nt = total = 0;
 		}
-		// root: receive every rank's table + block into device staging, land the blocks in page-locked memory
-		size_t need = 1024;
-		for (uint32_t r = 1; r < c->world; r++)
-			if (all[4 * r])
-				need += pad256(all[4 * r] * 32) + pad256(povu_hip_forest::ExtraBlock::bytes_for(all[4 * r + 1])) + 512;
-		c->stage.reserve(need);
+		// what this rank contributes: [n_trees, total entries, total components, status] + tree table + its result block
+		uint64_t *h = c->hsmall;
+		h[0] = nt, h[1] = nt ? total : 0, h[2] = mine ? mine->total_components : 0, h[3] = my_error.empty() ? 0 : 1;
+		uint64_t *dmy = c->dsmall, *dall = c->dsmall + 4;
+		HIP_CHECK(hipMemcpyAsync(dmy, h, 32, hipMemcpyHostToDevice, s));
+		NCCL_CHECK(R.AllGather(dmy, dall, 4, ncclUint64, c->comm, s));
+		HIP_CHECK(hipMemcpyAsync(h + 4, dall, 32 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		const uint64_t *all = h + 4;
+		if (!my_error.empty())
+			throw HipError(my_error);
+		for (uint32_t r = 0; r < c->world; r++)
+			if (all[4 * r + 3])
+				throw HipError("gather: rank " + std::to_string(r) + " could not contribute its forest");
+		// the root sizes its staging with everybody's numbers and says whether it can take them (second, one-word handshake)
 		struct In {
 			uint32_t rank;
 			size_t nt, total, mb, bb;
@@ -830,22 +865,64 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			char *dblk;
 		};
 		std::vector<In> in;
-		NCCL_CHECK(R.GroupStart());
-		for (uint32_t r = 1; r < c->world; r++) {
-			if (!all[4 * r])
-				continue;
-			In x{r, (size_t)all[4 * r], (size_t)all[4 * r + 1], 0, 0, nullptr, nullptr};
-			x.mb = x.nt * 32;
-			x.bb = povu_hip_forest::ExtraBlock::bytes_for(x.total);
-			x.dmeta = c->stage.take<uint32_t>(x.mb / 4);
-			x.dblk = c->stage.take<char>(x.bb);
-			NCCL_CHECK(R.Recv(x.dmeta, x.mb, ncclChar, (int)r, c->comm, s));
-			NCCL_CHECK(R.Recv(x.dblk, x.bb, ncclChar, (int)r, c->comm, s));
-			in.push_back(x);
+		uint64_t go = 1;
+		if (root) {
+			try {
+				size_t need = 1024;
+				for (uint32_t r = 1; r < c->world; r++)
+					if (all[4 * r])
+						need += pad256(all[4 * r] * 32) + pad256(povu_hip_forest::ExtraBlock::bytes_for(all[4 * r + 1])) + 512;
+				c->stage.reserve(need);
+				for (uint32_t r = 1; r < c->world; r++) {
+					if (!all[4 * r])
+						continue;
+					In x{r, (size_t)all[4 * r], (size_t)all[4 * r + 1], 0, 0, nullptr, nullptr};
+					x.mb = x.nt * 32;
+					x.bb = povu_hip_forest::ExtraBlock::bytes_for(x.total);
+					x.dmeta = c->stage.take<uint32_t>(x.mb / 4);
+					x.dblk = c->stage.take<char>(x.bb);
+					in.push_back(x);
+				}
+			} catch (const std::exception &) {
+				go = 0;
+			}
 		}
+		uint64_t *hgo = c->hsmall + 4 + 4 * (size_t)c->world, *dgo = c->dsmall + 4 + 4 * (size_t)c->world;
+		*hgo = go;
+		HIP_CHECK(hipMemcpyAsync(dgo, hgo, 8, hipMemcpyHostToDevice, s));
+		NCCL_CHECK(R.Broadcast(dgo, dgo, 1, ncclUint64, 0, c->comm, s));
+		HIP_CHECK(hipMemcpyAsync(hgo, dgo, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (!*hgo)
+			throw HipError("gather: the root has no room for the ranks' forests");
+		auto out = std::make_unique<povu_hip_forest>();
+		out->pool = ctx->pool;
+		if (!root) {
+			if (nt) {
+				HIP_CHECK(hipMemcpyAsync(dmeta, hmeta, nt * 32, hipMemcpyHostToDevice, s));
+				HIP_CHECK(hipMemcpyAsync(dblk, mine->block, bb, hipMemcpyHostToDevice, s));
+				NCCL_CHECK(R.GroupStart());
+				in_group = true;
+				NCCL_CHECK(R.Send(dmeta, mb, ncclChar, 0, c->comm, s));
+				NCCL_CHECK(R.Send(dblk, bb, ncclChar, 0, c->comm, s));
+				in_group = false;
+				NCCL_CHECK(R.GroupEnd());
+				HIP_CHECK(hipStreamSynchronize(s));
+			}
+			c->ms[1] = now_ms() - t0;
+			return out.release(); // empty
+		}
+		// root: receive every rank's table + block into device staging, land the blocks in page-locked memory
+		NCCL_CHECK(R.GroupStart());
+		in_group = true;
+		for (auto &x : in) {
+			NCCL_CHECK(R.Recv(x.dmeta, x.mb, ncclChar, (int)x.rank, c->comm, s));
+			NCCL_CHECK(R.Recv(x.dblk, x.bb, ncclChar, (int)x.rank, c->comm, s));
+		}
+		in_group = false;
 		NCCL_CHECK(R.GroupEnd());
 		uint32_t tc = mine->total_components;
-		std::vector<uint32_t *> hmeta;
+		std::vector<uint32_t *> hmetas;
 		for (auto &x : in) {
 			povu_hip_forest::ExtraBlock blk;
 			blk.pool = ctx->pool;
@@ -853,7 +930,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			blk.carve(x.total);
 			out->extra.push_back(blk);
 			uint32_t *hm = ctx->host.take<uint32_t>(8 * x.nt);
-			hmeta.push_back(hm);
+			hmetas.push_back(hm);
 			HIP_CHECK(hipMemcpyAsync(hm, x.dmeta, x.nt * 32, hipMemcpyDeviceToHost, s));
 			HIP_CHECK(hipMemcpyAsync(blk.p, x.dblk, x.bb, hipMemcpyDeviceToHost, s)); // same layout as the sender's block
 			tc = std::max<uint32_t>(tc, (uint32_t)all[4 * x.rank + 2]);
@@ -880,7 +957,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 		for (size_t k = 0; k < in.size(); k++) {
 			for (size_t i = 0; i < in[k].nt; i++) {
 				povu_hip_forest::Tree t{};
-				const uint32_t *q = hmeta[k] + 8 * i;
+				const uint32_t *q = hmetas[k] + 8 * i;
 				t.component_id = q[0], t.n_vtx = q[1], t.n_links = q[2], t.n_pvst = q[3];
 				t.off = q[4];
 				t.blk = (int)k;
@@ -894,8 +971,17 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 		c->ms[1] = now_ms() - t0;
 		return out.release();
 	} catch (const std::exception &e) {
-		if (c && c->ctx)
+		if (in_group) {
+			try {
+				(void)rccl().GroupEnd();
+			} catch (...) {
+			}
+		}
+		if (c && c->ctx) {
 			(void)hipStreamSynchronize(c->ctx->stream);
+			if (c->side)
+				(void)hipStreamSynchronize(c->side);
+		}
 		set_err(err, errlen, e.what());
 		return nullptr;
 	}

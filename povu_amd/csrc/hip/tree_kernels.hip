@@ -48,6 +48,7 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 // b = 3 (1 in 8) for short lists, whose walks are bound by their longest segment; b = 4 for lists of 2^26+ elements.
 static unsigned rank_bucket_bits(size_t n) { return n < (size_t(1) << 26) ? 3u : 4u; }
 static constexpr uint32_t PK_END = 0x1FFFFFFFu, PK_HEAD = 0x40000000u, PK_STOP = 0x80000000u;
+static constexpr uint32_t FT_NONE = 0x7FFFFFFFu, FT_HASH = 0x80000000u; // ft words: first arc of a side | "its hash word was written"
 __device__ __forceinline__ uint32_t bucket_splitter(uint32_t q, unsigned b) { return (q << b) | ((q * 0x9E3779B1u) >> (32u - b)); }
 __device__ __forceinline__ bool is_splitter(uint32_t i, unsigned b) { return bucket_splitter(i >> b, b) == i; }
 // One word per list element, so that a walk step is ONE dependent load: bits 0..28 successor (PK_END = none),
@@ -99,32 +100,41 @@ __device__ __forceinline__ uint32_t arc_twin(const uint32_t *__restrict__ loff, 
 	return loff[w] + find_link_slot(loff, lle, w, lle[at]) - 1;
 }
 // (bridge test of step 3, see k_t0_parents) every non-tree link gets a 64-bit hash of its local edge idx
-__device__ __forceinline__ unsigned long long link_hash(uint32_t le)
+// -- TWO independent 64-bit hashes, carried side by side in one 16-byte word (the second one is what stands behind the
+// first: a tree edge is called a bridge only when both running xors vanish)
+__device__ __forceinline__ ulonglong2 link_hash(uint32_t le)
 {
 	unsigned long long z = ((unsigned long long)le + 1ull) * 0x9E3779B97F4A7C15ull; // splitmix64 finaliser
 	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
 	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-	return z ^ (z >> 31);
+	unsigned long long y = ((unsigned long long)le ^ 0x5851F42D4C957F2Dull) * 0xD6E8FEB86659FD93ull; // murmur3 finaliser, other constants
+	y = (y ^ (y >> 33)) * 0xFF51AFD7ED558CCDull;
+	y = (y ^ (y >> 33)) * 0xC4CEB9FE1A85EC53ull;
+	return make_ulonglong2(z ^ (z >> 31), y ^ (y >> 33));
 }
+__device__ __forceinline__ ulonglong2 hx(const ulonglong2 a, const ulonglong2 b) { return make_ulonglong2(a.x ^ b.x, a.y ^ b.y); }
+__device__ __forceinline__ bool hzero(const ulonglong2 a) { return (a.x | a.y) == 0ull; }
+__device__ __forceinline__ bool heq(const ulonglong2 a, const ulonglong2 b) { return a.x == b.x && a.y == b.y; }
 // Euler tour successor: after u->w comes the arc that follows w->u among the arcs of w's segment (cyclically; w->u
 // itself when the segment has no other).  Slots that are no arcs get an inert word (no lane ever walks into them).
 // Also, while the side's links are in hand: hside[S] = xor of the hashes of its non-tree links (a link is in the lists
-// of both its ends, also when they are l and r of one segment), ft[S] = its first arc (NIL: none).
+// of both its ends, also when they are l and r of one segment), written only where it is not zero (four sides in five
+// of a pangenome graph have no such link); ft[S] = its first arc (FT_NONE: none), bit 31 set when hside[S] was written.
 __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b,
-			     unsigned long long *__restrict__ hside, uint32_t *__restrict__ ft, uint32_t *__restrict__ twin)
+			     ulonglong2 *__restrict__ hside, uint32_t *__restrict__ ft, uint32_t *__restrict__ twin)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	const uint32_t lo = loff[S], hi = loff[S + 1];
-	unsigned long long h = 0;
+	ulonglong2 h = make_ulonglong2(0ull, 0ull);
 	uint32_t first = NIL;
 	for (uint32_t at = lo; at < hi; at++) {
 		const uint32_t le = lle[at];
 		if (!tgray[le]) {
 			pk[at] = PK_END | PK_STOP;
-			h ^= link_hash(le);
+			h = hx(h, link_hash(le));
 			continue;
 		}
 		if (first == NIL)
@@ -141,8 +151,10 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 				nxt = j;
 		pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 	}
-	hside[S] = h;
-	ft[S] = first;
+	const bool nz = !hzero(h);
+	if (nz)
+		hside[S] = h;
+	ft[S] = (first == NIL ? FT_NONE : first) | (nz ? FT_HASH : 0u);
 }
 // sorted side id of the DFS start of component c: smallest tip (types.cpp:60-68) or (l, idx 0)
 __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *start_key, const uint32_t *voff, uint32_t c)
@@ -512,8 +524,8 @@ static constexpr uint32_t T0_RBIT = 0x80000000u;
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
-			     const unsigned long long *__restrict__ hside, const uint32_t *__restrict__ heads,
-			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, unsigned long long *__restrict__ val, uint32_t C,
+			     const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
+			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, ulonglong2 *__restrict__ val, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,15 +552,19 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
 		t0seg[child >> 1] = make_uint4(parent, le | ((child & 1u) ? T0_RBIT : 0u), p_in, p_out); // ONE scattered 16-byte store
 		// (val was cleared by the caller: most segments have no non-tree link, and a scattered 8-byte store costs a sector)
-		const unsigned long long h = hside[child] ^ hside[child ^ 1u];
-		if (h)
-			val[p_in] = h;
+		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + (child & ~1u)); // both sides of the child's segment
+		if ((f2.x | f2.y) & FT_HASH) {
+			const ulonglong2 z = make_ulonglong2(0ull, 0ull);
+			const ulonglong2 h = hx((f2.x & FT_HASH) ? hside[child & ~1u] : z, (f2.y & FT_HASH) ? hside[child | 1u] : z);
+			if (!hzero(h))
+				val[p_in] = h;
+		}
 	}
 }
 // pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
 static constexpr uint32_t PB_BRIDGE = 0x80000000u;
-__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const unsigned long long *__restrict__ px,
-			  const unsigned long long *__restrict__ hside, const uint32_t *__restrict__ ft,
+__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ulonglong2 *__restrict__ px,
+			  const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft,
 			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
 			  const uint32_t *__restrict__ voff, uint32_t *__restrict__ pbr, uint8_t *multi)
 {
@@ -563,7 +579,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const un
 	if (S == entered) {
 		if (r.x == NIL) {
 			pbr[S] = NIL;
-		} else if (px[r.z] == px[r.w + 1]) {
+		} else if (heq(px[r.z], px[r.w + 1])) {
 			pbr[S] = r.x | PB_BRIDGE;
 		} else {
 			pbr[S] = r.x;
@@ -573,21 +589,21 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const un
 		return;
 	}
 	// the black edge entered -> S: what leaves subtree(S) = S's own non-tree links and those of the subtrees hanging off S
-	unsigned long long x = hside[S];
-	const uint32_t a1 = ft[S];
-	if (a1 != NIL) {
+	const uint32_t f1 = ft[S], a1 = f1 & FT_NONE;
+	ulonglong2 x = (f1 & FT_HASH) ? hside[S] : make_ulonglong2(0ull, 0ull);
+	if (a1 != FT_NONE) {
 		const uint32_t c = ckey[S >> 1], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
-		const uint32_t a3 = ft[entered];
+		const uint32_t a3 = ft[entered] & FT_NONE;
 		uint32_t end; // position behind the last of them
 		if (r.x == NIL) // root segment: the start side's arcs come first, S's are the rest of the tour
 			end = abase + L;
-		else if (a3 != NIL && lle[a3] != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
+		else if (a3 != FT_NONE && lle[a3] != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
 			end = abase + (L - 1 - dist[a3]);
 		else
 			end = r.w;
-		x ^= px[abase + (L - 1 - dist[a1])] ^ px[end];
+		x = hx(x, hx(px[abase + (L - 1 - dist[a1])], px[end]));
 	}
-	if (x == 0) {
+	if (hzero(x)) {
 		pbr[S] = entered | PB_BRIDGE;
 	} else {
 		pbr[S] = entered;
@@ -1383,8 +1399,8 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	const size_t NSL = std::max<size_t>(2 * V + 2 * E, 4 * V) + 16; // scan slots of all sides / events of the second ranking
 	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
 	take((void **)&tw.dist, NSL * 4);
-	take((void **)&tw.xval, (NA + 2) * 8);
-	take((void **)&tw.xps, (NA + 2) * 8);
+	take((void **)&tw.xval, (NA + 2) * 16);
+	take((void **)&tw.xps, (NA + 2) * 16);
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0seg, (V + 2) * 16);
 	for (uint32_t **p : {&tw.pbr,
@@ -1432,7 +1448,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const size_t n_slots = 2 * (size_t)E; // list elements = adjacency slots (loff[nS] = 2E: every link has one at either end)
 	RankBufs rb{tw.rk_pk, tw.rk_heads, tw.rk_nx, tw.rk_wa, tw.rk_wb, tw.rk_tA, tw.rk_tB, tw.rk_tC};
 	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
-	unsigned long long *hside = reinterpret_cast<unsigned long long *>(tw.evt); // [nS] (evt: free until the second ranking)
+	ulonglong2 *hside = reinterpret_cast<ulonglong2 *>(tw.evt); // [nS] 16-byte words (evt, [max(4V, 2E)] 8-byte words, is free until the second ranking)
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
 	if (n_slots >= PK_END || 3 * (size_t)V >= PK_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
 		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^29");
@@ -1442,15 +1458,15 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	if (n_slots)
 		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
-	unsigned long long *val = tw.xval, *px = tw.xps; // [NA+1] each
-	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 8, s));
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, hside, rb.heads,
+	ulonglong2 *val = tw.xval, *px = tw.xps; // [NA+1] each
+	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 16, s));
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, hside, ft, rb.heads,
 	       twin, tw.t0seg, val, C, start_key, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
-	scan_exclusive_xor_u64(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	scan_exclusive_xor_u128(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
 	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
 	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.lle, cs.ckey, cs.voff, tw.pbr, multi);

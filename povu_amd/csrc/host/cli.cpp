@@ -134,16 +134,22 @@ int main(int argc, char **argv)
 	}
 	if (const char *d = std::getenv("POVU_HIP_DEVICE"))
 		cfg.device = atoi(d);
-	// exceptions propagate like in the reference (uncaught -> terminate)
-	if (command == "info")
-		povu_host::do_info(cfg, print_tips);
-	else if (command == "prune")
-		povu_host::do_prune(cfg);
-	else if (command == "gfa2vcf")
-		povu_host::do_gfa2vcf(cfg, call_args);
-	else {
-		povu_host::reset_debug_sidecar(cfg);
-		povu_host::do_decompose(cfg);
+	// The reference lets exceptions escape main (uncaught -> std::terminate -> abort).  Same message, same non-zero exit,
+	// but an orderly one: this process holds a GPU context, and an abort would take it down mid-flight.
+	try {
+		if (command == "info")
+			povu_host::do_info(cfg, print_tips);
+		else if (command == "prune")
+			povu_host::do_prune(cfg);
+		else if (command == "gfa2vcf")
+			povu_host::do_gfa2vcf(cfg, call_args);
+		else {
+			povu_host::reset_debug_sidecar(cfg);
+			povu_host::do_decompose(cfg);
+		}
+	} catch (const std::exception &e) {
+		std::cerr << "terminate called after throwing an instance of 'std::runtime_error'\n  what():  " << e.what() << std::endl;
+		return EXIT_FAILURE;
 	}
 	return 0;
 }

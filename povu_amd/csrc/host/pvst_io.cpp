@@ -5,6 +5,7 @@
 // (:136-158), children as comma-separated FILE vertex ids (:83-130, :284-297), route L/R (:155-157).
 #include "../../../include/povu_hip.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -19,6 +20,72 @@ void set_err(char *err, size_t n, const std::string &m)
 		snprintf(err, n, "%s", m.c_str());
 }
 } // namespace
+
+// GFA v1 text of a whole graph, the inverse of the loader contract (host/gfa.cpp; mto::to_gfa::write_gfa,
+// src/mto/to_gfa.cpp:13-56, writes the same three record shapes): header, one `S <id> A` per segment in vertex order, one
+// `L <a> <+|-> <b> <+|-> 0M` per link in link order, `+` = leaves a through its r side / enters b through its l side.
+// Hand-rolled number formatting into a large buffer: a whole-genome graph is several gigabytes of text.
+extern "C" int povu_hip_gfa_write(const char *path, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links, const uint32_t *v1,
+				  const uint8_t *s1, const uint32_t *v2, const uint8_t *s2, char *err, size_t errlen)
+{
+	if (!path || (n_vtx && !vid) || (n_links && (!v1 || !s1 || !v2 || !s2))) {
+		set_err(err, errlen, "gfa_write: bad arguments");
+		return 1;
+	}
+	FILE *o = fopen(path, "wb");
+	if (!o) {
+		set_err(err, errlen, std::string("gfa_write: could not open ") + path);
+		return 1;
+	}
+	const size_t cap = size_t(8) << 20;
+	std::vector<char> buf(cap + 64);
+	size_t at = 0;
+	bool ok = true;
+	auto flush = [&]() {
+		ok = ok && fwrite(buf.data(), 1, at, o) == at;
+		at = 0;
+	};
+	auto num = [&](uint32_t v) {
+		char t[10];
+		int n = 0;
+		do {
+			t[n++] = (char)('0' + v % 10);
+			v /= 10;
+		} while (v);
+		while (n)
+			buf[at++] = t[--n];
+	};
+	memcpy(buf.data(), "H\tVN:Z:1.0\n", 11);
+	at = 11;
+	for (uint32_t v = 0; v < n_vtx; v++) {
+		buf[at++] = 'S', buf[at++] = '\t';
+		num(vid[v]);
+		buf[at++] = '\t', buf[at++] = 'A', buf[at++] = '\n';
+		if (at >= cap)
+			flush();
+	}
+	for (uint32_t e = 0; e < n_links; e++) {
+		if (v1[e] >= n_vtx || v2[e] >= n_vtx) {
+			fclose(o);
+			set_err(err, errlen, "gfa_write: link " + std::to_string(e) + " names an unknown vertex");
+			return 1;
+		}
+		buf[at++] = 'L', buf[at++] = '\t';
+		num(vid[v1[e]]);
+		buf[at++] = '\t', buf[at++] = s1[e] == POVU_SIDE_R ? '+' : '-', buf[at++] = '\t';
+		num(vid[v2[e]]);
+		buf[at++] = '\t', buf[at++] = s2[e] == POVU_SIDE_L ? '+' : '-', buf[at++] = '\t', buf[at++] = '0', buf[at++] = 'M', buf[at++] = '\n';
+		if (at >= cap)
+			flush();
+	}
+	flush();
+	ok = (fclose(o) == 0) && ok;
+	if (!ok) {
+		set_err(err, errlen, std::string("gfa_write: short write to ") + path);
+		return 1;
+	}
+	return 0;
+}
 
 extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *err, size_t errlen)
 {

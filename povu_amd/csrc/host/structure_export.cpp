@@ -69,7 +69,12 @@ void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t c
 	if (povu_hip_debug_tree(ctx, comp_rank, &n2, gid.data(), typ.data(), par.data(), nullptr) != 0 || n2 != n_tree ||
 	    povu_hip_debug_edge_ids(ctx, comp_rank, &n2, eid.data()) != 0 || n2 != n_tree ||
 	    povu_hip_debug_stack(ctx, comp_rank, &n2, s_vtx.data(), s_cls.data(), next_seen.data()) != 0 || n2 != n_stack)
-		throw std::runtime_error("flubble debug sidecar: could not read the state of component " + std::to_string(comp_rank + 1));
+		throw std::runtime_error("flubble debug sidecar: could not read the state of component " + std::to_string(comp_rank + 1) +
+					 " (after a pass that redid some components sequentially the stage state is not exported)");
+	for (uint32_t i = 0; i < n_stack; i++) // every entry names a black tree edge: a child below the root, inside the tree
+		if (s_vtx[i] == 0 || s_vtx[i] >= n_tree || par[s_vtx[i]] >= n_tree)
+			throw std::runtime_error("flubble debug sidecar: candidate stack entry " + std::to_string(i) + " of component " +
+						 std::to_string(comp_rank + 1) + " lies outside its tree");
 	// expected_next_seen (flubbles.cpp:94-106): the next later entry of the same class, else the entry itself
 	std::vector<uint32_t> expected(n_stack);
 	{

@@ -157,8 +157,25 @@ def load_lib():
     l.povu_hip_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     l.povu_hip_comm_times.restype = C.c_int
     l.povu_hip_comm_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    l.povu_hip_gfa_write.restype = C.c_int
+    l.povu_hip_gfa_write.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_char_p, C.c_size_t]
     _lib = l
     return l
+
+
+def write_gfa(links, path: str) -> None:
+    """GFA v1 text of a workloads.Links through the host library's writer (host only, no GPU needed)."""
+    l = load_lib()
+    vid = np.ascontiguousarray(links.vid, dtype=np.uint32)
+    v1 = np.ascontiguousarray(links.v1, dtype=np.uint32)
+    v2 = np.ascontiguousarray(links.v2, dtype=np.uint32)
+    s1 = np.ascontiguousarray(links.s1, dtype=np.uint8)
+    s2 = np.ascontiguousarray(links.s2, dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    if l.povu_hip_gfa_write(path.encode(), len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
+                            v2.ctypes.data, s2.ctypes.data, err, 512) != 0:
+        raise RuntimeError(err.value.decode())
 
 
 def lpt_assign(weights, world: int) -> np.ndarray:

@@ -374,3 +374,14 @@ def test_host_code_under_address_and_ub_sanitizers(golden_dir, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     assert "parsed" in r.stdout
+
+
+def test_gfa_writer_is_the_inverse_of_the_loader_contract(tmp_path):
+    """povu_hip_gfa_write (host only): the text equals the workload generator's own GFA text, record for record."""
+    from povu_amd import hip as H, workloads as W
+    for g in (W.random_bidirected(300, 520, 11, self_loops=True), W.chain_of_bubbles(50), W.hprc_shaped([120, 30], seed=2, tiny=3)):
+        p = tmp_path / "g.gfa"
+        H.write_gfa(g, str(p))
+        assert p.read_text() == g.to_gfa()
+    with pytest.raises(RuntimeError):
+        H.write_gfa(W.chain_of_bubbles(3), str(tmp_path / "no" / "such" / "dir.gfa"))

@@ -201,11 +201,69 @@ def test_partial_sequential_redo_keeps_the_parallel_results_of_the_rest(hip, see
     assert f.texts() == want  # the earlier forest still owns its blocks
 
 
+def test_debug_hooks_refuse_the_state_of_a_mixed_pass(hip):
+    """After a pass that redid SOME components sequentially the classes and candidate stacks sit in two layouts: the hooks
+    return 4 instead of half-valid arrays (and work again after an all-parallel pass)."""
+    from povu_amd.hip import F_REDO_ODD
+    g = W.hprc_shaped([300, 120, 75, 210], seed=5, tiny=9)
+    hip.upload(g)
+    hip.decompose(flags=F_REDO_ODD)
+    assert 0 < hip.seq_redo_count()
+    import ctypes as C
+    n = C.c_uint32(0)
+    lib, ctx = hip._lib, hip._ctx
+    assert lib.povu_hip_debug_stack(ctx, 0, C.byref(n), None, None, None) == 4
+    assert lib.povu_hip_debug_edge_ids(ctx, 0, C.byref(n), None) == 4
+    cls = np.zeros(4 * g.n_vtx + 8, dtype=np.uint32)
+    assert lib.povu_hip_debug_tree(ctx, 0, C.byref(n), None, None, None, cls.ctypes.data) == 4
+    assert lib.povu_hip_debug_tree(ctx, 0, C.byref(n), None, None, None, None) == 0 and n.value > 0
+    hip.decompose()
+    assert lib.povu_hip_debug_stack(ctx, 0, C.byref(n), None, None, None) == 0 and n.value > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_laminar_check_on_demand_never_fires(hip, seed):
+    """The range-min check of the candidate stack's (prev, i) intervals runs only when the literal hi_2 rule capped
+    differently from the second-highest reach (DESIGN.md section 4, Row G has the proof for the other case);
+    POVU_HIP_F_CHECK_LAMINAR forces it.  With and without it: same PVSTs, no component sent to the sequential redo."""
+    from povu_amd.hip import F_CHECK_LAMINAR
+    if seed % 3 == 0:
+        g = W.hprc_shaped([900 + 200 * seed, 70], seed=300 + seed, tiny=5)
+    elif seed % 3 == 1:
+        n = 80 + 31 * seed
+        g = W.random_bidirected(n, int(n * (1.3 + 0.2 * (seed % 4))), 9100 + seed, connected=True, self_loops=(seed % 2 == 0))
+    else:
+        g = W.hprc_tangled(4000, seed=seed, tangle_every=900, max_tangle=500)
+    want = O.decompose(g)
+    hip.upload(g)
+    assert hip.decompose(flags=F_CHECK_LAMINAR).texts() == want and hip.seq_redo_count() == 0
+    assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
+
+
+def test_sequential_redo_of_a_million_segment_component(hip, golden_dir):
+    """What the guard path costs at size: BASELINE config 2 (one component of 10^6 segments) forced through the one-lane
+    kernels.  Bit-exact against the reference md5; the time is printed (`pytest -s`) and bounded loosely -- the redo is a
+    single lane walking the whole component, seconds where the parallel pass takes 1.3 ms."""
+    import time
+    from povu_amd.hip import F_FORCE_REDO
+    a = json.load(open(os.path.join(golden_dir, "anchors.json")))
+    g = W.chain_of_bubbles(333333)
+    hip.upload(g)
+    t0 = time.perf_counter()
+    f = hip.decompose(flags=F_FORCE_REDO)
+    dt = time.perf_counter() - t0
+    assert hip.seq_redo_count() == 1
+    assert md5(f.text(0)) == a["md5"]["chain_of_bubbles:333333"]
+    print(f"sequential redo of 10^6 segments / 2*10^6 links: {dt:.2f} s")
+    assert dt < 300
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_both_class_walks(hip, seed):
-    """The per-class DFS has two walks: the plain one (small classes) and the one over class-filtered scan
-    lists that is chosen when the sampled class sizes report a large class; POVU_HIP_F_BIG_CLASS_DFS forces
-    the latter.  Dense random graphs = few large 2-edge-connected classes with many in-class back edges."""
+    """The per-class DFS has two walks: one lane per class (small classes) and the wave-cooperative walk over
+    class-filtered candidate records that a class gets once it turns out larger than the lane's budget;
+    POVU_HIP_F_BIG_CLASS_DFS sends every class through the latter.  Dense random graphs = few large 2-edge-connected
+    classes with many in-class back edges."""
     from povu_amd.hip import F_BIG_CLASS_DFS
     n = 60 + 37 * seed
     g = W.random_bidirected(n, int(n * (1.2 + 0.25 * (seed % 5))), 8800 + seed, connected=(seed % 2 == 0), self_loops=(seed % 3 == 0))
