@@ -76,7 +76,7 @@ def build_workload(name, scale):
 
 def count_flubbles(forest):
     """PVST vertices that are flubbles (every tree has one root vertex besides them)."""
-    return sum(forest.tree(i).n_pvst - 1 for i in range(len(forest)))
+    return sum(n - 1 for n in forest.pvst_sizes())
 
 
 def time_single(hip, g, steps, warmup, flags):
@@ -289,6 +289,10 @@ def main():
                        "note": "csr_build = side degrees, offsets, adjacency sorted per side, other-end table, tips; "
                                "twin_index = reverse-slot table (atwin); both device time"},
             "value_incl_index_build": E / (step_s + (up["csr_ms"] + up["twin_ms"]) * 1e-3),
+            # the two definitions the --gpus N line reports, at N = 1: from the resident CSR (= `value`), and the whole job from
+            # the link arrays in HBM (CSR build + decompose; at N > 1 also label + partition + scatter)
+            "value_from_resident_shards": E * args.steps / dt,
+            "value_whole_job": E / (step_s + (up["csr_ms"] + up["twin_ms"]) * 1e-3),
             "pcie_inclusive_value": E / (step_s + upload_s),
         }
         if not args.no_secondary and args.workload == "hprc-wg":
@@ -325,6 +329,17 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # second measurement, same start / end as the N = 1 line: the shards the last step scattered stay resident (CSR built),
+        # a step = per-shard decompose + gather to rank 0
+        sb.step_resident()
+        sb.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sb.step_resident()
+        sb.sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_res = float(t.item())
         info = sb.summary()  # collective: per-rank loads and phase times
         if rank == 0:
             E, V, F = info["links"], info["segments"], info["flubbles"]
@@ -350,6 +365,12 @@ def main():
                              "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
                              "traffic": None, "algorithmic_bytes_per_launch": alg, "ms_per_launch": step_s * 1e3,
                              "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d) over the aggregate peak of all GPUs"},
+                # like-for-like with the N = 1 line's `value` (graph / shards resident as CSR -> forest on rank 0's host); `value`
+                # above is the whole job (label + partition + scatter + CSR build + decompose + gather), like-for-like with
+                # the N = 1 line's `value_whole_job`
+                "value_from_resident_shards": E * args.steps / dt_res,
+                "ms_per_step_from_resident_shards": dt_res / args.steps * 1e3,
+                "value_whole_job": E * args.steps / dt,
                 "shards": info["shards"],
                 "lpt_max_over_mean": info["lpt_max_over_mean"],
                 "phase_ms": info["phase_ms"],

@@ -1,8 +1,6 @@
-// primitives.hip -- device-wide primitives between the decompose kernels: hand-written exclusive
-// scans, rocPRIM for the stable radix sorts.
+// primitives.hip -- device-wide primitives between the decompose kernels: exclusive scans and the stable radix sort
+// of (key, value) pairs, all hand-written.
 #include "common.hpp"
-
-#include <rocprim/rocprim.hpp>
 
 namespace povu_hip
 {
@@ -362,22 +360,170 @@ void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, vo
 	KLAUNCH(k_xor128_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
 }
 
-// 25..27 key bits (the class sort of a whole-genome graph: ~2^26 brackets) take four 8-bit places with rocPRIM's tuned
-// default; three 9-bit places move a quarter less data (13-bit digits would need more LDS than a CU has)
-using nine = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-					rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 9,
-									    rocprim::block_radix_rank_algorithm::match>>;
-// rocPRIM merge-sorts up to 2^20 items by default: some twenty launches, which a pass that is bound by its launches on a
-// graph of that size feels more than the radix sort's four or five
-using few_launches = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t(1) << 16)>;
+// ---- stable LSD radix sort of (key, value) pairs, hand-written.  Per place of RB bits: a histogram per tile of RS_TILE
+// consecutive pairs, an exclusive scan over the [digit][tile] table (the scans above), and a scatter kernel in which
+// every wave ranks its stretch of the tile with ballots (the lanes that hold the same digit find each other by RB
+// ballots: no atomics, the order of equal keys is the order of the input), the tile is sorted into LDS, and consecutive
+// lanes then write consecutive pairs of one digit to consecutive addresses.  Pangenome keys cluster (brackets of one
+// bubble, slots of one side): runs of one digit inside a tile are long, and the table says where each run goes.
+static constexpr int RS_TPB = 256, RS_WAVES = RS_TPB / 64, RS_ITEMS = 16, RS_TILE = RS_TPB * RS_ITEMS, RS_MAX_BINS = 1024;
+
+__global__ void __launch_bounds__(RS_TPB) k_rs_hist(const uint32_t *__restrict__ keys, uint32_t n, unsigned shift, unsigned rb,
+						     uint32_t *__restrict__ hist, uint32_t ntiles)
+{
+	__shared__ uint32_t h[RS_MAX_BINS];
+	const uint32_t bins = 1u << rb, mask = bins - 1u;
+	for (uint32_t d = threadIdx.x; d < bins; d += RS_TPB)
+		h[d] = 0;
+	__syncthreads();
+	const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+	for (int r = 0; r < RS_ITEMS; r++) {
+		const uint32_t i = base + r * RS_TPB + threadIdx.x;
+		const bool live = i < n;
+		const uint32_t d = live ? (keys[i] >> shift) & mask : 0u;
+		// a whole wave on one digit (clustered keys) adds once
+		const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+		const unsigned long long lv = __ballot(live);
+		if (lv == ~0ull && __all(d == d0)) {
+			if ((threadIdx.x & 63) == 0)
+				atomicAdd(&h[d0], 64u);
+		} else if (live) {
+			atomicAdd(&h[d], 1u);
+		}
+	}
+	__syncthreads();
+	for (uint32_t d = threadIdx.x; d < bins; d += RS_TPB)
+		hist[(size_t)d * ntiles + blockIdx.x] = h[d];
+}
+
+__global__ void __launch_bounds__(RS_TPB) k_rs_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+							uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n, unsigned shift,
+							unsigned rb, const uint32_t *__restrict__ gofs, uint32_t ntiles)
+{
+	// the counters are dead once every pair knows its tile-local position: the staging area lies over them (36 KB of
+	// LDS in all, four workgroups per CU)
+	struct Counters {
+		uint32_t wcnt[RS_WAVES][RS_MAX_BINS]; // per wave: pairs of a digit seen so far; later: pairs in the waves before
+		uint32_t bbase[RS_MAX_BINS];	      // first tile-local position of a digit
+	};
+	union Overlay {
+		Counters c;
+		uint2 stage[RS_TILE];
+	};
+	__shared__ Overlay sh;
+	__shared__ uint32_t gof[RS_MAX_BINS]; // where the digit's run of this tile starts in the output, less bbase
+	__shared__ uint32_t wsum[RS_WAVES];
+	const uint32_t bins = 1u << rb, mask = bins - 1u;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	for (uint32_t k = 0; k < RS_WAVES; k++)
+		for (uint32_t d = threadIdx.x; d < bins; d += RS_TPB)
+			sh.c.wcnt[k][d] = 0;
+	const uint32_t base = blockIdx.x * RS_TILE, wbase = base + wave * (RS_ITEMS * 64);
+	uint32_t key[RS_ITEMS], val[RS_ITEMS], pos[RS_ITEMS];
+#pragma unroll
+	for (int r = 0; r < RS_ITEMS; r++) {
+		const uint32_t i = wbase + r * 64 + lane;
+		key[r] = i < n ? kin[i] : 0xFFFFFFFFu;
+		val[r] = i < n ? vin[i] : 0u;
+	}
+	__syncthreads();
+	// ---- rank inside the wave's stretch
+#pragma unroll
+	for (int r = 0; r < RS_ITEMS; r++) {
+		const bool live = wbase + r * 64 + lane < n;
+		const uint32_t d = (key[r] >> shift) & mask;
+		unsigned long long peers = __ballot(live);
+		for (unsigned b = 0; b < rb; b++) {
+			const unsigned long long m = __ballot((d >> b) & 1u);
+			peers &= ((d >> b) & 1u) ? m : ~m;
+		}
+		uint32_t old = 0;
+		if (live) {
+			const int leader = __ffsll((long long)peers) - 1;
+			if ((int)lane == leader) {
+				old = sh.c.wcnt[wave][d];
+				sh.c.wcnt[wave][d] = old + (uint32_t)__popcll(peers);
+			}
+			old = __shfl(old, leader);
+		}
+		pos[r] = old + (uint32_t)__popcll(peers & lt);
+	}
+	__syncthreads();
+	// ---- per digit: the pairs of the waves before (exclusive over waves), the tile's count; then the tile-local bases
+	uint32_t mine = 0; // pairs of the digits this thread owns: digits [t * per, (t + 1) * per)
+	const uint32_t per = (bins + RS_TPB - 1) / RS_TPB;
+	for (uint32_t k = 0; k < per; k++) {
+		const uint32_t d = threadIdx.x * per + k;
+		if (d < bins) {
+			uint32_t run = 0;
+			for (int w = 0; w < RS_WAVES; w++) {
+				const uint32_t c = sh.c.wcnt[w][d];
+				sh.c.wcnt[w][d] = run;
+				run += c;
+			}
+			sh.c.bbase[d] = run; // (count for now)
+			mine += run;
+		}
+	}
+	uint32_t inc = mine;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(inc, off);
+		if ((int)lane >= off)
+			inc += y;
+	}
+	if (lane == 63)
+		wsum[wave] = inc;
+	__syncthreads();
+	uint32_t before = inc - mine;
+	for (uint32_t w = 0; w < wave; w++)
+		before += wsum[w];
+	for (uint32_t k = 0; k < per; k++) {
+		const uint32_t d = threadIdx.x * per + k;
+		if (d < bins) {
+			const uint32_t c = sh.c.bbase[d];
+			sh.c.bbase[d] = before;
+			gof[d] = gofs[(size_t)d * ntiles + blockIdx.x] - before;
+			before += c;
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int r = 0; r < RS_ITEMS; r++) {
+		const uint32_t d = (key[r] >> shift) & mask;
+		pos[r] += sh.c.bbase[d] + sh.c.wcnt[wave][d];
+	}
+	__syncthreads(); // the counters are dead: the tile, sorted by digit, goes over them
+#pragma unroll
+	for (int r = 0; r < RS_ITEMS; r++)
+		if (wbase + r * 64 + lane < n)
+			sh.stage[pos[r]] = make_uint2(key[r], val[r]);
+	__syncthreads();
+	const uint32_t cnt = min((uint32_t)RS_TILE, n - base);
+	for (uint32_t j = threadIdx.x; j < cnt; j += RS_TPB) {
+		const uint2 e = sh.stage[j];
+		const uint32_t gp = gof[(e.x >> shift) & mask] + j;
+		kout[gp] = e.x;
+		vout[gp] = e.y;
+	}
+}
+
+static unsigned rs_places(size_t n, unsigned bits, unsigned &rb)
+{
+	// 9-bit digits (three places for the 25..27 key bits of a whole-genome graph); small inputs, whose table stays small,
+	// take 10 and save a place where that helps
+	const unsigned widest = n <= (size_t(1) << 24) ? 10u : 9u;
+	const unsigned places = (bits + widest - 1) / widest;
+	rb = (bits + places - 1) / places;
+	return places;
+}
+static size_t rs_table_words(size_t n) { return (size_t)RS_MAX_BINS / (n <= (size_t(1) << 24) ? 1 : 2) * ((n + RS_TILE - 1) / RS_TILE) + 64; }
+
 size_t sort_tmp_bytes(size_t n)
 {
-	size_t bytes = 0, bytes9 = 0;
-	(void)rocprim::radix_sort_pairs<few_launches>(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-						      (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32);
-	(void)rocprim::radix_sort_pairs<nine>(nullptr, bytes9, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-					      (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 27);
-	return std::max(bytes, bytes9) + 256;
+	// ping-pong buffer for keys and values + the [digit][tile] table (scanned in place) + the scan's own scratch
+	return 2 * ((n * 4 + 255) & ~size_t(255)) + ((rs_table_words(n) * 4 + 255) & ~size_t(255)) + scan_tmp_bytes(rs_table_words(n)) + 1024;
 }
 
 void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned bits,
@@ -385,10 +531,37 @@ void sort_pairs_u32(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, ui
 {
 	if (n == 0)
 		return;
-	if ((bits + 8) / 9 < (bits + 7) / 8 && n > (size_t(1) << 22)) // fewer places with 9-bit digits (17-18, 25-27 key bits)
-		HIP_CHECK(rocprim::radix_sort_pairs<nine>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
-	else
-		HIP_CHECK(rocprim::radix_sort_pairs<few_launches>(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, bits, s));
+	if (n >= (size_t(1) << 32) - RS_TILE)
+		throw HipError("sort: too many pairs");
+	if (tmp_bytes < sort_tmp_bytes(n))
+		throw HipError("sort: temporary storage too small");
+	if (bits == 0)
+		bits = 1;
+	char *q = static_cast<char *>(tmp);
+	uint32_t *kt = reinterpret_cast<uint32_t *>(q);
+	q += (n * 4 + 255) & ~size_t(255);
+	uint32_t *vt = reinterpret_cast<uint32_t *>(q);
+	q += (n * 4 + 255) & ~size_t(255);
+	uint32_t *table = reinterpret_cast<uint32_t *>(q);
+	q += (rs_table_words(n) * 4 + 255) & ~size_t(255);
+	void *stmp = q;
+	const size_t stmp_bytes = scan_tmp_bytes(rs_table_words(n));
+	unsigned rb = 0;
+	const unsigned places = rs_places(n, bits, rb);
+	const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+	// the last place writes kout / vout: in -> [tmp ->] out for an even / odd number of places
+	const uint32_t *ki = kin, *vi = vin;
+	for (unsigned p = 0; p < places; p++) {
+		const bool to_out = ((places - 1 - p) & 1u) == 0;
+		uint32_t *ko = to_out ? kout : kt, *vo = to_out ? vout : vt;
+		const unsigned shift = p * rb, w = std::min(rb, bits - std::min(bits, shift));
+		const unsigned prb = w ? w : 1u;
+		const size_t words = ((size_t)1 << prb) * ntiles;
+		KLAUNCH(k_rs_hist, dim3(ntiles), dim3(RS_TPB), 0, s, ki, (uint32_t)n, shift, prb, table, ntiles);
+		scan_exclusive_u32(table, table, words, stmp, stmp_bytes, s);
+		KLAUNCH(k_rs_scatter, dim3(ntiles), dim3(RS_TPB), 0, s, ki, vi, ko, vo, (uint32_t)n, shift, prb, table, ntiles);
+		ki = ko, vi = vo;
+	}
 }
 
 } // namespace povu_hip

@@ -219,6 +219,16 @@ class Forest:
     def __len__(self) -> int:
         return self._lib.povu_hip_forest_tree_count(self._h)
 
+    def pvst_sizes(self) -> List[int]:
+        """PVST vertices of every tree (no array is copied)."""
+        out = []
+        t = _Tree()
+        for i in range(len(self)):
+            if self._lib.povu_hip_forest_get(self._h, i, C.byref(t)) != 0:
+                raise IndexError(i)
+            out.append(int(t.n_pvst))
+        return out
+
     def tree(self, i: int, with_text: bool = False) -> PvstTree:
         t = _Tree()
         if self._lib.povu_hip_forest_get(self._h, i, C.byref(t)) != 0:

@@ -262,6 +262,16 @@ class ShardedBench:
         del f
         return merged
 
+    def step_resident(self):
+        """The part of a step that starts from "every rank's shard CSR resident" (what the last scatter left) and ends with
+        "forest merged on rank 0": per-shard decompose + gather.  Same start and end as the N = 1 measurement of bench.py."""
+        f = self.work.decompose_shard(flags=_hip.F_NO_STAGE_TIMES)
+        merged = self.comm.gather(f) if self.native else gather_over_dist(self.work, f, self.rank, self.world, self.dev)
+        if self.rank == 0:
+            self.last = merged
+        del f
+        return merged
+
     def sync(self):
         import torch
         import torch.distributed as dist

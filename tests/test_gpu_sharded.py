@@ -168,3 +168,5 @@ def test_bench_rehearsal_two_ranks_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["components"] == 2024 and len(line["shards"]) == 2
     assert sum(s["n_links"] for s in line["shards"]) == line["config"]["links"]
+    # both definitions of the rate: the whole job, and from resident shards (what the N = 1 line's `value` measures)
+    assert line["value_whole_job"] == line["value"] and line["value_from_resident_shards"] > line["value"] > 0
