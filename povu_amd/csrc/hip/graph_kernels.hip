@@ -443,23 +443,19 @@ __device__ __forceinline__ bool slot_is_first(uint32_t i, uint32_t s, uint32_t v
 		return (o & 1u) == s || s == 0;
 	return i < (pos ? pos[o >> 1] : (o >> 1)); // pos == nullptr: one component, sorted order = global order
 }
-// first-encounter flags + the local degree of every side (no atomics) + the largest of them
-__global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
-			      const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
-			      const uint32_t *__restrict__ sbase, uint8_t *__restrict__ flag, uint8_t *__restrict__ ldeg,
-			      uint32_t *__restrict__ stats)
+// the local degree of every side (no atomics) + the largest of them
+__global__ void k_local_degree(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
+			       const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth, uint8_t *__restrict__ ldeg,
+			       uint32_t *__restrict__ stats)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t cnt = 0;
 	if (S < 2 * V) {
 		uint32_t i = S >> 1, s = S & 1, v = perm ? perm[i] : i;
-		uint32_t b0 = off[2 * v], lo = off[2 * v + s], hi = off[2 * v + s + 1];
-		uint32_t P = (sbase ? sbase[i] : b0) + (lo - b0); // (no sbase: sorted space = global space, slot bases are the CSR offsets)
-		for (uint32_t k = lo; k < hi; k++, P++) {
+		uint32_t lo = off[2 * v + s], hi = off[2 * v + s + 1];
+		for (uint32_t k = lo; k < hi; k++) {
 			const uint32_t o = aoth[k];
-			const bool f = slot_is_first(i, s, v, o, pos);
-			flag[P] = f ? 1 : 0;
-			cnt += ((o >> 1) == v) ? (f ? 1u : 0u) : 1u;
+			cnt += ((o >> 1) == v) ? (slot_is_first(i, s, v, o, pos) ? 1u : 0u) : 1u;
 		}
 		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1];
 		for (uint32_t k = lo; k < hi; k++) {
@@ -486,16 +482,18 @@ __global__ void k_mark_first3(uint32_t V, const uint32_t *__restrict__ perm, con
 	}
 }
 
-// every side gathers its (local edge, other side) pairs and keeps them ascending by local edge with an
-// insertion sort in place (std::set order of the per-side edge lists); the first-encounter slot also
-// writes the local edge itself.  The local edge of a slot that is not the first encounter is the rank of its
-// twin slot (atwin, built at upload).
+// Every side gathers its (link id, other side) pairs and keeps them ascending by link id with an insertion sort in place
+// (std::set order of the per-side edge lists).  componetize numbers a component's links in first-encounter order
+// (bidirected.cpp:558-569); all the traversal needs of that number is (a) the ORDER it gives the links of one side and (b) a
+// name that both ends of a link agree on.  The position of the link's first-encounter slot in the sorted slot order
+// has both properties and needs no counting: it is this slot's own position for the end that meets the link first, the
+// twin slot's (atwin, built at upload) for the other end.  lle[slot] = that id | LLE_TREE when the link is in the spanning
+// forest of the segments (so that the tree kernels read the flag with the slot, not through the id).
 __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
 			    const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
 			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ atwin,
-			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ erank,
-			    const uint32_t *__restrict__ loff, const uint8_t *__restrict__ hook, uint32_t *__restrict__ la,
-			    uint32_t *__restrict__ lb, uint8_t *__restrict__ tgray, uint32_t *ladj, uint32_t *lle)
+			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ loff,
+			    const uint8_t *__restrict__ hook, uint32_t *ladj, uint32_t *lle)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
@@ -509,19 +507,20 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 	// the first four entries of a side are kept sorted in registers (almost every side has fewer) and written once;
 	// a fifth entry flushes them and the insertion sort continues in place in global memory
 	uint32_t l0 = NIL32, l1 = NIL32, l2 = NIL32, l3 = NIL32, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-	auto insert = [&](uint32_t le, uint32_t other) {
+	auto id_of = [](uint32_t w) { return w == NIL32 ? NIL32 : (w & LLE_ID); };
+	auto insert = [&](uint32_t le, uint32_t other) { // le: id | flag
 		if (n < 4) {
 			l3 = le, o3 = other; // slot 3 is free while n < 4 (free slots hold NIL32 = +inf)
 			uint32_t t;
-			if (l3 < l2) {
+			if (id_of(l3) < id_of(l2)) {
 				t = l2, l2 = l3, l3 = t;
 				t = o2, o2 = o3, o3 = t;
 			}
-			if (l2 < l1) {
+			if (id_of(l2) < id_of(l1)) {
 				t = l1, l1 = l2, l2 = t;
 				t = o1, o1 = o2, o2 = t;
 			}
-			if (l1 < l0) {
+			if (id_of(l1) < id_of(l0)) {
 				t = l0, l0 = l1, l1 = t;
 				t = o0, o0 = o1, o1 = t;
 			}
@@ -533,7 +532,7 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 			ladj[base] = o0, ladj[base + 1] = o1, ladj[base + 2] = o2, ladj[base + 3] = o3;
 		}
 		uint32_t j = n++;
-		while (j > 0 && lle[base + j - 1] > le) {
+		while (j > 0 && (lle[base + j - 1] & LLE_ID) > (le & LLE_ID)) {
 			lle[base + j] = lle[base + j - 1];
 			ladj[base + j] = ladj[base + j - 1];
 			j--;
@@ -544,32 +543,24 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 	for (uint32_t k = lo; k < hi; k++, P++) {
 		const uint32_t o = aoth[k], vo = o >> 1;
 		const bool loop = vo == v;
+		const uint32_t tree = hook[adj[k]] ? LLE_TREE : 0u;
 		if (loop) {
 			if (!slot_is_first(i, s, v, o, pos))
 				continue; // the l-r loop's r slot: the l side owns the edge, this side gets it below
-			const uint32_t le = erank[P];
-			la[le] = S;
-			lb[le] = S ^ 1u;
-			tgray[le] = hook[adj[k]];
-			insert(le, S ^ 1u);
+			insert(P | tree, S ^ 1u);
 			continue;
 		}
 		const uint32_t io = pos ? pos[vo] : vo, other = 2 * io + (o & 1u);
-		if (i < io) { // first encounter
-			const uint32_t le = erank[P];
-			la[le] = S;
-			lb[le] = other;
-			tgray[le] = hook[adj[k]];
-			insert(le, other);
-		} else {
-			insert(erank[sbase ? sbase[io] + (atwin[k] - off[2 * vo]) : atwin[k]], other);
-		}
+		if (i < io) // first encounter: the link is named after this slot
+			insert(P | tree, other);
+		else
+			insert((sbase ? sbase[io] + (atwin[k] - off[2 * vo]) : atwin[k]) | tree, other);
 	}
 	lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sb + (lo - b0);
 	for (uint32_t k = lo; k < hi; k++, P++) {
 		const uint32_t o = aoth[k];
 		if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
-			insert(erank[P], S ^ 1u);
+			insert(P | (hook[adj[k]] ? LLE_TREE : 0u), S ^ 1u);
 	}
 	if (n <= 4) { // never flushed: write the registers
 		if (n > 0)
@@ -585,14 +576,15 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 
 // after the stable sort by side: other side and local edge of every adjacency slot
 __global__ void k_local_slots(uint32_t n, const uint32_t *__restrict__ origin, const uint32_t *__restrict__ la,
-			      const uint32_t *__restrict__ lb, uint32_t *__restrict__ ladj, uint32_t *__restrict__ lle)
+			      const uint32_t *__restrict__ lb, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ ladj,
+			      uint32_t *__restrict__ lle)
 {
 	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= n)
 		return;
 	uint32_t o = origin[k], le = o >> 1;
 	ladj[k] = (o & 1) ? la[le] : lb[le];
-	lle[k] = le;
+	lle[k] = le | (tgray[le] ? LLE_TREE : 0u); // (here the id is the dense first-encounter rank: same order, same agreement)
 }
 
 __global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *out)
@@ -615,15 +607,16 @@ __global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *
 
 // first local edge of every component; also publishes voff / eoff / stats straight into the context's
 // page-locked host buffer [voff C+1 | eoff C+1 | stats 4] when one is given
-__global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ off,
-				    const uint32_t *__restrict__ sbase,
-				    const uint32_t *__restrict__ erank, uint32_t *__restrict__ eoff,
-				    const uint32_t *__restrict__ stats, uint32_t *__restrict__ host_pub)
+// (every local link owns one slot at either end and the components are contiguous in sorted space: the links in front of
+// component c are half the local slots in front of its first side)
+__global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff,
+				    uint32_t *__restrict__ eoff, const uint32_t *__restrict__ stats,
+				    uint32_t *__restrict__ host_pub)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c > C)
 		return;
-	const uint32_t vo = voff[c], eo = erank[sbase ? sbase[vo] : off[2 * vo]];
+	const uint32_t vo = voff[c], eo = loff[2 * vo] / 2;
 	eoff[c] = eo;
 	if (host_pub) {
 		host_pub[c] = vo;
@@ -795,14 +788,14 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	if (sort_free) {
 		const uint32_t *pos_or_identity = identity ? nullptr : st.pos; // sorted order = global order: no vertex is renumbered
 		const uint32_t *perm = st.lean_identity ? nullptr : st.perm, *sbase = st.lean_identity ? nullptr : st.sbase;
-		uint8_t *first8 = reinterpret_cast<uint8_t *>(st.flag), *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
-		KLAUNCH(k_mark_first3, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, sbase, first8, ldeg8,
-				   st.stats);
-		scan_exclusive_u8(first8, st.erank, (size_t)g.n_slots + 1, ldeg8, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+		uint8_t *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
+		KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
+		scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin, sbase,
-				   st.erank, st.loff, st.hook, st.la, st.lb, st.tgray, st.ladj, st.lle);
-		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, g.off, sbase, st.erank, st.eoff,
-				   st.stats, st.host_pub);
+				   st.loff, st.hook, st.ladj, st.lle);
+		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats,
+				   st.host_pub);
+		st.dense_edges = false;
 		tm.end(launches + 7);
 		return;
 	}
@@ -818,13 +811,13 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			   st.tgray);
 	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
 	KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
-	KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, g.off, st.sbase, st.erank,
-			   st.eoff, st.stats, st.host_pub);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
+	KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats, st.host_pub);
+	st.dense_edges = true; // la / lb hold the links in local edge order (povu_hip_componetize)
 	// local per-side adjacency (other side ids), ascending local edge idx
 	sort_pairs_u32(st.keys, st.keys2, st.vals, st.vals2, 2 * (size_t)E, bits_for(nS), st.sort_tmp, st.sort_tmp_bytes, s);
 	if (E)
-		KLAUNCH(k_local_slots, dim3(nblk(2 * (size_t)E)), dim3(TPB), 0, s, 2 * E, st.vals2, st.la, st.lb,
+		KLAUNCH(k_local_slots, dim3(nblk(2 * (size_t)E)), dim3(TPB), 0, s, 2 * E, st.vals2, st.la, st.lb, st.tgray,
 				   st.ladj, st.lle);
 	launches += 10;
 	tm.end(launches);

@@ -25,6 +25,8 @@ struct ResidentGraph {
 	void *block = nullptr;			    // one allocation backing all of the above
 };
 
+static constexpr uint32_t LLE_ID = 0x1FFFFFFFu, LLE_TREE = 0x40000000u; // lle words (below)
+
 // Rows B outputs, all in the "sorted" vertex space: sorted position i = vertices
 // ordered by (component rank, global idx); component c owns positions
 // [voff[c], voff[c+1]) and local vertex idx = i - voff[c]; sorted side id = 2i + end.
@@ -33,9 +35,12 @@ struct CompState {
 	uint32_t *voff, *eoff, *vdeg, *sbase, *first, *erank, *ldeg, *loff, *ladj;
 	uint32_t *keys, *vals, *keys2, *vals2;
 	uint8_t *hook;	   // [E]  1 = the link merged two union-find trees (spanning forest of the segments)
-	uint32_t *la, *lb; // [E]  sorted side ids of local edge le (la = first-encounter side)
-	uint32_t *lle;	   // [2E] local edge idx of every adjacency slot
-	uint8_t *tgray;	   // [E+1] local edge is in the spanning forest
+	uint32_t *la, *lb; // [E]  sorted side ids of local edge le (la = first-encounter side); only the sorted-adjacency builder fills them
+	uint32_t *lle;	   // [2E] per local adjacency slot: the link's id (LLE_ID bits) | LLE_TREE.  Both ends of a link carry the same id
+			   //      and a side's slots ascend by it in first-encounter order: the position of the link's first-encounter slot
+			   //      (sort-free builder) or its dense rank = componetize's local edge idx (sorted-adjacency builder)
+	uint8_t *tgray;	   // [E+1] local edge is in the spanning forest (sorted-adjacency builder only; the traversal reads LLE_TREE)
+	bool dense_edges;  // la / lb / dense local edge ids are valid (sorted-adjacency builder)
 	uint32_t *stats;   // [4]  stats[0] = max links on one side
 	uint32_t *gid_s; // (may alias the resident graph's vid / tip: never written through)
 	uint8_t *tip_s;

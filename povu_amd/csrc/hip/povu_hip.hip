@@ -329,7 +329,9 @@ extern "C" povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *er
 		tm.reset();
 		tm.enabled = true;
 		const uint32_t C = label_components(g, cs, tm, s);
-		reindex_components(g, cs, C, tm, s);
+		reindex_components(g, cs, C, tm, s, true); // (the builder that numbers the local edges: la / lb in local edge order)
+		if (!cs.dense_edges)
+			throw HipError("componetize: local edges were not numbered (internal)");
 		auto o = std::make_unique<ComponentsOwner>();
 		const size_t V = g.V, E = g.E;
 		o->voff.resize(C + 1);

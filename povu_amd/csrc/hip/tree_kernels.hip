@@ -71,7 +71,7 @@ __device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, unsigned 
 // or stored per arc: the twin of a slot is found in the (short, ascending) list of the side at the other end, and
 // the arcs around a segment are taken in slot order -- the slots of its l side, then those of its r side, which are
 // one contiguous index range [loff[2w], loff[2w + 2]) -- so the subtrees hanging off ONE side are contiguous in the tour.
-// slot (1-based) of local edge `le` in the list of side w (ascending by local edge idx)
+// slot (1-based) of the link with id `le` (LLE_ID bits of its lle words) in the list of side w (ascending by link id)
 __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle, uint32_t w,
 						   uint32_t le)
 {
@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ 
 	if (hi - lo > 8) {
 		while (lo < hi) {
 			const uint32_t mid = (lo + hi) >> 1;
-			if (lle[mid] < le)
+			if ((lle[mid] & LLE_ID) < le)
 				lo = mid + 1;
 			else
 				hi = mid;
@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ 
 		return lo - l0 + 1;
 	}
 	for (uint32_t j = lo; j < hi; j++)
-		if (lle[j] == le)
+		if ((lle[j] & LLE_ID) == le)
 			return j - l0 + 1;
 	return 0; // (not reached: a link sits in the lists of both its ends)
 }
@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t arc_twin(const uint32_t *__restrict__ loff, 
 					     const uint32_t *__restrict__ lle, uint32_t at)
 {
 	const uint32_t w = ladj[at];
-	return loff[w] + find_link_slot(loff, lle, w, lle[at]) - 1;
+	return loff[w] + find_link_slot(loff, lle, w, lle[at] & LLE_ID) - 1;
 }
 // (bridge test of step 3, see k_t0_parents) every non-tree link gets a 64-bit hash of its local edge idx
 // -- TWO independent 64-bit hashes, carried side by side in one 16-byte word (the second one is what stands behind the
@@ -121,7 +121,7 @@ __device__ __forceinline__ bool heq(const ulonglong2 a, const ulonglong2 b) { re
 // of both its ends, also when they are l and r of one segment), written only where it is not zero (four sides in five
 // of a pangenome graph have no such link); ft[S] = its first arc (FT_NONE: none), bit 31 set when hside[S] was written.
 __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			     const uint32_t *__restrict__ lle, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, unsigned b,
+			     const uint32_t *__restrict__ lle, uint32_t *__restrict__ pk, unsigned b,
 			     ulonglong2 *__restrict__ hside, uint32_t *__restrict__ ft, uint32_t *__restrict__ twin)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,8 +131,8 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 	ulonglong2 h = make_ulonglong2(0ull, 0ull);
 	uint32_t first = NIL;
 	for (uint32_t at = lo; at < hi; at++) {
-		const uint32_t le = lle[at];
-		if (!tgray[le]) {
+		const uint32_t lw = lle[at], le = lw & LLE_ID;
+		if (!(lw & LLE_TREE)) {
 			pk[at] = PK_END | PK_STOP;
 			h = hx(h, link_hash(le));
 			continue;
@@ -144,10 +144,10 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 		const uint32_t sb = loff[w & ~1u], se = loff[(w & ~1u) + 2];
 		uint32_t nxt = t;
 		for (uint32_t j = t + 1; j < se && nxt == t; j++)
-			if (tgray[lle[j]])
+			if (lle[j] & LLE_TREE)
 				nxt = j;
 		for (uint32_t j = sb; j < t && nxt == t; j++)
-			if (tgray[lle[j]])
+			if (lle[j] & LLE_TREE)
 				nxt = j;
 		pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 	}
@@ -167,7 +167,7 @@ __device__ __forceinline__ uint32_t comp_root_side(const unsigned long long *sta
 // A component of one segment has no arc and heads no list.
 __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const unsigned long long *__restrict__ start_key,
 			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
-			    const uint8_t *__restrict__ tgray, uint32_t *__restrict__ pk, uint32_t *__restrict__ heads)
+			    uint32_t *__restrict__ pk, uint32_t *__restrict__ heads)
 {
 	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= C)
@@ -176,13 +176,13 @@ __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const
 	// cyclic order from `mid`: [mid, se) then [sb, mid)
 	uint32_t a_first = NIL, a_last = NIL;
 	for (uint32_t j = mid; j < se; j++)
-		if (tgray[lle[j]]) {
+		if (lle[j] & LLE_TREE) {
 			if (a_first == NIL)
 				a_first = j;
 			a_last = j;
 		}
 	for (uint32_t j = sb; j < mid; j++)
-		if (tgray[lle[j]]) {
+		if (lle[j] & LLE_TREE) {
 			if (a_first == NIL)
 				a_first = j;
 			a_last = j;
@@ -523,7 +523,7 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 static constexpr uint32_t T0_RBIT = 0x80000000u;
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
-			     const uint32_t *__restrict__ lle, const uint32_t *__restrict__ la, const uint8_t *__restrict__ tgray,
+			     const uint32_t *__restrict__ lle,
 			     const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
 			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, ulonglong2 *__restrict__ val, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
@@ -542,10 +542,12 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 	const uint32_t c = ckey[S >> 1], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
 	const uint32_t lo = loff[S], hi = loff[S + 1];
 	for (uint32_t at = lo; at < hi; at++) {
-		const uint32_t le = lle[at];
-		if (!tgray[le] || la[le] != S)
-			continue; // a link of the forest is handled once, from the side that met it first
-		const uint32_t w = ladj[at], t = twin[at];
+		const uint32_t lw = lle[at], le = lw & LLE_ID, w = ladj[at];
+		// a link of the forest is handled once, from the side that met it first = the one of the smaller sorted vertex (a
+		// self loop never is a forest link)
+		if (!(lw & LLE_TREE) || (S >> 1) >= (w >> 1))
+			continue;
+		const uint32_t t = twin[at];
 		const uint32_t da = dist[at], dt = dist[t];
 		const uint32_t pa = abase + (L - 1 - da), pt = abase + (L - 1 - dt); // tour positions of the two arcs
 		const bool down = da > dt;					      // `at` comes first: S is the parent of w
@@ -597,7 +599,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 		uint32_t end; // position behind the last of them
 		if (r.x == NIL) // root segment: the start side's arcs come first, S's are the rest of the tour
 			end = abase + L;
-		else if (a3 != FT_NONE && lle[a3] != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
+		else if (a3 != FT_NONE && (lle[a3] & LLE_ID) != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
 			end = abase + (L - 1 - dist[a3]);
 		else
 			end = r.w;
@@ -651,7 +653,7 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 				uint32_t le = t0seg[S >> 1].y & ~T0_RBIT, lo = loff[p], hi = loff[p + 1];
 				while (lo < hi) {
 					uint32_t mid = (lo + hi) >> 1;
-					if (lle[mid] < le)
+					if ((lle[mid] & LLE_ID) < le)
 						lo = mid + 1;
 					else
 						hi = mid;
@@ -1453,14 +1455,14 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	if (n_slots >= PK_END || 3 * (size_t)V >= PK_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
 		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^29");
 	uint32_t *twin = tw.wadj; // [2E] (the filtered scan lists come much later)
-	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, bitsA, hside, ft, twin);
-	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, cs.tgray, rb.pk, rb.heads);
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, rb.pk, bitsA, hside, ft, twin);
+	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, rb.pk, rb.heads);
 	if (n_slots)
 		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
 	ulonglong2 *val = tw.xval, *px = tw.xps; // [NA+1] each
 	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 16, s));
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, cs.la, cs.tgray, hside, ft, rb.heads,
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, hside, ft, rb.heads,
 	       twin, tw.t0seg, val, C, start_key, pw.err + 2);
 	tm.end(40);
 
