@@ -206,6 +206,10 @@ void scan_exclusive_diff_u32(const uint32_t *in, const uint32_t *sub, uint32_t *
 // exclusive running xor of 128-bit words (two independent 64-bit hashes side by side)
 void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
 size_t scan_tmp_bytes(size_t n);
+// indices of the non-zero bytes of flag[0..n), ascending, into out; their number into *count_dev (device memory).  No
+// prefix array is written: tiles are counted, the counts scanned, the tiles ranked again.
+void compact_flagged_u8(const uint8_t *flag, size_t n, uint32_t *out, uint32_t *count_dev, void *tmp, size_t tmp_bytes, hipStream_t s);
+size_t compact_tmp_bytes(size_t n);
 // exclusive running maximum (identity 0)
 void scan_exclusive_max_u32(const uint32_t *in, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
 // stable LSD radix sort of (key,value) pairs on the low `bits` bits of the key

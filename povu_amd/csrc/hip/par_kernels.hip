@@ -276,26 +276,81 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 // The brackets are laid out in an initial order that already satisfies the second criterion
 // (simplifying | capping | ordinary by DESCENDING dense idx), so ONE stable 32-bit radix sort by the
 // source's mirror pre-order yields the list order.
-__global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
-				const uint32_t *__restrict__ pscap, const uint8_t *__restrict__ simp,
-				const uint32_t *__restrict__ pssimp, const uint32_t *__restrict__ cap_tgt,
-				const RootOf root_of, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
-				const uint32_t *__restrict__ ordcnt, const uint32_t *__restrict__ gsize,
-				const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt, uint32_t *__restrict__ srccnt)
+// Where a capping / simplifying bracket goes needs the rank of its vertex among the flagged ones.  No prefix arrays: the
+// flags are counted per workgroup of k_bracket_extra (k_flag_tile_counts, 256 vertices a tile), the two count arrays
+// scanned, and k_bracket_extra ranks its own 256 flags again with ballots.
+static constexpr uint32_t BX_TILE = TPB;
+__global__ void __launch_bounds__(TPB) k_flag_tile_counts(uint32_t T, const uint8_t *__restrict__ capf, const uint8_t *__restrict__ simp,
+							   uint32_t *__restrict__ tcap, uint32_t *__restrict__ tsimp, uint32_t ntiles)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
+	// a workgroup counts 16 tiles: every lane takes 16 consecutive vertices (one 16-byte load per flag array), sixteen
+	// consecutive lanes make a tile
+	const uint32_t e0 = (blockIdx.x * TPB + threadIdx.x) * 16u;
+	uint32_t nc = 0, ns = 0;
+	if (e0 + 16 <= T) {
+		const uint4 a = *reinterpret_cast<const uint4 *>(capf + e0), b = *reinterpret_cast<const uint4 *>(simp + e0);
+		const uint32_t wa[4] = {a.x, a.y, a.z, a.w}, wb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				nc += ((wa[k] >> (8 * q)) & 0xFFu) ? 1u : 0u;
+				ns += ((wb[k] >> (8 * q)) & 0xFFu) ? 1u : 0u;
+			}
+	} else {
+		for (uint32_t k = e0; k < T; k++) {
+			nc += capf[k] ? 1u : 0u;
+			ns += simp[k] ? 1u : 0u;
+		}
+	}
+	for (int off = 8; off; off >>= 1) {
+		nc += __shfl_down(nc, off, 16);
+		ns += __shfl_down(ns, off, 16);
+	}
+	const uint32_t tile = (blockIdx.x * TPB + threadIdx.x) / 16u;
+	if ((threadIdx.x & 15u) == 0 && tile <= ntiles) { // (tile == ntiles closes the arrays: the scan leaves the totals there)
+		tcap[tile] = tile < ntiles ? nc : 0u;
+		tsimp[tile] = tile < ntiles ? ns : 0u;
+	}
+}
+__global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
+							const uint32_t *__restrict__ tcap, const uint8_t *__restrict__ simp,
+							const uint32_t *__restrict__ tsimp, const uint32_t *__restrict__ cap_tgt,
+							const RootOf root_of, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
+							const uint32_t *__restrict__ ordcnt, const uint32_t *__restrict__ gsize,
+							const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
+							uint32_t *__restrict__ srccnt)
+{
+	__shared__ uint32_t wc[TPB / 64], ws[TPB / 64];
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool live = v < T;
+	const uint32_t c = live ? capf[v] : 0u, sm = live ? simp[v] : 0u;
+	// rank among the flagged vertices: the tiles before (scanned counts) + the waves before + the lanes before
+	const unsigned long long mc = __ballot(c != 0), ms = __ballot(sm != 0);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (lane == 0) {
+		wc[wave] = (uint32_t)__popcll(mc);
+		ws[wave] = (uint32_t)__popcll(ms);
+	}
+	__syncthreads();
+	if (!live)
 		return;
-	const uint32_t c = capf[v], sm = simp[v];
+	const unsigned long long lt = (1ull << lane) - 1ull;
 	if (c) {
-		uint32_t j = NB0 + pscap[v];
+		uint32_t r = tcap[blockIdx.x] + (uint32_t)__popcll(mc & lt);
+		for (uint32_t w = 0; w < wave; w++)
+			r += wc[w];
+		const uint32_t j = NB0 + r;
 		b_src[j] = v;
 		b_tgt[j] = cap_tgt[v];
 		if (ordcnt)
 			atomicAdd(&incnt[cap_tgt[v]], 1u);
 	}
 	if (sm) {
-		uint32_t j = NB0 + ncap + pssimp[v];
+		uint32_t r = tsimp[blockIdx.x] + (uint32_t)__popcll(ms & lt);
+		for (uint32_t w = 0; w < wave; w++)
+			r += ws[w];
+		const uint32_t j = NB0 + ncap + r;
 		const uint32_t root = root_of(v);
 		b_src[j] = v;
 		b_tgt[j] = root;
@@ -304,7 +359,7 @@ __global__ void k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const u
 	}
 	// (dense path) brackets per source, at its place in the list order: known per vertex, no counting pass over the brackets
 	if (ordcnt && gsize[v])
-		srccnt[mpre[v]] = ordcnt[v] + c + sm;
+		srccnt[mpre[v]] = ordcnt[v] + (c ? 1u : 0u) + (sm ? 1u : 0u);
 }
 __global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32_t nsimp, const uint32_t *__restrict__ b_src,
 				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ mpre,
@@ -879,7 +934,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segH1.tree, SegTree::tree_words(T + 1) * 4);
 	take((void **)&pw.segH2.tree, SegTree::tree_words(T + 1) * 4);
 	take((void **)&pw.segH3.tree, SegTree::tree_words(T + 1) * 4);
-	pw.scan_tmp_bytes = scan_tmp_bytes(std::max(T, NB) + 4);
+	pw.scan_tmp_bytes = std::max(scan_tmp_bytes(std::max(T, NB) + 4), 2 * compact_tmp_bytes(std::max(T, NB) + 4));
 	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), std::max(4 * V, 2 * E) + 8) + 4);
 	take(&pw.scan_tmp, pw.scan_tmp_bytes);
 	take(&pw.sort_tmp, pw.sort_tmp_bytes);
@@ -995,11 +1050,15 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan8(bridge, psb, (size_t)T + 1);
 	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, pw.hi0, root_of,
 	       pw.segA, pw.err + 5);
-	scan_exclusive_u8(simp, pssimp, (size_t)T + 1, capf, pscap, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	// capping / simplifying vertices per tile of k_bracket_extra, scanned: [ntiles + 1] each, the totals in the last word
+	const uint32_t ntiles = (T + BX_TILE - 1) / BX_TILE;
+	uint32_t *tsimp = pssimp, *tcap = pscap;
+	KLAUNCH(k_flag_tile_counts, dim3((ntiles + 1 + 15) / 16 + 1), dim3(TPB), 0, s, T, capf, simp, tcap, tsimp, ntiles);
+	scan_exclusive_u32_pair(tsimp, tsimp, (size_t)ntiles + 1, tcap, tcap, (size_t)ntiles + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	uint32_t *extra = pw.host->take<uint32_t>(3);
-	HIP_CHECK(hipMemcpyAsync(&extra[0], pscap + T, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(&extra[1], pssimp + T, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&extra[0], tcap + ntiles, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&extra[1], tsimp + ntiles, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(&extra[2], pw.err + 5, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
@@ -1013,7 +1072,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// both take the all-vertices pass.
 	const bool black_only = !want_hp && !pw.all_vertex_classes && extra[2] == 0;
 	pw.black_only_used = black_only;
-	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, pscap, simp, pssimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
+	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, tcap, simp, tsimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
 	       dense_nb0 >= 0 ? pw.lsz : nullptr, pw.gsize, pw.mpre, pw.incnt, srccnt);
 	if (dense_nb0 >= 0) { // ranks inside every source and the counts per source are known: place directly
 		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);

@@ -360,6 +360,123 @@ void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, vo
 	KLAUNCH(k_xor128_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
 }
 
+// ---- indices of the set bytes of a flag array, in order (stream compaction without a prefix array): per-tile counts,
+// one workgroup scans the counts, the tiles then rank their own flags again and write the indices.  The flags are read
+// twice (a byte each); the 4-byte prefix array a scan would hand to a separate compaction kernel is never written.
+static constexpr int CP_TPB = 256, CP_ITEMS = 16, CP_TILE = CP_TPB * CP_ITEMS;
+__device__ __forceinline__ uint32_t cp_load16(const uint8_t *__restrict__ flag, size_t e0, size_t n, uint32_t &bits)
+{
+	bits = 0;
+	if (e0 + CP_ITEMS <= n) {
+		const uint4 a = *reinterpret_cast<const uint4 *>(flag + e0);
+		const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+#pragma unroll
+			for (int b = 0; b < 4; b++)
+				if ((w[k] >> (8 * b)) & 0xFFu)
+					bits |= 1u << (4 * k + b);
+	} else {
+		for (int k = 0; k < CP_ITEMS; k++)
+			if (e0 + k < n && flag[e0 + k])
+				bits |= 1u << k;
+	}
+	return (uint32_t)__popc(bits);
+}
+__device__ __forceinline__ uint32_t cp_block_exclusive(uint32_t v, uint32_t *sh, uint32_t &total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inc = v;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(inc, off);
+		if (lane >= off)
+			inc += y;
+	}
+	if (lane == 63)
+		sh[wave] = inc;
+	__syncthreads();
+	uint32_t before = inc - v;
+	total = 0;
+	for (int w = 0; w < CP_TPB / 64; w++) {
+		if (w < wave)
+			before += sh[w];
+		total += sh[w];
+	}
+	return before;
+}
+__global__ void __launch_bounds__(CP_TPB) k_cp_count(const uint8_t *__restrict__ flag, size_t n, uint32_t *__restrict__ tile_cnt)
+{
+	__shared__ uint32_t sh[CP_TPB / 64];
+	uint32_t bits, total;
+	const uint32_t c = cp_load16(flag, (size_t)blockIdx.x * CP_TILE + (size_t)threadIdx.x * CP_ITEMS, n, bits);
+	(void)cp_block_exclusive(c, sh, total);
+	if (threadIdx.x == 0)
+		tile_cnt[blockIdx.x] = total;
+}
+// exclusive scan of the tile counts in place, one workgroup (a few ten thousand tiles); *count_out = the grand total
+__global__ void __launch_bounds__(1024) k_cp_scan_tiles(uint32_t *tile_cnt, uint32_t ntiles, uint32_t *__restrict__ count_out)
+{
+	__shared__ uint32_t sh[16];
+	const uint32_t per = (ntiles + 1023) / 1024, lo = min(ntiles, threadIdx.x * per), hi = min(ntiles, lo + per);
+	uint32_t sum = 0;
+	for (uint32_t k = lo; k < hi; k++)
+		sum += tile_cnt[k];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t inc = sum;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(inc, off);
+		if (lane >= off)
+			inc += y;
+	}
+	if (lane == 63)
+		sh[wave] = inc;
+	__syncthreads();
+	uint32_t before = inc - sum, total = 0;
+	for (int w = 0; w < 16; w++) {
+		if (w < wave)
+			before += sh[w];
+		total += sh[w];
+	}
+	for (uint32_t k = lo; k < hi; k++) {
+		const uint32_t c = tile_cnt[k];
+		tile_cnt[k] = before;
+		before += c;
+	}
+	if (threadIdx.x == 0)
+		*count_out = total;
+}
+__global__ void __launch_bounds__(CP_TPB) k_cp_write(const uint8_t *__restrict__ flag, size_t n, const uint32_t *__restrict__ tile_base,
+						      uint32_t *__restrict__ out)
+{
+	__shared__ uint32_t sh[CP_TPB / 64];
+	const size_t e0 = (size_t)blockIdx.x * CP_TILE + (size_t)threadIdx.x * CP_ITEMS;
+	uint32_t bits, total;
+	const uint32_t c = cp_load16(flag, e0, n, bits);
+	uint32_t at = tile_base[blockIdx.x] + cp_block_exclusive(c, sh, total);
+	while (bits) {
+		const int k = __ffs((int)bits) - 1;
+		bits &= bits - 1;
+		out[at++] = (uint32_t)(e0 + k);
+	}
+}
+size_t compact_tmp_bytes(size_t n) { return ((n + CP_TILE - 1) / CP_TILE + 1) * 4 + 256; }
+void compact_flagged_u8(const uint8_t *flag, size_t n, uint32_t *out, uint32_t *count_dev, void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	if (n == 0) {
+		HIP_CHECK(hipMemsetAsync(count_dev, 0, 4, s));
+		return;
+	}
+	if (reinterpret_cast<uintptr_t>(flag) & 15)
+		throw HipError("compaction: the flags must be 16-byte aligned");
+	if (tmp_bytes < compact_tmp_bytes(n))
+		throw HipError("compaction: temporary storage too small");
+	const uint32_t ntiles = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
+	uint32_t *tile_cnt = static_cast<uint32_t *>(tmp);
+	KLAUNCH(k_cp_count, dim3(ntiles), dim3(CP_TPB), 0, s, flag, n, tile_cnt);
+	KLAUNCH(k_cp_scan_tiles, dim3(1), dim3(1024), 0, s, tile_cnt, ntiles, count_dev);
+	KLAUNCH(k_cp_write, dim3(ntiles), dim3(CP_TPB), 0, s, flag, n, tile_cnt, out);
+}
+
 // ---- stable LSD radix sort of (key, value) pairs, hand-written.  Per place of RB bits: a histogram per tile of RS_TILE
 // consecutive pairs, an exclusive scan over the [digit][tile] table (the scans above), and a scatter kernel in which
 // every wave ranks its stretch of the tile with ballots (the lanes that hold the same digit find each other by RB

@@ -665,14 +665,6 @@ __global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const u
 	dps[S] = rec;
 	entry_flag[S] = ef;
 }
-__global__ void k_compact(uint32_t n, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
-			  uint32_t *__restrict__ out)
-{
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && flag[i])
-		out[ps[i]] = i;
-}
-
 // ------------------------------------------------------------------ 6. the DFS inside every class
 // Small classes (a bubble: a handful of sides) are walked by ONE LANE each, millions at a time (k_class_dfs_small).
 // A class that turns out larger than CLASS_BUDGET sides is handed to the WAVE-COOPERATIVE walk below, one wave per
@@ -1098,7 +1090,8 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 				t_flags[tr] = 2;
 				t_par[tr] = NIL;
 				t_size[tr] = Nr + 1;
-				t_depth[tr] = 0;
+				if (t_depth)
+					t_depth[tr] = 0;
 				mpre[tr] = tr;
 				ordcnt[tr] = 0; // (a dummy root has no back edges of its own; every other tree vertex gets these from k_back_edges)
 				hi0[tr] = NIL;
@@ -1145,7 +1138,8 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 	t_flags[t] = (uint8_t)((S & 1) | (far ? TF_BLACK : 0));
 	t_par[t] = par;
 	t_size[t] = size;
-	t_depth[t] = depth + hd;
+	if (t_depth) // (only the hairpin report's T-space setup reads the depths again)
+		t_depth[t] = depth + hd;
 	mpre[t] = tb + (depth + hd) + (Nh + hd) - l - size;
 	side_tidx[S] = t;
 }
@@ -1478,9 +1472,9 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	tm.begin("tree_class_dfs");
 	uint32_t *cstate = sw.cur; // [nS+1]
 	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.dps, tw.entry_flag, cstate);
-	scan_exclusive_u8(tw.entry_flag, tw.entry_ps, (size_t)nS + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	LAUNCH(k_compact, nS, s, nS, tw.entry_flag, tw.entry_ps, tw.entry_list);
-	const uint32_t n_entry = tw.host->read_u32(tw.entry_ps + nS, s);
+	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
+	compact_flagged_u8(tw.entry_flag, nS, tw.entry_list, n_entry_dev, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	const uint32_t n_entry = tw.host->read_u32(n_entry_dev, s);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
 	// gives up and reports the entry; those classes are then walked from the start by the walk with the short dependent
 	// chain, at the price of a filtering pass over the adjacency (it marks visits in its own bytes and rewrites the same
@@ -1528,7 +1522,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
 	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
-	       sw.t_par, sw.t_size, sw.t_depth, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
+	       sw.t_par, sw.t_size, sw.hairpins ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
 	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
