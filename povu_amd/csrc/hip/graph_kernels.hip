@@ -132,6 +132,9 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 // global atomics, no long global pointer chains), otherwise the slot goes onto the cross list -- wave ballot +
 // prefix popcount, one atomic per wave -- and k_uf_cross unites it in global memory afterwards.
 static constexpr uint32_t UF_TILE = 8192, UF_TPB = 1024, UF_HEAVY = 128, UF_HEAVY_CAP = 256;
+// vertices with more links than this take the radix-sorted adjacency path of the re-index (an insertion sort per side is
+// quadratic in the side's links)
+static constexpr uint32_t SORT_FREE_MAX_VDEG = 48;
 
 __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 {
@@ -174,9 +177,15 @@ __device__ __forceinline__ void wave_append(bool take, uint32_t v, uint32_t k, u
 		xlist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, k);
 }
 
+// ldeg (optional): the LOCAL degree of every side, for the sort-free adjacency builder of the re-index -- a side's links,
+// where a self loop counts once on the side that meets it first AND once on the opposite side (it is stored as
+// (ve, complement(ve)), bidirected.cpp:529-531).  The slots are in hand here anyway; which slot of a loop comes first
+// does not depend on the components (slot_is_first).  Sides with more than UF_HEAVY links get no count (graphs that
+// have them take the sorted-adjacency builder).
 __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
 						  const uint32_t *__restrict__ adj, uint32_t *__restrict__ label,
-						  uint8_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist)
+						  uint8_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist,
+						  uint8_t *__restrict__ ldeg, uint32_t *__restrict__ stats)
 {
 	__shared__ uint32_t par[UF_TILE];
 	__shared__ uint32_t heavy[UF_HEAVY_CAP];
@@ -187,8 +196,8 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 	if (threadIdx.x == 0)
 		n_heavy = 0;
 	__syncthreads();
-	auto handle = [&](uint32_t v, uint32_t k) -> bool { // true: the slot leaves the tile upwards
-		const uint32_t vo = aoth[k] >> 1;
+	auto handle = [&](uint32_t v, uint32_t k, uint32_t o) -> bool { // o = aoth[k]; true: the slot leaves the tile upwards
+		const uint32_t vo = o >> 1;
 		if (vo <= v)
 			return false; // handled from the other end (or a self loop: never a forest link)
 		if (vo >= v1)
@@ -198,6 +207,7 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		return false;
 	};
 	const uint32_t S0 = 2 * v0, S1 = 2 * v1;
+	uint32_t ldeg_most = 0;
 	for (uint32_t base = S0; base < S1; base += blockDim.x) { // uniform trip count: the ballots below need whole waves
 		const uint32_t S = base + threadIdx.x;
 		uint32_t k = 0, hi = 0;
@@ -212,12 +222,32 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 				}
 			}
 		}
+		uint32_t own = hi - k, opp = 0; // local slots of S from its own links; self loops S meets first (they also sit on S ^ 1)
 		while (__any(k < hi)) {
 			const bool live = k < hi;
-			const bool cross = live && handle(S >> 1, k);
+			const uint32_t o = live ? aoth[k] : 0u;
+			const bool cross = live && handle(S >> 1, k, o);
 			wave_append(cross, S >> 1, k, xcount, xlist);
+			if (live && (o >> 1) == (S >> 1)) { // a self loop: counts on the side that meets it first, there and opposite
+				const uint32_t f = ((o & 1u) == (S & 1u) || (S & 1u) == 0u) ? 1u : 0u;
+				own -= 1u - f, opp += f;
+			}
 			k++;
 		}
+		if (ldeg) { // (S and S ^ 1 are neighbouring lanes: tiles start on even sides, the stride is even)
+			const uint32_t cnt = own + __shfl_xor(opp, 1);
+			if (S < S1)
+				ldeg[S] = (uint8_t)min(cnt, 255u);
+			if (S == 2 * V - 1)
+				ldeg[2 * V] = 0; // closes the array the scan turns into loff
+			ldeg_most = max(ldeg_most, S < S1 ? cnt : 0u);
+		}
+	}
+	if (ldeg) { // stats[0] = most local slots on one side
+		for (int o = 32; o; o >>= 1)
+			ldeg_most = max(ldeg_most, __shfl_down(ldeg_most, o));
+		if ((threadIdx.x & 63) == 0 && ldeg_most > __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+			atomicMax(stats, ldeg_most); // (few waves ever need the atomic)
 	}
 	__syncthreads();
 	const uint32_t nh = min(n_heavy, UF_HEAVY_CAP);
@@ -225,7 +255,7 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		const uint32_t S = heavy[q], lo = off[S], hi = off[S + 1];
 		for (uint32_t kb = lo; kb < hi; kb += blockDim.x) {
 			const uint32_t k = kb + threadIdx.x;
-			const bool cross = k < hi && handle(S >> 1, k);
+			const bool cross = k < hi && handle(S >> 1, k, aoth[k]);
 			wave_append(cross, S >> 1, k, xcount, xlist);
 		}
 	}
@@ -720,17 +750,21 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	HIP_CHECK(hipEventElapsedTime(&g.twin_ms, ev[1], ev[2]));
 }
 
-uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
+bool sort_free_adjacency(const ResidentGraph &g, bool force_sorted_adjacency) { return g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency; }
+
+uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s, bool want_local_degrees)
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
 	// one byte per link; the length of the cross list sits behind them (zeroed by the same memset)
 	const size_t xoff = ((size_t)E + 7) & ~size_t(7);
-	HIP_CHECK(hipMemsetAsync(st.hook, 0, xoff + 8, s));
+	HIP_CHECK(hipMemsetAsync(st.hook, 0, xoff + 24, s));
 	uint32_t *xcount = reinterpret_cast<uint32_t *>(st.hook + xoff);
+	st.ldeg_max = xcount + 1; // [4] most local slots on one side (k_uf_tiles), cleared with the flags
+	st.ldeg_ready = want_local_degrees && sort_free_adjacency(g, false);
 	uint2 *xlist = reinterpret_cast<uint2 *>(st.keys); // [E] pairs fit the 2E+2 words; free until the re-index
 	KLAUNCH(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, g.off, g.aoth, g.adj, st.label,
-			   st.hook, xcount, xlist);
+			   st.hook, xcount, xlist, st.ldeg_ready ? reinterpret_cast<uint8_t *>(st.ldeg) : nullptr, st.ldeg_max);
 	if (E) {
 		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, xcount, xlist, g.aoth, g.adj,
 				   st.label, st.hook);
@@ -748,9 +782,6 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	return h[0];
 }
 
-// vertices with more links than this take the radix-sorted adjacency path (an insertion sort per side is
-// quadratic in the side's links)
-static constexpr uint32_t SORT_FREE_MAX_VDEG = 48;
 
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
 			bool force_sorted_adjacency)
@@ -762,7 +793,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	// stable sort of vertices by component rank: local vertex idx = rank inside the component,
 	// ascending global idx (comp_vtxs is a std::set, bidirected.cpp:552-555)
 	const bool identity = C == 1 || st.comp_sorted;
-	const bool sort_free = g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency;
+	const bool sort_free = sort_free_adjacency(g, force_sorted_adjacency);
 	// One component, or components one after the other in the vertex order: the order already is (component, idx), sorted
 	// space is the global vertex space.  The sort-free builder then needs no permutation, position, slot-base, id or tip
 	// array at all -- it reads the resident graph's own (slot base of vertex i = off[2 i]).
@@ -789,11 +820,17 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		const uint32_t *pos_or_identity = identity ? nullptr : st.pos; // sorted order = global order: no vertex is renumbered
 		const uint32_t *perm = st.lean_identity ? nullptr : st.perm, *sbase = st.lean_identity ? nullptr : st.sbase;
 		uint8_t *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
-		KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
+		// the local degrees: the labelling kernel left them when the vertices keep their places (they are a property of the
+		// sides: which slot of a self loop comes first does not depend on the components)
+		const uint32_t *side_max = st.stats;
+		if (st.ldeg_ready && st.lean_identity)
+			side_max = st.ldeg_max;
+		else
+			KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
 		scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin, sbase,
 				   st.loff, st.hook, st.ladj, st.lle);
-		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats,
+		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, side_max,
 				   st.host_pub);
 		st.dense_edges = false;
 		tm.end(launches + 7);
