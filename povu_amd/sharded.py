@@ -9,9 +9,10 @@ The work is done by the C library (`povu_amd/csrc/hip/shard.hip`, declared in `i
   context's own stream: shards out, PVST blocks back to the root (replaces the reference's static contiguous
   chunks per thread, app/subcommand/decompose.cpp:78-92,116-157).  No collective runs inside the traversal.
 
-This module is the launcher-side plumbing: it hands the RCCL unique id around with `torch.distributed`, offers
-the same scatter / gather over any `torch.distributed` backend through host memory (`*_over_dist`, what the
-gloo tests and single-GPU rehearsals use), and a numpy model of the partition for the tests.
+This module is the launcher-side plumbing: the same scatter / gather over `torch.distributed` (`*_over_dist`: with
+backend "nccl" the packed shards and forests travel device to device through RCCL, with gloo through host memory --
+the CPU-side tests and single-GPU rehearsals), the hand-over of the RCCL unique id for the library's own calls, and a
+numpy model of the partition for the tests.
 """
 from __future__ import annotations
 
@@ -158,13 +159,24 @@ class ShardComm:
         return dict(scatter_ms=t[0], gather_ms=t[1])
 
 
-# ---------------------------------------------------------------- the same over torch.distributed, through host memory
+# ---------------------------------------------------------------- the same over torch.distributed
+class _DeviceBytes:
+    """Zero-copy view of library-owned device memory for torch.as_tensor (CUDA array interface, works on ROCm)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
 def scatter_over_dist(full: Optional["_hip.HipDecomposer"], work: "_hip.HipDecomposer", rank: int, world: int, device):
-    """Scatter with any torch.distributed backend (gloo in the CPU-side tests, single-GPU rehearsals): the root
-    partitions on its GPU, exports every packed shard to host memory and sends it; receivers load it."""
+    """Scatter with a torch.distributed backend.  On GPUs (backend "nccl" = RCCL) the packed shards travel device to
+    device over xGMI: the root sends straight out of its partition block in HBM (no copy), a receiver builds its CSR from
+    the bytes where they land.  With a CPU backend (gloo: CPU-side tests, single-GPU rehearsals) they go through host
+    memory.  The root's sends are asynchronous: its own shard is loaded and its CSR built beside them."""
     import torch
     import torch.distributed as dist
 
+    on_gpu = device.type == "cuda"
     if rank == 0:
         shards = full.partition(world)
         sizes = torch.tensor([shards.info(r)["bytes"] for r in range(world)], dtype=torch.int64, device=device)
@@ -175,21 +187,28 @@ def scatter_over_dist(full: Optional["_hip.HipDecomposer"], work: "_hip.HipDecom
     if rank == 0:
         pending = []
         for r in range(1, world):
-            t = torch.from_numpy(shards.export(r)).to(device)
+            i = shards.info(r)
+            t = (torch.as_tensor(_DeviceBytes(i["device_ptr"], i["bytes"]), device=device) if on_gpu
+                 else torch.from_numpy(shards.export(r)))
             pending.append((dist.isend(t, r), t))
         i0 = shards.info(0)
         work.upload_shard(i0["device_ptr"], i0["bytes"], on_device=True)
         for w, _t in pending:
             w.wait()
         return shards
-    buf = torch.zeros(int(sizes[rank].item()), dtype=torch.uint8, device=device)
+    n = int(sizes[rank].item())
+    buf = torch.empty(n, dtype=torch.uint8, device=device)
     dist.recv(buf, 0)
-    work.upload_shard(buf.cpu().numpy())
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()  # (the library works on its own stream)
+        work.upload_shard(buf.data_ptr(), n, on_device=True)
+    else:
+        work.upload_shard(buf.numpy())
     return None
 
 
 def gather_over_dist(work: "_hip.HipDecomposer", forest: "_hip.Forest", rank: int, world: int, device):
-    """PVST gather to rank 0 over torch.distributed: packed forests through host memory, merged by the library."""
+    """PVST gather to rank 0 over torch.distributed: packed forests (device to device on GPUs), merged by the library."""
     import torch
     import torch.distributed as dist
 
@@ -201,9 +220,12 @@ def gather_over_dist(work: "_hip.HipDecomposer", forest: "_hip.Forest", rank: in
         dist.send(torch.from_numpy(mine).to(device), 0)
         return None
     parts = [mine]
+    recv = []
     for r in range(1, world):
-        b = torch.zeros(int(sizes[r].item()), dtype=torch.uint8, device=device)
-        dist.recv(b, r)
+        b = torch.empty(int(sizes[r].item()), dtype=torch.uint8, device=device)
+        recv.append((dist.irecv(b, r), b))
+    for w, b in recv:
+        w.wait()
         parts.append(b.cpu().numpy())
     return work.merge_forests(parts)
 
@@ -218,7 +240,11 @@ class ShardedBench:
         import torch.distributed as dist
 
         self.work, self.rank, self.world, self.dev = work, rank, world, comm_device
-        self.native = comm_device.type == "cuda"  # RCCL from C++; otherwise torch.distributed through host memory
+        # Transfers: torch.distributed (backend "nccl" = RCCL: ncclSend / ncclRecv of device buffers over xGMI) by default;
+        # POVU_BENCH_NATIVE_RCCL=1 takes the library's own RCCL calls (shard.hip: povu_hip_comm_scatter / _gather), which
+        # no multi-GPU box has run yet
+        import os
+        self.native = comm_device.type == "cuda" and os.environ.get("POVU_BENCH_NATIVE_RCCL") == "1"
         self.full = None
         self.meta = None
         if rank == 0:
@@ -313,8 +339,11 @@ class ShardedBench:
         out.update(components=len(ids), flubbles=flub, shards=shards,
                    lpt_max_over_mean=max(s["weight"] for s in shards) / mean_w,
                    sharding=("strong scaling: rank 0 labels the components on its GPU, LPT bin-packing, device partition, "
-                             + ("RCCL ncclSend/ncclRecv scatter of the packed shards and gather of the PVST blocks (C++, shard.hip)"
-                                if self.native else "scatter / gather over torch.distributed through host memory (rehearsal)")
+                             + ("RCCL ncclSend/ncclRecv scatter of the packed shards and gather of the PVST blocks from C++ (shard.hip)"
+                                if self.native else
+                                ("RCCL send/recv (torch.distributed, backend nccl) of the packed shards out of the partition block in HBM "
+                                 "and of the packed forests back" if self.dev.type == "cuda" else
+                                 "scatter / gather over torch.distributed through host memory (rehearsal)"))
                              + "; all inside the timed region"),
                    phase_ms={"per_rank": [dict(zip(("partition", "scatter", "decompose", "gather"), [float(x) for x in p.tolist()]))
                                           for p in allp],

@@ -170,3 +170,29 @@ def test_bench_rehearsal_two_ranks_one_gpu(tmp_path):
     assert sum(s["n_links"] for s in line["shards"]) == line["config"]["links"]
     # both definitions of the rate: the whole job, and from resident shards (what the N = 1 line's `value` measures)
     assert line["value_whole_job"] == line["value"] and line["value_from_resident_shards"] > line["value"] > 0
+
+
+def test_shards_leave_the_partition_block_without_a_copy():
+    """What the torch.distributed scatter sends on GPUs: a zero-copy torch view of the packed shard in the root's HBM
+    (CUDA array interface) holds exactly the bytes `export` returns, and a shard loads from a torch CUDA tensor's
+    device pointer -- the receiving side of an RCCL recv."""
+    from povu_amd import HipDecomposer
+    g = _graph()
+    want = O.decompose(g)
+    full, work = HipDecomposer(0), HipDecomposer(0)
+    full.upload(g)
+    sh = full.partition(3)
+    dev = torch.device("cuda", 0)
+    got = {}
+    for r in range(3):
+        i = sh.info(r)
+        t = torch.as_tensor(sharded._DeviceBytes(i["device_ptr"], i["bytes"]), device=dev)
+        assert t.dtype == torch.uint8 and t.numel() == i["bytes"] and t.data_ptr() == i["device_ptr"]
+        assert np.array_equal(t.cpu().numpy(), sh.export(r))
+        landed = t.clone()  # (an RCCL recv would have written these bytes)
+        torch.cuda.synchronize()
+        work.upload_shard(landed.data_ptr(), landed.numel(), on_device=True)
+        got.update(work.decompose_shard().texts())
+    assert got == want
+    full.close()
+    work.close()
