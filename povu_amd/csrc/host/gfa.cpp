@@ -74,7 +74,9 @@ struct Seg {
 };
 // what one tokenizer thread found in its slice of the file (whole lines, in file order)
 struct Slice {
-	std::vector<Seg> segs;
+	std::vector<uint32_t> ids;  // segment ids in file order
+	std::vector<Seg> segs;	    // ... with their sequences (only with want_labels)
+	bool ascending = true;	    // ids strictly ascending inside the slice
 	std::vector<uint32_t> la, lb;
 	std::vector<uint8_t> sa, sb;
 	std::vector<GfaPath> paths;
@@ -103,7 +105,7 @@ std::string slice_error(const std::string &fp, int kind, size_t line, char c)
 	}
 }
 
-void tokenize_slice(const char *p, const char *end, bool want_paths, Slice &out)
+void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_labels, Slice &out)
 {
 	size_t line_no = 1;
 	auto fail = [&](int kind, char c = 0) {
@@ -144,7 +146,11 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, Slice &out)
 			uint32_t id;
 			if (!parse_id(fb[1], fe[1], id))
 				return fail(4);
-			out.segs.push_back({id, fb[2], fe[2]});
+			if (!out.ids.empty() && id <= out.ids.back())
+				out.ascending = false;
+			out.ids.push_back(id);
+			if (want_labels)
+				out.segs.push_back({id, fb[2], fe[2]});
 			break;
 		}
 		case 'L': {
@@ -206,13 +212,32 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, Slice &out)
 }
 } // namespace
 
+namespace
+{
+// fn(t, lo, hi) over [0, n) cut into T contiguous ranges, one thread each
+template <typename F>
+void parallel_ranges(size_t T, size_t n, F &&fn)
+{
+	T = std::max<size_t>(1, std::min(T, n / 65536 + 1));
+	if (T == 1) {
+		fn(0, 0, n);
+		return;
+	}
+	std::vector<std::thread> pool;
+	for (size_t t = 0; t < T; t++)
+		pool.emplace_back([&, t]() { fn(t, n / T * t, t + 1 == T ? n : n / T * (t + 1)); });
+	for (auto &th : pool)
+		th.join();
+}
+} // namespace
+
 GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int threads)
 {
 	Mapped f(fp);
 	GfaGraph g;
 	// slices of whole lines, one tokenizer thread each; results are stitched together in file order
-	size_t T = (size_t)std::max(1, threads);
-	T = std::min<size_t>(T, std::max<size_t>(1, f.n >> 22)); // at least 4 MiB per thread
+	const size_t TH = (size_t)std::max(1, threads);
+	size_t T = std::min<size_t>(TH, std::max<size_t>(1, f.n >> 22)); // at least 4 MiB per thread
 	std::vector<const char *> cut(T + 1);
 	cut[0] = f.p;
 	cut[T] = f.p + f.n;
@@ -225,48 +250,79 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	}
 	std::vector<Slice> slices(T);
 	if (T == 1) {
-		tokenize_slice(cut[0], cut[1], want_paths, slices[0]);
+		tokenize_slice(cut[0], cut[1], want_paths, want_labels, slices[0]);
 	} else {
 		std::vector<std::thread> pool;
 		for (size_t t = 0; t < T; t++)
-			pool.emplace_back([&, t]() { tokenize_slice(cut[t], cut[t + 1], want_paths, slices[t]); });
+			pool.emplace_back([&, t]() { tokenize_slice(cut[t], cut[t + 1], want_paths, want_labels, slices[t]); });
 		for (auto &th : pool)
 			th.join();
 	}
-	size_t lines_before = 0, n_seg = 0, n_link = 0;
-	for (const Slice &sl : slices) { // the first malformed record in file order
+	size_t lines_before = 0;
+	std::vector<size_t> seg_at(T + 1, 0), link_at(T + 1, 0);
+	bool ascending = true; // segment ids strictly ascending over the whole file (what GFA writers usually produce)
+	for (size_t t = 0; t < T; t++) { // the first malformed record in file order
+		const Slice &sl = slices[t];
 		if (sl.err_kind)
 			throw std::runtime_error(slice_error(fp, sl.err_kind, lines_before + sl.err_line, sl.err_char));
 		lines_before += sl.lines;
-		n_seg += sl.segs.size();
-		n_link += sl.la.size();
+		seg_at[t + 1] = seg_at[t] + sl.ids.size();
+		link_at[t + 1] = link_at[t] + sl.la.size();
+		ascending = ascending && sl.ascending;
 	}
-	std::vector<Seg> segs;
-	std::vector<uint32_t> la, lb;
-	std::vector<uint8_t> sa, sb;
-	segs.reserve(n_seg);
-	la.reserve(n_link);
-	lb.reserve(n_link);
-	sa.reserve(n_link);
-	sb.reserve(n_link);
-	for (Slice &sl : slices) {
-		segs.insert(segs.end(), sl.segs.begin(), sl.segs.end());
-		la.insert(la.end(), sl.la.begin(), sl.la.end());
-		lb.insert(lb.end(), sl.lb.begin(), sl.lb.end());
-		sa.insert(sa.end(), sl.sa.begin(), sl.sa.end());
-		sb.insert(sb.end(), sl.sb.begin(), sl.sb.end());
+	{ // (slices without segments do not break the order)
+		uint32_t last = 0;
+		bool any = false;
+		for (const Slice &sl : slices)
+			if (!sl.ids.empty()) {
+				if (any && sl.ids.front() <= last)
+					ascending = false;
+				last = sl.ids.back();
+				any = true;
+			}
+	}
+	const size_t n_seg = seg_at[T], E = link_at[T];
+	if (n_seg == 0)
+		throw std::runtime_error(invalid(fp, "liteseq returned no vertices"));
+	// every thread moves its slice to its place in the final arrays
+	std::vector<uint32_t> la(E), lb(E);
+	g.vid.resize(n_seg);
+	g.s1.resize(E);
+	g.s2.resize(E);
+	std::vector<Seg> segs(want_labels ? n_seg : 0);
+	{
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < T; t++)
+			pool.emplace_back([&, t]() {
+				Slice &sl = slices[t];
+				std::copy(sl.ids.begin(), sl.ids.end(), g.vid.begin() + seg_at[t]);
+				std::copy(sl.la.begin(), sl.la.end(), la.begin() + link_at[t]);
+				std::copy(sl.lb.begin(), sl.lb.end(), lb.begin() + link_at[t]);
+				std::copy(sl.sa.begin(), sl.sa.end(), g.s1.begin() + link_at[t]);
+				std::copy(sl.sb.begin(), sl.sb.end(), g.s2.begin() + link_at[t]);
+				if (want_labels)
+					std::copy(sl.segs.begin(), sl.segs.end(), segs.begin() + seg_at[t]);
+				sl.ids = {}, sl.la = {}, sl.lb = {}, sl.sa = {}, sl.sb = {}, sl.segs = {};
+			});
+		for (auto &th : pool)
+			th.join();
+	}
+	for (Slice &sl : slices)
 		for (auto &pa : sl.paths)
 			g.paths.push_back(std::move(pa));
-		sl = Slice{};
+	if (!ascending) { // vertices ascending by segment id, the first record of an id wins
+		if (want_labels) {
+			std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.id < y.id; });
+			segs.erase(std::unique(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.id == y.id; }), segs.end());
+			g.vid.resize(segs.size());
+			for (size_t i = 0; i < segs.size(); i++)
+				g.vid[i] = segs[i].id;
+		} else {
+			std::sort(g.vid.begin(), g.vid.end());
+			g.vid.erase(std::unique(g.vid.begin(), g.vid.end()), g.vid.end());
+		}
 	}
-	if (segs.empty())
-		throw std::runtime_error(invalid(fp, "liteseq returned no vertices"));
-	std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.id < y.id; });
-	segs.erase(std::unique(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.id == y.id; }), segs.end());
-	const size_t V = segs.size(), E = la.size();
-	g.vid.resize(V);
-	for (size_t i = 0; i < V; i++)
-		g.vid[i] = segs[i].id;
+	const size_t V = g.vid.size();
 	if (want_labels) {
 		g.seq.resize(V);
 		for (size_t i = 0; i < V; i++)
@@ -277,31 +333,36 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	std::vector<uint32_t> table;
 	if ((uint64_t)max_id < 4 * (uint64_t)V + 1024) {
 		table.assign((size_t)max_id + 1, 0xFFFFFFFFu);
-		for (size_t i = 0; i < V; i++)
-			table[g.vid[i]] = (uint32_t)i;
+		parallel_ranges(TH, V, [&](size_t, size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; i++)
+				table[g.vid[i]] = (uint32_t)i;
+		});
 	}
-	auto idx_of = [&](uint32_t id, size_t e) -> uint32_t {
-		uint32_t r = 0xFFFFFFFFu;
-		if (!table.empty()) {
-			if (id <= max_id)
-				r = table[id];
-		} else {
-			auto it = std::lower_bound(g.vid.begin(), g.vid.end(), id);
-			if (it != g.vid.end() && *it == id)
-				r = (uint32_t)(it - g.vid.begin());
-		}
-		if (r == 0xFFFFFFFFu)
-			throw std::runtime_error(invalid(fp, "L record " + std::to_string(e) + " references unknown segment " +
-								     std::to_string(id)));
-		return r;
-	};
 	g.v1.resize(E);
 	g.v2.resize(E);
-	g.s1 = std::move(sa);
-	g.s2 = std::move(sb);
-	for (size_t e = 0; e < E; e++) {
-		g.v1[e] = idx_of(la[e], e);
-		g.v2[e] = idx_of(lb[e], e);
+	std::vector<size_t> bad(TH, (size_t)-1); // first link of a range that names an unknown segment
+	parallel_ranges(TH, E, [&](size_t t, size_t lo, size_t hi) {
+		auto idx_of = [&](uint32_t id) -> uint32_t {
+			if (!table.empty())
+				return id <= max_id ? table[id] : 0xFFFFFFFFu;
+			auto it = std::lower_bound(g.vid.begin(), g.vid.end(), id);
+			return (it != g.vid.end() && *it == id) ? (uint32_t)(it - g.vid.begin()) : 0xFFFFFFFFu;
+		};
+		for (size_t e = lo; e < hi; e++) {
+			const uint32_t a = idx_of(la[e]), b = idx_of(lb[e]);
+			if ((a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) && bad[t] == (size_t)-1)
+				bad[t] = e;
+			g.v1[e] = a;
+			g.v2[e] = b;
+		}
+	});
+	size_t first_bad = (size_t)-1;
+	for (size_t b : bad)
+		first_bad = std::min(first_bad, b);
+	if (first_bad != (size_t)-1) {
+		const uint32_t id = g.v1[first_bad] == 0xFFFFFFFFu ? la[first_bad] : lb[first_bad];
+		throw std::runtime_error(invalid(fp, "L record " + std::to_string(first_bad) + " references unknown segment " +
+							     std::to_string(id)));
 	}
 	return g;
 }
