@@ -177,15 +177,13 @@ __device__ __forceinline__ void wave_append(bool take, uint32_t v, uint32_t k, u
 		xlist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(v, k);
 }
 
-// ldeg (optional): the LOCAL degree of every side, for the sort-free adjacency builder of the re-index -- a side's links,
-// where a self loop counts once on the side that meets it first AND once on the opposite side (it is stored as
-// (ve, complement(ve)), bidirected.cpp:529-531).  The slots are in hand here anyway; which slot of a loop comes first
-// does not depend on the components (slot_is_first).  Sides with more than UF_HEAVY links get no count (graphs that
-// have them take the sorted-adjacency builder).
+// *any_loop is raised when some link joins a segment to itself: without self loops the local adjacency of the re-index
+// has exactly the global slots (a self loop is stored as (ve, complement(ve)) and owns a slot on either side,
+// bidirected.cpp:529-531), so its offsets are the CSR's own.
 __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
 						  const uint32_t *__restrict__ adj, uint32_t *__restrict__ label,
 						  uint8_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist,
-						  uint8_t *__restrict__ ldeg, uint32_t *__restrict__ stats)
+						  uint32_t *__restrict__ any_loop)
 {
 	__shared__ uint32_t par[UF_TILE];
 	__shared__ uint32_t heavy[UF_HEAVY_CAP];
@@ -196,10 +194,13 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 	if (threadIdx.x == 0)
 		n_heavy = 0;
 	__syncthreads();
+	bool loop_seen = false;
 	auto handle = [&](uint32_t v, uint32_t k, uint32_t o) -> bool { // o = aoth[k]; true: the slot leaves the tile upwards
 		const uint32_t vo = o >> 1;
-		if (vo <= v)
+		if (vo <= v) {
+			loop_seen = loop_seen || vo == v;
 			return false; // handled from the other end (or a self loop: never a forest link)
+		}
 		if (vo >= v1)
 			return true;
 		if (lds_union(par, v - v0, vo - v0))
@@ -207,7 +208,6 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		return false;
 	};
 	const uint32_t S0 = 2 * v0, S1 = 2 * v1;
-	uint32_t ldeg_most = 0;
 	for (uint32_t base = S0; base < S1; base += blockDim.x) { // uniform trip count: the ballots below need whole waves
 		const uint32_t S = base + threadIdx.x;
 		uint32_t k = 0, hi = 0;
@@ -222,32 +222,12 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 				}
 			}
 		}
-		uint32_t own = hi - k, opp = 0; // local slots of S from its own links; self loops S meets first (they also sit on S ^ 1)
 		while (__any(k < hi)) {
 			const bool live = k < hi;
-			const uint32_t o = live ? aoth[k] : 0u;
-			const bool cross = live && handle(S >> 1, k, o);
+			const bool cross = live && handle(S >> 1, k, live ? aoth[k] : 0u);
 			wave_append(cross, S >> 1, k, xcount, xlist);
-			if (live && (o >> 1) == (S >> 1)) { // a self loop: counts on the side that meets it first, there and opposite
-				const uint32_t f = ((o & 1u) == (S & 1u) || (S & 1u) == 0u) ? 1u : 0u;
-				own -= 1u - f, opp += f;
-			}
 			k++;
 		}
-		if (ldeg) { // (S and S ^ 1 are neighbouring lanes: tiles start on even sides, the stride is even)
-			const uint32_t cnt = own + __shfl_xor(opp, 1);
-			if (S < S1)
-				ldeg[S] = (uint8_t)min(cnt, 255u);
-			if (S == 2 * V - 1)
-				ldeg[2 * V] = 0; // closes the array the scan turns into loff
-			ldeg_most = max(ldeg_most, S < S1 ? cnt : 0u);
-		}
-	}
-	if (ldeg) { // stats[0] = most local slots on one side
-		for (int o = 32; o; o >>= 1)
-			ldeg_most = max(ldeg_most, __shfl_down(ldeg_most, o));
-		if ((threadIdx.x & 63) == 0 && ldeg_most > __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-			atomicMax(stats, ldeg_most); // (few waves ever need the atomic)
 	}
 	__syncthreads();
 	const uint32_t nh = min(n_heavy, UF_HEAVY_CAP);
@@ -259,6 +239,8 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 			wave_append(cross, S >> 1, k, xcount, xlist);
 		}
 	}
+	if (__any(loop_seen) && (threadIdx.x & 63) == 0)
+		*any_loop = 1u; // (same value from every writer)
 	__syncthreads();
 	// flatten by pointer doubling (a long chain of segments leaves a parent chain as long: walking it once per
 	// vertex would be quadratic); a round without a change ends it
@@ -752,7 +734,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 
 bool sort_free_adjacency(const ResidentGraph &g, bool force_sorted_adjacency) { return g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency; }
 
-uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s, bool want_local_degrees)
+uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
@@ -760,11 +742,10 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	const size_t xoff = ((size_t)E + 7) & ~size_t(7);
 	HIP_CHECK(hipMemsetAsync(st.hook, 0, xoff + 24, s));
 	uint32_t *xcount = reinterpret_cast<uint32_t *>(st.hook + xoff);
-	st.ldeg_max = xcount + 1; // [4] most local slots on one side (k_uf_tiles), cleared with the flags
-	st.ldeg_ready = want_local_degrees && sort_free_adjacency(g, false);
+	uint32_t *any_loop = xcount + 1; // cleared with the flags
 	uint2 *xlist = reinterpret_cast<uint2 *>(st.keys); // [E] pairs fit the 2E+2 words; free until the re-index
 	KLAUNCH(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, g.off, g.aoth, g.adj, st.label,
-			   st.hook, xcount, xlist, st.ldeg_ready ? reinterpret_cast<uint8_t *>(st.ldeg) : nullptr, st.ldeg_max);
+			   st.hook, xcount, xlist, any_loop);
 	if (E) {
 		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, xcount, xlist, g.aoth, g.adj,
 				   st.label, st.hook);
@@ -774,11 +755,13 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	KLAUNCH(k_labels_sorted, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.stats + 9);
 	scan_exclusive_u8(is_root, st.crank, (size_t)V + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(7);
-	uint32_t *h = st.host->take<uint32_t>(2); // component count and the order flag in one round trip
+	uint32_t *h = st.host->take<uint32_t>(3); // component count, the order flag and the self-loop flag in one round trip
 	HIP_CHECK(hipMemcpyAsync(h, st.crank + V, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(h + 1, st.stats + 9, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(h + 2, any_loop, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	st.comp_sorted = h[1] == 0;
+	st.has_self_loops = h[2] != 0;
 	return h[0];
 }
 
@@ -820,17 +803,18 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		const uint32_t *pos_or_identity = identity ? nullptr : st.pos; // sorted order = global order: no vertex is renumbered
 		const uint32_t *perm = st.lean_identity ? nullptr : st.perm, *sbase = st.lean_identity ? nullptr : st.sbase;
 		uint8_t *ldeg8 = reinterpret_cast<uint8_t *>(st.ldeg); // bytes here
-		// the local degrees: the labelling kernel left them when the vertices keep their places (they are a property of the
-		// sides: which slot of a self loop comes first does not depend on the components)
-		const uint32_t *side_max = st.stats;
-		if (st.ldeg_ready && st.lean_identity)
-			side_max = st.ldeg_max;
-		else
+		// Local offsets: without self loops (the labelling kernel looked) a side's local slots are its global ones; when the
+		// vertices also keep their places the local offsets ARE the CSR's (no degree pass, no scan, no array)
+		if (st.lean_identity && !st.has_self_loops) {
+			st.loff = g.off;
+			HIP_CHECK(hipMemcpyAsync(st.stats, &g.max_vdeg, 4, hipMemcpyHostToDevice, s)); // (an upper bound of the most links on one side)
+		} else {
 			KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
-		scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
+			scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
+		}
 		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin, sbase,
 				   st.loff, st.hook, st.ladj, st.lle);
-		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, side_max,
+		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats,
 				   st.host_pub);
 		st.dense_edges = false;
 		tm.end(launches + 7);

@@ -40,8 +40,7 @@ struct CompState {
 			   //      and a side's slots ascend by it in first-encounter order: the position of the link's first-encounter slot
 			   //      (sort-free builder) or its dense rank = componetize's local edge idx (sorted-adjacency builder)
 	uint8_t *tgray;	   // [E+1] local edge is in the spanning forest (sorted-adjacency builder only; the traversal reads LLE_TREE)
-	uint32_t *ldeg_max; // [4] most local slots on one side, when the labelling kernel counted them (ldeg_ready)
-	bool ldeg_ready;   // ldeg holds the sides' local degrees (bytes) in GLOBAL side order
+	bool has_self_loops; // some link joins a segment to itself (the labelling kernel looked)
 	bool dense_edges;  // la / lb / dense local edge ids are valid (sorted-adjacency builder)
 	uint32_t *stats;   // [4]  stats[0] = max links on one side
 	uint32_t *gid_s; // (may alias the resident graph's vid / tip: never written through)
@@ -60,8 +59,7 @@ void mark_odd_u32(uint32_t *p, size_t n, hipStream_t s); // p[i] = 1 for odd i (
 // Builds off / adj / aoth / atwin / tip from the link arrays already in g (device memory).  Throws when a link names
 // an unknown vertex or side (validated on the device).
 void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);
-// want_local_degrees: also leave every side's local degree in st.ldeg (bytes) for the sort-free re-index
-uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s, bool want_local_degrees = false);
+uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
 			bool force_sorted_adjacency = false);
 

@@ -453,7 +453,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		HIP_CHECK(hipEventRecord(ev_all0, s));
 
 		// ---- row B
-		const uint32_t C = label_components(g, cs, tm, s, (o.flags & POVU_HIP_F_SORTED_ADJ) == 0);
+		const uint32_t C = label_components(g, cs, tm, s);
 		// component sizes on the host (shard assignment = LPT over link counts, launch order): the last
 		// re-index kernel writes them into pinned memory itself
 		uint32_t *pub = ctx->host.take<uint32_t>(2 * ((size_t)C + 1) + 4);
