@@ -111,7 +111,7 @@ void check_graph_size(uint32_t n_vtx, uint32_t n_links)
 	// 32-bit index spaces: the packed list-ranking words hold 29-bit successors -- 3 events per segment and 2 adjacency
 	// slots per link must stay below 2^29.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
 	if (3ull * n_vtx >= (1u << 29) || 2ull * n_links >= (1u << 29))
-		throw HipError("graph too large for this build: at most 178 956 969 segments and 268 435 455 links");
+		throw HipError("graph too large for this build: at most 178 956 970 segments and 268 435 455 links");
 }
 
 extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links,
@@ -122,13 +122,13 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 	try {
 		if (!ctx)
 			throw HipError("null context");
-		check_graph_size(n_vtx, n_links);
-		HIP_CHECK(hipSetDevice(ctx->device));
-		// the old graph goes first (the new one reuses its memory); a failed upload leaves the context without a graph
+		// the old graph (or shard) goes first, whatever happens next: a failed upload leaves the context without a graph
 		free_resident_graph(ctx->g);
 		ctx->have_state = false;
 		ctx->shard_comp_ids.clear();
 		ctx->shard_total_components = 0;
+		check_graph_size(n_vtx, n_links);
+		HIP_CHECK(hipSetDevice(ctx->device));
 		alloc_resident_graph(ctx->graph_arena, g, n_vtx, n_links, tips != nullptr);
 		const size_t V = n_vtx, E = n_links;
 		hipStream_t s = ctx->stream;

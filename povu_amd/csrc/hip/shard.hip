@@ -423,6 +423,7 @@ struct ForestLayout {
 		bytes = o;
 	}
 };
+static constexpr uint64_t FOREST_MAGIC = 0x31747372665F7670ull; // "pv_frst1"
 // copies `n` bytes with a few threads when the block is large (page-locked host memory on both sides)
 void big_copy(void *dst, const void *src, size_t n)
 {
@@ -457,6 +458,8 @@ extern "C" int povu_hip_forest_pack(const povu_hip_forest *f, void *dst, size_t 
 {
 	if (!f || !dst)
 		return 1;
+	if (!f->hairpins.empty())
+		return 4; // the wire format carries no hairpin boundaries: refuse rather than drop them
 	size_t total = 0;
 	for (const auto &t : f->trees)
 		total += t.n_pvst;
@@ -466,7 +469,7 @@ extern "C" int povu_hip_forest_pack(const povu_hip_forest *f, void *dst, size_t 
 	char *b = static_cast<char *>(dst);
 	uint64_t *h = reinterpret_cast<uint64_t *>(b);
 	memset(h, 0, 64);
-	h[0] = f->trees.size(), h[1] = total, h[2] = f->total_components;
+	h[0] = f->trees.size(), h[1] = total, h[2] = f->total_components, h[3] = FOREST_MAGIC;
 	uint32_t *meta = reinterpret_cast<uint32_t *>(b + L.meta);
 	size_t at = 0;
 	for (size_t i = 0; i < f->trees.size(); i++) {
@@ -490,6 +493,11 @@ static void adopt_packed(povu_hip_forest &out, std::shared_ptr<PinnedPool> pool,
 	if (bytes < 64)
 		throw HipError("packed forest too short");
 	const uint64_t *h = reinterpret_cast<const uint64_t *>(b);
+	if (h[3] != FOREST_MAGIC)
+		throw HipError("packed forest: bad magic word");
+	// (counts from the wire: bound them by the buffer before any arithmetic that could wrap)
+	if (h[0] > bytes / 16 || h[1] > bytes / 4)
+		throw HipError("packed forest has the wrong size");
 	const size_t n_trees = h[0], total = h[1];
 	const ForestLayout L(n_trees, total);
 	if (L.bytes > bytes)
@@ -517,6 +525,8 @@ static void adopt_packed(povu_hip_forest &out, std::shared_ptr<PinnedPool> pool,
 		t.hp_off = 0;
 		t.n_hairpins = 0;
 		t.blk = bi;
+		if (at + t.n_pvst > total)
+			throw HipError("packed forest: tree sizes do not add up");
 		at += t.n_pvst;
 		out.trees.push_back(t);
 	}

@@ -213,13 +213,20 @@ extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *er
 		for (uint32_t i = 0; i < n; i++)
 			if (d->parent[i] != POVU_HIP_NIL)
 				cadj[cur[d->parent[i]]++] = i;
+		// (a malformed file may list the root, or an ancestor, as somebody's child: every vertex is entered once)
+		std::vector<uint8_t> seen(n, 0);
+		seen[root] = 1;
 		stack.push_back(root);
 		while (!stack.empty()) {
 			const uint32_t v = stack.back();
 			stack.pop_back();
 			for (uint32_t k = coff[v]; k < coff[v + 1]; k++) {
-				d->height[cadj[k]] = d->height[v] + 1;
-				stack.push_back(cadj[k]);
+				const uint32_t c = cadj[k];
+				if (seen[c])
+					continue;
+				seen[c] = 1;
+				d->height[c] = d->height[v] + 1;
+				stack.push_back(c);
 			}
 		}
 	}
