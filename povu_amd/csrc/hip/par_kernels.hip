@@ -230,46 +230,34 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 }
 // simplifying(v): bridge(v) and no bridge vertex below it (the deepest ones get the back edge to
 // the root, flubbles.cpp:621-643)
-// ... and the capping edges.  Only BRANCHING vertices (two or more children) can get one, about one lane in six: the
-// workgroup collects its branching vertices in LDS (wave ballots + prefix popcounts) and its first lanes work
-// through that list, so the sweeps over the children run on full waves.
+// ... and which vertices BRANCH (two or more children): only they can get a capping edge, about one vertex in nine.
+// The sweep over a branching vertex's children is a chain of dependent gathers (child, its size, the flags behind its
+// subtree, the next child ...): it runs in a kernel of its own over the compacted list of branching vertices, every lane
+// busy with one of them -- inside this kernel the few lanes that had work left the rest of their workgroup waiting.
 __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
 			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
-			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, const uint32_t *__restrict__ hi0,
-			  const RootOf root_of, const SegTree segA,
-			  uint32_t *__restrict__ literal_rule_seen)
+			  uint8_t *__restrict__ capf, uint8_t *__restrict__ branching)
 {
 	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-	bool branching = false;
-	if (t < T) {
-		uint32_t sz = gsize[t];
-		const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
-		simp[t] = sm;
-		if (t == T - 1)
-			simp[T] = 0;
-		if (hpf)
-			hpf[t] = sm;
-		capf[t] = 0; // (cap_tgt is only read where capf says so)
-		branching = sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz; // the first child does not fill the subtree
-	}
-	__shared__ uint32_t wcnt[TPB / 64];
-	__shared__ uint32_t list[TPB];
-	const unsigned long long m = __ballot(branching);
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	if (lane == 0)
-		wcnt[wave] = (uint32_t)__popcll(m);
-	__syncthreads();
-	uint32_t before = 0, total = 0;
-	for (uint32_t w = 0; w < TPB / 64; w++) {
-		if (w < wave)
-			before += wcnt[w];
-		total += wcnt[w];
-	}
-	if (branching)
-		list[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
-	__syncthreads(); // (also orders the cap_tgt / capf defaults above before the stores of capping_of)
-	if (threadIdx.x < total)
-		capping_of(list[threadIdx.x], gsize, hi0, psb, root_of, segA, cap_tgt, capf, literal_rule_seen);
+	if (t >= T)
+		return;
+	uint32_t sz = gsize[t];
+	const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
+	simp[t] = sm;
+	if (t == T - 1)
+		simp[T] = 0;
+	if (hpf)
+		hpf[t] = sm;
+	capf[t] = 0; // (cap_tgt is only read where capf says so)
+	branching[t] = (sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz) ? 1 : 0; // the first child does not fill the subtree
+}
+__global__ void k_capping(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const uint32_t *__restrict__ gsize,
+			  const uint32_t *__restrict__ hi0, const uint32_t *__restrict__ psb, const RootOf root_of, const SegTree segA,
+			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, uint32_t *__restrict__ literal_rule_seen)
+{
+	const uint32_t n = *n_list; // (the count only exists on the device: grid-stride)
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+		capping_of(list[i], gsize, hi0, psb, root_of, segA, cap_tgt, capf, literal_rule_seen);
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
@@ -904,7 +892,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
 			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.vals_t, &pw.vals_t2})
 		take((void **)p, (T + 2) * 4);
-	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c})
+	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c, &pw.f8d})
 		take((void **)p, T + 32);
 	take((void **)&pw.keys_t, (T + 2) * 8);
 	take((void **)&pw.keys_t2, (T + 2) * 8);
@@ -1048,8 +1036,12 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, pw.cap_tgt, capf, pw.hi0, root_of,
-	       pw.segA, pw.err + 5);
+	uint8_t *branching = pw.f8d;
+	uint32_t *br_list = pw.vals_t, *n_br = pw.err + 10; // (the sort's value buffer is free until the class pass)
+	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, branching);
+	compact_flagged_u8(branching, T, br_list, n_br, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	KLAUNCH(k_capping, dim3(std::min<unsigned>(nblk(T / 8 + 1), 16384)), dim3(TPB), 0, s, n_br, br_list, pw.gsize, pw.hi0, psb, root_of,
+		pw.segA, pw.cap_tgt, capf, pw.err + 5);
 	// capping / simplifying vertices per tile of k_bracket_extra, scanned: [ntiles + 1] each, the totals in the last word
 	const uint32_t ntiles = (T + BX_TILE - 1) / BX_TILE;
 	uint32_t *tsimp = pssimp, *tcap = pscap;

@@ -40,7 +40,7 @@ struct ParWs {
 	// T-space (global tree vertex idx)
 	uint32_t *t_comp, *t_root, *gpar, *gsize;
 	uint32_t *hi0, *cov, *psA, *psB, *flagC, *psC; // exclusive scans of the byte flags below [T+1]; flagC: run marks
-	uint8_t *f8a, *f8b, *f8c;	 // [T+1] one-byte flags (bridge / simplifying / capping vertex, class and stack flags)
+	uint8_t *f8a, *f8b, *f8c, *f8d; // [T+1] one-byte flags (bridge / simplifying / capping / branching vertex, class and stack flags)
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
 	uint32_t *vals_t, *vals_t2;
 	uint64_t *keys_t, *keys_t2; // [T]

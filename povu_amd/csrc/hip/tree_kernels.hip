@@ -1154,7 +1154,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 // sides again (now from cache) and writes them.  The dense list is in no particular order -- nothing downstream needs one:
 // a bracket's place in its list follows from its source and b_ord, its rank among the ordinary edges of that source
 // (bottom first; k_bracket_place turns it round).
-static constexpr uint32_t BE_ITER = 16, BE_SIDES = TPB * BE_ITER;
+static constexpr uint32_t BE_ITER = 8, BE_SIDES = TPB * BE_ITER;
 template <bool EMIT>
 __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint32_t at,
 						    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
