@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import bench  # kernel_source_digest
 F = os.path.join(ROOT, "gpurun_out", "final")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 PASSES = 4  # bench.py --steps 2 --warmup 1: 1 warm-up + 2 timed + 1 stage-breakdown pass
 
 
@@ -32,16 +32,16 @@ for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline work
         shutil.copy(os.path.join(D, src), os.path.join(P, f"{tag}_{wl}_{dst}"))
     E, V = bench_line["config"]["links"], bench_line["config"]["segments"]
     rows = list(csv.DictReader(open(os.path.join(D, "kernel_stats.csv"))))
-    # calibration of FETCH_SIZE on kernels of this very run whose bytes are known: the 64-bit xor scan of the bridge
-    # test reads its input exactly once in each of its two kernels (k_xor64_partials with 8-byte-per-lane loads,
-    # k_xor64_chunks with 32-byte-per-lane loads) and k_xor64_chunks writes as many bytes as it reads (WRITE_SIZE is
+    # calibration of FETCH_SIZE on kernels of this very run whose bytes are known: the 128-bit xor scan of the bridge
+    # test reads its input exactly once in each of its two kernels (k_xor128_partials with 16-byte-per-lane loads,
+    # k_xor128_chunks with 32-byte-per-lane loads) and k_xor128_chunks writes as many bytes as it reads (WRITE_SIZE is
     # exact for streaming stores of whole lines, MI355X_MICROARCH.md)
     fmap = {k: v for k, v in fetch["top"]}
     wmap = {k: v for k, v in write["top"]}
     cal = {}
-    if fmap.get("k_xor64_chunks") and wmap.get("k_xor64_chunks"):
-        known = wmap["k_xor64_chunks"]
-        cal = {"read_32B_per_lane": fmap["k_xor64_chunks"] / known, "read_8B_per_lane": fmap.get("k_xor64_partials", 0) / known}
+    if fmap.get("k_xor128_chunks") and wmap.get("k_xor128_chunks"):
+        known = wmap["k_xor128_chunks"]
+        cal = {"read_32B_per_lane": fmap["k_xor128_chunks"] / known, "read_16B_per_lane": fmap.get("k_xor128_partials", 0) / known}
     raw = (fetch["per_pass"] + write["per_pass"]) * 1024.0
     # corrected: the guide's gfx950 rule (coalesced reads are counted at one half) holds for wide AND for narrow per
     # lane loads here (both calibrate at ~0.5), so FETCH_SIZE is doubled as a whole; scattered 4-byte gathers are
@@ -67,7 +67,7 @@ for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline work
     L.append(f"Bench line (`{tag}_{wl}_bench.json`): **{bench_line['value']:.3e} links/s, {bench_line['ms_per_step']:.2f} ms per pass**, HIP-event time of "
              f"the pass {bench_line['roofline']['ms_per_launch']:.2f} ms, roofline frac {bench_line['roofline']['frac']:.4f} (algorithmic 48E+108V+16F = "
              f"{alg/1e9:.3f} GB per pass)" + (f"; CPU port on the box: {cb['value']:.3e} links/s on {cb['cores']} threads (reference scheme), "
-                                              f"{cb['value_lpt_threads']:.3e} bin-packed, {cb['value_one_thread']:.3e} on one thread" if cb else "") + ".\n")
+                                              f"{cb['value_lpt_threads']:.3e} bin-packed, {cb['value_one_thread']:.3e} on one thread ({cb.get('one_thread_sample', '')})" if cb else "") + ".\n")
     L.append(f"### Kernel trace\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --no-cpu-baseline --no-secondary --steps 2 --warmup 1` "
              f"({passes} passes + one upload): sum of kernel durations {tot_ns/1e6:.2f} ms over {calls} launches; the last pass: "
              f"`{open(os.path.join(D, 'timeline_summary.txt')).read().strip()}` (HIP-event time of a pass in that run: {under['roofline']['ms_per_launch']:.2f} ms).\n")
