@@ -5,13 +5,13 @@ import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import (F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_SPARSE_SPLITTERS,
-                          F_ALL_VERTEX_CLASSES)
+                          F_ALL_VERTEX_CLASSES, F_CHECK_LAMINAR)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
 hip = HipDecomposer(0)
 rng = np.random.default_rng(12345)
-t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0
+t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0; n_redo = 0
 last = t0
 while time.time() - t0 < budget:
     if time.time() - last > 60:
@@ -49,12 +49,16 @@ while time.time() - t0 < budget:
         tips = np.zeros(g.n_vtx, dtype=np.uint8)  # builder-style graphs without tips
     want = O.decompose(g, tips=tips)
     hip.upload(g, tips)
-    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS, F_SPARSE_SPLITTERS, F_ALL_VERTEX_CLASSES][(n_graphs + n_graphs // 9) % 9]
+    flags = [0, F_SEQ_TREE, F_HAIRPINS, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_BIG_CLASS_DFS | F_HAIRPINS, F_SPARSE_SPLITTERS, F_ALL_VERTEX_CLASSES, F_CHECK_LAMINAR][(n_graphs + n_graphs // 10) % 10]
     got = hip.decompose(flags=flags).texts()
     if got != want:
         print('MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', flags, 'tips', tips is not None)
         np.savez('gpurun_out/fuzz_fail.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
         sys.exit(1)
+    if hip.seq_redo_count() and not (flags & F_SEQ_TREE):
+        print('REDO fired (a non-laminar candidate stack) kind', kind, 'seed', seed, 'flags', flags)
+        np.savez('gpurun_out/fuzz_redo.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
+        n_redo += 1
     n_black_only += int(hip.last_black_only_classes())
     n_graphs += 1; n_links += g.n_links
-print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only')
+print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only;', n_redo, 'passes sent a component to the sequential redo')
