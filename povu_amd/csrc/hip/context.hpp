@@ -154,6 +154,7 @@ struct povu_hip_ctx {
 	ParWs pw{};
 	TreeWs tw{};
 	uint32_t last_seq_redo = 0;
+	bool redo_pvst_only = false; // the last redo only re-ran add_flubbles: tree, classes and stack are the parallel stages'
 	bool last_mixed = false; // the last pass redid SOME components sequentially: the stage state is half parallel layout, half sequential
 	bool stack_export_pending = false; // the parallel stages' candidate stack is still in its dense layout
 	bool tree_in_par = false;	   // the tree of the last pass came from the parallel kernels (their per-side state is still there)

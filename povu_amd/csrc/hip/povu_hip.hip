@@ -437,6 +437,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		SeqWs &sw = ctx->sw;
 		ctx->have_state = false;
 		ctx->last_mixed = false;
+		ctx->redo_pvst_only = false;
 		ctx->stack_export_pending = false;
 		ctx->classes_in_par = false;
 		ctx->tree_in_par = false;
@@ -638,9 +639,21 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			ctx->last_mixed = mixed;
 			if (nbad) { // components whose candidate stack is not laminar: exact sequential redo
 				tm.begin("redo_seq");
-				if (dense_nb0 >= 0) // parallel tree: the one-lane kernels start from scratch
-					init_seq_workspace();
-				sw.stages = dense_nb0 >= 0 ? SEQ_STAGE_ALL : (SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST);
+				if (dense_nb0 >= 0 && !hairpins) {
+					// Only add_flubbles' stack machine (flubbles.cpp:316-365) cannot be evaluated in closed form on
+					// such a stack; tree, classes, candidate stack and next_seen of the parallel stages stand.  They
+					// are copied into the per-component layout, one lane per flagged component runs the machine.
+					need_seq_workspace();
+					export_parallel_stack(cs, sw, ctx->pw, s);
+					ctx->stack_export_pending = false;
+					HIP_CHECK(hipMemsetAsync(sw.in_s, 0, B + T, s));
+					sw.stages = SEQ_STAGE_PVST | SEQ_STAGE_GIVEN_STACK;
+					ctx->redo_pvst_only = true;
+				} else {
+					if (dense_nb0 >= 0) // parallel tree: the one-lane kernels start from scratch
+						init_seq_workspace();
+					sw.stages = dense_nb0 >= 0 ? SEQ_STAGE_ALL : (SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST);
+				}
 				sw.comp_sel = ctx->pw.comp_bad;
 				launch_seq_components(sw, s);
 				sw.comp_sel = nullptr;
@@ -1028,13 +1041,13 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 			HIP_CHECK(hipMemcpy(gid, ctx->sw.t_gid + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
 		if (par)
 			HIP_CHECK(hipMemcpy(par, ctx->sw.t_par + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
-		if (cls && ctx->classes_in_par && ctx->last_seq_redo == 0) {
+		const bool par_cls = ctx->classes_in_par && (ctx->last_seq_redo == 0 || ctx->redo_pvst_only);
+		if (cls && par_cls) {
 			classes_to_tree_space(ctx->pw, ctx->stream);
 			HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		}
 		if (cls) // the parallel class stage keeps the classes in its own T-space array
-			HIP_CHECK(hipMemcpy(cls, (ctx->classes_in_par && ctx->last_seq_redo == 0 ? ctx->pw.gcls : ctx->sw.t_cls) + tb,
-					    (size_t)N * 4, hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(cls, (par_cls ? ctx->pw.gcls : ctx->sw.t_cls) + tb, (size_t)N * 4, hipMemcpyDeviceToHost));
 		if (typ)
 			HIP_CHECK(hipMemcpy(typ, ctx->sw.t_flags + tb, N, hipMemcpyDeviceToHost));
 		return 0;

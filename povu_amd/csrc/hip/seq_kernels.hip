@@ -366,20 +366,27 @@ __device__ static uint32_t seq_candidate_stack(CompView &c)
 }
 
 // ------------------------------------------------------------------ rows F, G
-__device__ static uint32_t seq_pvst(CompView &c, uint32_t n)
+__device__ static uint32_t seq_pvst(CompView &c, uint32_t n, bool given_stack)
 {
 	// last is pre-filled with NIL, in_s with 0
-	for (uint32_t i = n; i-- > 0;) { // compute_eq_class_metadata, flubbles.cpp:391-399
-		const uint32_t cl = c.s_cls[i];
-		c.next_seen[i] = c.last[cl] != NIL ? c.last[cl] : i;
-		c.last[cl] = i;
+	uint32_t cls_base = 0;
+	if (given_stack) { // next_seen is there already; the class ids count over all components: this one's are a contiguous range
+		cls_base = NIL;
+		for (uint32_t i = 0; i < n; i++)
+			cls_base = min(cls_base, c.s_cls[i]);
+	} else {
+		for (uint32_t i = n; i-- > 0;) { // compute_eq_class_metadata, flubbles.cpp:391-399
+			const uint32_t cl = c.s_cls[i];
+			c.next_seen[i] = c.last[cl] != NIL ? c.last[cl] : i;
+			c.last[cl] = i;
+		}
 	}
 	uint32_t np = 1, sp = 0, prt = 0;
 	c.p_parent[0] = NIL;
 	c.p_a[0] = c.p_z[0] = NIL;
 	c.p_or[0] = 0;
 	for (uint32_t i = 0; i < n; i++) { // add_flubbles, flubbles.cpp:316-365
-		const uint32_t cl = c.s_cls[i];
+		const uint32_t cl = c.s_cls[i] - cls_base;
 		if (c.in_s[cl]) {
 			while (sp) {
 				const uint32_t k = c.aux[--sp];
@@ -512,7 +519,7 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 			w.c_nstack[ci] = n;
 		}
 		if (w.stages & SEQ_STAGE_PVST)
-			w.c_npvst[ci] = seq_pvst(c, n);
+			w.c_npvst[ci] = seq_pvst(c, n, (w.stages & SEQ_STAGE_GIVEN_STACK) != 0);
 		w.c_status[ci] = 1;
 	}
 }

@@ -14,6 +14,8 @@ namespace povu_hip
 #define SEQ_STAGE_STACK 4u
 #define SEQ_STAGE_PVST 8u
 #define SEQ_STAGE_ALL 15u
+#define SEQ_STAGE_GIVEN_STACK 16u /* with SEQ_STAGE_PVST alone: s_vtx / s_cls / next_seen come from the parallel stages (class ids \
+				      are global: the component's smallest is subtracted); only add_flubbles itself runs */
 
 // Sizes: V vertices, E links, C components.
 //   T = 2V + C tree vertices;  component c owns [toff(c), toff(c)+2*nv_c+1),  toff(c) = 2*voff[c] + c

@@ -240,6 +240,20 @@ def test_laminar_check_on_demand_never_fires(hip, seed):
     assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
 
 
+def test_non_laminar_stack_takes_the_redo(hip, golden_dir):
+    """The guard path on a real case (tests/test_laminar_fuzz.py::test_the_literal_hi2_rule_can_cross_intervals): the
+    literal hi_2 rule deviates, the pass numbers all tree vertices, the laminarity check runs by itself, finds the crossing
+    pair and the component goes through the sequential kernels -- bit-exact either way."""
+    from povu_amd.hip import F_CHECK_LAMINAR
+    d = np.load(os.path.join(golden_dir, "literal_hi2_crossing_stack.npz"))
+    g = W._mk(d["vid"], d["v1"], d["s1"], d["v2"], d["s2"])
+    want = O.decompose(g)
+    hip.upload(g)
+    for flags in (0, F_CHECK_LAMINAR):
+        assert hip.decompose(flags=flags).texts() == want
+        assert hip.seq_redo_count() == 1 and not hip.last_black_only_classes()
+
+
 def test_sequential_redo_of_a_million_segment_component(hip, golden_dir):
     """What the guard path costs at size: BASELINE config 2 (one component of 10^6 segments) forced through the one-lane
     kernels.  Bit-exact against the reference md5; the time is printed (`pytest -s`) and bounded loosely -- the redo is a

@@ -70,6 +70,19 @@ def test_candidate_stack_intervals_are_laminar_on_every_fuzzed_graph():
     assert comps > 150 and entries > 30000  # (the hunt did look at something)
 
 
+def test_the_literal_hi2_rule_can_cross_intervals(golden_dir):
+    """A graph the GPU fuzz found (kept as data: an HPRC-shaped backbone of 8 299 segments with random tangles,
+    `workloads.hprc_tangled`): the literal hi_2 rule caps below the second-highest reach there, the reference's classes are
+    not the exact cycle-equivalence classes, and its OWN candidate stack has one crossing pair of intervals.  This is the
+    case the HIP path's range-min check exists for (it runs exactly when `k_capping` saw the rule deviate) and the
+    component is then redone by the sequential kernels: tests/test_gpu_parity.py::test_non_laminar_stack_takes_the_redo."""
+    import os
+    d = np.load(os.path.join(golden_dir, "literal_hi2_crossing_stack.npz"))
+    g = W._mk(d["vid"], d["v1"], d["s1"], d["v2"], d["s2"])
+    dd = dump_component(g, 0)
+    assert len(dd["s_cls"]) == g.n_vtx and crossing_pairs(dd["s_cls"]) == 1
+
+
 def test_crossing_detector_sees_a_crossing():
     assert crossing_pairs(np.array([1, 2, 1, 2])) == 1
     assert crossing_pairs(np.array([1, 2, 2, 1, 3, 3])) == 0
