@@ -7,15 +7,18 @@
 // the DFS can enter a 2-edge-connected class only through the unique bridge that leads to the root,
 // and its walk inside a class never depends on the rest of the graph.  So
 //   1. spanning forest of H  (black edges + the links that won a hook in the WCC union-find)
-//   2. root it at the DFS start side: Euler tour + list ranking (pointer jumping)
-//   3. bridges: subtree min/max of the non-tree links' far ends (segment trees over pre-order)
-//   4. 2-edge-connected classes: union-find over the non-bridge edges
+//   2. root it at the DFS start side: Euler tour over the forest of segments + list ranking (random splitters, recursive)
+//   3. bridges: a tree edge is a bridge iff the xor of TWO independent hashes of the non-tree links over its subtree's
+//      stretch of the tour vanishes (running xor over tour positions)
+//   4. 2-edge-connected classes = the pieces of the rooted forest when its bridges are cut (never numbered)
 //   5. per class: entry side = top of the class, DFS parent = far end of its bridge
-//   6. ONE LANE PER CLASS runs the reference DFS inside its class (pangenome graphs are chains of
-//      small bubbles, so there are very many small classes)
+//   6. the reference DFS inside every class: ONE LANE per small class (pangenome graphs are chains of small bubbles, so
+//      there are millions of them), ONE WAVE per class that turns out large (candidates probed by ballot, one dependent
+//      gather per tree edge)
 //   7. pre-order / subtree size / depth of the union tree: Euler tour of (parent, scan-slot)
 //      ordered children + list ranking
-//   8. tree arrays in pre-order + the from_bd back edges (de-duplication rules of :360-398)
+//   8. tree arrays in pre-order (T-space, as the class stage reads them) + the from_bd back edges (de-duplication rules
+//      of :360-398)
 // tests/test_parallel_tree_model.py checks this formulation against the oracle on the CPU.
 #include "tree_kernels.hpp"
 
