@@ -739,7 +739,7 @@ __global__ void k_class_recs(uint32_t nS, const uint32_t *__restrict__ loff, con
 // entry and its state word on the way down; {parent, slot} of the finished side and the parent's list bounds on the way
 // back -- the parent resumes its scan behind the slot the child was found through, so no cursor is stored.
 static constexpr uint32_t DFS_STK = 8; // levels of a walk whose scan state stays in LDS (most classes are bubbles a few sides deep)
-__global__ void __launch_bounds__(64) k_class_dfs_small(uint32_t n_entry, const uint32_t *__restrict__ entry_list,
+__global__ void __launch_bounds__(64) k_class_dfs_small(const uint32_t *__restrict__ n_entry_dev, const uint32_t *__restrict__ entry_list,
 							 const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 							 uint32_t *__restrict__ cstate, uint2 *__restrict__ dps, uint32_t budget,
 							 uint32_t *__restrict__ n_over, uint32_t *__restrict__ over_list)
@@ -749,6 +749,7 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(uint32_t n_entry, const 
 	__shared__ uint4 stk[DFS_STK][64];
 	const uint32_t lane = threadIdx.x;
 	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
+	const uint32_t n_entry = *n_entry_dev; // (the count only exists on the device: no read-back sizes this launch)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
 		const uint32_t s = entry_list[i];
 		const uint32_t s_up = cstate[s] & ~(CS_VISITED | PB_BRIDGE); // the entry's parent, across its bridge (root: all ones)
@@ -1477,23 +1478,23 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.dps, tw.entry_flag, cstate);
 	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
 	compact_flagged_u8(tw.entry_flag, nS, tw.entry_list, n_entry_dev, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	const uint32_t n_entry = tw.host->read_u32(n_entry_dev, s);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
 	// gives up and reports the entry; those classes are then walked from the start by the walk with the short dependent
 	// chain, at the price of a filtering pass over the adjacency (it marks visits in its own bytes and rewrites the same
 	// parents, so the abandoned attempt leaves nothing behind).
 	const uint32_t *big_list = tw.entry_list;
-	uint32_t n_big = force_big_class_dfs ? n_entry : 0;
-	if (n_entry && !force_big_class_dfs) {
+	uint32_t n_big = force_big_class_dfs ? tw.host->read_u32(n_entry_dev, s) : 0; // (A/B mode: every class through the wave walk)
+	if (!force_big_class_dfs) {
 		// Lanes in flight = a window of sides whose scattered stores meet again in L2: ~3000 x 64 lanes measured best
 		// from a few hundred thousand to twenty million small classes (wider windows thrash the caches, narrower
-		// ones leave latency uncovered).
-		const unsigned all_blocks = (n_entry + 63) / 64;
+		// ones leave latency uncovered).  The number of classes stays on the device: the launch is a grid-stride
+		// loop, one synchronisation (how many classes overflowed) serves both.
+		const unsigned all_blocks = (nS + 63) / 64;
 		unsigned dfs_blocks = std::min(all_blocks, 3072u);
 		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
 			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
 		uint32_t *n_over = pw.err + 4, *over_list = tw.entry_ps; // (the scan of the entry flags is dead once compacted)
-		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps,
+		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry_dev, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps,
 			CLASS_BUDGET, n_over, over_list);
 		n_big = tw.host->read_u32(n_over, s);
 		big_list = over_list;
