@@ -188,8 +188,16 @@ def scatter_over_dist(full: Optional["_hip.HipDecomposer"], work: "_hip.HipDecom
         pending = []
         for r in range(1, world):
             i = shards.info(r)
-            t = (torch.as_tensor(_DeviceBytes(i["device_ptr"], i["bytes"]), device=device) if on_gpu
-                 else torch.from_numpy(shards.export(r)))
+            t = None
+            if on_gpu:
+                try:  # zero-copy view of the shard in the partition block
+                    t = torch.as_tensor(_DeviceBytes(i["device_ptr"], i["bytes"]), device=device)
+                except Exception:  # (a torch build without the CUDA array interface: stage through host memory)
+                    t = None
+            if t is None:
+                t = torch.from_numpy(shards.export(r))
+                if on_gpu:
+                    t = t.to(device)
             pending.append((dist.isend(t, r), t))
         i0 = shards.info(0)
         work.upload_shard(i0["device_ptr"], i0["bytes"], on_device=True)
