@@ -748,8 +748,10 @@ def test_hub_with_many_parallel_links(hip):
     want = O.decompose(g)
     assert gpu_texts(hip, g) == want
     assert np.array_equal(hip.debug_edge_ids(0), dump_component(g, 0)["pe_id"])
-    from povu_amd.hip import F_SEQ_TREE
+    from povu_amd.hip import F_SEQ_TREE, F_BIG_CLASS_DFS
     hip.upload(g)
+    # (the hub side has thousands of candidates inside its class: the wave walk's overflow lists and 64-candidate windows)
+    assert hip.decompose(flags=F_BIG_CLASS_DFS).texts() == want
     assert hip.decompose(flags=F_SEQ_TREE).texts() == want
     with pytest.raises(RuntimeError):
         hip.debug_edge_ids(0)
