@@ -568,10 +568,17 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 }
 // pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
 static constexpr uint32_t PB_BRIDGE = 0x80000000u;
+// Also, while parent and bridge bit of a side are in hand, what the class walks start from (section 5): the side's state word
+// cstate (forest parent, bridge bit, visited bit: one load tells a walk "not yet visited", which covers "not across a
+// bridge" on the way down) and, for an ENTRY -- a root or the lower end of a bridge: the one side of its class the DFS
+// reaches first --, its DFS record dps = {parent across the bridge, scan slot of the parent it is found through}.
+static constexpr uint32_t CLASS_BUDGET = 256;  // sides a lane walks before it hands its class to the big-class walk
+static constexpr uint32_t CS_VISITED = 0x40000000u; // (side ids stay below 2^29, bit 31 is PB_BRIDGE)
 __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ulonglong2 *__restrict__ px,
 			  const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft,
-			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
-			  const uint32_t *__restrict__ voff, uint32_t *__restrict__ pbr, uint8_t *multi)
+			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
+			  const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
+			  uint32_t *__restrict__ pbr, uint8_t *multi, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -580,41 +587,63 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 	// (cleared by the caller).  Most sides of a pangenome graph sit on bridges only and are classes of their own; those
 	// need no walk at all.
 	const uint4 r = t0seg[S >> 1];
-	const uint32_t entered = (S & ~1u) | (r.y >> 31);
+	const uint32_t entered = (S & ~1u) | (r.y >> 31), c = ckey[S >> 1];
+	const bool proc = cproc[c] != 0; // (components that are not decomposed here get inert words)
+	uint32_t pv; // parent | bridge bit
 	if (S == entered) {
 		if (r.x == NIL) {
-			pbr[S] = NIL;
+			pv = NIL;
 		} else if (heq(px[r.z], px[r.w + 1])) {
-			pbr[S] = r.x | PB_BRIDGE;
+			pv = r.x | PB_BRIDGE;
 		} else {
-			pbr[S] = r.x;
+			pv = r.x;
 			multi[S] = 1;
 			multi[r.x] = 1;
 		}
-		return;
-	}
-	// the black edge entered -> S: what leaves subtree(S) = S's own non-tree links and those of the subtrees hanging off S
-	const uint32_t f1 = ft[S], a1 = f1 & FT_NONE;
-	ulonglong2 x = (f1 & FT_HASH) ? hside[S] : make_ulonglong2(0ull, 0ull);
-	if (a1 != FT_NONE) {
-		const uint32_t c = ckey[S >> 1], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
-		const uint32_t a3 = ft[entered] & FT_NONE;
-		uint32_t end; // position behind the last of them
-		if (r.x == NIL) // root segment: the start side's arcs come first, S's are the rest of the tour
-			end = abase + L;
-		else if (a3 != FT_NONE && (lle[a3] & LLE_ID) != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
-			end = abase + (L - 1 - dist[a3]);
-		else
-			end = r.w;
-		x = hx(x, hx(px[abase + (L - 1 - dist[a1])], px[end]));
-	}
-	if (hzero(x)) {
-		pbr[S] = entered | PB_BRIDGE;
 	} else {
-		pbr[S] = entered;
-		multi[S] = 1;
-		multi[entered] = 1;
+		// the black edge entered -> S: what leaves subtree(S) = S's own non-tree links and those of the subtrees hanging off S
+		const uint32_t f1 = ft[S], a1 = f1 & FT_NONE;
+		ulonglong2 x = (f1 & FT_HASH) ? hside[S] : make_ulonglong2(0ull, 0ull);
+		if (a1 != FT_NONE) {
+			const uint32_t L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
+			const uint32_t a3 = ft[entered] & FT_NONE;
+			uint32_t end; // position behind the last of them
+			if (r.x == NIL) // root segment: the start side's arcs come first, S's are the rest of the tour
+				end = abase + L;
+			else if (a3 != FT_NONE && (lle[a3] & LLE_ID) != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
+				end = abase + (L - 1 - dist[a3]);
+			else
+				end = r.w;
+			x = hx(x, hx(px[abase + (L - 1 - dist[a1])], px[end]));
+		}
+		if (hzero(x)) {
+			pv = entered | PB_BRIDGE;
+		} else {
+			pv = entered;
+			multi[S] = 1;
+			multi[entered] = 1;
+		}
 	}
+	pbr[S] = pv;
+	const bool entry = proc && (pv & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
+	cstate[S] = proc ? (pv | (entry ? CS_VISITED : 0u)) : NIL;
+	uint2 rec = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}: one word pair, one store
+	if (entry && pv != NIL) { // (NIL: DFS start of the component)
+		const uint32_t p = pv & ~PB_BRIDGE;
+		rec.x = p;
+		if (p != (S ^ 1u)) { // (black edge: slot 0, scanned first) gray bridge: its slot in the parent's list (ascending link id)
+			uint32_t le = r.y & ~T0_RBIT, lo = loff[p], hi = loff[p + 1];
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if ((lle[mid] & LLE_ID) < le)
+					lo = mid + 1;
+				else
+					hi = mid;
+			}
+			rec.y = lo - loff[p] + 1;
+		}
+	}
+	dps[S] = rec;
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
@@ -627,47 +656,18 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 // so a walk never runs down across a bridge, and only the entry itself has to skip the way up.
 
 // ------------------------------------------------------------------ 5. class entries
-static constexpr uint32_t CLASS_BUDGET = 256;  // sides a lane walks before it hands its class to the big-class walk
-static constexpr uint32_t CS_VISITED = 0x40000000u; // (side ids stay below 2^29, bit 31 is PB_BRIDGE)
-__global__ void k_entries(uint32_t nS, const uint32_t *__restrict__ pbr, const uint4 *__restrict__ t0seg,
-			  const uint32_t *__restrict__ loff,
-			  const uint32_t *__restrict__ lle, const uint32_t *__restrict__ ckey,
-			  const uint32_t *__restrict__ cproc, const uint8_t *__restrict__ multi,
-			  uint2 *__restrict__ dps, uint8_t *__restrict__ entry_flag, uint32_t *__restrict__ cstate)
+// a class is walked from its entry side (k_bridges marked the entries visited and wrote their DFS records); a side that
+// is alone in its class has nothing to walk: the walks start from the entries that share their class (multi)
+__global__ void k_entry_flags(uint32_t nS, const uint32_t *__restrict__ pbr, const uint8_t *__restrict__ multi,
+			      const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, uint8_t *__restrict__ entry_flag)
 {
 	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
-	uint2 rec = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}: one word pair, one store
-	uint8_t ef = 0;
-	// forest parent, bridge bit and visited bit of a side in ONE word: the walk tests "not yet visited" with one load, and
-	// that covers "not across a bridge" too on the way down (see section 4)
-	const bool proc = cproc[ckey[S >> 1]] != 0;
-	const uint32_t p0 = proc ? pbr[S] : 0u;
-	const bool entry = proc && (p0 & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
-	cstate[S] = proc ? (p0 | (entry ? CS_VISITED : 0u)) : NIL;
-	if (entry) {
-		// a class is walked from its entry side; a side that is alone in its class has nothing to walk
-		ef = multi[S] ? 1 : 0;
-		if (p0 != NIL) { // (NIL: DFS start of the component)
-			const uint32_t p = p0 & ~PB_BRIDGE;
-			rec.x = p;
-			if (p != (S ^ 1)) { // (black edge: slot 0, scanned first) gray bridge: its slot in the parent's list (ascending local edge idx)
-				uint32_t le = t0seg[S >> 1].y & ~T0_RBIT, lo = loff[p], hi = loff[p + 1];
-				while (lo < hi) {
-					uint32_t mid = (lo + hi) >> 1;
-					if ((lle[mid] & LLE_ID) < le)
-						lo = mid + 1;
-					else
-						hi = mid;
-				}
-				rec.y = lo - loff[p] + 1;
-			}
-		}
-	}
-	dps[S] = rec;
-	entry_flag[S] = ef;
+	// an entry: a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
+	entry_flag[S] = (multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1 : 0;
 }
+
 // ------------------------------------------------------------------ 6. the DFS inside every class
 // Small classes (a bubble: a handful of sides) are walked by ONE LANE each, millions at a time (k_class_dfs_small).
 // A class that turns out larger than CLASS_BUDGET sides is handed to the WAVE-COOPERATIVE walk below, one wave per
@@ -1469,13 +1469,13 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	scan_exclusive_xor_u128(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
 	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
-	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.lle, cs.ckey, cs.voff, tw.pbr, multi);
+	uint32_t *cstate = sw.cur; // [nS+1]
+	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, tw.pbr, multi, cstate, tw.dps);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
-	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_entries, nS, s, nS, tw.pbr, tw.t0seg, cs.loff, cs.lle, cs.ckey, tw.cproc, multi, tw.dps, tw.entry_flag, cstate);
+	LAUNCH(k_entry_flags, nS, s, nS, tw.pbr, multi, cs.ckey, tw.cproc, tw.entry_flag);
 	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
 	compact_flagged_u8(tw.entry_flag, nS, tw.entry_list, n_entry_dev, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
