@@ -81,6 +81,7 @@ typedef struct {
 #define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with the 1-in-16 splitters lists of 2^26+ elements get (A/B testing) */
 #define POVU_HIP_F_ALL_VERTEX_CLASSES 512u /* number the cycle classes of all tree edges, not just the black ones the candidate stack holds (A/B testing) */
 #define POVU_HIP_F_CHECK_LAMINAR 1024u /* always run the laminarity check of the candidate stack's (prev, i) intervals; by default it only runs when the literal hi_2 rule capped differently from the second-highest reach, DESIGN.md section 4 has the proof for the other case (A/B testing, fuzzing) */
+#define POVU_HIP_F_LEAF_SUBFLUBBLES 2048u /* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) and find_parallel (parallel.cpp:263-287) on every PVST; the forest then also carries ai / zi and the line letter of every vertex (povu_hip_forest_get_sub).  Not the reference's whole `-s`: its three inserting passes are not built */
 #define POVU_HIP_F_SORTED_ADJ 16u /* build the local adjacency with the radix sort hub graphs use (A/B testing) */
 
 /*
@@ -195,6 +196,11 @@ typedef struct {
 } povu_hip_tree;
 
 int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hip_tree *out);
+/* With POVU_HIP_F_LEAF_SUBFLUBBLES: per PVST vertex of tree i (n_pvst entries, entry 0 = dummy root) the spanning-tree
+ * vertices ai / zi that pvst::Flubble::create takes (compute_ai_zi, flubbles.cpp:264-290; POVU_HIP_NIL for the root) and
+ * the line letter 'D' 'F' 'T' (tiny) 'O' (parallel).  Any of the three pointers may be NULL.  Returns 3 when the
+ * forest carries none. */
+int povu_hip_forest_get_sub(const povu_hip_forest *f, uint32_t i, const uint32_t **ai, const uint32_t **zi, const uint8_t **fam);
 /*
  * The forest's arrays as ONE page-locked host block (what a multi-GPU gather ships):
  * offsets[0..4] = byte offsets of a_id, z_id, parent (u32 x total) and a_or, z_or (u8 x total);
@@ -213,6 +219,9 @@ char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i, size_t *le
 /* the same serialiser on caller-provided PVST arrays (host only, no GPU needed); NULL on bad input */
 char *povu_hip_pvst_format(uint32_t n_pvst, const uint32_t *a_id, const uint32_t *z_id, const uint8_t *a_or,
 			   const uint8_t *z_or, const uint32_t *parent, size_t *len);
+/* ... with the line letter of every vertex given ('D' for entry 0, then 'F' / 'T' / 'O'); fam == NULL = all flubbles */
+char *povu_hip_pvst_format_fam(uint32_t n_pvst, const uint32_t *a_id, const uint32_t *z_id, const uint8_t *a_or,
+			       const uint8_t *z_or, const uint32_t *parent, const uint8_t *fam, size_t *len);
 void povu_hip_buffer_free(void *p);
 
 /* ---- PVST reader (host only): mto::from_pvst::read_pvst + pvst::Tree::comp_heights,

@@ -86,6 +86,7 @@ typedef struct {
 	uint8_t *z_or;	  /* [n] */
 	uint32_t *parent; /* [n] ORC_NIL for root */
 	uint32_t *ai, *zi; /* [n] flubbles.cpp:264-290 */
+	uint8_t *fam;	  /* [n] line letter 'D' 'F' 'T' 'O', or NULL before orc_leaf_subflubbles */
 } orc_pvst;
 
 /* ---- construction ---- */
@@ -116,6 +117,17 @@ orc_pvst *orc_add_flubbles(const orc_tree *t, const orc_oic *s, const uint32_t *
 void orc_pvst_free(orc_pvst *p);
 /* find_flubbles, flubbles.cpp:721-745 */
 orc_pvst *orc_find_flubbles(orc_tree *t);
+/* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) + find_parallel (parallel.cpp:263-287) over
+ * gen_tree_meta's bracket table (tree_utils.cpp:531-690); the three inserting passes are not restated.  Fills p->fam.
+ * PARITY UNPINNED (the reference holds no T / O line anywhere). */
+void orc_leaf_subflubbles(const orc_tree *t, orc_pvst *p);
+/* when on, the decompose entry points and orc_dump_component run orc_leaf_subflubbles on every PVST */
+void orc_set_leaf_subflubbles(int on);
+/* which rule decided, counted since the last reset (tests: does the fuzz reach every rule?): out[11] = leaves whose Y is
+ * empty, tiny by a bracket to ai, tiny by an ordinary / a capping-or-simplifying back-edge INDEX equal to ai, parallel by
+ * in_branch with ai / with zi, by in_trunk with ai / with zi, inspect_trunk's cond_b, leaves looked at, times the index comparison was reached with a
+ * non-empty OBE(c).  Not thread safe. */
+void orc_leaf_stats(uint64_t *out, int reset);
 /* write_pvst, src/mto/to_pvst.cpp:30-109: returns malloc'd text, length in *len */
 char *orc_pvst_text(const orc_pvst *p, size_t *len);
 
@@ -176,6 +188,8 @@ typedef struct {
 	uint32_t n_pvst;
 	uint32_t *p_parent, *p_a_id, *p_z_id, *p_ai, *p_zi;
 	uint8_t *p_a_or, *p_z_or;
+	uint8_t *p_fam; /* NULL unless orc_set_leaf_subflubbles(1) */
+	uint32_t *pre, *post; /* [n_tree] the shared visit counter of from_bd */
 	uint32_t n_bry;
 	uint64_t *bry;
 } orc_dump;

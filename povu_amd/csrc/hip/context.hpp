@@ -4,6 +4,7 @@
 #include "../../../include/povu_hip.h"
 
 #include "graph_kernels.hpp"
+#include "leaf_kernels.hpp"
 #include "par_kernels.hpp"
 #include "seq_kernels.hpp"
 #include "tree_kernels.hpp"
@@ -97,6 +98,8 @@ struct povu_hip_forest {
 		std::shared_ptr<PinnedPool> pool;
 		uint32_t *a = nullptr, *z = nullptr, *parent = nullptr;
 		uint8_t *aor = nullptr, *zor = nullptr;
+		std::vector<uint32_t> sub_ai, sub_zi; // with POVU_HIP_F_LEAF_SUBFLUBBLES (see the forest's own sub_ai)
+		std::vector<uint8_t> sub_fam;
 		void carve(size_t total_entries)
 		{
 			total = total_entries;
@@ -133,6 +136,10 @@ struct povu_hip_forest {
 	Span<uint32_t> a_id, z_id, parent;
 	Span<uint8_t> a_or, z_or;
 	std::vector<uint64_t> hairpins;
+	// with POVU_HIP_F_LEAF_SUBFLUBBLES: ai / zi (flubbles.cpp:264-290) and the line letter of every PVST vertex, indexed
+	// like the arrays of this forest's own block
+	std::vector<uint32_t> sub_ai, sub_zi;
+	std::vector<uint8_t> sub_fam;
 };
 
 struct povu_hip_ctx {
@@ -140,7 +147,7 @@ struct povu_hip_ctx {
 	hipStream_t stream = nullptr;
 	SideStream side; // PCIe-bound result writes run beside the main stream's kernels
 	ResidentGraph g;
-	Arena ws, ws2, ws_seq, upload_tmp;
+	Arena ws, ws2, ws_seq, ws_leaf, upload_tmp;
 	HostScratch host;
 	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 	StageTimer timer;

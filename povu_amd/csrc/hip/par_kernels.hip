@@ -1054,6 +1054,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	HIP_CHECK(hipMemcpyAsync(&extra[2], pw.err + 5, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
+	pw.nb0 = NB0;
+	pw.ncap = ncap;
+	pw.nsimp = nsimp;
 	// Classes of the black tree edges only (the candidate stack holds no others: half the vertices to look up, sort and
 	// number).  Per top bracket the reference walks ALL vertices that have it on top, deepest first, and opens a class
 	// whenever the list size differs from the one before (recent_size, flubbles.cpp:668-676); leaving the gray edges'
@@ -1142,6 +1145,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	tm.begin("par_pvst");
 	scan8(dflag, pw.erank, (size_t)S + 1);
 	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
+	pw.n_emitted = NE;
 	// The five PVST arrays back to back (povu_hip_forest::alloc has the same layout).  Small results are written by the
 	// emit kernels straight into the forest's page-locked host block (no copy, no extra launch).  Large ones go
 	// through a device block of the same layout: the scattered 4- and 1-byte stores of the emit kernels make poor PCIe

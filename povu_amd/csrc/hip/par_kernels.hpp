@@ -59,6 +59,8 @@ struct ParWs {
 	uint32_t *cproc_ps, *doff;	 // [C+1] processed components before c; first dense PVST slot of c
 	size_t d_total;			 // PVST vertices of all processed components (dense output)
 	uint32_t n_stack;		 // candidate-stack entries of the last pass
+	uint32_t nb0 = 0, ncap = 0, nsimp = 0; // out: ordinary / capping / simplifying back edges of the last pass (b_src / b_tgt hold them in that order)
+	uint32_t n_emitted = 0;		 // out: flubbles the last pass emitted (e_i / lev hold one entry each)
 	uint32_t *d_a, *d_z, *d_parent;	 // [d_total] device views into the forest's page-locked result block
 	uint8_t *d_aor, *d_zor;		 // [d_total] 0 forward, 1 reverse
 	void *stage;			 // device block with the layout of the result block (large results are copied out by the DMA engine)

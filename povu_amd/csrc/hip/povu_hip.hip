@@ -444,6 +444,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		ctx->host.reset();
 		cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
+		const bool leaf_sub = (o.flags & POVU_HIP_F_LEAF_SUBFLUBBLES) != 0;
+		LeafState leaf_state;
+		if (leaf_sub && (o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE)))
+			throw HipError("the leaf subflubble passes read the state of the parallel stages: not with the sequential tree / all-sequential test modes");
 		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, hairpins));
 		carve_workspace(&ctx->ws, 0, z, cs, sw, hairpins);
 
@@ -540,6 +544,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		sw.gid_s = cs.gid_s;
 		sw.tip_s = cs.tip_s;
 		sw.start_key = cs.start_key;
+		sw.p_ai = sw.p_zi = nullptr;
 		const size_t T = 2 * (size_t)g.V + C, B = (size_t)g.E + g.V + 2 * T;
 		// the one-lane kernels expect their lists empty; only paid for when they actually run
 		auto init_seq_workspace = [&]() {
@@ -622,6 +627,28 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			uint32_t nbad = 0;
 			for (uint32_t c = 0; c < C; c++)
 				nbad += sum[4 + c] ? 1 : 0;
+			if (leaf_sub) {
+				// find_tiny + find_parallel relabel leaf flubbles (leaf_kernels.hip): the PVSTs the parallel stages just
+				// emitted here, those of components that go through the redo of add_flubbles after it (below)
+				if (nbad && hairpins)
+					throw HipError("leaf subflubble passes: with --hairpins a component that needs the sequential redo is rebuilt "
+						       "from scratch by the one-lane kernels, whose tree state the passes do not read");
+				tm.begin("leaf_subflubbles");
+				leaf_prepare(cs, sw, ctx->pw, ctx->tw, C, ctx->ws_leaf, leaf_state, s);
+				leaf_dense(leaf_state, sw, ctx->pw, C, s);
+				const size_t n = ctx->pw.d_total;
+				f->sub_ai.resize(n);
+				f->sub_zi.resize(n);
+				f->sub_fam.resize(n);
+				if (n) {
+					HIP_CHECK(hipMemcpyAsync(f->sub_ai.data(), leaf_state.dense.ai, n * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipMemcpyAsync(f->sub_zi.data(), leaf_state.dense.zi, n * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(hipMemcpyAsync(f->sub_fam.data(), leaf_state.dense.fam, n, hipMemcpyDeviceToHost, s));
+				}
+				tm.end(16);
+				HIP_CHECK(hipStreamSynchronize(s));
+				sum = nullptr; // (read again below: the pass total then includes this stage)
+			}
 			if (hairpins && !nbad) {
 				run_parallel_hairpins(cs, sw, ctx->pw, C, tm, s);
 				sum = nullptr;
@@ -650,13 +677,22 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 					sw.stages = SEQ_STAGE_PVST | SEQ_STAGE_GIVEN_STACK;
 					ctx->redo_pvst_only = true;
 				} else {
+					if (leaf_sub)
+						throw HipError("leaf subflubble passes: this pass rebuilds the flagged components from scratch with the "
+							       "one-lane kernels, whose tree state the passes do not read");
 					if (dense_nb0 >= 0) // parallel tree: the one-lane kernels start from scratch
 						init_seq_workspace();
 					sw.stages = dense_nb0 >= 0 ? SEQ_STAGE_ALL : (SEQ_STAGE_CLASSES | SEQ_STAGE_STACK | SEQ_STAGE_PVST);
 				}
 				sw.comp_sel = ctx->pw.comp_bad;
+				if (leaf_sub) { // (only reached with the PVST-only redo, see above)
+					sw.p_ai = leaf_state.p_ai;
+					sw.p_zi = leaf_state.p_zi;
+				}
 				launch_seq_components(sw, s);
 				sw.comp_sel = nullptr;
+				if (leaf_sub)
+					leaf_seq(leaf_state, cs, sw, ctx->pw.comp_bad, C, s);
 				tm.end(1);
 				sum = nullptr;
 			}
@@ -736,6 +772,26 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				dzo[i] = (ors[i] >> 1) & 1;
 			}
 		};
+		// ... and their subflubble labels (leaf_seq wrote them in the same per-component layout)
+		auto fetch_seq_sub = [&](std::vector<povu_hip_forest::Tree *> &ts, std::vector<uint32_t> &dai, std::vector<uint32_t> &dzi,
+					 std::vector<uint8_t> &dfam, size_t n_total) {
+			dai.assign(n_total, POVU_NIL);
+			dzi.assign(n_total, POVU_NIL);
+			dfam.assign(n_total, 0);
+			const size_t P = (size_t)g.V + C;
+			std::vector<uint32_t> ha(P), hz(P);
+			std::vector<uint8_t> hf(P);
+			HIP_CHECK(hipMemcpyAsync(ha.data(), leaf_state.p_ai, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(hz.data(), leaf_state.p_zi, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipMemcpyAsync(hf.data(), leaf_state.p_fam, P, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			for (const auto *t : ts) {
+				const size_t pb = (size_t)voff[t->component_id - 1] + (t->component_id - 1);
+				std::copy_n(ha.begin() + pb, t->n_pvst, dai.begin() + t->off);
+				std::copy_n(hz.begin() + pb, t->n_pvst, dzi.begin() + t->off);
+				std::copy_n(hf.begin() + pb, t->n_pvst, dfam.begin() + t->off);
+			}
+		};
 		f->hairpins.resize(2 * total_hp);
 		if (dense_out) { // the parallel stages wrote every PVST back to back into f->block
 			if (!mixed && (doff[C] != total || total != ctx->pw.d_total))
@@ -771,6 +827,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				for (auto *t : redo)
 					t->blk = 0;
 				fetch_seq(redo, blk.a, blk.z, blk.parent, blk.aor, blk.zor, redo_total);
+				if (leaf_sub)
+					fetch_seq_sub(redo, f->extra[0].sub_ai, f->extra[0].sub_zi, f->extra[0].sub_fam, redo_total);
 			} else if (more || tm.enabled) { // (the stage events themselves have to complete before they are read)
 				HIP_CHECK(hipEventRecord(ev_all1, s));
 				HIP_CHECK(hipStreamSynchronize(s));
@@ -785,7 +843,11 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				all.push_back(&t);
 			tm.end(0);
 			fetch_seq(all, f->a_id.data(), f->z_id.data(), f->parent.data(), f->a_or.data(), f->z_or.data(), total);
+			if (leaf_sub)
+				fetch_seq_sub(all, f->sub_ai, f->sub_zi, f->sub_fam, total);
 		}
+		if (leaf_sub)
+			ctx->ws_leaf.release(); // (not part of the workspace a plain decompose keeps warm)
 		// stage times
 		ctx->last_times.clear();
 		for (auto &r : tm.recs) {
@@ -876,19 +938,52 @@ extern "C" void povu_hip_forest_free(povu_hip_forest *f) { delete f; }
 extern "C" void povu_hip_buffer_free(void *p) { free(p); }
 
 // mto::to_pvst::write_pvst, src/mto/to_pvst.cpp:23-109
+extern "C" int povu_hip_forest_get_sub(const povu_hip_forest *f, uint32_t i, const uint32_t **ai, const uint32_t **zi,
+				       const uint8_t **fam)
+{
+	if (!f || i >= f->trees.size())
+		return 1;
+	const auto &t = f->trees[i];
+	const std::vector<uint32_t> &va = t.blk < 0 ? f->sub_ai : f->extra[(size_t)t.blk].sub_ai;
+	const std::vector<uint32_t> &vz = t.blk < 0 ? f->sub_zi : f->extra[(size_t)t.blk].sub_zi;
+	const std::vector<uint8_t> &vf = t.blk < 0 ? f->sub_fam : f->extra[(size_t)t.blk].sub_fam;
+	if (f->sub_fam.empty() || t.off + t.n_pvst > vf.size())
+		return 3; // the forest was not decomposed with POVU_HIP_F_LEAF_SUBFLUBBLES
+	if (ai)
+		*ai = va.data() + t.off;
+	if (zi)
+		*zi = vz.data() + t.off;
+	if (fam)
+		*fam = vf.data() + t.off;
+	return 0;
+}
+
 extern "C" char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i, size_t *len)
 {
 	povu_hip_tree t;
 	if (povu_hip_forest_get(f, i, &t) != 0)
 		return nullptr;
-	return povu_hip_pvst_format(t.n_pvst, t.a_id, t.z_id, t.a_or, t.z_or, t.parent, len);
+	const uint8_t *fam = nullptr;
+	if (povu_hip_forest_get_sub(f, i, nullptr, nullptr, &fam) != 0)
+		fam = nullptr;
+	return povu_hip_pvst_format_fam(t.n_pvst, t.a_id, t.z_id, t.a_or, t.z_or, t.parent, fam, len);
 }
 
 extern "C" char *povu_hip_pvst_format(uint32_t n_pvst, const uint32_t *a_id, const uint32_t *z_id, const uint8_t *a_or,
 				      const uint8_t *z_or, const uint32_t *parent, size_t *len)
 {
+	return povu_hip_pvst_format_fam(n_pvst, a_id, z_id, a_or, z_or, parent, nullptr, len);
+}
+
+extern "C" char *povu_hip_pvst_format_fam(uint32_t n_pvst, const uint32_t *a_id, const uint32_t *z_id, const uint8_t *a_or,
+					  const uint8_t *z_or, const uint32_t *parent, const uint8_t *fam, size_t *len)
+{
 	if (n_pvst == 0 || !a_id || !z_id || !a_or || !z_or || !parent)
 		return nullptr;
+	if (fam)
+		for (uint32_t v = 0; v < n_pvst; v++)
+			if (fam[v] != (v == 0 ? 'D' : 'F') && (v == 0 || (fam[v] != 'T' && fam[v] != 'O')))
+				return nullptr; // line letters this writer knows: D for the root, F / T / O below it
 	struct {
 		uint32_t n_pvst;
 		const uint32_t *a_id, *z_id, *parent;
@@ -918,7 +1013,12 @@ extern "C" char *povu_hip_pvst_format(uint32_t n_pvst, const uint32_t *a_id, con
 		out.append(num, (size_t)l);
 	};
 	for (uint32_t v = 0; v < n; v++) {
-		out += v == 0 ? "D\t" : "F\t";
+		if (fam) { // to_pvst.cpp:52-79: the line identifier follows the vertex family
+			out += (char)fam[v];
+			out += '\t';
+		} else {
+			out += v == 0 ? "D\t" : "F\t";
+		}
 		put(v);
 		out += '\t';
 		if (v == 0) {

@@ -38,7 +38,7 @@ struct CompView {
 	uint32_t *o_head, *o_tail, *i_head, *i_tail, *l_head, *l_tail, *l_size, *bl;
 	uint32_t *nxt, *st_head, *st_tail;
 	uint32_t *s_vtx, *s_cls, *next_seen, *last;
-	uint32_t *p_parent, *p_a, *p_z, *aux;
+	uint32_t *p_parent, *p_a, *p_z, *aux, *p_ai, *p_zi;
 	uint8_t *p_or, *in_s;
 	uint64_t *hairpins;
 	uint32_t n_be, n_class, n_bry;
@@ -385,6 +385,8 @@ __device__ static uint32_t seq_pvst(CompView &c, uint32_t n, bool given_stack)
 	c.p_parent[0] = NIL;
 	c.p_a[0] = c.p_z[0] = NIL;
 	c.p_or[0] = 0;
+	if (c.p_ai)
+		c.p_ai[0] = c.p_zi[0] = NIL;
 	for (uint32_t i = 0; i < n; i++) { // add_flubbles, flubbles.cpp:316-365
 		const uint32_t cl = c.s_cls[i] - cls_base;
 		if (c.in_s[cl]) {
@@ -411,6 +413,18 @@ __device__ static uint32_t seq_pvst(CompView &c, uint32_t n, bool given_stack)
 				c.p_a[k] = c.gid[va];
 				c.p_z[k] = c.gid[vz];
 				c.p_or[k] = (uint8_t)(ra | (rz << 1));
+			}
+			if (c.p_ai) { // compute_ai_zi, flubbles.cpp:264-290: the middle two of the boundary edges' four end vertices
+				uint32_t v[4] = {va, c.par[va], vz, c.par[vz]};
+				for (int a = 0; a < 3; a++)
+					for (int b = 0; b < 3 - a; b++)
+						if (v[b] > v[b + 1]) {
+							const uint32_t x = v[b];
+							v[b] = v[b + 1];
+							v[b + 1] = x;
+						}
+				c.p_ai[k] = v[1];
+				c.p_zi[k] = v[2];
 			}
 			c.p_parent[k] = prt;
 			prt = k;
@@ -489,6 +503,8 @@ __global__ void __launch_bounds__(64) k_seq_components(SeqWs w)
 		c.p_a = w.p_a + pb;
 		c.p_z = w.p_z + pb;
 		c.p_or = w.p_or + pb;
+		c.p_ai = w.p_ai ? w.p_ai + pb : nullptr;
+		c.p_zi = w.p_zi ? w.p_zi + pb : nullptr;
 		c.aux = w.aux + pb;
 		c.hairpins = w.hairpins ? w.hairpins + 2 * pb : nullptr;
 

@@ -53,6 +53,7 @@ struct SeqWs {
 	// PVST
 	uint32_t *p_parent, *p_a, *p_z; // [V+C]
 	uint8_t *p_or;			// [V+C] bit0 a reverse, bit1 z reverse
+	uint32_t *p_ai, *p_zi;		// [V+C] or null: compute_ai_zi of every flubble (flubbles.cpp:264-290), for the leaf subflubble passes
 	uint32_t *aux;			// [V+C]
 	uint8_t *in_s;			// [B+T]
 	uint64_t *hairpins;		// [2*(V+C)] or null

@@ -458,8 +458,8 @@ extern "C" int povu_hip_forest_pack(const povu_hip_forest *f, void *dst, size_t 
 {
 	if (!f || !dst)
 		return 1;
-	if (!f->hairpins.empty())
-		return 4; // the wire format carries no hairpin boundaries: refuse rather than drop them
+	if (!f->hairpins.empty() || !f->sub_fam.empty())
+		return 4; // the wire format carries no hairpin boundaries and no subflubble labels: refuse rather than drop them
 	size_t total = 0;
 	for (const auto &t : f->trees)
 		total += t.n_pvst;
@@ -828,6 +828,8 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 				throw HipError("gather: bad arguments");
 			if (!mine->hairpins.empty())
 				throw HipError("gather: hairpin boundaries do not travel");
+			if (!mine->sub_fam.empty())
+				throw HipError("gather: subflubble labels do not travel");
 			if (!mine->extra.empty()) { // (rare: some components went through the sequential redo)
 				compacted = compact_forest(mine);
 				mine = compacted.get();

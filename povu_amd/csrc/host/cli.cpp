@@ -36,6 +36,9 @@ static void usage(std::ostream &os)
 	      "        --output-dir=[output_dir]         Output directory [default: .]\n"
 	      "        -h, --hairpins                    Find hairpins in the variation graph [default: false]\n"
 	      "        -s, --subflubbles                 Find subflubbles in the variation graph [default: false]\n"
+	      "                                          (refused: only its first two passes are built, see --leaf-subflubbles)\n"
+	      "        --leaf-subflubbles                Relabel leaf flubbles as tiny (T) / parallel (O): the find_tiny and\n"
+	      "                                          find_parallel passes of -s, without its three inserting passes\n"
 	      "        --structure-export=[structure_json]\n"
 	      "                                          Write the flubble debug sidecar <structure_json>.flubble-debug.jsonl\n"
 	      "                                          [conformance]\n";
@@ -91,6 +94,8 @@ int main(int argc, char **argv)
 			cfg.hairpins = true;
 		} else if ((command == "decompose" || command == "gfa2vcf") && (!strcmp(a, "-s") || !strcmp(a, "--subflubbles"))) {
 			cfg.subflubbles = true;
+		} else if ((command == "decompose" || command == "gfa2vcf") && !strcmp(a, "--leaf-subflubbles")) {
+			cfg.leaf_subflubbles = true;
 		} else if ((command == "decompose" || command == "gfa2vcf") && !strncmp(a, "--structure-export", 18) &&
 			   (a[18] == 0 || a[18] == '=')) {
 			if (a[18] == '=') {

@@ -32,7 +32,8 @@ void do_decompose(const Config &cfg)
 {
 	const int ll = cfg.verbosity;
 	if (cfg.subflubbles)
-		throw std::runtime_error("-s/--subflubbles is not part of the MI355X decompose path yet (flubbles only)");
+		throw std::runtime_error("-s/--subflubbles is not part of the MI355X decompose path: of its five passes only find_tiny and "
+					 "find_parallel are built (--leaf-subflubbles); concealed, midi and smothered are not");
 	const double t0 = now_ms();
 	// the HIP runtime comes up (~0.1 s) while the GFA is being parsed
 	char err[512] = {0}, cerr_buf[512] = {0};
@@ -58,7 +59,8 @@ void do_decompose(const Config &cfg)
 	if (ll > 1)
 		info("Finding components");
 	// per-stage HIP events only when the stage-cost lines will be printed
-	povu_hip_opts opts{0, 1, (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | (ll ? 0u : POVU_HIP_F_NO_STAGE_TIMES)};
+	povu_hip_opts opts{0, 1, (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | (ll ? 0u : POVU_HIP_F_NO_STAGE_TIMES) |
+				    (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u)};
 	const double t2 = now_ms();
 	povu_hip_forest *f = povu_hip_decompose(ctx, &opts, err, sizeof err);
 	const double t3 = now_ms();

@@ -18,6 +18,7 @@ struct Config {
 	int threads = 1;
 	bool hairpins = false;
 	bool subflubbles = false;
+	bool leaf_subflubbles = false; // --leaf-subflubbles: find_tiny + find_parallel only (the two passes of -s that relabel leaf flubbles)
 	int device = 0;
 	// --structure-export <path>: also write <path>.flubble-debug.jsonl (one frame per decomposed component)
 	std::string structure_export;

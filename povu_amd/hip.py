@@ -54,6 +54,7 @@ F_SPARSE_SPLITTERS = 128
 F_REDO_ODD = 256
 F_ALL_VERTEX_CLASSES = 512
 F_CHECK_LAMINAR = 1024
+F_LEAF_SUBFLUBBLES = 2048
 
 _lib = None
 
@@ -85,6 +86,9 @@ def load_lib():
     l.povu_hip_forest_get.restype = C.c_int
     l.povu_hip_forest_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Tree)]
     l.povu_hip_forest_free.argtypes = [C.c_void_p]
+    l.povu_hip_forest_get_sub.restype = C.c_int
+    l.povu_hip_forest_get_sub.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)),
+                                          C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint8))]
     l.povu_hip_forest_raw.restype = C.c_int
     l.povu_hip_forest_raw.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)]
@@ -242,6 +246,20 @@ class Forest:
         if with_text:
             out.text = self.text(i)
         return out
+
+    def sub(self, i: int):
+        """(ai, zi, line letters) of tree i after a decompose with F_LEAF_SUBFLUBBLES: compute_ai_zi's spanning-tree
+        vertices (flubbles.cpp:264-290) and 'D' / 'F' / 'T' / 'O' per PVST vertex."""
+        t = _Tree()
+        if self._lib.povu_hip_forest_get(self._h, i, C.byref(t)) != 0:
+            raise IndexError(i)
+        ai, zi, fam = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint8)()
+        rc = self._lib.povu_hip_forest_get_sub(self._h, i, C.byref(ai), C.byref(zi), C.byref(fam))
+        if rc != 0:
+            raise RuntimeError(f"forest carries no subflubble labels (rc {rc})")
+        n = t.n_pvst
+        return (np.ctypeslib.as_array(ai, shape=(n,)).copy(), np.ctypeslib.as_array(zi, shape=(n,)).copy(),
+                np.ctypeslib.as_array(fam, shape=(n,)).copy())
 
     def raw(self):
         """Zero-copy view of the whole result: (uint8 block over the pinned host memory, total entries,

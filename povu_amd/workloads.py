@@ -270,3 +270,161 @@ def random_bidirected(n_vtx: int, n_links: int, seed: int, self_loops: bool = Tr
     s1[fwd] = R
     s2[fwd] = L
     return _mk(vid, v1, s1, v2, s2)
+
+
+def bubble_zoo(n_comp: int, sites: int, seed: int, shuffle_ids: bool = True) -> Links:
+    """Many small components, each a backbone whose sites are small motifs drawn at random: SNPs, multi-allelic sites,
+    indels, the chain-of-bubbles unit, repeated links, inversions, self loops (both kinds), a bubble nested in an allele,
+    small random tangles, dangling hairpins, flipped interior segments.  The leaf flubbles of such graphs come in every
+    shape the two relabelling passes of `-s` (find_tiny / find_parallel) distinguish, and the components are small enough
+    that a back-edge INDEX often equals a tree vertex index (tiny.cpp:52-56 compares the two)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    links = []  # (a, side_a, b, side_b) over provisional vertex numbers
+    nv = 0
+
+    def new():
+        nonlocal nv
+        nv += 1
+        return nv - 1
+
+    def fwd(a, b, fa=False, fb=False):  # a -> b; a flipped segment presents its other side
+        links.append((a, L if fa else R, b, R if fb else L))
+
+    for _ in range(n_comp):
+        prev = new()
+        anchors = []
+        for _ in range(int(rng.integers(1, sites + 1))):
+            nxt = new()
+            m = int(rng.integers(0, 16))
+            flip = bool(rng.random() < 0.25)
+            if m == 0:  # SNP
+                for _ in range(2):
+                    x = new()
+                    fwd(prev, x, fb=flip)
+                    fwd(x, nxt, fa=flip)
+            elif m == 1:  # multi-allelic
+                for _ in range(int(rng.integers(3, 7))):
+                    x = new()
+                    fwd(prev, x)
+                    fwd(x, nxt)
+            elif m == 2:  # indel
+                x = new()
+                fwd(prev, x, fb=flip)
+                fwd(x, nxt, fa=flip)
+                fwd(prev, nxt)
+            elif m == 3:  # the unit of chain_of_bubbles
+                x, y = new(), new()
+                fwd(prev, x), fwd(prev, y), fwd(x, y), fwd(x, nxt), fwd(y, nxt), fwd(prev, nxt)
+            elif m == 4:  # repeated links
+                x = new()
+                for _ in range(int(rng.integers(2, 4))):
+                    fwd(prev, x)
+                fwd(x, nxt)
+                if rng.random() < 0.5:
+                    fwd(x, nxt)
+            elif m == 5:  # inversion: the allele is entered from both ends
+                x = new()
+                fwd(prev, x), fwd(x, nxt)
+                fwd(prev, x, fb=True), fwd(x, nxt, fa=True)
+            elif m == 6:  # self loops
+                x = new()
+                fwd(prev, x), fwd(x, nxt)
+                if rng.random() < 0.5:
+                    links.append((x, R, x, L))
+                else:
+                    s = int(rng.integers(0, 2))
+                    links.append((x, s, x, s))
+                if rng.random() < 0.5:
+                    fwd(prev, nxt)
+            elif m == 7:  # a SNP nested in one allele
+                x, y, a, b = new(), new(), new(), new()
+                fwd(prev, x), fwd(x, a), fwd(x, b), fwd(a, y), fwd(b, y), fwd(y, nxt)
+                z = new()
+                fwd(prev, z), fwd(z, nxt)
+            elif m == 8:  # small random tangle between the anchors
+                k = int(rng.integers(2, 6))
+                xs = [new() for _ in range(k)]
+                fwd(prev, xs[0]), fwd(xs[-1], nxt)
+                for _ in range(int(rng.integers(k, 3 * k))):
+                    a, b = int(rng.integers(0, k)), int(rng.integers(0, k))
+                    links.append((xs[a], int(rng.integers(0, 2)), xs[b], int(rng.integers(0, 2))))
+                for i in range(k - 1):
+                    fwd(xs[i], xs[i + 1])
+            elif m == 9:  # dangling hairpin and a plain step
+                x = new()
+                fwd(prev, x)
+                links.append((x, R, x, R))
+                fwd(prev, nxt)
+            elif m == 10:  # two alleles of different length
+                x, y, z = new(), new(), new()
+                fwd(prev, x), fwd(x, nxt), fwd(prev, y), fwd(y, z), fwd(z, nxt)
+            elif m == 11:  # funnel: several alleles merge into one segment before the site ends; plus the direct step
+                k = int(rng.integers(3, 6))
+                x = new()
+                for _ in range(k):
+                    y = new()
+                    fwd(prev, y), fwd(y, x)
+                fwd(x, nxt), fwd(prev, nxt)
+            elif m == 12:  # the funnel the other way round
+                k = int(rng.integers(3, 6))
+                x = new()
+                fwd(prev, x)
+                for _ in range(k):
+                    y = new()
+                    fwd(x, y), fwd(y, nxt)
+                fwd(prev, nxt)
+            elif m == 13:  # a segment hanging off the site, reached from earlier anchors as well
+                x = new()
+                fwd(prev, x)
+                fwd(prev, nxt)
+                for a in anchors[-3:]:
+                    if rng.random() < 0.6:
+                        fwd(a, x)
+                if rng.random() < 0.5 and anchors:
+                    fwd(x, anchors[int(rng.integers(0, len(anchors)))], fb=True)
+            elif m == 14:  # a tip hanging off the far end of the site
+                x = new()
+                fwd(prev, nxt)
+                links.append((nxt, L, x, int(rng.integers(0, 2))))
+            else:  # plain step, sometimes doubled
+                fwd(prev, nxt)
+                if rng.random() < 0.3:
+                    fwd(prev, nxt)
+            anchors.append(prev)
+            prev = nxt
+    perm = rng.permutation(nv) if shuffle_ids else np.arange(nv)
+    arr = np.array(links, dtype=np.int64).reshape(-1, 4)
+    order = rng.permutation(len(arr)) if shuffle_ids else np.arange(len(arr))
+    arr = arr[order]
+    vid = np.arange(1, nv + 1, dtype=np.uint32)
+    return _mk(vid, perm[arr[:, 0]], arr[:, 1], perm[arr[:, 2]], arr[:, 3])
+
+
+def hanger_family(prefix: int, suffix: int, variant: int, direct_first: bool = True) -> Links:
+    """One component: `prefix` plain steps, an indel site (prev -> y -> nxt and prev -> nxt) with one more segment x
+    hanging off the inner side of nxt, then `suffix` plain steps.  variant 0: x carries a loop between its two sides
+    (its tree edge is a bridge: x gets a simplifying back edge); variant 1: x's far side is a tip and its near side is also
+    reached from the first segment of the component (an ordinary back edge out of x); variant 2: both.  As the prefix
+    grows, the tree vertex idx of the site's boundary sweeps across the back-edge indices of x's edges -- the
+    coincidence tiny.cpp:52-56 turns into a 'tiny' label."""
+    links = []
+    n = prefix + 4 + suffix + 1
+    first = 0
+    for i in range(prefix):
+        links.append((i, R, i + 1, L))
+    prev, y, nxt, x = prefix, prefix + 1, prefix + 2, prefix + 3
+    site = [(prev, R, nxt, L), (prev, R, y, L), (y, R, nxt, L)]
+    if not direct_first:
+        site = site[1:] + site[:1]
+    links += site
+    links.append((nxt, L, x, L))
+    if variant in (0, 2):
+        links.append((x, R, x, L))
+    if variant in (1, 2) and prefix > 0:
+        links.append((first, R, x, L))
+    last = nxt
+    for i in range(suffix):
+        links.append((last, R, prefix + 4 + i, L))
+        last = prefix + 4 + i
+    arr = np.array(links, dtype=np.int64)
+    return _mk(np.arange(1, n + 1, dtype=np.uint32), arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3])

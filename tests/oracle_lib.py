@@ -40,14 +40,16 @@ def lib():
         _lib.orc_decompose_gfa.restype = C.c_int
         _lib.orc_decompose_gfa.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         _lib.orc_set_faithful_rescan.argtypes = [C.c_int]
+        _lib.orc_set_leaf_subflubbles.argtypes = [C.c_int]
     return _lib
 
 
-def decompose(links, tips=None, want_text=True, timings=False, threads=1, lpt=False):
+def decompose(links, tips=None, want_text=True, timings=False, threads=1, lpt=False, leaf=False):
     """Run the oracle on a workloads.Links. Returns {component_id: pvst_text}
     (component ids are 1-based, skipped components absent).  threads > 1 runs the per-component part
     on that many threads: the reference's contiguous chunks (decompose.cpp:78-92,116-157) or, with
-    lpt, components bin-packed by size."""
+    lpt, components bin-packed by size.  leaf=True: the two relabelling passes of `-s` (find_tiny, find_parallel)
+    run on every PVST, so the text carries T / O lines."""
     l = lib()
     vid = np.ascontiguousarray(links.vid, dtype=np.uint32)
     v1 = np.ascontiguousarray(links.v1, dtype=np.uint32)
@@ -58,9 +60,13 @@ def decompose(links, tips=None, want_text=True, timings=False, threads=1, lpt=Fa
     if tips is not None:
         tips = np.ascontiguousarray(tips, dtype=np.uint8)
         tp = tips.ctypes.data
-    f = l.orc_decompose_arrays_mt(len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
-                                  v2.ctypes.data, s2.ctypes.data, tp, 1 if want_text else 0, int(threads),
-                                  1 if lpt else 0)
+    l.orc_set_leaf_subflubbles(1 if leaf else 0)
+    try:
+        f = l.orc_decompose_arrays_mt(len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
+                                      v2.ctypes.data, s2.ctypes.data, tp, 1 if want_text else 0, int(threads),
+                                      1 if lpt else 0)
+    finally:
+        l.orc_set_leaf_subflubbles(0)
     fo = f.contents
     out = {}
     for c in range(fo.n_comp):

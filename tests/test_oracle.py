@@ -192,18 +192,25 @@ class _Dump(C.Structure):
                 ("n_pvst", C.c_uint32), ("p_parent", C.POINTER(C.c_uint32)), ("p_a_id", C.POINTER(C.c_uint32)),
                 ("p_z_id", C.POINTER(C.c_uint32)), ("p_ai", C.POINTER(C.c_uint32)), ("p_zi", C.POINTER(C.c_uint32)),
                 ("p_a_or", C.POINTER(C.c_uint8)), ("p_z_or", C.POINTER(C.c_uint8)),
+                ("p_fam", C.POINTER(C.c_uint8)), ("pre", C.POINTER(C.c_uint32)), ("post", C.POINTER(C.c_uint32)),
                 ("n_bry", C.c_uint32), ("bry", C.POINTER(C.c_uint64))]
 
 
-def dump_component(links, comp=0, tips=None):
+def dump_component(links, comp=0, tips=None, leaf=False):
+    """Every intermediate array of one component; leaf=True also runs the two relabelling passes of `-s`
+    (orc_leaf_subflubbles) and returns the line letters as p_fam."""
     lib = O.lib()
     lib.orc_dump_component.restype = C.POINTER(_Dump)
     lib.orc_dump_component.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_uint32]
     lib.orc_dump_free.argtypes = [C.POINTER(_Dump)]
     tp = None if tips is None else np.ascontiguousarray(tips, dtype=np.uint8).ctypes.data
-    d = lib.orc_dump_component(links.n_vtx, links.vid.ctypes.data, links.n_links, links.v1.ctypes.data,
-                               links.s1.ctypes.data, links.v2.ctypes.data, links.s2.ctypes.data, tp, comp)
+    lib.orc_set_leaf_subflubbles(1 if leaf else 0)
+    try:
+        d = lib.orc_dump_component(links.n_vtx, links.vid.ctypes.data, links.n_links, links.v1.ctypes.data,
+                                   links.s1.ctypes.data, links.v2.ctypes.data, links.s2.ctypes.data, tp, comp)
+    finally:
+        lib.orc_set_leaf_subflubbles(0)
     if not d:
         return None
     c = d.contents
@@ -215,10 +222,13 @@ def dump_component(links, comp=0, tips=None):
                  ("be_type", c.n_be), ("s_id", c.n_stack), ("s_st_idx", c.n_stack), ("s_edge_id", c.n_stack),
                  ("s_cls", c.n_stack), ("next_seen", c.n_stack), ("s_orient", c.n_stack),
                  ("p_parent", c.n_pvst), ("p_a_id", c.n_pvst), ("p_z_id", c.n_pvst), ("p_a_or", c.n_pvst),
-                 ("p_z_or", c.n_pvst), ("ev1", c.ne), ("ev2", c.ne),
+                 ("p_z_or", c.n_pvst), ("p_ai", c.n_pvst), ("p_zi", c.n_pvst), ("pre", c.n_tree), ("post", c.n_tree),
+                 ("ev1", c.ne), ("ev2", c.ne),
                  ("es1", c.ne), ("es2", c.ne), ("gidx", c.nv)]:
         out[f] = arr(getattr(c, f), n)
     out["n_be0"] = c.n_be0
+    if leaf:
+        out["p_fam"] = arr(c.p_fam, c.n_pvst) if c.p_fam else np.zeros(0, dtype=np.uint8)
     out["bry"] = arr(c.bry, 2 * c.n_bry).reshape(-1, 2)
     lib.orc_dump_free(d)
     return out
