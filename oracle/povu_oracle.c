@@ -1185,6 +1185,7 @@ orc_pvst *orc_find_flubbles(orc_tree *t)
 enum { LS_TINY_NO_Y, LS_TINY_BRACKET, LS_TINY_IDX_ORD, LS_TINY_IDX_EXTRA, LS_PAR_BRANCH_AI, LS_PAR_BRANCH_ZI, LS_PAR_TRUNK_AI,
        LS_PAR_TRUNK_ZI, LS_TRUNK_COND_B, LS_LEAVES, LS_TINY_IDX_ASKED, LS_N };
 static uint64_t g_leaf_stats[LS_N];
+#define LS_INC(i) ((void)__atomic_fetch_add(&g_leaf_stats[i], 1, __ATOMIC_RELAXED)) /* (the threaded entry points count too) */
 void orc_leaf_stats(uint64_t *out, int reset)
 {
 	if (out)
@@ -1299,20 +1300,20 @@ static int tiny_branches(const orc_tree *t, const tree_meta *m, uint32_t ai, uin
 		for (uint32_t b = m->off[c]; b < m->off[c + 1] && !hit; b++)
 			hit = t->be_tgt[m->be[b]] == ai;
 		if (hit)
-			g_leaf_stats[LS_TINY_BRACKET]++;
+			LS_INC(LS_TINY_BRACKET);
 		else if (m->o_off[c + 1] > m->o_off[c])
-			g_leaf_stats[LS_TINY_IDX_ASKED]++;
+			LS_INC(LS_TINY_IDX_ASKED);
 		for (uint32_t b = m->o_off[c]; b < m->o_off[c + 1] && !hit; b++) {
 			hit = m->o_adj[b] == ai; /* (sic) a back-edge idx against a vertex idx, tiny.cpp:52-56 */
 			if (hit)
-				g_leaf_stats[t->be_type[m->o_adj[b]] == ORC_BE_BACK ? LS_TINY_IDX_ORD : LS_TINY_IDX_EXTRA]++;
+				LS_INC(t->be_type[m->o_adj[b]] == ORC_BE_BACK ? LS_TINY_IDX_ORD : LS_TINY_IDX_EXTRA);
 		}
 		if (!hit)
 			return 0;
 		any = 1;
 	}
 	if (!any)
-		g_leaf_stats[LS_TINY_NO_Y]++;
+		LS_INC(LS_TINY_NO_Y);
 	return 1;
 }
 
@@ -1344,7 +1345,7 @@ static int par_inspect_trunk(const orc_tree *t, const tree_meta *m, uint32_t ai,
 	for (uint32_t k = m->c_off[branching]; k < m->c_off[branching + 1]; k++) {
 		uint32_t c = m->c_adj[k];
 		if (c > zi && t->post[c] - t->pre[c] == 3) {
-			g_leaf_stats[LS_TRUNK_COND_B]++;
+			LS_INC(LS_TRUNK_COND_B);
 			return 1;
 		}
 	}
@@ -1362,14 +1363,14 @@ static int par_in_trunk(const orc_tree *t, const tree_meta *m, uint32_t ai, uint
 		return 0;
 	uint32_t in_ai = count_type(t, m->i_off, m->i_adj, ai, ORC_BE_BACK);
 	if (2 * in_ai >= (zi - ai) - 3) { /* u32, as the reference */
-		g_leaf_stats[LS_PAR_TRUNK_AI]++;
+		LS_INC(LS_PAR_TRUNK_AI);
 		return 1;
 	}
 	if (in_ai != 0)
 		return 0;
 	uint32_t out_zi = count_type(t, m->o_off, m->o_adj, zi, ORC_BE_BACK);
 	if (2 * out_zi >= (zi - ai) - 3) {
-		g_leaf_stats[LS_PAR_TRUNK_ZI]++;
+		LS_INC(LS_PAR_TRUNK_ZI);
 		return 1;
 	}
 	return 0;
@@ -1395,11 +1396,11 @@ static int par_in_branch(const orc_tree *t, const tree_meta *m, uint32_t ai, uin
 	if (br <= 2)
 		return 0;
 	if (count_type(t, m->i_off, m->i_adj, ai, ORC_BE_BACK) >= br + ch_obe) {
-		g_leaf_stats[LS_PAR_BRANCH_AI]++;
+		LS_INC(LS_PAR_BRANCH_AI);
 		return 1;
 	}
 	if (m->o_off[zi + 1] - m->o_off[zi] >= br + ch_obe) {
-		g_leaf_stats[LS_PAR_BRANCH_ZI]++;
+		LS_INC(LS_PAR_BRANCH_ZI);
 		return 1;
 	}
 	return 0;
@@ -1421,7 +1422,7 @@ void orc_leaf_subflubbles(const orc_tree *t, orc_pvst *p)
 	for (uint32_t v = 1; v < p->n; v++) { /* find_tiny */
 		if (has_child[v])
 			continue;
-		g_leaf_stats[LS_LEAVES]++;
+		LS_INC(LS_LEAVES);
 		uint32_t ai = p->ai[v], zi = p->zi[v];
 		if (!(zi - ai == 1 || zi - ai == 3))
 			continue;

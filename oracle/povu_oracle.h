@@ -126,7 +126,7 @@ void orc_set_leaf_subflubbles(int on);
 /* which rule decided, counted since the last reset (tests: does the fuzz reach every rule?): out[11] = leaves whose Y is
  * empty, tiny by a bracket to ai, tiny by an ordinary / a capping-or-simplifying back-edge INDEX equal to ai, parallel by
  * in_branch with ai / with zi, by in_trunk with ai / with zi, inspect_trunk's cond_b, leaves looked at, times the index comparison was reached with a
- * non-empty OBE(c).  Not thread safe. */
+ * non-empty OBE(c). */
 void orc_leaf_stats(uint64_t *out, int reset);
 /* write_pvst, src/mto/to_pvst.cpp:30-109: returns malloc'd text, length in *len */
 char *orc_pvst_text(const orc_pvst *p, size_t *len);

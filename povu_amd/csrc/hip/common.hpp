@@ -12,6 +12,21 @@
 
 #define POVU_NIL 0xFFFFFFFFu
 
+// Workgroup index with the 8 XCDs in mind: the dispatcher deals workgroups round-robin over the XCDs (blocks b and b + 8
+// share one, MI355X_MICROARCH.md "Workgroup dispatch"), so neighbouring blocks -- which touch neighbouring lines in
+// almost every kernel here -- land in eight different L2s.  BIDX renumbers the blocks so that every XCD works on one
+// contiguous stretch of the grid (bijective for any grid size); a speed choice only, nothing depends on placement.
+#ifdef POVU_XCD_SWIZZLE
+__device__ __forceinline__ unsigned povu_xcd_bid()
+{
+	const unsigned nwg = gridDim.x, q = nwg >> 3, r = nwg & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+	return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+#define BIDX povu_xcd_bid()
+#else
+#define BIDX blockIdx.x
+#endif
+
 namespace povu_hip
 {
 

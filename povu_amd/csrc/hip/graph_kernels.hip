@@ -22,7 +22,7 @@ __global__ void k_side_degree(uint32_t E, uint32_t V, const uint32_t *__restrict
 			      uint32_t *__restrict__ deg, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
 			      uint32_t sentinel, uint32_t *__restrict__ bad)
 {
-	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t e = BIDX * blockDim.x + threadIdx.x;
 	if (e >= E)
 		return;
 	if (v1[e] >= V || v2[e] >= V || s1[e] > 1 || s2[e] > 1) {
@@ -50,7 +50,7 @@ __global__ void k_slot_other(uint32_t nS, const uint32_t *__restrict__ off, cons
 			     const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
 			     const uint8_t *__restrict__ s2, uint32_t *__restrict__ aoth)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	for (uint32_t k = off[S]; k < off[S + 1]; k++) {
@@ -65,7 +65,7 @@ __global__ void k_slot_twin(uint32_t E, const uint32_t *__restrict__ off, const 
 			    const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
 			    const uint8_t *__restrict__ s2, uint32_t *__restrict__ atwin)
 {
-	uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t e = BIDX * blockDim.x + threadIdx.x;
 	if (e >= E)
 		return;
 	const uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
@@ -86,7 +86,7 @@ __global__ void k_slot_twin(uint32_t E, const uint32_t *__restrict__ off, const 
 }
 __global__ void k_vertex_degree(uint32_t V, const uint32_t *__restrict__ off, uint32_t *__restrict__ deg)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v < V)
 		deg[v] = off[2 * v + 2] - off[2 * v];
 }
@@ -94,7 +94,7 @@ __global__ void k_vertex_degree(uint32_t V, const uint32_t *__restrict__ off, ui
 // tips as the loader infers them, src/mto/from_gfa.cpp:262-277
 __global__ void k_infer_tips(uint32_t V, const uint32_t *__restrict__ off, uint8_t *__restrict__ tip)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v >= V)
 		return;
 	bool le = off[2 * v + 1] == off[2 * v], re = off[2 * v + 2] == off[2 * v + 1];
@@ -102,7 +102,7 @@ __global__ void k_infer_tips(uint32_t V, const uint32_t *__restrict__ off, uint8
 }
 __global__ void k_check_tips(uint32_t V, const uint8_t *__restrict__ tip, uint32_t *__restrict__ bad)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v < V && tip[v] > 2)
 		atomicMin(bad, v);
 }
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 	__shared__ uint32_t par[UF_TILE];
 	__shared__ uint32_t heavy[UF_HEAVY_CAP];
 	__shared__ uint32_t n_heavy;
-	const uint32_t v0 = blockIdx.x * UF_TILE, v1 = min(V, v0 + UF_TILE);
+	const uint32_t v0 = BIDX * UF_TILE, v1 = min(V, v0 + UF_TILE);
 	for (uint32_t i = threadIdx.x; i < UF_TILE; i += blockDim.x)
 		par[i] = i;
 	if (threadIdx.x == 0)
@@ -270,7 +270,7 @@ __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__r
 			   uint8_t *__restrict__ hook)
 {
 	const uint32_t NX = *xcount;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NX; i += gridDim.x * blockDim.x) {
+	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < NX; i += gridDim.x * blockDim.x) {
 		const uint2 x = xlist[i];
 		uint32_t ra = uf_find(parent, x.x), rb = uf_find(parent, aoth[x.y] >> 1);
 		while (ra != rb) {
@@ -289,14 +289,14 @@ __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__r
 __global__ void k_compact_pos(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 			      uint32_t *__restrict__ out)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i < n && flag[i])
 		out[ps[i]] = i;
 }
 
 __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__ is_root, uint32_t *__restrict__ unsorted)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v == 0)
 		*unsorted = 0; // (k_labels_sorted, the next launch, raises it)
 	if (v >= V)
@@ -317,7 +317,7 @@ __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__
 // written chromosome by chromosome, and then the stable sort of the vertices by component is the identity.
 __global__ void k_labels_sorted(uint32_t V, const uint32_t *__restrict__ label, uint32_t *__restrict__ unsorted)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v > 0 && v < V && label[v] < label[v - 1])
 		*unsorted = 1; // (same value from every writer)
 }
@@ -326,7 +326,7 @@ __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const 
 			  uint32_t *__restrict__ comp_of, uint32_t *__restrict__ iota, uint32_t C,
 			  unsigned long long *__restrict__ start_key)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v >= V)
 		return;
 	comp_of[v] = crank[label[v]];
@@ -349,7 +349,7 @@ __global__ void k_sorted_vertices(uint32_t V, uint32_t C, const uint32_t *__rest
 				  uint32_t *__restrict__ gid_s, uint8_t *__restrict__ tip_s,
 				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i >= V)
 		return;
 	if (i < 4)
@@ -377,7 +377,7 @@ __global__ void k_first_slot(uint32_t V, const uint32_t *__restrict__ perm, cons
 			     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ sbase,
 			     uint32_t *__restrict__ first)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x; // sorted side id
+	uint32_t S = BIDX * blockDim.x + threadIdx.x; // sorted side id
 	if (S >= 2 * V)
 		return;
 	uint32_t i = S >> 1, s = S & 1, v = perm[i];
@@ -390,7 +390,7 @@ __global__ void k_mark_first(uint32_t V, const uint32_t *__restrict__ perm, cons
 			     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ sbase,
 			     const uint32_t *__restrict__ first, uint32_t *__restrict__ flag)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
 		return;
 	uint32_t i = S >> 1, s = S & 1, v = perm[i];
@@ -410,7 +410,7 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 			      uint32_t *__restrict__ ldeg, const uint8_t *__restrict__ hook, uint32_t *__restrict__ la,
 			      uint32_t *__restrict__ lb, uint8_t *__restrict__ tgray)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
 		return;
 	uint32_t i = S >> 1, s = S & 1, v = perm[i];
@@ -460,7 +460,7 @@ __global__ void k_local_degree(uint32_t V, const uint32_t *__restrict__ perm, co
 			       const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth, uint8_t *__restrict__ ldeg,
 			       uint32_t *__restrict__ stats)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	uint32_t cnt = 0;
 	if (S < 2 * V) {
 		uint32_t i = S >> 1, s = S & 1, v = perm ? perm[i] : i;
@@ -507,7 +507,7 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ loff,
 			    const uint8_t *__restrict__ hook, uint32_t *ladj, uint32_t *lle)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
 		return;
 	uint32_t i = S >> 1, s = S & 1, v = perm ? perm[i] : i;
@@ -591,7 +591,7 @@ __global__ void k_local_slots(uint32_t n, const uint32_t *__restrict__ origin, c
 			      const uint32_t *__restrict__ lb, const uint8_t *__restrict__ tgray, uint32_t *__restrict__ ladj,
 			      uint32_t *__restrict__ lle)
 {
-	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t k = BIDX * blockDim.x + threadIdx.x;
 	if (k >= n)
 		return;
 	uint32_t o = origin[k], le = o >> 1;
@@ -603,7 +603,7 @@ __global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *
 {
 	__shared__ uint32_t sh[4];
 	uint32_t m = 0;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 		m = max(m, v[i]);
 	for (int off = 32; off; off >>= 1)
 		m = max(m, __shfl_down(m, off));
@@ -625,7 +625,7 @@ __global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ vof
 				    uint32_t *__restrict__ eoff, const uint32_t *__restrict__ stats,
 				    uint32_t *__restrict__ host_pub)
 {
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t c = BIDX * blockDim.x + threadIdx.x;
 	if (c > C)
 		return;
 	const uint32_t vo = voff[c], eo = loff[2 * vo] / 2;
@@ -640,14 +640,14 @@ __global__ void k_comp_edge_offsets(uint32_t C, const uint32_t *__restrict__ vof
 
 __global__ void k_fill_u32(size_t n, uint32_t *p, uint32_t val)
 {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	size_t i = (size_t)BIDX * blockDim.x + threadIdx.x;
 	if (i < n)
 		p[i] = val;
 }
 
 __global__ void k_mark_odd(size_t n, uint32_t *p)
 {
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	size_t i = (size_t)BIDX * blockDim.x + threadIdx.x;
 	if (i < n && (i & 1))
 		p[i] = 1u;
 }

@@ -42,7 +42,7 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 __global__ void k_tcomp_vertices(uint32_t V, uint32_t T, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ voff,
 				 uint32_t *__restrict__ t_comp)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i >= V)
 		return;
 	uint32_t c = ckey[i];
@@ -60,7 +60,7 @@ __global__ void k_globalize(uint32_t T, const uint32_t *__restrict__ t_comp, con
 			    const uint32_t *__restrict__ depth, uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
 			    uint32_t *__restrict__ srccnt)
 {
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t t = BIDX * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	srccnt[t] = 0; // brackets per source, [T+2]
@@ -100,7 +100,7 @@ __global__ void k_dense_be(uint32_t NB0, uint32_t C, const uint32_t *__restrict_
 			   const uint32_t *__restrict__ eoff, const uint32_t *__restrict__ be_src,
 			   const uint32_t *__restrict__ be_tgt, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt)
 {
-	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t j = BIDX * blockDim.x + threadIdx.x;
 	if (j >= NB0)
 		return;
 	uint32_t lo = 0, hi = C; // last c with dbo[c] <= j
@@ -125,7 +125,7 @@ __global__ void k_dense_be(uint32_t NB0, uint32_t C, const uint32_t *__restrict_
 __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
 		      uint32_t *__restrict__ hi0, uint32_t *__restrict__ cov, uint32_t *__restrict__ incnt)
 {
-	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t j = BIDX * blockDim.x + threadIdx.x;
 	if (j >= NB0)
 		return;
 	const uint32_t sv = b_src[j], tv = b_tgt[j];
@@ -142,7 +142,7 @@ __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const ui
 __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
 			       const uint32_t *__restrict__ pscov, uint8_t *__restrict__ bridge)
 {
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t t = BIDX * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	const uint32_t sz = gsize[t];
@@ -238,7 +238,7 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
 			  uint8_t *__restrict__ capf, uint8_t *__restrict__ branching)
 {
-	uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t t = BIDX * blockDim.x + threadIdx.x;
 	if (t >= T)
 		return;
 	uint32_t sz = gsize[t];
@@ -256,7 +256,7 @@ __global__ void k_capping(const uint32_t *__restrict__ n_list, const uint32_t *_
 			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, uint32_t *__restrict__ literal_rule_seen)
 {
 	const uint32_t n = *n_list; // (the count only exists on the device: grid-stride)
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
 		capping_of(list[i], gsize, hi0, psb, root_of, segA, cap_tgt, capf, literal_rule_seen);
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0,
 							uint32_t *__restrict__ srccnt)
 {
 	__shared__ uint32_t wc[TPB / 64], ws[TPB / 64];
-	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	const bool live = v < T;
 	const uint32_t c = live ? capf[v] : 0u, sm = live ? simp[v] : 0u;
 	// rank among the flagged vertices: the tiles before (scanned counts) + the waves before + the lanes before
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0,
 		return;
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	if (c) {
-		uint32_t r = tcap[blockIdx.x] + (uint32_t)__popcll(mc & lt);
+		uint32_t r = tcap[v / TPB] + (uint32_t)__popcll(mc & lt);
 		for (uint32_t w = 0; w < wave; w++)
 			r += wc[w];
 		const uint32_t j = NB0 + r;
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0,
 			atomicAdd(&incnt[cap_tgt[v]], 1u);
 	}
 	if (sm) {
-		uint32_t r = tsimp[blockIdx.x] + (uint32_t)__popcll(ms & lt);
+		uint32_t r = tsimp[v / TPB] + (uint32_t)__popcll(ms & lt);
 		for (uint32_t w = 0; w < wave; w++)
 			r += ws[w];
 		const uint32_t j = NB0 + ncap + r;
@@ -354,7 +354,7 @@ __global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32
 				uint32_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t *__restrict__ incnt,
 				uint32_t *__restrict__ srccnt)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q >= NB)
 		return;
 	uint32_t j;
@@ -379,7 +379,7 @@ __global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const 
 				const uint8_t *__restrict__ capf, const uint8_t *__restrict__ simp,
 				uint32_t *__restrict__ tgtR, uint32_t *__restrict__ rid)
 {
-	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t j = BIDX * blockDim.x + threadIdx.x;
 	if (j >= NB)
 		return;
 	const uint32_t v = b_src[j];
@@ -397,7 +397,7 @@ __global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const 
 __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src,
 			     uint32_t *__restrict__ dst)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i < n)
 		dst[i] = src[idx[i]];
 }
@@ -423,7 +423,7 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 			      uint32_t first_simp_id, uint8_t *__restrict__ hpf, const uint32_t *__restrict__ seg_comp,
 			      const uint32_t *__restrict__ c_ntree, const StackPlace sp)
 {
-	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q >= n)
 		return;
 	uint32_t v = n - 1 - q, c = 0;
@@ -496,7 +496,7 @@ __global__ void k_class_flags(uint32_t n, uint32_t V, const uint32_t *__restrict
 			      const uint32_t *__restrict__ lsz, const uint8_t *__restrict__ tf, uint8_t *__restrict__ flag,
 			      uint32_t *__restrict__ dlt, uint32_t *__restrict__ mark)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (!BLACK && q < V + 2)
 		dlt[q] = 0; // row E's difference array, [V+2] (launched with max(n, V + 2) threads; BLACK: row E ran already)
 	if (q >= n)
@@ -518,7 +518,7 @@ __global__ void k_class_scatter(uint32_t n, const uint32_t *__restrict__ skey, c
 				const uint8_t *__restrict__ flag, const uint32_t *__restrict__ ps,
 				uint32_t *__restrict__ gcls)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q >= n)
 		return;
 	const uint32_t cls = skey[q] == NIL ? NIL : ps[q] + flag[q] - 1; // inclusive scan - 1
@@ -535,7 +535,7 @@ __global__ void k_class_scatter(uint32_t n, const uint32_t *__restrict__ skey, c
 __global__ void k_shift_delta(uint32_t V, const uint32_t *__restrict__ seg_comp, const uint32_t *__restrict__ c_ntree,
 			      const uint32_t *__restrict__ gsize, uint32_t *__restrict__ dlt)
 {
-	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t g = BIDX * blockDim.x + threadIdx.x;
 	if (g >= V)
 		return;
 	const uint32_t c = seg_comp[g], b = 2 * g + c + (c_ntree[c] & 1u) + 1, sb = gsize[b];
@@ -557,7 +557,7 @@ __global__ void k_stack_emit(uint32_t V, const uint32_t *__restrict__ seg_comp, 
 			     uint32_t *__restrict__ s_vtx, uint32_t *__restrict__ s_cls, uint32_t *__restrict__ s_comp,
 			     uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
 {
-	uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t g = BIDX * blockDim.x + threadIdx.x;
 	if (g >= V)
 		return;
 	const uint32_t c = seg_comp[g], b = 2 * g + c + (c_ntree[c] & 1u) + 1;
@@ -580,7 +580,7 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 				 const uint32_t *__restrict__ sval, const uint32_t *__restrict__ gcls,
 				 const uint32_t *__restrict__ sidx, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q >= T || !mark[q])
 		return;
 	const uint32_t p = lastb[q]; // 1 + position of the previous black entry of the sorted order
@@ -602,7 +602,7 @@ __global__ void k_class_finish_black(uint32_t n, uint32_t S, const uint32_t *__r
 				     const uint8_t *__restrict__ fresh, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev,
 				     uint8_t *__restrict__ dflag)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q == 0)
 		dflag[S] = 0;
 	if (q >= n || skey[q] == NIL)
@@ -617,7 +617,7 @@ __global__ void k_class_finish_black(uint32_t n, uint32_t S, const uint32_t *__r
 __global__ void k_class_ids_black(uint32_t n, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 				  const uint8_t *__restrict__ fresh, const uint32_t *__restrict__ ps, uint32_t *__restrict__ s_cls)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q < n && skey[q] != NIL)
 		s_cls[sval[q]] = ps[q] + fresh[q] - 1; // inclusive scan - 1
 }
@@ -625,7 +625,7 @@ __global__ void k_class_ids_black(uint32_t n, const uint32_t *__restrict__ skey,
 __global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx, const uint32_t *__restrict__ s_cls,
 				 uint32_t *__restrict__ gcls)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i < S)
 		gcls[s_vtx[i]] = s_cls[i];
 }
@@ -647,7 +647,7 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint32_t *__restrict__ comp_bad,
 			       const uint8_t *__restrict__ dflag, uint32_t *__restrict__ walk)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i >= S)
 		return;
 	const uint32_t p = prev[i];
@@ -677,7 +677,7 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const uint32_t *__restrict__ ps,
 			    uint32_t *__restrict__ out, uint32_t *__restrict__ neg)
 {
-	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t k = BIDX * blockDim.x + threadIdx.x;
 	if (k < n) {
 		const uint32_t w = ps[k] + walk[k] + 0x80000000u;
 		out[k] = w;
@@ -687,7 +687,7 @@ __global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const
 // entry i opens a flubble iff its class comes back later than at the next entry (flubbles.cpp:344)
 __global__ void k_dflag(uint32_t S, const uint32_t *__restrict__ ns, uint8_t *__restrict__ dflag)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i < S)
 		dflag[i] = (i + 1 < ns[i]) ? 1 : 0;
 	if (i == S)
@@ -703,7 +703,7 @@ __global__ void k_emit_endpoints(uint32_t S, const uint8_t *__restrict__ dflag, 
 				 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
 				 uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
 {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
 		if (!dflag[i])
 			continue;
 		// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
@@ -729,7 +729,7 @@ __global__ void k_levels(uint32_t S, const uint8_t *__restrict__ dflag, const ui
 			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ negmax,
 			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i >= S || !dflag[i])
 		return;
 	const uint32_t c = s_comp[i], i0 = soff[c];
@@ -747,7 +747,7 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 			    const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
 			    const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_parent)
 {
-	uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t j = BIDX * blockDim.x + threadIdx.x;
 	if (j >= NE)
 		return;
 	uint32_t i = e_i[j], c = s_comp[i], jb = erank[soff[c]];
@@ -762,7 +762,7 @@ __global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, cons
 			     uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor, uint32_t *__restrict__ c_npvst,
 			     uint32_t *__restrict__ c_nstack)
 {
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t c = BIDX * blockDim.x + threadIdx.x;
 	if (c > C)
 		return;
 	(void)voff;
@@ -787,7 +787,7 @@ __global__ void k_export_stack(uint32_t S, const uint32_t *__restrict__ s_comp, 
 			       const uint32_t *__restrict__ s_cls, const uint32_t *__restrict__ ns,
 			       uint32_t *__restrict__ o_vtx, uint32_t *__restrict__ o_cls, uint32_t *__restrict__ o_ns)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i >= S)
 		return;
 	uint32_t c = s_comp[i], l = i - soff[c], base = 2 * voff[c] + c;
@@ -804,7 +804,7 @@ __global__ void k_hp_inputs(uint32_t T, const uint32_t *__restrict__ gsize, cons
 			    const uint8_t *__restrict__ hpf, uint32_t *__restrict__ a_simp, uint32_t *__restrict__ a_q,
 			    uint32_t *__restrict__ a_close)
 {
-	uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t v = BIDX * blockDim.x + threadIdx.x;
 	if (v >= T)
 		return;
 	const uint32_t sz = gsize[v];
@@ -820,7 +820,7 @@ __global__ void k_hp_close(uint32_t T, const uint32_t *__restrict__ gsize, const
 			   const SegTree s1, const SegTree s2, const SegTree s3, uint8_t *__restrict__ push,
 			   unsigned long long *__restrict__ b12)
 {
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t c = BIDX * blockDim.x + threadIdx.x;
 	if (c >= T)
 		return;
 	push[c] = 0;
@@ -847,7 +847,7 @@ __global__ void k_hp_emit(uint32_t T, const uint8_t *__restrict__ push, const ui
 			  const unsigned long long *__restrict__ b12, unsigned long long *__restrict__ out,
 			  uint32_t *__restrict__ c_nbry)
 {
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t c = BIDX * blockDim.x + threadIdx.x;
 	if (c >= T)
 		return;
 	const uint32_t ci = t_comp[c];
@@ -948,7 +948,7 @@ __global__ void k_summary(uint32_t C, const uint32_t *__restrict__ err, const ui
 			  const uint32_t *__restrict__ status, const uint32_t *__restrict__ npvst,
 			  const uint32_t *__restrict__ nbry, const uint32_t *__restrict__ doff, uint32_t *__restrict__ out)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i > C)
 		return;
 	if (i == 0) {

@@ -408,10 +408,11 @@ __global__ void __launch_bounds__(CP_TPB) k_cp_count(const uint8_t *__restrict__
 {
 	__shared__ uint32_t sh[CP_TPB / 64];
 	uint32_t bits, total;
-	const uint32_t c = cp_load16(flag, (size_t)blockIdx.x * CP_TILE + (size_t)threadIdx.x * CP_ITEMS, n, bits);
+	const uint32_t bx = BIDX;
+	const uint32_t c = cp_load16(flag, (size_t)bx * CP_TILE + (size_t)threadIdx.x * CP_ITEMS, n, bits);
 	(void)cp_block_exclusive(c, sh, total);
 	if (threadIdx.x == 0)
-		tile_cnt[blockIdx.x] = total;
+		tile_cnt[bx] = total;
 }
 // exclusive scan of the tile counts in place, one workgroup (a few ten thousand tiles); *count_out = the grand total
 __global__ void __launch_bounds__(1024) k_cp_scan_tiles(uint32_t *tile_cnt, uint32_t ntiles, uint32_t *__restrict__ count_out)
@@ -449,10 +450,11 @@ __global__ void __launch_bounds__(CP_TPB) k_cp_write(const uint8_t *__restrict__
 						      uint32_t *__restrict__ out)
 {
 	__shared__ uint32_t sh[CP_TPB / 64];
-	const size_t e0 = (size_t)blockIdx.x * CP_TILE + (size_t)threadIdx.x * CP_ITEMS;
+	const uint32_t bx = BIDX;
+	const size_t e0 = (size_t)bx * CP_TILE + (size_t)threadIdx.x * CP_ITEMS;
 	uint32_t bits, total;
 	const uint32_t c = cp_load16(flag, e0, n, bits);
-	uint32_t at = tile_base[blockIdx.x] + cp_block_exclusive(c, sh, total);
+	uint32_t at = tile_base[bx] + cp_block_exclusive(c, sh, total);
 	while (bits) {
 		const int k = __ffs((int)bits) - 1;
 		bits &= bits - 1;
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(RS_TPB) k_rs_hist(const uint32_t *__restrict__
 	for (uint32_t d = threadIdx.x; d < bins; d += RS_TPB)
 		h[d] = 0;
 	__syncthreads();
-	const uint32_t base = blockIdx.x * RS_TILE;
+	const uint32_t bx = BIDX, base = bx * RS_TILE;
 #pragma unroll 4
 	for (int r = 0; r < RS_ITEMS; r++) {
 		const uint32_t i = base + r * RS_TPB + threadIdx.x;
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(RS_TPB) k_rs_hist(const uint32_t *__restrict__
 	}
 	__syncthreads();
 	for (uint32_t d = threadIdx.x; d < bins; d += RS_TPB)
-		hist[(size_t)d * ntiles + blockIdx.x] = h[d];
+		hist[(size_t)d * ntiles + bx] = h[d];
 }
 
 __global__ void __launch_bounds__(RS_TPB) k_rs_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
@@ -537,7 +539,7 @@ __global__ void __launch_bounds__(RS_TPB) k_rs_scatter(const uint32_t *__restric
 	for (uint32_t k = 0; k < RS_WAVES; k++)
 		for (uint32_t d = threadIdx.x; d < bins; d += RS_TPB)
 			sh.c.wcnt[k][d] = 0;
-	const uint32_t base = blockIdx.x * RS_TILE, wbase = base + wave * (RS_ITEMS * 64);
+	const uint32_t bx = BIDX, base = bx * RS_TILE, wbase = base + wave * (RS_ITEMS * 64);
 	uint32_t key[RS_ITEMS], val[RS_ITEMS], pos[RS_ITEMS];
 #pragma unroll
 	for (int r = 0; r < RS_ITEMS; r++) {
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(RS_TPB) k_rs_scatter(const uint32_t *__restric
 		if (d < bins) {
 			const uint32_t c = sh.c.bbase[d];
 			sh.c.bbase[d] = before;
-			gof[d] = gofs[(size_t)d * ntiles + blockIdx.x] - before;
+			gof[d] = gofs[(size_t)d * ntiles + bx] - before;
 			before += c;
 		}
 	}

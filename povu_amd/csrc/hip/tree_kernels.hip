@@ -127,7 +127,7 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 			     const uint32_t *__restrict__ lle, uint32_t *__restrict__ pk, unsigned b,
 			     ulonglong2 *__restrict__ hside, uint32_t *__restrict__ ft, uint32_t *__restrict__ twin)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	const uint32_t lo = loff[S], hi = loff[S + 1];
@@ -172,7 +172,7 @@ __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const
 			    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ lle,
 			    uint32_t *__restrict__ pk, uint32_t *__restrict__ heads)
 {
-	uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t c = BIDX * blockDim.x + threadIdx.x;
 	if (c >= C)
 		return;
 	const uint32_t r = comp_root_side(start_key, voff, c), sb = loff[r & ~1u], se = loff[(r & ~1u) + 2], mid = loff[r];
@@ -205,7 +205,7 @@ __global__ void k_wyllie(uint32_t n, const uint32_t *__restrict__ nxt_in, const 
 			 const uint32_t *__restrict__ b_in, uint32_t *__restrict__ nxt_out, uint32_t *__restrict__ a_out,
 			 uint32_t *__restrict__ b_out, const uint32_t *__restrict__ n_dev)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i >= n || (n_dev && i >= *n_dev))
 		return;
 	uint32_t nx = nxt_in[i], a = a_in[i], b = b_in ? b_in[i] : 0;
@@ -293,7 +293,7 @@ __global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restric
 			  const uint32_t *__restrict__ b_in, const uint32_t *__restrict__ heads, uint32_t *__restrict__ nx_out,
 			  uint32_t *__restrict__ a_out, uint32_t *__restrict__ b_out)
 {
-	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t id = BIDX * blockDim.x + threadIdx.x;
 	if (id >= A.M)
 		return;
 	uint32_t x = rank_lane_start<L0>(id, A, b, nx_in, heads);
@@ -332,7 +332,7 @@ __global__ void k_rank_down(RankLevelArgs A, unsigned b, const uint32_t *__restr
 			    const uint32_t *__restrict__ heads, const uint32_t *__restrict__ ra, const uint32_t *__restrict__ rb,
 			    uint32_t *__restrict__ out1, uint2 *__restrict__ out12)
 {
-	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t id = BIDX * blockDim.x + threadIdx.x;
 	if (id >= A.M)
 		return;
 	uint32_t x = rank_lane_start<L0>(id, A, b, nx_in, heads);
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(1024) k_rank_top(uint32_t n, const uint32_t *_
 // (top level too large for one workgroup -- graphs with very many tiny components: the old pointer jumping in global memory)
 __global__ void k_rank_unpack_next(uint32_t n, const uint32_t *__restrict__ nx_in, uint32_t *__restrict__ out)
 {
-	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t i = BIDX * blockDim.x + threadIdx.x;
 	if (i < n) {
 		const uint32_t p = nx_in[i] & PK_END;
 		out[i] = p == PK_END ? NIL : p;
@@ -531,7 +531,7 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, ulonglong2 *__restrict__ val, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S < C) { // the DFS start of component S roots its tree (no advance arc ever enters its segment)
 		const uint32_t r = comp_root_side(start_key, voff, S), L = 2 * (voff[S + 1] - voff[S] - 1);
 		t0seg[r >> 1] = make_uint4(NIL, (r & 1u) ? T0_RBIT : 0u, 0u, L ? L - 1 : 0u);
@@ -580,7 +580,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 			  const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
 			  uint32_t *__restrict__ pbr, uint8_t *multi, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	// multi[S] = 1: side S shares its 2-edge-connected class with another side, i.e. some tree edge at S is no bridge
@@ -661,7 +661,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 __global__ void k_entry_flags(uint32_t nS, const uint32_t *__restrict__ pbr, const uint8_t *__restrict__ multi,
 			      const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, uint8_t *__restrict__ entry_flag)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	// an entry: a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
@@ -698,7 +698,7 @@ __global__ void k_class_recs(uint32_t nS, const uint32_t *__restrict__ loff, con
 			     const uint32_t *__restrict__ cproc, uint32_t *__restrict__ wadj, uint4 *__restrict__ wrec,
 			     uint32_t *__restrict__ wpar)
 {
-	uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t u = BIDX * blockDim.x + threadIdx.x;
 	if (u >= nS)
 		return;
 	const uint32_t lo = loff[u], hi = loff[u + 1], base = lo + u; // deg + 1 slots per side
@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(const uint32_t *__restri
 	const uint32_t lane = threadIdx.x;
 	// grid-stride over the classes (entry_list is in side order): the lanes in flight work on one window of sides
 	const uint32_t n_entry = *n_entry_dev; // (the count only exists on the device: no read-back sizes this launch)
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
+	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < n_entry; i += gridDim.x * blockDim.x) {
 		const uint32_t s = entry_list[i];
 		const uint32_t s_up = cstate[s] & ~(CS_VISITED | PB_BRIDGE); // the entry's parent, across its bridge (root: all ones)
 		uint32_t u = s, k = 0, lo = loff[u], n = loff[u + 1] - lo, sides = 0, depth = 0;
@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 __global__ void k_walk_finish(uint32_t nS, const uint32_t *__restrict__ wpar, const uint32_t *__restrict__ pbr,
 			      const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj, uint2 *__restrict__ dps)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	const uint32_t p = wpar[S];
@@ -991,7 +991,7 @@ __global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps, const uint3
 			 const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc,
 			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b, uint8_t *__restrict__ merged)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x; // (nS is even and the workgroup size too: S and S ^ 1 are lanes of one wave)
+	uint32_t S = BIDX * blockDim.x + threadIdx.x; // (nS is even and the workgroup size too: S and S ^ 1 are lanes of one wave)
 	const bool live = S < nS;
 	const uint2 me = live ? dps[S] : make_uint2(NIL, 0u);
 	const uint32_t p = me.x;
@@ -1074,7 +1074,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 	// siblings', flubbles.cpp:586-588; with q(v) = mpre(v) + v + size(v) one gets q(child) = q(parent) + 1, hence
 	// mpre(v) = depth(v) + N - v - size(v) in local indices) and srccnt (brackets per mirror pre-order position, written for
 	// every vertex later: only the slots without a vertex are cleared here).  All of it is written right here.
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S == 0) {
 		const uint32_t T = 2 * (nS >> 1) + C;
 		hi0[T] = NIL;
@@ -1226,7 +1226,7 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 						     uint32_t *__restrict__ b_ord, const uint8_t *__restrict__ dupflag,
 						     uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0, uint32_t *__restrict__ incnt)
 {
-	const uint32_t S0 = blockIdx.x * BE_SIDES + threadIdx.x;
+	const uint32_t S0 = BIDX * BE_SIDES + threadIdx.x;
 	__shared__ uint32_t first2[BE_ITER][TPB][2]; // the first two targets of every side of the chunk
 	__shared__ uint8_t cnt8[BE_ITER][TPB];	     // min(its back edges, 255)
 	uint32_t n = 0;
@@ -1302,7 +1302,7 @@ __global__ void k_edge_id_weights(uint32_t nS, const uint32_t *__restrict__ loff
 				  const uint32_t *__restrict__ voff, const uint32_t *__restrict__ t_par,
 				  const uint8_t *__restrict__ dupflag, uint32_t *__restrict__ w, uint32_t *__restrict__ tail)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	const uint32_t p = side_tidx[S];
@@ -1360,7 +1360,7 @@ void debug_edge_id_weights(const CompState &cs, const SeqWs &sw, const TreeWs &t
 // the look-back is quadratic, so the flags come from a stable two-key radix sort of all slots instead.
 __global__ void k_slot_keys(uint32_t n, const uint32_t *__restrict__ ladj, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
 {
-	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t k = BIDX * blockDim.x + threadIdx.x;
 	if (k < n) {
 		key[k] = ladj[k];
 		val[k] = k;
@@ -1368,7 +1368,7 @@ __global__ void k_slot_keys(uint32_t n, const uint32_t *__restrict__ ladj, uint3
 }
 __global__ void k_slot_side(uint32_t nS, const uint32_t *__restrict__ loff, uint32_t *__restrict__ side_of)
 {
-	uint32_t S = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
 		return;
 	for (uint32_t k = loff[S]; k < loff[S + 1]; k++)
@@ -1376,14 +1376,14 @@ __global__ void k_slot_side(uint32_t nS, const uint32_t *__restrict__ loff, uint
 }
 __global__ void k_gather_keys(uint32_t n, const uint32_t *__restrict__ val, const uint32_t *__restrict__ src, uint32_t *__restrict__ key)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q < n)
 		key[q] = src[val[q]];
 }
 __global__ void k_dup_flags(uint32_t n, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 			    const uint32_t *__restrict__ ladj, uint8_t *__restrict__ dupflag)
 {
-	uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t q = BIDX * blockDim.x + threadIdx.x;
 	if (q >= n)
 		return;
 	// sorted by (side, far side), slots ascending inside equal pairs (both sorts are stable)

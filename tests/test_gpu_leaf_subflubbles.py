@@ -105,6 +105,35 @@ def test_hprc_shaped_chromosome(hip):
     assert f.texts() == O.decompose(g, leaf=True)
 
 
+def test_deep_nests(hip):
+    """BASELINE config 5's shape at a depth the reference's own bracket table still fits in memory (it materialises, per
+    back edge, every tree vertex the edge spans: tree_utils.cpp:169-216 -- quadratic in the depth; the HIP path's prefix
+    sums are not)."""
+    check(hip, W.nested_towers(300, 40), arrays=False)
+
+
+def test_config4_whole_genome_full_size(hip):
+    """BASELINE config 4 at full size with the two passes: md5 of every PVST text against the oracle (its components on
+    the host's cores), and what the extra stage costs."""
+    import hashlib
+    g = W.hprc_whole_genome(1e8)
+    cores = min(32, len(os.sched_getaffinity(0)))
+    want = {k: hashlib.md5(v.encode()).hexdigest() for k, v in O.decompose(g, threads=cores, lpt=True, leaf=True).items()}
+    hip.upload(g)
+    f = hip.decompose(flags=F_LEAF_SUBFLUBBLES)
+    assert hip.seq_redo_count() == 0
+    ms = {t["name"]: t["ms"] for t in hip.stage_times()}
+    got = {k: hashlib.md5(v.encode()).hexdigest() for k, v in f.texts().items()}
+    assert got == want and len(want) == 2024
+    letters = collections.Counter()
+    for i in range(0, len(f), 97):
+        letters.update(bytes(f.sub(i)[2]).decode())
+    print(f"leaf_subflubbles stage on config 4 at full size: {ms.get('leaf_subflubbles', -1):.2f} ms of {ms.get('total', -1):.2f}; "
+          f"letters of a sample of trees {dict(letters)}")
+    assert letters["T"] and letters["F"]
+    hip.upload(W.chain_of_bubbles(3))  # (frees the big graph for the tests that follow)
+
+
 def test_components_that_went_through_the_redo(hip, golden_dir):
     """A component whose add_flubbles went through the sequential redo (a candidate stack with a crossing pair,
     tests/golden/literal_hi2_crossing_stack.npz; one of the reference's own fixture graphs needs it too) has its PVST in
