@@ -5,19 +5,19 @@ import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import (F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_SPARSE_SPLITTERS,
-                          F_ALL_VERTEX_CLASSES, F_CHECK_LAMINAR)
+                          F_ALL_VERTEX_CLASSES, F_CHECK_LAMINAR, F_LEAF_SUBFLUBBLES)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
 hip = HipDecomposer(0)
 rng = np.random.default_rng(12345)
-t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0; n_redo = 0
+t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0; n_redo = 0; n_leaf = 0; n_leaf_redo = 0
 last = t0
 while time.time() - t0 < budget:
     if time.time() - last > 60:
         last = time.time(); print('...', n_graphs, 'graphs', flush=True)
     seed = int(rng.integers(1 << 30))
-    kind = n_graphs % 9
+    kind = n_graphs % 10
     if big:
         kind = 6 + n_graphs % 2
     if kind == 0:
@@ -30,6 +30,8 @@ while time.time() - t0 < budget:
         g = W.hprc_shaped([int(rng.integers(50, 3000)) for _ in range(int(rng.integers(1, 5)))], seed=seed, tiny=int(rng.integers(0, 20)))
     elif kind == 4:
         n = int(rng.integers(10, 200)); g = W.random_bidirected(n, int(n * rng.uniform(1.5, 4.0)), seed, self_loops=True, connected=True)
+    elif kind == 9:
+        g = W.bubble_zoo(int(rng.integers(1, 60)), int(rng.integers(1, 40)), seed)
     elif kind == 8:
         g = W.hprc_tangled(int(rng.integers(500, 20000)), seed=seed, tangle_every=int(rng.integers(200, 3000)), max_tangle=int(rng.integers(50, 3000)))
     elif kind == 6:
@@ -64,5 +66,21 @@ while time.time() - t0 < budget:
             np.savez('gpurun_out/fuzz_redo_exact.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
             sys.exit(2)
     n_black_only += int(hip.last_black_only_classes())
+    # the two relabelling passes of -s on top (the oracle materialises the reference's bracket table, quadratic on deep
+    # trees: small and mid-size graphs only)
+    if not big and kind in (0, 1, 3, 4, 5, 9) and g.n_vtx <= 6000 and n_graphs % 2 == 0:
+        want_leaf = O.decompose(g, tips=tips, leaf=True)
+        lf = F_LEAF_SUBFLUBBLES | [0, F_HAIRPINS, F_BIG_CLASS_DFS, F_CHECK_LAMINAR][(n_graphs // 2) % 4]
+        try:
+            got_leaf = hip.decompose(flags=lf).texts()
+        except RuntimeError as e:
+            if 'from scratch' not in str(e):  # (--hairpins + a component that needs the redo: refused by design)
+                raise
+            got_leaf = want_leaf
+        if got_leaf != want_leaf:
+            print('LEAF MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', lf, 'tips', tips is not None)
+            np.savez('gpurun_out/fuzz_leaf_fail.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
+            sys.exit(3)
+        n_leaf += 1; n_leaf_redo += int(hip.seq_redo_count() > 0)
     n_graphs += 1; n_links += g.n_links
-print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only;', n_redo, 'passes sent a component to the sequential redo (all of them with the literal hi_2 rule deviating)')
+print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only;', n_redo, 'passes sent a component to the sequential redo (all of them with the literal hi_2 rule deviating);', n_leaf, 'graphs also through the leaf subflubble passes (', n_leaf_redo, 'of them with a redone component)')
