@@ -289,6 +289,9 @@ int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t 
  * resident graph itself (~42 B/link + 13 B/segment) and the sequential kernels' lists; n_components = 0
  * assumes the worst case (every segment its own component); 0 when it cannot be computed */
 uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components);
+/* upper bound of the EXTRA device memory POVU_HIP_F_LEAF_SUBFLUBBLES takes while its stage runs (allocated and released
+ * inside the call; n_components = 0: not known) */
+uint64_t povu_hip_leaf_workspace_estimate(uint32_t n_vtx, uint32_t n_components);
 
 const char *povu_hip_version(void);
 

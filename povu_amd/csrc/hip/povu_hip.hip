@@ -398,6 +398,12 @@ extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links
 	}
 }
 
+extern "C" uint64_t povu_hip_leaf_workspace_estimate(uint32_t n_vtx, uint32_t n_components)
+{
+	// the PVST of a component has at most one vertex per segment and a root
+	return leaf_workspace_bytes(n_vtx, n_components ? n_components : n_vtx, (size_t)n_vtx + (n_components ? n_components : n_vtx));
+}
+
 extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip_opts *opts, char *err, size_t errlen)
 {
 	// declared outside the try block: on a failure the stream is drained BEFORE the forest returns its pinned

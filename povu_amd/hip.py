@@ -121,6 +121,8 @@ def load_lib():
                                       C.c_size_t]
     l.povu_hip_workspace_estimate.restype = C.c_uint64
     l.povu_hip_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    l.povu_hip_leaf_workspace_estimate.restype = C.c_uint64
+    l.povu_hip_leaf_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32]
     # ---- multi-GPU sharding
     l.povu_hip_lpt_assign.restype = C.c_int
     l.povu_hip_lpt_assign.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
