@@ -219,7 +219,9 @@ void scan_exclusive_u8(const uint8_t *in0, uint32_t *out0, size_t n0, const uint
 void scan_exclusive_diff_u32(const uint32_t *in, const uint32_t *sub, uint32_t *out, size_t n, void *tmp, size_t tmp_bytes,
 			     hipStream_t s);
 // exclusive running xor of 128-bit words (two independent 64-bit hashes side by side)
-void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s);
+// (n_dev, device memory, optional: only the first *n_dev + 1 words exist -- n then is the most there can be and sizes the launch)
+void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s,
+			     const uint32_t *n_dev = nullptr);
 size_t scan_tmp_bytes(size_t n);
 // indices of the non-zero bytes of flag[0..n), ascending, into out; their number into *count_dev (device memory).  No
 // prefix array is written: tiles are counted, the counts scanned, the tiles ranked again.

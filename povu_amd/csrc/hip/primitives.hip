@@ -274,7 +274,15 @@ struct Xor128Job {
 	size_t n, chunk;
 	uint32_t blocks;
 	ulonglong2 *partial;
+	const uint32_t *n_dev; // optional: only the first *n_dev + 1 words exist (n is then the most there can be)
 };
+__device__ __forceinline__ size_t x128_len(const Xor128Job &J)
+{
+	if (!J.n_dev)
+		return J.n;
+	const size_t m = (size_t)*J.n_dev + 1;
+	return m < J.n ? m : J.n;
+}
 __device__ __forceinline__ ulonglong2 x128(const ulonglong2 a, const ulonglong2 b) { return make_ulonglong2(a.x ^ b.x, a.y ^ b.y); }
 __device__ __forceinline__ ulonglong2 x128_shfl_down(const ulonglong2 v, int off) { return make_ulonglong2(__shfl_down(v.x, off), __shfl_down(v.y, off)); }
 __device__ __forceinline__ ulonglong2 x128_shfl_up(const ulonglong2 v, int off) { return make_ulonglong2(__shfl_up(v.x, off), __shfl_up(v.y, off)); }
@@ -292,7 +300,8 @@ __device__ __forceinline__ ulonglong2 x128_block_reduce(ulonglong2 v, ulonglong2
 __global__ void __launch_bounds__(SC_TPB) k_xor128_partials(const Xor128Job J)
 {
 	__shared__ ulonglong2 sh[4];
-	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < J.n ? b0 + J.chunk : J.n;
+	const size_t n = x128_len(J);
+	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < n ? b0 + J.chunk : n;
 	ulonglong2 acc = make_ulonglong2(0ull, 0ull);
 	for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
 		acc = x128(acc, J.in[i]);
@@ -307,7 +316,8 @@ __global__ void __launch_bounds__(SC_TPB) k_xor128_chunks(const Xor128Job J)
 	for (uint32_t k = threadIdx.x; k < blockIdx.x; k += SC_TPB)
 		base = x128(base, J.partial[k]);
 	ulonglong2 carry = x128_block_reduce(base, sh);
-	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < J.n ? b0 + J.chunk : J.n;
+	const size_t n = x128_len(J);
+	const size_t b0 = (size_t)blockIdx.x * J.chunk, b1 = b0 + J.chunk < n ? b0 + J.chunk : n;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	for (size_t t0 = b0; t0 < b1; t0 += X128_TILE) {
 		const size_t e0 = t0 + (size_t)threadIdx.x * X128_ITEMS;
@@ -343,7 +353,8 @@ __global__ void __launch_bounds__(SC_TPB) k_xor128_chunks(const Xor128Job J)
 		__syncthreads();
 	}
 }
-void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s)
+void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, void *tmp, size_t tmp_bytes, hipStream_t s,
+			     const uint32_t *n_dev)
 {
 	if (n == 0)
 		return;
@@ -355,7 +366,7 @@ void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, vo
 	size_t chunk = (n + blocks - 1) / blocks;
 	chunk = (chunk + X128_TILE - 1) / X128_TILE * X128_TILE;
 	blocks = (n + chunk - 1) / chunk;
-	const Xor128Job J{in, out, n, chunk, (uint32_t)blocks, static_cast<ulonglong2 *>(tmp)};
+	const Xor128Job J{in, out, n, chunk, (uint32_t)blocks, static_cast<ulonglong2 *>(tmp), n_dev};
 	KLAUNCH(k_xor128_partials, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
 	KLAUNCH(k_xor128_chunks, dim3((unsigned)blocks), dim3(SC_TPB), 0, s, J);
 }

@@ -527,8 +527,8 @@ static constexpr uint32_t T0_RBIT = 0x80000000u;
 __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle,
-			     const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
-			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, ulonglong2 *__restrict__ val, uint32_t C,
+			     const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
+			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, uint4 *__restrict__ xrec, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
 	uint32_t S = BIDX * blockDim.x + threadIdx.x;
@@ -556,15 +556,51 @@ __global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, con
 		const bool down = da > dt;					      // `at` comes first: S is the parent of w
 		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
 		t0seg[child >> 1] = make_uint4(parent, le | ((child & 1u) ? T0_RBIT : 0u), p_in, p_out); // ONE scattered 16-byte store
-		// (val was cleared by the caller: most segments have no non-tree link, and a scattered 8-byte store costs a sector)
+		// Most segments have no non-tree link, so the values are kept COMPACT (in tour order, only where a side carries
+		// one): here only the bit of the tour position is set; k_tour_values drops the value at its rank among the set bits.
 		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + (child & ~1u)); // both sides of the child's segment
-		if ((f2.x | f2.y) & FT_HASH) {
-			const ulonglong2 z = make_ulonglong2(0ull, 0ull);
-			const ulonglong2 h = hx((f2.x & FT_HASH) ? hside[child & ~1u] : z, (f2.y & FT_HASH) ? hside[child | 1u] : z);
-			if (!hzero(h))
-				val[p_in] = h;
-		}
+		if ((f2.x | f2.y) & FT_HASH)
+			atomicOr(reinterpret_cast<unsigned long long *>(&xrec[p_in >> 6]), 1ull << (p_in & 63u));
 	}
+}
+// The running xor is only ever read at tour positions, but only the positions of segments with non-tree links carry a
+// value (about one in six of a pangenome graph): the values sit compact, in tour order, behind a bitmap of the positions
+// (25 MB for 2e8 positions: cache resident) with the count of set bits in front of every word.
+//   rank(p)  = set bits at positions < p;   running xor in front of position p = xps[rank(p)]
+__global__ void k_bit_counts(uint32_t W, const uint4 *__restrict__ xrec, uint32_t *__restrict__ xrank)
+{
+	uint32_t w = BIDX * blockDim.x + threadIdx.x;
+	if (w <= W)
+		xrank[w] = w < W ? (uint32_t)(__popc(xrec[w].x) + __popc(xrec[w].y)) : 0u;
+}
+__global__ void k_bit_ranks(uint32_t W, const uint32_t *__restrict__ xrank, uint4 *__restrict__ xrec)
+{
+	uint32_t w = BIDX * blockDim.x + threadIdx.x;
+	if (w < W)
+		xrec[w].z = xrank[w];
+}
+// (one 16-byte load: the word of the bitmap and the count in front of it sit together)
+__device__ __forceinline__ uint32_t tour_rank(const uint4 *__restrict__ xrec, uint32_t p)
+{
+	const uint4 r = xrec[p >> 6];
+	const unsigned long long bits = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
+	return r.z + (uint32_t)__popcll(bits & ((1ull << (p & 63u)) - 1ull));
+}
+// one lane per segment (all reads in segment order): the value of a segment whose position bit is set
+__global__ void k_tour_values(uint32_t V, const uint4 *__restrict__ t0seg, const uint32_t *__restrict__ ft,
+			      const ulonglong2 *__restrict__ hside, const uint4 *__restrict__ xrec, ulonglong2 *__restrict__ xval)
+{
+	uint32_t g = BIDX * blockDim.x + threadIdx.x;
+	if (g >= V)
+		return;
+	const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
+	if (!((f2.x | f2.y) & FT_HASH))
+		return;
+	const uint4 r = t0seg[g];
+	if (r.x == NIL) // a root is entered by no arc: its value is in no stretch
+		return;
+	const ulonglong2 z = make_ulonglong2(0ull, 0ull);
+	xval[tour_rank(xrec, r.z)] = hx((f2.x & FT_HASH) ? hside[2 * g] : z, (f2.y & FT_HASH) ? hside[2 * g + 1] : z);
 }
 // pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
 static constexpr uint32_t PB_BRIDGE = 0x80000000u;
@@ -574,7 +610,8 @@ static constexpr uint32_t PB_BRIDGE = 0x80000000u;
 // reaches first --, its DFS record dps = {parent across the bridge, scan slot of the parent it is found through}.
 static constexpr uint32_t CLASS_BUDGET = 256;  // sides a lane walks before it hands its class to the big-class walk
 static constexpr uint32_t CS_VISITED = 0x40000000u; // (side ids stay below 2^29, bit 31 is PB_BRIDGE)
-__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ulonglong2 *__restrict__ px,
+__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ulonglong2 *__restrict__ xps,
+			  const uint4 *__restrict__ xrec,
 			  const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft,
 			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
 			  const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
@@ -586,6 +623,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 	// multi[S] = 1: side S shares its 2-edge-connected class with another side, i.e. some tree edge at S is no bridge
 	// (cleared by the caller).  Most sides of a pangenome graph sit on bridges only and are classes of their own; those
 	// need no walk at all.
+	auto px = [&](uint32_t p) { return xps[tour_rank(xrec, p)]; }; // running xor in front of tour position p
 	const uint4 r = t0seg[S >> 1];
 	const uint32_t entered = (S & ~1u) | (r.y >> 31), c = ckey[S >> 1];
 	const bool proc = cproc[c] != 0; // (components that are not decomposed here get inert words)
@@ -593,7 +631,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 	if (S == entered) {
 		if (r.x == NIL) {
 			pv = NIL;
-		} else if (heq(px[r.z], px[r.w + 1])) {
+		} else if (heq(px(r.z), px(r.w + 1))) {
 			pv = r.x | PB_BRIDGE;
 		} else {
 			pv = r.x;
@@ -614,7 +652,7 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 				end = abase + (L - 1 - dist[a3]);
 			else
 				end = r.w;
-			x = hx(x, hx(px[abase + (L - 1 - dist[a1])], px[end]));
+			x = hx(x, hx(px(abase + (L - 1 - dist[a1])), px(end)));
 		}
 		if (hzero(x)) {
 			pv = entered | PB_BRIDGE;
@@ -1401,6 +1439,8 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&tw.dist, NSL * 4);
 	take((void **)&tw.xval, (NA + 2) * 16);
 	take((void **)&tw.xps, (NA + 2) * 16);
+	take((void **)&tw.xrec, (NA / 64 + 4) * 16);
+	take((void **)&tw.xrank, (NA / 64 + 4) * 4);
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0seg, (V + 2) * 16);
 	for (uint32_t **p : {&tw.pbr,
@@ -1458,19 +1498,25 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	if (n_slots)
 		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
 	const uint32_t *dist = tw.dist;
-	ulonglong2 *val = tw.xval, *px = tw.xps; // [NA+1] each
-	HIP_CHECK(hipMemsetAsync(val, 0, ((size_t)NA + 1) * 16, s));
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, hside, ft, rb.heads,
-	       twin, tw.t0seg, val, C, start_key, pw.err + 2);
+	const uint32_t XW = NA / 64 + 1; // words of the position bitmap
+	HIP_CHECK(hipMemsetAsync(tw.xrec, 0, ((size_t)XW + 2) * 16, s));
+	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, ft, rb.heads,
+	       twin, tw.t0seg, tw.xrec, C, start_key, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
 	tm.begin("tree_bridges_classes");
-	scan_exclusive_xor_u128(val, px, (size_t)NA + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	LAUNCH(k_bit_counts, (size_t)XW + 1, s, XW, tw.xrec, tw.xrank);
+	scan_exclusive_u32(tw.xrank, tw.xrank, (size_t)XW + 1, pw.scan_tmp, pw.scan_tmp_bytes, s); // xrank[XW] = values in all
+	LAUNCH(k_bit_ranks, XW, s, XW, tw.xrank, tw.xrec);
+	LAUNCH(k_tour_values, V, s, V, tw.t0seg, ft, hside, tw.xrec, tw.xval);
+	// (the number of values stays on the device: the scan is launched for the most there can be, one per segment, and
+	// stops at their count + 1)
+	scan_exclusive_xor_u128(tw.xval, tw.xps, (size_t)V + 1, pw.scan_tmp, pw.scan_tmp_bytes, s, tw.xrank + XW);
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
 	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, px, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, tw.pbr, multi, cstate, tw.dps);
+	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, tw.xps, tw.xrec, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, tw.pbr, multi, cstate, tw.dps);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS

@@ -12,7 +12,9 @@ struct TreeWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	// unrooted spanning forest of the biedged graph H, as arcs
 	uint32_t *dist;					  // [2E] arcs behind an adjacency slot in its Euler tour (slots of hooked links = arcs, see tree_kernels.hip)
-	ulonglong2 *xval, *xps;				  // [4V+4] xor values (two 64-bit hashes) by tour position, their running xor
+	ulonglong2 *xval, *xps;				  // [4V+4] xor values (two 64-bit hashes) of the segments that have any, in tour order, and their running xor
+	uint4 *xrec;					  // [(4V+8)/64 + 4] per 64 tour positions {which of them carry a value (64 bits), set bits in front of the word, -}
+	uint32_t *xrank;				  // [(4V+8)/64 + 4] scan buffer of the bit counts (the last entry: their total)
 	uint4 *t0seg;					  // [V] rooted forest, per segment: {parent of the entered side, link to it | r bit, tour position in, out}
 	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
 	uint2 *dps;					  // [2V] {DFS parent side, scan slot of the parent it was found through}
