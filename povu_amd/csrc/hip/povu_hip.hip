@@ -213,7 +213,7 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take(&cs.hook, E + 32, 1);
 		take(&cs.la, E + 2, 4);
 		take(&cs.lb, E + 2, 4);
-		take(&cs.lle, 2 * E + 2, 4);
+		take(&cs.lle, 2 * E + 8, 4); // (+8: the tour kernel reads a segment's slot words four at a time)
 		take(&cs.tgray, E + 32, 1);
 		take(&cs.stats, 16, 4);
 		take(&cs.gid_s, V + 1, 4);

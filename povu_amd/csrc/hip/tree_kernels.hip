@@ -95,6 +95,13 @@ __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ 
 			return j - l0 + 1;
 	return 0; // (not reached: a link sits in the lists of both its ends)
 }
+// four consecutive words from a 4-byte aligned address in ONE load instruction (global_load_dwordx4 only needs dword alignment)
+__device__ __forceinline__ uint4 load4_unaligned(const uint32_t *__restrict__ p)
+{
+	typedef uint32_t v4a __attribute__((ext_vector_type(4), aligned(4)));
+	const v4a v = *reinterpret_cast<const v4a *>(p);
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
 // adjacency index of the same link in the list of the side at its other end
 __device__ __forceinline__ uint32_t arc_twin(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 					     const uint32_t *__restrict__ lle, uint32_t at)
@@ -142,16 +149,49 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 		}
 		if (first == NIL)
 			first = at;
-		const uint32_t w = ladj[at], t = loff[w] + find_link_slot(loff, lle, w, le) - 1;
+		// The slots of w's SEGMENT (l side, then r side: one index range) answer both questions -- where the link sits in
+		// w's list (its twin) and which forest slot follows the twin around the segment.  A gather whose 64 lanes hit 64
+		// lines keeps the CU's address unit busy for 64 cycles whatever it returns, and this kernel is bound by exactly
+		// that: a segment with at most eight slots (nearly all) is fetched with two offset loads and one or two 16-byte
+		// loads, and searched in registers.
+		const uint32_t w = ladj[at], g2 = w & ~1u;
+		const uint2 o01 = *reinterpret_cast<const uint2 *>(loff + g2); // (g2 is even: 8-byte aligned)
+		const uint32_t sb = o01.x, se = loff[g2 + 2];
+		const uint32_t wl = (w & 1u) ? o01.y : sb, wh = (w & 1u) ? se : o01.y; // w's own slots
+		uint32_t t, nxt;
+		if (se - sb <= 8) {
+			const uint32_t n = se - sb, tl = wl - sb, th = wh - sb;
+			const uint4 a = load4_unaligned(lle + sb);
+			uint4 c = make_uint4(0u, 0u, 0u, 0u);
+			if (n > 4)
+				c = load4_unaligned(lle + sb + 4);
+			const uint32_t r[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+			uint32_t tk = 0, first_tree = NIL, after = NIL;
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++)
+				if (k >= tl && k < th && (r[k] & LLE_ID) == le)
+					tk = k;
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++)
+				if (k < n && (r[k] & LLE_TREE)) {
+					if (first_tree == NIL)
+						first_tree = k;
+					if (k > tk && after == NIL)
+						after = k;
+				}
+			t = sb + tk;
+			nxt = sb + (after != NIL ? after : (first_tree < tk ? first_tree : tk)); // (the twin itself is a forest slot: first_tree <= tk)
+		} else {
+			t = wl + find_link_slot(loff, lle, w, le) - 1;
+			nxt = t;
+			for (uint32_t j = t + 1; j < se && nxt == t; j++)
+				if (lle[j] & LLE_TREE)
+					nxt = j;
+			for (uint32_t j = sb; j < t && nxt == t; j++)
+				if (lle[j] & LLE_TREE)
+					nxt = j;
+		}
 		twin[at] = t; // (k_t0_parents needs it again)
-		const uint32_t sb = loff[w & ~1u], se = loff[(w & ~1u) + 2];
-		uint32_t nxt = t;
-		for (uint32_t j = t + 1; j < se && nxt == t; j++)
-			if (lle[j] & LLE_TREE)
-				nxt = j;
-		for (uint32_t j = sb; j < t && nxt == t; j++)
-			if (lle[j] & LLE_TREE)
-				nxt = j;
 		pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 	}
 	const bool nz = !hzero(h);
