@@ -505,7 +505,7 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 			    const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
 			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ atwin,
 			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ loff,
-			    const uint8_t *__restrict__ hook, uint32_t *ladj, uint32_t *lle)
+			    const uint8_t *__restrict__ hook, uint32_t *ladj, uint32_t *lle, bool any_loop)
 {
 	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
@@ -568,11 +568,13 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 		else
 			insert((sbase ? sbase[io] + (atwin[k] - off[2 * vo]) : atwin[k]) | tree, other);
 	}
-	lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sb + (lo - b0);
-	for (uint32_t k = lo; k < hi; k++, P++) {
-		const uint32_t o = aoth[k];
-		if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
-			insert(P | (hook[adj[k]] ? LLE_TREE : 0u), S ^ 1u);
+	if (any_loop) { // (a graph without self loops: nothing of the other side's list belongs here)
+		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sb + (lo - b0);
+		for (uint32_t k = lo; k < hi; k++, P++) {
+			const uint32_t o = aoth[k];
+			if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
+				insert(P | (hook[adj[k]] ? LLE_TREE : 0u), S ^ 1u);
+		}
 	}
 	if (n <= 4) { // never flushed: write the registers
 		if (n > 0)
@@ -813,7 +815,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 		}
 		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin, sbase,
-				   st.loff, st.hook, st.ladj, st.lle);
+				   st.loff, st.hook, st.ladj, st.lle, st.has_self_loops);
 		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats,
 				   st.host_pub);
 		st.dense_edges = false;
