@@ -139,15 +139,28 @@ __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const ui
 }
 // bridge(v): no ordinary back edge out of subtree(v) reaches a proper ancestor of v (the bracket list of v would be
 // empty but for simplifying edges): the subtree sum of cov is zero
+// (four vertices a lane, 16-byte loads: see k_entry_flags)
 __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
 			       const uint32_t *__restrict__ pscov, uint8_t *__restrict__ bridge)
 {
-	uint32_t t = BIDX * blockDim.x + threadIdx.x;
-	if (t >= T)
+	const uint32_t t0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (t0 >= T)
 		return;
-	const uint32_t sz = gsize[t];
-	bridge[t] = (sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1 : 0;
-	if (t == T - 1)
+	if (t0 + 4 <= T) {
+		const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), gp = *reinterpret_cast<const uint4 *>(gpar + t0);
+		const uint4 pc = *reinterpret_cast<const uint4 *>(pscov + t0);
+		const uint32_t b0 = (sz.x && gp.x != NIL && pscov[t0 + sz.x] == pc.x) ? 1u : 0u;
+		const uint32_t b1 = (sz.y && gp.y != NIL && pscov[t0 + 1 + sz.y] == pc.y) ? 1u : 0u;
+		const uint32_t b2 = (sz.z && gp.z != NIL && pscov[t0 + 2 + sz.z] == pc.z) ? 1u : 0u;
+		const uint32_t b3 = (sz.w && gp.w != NIL && pscov[t0 + 3 + sz.w] == pc.w) ? 1u : 0u;
+		*reinterpret_cast<uint32_t *>(bridge + t0) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+	} else {
+		for (uint32_t t = t0; t < T; t++) {
+			const uint32_t sz = gsize[t];
+			bridge[t] = (sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1 : 0;
+		}
+	}
+	if (t0 + 4 >= T)
 		bridge[T] = 0;
 }
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
@@ -238,18 +251,40 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
 			  uint8_t *__restrict__ capf, uint8_t *__restrict__ branching)
 {
-	uint32_t t = BIDX * blockDim.x + threadIdx.x;
-	if (t >= T)
+	const uint32_t t0 = (BIDX * blockDim.x + threadIdx.x) * 4u; // (four vertices a lane, 16-byte loads: see k_entry_flags)
+	if (t0 >= T)
 		return;
-	uint32_t sz = gsize[t];
-	const uint8_t sm = (sz && bridge[t] && psb[t + sz] - psb[t] == 1) ? 1 : 0;
-	simp[t] = sm;
-	if (t == T - 1)
-		simp[T] = 0;
-	if (hpf)
-		hpf[t] = sm;
-	capf[t] = 0; // (cap_tgt is only read where capf says so)
-	branching[t] = (sz > 2 && t + 1 + max(gsize[t + 1], 1u) < t + sz) ? 1 : 0; // the first child does not fill the subtree
+	auto one = [&](uint32_t t, uint32_t sz, uint32_t br, uint32_t p0, uint32_t sz_next, uint32_t &sm, uint32_t &bch) {
+		sm = (sz && br && psb[t + sz] - p0 == 1) ? 1u : 0u;
+		bch = (sz > 2 && t + 1 + max(sz_next, 1u) < t + sz) ? 1u : 0u; // the first child does not fill the subtree
+	};
+	if (t0 + 4 < T) { // (strictly: the last of the four looks at its successor's size)
+		const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), p = *reinterpret_cast<const uint4 *>(psb + t0);
+		const uint32_t sz4 = gsize[t0 + 4], br = *reinterpret_cast<const uint32_t *>(bridge + t0);
+		uint32_t s0, s1, s2, s3, c0, c1, c2, c3;
+		one(t0, sz.x, br & 0xFFu, p.x, sz.y, s0, c0);
+		one(t0 + 1, sz.y, br & 0xFF00u, p.y, sz.z, s1, c1);
+		one(t0 + 2, sz.z, br & 0xFF0000u, p.z, sz.w, s2, c2);
+		one(t0 + 3, sz.w, br & 0xFF000000u, p.w, sz4, s3, c3);
+		const uint32_t sw = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+		*reinterpret_cast<uint32_t *>(simp + t0) = sw;
+		if (hpf)
+			*reinterpret_cast<uint32_t *>(hpf + t0) = sw;
+		*reinterpret_cast<uint32_t *>(capf + t0) = 0u; // (cap_tgt is only read where capf says so)
+		*reinterpret_cast<uint32_t *>(branching + t0) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+		return;
+	}
+	for (uint32_t t = t0; t < T; t++) {
+		uint32_t sm, bch;
+		one(t, gsize[t], bridge[t], psb[t], gsize[t + 1], sm, bch);
+		simp[t] = (uint8_t)sm;
+		if (t == T - 1)
+			simp[T] = 0;
+		if (hpf)
+			hpf[t] = (uint8_t)sm;
+		capf[t] = 0;
+		branching[t] = (uint8_t)bch;
+	}
 }
 __global__ void k_capping(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const uint32_t *__restrict__ gsize,
 			  const uint32_t *__restrict__ hi0, const uint32_t *__restrict__ psb, const RootOf root_of, const SegTree segA,
@@ -674,11 +709,19 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 }
 // inclusive prefix sums of the walk, biased so that u32 order = int order; neg = their complement (a running
 // maximum of the complement is the running minimum of the walk)
-__global__ void k_walk_bias(uint32_t n, const uint32_t *__restrict__ walk, const uint32_t *__restrict__ ps,
-			    uint32_t *__restrict__ out, uint32_t *__restrict__ neg)
+__global__ void k_walk_bias(uint32_t n, const uint32_t *walk, const uint32_t *ps, uint32_t *out, uint32_t *neg)
 {
-	uint32_t k = BIDX * blockDim.x + threadIdx.x;
-	if (k < n) {
+	const uint32_t k0 = (BIDX * blockDim.x + threadIdx.x) * 4u; // (in place on both arrays: a lane reads its four, then writes them)
+	if (k0 >= n)
+		return;
+	if (k0 + 4 <= n) {
+		const uint4 a = *reinterpret_cast<const uint4 *>(ps + k0), b = *reinterpret_cast<const uint4 *>(walk + k0);
+		const uint4 w = make_uint4(a.x + b.x + 0x80000000u, a.y + b.y + 0x80000000u, a.z + b.z + 0x80000000u, a.w + b.w + 0x80000000u);
+		*reinterpret_cast<uint4 *>(out + k0) = w;
+		*reinterpret_cast<uint4 *>(neg + k0) = make_uint4(~w.x, ~w.y, ~w.z, ~w.w);
+		return;
+	}
+	for (uint32_t k = k0; k < n; k++) {
 		const uint32_t w = ps[k] + walk[k] + 0x80000000u;
 		out[k] = w;
 		neg[k] = ~w;
@@ -1034,11 +1077,11 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		scan_exclusive_diff_u32(pw.lsz, pw.incnt, pscov, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	else
 		scan(pw.cov, pscov, (size_t)T + 1);
-	LAUNCH(k_bridge_flags, T, s, T, pw.gsize, pw.gpar, pscov, bridge);
+	LAUNCH(k_bridge_flags, (T + 3) / 4, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
 	uint8_t *branching = pw.f8d;
 	uint32_t *br_list = pw.vals_t, *n_br = pw.err + 10; // (the sort's value buffer is free until the class pass)
-	LAUNCH(k_hi_simp, T, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, branching);
+	LAUNCH(k_hi_simp, (T + 3) / 4, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, branching);
 	compact_flagged_u8(branching, T, br_list, n_br, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	KLAUNCH(k_capping, dim3(std::min<unsigned>(nblk(T / 8 + 1), 16384)), dim3(TPB), 0, s, n_br, br_list, pw.gsize, pw.hi0, psb, root_of,
 		pw.segA, pw.cap_tgt, capf, pw.err + 5);
@@ -1187,7 +1230,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan(pw.walk, pw.walk_ps, (size_t)S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
-	LAUNCH(k_walk_bias, (size_t)S, s, S, pw.walk, pw.walk_ps, wb, wneg);
+	LAUNCH(k_walk_bias, ((size_t)S + 3) / 4, s, S, pw.walk, pw.walk_ps, wb, wneg);
 	scan_exclusive_max_u32(wneg, wrun, (size_t)S, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);

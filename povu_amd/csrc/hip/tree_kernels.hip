@@ -736,14 +736,27 @@ __global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ul
 // ------------------------------------------------------------------ 5. class entries
 // a class is walked from its entry side (k_bridges marked the entries visited and wrote their DFS records); a side that
 // is alone in its class has nothing to walk: the walks start from the entries that share their class (multi)
+// (four sides a lane: one 16-byte, one 4-byte and one 8-byte load instead of twelve 4- and 1-byte ones -- a kernel of a few
+// loads per element is bound by the number of memory instructions its CU can retire, not by their bytes)
 __global__ void k_entry_flags(uint32_t nS, const uint32_t *__restrict__ pbr, const uint8_t *__restrict__ multi,
 			      const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, uint8_t *__restrict__ entry_flag)
 {
-	uint32_t S = BIDX * blockDim.x + threadIdx.x;
-	if (S >= nS)
+	const uint32_t S0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (S0 >= nS)
 		return;
 	// an entry: a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
-	entry_flag[S] = (multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1 : 0;
+	if (S0 + 4 <= nS) {
+		const uint4 pb = *reinterpret_cast<const uint4 *>(pbr + S0);
+		const uint32_t mu = *reinterpret_cast<const uint32_t *>(multi + S0);
+		const uint2 ck = *reinterpret_cast<const uint2 *>(ckey + (S0 >> 1));
+		const uint32_t c0 = cproc[ck.x] ? 1u : 0u, c1 = cproc[ck.y] ? 1u : 0u;
+		const uint32_t f0 = ((mu & 0xFFu) && (pb.x & PB_BRIDGE)) ? c0 : 0u, f1 = ((mu & 0xFF00u) && (pb.y & PB_BRIDGE)) ? c0 : 0u;
+		const uint32_t f2 = ((mu & 0xFF0000u) && (pb.z & PB_BRIDGE)) ? c1 : 0u, f3 = ((mu & 0xFF000000u) && (pb.w & PB_BRIDGE)) ? c1 : 0u;
+		*reinterpret_cast<uint32_t *>(entry_flag + S0) = f0 | (f1 << 8) | (f2 << 16) | (f3 << 24);
+		return;
+	}
+	for (uint32_t S = S0; S < nS; S++)
+		entry_flag[S] = (multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ 6. the DFS inside every class
@@ -1561,7 +1574,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
-	LAUNCH(k_entry_flags, nS, s, nS, tw.pbr, multi, cs.ckey, tw.cproc, tw.entry_flag);
+	LAUNCH(k_entry_flags, (nS + 3) / 4, s, nS, tw.pbr, multi, cs.ckey, tw.cproc, tw.entry_flag);
 	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
 	compact_flagged_u8(tw.entry_flag, nS, tw.entry_list, n_entry_dev, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
