@@ -336,6 +336,8 @@ __global__ void __launch_bounds__(TPB) k_flag_tile_counts(uint32_t T, const uint
 		tsimp[tile] = tile < ntiles ? ns : 0u;
 	}
 }
+// Four vertices a lane (16-byte loads: a kernel of a few loads per element is bound by its memory INSTRUCTIONS), so a
+// wave covers exactly one tile of 256 vertices and ranks its flags with eight ballots; no LDS, no barrier.
 __global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
 							const uint32_t *__restrict__ tcap, const uint8_t *__restrict__ simp,
 							const uint32_t *__restrict__ tsimp, const uint32_t *__restrict__ cap_tgt,
@@ -344,45 +346,70 @@ __global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0,
 							const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
 							uint32_t *__restrict__ srccnt)
 {
-	__shared__ uint32_t wc[TPB / 64], ws[TPB / 64];
-	const uint32_t v = BIDX * blockDim.x + threadIdx.x;
-	const bool live = v < T;
-	const uint32_t c = live ? capf[v] : 0u, sm = live ? simp[v] : 0u;
-	// rank among the flagged vertices: the tiles before (scanned counts) + the waves before + the lanes before
-	const unsigned long long mc = __ballot(c != 0), ms = __ballot(sm != 0);
-	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	if (lane == 0) {
-		wc[wave] = (uint32_t)__popcll(mc);
-		ws[wave] = (uint32_t)__popcll(ms);
+	const uint32_t v0 = (BIDX * blockDim.x + threadIdx.x) * 4u, lane = threadIdx.x & 63u, tile = v0 / BX_TILE;
+	uint32_t cw = 0, sw = 0; // the four flag bytes of this lane
+	if (v0 + 4 <= T) {
+		cw = *reinterpret_cast<const uint32_t *>(capf + v0);
+		sw = *reinterpret_cast<const uint32_t *>(simp + v0);
+	} else {
+		for (uint32_t j = 0; v0 + j < T && j < 4; j++) {
+			cw |= (capf[v0 + j] ? 1u : 0u) << (8 * j);
+			sw |= (simp[v0 + j] ? 1u : 0u) << (8 * j);
+		}
 	}
-	__syncthreads();
-	if (!live)
-		return;
+	// rank among the flagged vertices: the tiles before (scanned counts) + the lanes before + this lane's own earlier ones
 	const unsigned long long lt = (1ull << lane) - 1ull;
-	if (c) {
-		uint32_t r = tcap[v / TPB] + (uint32_t)__popcll(mc & lt);
-		for (uint32_t w = 0; w < wave; w++)
-			r += wc[w];
-		const uint32_t j = NB0 + r;
-		b_src[j] = v;
-		b_tgt[j] = cap_tgt[v];
-		if (ordcnt)
-			atomicAdd(&incnt[cap_tgt[v]], 1u);
+	uint32_t rc = 0, rs = 0;
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		rc += (uint32_t)__popcll(__ballot(((cw >> (8 * j)) & 0xFFu) != 0) & lt);
+		rs += (uint32_t)__popcll(__ballot(((sw >> (8 * j)) & 0xFFu) != 0) & lt);
 	}
-	if (sm) {
-		uint32_t r = tsimp[v / TPB] + (uint32_t)__popcll(ms & lt);
-		for (uint32_t w = 0; w < wave; w++)
-			r += ws[w];
-		const uint32_t j = NB0 + ncap + r;
-		const uint32_t root = root_of(v);
-		b_src[j] = v;
-		b_tgt[j] = root;
-		if (ordcnt)
-			atomicAdd(&incnt[root], 1u);
+	if (v0 >= T)
+		return;
+	if (cw)
+		rc += tcap[tile];
+	if (sw)
+		rs += tsimp[tile];
+	uint4 oc = make_uint4(0u, 0u, 0u, 0u), gs = oc, mp = oc;
+	if (ordcnt) {
+		if (v0 + 4 <= T) {
+			oc = *reinterpret_cast<const uint4 *>(ordcnt + v0);
+			gs = *reinterpret_cast<const uint4 *>(gsize + v0);
+			mp = *reinterpret_cast<const uint4 *>(mpre + v0);
+		} else {
+			uint32_t *o = &oc.x, *g = &gs.x, *m = &mp.x;
+			for (uint32_t j = 0; v0 + j < T && j < 4; j++)
+				o[j] = ordcnt[v0 + j], g[j] = gsize[v0 + j], m[j] = mpre[v0 + j];
+		}
 	}
-	// (dense path) brackets per source, at its place in the list order: known per vertex, no counting pass over the brackets
-	if (ordcnt && gsize[v])
-		srccnt[mpre[v]] = ordcnt[v] + (c ? 1u : 0u) + (sm ? 1u : 0u);
+	const uint32_t ocv[4] = {oc.x, oc.y, oc.z, oc.w}, gsv[4] = {gs.x, gs.y, gs.z, gs.w}, mpv[4] = {mp.x, mp.y, mp.z, mp.w};
+#pragma unroll
+	for (uint32_t j = 0; j < 4; j++) {
+		const uint32_t v = v0 + j;
+		if (v >= T)
+			break;
+		const uint32_t c = (cw >> (8 * j)) & 0xFFu, sm = (sw >> (8 * j)) & 0xFFu;
+		if (c) {
+			const uint32_t q = NB0 + rc++;
+			const uint32_t tg = cap_tgt[v];
+			b_src[q] = v;
+			b_tgt[q] = tg;
+			if (ordcnt)
+				atomicAdd(&incnt[tg], 1u);
+		}
+		if (sm) {
+			const uint32_t q = NB0 + ncap + rs++;
+			const uint32_t root = root_of(v);
+			b_src[q] = v;
+			b_tgt[q] = root;
+			if (ordcnt)
+				atomicAdd(&incnt[root], 1u);
+		}
+		// (dense path) brackets per source, at its place in the list order: known per vertex, no counting pass over the brackets
+		if (ordcnt && gsv[j])
+			srccnt[mpv[j]] = ocv[j] + (c ? 1u : 0u) + (sm ? 1u : 0u);
+	}
 }
 __global__ void k_bracket_order(uint32_t NB, uint32_t NB0, uint32_t ncap, uint32_t nsimp, const uint32_t *__restrict__ b_src,
 				const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ mpre,
@@ -1110,7 +1137,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// both take the all-vertices pass.
 	const bool black_only = !want_hp && !pw.all_vertex_classes && extra[2] == 0;
 	pw.black_only_used = black_only;
-	LAUNCH(k_bracket_extra, T, s, T, NB0, ncap, capf, tcap, simp, tsimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
+	LAUNCH(k_bracket_extra, ((size_t)T + 3) / 4, s, T, NB0, ncap, capf, tcap, simp, tsimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
 	       dense_nb0 >= 0 ? pw.lsz : nullptr, pw.gsize, pw.mpre, pw.incnt, srccnt);
 	if (dense_nb0 >= 0) { // ranks inside every source and the counts per source are known: place directly
 		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);

@@ -507,19 +507,27 @@ __global__ void __launch_bounds__(RS_TPB) k_rs_hist(const uint32_t *__restrict__
 		h[d] = 0;
 	__syncthreads();
 	const uint32_t bx = BIDX, base = bx * RS_TILE;
-#pragma unroll 4
-	for (int r = 0; r < RS_ITEMS; r++) {
-		const uint32_t i = base + r * RS_TPB + threadIdx.x;
-		const bool live = i < n;
-		const uint32_t d = live ? (keys[i] >> shift) & mask : 0u;
-		// a whole wave on one digit (clustered keys) adds once
-		const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-		const unsigned long long lv = __ballot(live);
-		if (lv == ~0ull && __all(d == d0)) {
-			if ((threadIdx.x & 63) == 0)
-				atomicAdd(&h[d0], 64u);
-		} else if (live) {
-			atomicAdd(&h[d], 1u);
+	// four consecutive keys a lane and load (a histogram does not care which lane counts which key): a quarter of the
+	// memory instructions
+#pragma unroll
+	for (int r = 0; r < RS_ITEMS / 4; r++) {
+		const uint32_t i0 = base + (r * RS_TPB + threadIdx.x) * 4u;
+		if (__all(i0 + 4 <= n)) {
+			const uint4 k = *reinterpret_cast<const uint4 *>(keys + i0);
+			const uint32_t d[4] = {(k.x >> shift) & mask, (k.y >> shift) & mask, (k.z >> shift) & mask, (k.w >> shift) & mask};
+			// a whole wave on one digit (clustered keys) adds once
+			const uint32_t d0 = __builtin_amdgcn_readfirstlane(d[0]);
+			if (__all(d[0] == d0 && d[1] == d0 && d[2] == d0 && d[3] == d0)) {
+				if ((threadIdx.x & 63) == 0)
+					atomicAdd(&h[d0], 256u);
+			} else {
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					atomicAdd(&h[d[q]], 1u);
+			}
+		} else {
+			for (uint32_t i = i0; i < i0 + 4 && i < n; i++)
+				atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
 		}
 	}
 	__syncthreads();
