@@ -650,78 +650,85 @@ static constexpr uint32_t PB_BRIDGE = 0x80000000u;
 // reaches first --, its DFS record dps = {parent across the bridge, scan slot of the parent it is found through}.
 static constexpr uint32_t CLASS_BUDGET = 256;  // sides a lane walks before it hands its class to the big-class walk
 static constexpr uint32_t CS_VISITED = 0x40000000u; // (side ids stay below 2^29, bit 31 is PB_BRIDGE)
-__global__ void k_bridges(uint32_t nS, const uint4 *__restrict__ t0seg, const ulonglong2 *__restrict__ xps,
+// One lane per SEGMENT: the side a segment is entered through and its far side ask different questions (the hooked link
+// into the segment / the black edge across it), so a lane per side left half of every wave idle in either branch; a lane
+// per segment answers both, loads the segment's record once and stores the words of its two sides together.
+__global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulonglong2 *__restrict__ xps,
 			  const uint4 *__restrict__ xrec,
 			  const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft,
 			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
 			  const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
 			  uint32_t *__restrict__ pbr, uint8_t *multi, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
 {
-	uint32_t S = BIDX * blockDim.x + threadIdx.x;
-	if (S >= nS)
+	const uint32_t g = BIDX * blockDim.x + threadIdx.x;
+	if (g >= V)
 		return;
 	// multi[S] = 1: side S shares its 2-edge-connected class with another side, i.e. some tree edge at S is no bridge
 	// (cleared by the caller).  Most sides of a pangenome graph sit on bridges only and are classes of their own; those
 	// need no walk at all.
 	auto px = [&](uint32_t p) { return xps[tour_rank(xrec, p)]; }; // running xor in front of tour position p
-	const uint4 r = t0seg[S >> 1];
-	const uint32_t entered = (S & ~1u) | (r.y >> 31), c = ckey[S >> 1];
+	const uint4 r = t0seg[g];
+	const uint32_t Se = (2 * g) | (r.y >> 31), Sf = Se ^ 1u, c = ckey[g]; // entered side, far side
 	const bool proc = cproc[c] != 0; // (components that are not decomposed here get inert words)
-	uint32_t pv; // parent | bridge bit
-	if (S == entered) {
-		if (r.x == NIL) {
-			pv = NIL;
-		} else if (heq(px(r.z), px(r.w + 1))) {
-			pv = r.x | PB_BRIDGE;
-		} else {
-			pv = r.x;
-			multi[S] = 1;
-			multi[r.x] = 1;
-		}
+	// ---- the entered side: the hooked link into the segment is a bridge iff nothing crosses the segment's stretch of the tour
+	uint32_t pvE; // parent | bridge bit
+	if (r.x == NIL) {
+		pvE = NIL;
+	} else if (heq(px(r.z), px(r.w + 1))) {
+		pvE = r.x | PB_BRIDGE;
 	} else {
-		// the black edge entered -> S: what leaves subtree(S) = S's own non-tree links and those of the subtrees hanging off S
-		const uint32_t f1 = ft[S], a1 = f1 & FT_NONE;
-		ulonglong2 x = (f1 & FT_HASH) ? hside[S] : make_ulonglong2(0ull, 0ull);
-		if (a1 != FT_NONE) {
-			const uint32_t L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
-			const uint32_t a3 = ft[entered] & FT_NONE;
-			uint32_t end; // position behind the last of them
-			if (r.x == NIL) // root segment: the start side's arcs come first, S's are the rest of the tour
-				end = abase + L;
-			else if (a3 != FT_NONE && (lle[a3] & LLE_ID) != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow S's
-				end = abase + (L - 1 - dist[a3]);
+		pvE = r.x;
+		multi[Se] = 1;
+		multi[r.x] = 1;
+	}
+	// ---- the far side, across the black edge: what leaves its subtree = its own non-tree links and those of the subtrees
+	// hanging off it
+	const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
+	const uint32_t fF = (Sf & 1u) ? f2.y : f2.x, fE = (Sf & 1u) ? f2.x : f2.y, a1 = fF & FT_NONE;
+	ulonglong2 x = (fF & FT_HASH) ? hside[Sf] : make_ulonglong2(0ull, 0ull);
+	if (a1 != FT_NONE) {
+		const uint32_t L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
+		const uint32_t a3 = fE & FT_NONE;
+		uint32_t end; // position behind the last of them
+		if (r.x == NIL) // root segment: the start side's arcs come first, the far side's are the rest of the tour
+			end = abase + L;
+		else if (a3 != FT_NONE && (lle[a3] & LLE_ID) != (r.y & ~T0_RBIT)) // arcs of the entered side in front of the entering one follow
+			end = abase + (L - 1 - dist[a3]);
+		else
+			end = r.w;
+		x = hx(x, hx(px(abase + (L - 1 - dist[a1])), px(end)));
+	}
+	uint32_t pvF;
+	if (hzero(x)) {
+		pvF = Se | PB_BRIDGE;
+	} else {
+		pvF = Se;
+		multi[Sf] = 1;
+		multi[Se] = 1;
+	}
+	// ---- the words of both sides, stored together
+	const bool entryE = proc && (pvE & PB_BRIDGE), entryF = proc && (pvF & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
+	const uint32_t csE = proc ? (pvE | (entryE ? CS_VISITED : 0u)) : NIL, csF = proc ? (pvF | (entryF ? CS_VISITED : 0u)) : NIL;
+	uint2 recE = make_uint2(NIL, 0u), recF = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}
+	if (entryE && pvE != NIL) { // (NIL: DFS start of the component) a gray bridge: its slot in the parent's list (ascending link id)
+		const uint32_t p = pvE & ~PB_BRIDGE;
+		recE.x = p;
+		uint32_t le = r.y & ~T0_RBIT, lo = loff[p], hi = loff[p + 1];
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((lle[mid] & LLE_ID) < le)
+				lo = mid + 1;
 			else
-				end = r.w;
-			x = hx(x, hx(px(abase + (L - 1 - dist[a1])), px(end)));
+				hi = mid;
 		}
-		if (hzero(x)) {
-			pv = entered | PB_BRIDGE;
-		} else {
-			pv = entered;
-			multi[S] = 1;
-			multi[entered] = 1;
-		}
+		recE.y = lo - loff[p] + 1;
 	}
-	pbr[S] = pv;
-	const bool entry = proc && (pv & PB_BRIDGE); // a root (NIL) or the lower end of a bridge
-	cstate[S] = proc ? (pv | (entry ? CS_VISITED : 0u)) : NIL;
-	uint2 rec = make_uint2(NIL, 0u); // {DFS parent, scan slot it was found through}: one word pair, one store
-	if (entry && pv != NIL) { // (NIL: DFS start of the component)
-		const uint32_t p = pv & ~PB_BRIDGE;
-		rec.x = p;
-		if (p != (S ^ 1u)) { // (black edge: slot 0, scanned first) gray bridge: its slot in the parent's list (ascending link id)
-			uint32_t le = r.y & ~T0_RBIT, lo = loff[p], hi = loff[p + 1];
-			while (lo < hi) {
-				const uint32_t mid = (lo + hi) >> 1;
-				if ((lle[mid] & LLE_ID) < le)
-					lo = mid + 1;
-				else
-					hi = mid;
-			}
-			rec.y = lo - loff[p] + 1;
-		}
-	}
-	dps[S] = rec;
+	if (entryF)
+		recF.x = Se; // (the black edge: slot 0, scanned first)
+	const bool e_first = !(Se & 1u);
+	*reinterpret_cast<uint2 *>(pbr + 2 * g) = e_first ? make_uint2(pvE, pvF) : make_uint2(pvF, pvE);
+	*reinterpret_cast<uint2 *>(cstate + 2 * g) = e_first ? make_uint2(csE, csF) : make_uint2(csF, csE);
+	*reinterpret_cast<uint4 *>(dps + 2 * g) = e_first ? make_uint4(recE.x, recE.y, recF.x, recF.y) : make_uint4(recF.x, recF.y, recE.x, recE.y);
 }
 
 // ------------------------------------------------------------------ 4. 2-edge-connected classes
@@ -1569,7 +1576,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
 	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_bridges, nS, s, nS, tw.t0seg, tw.xps, tw.xrec, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, tw.pbr, multi, cstate, tw.dps);
+	LAUNCH(k_bridges, V, s, V, tw.t0seg, tw.xps, tw.xrec, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, tw.pbr, multi, cstate, tw.dps);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
