@@ -102,6 +102,15 @@ __device__ __forceinline__ uint4 load4_unaligned(const uint32_t *__restrict__ p)
 	const v4a v = *reinterpret_cast<const v4a *>(p);
 	return make_uint4(v.x, v.y, v.z, v.w);
 }
+// two consecutive words to a 4-byte aligned address in one store instruction
+__device__ __forceinline__ void store2_unaligned(uint32_t *p, uint32_t a, uint32_t b)
+{
+	typedef uint32_t v2a __attribute__((ext_vector_type(2), aligned(4)));
+	v2a v;
+	v.x = a;
+	v.y = b;
+	*reinterpret_cast<v2a *>(p) = v;
+}
 // adjacency index of the same link in the list of the side at its other end
 __device__ __forceinline__ uint32_t arc_twin(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 					     const uint32_t *__restrict__ lle, uint32_t at)
@@ -1203,47 +1212,45 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			}
 		}
 	}
-	if (S >= nS)
+	// One lane per SEGMENT: the entered side e and the far side o (its black child) are neighbours in pre-order, so every
+	// array gets their two words in one 8-byte store, and the segment's event words are loaded once for both.
+	const uint32_t g = S;
+	if (g >= (nS >> 1))
 		return;
-	uint32_t c = ckey[S >> 1];
-	side_tidx[S] = NIL;
-	const uint32_t tb = 2 * voff[c] + c, g = S >> 1;
+	const uint32_t c = ckey[g], v0 = voff[c];
+	const uint32_t tb = 2 * v0 + c;
 	if (!cproc[c]) {
-		const uint32_t t = tb + (S - 2 * voff[c]);
-		t_size[t] = 0;
-		srccnt[t] = 0;
+		const uint32_t t = tb + 2 * (g - v0);
+		store2_unaligned(t_size + t, 0u, 0u);
+		store2_unaligned(srccnt + t, 0u, 0u);
+		*reinterpret_cast<uint2 *>(side_tidx + 2 * g) = make_uint2(NIL, NIL);
 		return;
 	}
-	const uint32_t Nh = 2 * (voff[c + 1] - voff[c]), hd = start_key[c] != ~0ull ? 1u : 0u;
+	const uint32_t Nh = 2 * (voff[c + 1] - v0), hd = start_key[c] != ~0ull ? 1u : 0u;
 	// cd[event] = {sides entered from this event to the end of the list, net depth change from here to the end}
-	const uint2 ent = cd[3 * g], lv_o = cd[3 * g + 1];
-	const uint32_t p = dps[S].x;
-	const bool far = p == (S ^ 1u);
+	const uint4 cd01 = load4_unaligned(reinterpret_cast<const uint32_t *>(cd + 3 * g)); // cd[3g], cd[3g + 1]
+	const uint2 ent = make_uint2(cd01.x, cd01.y), lv_o = make_uint2(cd01.z, cd01.w);
+	const uint4 d4 = *reinterpret_cast<const uint4 *>(dps + 2 * g); // the DFS records of both sides
+	const uint32_t o = d4.x == 2 * g + 1 ? 2 * g : 2 * g + 1, e = o ^ 1u; // far side: its DFS parent is the other side
+	const uint32_t p = (e & 1u) ? d4.z : d4.x;			       // the entered side's parent
 	const uint32_t pre_e = Nh - ent.x, depth_e = 0u - ent.y;
-	uint32_t pre, size, depth, par;
-	if (far) {
-		pre = pre_e + 1;
-		size = ent.x - 1 - lv_o.x;
-		depth = depth_e + 1;
-		par = hd + pre_e;
-	} else {
-		pre = pre_e;
-		size = ent.x - (merged[g] ? lv_o.x : cd[3 * g + 2].x);
-		depth = depth_e;
-		if (p == NIL)
-			par = hd ? 0u : NIL;
-		else
-			par = hd + (Nh - cd[3 * (p >> 1)].x) + (dps[p].x == (p ^ 1u) ? 1u : 0u);
-	}
-	const uint32_t l = hd + pre, t = tb + l;
-	t_gid[t] = gid_s[g];
-	t_flags[t] = (uint8_t)((S & 1) | (far ? TF_BLACK : 0));
-	t_par[t] = par;
-	t_size[t] = size;
+	const uint32_t size_o = ent.x - 1 - lv_o.x, size_e = ent.x - (merged[g] ? lv_o.x : cd[3 * g + 2].x);
+	uint32_t par_e;
+	if (p == NIL)
+		par_e = hd ? 0u : NIL;
+	else
+		par_e = hd + (Nh - cd[3 * (p >> 1)].x) + (dps[p].x == (p ^ 1u) ? 1u : 0u);
+	const uint32_t l = hd + pre_e, t = tb + l; // e sits at t, o at t + 1
+	const uint32_t gid = gid_s[g];
+	store2_unaligned(t_gid + t, gid, gid);
+	t_flags[t] = (uint8_t)(e & 1u);
+	t_flags[t + 1] = (uint8_t)((o & 1u) | TF_BLACK);
+	store2_unaligned(t_par + t, par_e, l); // (o's parent is e)
+	store2_unaligned(t_size + t, size_e, size_o);
 	if (t_depth) // (only the hairpin report's T-space setup reads the depths again)
-		t_depth[t] = depth + hd;
-	mpre[t] = tb + (depth + hd) + (Nh + hd) - l - size;
-	side_tidx[S] = t;
+		store2_unaligned(t_depth + t, depth_e + hd, depth_e + 1 + hd);
+	store2_unaligned(mpre + t, tb + (depth_e + hd) + (Nh + hd) - l - size_e, tb + (depth_e + 1 + hd) + (Nh + hd) - (l + 1) - size_o);
+	*reinterpret_cast<uint2 *>(side_tidx + 2 * g) = (e & 1u) ? make_uint2(t + 1, t) : make_uint2(t, t + 1);
 }
 // back edges of from_bd out of side S, in scan order (process_edge, spanning_tree.cpp:360-398):
 //  - a side without links points back at the root unless the root is its tree parent (:433-438)
@@ -1631,7 +1638,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
-	LAUNCH(k_tree_emit, nS, s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
+	LAUNCH(k_tree_emit, std::max(V, C), s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
 	       sw.t_par, sw.t_size, sw.hairpins ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
 	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
