@@ -661,20 +661,57 @@ __global__ void k_next_from_runs(uint32_t T, const uint32_t *__restrict__ mark, 
 // first), so next_seen[u] = the entry before it in the run, prev[u] = the entry after it.  Nothing downstream needs the
 // classes as numbers; the debug hooks number them on demand (k_class_ids_black).
 __global__ void k_class_finish_black(uint32_t n, uint32_t S, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
-				     const uint8_t *__restrict__ fresh, uint32_t *__restrict__ ns, uint32_t *__restrict__ prev,
-				     uint8_t *__restrict__ dflag)
+				     const uint32_t *__restrict__ lsz, uint8_t *__restrict__ flag, uint32_t *__restrict__ ns,
+				     uint32_t *__restrict__ prev, uint8_t *__restrict__ dflag)
 {
-	uint32_t q = BIDX * blockDim.x + threadIdx.x;
-	if (q == 0)
+	// Four sorted positions a lane (the sorted keys, the stack indices and the flags move in 16-byte words), and the
+	// "opens a new class" flags (k_class_flags<true>: a bracket hands out a new class whenever the list size differs from
+	// the one it saw last, flubbles.cpp:668-676) are worked out right here, for the four and the one behind them.
+	const uint32_t q0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (q0 == 0)
 		dflag[S] = 0;
-	if (q >= n || skey[q] == NIL)
+	if (q0 >= n)
 		return;
-	const uint32_t u = sval[q];
-	const uint8_t f = fresh[q];
-	const uint32_t nx = f ? u : sval[q - 1];
-	ns[u] = nx;
-	prev[u] = (q + 1 < n && skey[q + 1] != NIL && !fresh[q + 1]) ? sval[q + 1] : NIL;
-	dflag[u] = (u + 1 < nx) ? 1 : 0; // entry u opens a flubble iff its class comes back later than at the next entry
+	uint32_t K[6], U[6], L[6]; // positions q0 - 1 .. q0 + 4
+	if (q0 + 4 <= n) {
+		const uint4 k4 = *reinterpret_cast<const uint4 *>(skey + q0), u4 = *reinterpret_cast<const uint4 *>(sval + q0);
+		K[1] = k4.x, K[2] = k4.y, K[3] = k4.z, K[4] = k4.w;
+		U[1] = u4.x, U[2] = u4.y, U[3] = u4.z, U[4] = u4.w;
+	} else {
+		for (uint32_t j = 1; j <= 4; j++) {
+			K[j] = q0 + j - 1 < n ? skey[q0 + j - 1] : NIL;
+			U[j] = q0 + j - 1 < n ? sval[q0 + j - 1] : 0u;
+		}
+	}
+	K[0] = q0 ? skey[q0 - 1] : NIL, U[0] = q0 ? sval[q0 - 1] : 0u;
+	K[5] = q0 + 4 < n ? skey[q0 + 4] : NIL, U[5] = q0 + 4 < n ? sval[q0 + 4] : 0u;
+#pragma unroll
+	for (int j = 0; j < 6; j++)
+		L[j] = K[j] != NIL ? lsz[U[j]] : 0u;
+	bool fresh[6];
+	fresh[0] = true;
+#pragma unroll
+	for (int j = 1; j < 6; j++)
+		fresh[j] = (q0 + j - 1 == 0) || K[j - 1] != K[j] || L[j - 1] != L[j];
+	uint32_t fw = 0;
+#pragma unroll
+	for (int j = 1; j <= 4; j++) {
+		const uint32_t q = q0 + j - 1;
+		if (q >= n || K[j] == NIL)
+			continue; // (invalid entries carry NIL and sit behind every valid key: flag 0)
+		const uint32_t u = U[j];
+		fw |= (fresh[j] ? 1u : 0u) << (8 * (j - 1));
+		const uint32_t nx = fresh[j] ? u : U[j - 1];
+		ns[u] = nx;
+		prev[u] = (K[j + 1] != NIL && !fresh[j + 1]) ? U[j + 1] : NIL;
+		dflag[u] = (u + 1 < nx) ? 1 : 0; // entry u opens a flubble iff its class comes back later than at the next entry
+	}
+	if (q0 + 4 <= n) {
+		*reinterpret_cast<uint32_t *>(flag + q0) = fw;
+	} else {
+		for (uint32_t j = 0; q0 + j < n; j++)
+			flag[q0 + j] = (uint8_t)((fw >> (8 * j)) & 0xFFu);
+	}
 }
 __global__ void k_class_ids_black(uint32_t n, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
 				  const uint8_t *__restrict__ fresh, const uint32_t *__restrict__ ps, uint32_t *__restrict__ s_cls)
@@ -1170,10 +1207,11 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree, sp);
 		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
-		LAUNCH(k_class_flags<true>, NC, s, NC, V, ck2, pw.vals_t2, pw.lsz, sw.t_flags, cflag, pw.dlt, nullptr);
 		tm.end(30 + 2 * 22);
 		tm.begin("par_stack");
-		LAUNCH(k_class_finish_black, std::max<size_t>(NC, 1), s, NC, S, ck2, pw.vals_t2, cflag, pw.ns, pw.prev, dflag);
+		// (the class flags are worked out by the same kernel: invalid entries carry NIL and sort behind every valid key)
+		LAUNCH(k_class_finish_black, std::max<size_t>(((size_t)NC + 3) / 4, 1), s, NC, S, ck2, pw.vals_t2, pw.lsz, cflag, pw.ns, pw.prev,
+		       dflag);
 		tm.end(1);
 		tm.begin("par_next_seen"); // (folded into the kernel above)
 		tm.end(0);
