@@ -804,30 +804,60 @@ __global__ void k_dflag(uint32_t S, const uint32_t *__restrict__ ns, uint8_t *__
 // the candidate stack and next_seen, so this kernel runs on the context's side stream while the main stream still
 // computes levels and parents: the PCIe writes (10 of the 14 bytes per PVST vertex) hide behind that work.  A small
 // grid-stride launch: a few ten thousand lanes keep the link busy and leave the CUs to the main stream.
-__global__ void k_emit_endpoints(uint32_t S, const uint8_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
-				 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ ns,
-				 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
-				 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ p_a,
-				 uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
+__global__ void __launch_bounds__(TPB) k_emit_endpoints(uint32_t S, const uint8_t *__restrict__ dflag, const uint32_t *__restrict__ erank,
+							 const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ ns,
+							 const uint32_t *__restrict__ s_vtx, const uint8_t *__restrict__ tf,
+							 const uint32_t *__restrict__ t_gid, const uint32_t *__restrict__ cproc_ps,
+							 uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z, uint8_t *__restrict__ p_aor,
+							 uint8_t *__restrict__ p_zor)
 {
-	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
-		if (!dflag[i])
-			continue;
-		// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
-		const uint64_t q = (uint64_t)erank[i] + cproc_ps[s_comp[i]] + 1;
-		uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
-		uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
-		if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
-			p_a[q] = t_gid[vz];
-			p_z[q] = t_gid[va];
-			p_aor[q] = 0;
-			p_zor[q] = 0;
+	// Only one entry in four or five opens a flubble.  A wave reads the flags of 256 entries (four a lane, one load),
+	// lists the ones that do in LDS, and then every lane takes one of THOSE: the ten gathers behind an emitted flubble run
+	// with full waves instead of waves that are four fifths idle.
+	__shared__ uint32_t list[TPB / 64][256];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (uint32_t b0 = blockIdx.x * (4u * TPB); b0 < S; b0 += gridDim.x * (4u * TPB)) { // (uniform per workgroup: the barriers below are safe)
+		const uint32_t i0 = b0 + wave * 256u + lane * 4u;
+		uint32_t fl = 0;
+		if (i0 + 4 <= S) {
+			fl = *reinterpret_cast<const uint32_t *>(dflag + i0);
 		} else {
-			p_a[q] = t_gid[va];
-			p_z[q] = t_gid[vz];
-			p_aor[q] = (uint8_t)ra;
-			p_zor[q] = (uint8_t)rz;
+			for (uint32_t k = 0; i0 + k < S && k < 4; k++)
+				fl |= (dflag[i0 + k] ? 1u : 0u) << (8 * k);
 		}
+		const uint32_t cnt = ((fl & 0xFFu) ? 1u : 0u) + ((fl & 0xFF00u) ? 1u : 0u) + ((fl & 0xFF0000u) ? 1u : 0u) + ((fl & 0xFF000000u) ? 1u : 0u);
+		uint32_t inc = cnt;
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t y = __shfl_up(inc, off);
+			if ((int)lane >= off)
+				inc += y;
+		}
+		const uint32_t total = __shfl(inc, 63);
+		uint32_t at = inc - cnt;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; k++)
+			if ((fl >> (8 * k)) & 0xFFu)
+				list[wave][at++] = i0 + k;
+		__syncthreads();
+		for (uint32_t k = lane; k < total; k += 64) {
+			const uint32_t i = list[wave][k];
+			// dense output slot: flubbles emitted before + one root per earlier component, + 1 for this component's root
+			const uint64_t q = (uint64_t)erank[i] + cproc_ps[s_comp[i]] + 1;
+			uint32_t va = s_vtx[i], vz = s_vtx[ns[i]];
+			uint32_t ra = ((tf[va] & TF_TYPE_MASK) == 1) ? 0u : 1u, rz = ((tf[vz] & TF_TYPE_MASK) == 1) ? 0u : 1u;
+			if (ra && rz) { // normalize_endpoints, flubbles.cpp:233-244
+				p_a[q] = t_gid[vz];
+				p_z[q] = t_gid[va];
+				p_aor[q] = 0;
+				p_zor[q] = 0;
+			} else {
+				p_a[q] = t_gid[va];
+				p_z[q] = t_gid[vz];
+				p_aor[q] = (uint8_t)ra;
+				p_zor[q] = (uint8_t)rz;
+			}
+		}
+		__syncthreads();
 	}
 }
 // level of every emitted flubble
@@ -1274,7 +1304,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	if (S && side.stream) {
 		HIP_CHECK(hipEventRecord(side.fork, s));
 		HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork, 0));
-		KLAUNCH(k_emit_endpoints, dim3(staged ? nblk(S) : std::min<unsigned>(nblk(S), 160)), dim3(TPB), 0, side.stream, S, dflag, pw.erank,
+		KLAUNCH(k_emit_endpoints, dim3(staged ? nblk((S + 3) / 4) : std::min<unsigned>(nblk((S + 3) / 4), 160)), dim3(TPB), 0, side.stream, S, dflag, pw.erank,
 			pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 		if (staged) {
 			HIP_CHECK(hipMemcpyAsync(host_blk, blk, 2 * p4, hipMemcpyDeviceToHost, side.stream));
@@ -1282,7 +1312,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		}
 		HIP_CHECK(hipEventRecord(side.join, side.stream));
 	} else if (S) {
-		KLAUNCH(k_emit_endpoints, dim3(nblk(S)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
+		KLAUNCH(k_emit_endpoints, dim3(nblk((S + 3) / 4)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
 			sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	}
 	// The (prev, i) intervals of exact cycle-equivalence classes never cross ("Row G"): the check is
