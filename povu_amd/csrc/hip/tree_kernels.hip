@@ -573,43 +573,45 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 // idx, so a result is reproducible).  This replaces two range-min queries per side over segment trees of the far ends'
 // pre-order numbers, and the forest needs no pre-order numbering at all.
 static constexpr uint32_t T0_RBIT = 0x80000000u;
-__global__ void k_t0_parents(uint32_t nS, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
+__global__ void k_t0_parents(uint32_t V, const uint32_t *__restrict__ dist, const uint32_t *__restrict__ ckey,
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle,
 			     const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
 			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, uint4 *__restrict__ xrec, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
-	uint32_t S = BIDX * blockDim.x + threadIdx.x;
-	if (S < C) { // the DFS start of component S roots its tree (no advance arc ever enters its segment)
-		const uint32_t r = comp_root_side(start_key, voff, S), L = 2 * (voff[S + 1] - voff[S] - 1);
+	uint32_t g = BIDX * blockDim.x + threadIdx.x;
+	if (g < C) { // the DFS start of component g roots its tree (no advance arc ever enters its segment)
+		const uint32_t r = comp_root_side(start_key, voff, g), L = 2 * (voff[g + 1] - voff[g] - 1);
 		t0seg[r >> 1] = make_uint4(NIL, (r & 1u) ? T0_RBIT : 0u, 0u, L ? L - 1 : 0u);
 		// the tour of the component covers all its arcs iff the hooks of the union-find are a spanning tree
-		const uint32_t h = heads[S];
+		const uint32_t h = heads[g];
 		if (h == NIL ? L != 0 : dist[h] != L - 1)
 			atomicExch(err, 1u);
 	}
-	if (S >= nS)
+	if (g >= V)
 		return;
-	const uint32_t c = ckey[S >> 1], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
-	const uint32_t lo = loff[S], hi = loff[S + 1];
-	for (uint32_t at = lo; at < hi; at++) {
-		const uint32_t lw = lle[at], le = lw & LLE_ID, w = ladj[at];
-		// a link of the forest is handled once, from the side that met it first = the one of the smaller sorted vertex (a
-		// self loop never is a forest link)
-		if (!(lw & LLE_TREE) || (S >> 1) >= (w >> 1))
+	// One lane per SEGMENT, from the child's end: of the forest slots of a segment exactly one belongs to the link it was
+	// entered through -- the one whose twin (the arc INTO the segment) comes before it in the tour; the slots to its
+	// children come before their twins, and the root has no such slot.  The segment's record is this lane's own 16 bytes
+	// (a lane per link, from the parent's end, scattered them).
+	const uint32_t sb = loff[2 * g], sm = loff[2 * g + 1], se = loff[2 * g + 2];
+	for (uint32_t at = sb; at < se; at++) {
+		const uint32_t lw = lle[at];
+		if (!(lw & LLE_TREE))
 			continue;
-		const uint32_t t = twin[at];
-		const uint32_t da = dist[at], dt = dist[t];
-		const uint32_t pa = abase + (L - 1 - da), pt = abase + (L - 1 - dt); // tour positions of the two arcs
-		const bool down = da > dt;					      // `at` comes first: S is the parent of w
-		const uint32_t child = down ? w : S, parent = down ? S : w, p_in = down ? pa : pt, p_out = down ? pt : pa;
-		t0seg[child >> 1] = make_uint4(parent, le | ((child & 1u) ? T0_RBIT : 0u), p_in, p_out); // ONE scattered 16-byte store
+		const uint32_t t = twin[at], da = dist[at], dt = dist[t];
+		if (dt < da)
+			continue; // a child: its own record names this slot
+		const uint32_t c = ckey[g], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
+		const uint32_t p_in = abase + (L - 1 - dt), p_out = abase + (L - 1 - da); // tour positions of the arc in and the arc back
+		t0seg[g] = make_uint4(ladj[at], (lw & LLE_ID) | (at >= sm ? T0_RBIT : 0u), p_in, p_out);
 		// Most segments have no non-tree link, so the values are kept COMPACT (in tour order, only where a side carries
 		// one): here only the bit of the tour position is set; k_tour_values drops the value at its rank among the set bits.
-		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + (child & ~1u)); // both sides of the child's segment
+		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
 		if ((f2.x | f2.y) & FT_HASH)
 			atomicOr(reinterpret_cast<unsigned long long *>(&xrec[p_in >> 6]), 1ull << (p_in & 63u));
+		break;
 	}
 }
 // The running xor is only ever read at tour positions, but only the positions of segments with non-tree links carry a
@@ -1567,7 +1569,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const uint32_t *dist = tw.dist;
 	const uint32_t XW = NA / 64 + 1; // words of the position bitmap
 	HIP_CHECK(hipMemsetAsync(tw.xrec, 0, ((size_t)XW + 2) * 16, s));
-	LAUNCH(k_t0_parents, std::max(nS, C), s, nS, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, ft, rb.heads,
+	LAUNCH(k_t0_parents, std::max(V, C), s, V, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, ft, rb.heads,
 	       twin, tw.t0seg, tw.xrec, C, start_key, pw.err + 2);
 	tm.end(40);
 
