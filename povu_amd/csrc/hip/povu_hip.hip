@@ -205,7 +205,7 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take(&cs.erank, z.slots + 2, 4);
 		take(&cs.ldeg, nS + 2, 4);
 		take(&cs.loff, nS + 2, 4);
-		take(&cs.ladj, 2 * E + 2, 4);
+		take(&cs.ladj, 2 * E + 8, 4); // (+8: the class walk reads a side's list words four at a time)
 		take(&cs.keys, 2 * E + 2, 4);
 		take(&cs.vals, 2 * E + 2, 4);
 		take(&cs.keys2, 2 * E + 2, 4);

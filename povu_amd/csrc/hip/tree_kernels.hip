@@ -866,26 +866,48 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(const uint32_t *__restri
 		for (;;) {
 			bool adv = false;
 			while (k <= n) {
-				const uint32_t o = k == 0 ? (u ^ 1) : ladj[lo + k - 1];
-				const uint32_t slot = k++;
-				const uint32_t w = cstate[o];
-				if (!(w & CS_VISITED) && !(u == s && o == s_up)) { // not visited yet (hence no entry of another class), not the way up
-					// (loads of the next step before the stores of this one: vmcnt counts both in issue order,
-					// and a wait for a load behind a store waits for the store too)
-					const uint32_t nlo = loff[o], nhi = loff[o + 1];
-					cstate[o] = w | CS_VISITED;
-					dps[o] = make_uint2(u, slot);
-					if (depth < DFS_STK)
-						stk[depth][lane] = make_uint4(u, k, lo, n);
-					depth++;
-					u = o;
-					k = 0;
-					lo = nlo;
-					n = nhi - nlo;
-					adv = true;
-					sides++;
-					break;
+				// The next four candidates at once (slot 0 is the black neighbour, slots 1.. the links): their list words in
+				// one 16-byte load, their state words in four independent gathers -- one round trip for all of them, where a
+				// probe at a time paid two per candidate that turned out visited.  Nobody else writes the states of this
+				// class, and a side that is scanned again after a return loads them afresh.
+				const uint32_t rem = n + 1 - k;
+				uint32_t o0, o1, o2, o3;
+				if (k == 0) {
+					const uint4 x = load4_unaligned(ladj + lo);
+					o0 = u ^ 1u, o1 = x.x, o2 = x.y, o3 = x.z;
+				} else {
+					const uint4 x = load4_unaligned(ladj + lo + k - 1);
+					o0 = x.x, o1 = x.y, o2 = x.z, o3 = x.w;
 				}
+				const uint32_t w0 = cstate[o0];
+				const uint32_t w1 = rem > 1 ? cstate[o1] : CS_VISITED;
+				const uint32_t w2 = rem > 2 ? cstate[o2] : CS_VISITED;
+				const uint32_t w3 = rem > 3 ? cstate[o3] : CS_VISITED;
+				// not visited yet (hence no entry of another class), not the way up
+				auto open = [&](uint32_t o, uint32_t w) { return !(w & CS_VISITED) && !(u == s && o == s_up); };
+				const uint32_t j = open(o0, w0) ? 0u : open(o1, w1) ? 1u : open(o2, w2) ? 2u : open(o3, w3) ? 3u : 4u;
+				if (j == 4) {
+					k += min(rem, 4u);
+					continue;
+				}
+				const uint32_t o = j == 0 ? o0 : j == 1 ? o1 : j == 2 ? o2 : o3, w = j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : w3;
+				const uint32_t slot = k + j;
+				k = slot + 1;
+				// (loads of the next step before the stores of this one: vmcnt counts both in issue order,
+				// and a wait for a load behind a store waits for the store too)
+				const uint32_t nlo = loff[o], nhi = loff[o + 1];
+				cstate[o] = w | CS_VISITED;
+				dps[o] = make_uint2(u, slot);
+				if (depth < DFS_STK)
+					stk[depth][lane] = make_uint4(u, k, lo, n);
+				depth++;
+				u = o;
+				k = 0;
+				lo = nlo;
+				n = nhi - nlo;
+				adv = true;
+				sides++;
+				break;
 			}
 			if (adv) {
 				if (sides > budget) { // a large class: the walk with the short dependent chain starts it over (k_class_dfs)
