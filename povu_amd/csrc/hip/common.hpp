@@ -12,6 +12,15 @@
 
 #define POVU_NIL 0xFFFFFFFFu
 
+// four consecutive words from a 4-byte aligned address in ONE load instruction (global_load_dwordx4 only needs dword
+// alignment); the caller makes sure the array carries three words of slack behind the last one it may name
+__device__ __forceinline__ uint4 load4_unaligned(const unsigned *__restrict__ p)
+{
+	typedef unsigned v4a __attribute__((ext_vector_type(4), aligned(4)));
+	const v4a v = *reinterpret_cast<const v4a *>(p);
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Workgroup index with the 8 XCDs in mind: the dispatcher deals workgroups round-robin over the XCDs (blocks b and b + 8
 // share one, MI355X_MICROARCH.md "Workgroup dispatch"), so neighbouring blocks -- which touch neighbouring lines in
 // almost every kernel here -- land in eight different L2s.  BIDX renumbers the blocks so that every XCD works on one

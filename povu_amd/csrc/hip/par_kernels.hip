@@ -495,7 +495,7 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 		v = 2 * g + c + (c_ntree[c] & 1u) + 1;
 	}
 	uint32_t sz = gsize[v];
-	if (sz == 0 || gpar[v] == NIL) {
+	if (sz == 0 || (!BLACK && gpar[v] == NIL)) { // (the far end of a black edge always has a parent: the entered side)
 		cval[q] = v;
 		ckey[q] = NIL;
 		if (!BLACK)
@@ -519,24 +519,27 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 	// ones, and the top bracket is the first of them: no search at all.
 	const uint32_t live = (hi - lo) - (psin[v + sz] - psin[v]);
 	uint32_t i = NIL;
-	if (live >= 1 && live <= 4) {
-		bool all = true;
-		for (uint32_t k = hi - live; k < hi; k++)
-			all = all && tgtR[k] < v;
+	if (live >= 1 && live <= 4) { // (the four words in one 16-byte load; the array carries slack behind its last entry)
+		const uint4 a = load4_unaligned(tgtR + (hi - live));
+		const bool all = a.x < v && (live < 2 || a.y < v) && (live < 3 || a.z < v) && (live < 4 || a.w < v);
 		if (all)
 			i = hi - live;
 	}
-	// otherwise the top bracket often is one of the first few of the range: probe them linearly
-	// (one cache line) before falling back to the O(log n) descent
+	// otherwise the top bracket often is one of the first few of the range: probe them (one load)
+	// before falling back to the O(log n) descent
 	if (i == NIL) {
-		const uint32_t probe_end = min(hi, lo + 4);
-		for (uint32_t k = lo; k < probe_end; k++)
-			if (tgtR[k] < v) {
-				i = k;
-				break;
-			}
-		if (i == NIL && probe_end < hi)
-			i = seg_first_less(segB, probe_end, hi, v);
+		const uint32_t np = min(hi - lo, 4u);
+		const uint4 a = load4_unaligned(tgtR + lo);
+		if (np > 0 && a.x < v)
+			i = lo;
+		else if (np > 1 && a.y < v)
+			i = lo + 1;
+		else if (np > 2 && a.z < v)
+			i = lo + 2;
+		else if (np > 3 && a.w < v)
+			i = lo + 3;
+		if (i == NIL && lo + np < hi)
+			i = seg_first_less(segB, lo + np, hi, v);
 	}
 	if (i == NIL) {
 		atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket

@@ -95,13 +95,6 @@ __device__ __forceinline__ uint32_t find_link_slot(const uint32_t *__restrict__ 
 			return j - l0 + 1;
 	return 0; // (not reached: a link sits in the lists of both its ends)
 }
-// four consecutive words from a 4-byte aligned address in ONE load instruction (global_load_dwordx4 only needs dword alignment)
-__device__ __forceinline__ uint4 load4_unaligned(const uint32_t *__restrict__ p)
-{
-	typedef uint32_t v4a __attribute__((ext_vector_type(4), aligned(4)));
-	const v4a v = *reinterpret_cast<const v4a *>(p);
-	return make_uint4(v.x, v.y, v.z, v.w);
-}
 // two consecutive words to a 4-byte aligned address in one store instruction
 __device__ __forceinline__ void store2_unaligned(uint32_t *p, uint32_t a, uint32_t b)
 {
