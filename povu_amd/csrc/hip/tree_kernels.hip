@@ -1120,27 +1120,39 @@ __global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps, const uint3
 	const uint2 me = live ? dps[S] : make_uint2(NIL, 0u);
 	const uint32_t p = me.x;
 	uint32_t c = NIL, ns = NIL;
+	// first side behind slot `from` (>= 1) of the list of `par` that names (par, its slot) as its discovery: four list words
+	// in one load and their four records in independent gathers a round (a probe at a time paid two round trips per slot)
+	auto child_behind = [&](uint32_t par, uint32_t lo, uint32_t n, uint32_t from) {
+		for (uint32_t k = from; k <= n; k += 4) {
+			const uint4 x = load4_unaligned(ladj + lo + k - 1);
+			const uint32_t rem = n + 1 - k;
+			const uint2 r0 = dps[x.x];
+			const uint2 r1 = rem > 1 ? dps[x.y] : make_uint2(NIL, 0u);
+			const uint2 r2 = rem > 2 ? dps[x.z] : make_uint2(NIL, 0u);
+			const uint2 r3 = rem > 3 ? dps[x.w] : make_uint2(NIL, 0u);
+			if (r0.x == par && r0.y == k)
+				return x.x;
+			if (r1.x == par && r1.y == k + 1)
+				return x.y;
+			if (r2.x == par && r2.y == k + 2)
+				return x.z;
+			if (r3.x == par && r3.y == k + 3)
+				return x.w;
+		}
+		return NIL;
+	};
 	if (live) {
-		const uint32_t lo = loff[S], n = loff[S + 1] - lo;
-		for (uint32_t k = 0; k <= n; k++) {
-			const uint32_t o = k == 0 ? (S ^ 1u) : ladj[lo + k - 1];
-			const uint2 r = dps[o];
-			if (r.x == S && r.y == k) {
-				c = o;
-				break;
-			}
+		const uint2 r = dps[S ^ 1u]; // slot 0: the black edge
+		if (r.x == S && r.y == 0) {
+			c = S ^ 1u;
+		} else {
+			const uint32_t lo = loff[S], n = loff[S + 1] - lo;
+			c = child_behind(S, lo, n, 1u);
 		}
 	}
 	if (live && p != NIL) {
 		const uint32_t lo = loff[p], n = loff[p + 1] - lo;
-		for (uint32_t k = me.y + 1; k <= n; k++) {
-			const uint32_t o = ladj[lo + k - 1];
-			const uint2 r = dps[o];
-			if (r.x == p && r.y == k) {
-				ns = o;
-				break;
-			}
-		}
+		ns = child_behind(p, lo, n, me.y + 1);
 	}
 	const bool far = live && p == (S ^ 1u); // S is the far side o of its segment (its parent is the entered side)
 	// what follows "leave the entered side": its next sibling, else the leave of its parent, else nothing (DFS start)
