@@ -1326,29 +1326,39 @@ __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint
 	}
 	const uint32_t dp = dps[S].x;
 	bool loop_seen = false;
-	for (uint32_t k = lo; k < hi; k++) {
-		const uint32_t o = ladj[k];
-		if (o == (S ^ 1)) {
-			if (dp == o && !loop_seen)
-				out(side_tidx[o]);
-			loop_seen = true;
-			continue;
+	// four slots a round: their far sides in one 16-byte load, the tree vertices of those in four independent gathers
+	for (uint32_t k0 = lo; k0 < hi; k0 += 4) {
+		const uint4 o4 = load4_unaligned(ladj + k0);
+		const uint32_t rem = hi - k0;
+		const uint32_t os[4] = {o4.x, o4.y, o4.z, o4.w};
+		const uint32_t xs[4] = {side_tidx[o4.x], rem > 1 ? side_tidx[o4.y] : NIL, rem > 2 ? side_tidx[o4.z] : NIL,
+					rem > 3 ? side_tidx[o4.w] : NIL};
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			if (q >= rem)
+				break;
+			const uint32_t k = k0 + q, o = os[q], x = xs[q];
+			if (o == (S ^ 1)) {
+				if (dp == o && !loop_seen)
+					out(x);
+				loop_seen = true;
+				continue;
+			}
+			if (x > p || o == dp)
+				continue;
+			bool dup = false;
+			if (dupflag) {
+				dup = dupflag[k] != 0;
+			} else {
+				for (uint32_t j = lo; j < k; j++)
+					if (ladj[j] == o) {
+						dup = true;
+						break;
+					}
+			}
+			if (!dup)
+				out(x);
 		}
-		const uint32_t x = side_tidx[o];
-		if (x > p || o == dp)
-			continue;
-		bool dup = false;
-		if (dupflag) {
-			dup = dupflag[k] != 0;
-		} else {
-			for (uint32_t j = lo; j < k; j++)
-				if (ladj[j] == o) {
-					dup = true;
-					break;
-				}
-		}
-		if (!dup)
-			out(x);
 	}
 	return n;
 }
