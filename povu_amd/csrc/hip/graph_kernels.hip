@@ -552,21 +552,33 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 		lle[base + j] = le;
 		ladj[base + j] = other;
 	};
-	for (uint32_t k = lo; k < hi; k++, P++) {
-		const uint32_t o = aoth[k], vo = o >> 1;
-		const bool loop = vo == v;
-		const uint32_t tree = hook[adj[k]] ? LLE_TREE : 0u;
-		if (loop) {
-			if (!slot_is_first(i, s, v, o, pos))
-				continue; // the l-r loop's r slot: the l side owns the edge, this side gets it below
-			insert(P | tree, S ^ 1u);
-			continue;
+	// four slots a round: far sides, link ids and twin slots in one 16-byte load each, the forest flags of the four links in
+	// independent gathers (the global arrays carry slack behind their last slot)
+	for (uint32_t k0 = lo; k0 < hi; k0 += 4) {
+		const uint4 o4 = load4_unaligned(aoth + k0), e4 = load4_unaligned(adj + k0), t4 = load4_unaligned(atwin + k0);
+		const uint32_t rem = hi - k0;
+		const uint32_t os[4] = {o4.x, o4.y, o4.z, o4.w}, ts[4] = {t4.x, t4.y, t4.z, t4.w};
+		const uint32_t hs[4] = {hook[e4.x], rem > 1 ? hook[e4.y] : 0u, rem > 2 ? hook[e4.z] : 0u, rem > 3 ? hook[e4.w] : 0u};
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			if (q >= rem)
+				break;
+			const uint32_t o = os[q], vo = o >> 1, Pq = P + q;
+			const bool loop = vo == v;
+			const uint32_t tree = hs[q] ? LLE_TREE : 0u;
+			if (loop) {
+				if (!slot_is_first(i, s, v, o, pos))
+					continue; // the l-r loop's r slot: the l side owns the edge, this side gets it below
+				insert(Pq | tree, S ^ 1u);
+				continue;
+			}
+			const uint32_t io = pos ? pos[vo] : vo, other = 2 * io + (o & 1u);
+			if (i < io) // first encounter: the link is named after this slot
+				insert(Pq | tree, other);
+			else
+				insert((sbase ? sbase[io] + (ts[q] - off[2 * vo]) : ts[q]) | tree, other);
 		}
-		const uint32_t io = pos ? pos[vo] : vo, other = 2 * io + (o & 1u);
-		if (i < io) // first encounter: the link is named after this slot
-			insert(P | tree, other);
-		else
-			insert((sbase ? sbase[io] + (atwin[k] - off[2 * vo]) : atwin[k]) | tree, other);
+		P += 4;
 	}
 	if (any_loop) { // (a graph without self loops: nothing of the other side's list belongs here)
 		lo = off[2 * v + (1 - s)], hi = off[2 * v + (1 - s) + 1], P = sb + (lo - b0);

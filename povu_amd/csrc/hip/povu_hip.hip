@@ -89,7 +89,7 @@ void alloc_resident_graph(Arena &arena, ResidentGraph &g, uint32_t n_vtx, uint32
 	g.tips_given = tips_given;
 	const size_t V = n_vtx, E = n_links;
 	const size_t bytes = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
-			     Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 2, 4) + 16 * 256;
+			     Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 8, 4) + 16 * 256;
 	arena.reserve(bytes);
 	g.vid = arena.take<uint32_t>(V);
 	g.block = g.vid;
@@ -99,9 +99,9 @@ void alloc_resident_graph(Arena &arena, ResidentGraph &g, uint32_t n_vtx, uint32
 	g.s2 = arena.take<uint8_t>(E + 1);
 	g.tip = arena.take<uint8_t>(V);
 	g.off = arena.take<uint32_t>(2 * V + 2);
-	g.adj = arena.take<uint32_t>(2 * E + 2);
-	g.aoth = arena.take<uint32_t>(2 * E + 2);
-	g.atwin = arena.take<uint32_t>(2 * E + 2);
+	g.adj = arena.take<uint32_t>(2 * E + 8); // (+8: kernels read a side's slots four at a time)
+	g.aoth = arena.take<uint32_t>(2 * E + 8);
+	g.atwin = arena.take<uint32_t>(2 * E + 8);
 }
 
 void check_graph_size(uint32_t n_vtx, uint32_t n_links)
