@@ -142,59 +142,86 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 	const uint32_t lo = loff[S], hi = loff[S + 1];
 	ulonglong2 h = make_ulonglong2(0ull, 0ull);
 	uint32_t first = NIL;
-	for (uint32_t at = lo; at < hi; at++) {
-		const uint32_t lw = lle[at], le = lw & LLE_ID;
-		if (!(lw & LLE_TREE)) {
-			pk[at] = PK_END | PK_STOP;
-			h = hx(h, link_hash(le));
-			continue;
-		}
-		if (first == NIL)
-			first = at;
-		// The slots of w's SEGMENT (l side, then r side: one index range) answer both questions -- where the link sits in
-		// w's list (its twin) and which forest slot follows the twin around the segment.  A gather whose 64 lanes hit 64
-		// lines keeps the CU's address unit busy for 64 cycles whatever it returns, and this kernel is bound by exactly
-		// that: a segment with at most eight slots (nearly all) is fetched with two offset loads and one or two 16-byte
-		// loads, and searched in registers.
-		const uint32_t w = ladj[at], g2 = w & ~1u;
-		const uint2 o01 = *reinterpret_cast<const uint2 *>(loff + g2); // (g2 is even: 8-byte aligned)
-		const uint32_t sb = o01.x, se = loff[g2 + 2];
-		const uint32_t wl = (w & 1u) ? o01.y : sb, wh = (w & 1u) ? se : o01.y; // w's own slots
-		uint32_t t, nxt;
-		if (se - sb <= 8) {
-			const uint32_t n = se - sb, tl = wl - sb, th = wh - sb;
-			const uint4 a = load4_unaligned(lle + sb);
-			uint4 c = make_uint4(0u, 0u, 0u, 0u);
-			if (n > 4)
-				c = load4_unaligned(lle + sb + 4);
-			const uint32_t r[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-			uint32_t tk = 0, first_tree = NIL, after = NIL;
+	// The slots of the far side's SEGMENT (l side, then r side: one index range) answer both questions about a forest slot
+	// -- where the link sits in the far side's list (its twin) and which forest slot follows the twin around the segment.
+	// A gather whose 64 lanes hit 64 lines keeps the CU's address unit busy for 64 cycles whatever it returns, and this
+	// kernel is bound by exactly that: four slots are taken a round, in phases, so that the loads of one phase are all in
+	// flight together -- own words (two 16-byte loads), the far segments' offsets, their slot words (a segment with at
+	// most eight slots, nearly all, in one or two 16-byte loads, searched in registers).
+	for (uint32_t at0 = lo; at0 < hi; at0 += 4) {
+		const uint32_t rem = hi - at0;
+		const uint4 lw4 = load4_unaligned(lle + at0), w4 = load4_unaligned(ladj + at0);
+		const uint32_t lws[4] = {lw4.x, lw4.y, lw4.z, lw4.w}, ws[4] = {w4.x, w4.y, w4.z, w4.w};
+		bool tree[4];
+		uint2 o01[4];
+		uint32_t se[4];
 #pragma unroll
-			for (uint32_t k = 0; k < 8; k++)
-				if (k >= tl && k < th && (r[k] & LLE_ID) == le)
-					tk = k;
-#pragma unroll
-			for (uint32_t k = 0; k < 8; k++)
-				if (k < n && (r[k] & LLE_TREE)) {
-					if (first_tree == NIL)
-						first_tree = k;
-					if (k > tk && after == NIL)
-						after = k;
-				}
-			t = sb + tk;
-			nxt = sb + (after != NIL ? after : (first_tree < tk ? first_tree : tk)); // (the twin itself is a forest slot: first_tree <= tk)
-		} else {
-			t = wl + find_link_slot(loff, lle, w, le) - 1;
-			nxt = t;
-			for (uint32_t j = t + 1; j < se && nxt == t; j++)
-				if (lle[j] & LLE_TREE)
-					nxt = j;
-			for (uint32_t j = sb; j < t && nxt == t; j++)
-				if (lle[j] & LLE_TREE)
-					nxt = j;
+		for (uint32_t q = 0; q < 4; q++) {
+			tree[q] = q < rem && (lws[q] & LLE_TREE);
+			o01[q] = make_uint2(0u, 0u);
+			se[q] = 0;
+			if (tree[q]) {
+				const uint32_t g2 = ws[q] & ~1u;
+				o01[q] = *reinterpret_cast<const uint2 *>(loff + g2); // (g2 is even: 8-byte aligned)
+				se[q] = loff[g2 + 2];
+			}
 		}
-		twin[at] = t; // (k_t0_parents needs it again)
-		pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
+		uint4 a[4];
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			a[q] = make_uint4(0u, 0u, 0u, 0u);
+			if (tree[q] && se[q] - o01[q].x <= 8)
+				a[q] = load4_unaligned(lle + o01[q].x);
+		}
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			if (q >= rem)
+				break;
+			const uint32_t at = at0 + q, lw = lws[q], le = lw & LLE_ID;
+			if (!tree[q]) {
+				pk[at] = PK_END | PK_STOP;
+				h = hx(h, link_hash(le));
+				continue;
+			}
+			if (first == NIL)
+				first = at;
+			const uint32_t w = ws[q], sb = o01[q].x;
+			const uint32_t wl = (w & 1u) ? o01[q].y : sb, wh = (w & 1u) ? se[q] : o01[q].y; // w's own slots
+			uint32_t t, nxt;
+			if (se[q] - sb <= 8) {
+				const uint32_t n = se[q] - sb, tl = wl - sb, th = wh - sb;
+				uint4 c = make_uint4(0u, 0u, 0u, 0u);
+				if (n > 4)
+					c = load4_unaligned(lle + sb + 4);
+				const uint32_t r[8] = {a[q].x, a[q].y, a[q].z, a[q].w, c.x, c.y, c.z, c.w};
+				uint32_t tk = 0, first_tree = NIL, after = NIL;
+#pragma unroll
+				for (uint32_t k = 0; k < 8; k++)
+					if (k >= tl && k < th && (r[k] & LLE_ID) == le)
+						tk = k;
+#pragma unroll
+				for (uint32_t k = 0; k < 8; k++)
+					if (k < n && (r[k] & LLE_TREE)) {
+						if (first_tree == NIL)
+							first_tree = k;
+						if (k > tk && after == NIL)
+							after = k;
+					}
+				t = sb + tk;
+				nxt = sb + (after != NIL ? after : (first_tree < tk ? first_tree : tk)); // (the twin itself is a forest slot: first_tree <= tk)
+			} else {
+				t = wl + find_link_slot(loff, lle, w, le) - 1;
+				nxt = t;
+				for (uint32_t jj = t + 1; jj < se[q] && nxt == t; jj++)
+					if (lle[jj] & LLE_TREE)
+						nxt = jj;
+				for (uint32_t jj = sb; jj < t && nxt == t; jj++)
+					if (lle[jj] & LLE_TREE)
+						nxt = jj;
+			}
+			twin[at] = t; // (k_t0_parents needs it again)
+			pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
+		}
 	}
 	const bool nz = !hzero(h);
 	if (nz)
