@@ -9,7 +9,8 @@
 //   1. spanning forest of H  (black edges + the links that won a hook in the WCC union-find)
 //   2. root it at the DFS start side: Euler tour over the forest of segments + list ranking (random splitters, recursive)
 //   3. bridges: a tree edge is a bridge iff the xor of TWO independent hashes of the non-tree links over its subtree's
-//      stretch of the tour vanishes (running xor over tour positions)
+//      stretch of the tour vanishes (running xor over the values in tour order, kept compact behind a bitmap of the
+//      positions that carry one)
 //   4. 2-edge-connected classes = the pieces of the rooted forest when its bridges are cut (never numbered)
 //   5. per class: entry side = top of the class, DFS parent = far end of its bridge
 //   6. the reference DFS inside every class: ONE LANE per small class (pangenome graphs are chains of small bubbles, so
@@ -20,6 +21,12 @@
 //   8. tree arrays in pre-order (T-space, as the class stage reads them) + the from_bd back edges (de-duplication rules
 //      of :360-398)
 // tests/test_parallel_tree_model.py checks this formulation against the oracle on the CPU.
+//
+// How the kernels are shaped ("What bounds the pass"): nearly every kernel here is bound by the
+// vector-memory instructions its CU retires, so they issue few and wide ones -- one lane per SEGMENT where the two sides
+// ask different questions (k_bridges, k_tree_emit, k_t0_parents), four slots of an adjacency list a round with 16-byte
+// loads and the gathers they lead to issued together (k_tour_words, k_events, side_back_edges, k_class_dfs_small), four
+// elements a lane where a kernel only streams (k_entry_flags).
 #include "tree_kernels.hpp"
 
 #include <cstdlib>
@@ -1114,7 +1121,7 @@ __global__ void k_walk_finish(uint32_t nS, const uint32_t *__restrict__ wpar, co
 		return;
 	const uint32_t p = wpar[S];
 	if (p == W_UNVIS || (pbr[S] & PB_BRIDGE))
-		return; // not reached by a wave walk / an entry (k_entries wrote its record)
+		return; // not reached by a wave walk / an entry (k_bridges wrote its record)
 	uint32_t slot = 0;
 	if (S != (p ^ 1u)) {
 		const uint32_t lo = loff[p], hi = loff[p + 1];
