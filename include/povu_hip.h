@@ -78,7 +78,7 @@ typedef struct {
 #define POVU_HIP_F_REDO_ODD 256u /* treat every second component as flagged for the sequential redo (tests of the mixed result) */
 #define POVU_HIP_F_NO_STAGE_TIMES 32u /* record only the pass total, not the per-stage HIP events */
 #define POVU_HIP_F_BIG_CLASS_DFS 64u /* always walk the classes with the filtered-scan-list DFS large classes get (A/B testing) */
-#define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with the 1-in-16 splitters lists of 2^26+ elements get (A/B testing) */
+#define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with 1-in-16 splitters instead of 1-in-8 (A/B testing) */
 #define POVU_HIP_F_ALL_VERTEX_CLASSES 512u /* number the cycle classes of all tree edges, not just the black ones the candidate stack holds (A/B testing) */
 #define POVU_HIP_F_CHECK_LAMINAR 1024u /* always run the laminarity check of the candidate stack's (prev, i) intervals; by default it only runs when the literal hi_2 rule capped differently from the second-highest reach, DESIGN.md section 4 has the proof for the other case (A/B testing, fuzzing) */
 #define POVU_HIP_F_LEAF_SUBFLUBBLES 2048u /* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) and find_parallel (parallel.cpp:263-287) on every PVST; the forest then also carries ai / zi and the line letter of every vertex (povu_hip_forest_get_sub).  Not the reference's whole `-s`: its three inserting passes are not built */

@@ -55,8 +55,14 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 // (multiplicative hash of the bucket idx).  So the splitter of bucket q is computed, not looked up; a splitter's id on
 // the next level IS its bucket idx (dense, no flag array, no scan, no compaction), and lane q of a walk kernel works
 // near element q * 2^b (the scattered rank stores of neighbouring lanes meet again in L2).
-// b = 3 (1 in 8) for short lists, whose walks are bound by their longest segment; b = 4 for lists of 2^26+ elements.
-static unsigned rank_bucket_bits(size_t n) { return n < (size_t(1) << 26) ? 3u : 4u; }
+// b = 3 (1 in 8): short segments, whose walks are bound by their longest one; b = 4 is kept as an A/B switch.
+static unsigned rank_bucket_bits(size_t n)
+{
+	if (const char *ev = getenv("POVU_HIP_RANK_BITS")) // (tuning hook)
+		return (unsigned)std::min(6, std::max(2, atoi(ev)));
+	(void)n;
+	return 3u; // (1 in 16 measured 0.2 ms slower on 2.4e8 slots once the other kernels had changed; POVU_HIP_F_SPARSE_SPLITTERS still forces it)
+}
 static constexpr uint32_t PK_END = 0x1FFFFFFFu, PK_HEAD = 0x40000000u, PK_STOP = 0x80000000u;
 static constexpr uint32_t FT_NONE = 0x7FFFFFFFu, FT_HASH = 0x80000000u; // ft words: first arc of a side | "its hash word was written"
 __device__ __forceinline__ uint32_t bucket_splitter(uint32_t q, unsigned b) { return (q << b) | ((q * 0x9E3779B1u) >> (32u - b)); }
