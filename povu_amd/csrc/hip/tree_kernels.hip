@@ -1151,15 +1151,25 @@ __global__ void k_walk_finish(uint32_t nS, const uint32_t *__restrict__ wpar, co
 // "enter" heads the list of its component iff e is the DFS start of a processed component (segments of other
 // components get inert words).  merged[g] remembers which form the segment took.
 __device__ __forceinline__ uint32_t leave_event(uint32_t p, bool p_is_far) { return 3 * (p >> 1) + (p_is_far ? 1u : 2u); }
-__global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps, const uint32_t *__restrict__ loff,
+__global__ void k_events(uint32_t V, const uint2 *__restrict__ dps, const uint32_t *__restrict__ loff,
 			 const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc,
 			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b, uint8_t *__restrict__ merged)
 {
-	uint32_t S = BIDX * blockDim.x + threadIdx.x; // (nS is even and the workgroup size too: S and S ^ 1 are lanes of one wave)
-	const bool live = S < nS;
-	const uint2 me = live ? dps[S] : make_uint2(NIL, 0u);
-	const uint32_t p = me.x;
-	uint32_t c = NIL, ns = NIL;
+	// One lane per SEGMENT: it needs the first child of the far side o, the next sibling of o (= the first gray child of the
+	// entered side e, whose first child is o itself) and the next sibling of e -- three searches, the records of both sides
+	// in one 16-byte load, the three words written by the lane that worked them out.
+	const uint32_t g = BIDX * blockDim.x + threadIdx.x;
+	if (g >= V)
+		return;
+	const uint32_t A = 3 * g;
+	const uint4 d4 = *reinterpret_cast<const uint4 *>(dps + 2 * g);
+	if (d4.x != 2 * g + 1 && d4.z != 2 * g) { // a segment outside the decomposed components: three inert words
+		pk[A] = pk[A + 1] = pk[A + 2] = PK_END | PK_STOP;
+		merged[g] = 1;
+		return;
+	}
+	const uint32_t o = d4.x == 2 * g + 1 ? 2 * g : 2 * g + 1, e = o ^ 1u; // far side: its DFS parent is the other side
+	const uint32_t p = (e & 1u) ? d4.z : d4.x, slot_e = (e & 1u) ? d4.w : d4.y;
 	// first side behind slot `from` (>= 1) of the list of `par` that names (par, its slot) as its discovery: four list words
 	// in one load and their four records in independent gathers a round (a probe at a time paid two round trips per slot)
 	auto child_behind = [&](uint32_t par, uint32_t lo, uint32_t n, uint32_t from) {
@@ -1181,41 +1191,21 @@ __global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps, const uint3
 		}
 		return NIL;
 	};
-	if (live) {
-		const uint2 r = dps[S ^ 1u]; // slot 0: the black edge
-		if (r.x == S && r.y == 0) {
-			c = S ^ 1u;
-		} else {
-			const uint32_t lo = loff[S], n = loff[S + 1] - lo;
-			c = child_behind(S, lo, n, 1u);
-		}
-	}
-	if (live && p != NIL) {
-		const uint32_t lo = loff[p], n = loff[p + 1] - lo;
-		ns = child_behind(p, lo, n, me.y + 1);
-	}
-	const bool far = live && p == (S ^ 1u); // S is the far side o of its segment (its parent is the entered side)
+	const uint2 s01 = *reinterpret_cast<const uint2 *>(loff + 2 * g);
+	const uint32_t s2 = loff[2 * g + 2];
+	const uint32_t lo_o = (o & 1u) ? s01.y : s01.x, n_o = ((o & 1u) ? s2 : s01.y) - lo_o;
+	const uint32_t lo_e = (e & 1u) ? s01.y : s01.x, n_e = ((e & 1u) ? s2 : s01.y) - lo_e;
+	const uint32_t c_o = child_behind(o, lo_o, n_o, 1u);  // first child of the far side
+	const uint32_t ns_o = child_behind(e, lo_e, n_e, 1u); // next sibling of the far side = first gray child of the entered side
 	// what follows "leave the entered side": its next sibling, else the leave of its parent, else nothing (DFS start)
 	uint32_t after_e = NIL;
-	if (live && !far) {
-		if (ns != NIL)
-			after_e = 3 * (ns >> 1);
-		else if (p != NIL)
-			after_e = leave_event(p, dps[p].x == (p ^ 1u));
+	if (p != NIL) {
+		const uint32_t lo_p = loff[p], n_p = loff[p + 1] - lo_p;
+		const uint32_t ns_e = child_behind(p, lo_p, n_p, slot_e + 1);
+		after_e = ns_e != NIL ? 3 * (ns_e >> 1) : leave_event(p, dps[p].x == (p ^ 1u));
 	}
-	// the far side's lane writes the segment's three words; it gets the entered side's part from the neighbouring lane
-	const uint32_t e_after = __shfl_xor(after_e, 1);
-	const uint32_t e_par = __shfl_xor(p, 1);
-	const bool other_far = __shfl_xor(far ? 1 : 0, 1) != 0;
-	if (live && !far && !other_far && !(S & 1u)) { // a segment outside the decomposed components: three inert words
-		pk[3 * (S >> 1)] = pk[3 * (S >> 1) + 1] = pk[3 * (S >> 1) + 2] = PK_END | PK_STOP;
-		merged[S >> 1] = 1;
-	}
-	if (!far)
-		return;
-	const uint32_t g = S >> 1, A = 3 * g;
-	uint32_t enter = rank_pack(c != NIL ? 3 * (c >> 1) : A + 1, 0u, b);
-	if (e_par == NIL) {
+	uint32_t enter = rank_pack(c_o != NIL ? 3 * (c_o >> 1) : A + 1, 0u, b);
+	if (p == NIL) {
 		const uint32_t comp = ckey[g];
 		if (cproc[comp]) {
 			enter |= PK_HEAD;
@@ -1223,12 +1213,12 @@ __global__ void k_events(uint32_t nS, const uint2 *__restrict__ dps, const uint3
 		}
 	}
 	pk[A] = enter;
-	if (ns != NIL) { // the entered side has more children: leave o -> the first of them; leave e on its own
-		pk[A + 1] = rank_pack(3 * (ns >> 1), 0u, b);
-		pk[A + 2] = rank_pack(e_after, 0u, b);
+	if (ns_o != NIL) { // the entered side has more children: leave o -> the first of them; leave e on its own
+		pk[A + 1] = rank_pack(3 * (ns_o >> 1), 0u, b);
+		pk[A + 2] = rank_pack(after_e, 0u, b);
 		merged[g] = 0;
 	} else {
-		pk[A + 1] = rank_pack(e_after, 1u, b); // both leaves in one
+		pk[A + 1] = rank_pack(after_e, 1u, b); // both leaves in one
 		pk[A + 2] = PK_END | PK_STOP;
 		merged[g] = 1;
 	}
@@ -1710,7 +1700,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(n_events);
 	uint8_t *merged = tw.dvis; // [V] (the visited bytes of the class walk are dead)
 	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
-	LAUNCH(k_events, nS, s, nS, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged);
+	LAUNCH(k_events, V, s, V, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged);
 	list_rank_splitters<true, true>(n_events, bitsE, nullptr, tw.evt, C, rb, s);
 	(void)event_lists;
 	tm.end(40);
