@@ -289,6 +289,12 @@ int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t 
  * resident graph itself (~42 B/link + 13 B/segment) and the sequential kernels' lists; n_components = 0
  * assumes the worst case (every segment its own component); 0 when it cannot be computed */
 uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components);
+/* Reserves the device memory a graph of this size will need (resident graph, CSR build scratch, decompose workspace for
+ * the worst case of components) on a context that holds nothing yet, so that the first upload + decompose do not pay for
+ * the allocation: meant to run on another thread while the caller still parses its input (the CLI does).  Best effort:
+ * returns 0 and reserves nothing when the worst case does not fit; 1 + message only for bad arguments / HIP errors.  Must
+ * not run concurrently with another call on the same context. */
+int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_links, char *err, size_t errlen);
 /* upper bound of the EXTRA device memory POVU_HIP_F_LEAF_SUBFLUBBLES takes while its stage runs (allocated and released
  * inside the call; n_components = 0: not known) */
 uint64_t povu_hip_leaf_workspace_estimate(uint32_t n_vtx, uint32_t n_components);

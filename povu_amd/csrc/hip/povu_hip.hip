@@ -398,6 +398,52 @@ extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links
 	}
 }
 
+// Reserve, ahead of time, the device arenas a graph of this size will need (the resident graph, the CSR build's scratch and
+// the decompose workspace for a graph of few components): the first upload + decompose on a fresh context otherwise
+// pay for ~2 KB of device memory per segment being mapped (0.5 - 3 s for a whole-genome graph).  The CLI calls this on
+// the thread that brought HIP up, as soon as the tokenizer knows the counts and while the rest of the parse runs.
+// Best effort: when that does not fit, the arenas are left alone and the real calls allocate exactly.
+extern "C" int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_links, char *err, size_t errlen)
+{
+	try {
+		if (!ctx)
+			throw HipError("null context");
+		if (ctx->g.block || ctx->have_state)
+			return 0; // (only for a context that holds nothing yet: a reserve invalidates what an arena holds)
+		check_graph_size(n_vtx, n_links);
+		HIP_CHECK(hipSetDevice(ctx->device));
+		const size_t V = n_vtx, E = n_links, nS = 2 * V;
+		size_t free_b = 0, total_b = 0;
+		HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+		const size_t graph_b = Arena::padded(V, 4) + 2 * Arena::padded(E + 1, 4) + 2 * Arena::padded(E + 1, 1) + Arena::padded(V, 1) +
+				       Arena::padded(2 * V + 2, 4) + 3 * Arena::padded(2 * E + 8, 4) + 16 * 256;
+		const size_t tmp_b = Arena::padded(2 * E + 2, 4) * 4 + Arena::padded(nS + 2, 4) + sort_tmp_bytes(2 * E) +
+				     scan_tmp_bytes(std::max<size_t>(nS, E) + 2) + (1 << 16);
+		Sizes z;
+		// (components: a guess -- a pangenome graph has few, and a larger count only means that the decompose call grows
+		// its arena after all; reserving for V components took three times as long as the exact size)
+		z.V = V, z.E = E, z.nS = nS, z.slots = 2 * E, z.Cmax = V, z.T = z.B = 0; // (rows A/B are sized before the count is known)
+		CompState cs{};
+		SeqWs sw{};
+		const size_t ws_b = carve_workspace(nullptr, 0, z, cs, sw, false);
+		z.Cmax = std::min<size_t>(V, std::max<size_t>(1024, V / 64));
+		z.T = 2 * V + z.Cmax;
+		z.B = E + V + 2 * z.T;
+		const size_t ws2_b = carve_workspace(nullptr, 1, z, cs, sw, false) + par_workspace_bytes(V, E, z.Cmax) + tree_workspace_bytes(V, E, z.Cmax);
+		const size_t need = graph_b + tmp_b + ws_b + ws2_b;
+		if (need + need / 8 + (size_t(64) << 20) > free_b)
+			return 0; // the worst case does not fit beside what is there: let the real calls size things
+		ctx->graph_arena.reserve(graph_b);
+		ctx->upload_tmp.reserve(tmp_b);
+		ctx->ws.reserve(ws_b);
+		ctx->ws2.reserve(ws2_b);
+		return 0;
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return 1;
+	}
+}
+
 extern "C" uint64_t povu_hip_leaf_workspace_estimate(uint32_t n_vtx, uint32_t n_components)
 {
 	// the PVST of a component has at most one vertex per segment and a root

@@ -37,16 +37,35 @@ void do_decompose(const Config &cfg)
 	const double t0 = now_ms();
 	// the HIP runtime comes up (~0.1 s) while the GFA is being parsed
 	char err[512] = {0}, cerr_buf[512] = {0};
-	std::future<povu_hip_ctx *> ctx_f =
-		std::async(std::launch::async, [&]() { return povu_hip_create(cfg.device, cerr_buf, sizeof cerr_buf); });
+	// ... and as soon as the tokenizer knows how many segments and links there are, the same thread reserves the device
+	// memory the graph will need (povu_hip_prewarm) while the parse goes on
+	std::promise<std::pair<size_t, size_t>> counts_p;
+	std::future<std::pair<size_t, size_t>> counts_f = counts_p.get_future();
+	std::future<povu_hip_ctx *> ctx_f = std::async(std::launch::async, [&]() {
+		povu_hip_ctx *c = povu_hip_create(cfg.device, cerr_buf, sizeof cerr_buf);
+		const std::pair<size_t, size_t> n = counts_f.get(); // ({0, 0}: the parse failed before it knew)
+		if (c && n.first && n.first < 0xFFFFFFFFull && n.second < 0xFFFFFFFFull) {
+			char perr[256];
+			(void)povu_hip_prewarm(c, (uint32_t)n.first, (uint32_t)n.second, perr, sizeof perr); // (best effort)
+		}
+		return c;
+	});
 	GfaGraph g;
+	bool counted = false;
 	try {
-		g = load_gfa(cfg.input_gfa, false, false, cfg.threads);
+		g = load_gfa(cfg.input_gfa, false, false, cfg.threads, [&](size_t v, size_t e) {
+			counted = true;
+			counts_p.set_value({v, e});
+		});
 	} catch (...) {
+		if (!counted)
+			counts_p.set_value({0, 0});
 		if (povu_hip_ctx *c = ctx_f.get())
 			povu_hip_destroy(c);
 		throw;
 	}
+	if (!counted)
+		counts_p.set_value({0, 0});
 	const double t1 = now_ms();
 	povu_hip_ctx *ctx = ctx_f.get();
 	if (!ctx)

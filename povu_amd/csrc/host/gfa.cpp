@@ -231,7 +231,8 @@ void parallel_ranges(size_t T, size_t n, F &&fn)
 }
 } // namespace
 
-GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int threads)
+GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int threads,
+		  const std::function<void(size_t, size_t)> &on_counts)
 {
 	Mapped f(fp);
 	GfaGraph g;
@@ -284,6 +285,8 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	const size_t n_seg = seg_at[T], E = link_at[T];
 	if (n_seg == 0)
 		throw std::runtime_error(invalid(fp, "liteseq returned no vertices"));
+	if (on_counts)
+		on_counts(n_seg, E);
 	// every thread moves its slice to its place in the final arrays
 	std::vector<uint32_t> la(E), lb(E);
 	g.vid.resize(n_seg);

@@ -7,6 +7,7 @@
 // validate_gfa_for_liteseq (from_gfa.cpp:28-98).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,9 @@ struct GfaGraph {
 
 // throws std::runtime_error("Invalid GFA '<path>': ...") for the first malformed record in file order;
 // `threads` tokenizer threads share the file (slices of whole lines, >= 4 MiB each)
-GfaGraph load_gfa(const std::string &path, bool want_labels = false, bool want_paths = false, int threads = 1);
+// on_counts(segments, links), when given, is called once as soon as the tokenizer knows both numbers (the stitching and
+// the link mapping still lie ahead): the CLI uses it to have the device memory reserved meanwhile
+GfaGraph load_gfa(const std::string &path, bool want_labels = false, bool want_paths = false, int threads = 1,
+		  const std::function<void(size_t, size_t)> &on_counts = nullptr);
 
 } // namespace povu_host
