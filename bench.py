@@ -149,7 +149,7 @@ def end_to_end_cli(g, wl):
         H.write_gfa(g, gfa)
         t_write_gfa = time.perf_counter() - t0
         size = os.path.getsize(gfa)
-        threads = str(min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
+        threads = str(min(int(os.environ.get("POVU_BENCH_CLI_THREADS", "32")), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
         env = dict(os.environ, POVU_STAGE_COST_TRACE="1")
         # process start + HIP bring-up alone: the CLI on a one-segment graph
         tiny = os.path.join(d, "tiny.gfa")
