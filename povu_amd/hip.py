@@ -121,6 +121,8 @@ def load_lib():
                                       C.c_size_t]
     l.povu_hip_workspace_estimate.restype = C.c_uint64
     l.povu_hip_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    l.povu_hip_prewarm.restype = C.c_int
+    l.povu_hip_prewarm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
     l.povu_hip_leaf_workspace_estimate.restype = C.c_uint64
     l.povu_hip_leaf_workspace_estimate.argtypes = [C.c_uint32, C.c_uint32]
     # ---- multi-GPU sharding
@@ -392,6 +394,12 @@ class HipDecomposer:
         rc = self._lib.povu_hip_graph_upload(self._ctx, len(vid), vid.ctypes.data, len(v1), v1.ctypes.data,
                                              s1.ctypes.data, v2.ctypes.data, s2.ctypes.data, tp, err, 512)
         if rc != 0:
+            raise RuntimeError(err.value.decode())
+
+    def prewarm(self, n_vtx: int, n_links: int) -> None:
+        """Reserve the device memory a graph of this size will need (povu_hip_prewarm; only on a context that holds nothing)."""
+        err = C.create_string_buffer(512)
+        if self._lib.povu_hip_prewarm(self._ctx, n_vtx, n_links, err, 512) != 0:
             raise RuntimeError(err.value.decode())
 
     def upload_times(self) -> dict:

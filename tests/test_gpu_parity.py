@@ -958,3 +958,25 @@ def test_black_edge_only_class_pass(hip, golden_dir):
         used[int(hip.last_black_only_classes())] += 1
         assert hip.decompose(flags=F_ALL_VERTEX_CLASSES).texts() == want, seed
     assert used[0] > 0 and used[1] > 0, used
+
+
+def test_prewarm_reserves_without_changing_results():
+    """povu_hip_prewarm on a fresh context (what the CLI does while it parses): same PVSTs afterwards, a second call on a
+    context that holds a graph is a no-op, and a graph larger than the one announced still works (the arenas grow)."""
+    d = HipDecomposer(0)
+    g = W.hprc_shaped([3000, 500], seed=5, tiny=20)
+    d.prewarm(g.n_vtx, g.n_links)
+    d.upload(g)
+    assert d.decompose().texts() == O.decompose(g)
+    d.prewarm(10, 10)  # holds a graph: nothing happens
+    assert d.decompose().texts() == O.decompose(g)
+    big = W.hprc_shaped([20000, 900], seed=6, tiny=50)
+    d.upload(big)
+    assert d.decompose().texts() == O.decompose(big)
+    d.close()
+    with pytest.raises(RuntimeError):
+        e = HipDecomposer(0)
+        try:
+            e.prewarm(0, 0)  # no vertices: refused like an upload
+        finally:
+            e.close()
