@@ -89,10 +89,10 @@ PovuGraph *povu_graph_from_gfa(const char *gfa_path, PovuError *error) // povu_f
 		g->seqs = std::move(gg.seq);
 		for (size_t i = 0; i < g->ids.size(); i++)
 			g->idx_of.emplace(g->ids[i], (uint32_t)i);
-		g->v1 = std::move(gg.v1);
-		g->v2 = std::move(gg.v2);
-		g->s1 = std::move(gg.s1);
-		g->s2 = std::move(gg.s2);
+		g->v1.assign(gg.v1.begin(), gg.v1.end());
+		g->v2.assign(gg.v2.begin(), gg.v2.end());
+		g->s1.assign(gg.s1.begin(), gg.s1.end());
+		g->s2.assign(gg.s2.begin(), gg.s2.end());
 		g->paths = std::move(gg.paths);
 		return g;
 	} catch (const std::exception &e) {

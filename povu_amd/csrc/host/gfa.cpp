@@ -114,8 +114,22 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_l
 		out.err_char = c;
 	};
 	while (p < end) {
-		const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-		const char *le = nl ? nl : end, *next = nl ? nl + 1 : end;
+		// one pass over the line: its end and the first eight tab-separated fields (S and L lines of a pangenome GFA are
+		// 13 - 30 bytes long: a library call per field cost more than the bytes)
+		const char *fb[8], *fe[8];
+		int nf = 0;
+		bool open = true; // field nf is still being read
+		fb[0] = p;
+		const char *q = p;
+		for (; q < end && *q != '\n'; q++)
+			if (*q == '\t' && open) {
+				fe[nf++] = q;
+				if (nf < 8)
+					fb[nf] = q + 1;
+				else
+					open = false;
+			}
+		const char *le = q, *next = q < end ? q + 1 : end;
 		if (le > p && le[-1] == '\r')
 			le--;
 		if (le == p) {
@@ -123,15 +137,9 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_l
 			p = next;
 			continue;
 		}
-		const char *fb[8], *fe[8];
-		int nf = 0;
-		for (const char *q = p; nf < 8;) {
-			fb[nf] = q;
-			const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
-			fe[nf++] = t ? t : le;
-			if (!t)
-				break;
-			q = t + 1;
+		if (open) {
+			fe[nf] = le < fb[nf] ? fb[nf] : le;
+			nf++;
 		}
 		switch (*p) {
 		case 'H':
@@ -288,7 +296,7 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	if (on_counts)
 		on_counts(n_seg, E);
 	// every thread moves its slice to its place in the final arrays
-	std::vector<uint32_t> la(E), lb(E);
+	U32Vec la(E), lb(E); // (uninitialised: every element is written by the thread that owns its slice)
 	g.vid.resize(n_seg);
 	g.s1.resize(E);
 	g.s2.resize(E);
@@ -333,9 +341,10 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	}
 	// id -> idx: direct table when ids are dense, binary search otherwise
 	const uint32_t max_id = g.vid.back();
-	std::vector<uint32_t> table;
+	U32Vec table;
 	if ((uint64_t)max_id < 4 * (uint64_t)V + 1024) {
-		table.assign((size_t)max_id + 1, 0xFFFFFFFFu);
+		table.resize((size_t)max_id + 1);
+		parallel_ranges(TH, table.size(), [&](size_t, size_t lo, size_t hi) { std::fill(table.begin() + lo, table.begin() + hi, 0xFFFFFFFFu); });
 		parallel_ranges(TH, V, [&](size_t, size_t lo, size_t hi) {
 			for (size_t i = lo; i < hi; i++)
 				table[g.vid[i]] = (uint32_t)i;

@@ -8,7 +8,9 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace povu_host
@@ -20,10 +22,44 @@ struct GfaPath {
 	std::vector<uint8_t> step_rev; // 0 forward, 1 reverse
 };
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the big arrays of a whole-genome graph
+// are filled by the tokenizer's threads, which then also are the first to touch their pages -- value-initialising a few
+// gigabytes on ONE thread beforehand was a third of the parse
+template <class T>
+struct NoInitAlloc {
+	using value_type = T;
+	NoInitAlloc() = default;
+	template <class U>
+	NoInitAlloc(const NoInitAlloc<U> &)
+	{}
+	T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+	void deallocate(T *p, size_t) { ::operator delete(p); }
+	template <class U, class... A>
+	void construct(U *p, A &&...a)
+	{
+		if constexpr (sizeof...(A) == 0)
+			::new ((void *)p) U; // default-initialisation: nothing for an integer
+		else
+			::new ((void *)p) U(std::forward<A>(a)...);
+	}
+	template <class U>
+	bool operator==(const NoInitAlloc<U> &) const
+	{
+		return true;
+	}
+	template <class U>
+	bool operator!=(const NoInitAlloc<U> &) const
+	{
+		return false;
+	}
+};
+using U32Vec = std::vector<uint32_t, NoInitAlloc<uint32_t>>;
+using U8Vec = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
+
 struct GfaGraph {
-	std::vector<uint32_t> vid;	 // ascending segment ids
-	std::vector<uint32_t> v1, v2;	 // link endpoints (vertex idx), L-line order
-	std::vector<uint8_t> s1, s2;	 // link endpoint sides (0 = l, 1 = r)
+	U32Vec vid;			 // ascending segment ids
+	U32Vec v1, v2;			 // link endpoints (vertex idx), L-line order
+	U8Vec s1, s2;			 // link endpoint sides (0 = l, 1 = r)
 	std::vector<std::string> seq;	 // only with want_labels
 	std::vector<GfaPath> paths;	 // only with want_paths (P and W records)
 };
