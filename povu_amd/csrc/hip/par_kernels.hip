@@ -1027,7 +1027,9 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 template <typename F>
 static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 {
-	const size_t T = 2 * V + Cmax, NB = E + V + 2 * T, S = V + 1;
+	// brackets: the back edges of from_bd (links outside the tree, one per side without links) and, per tree vertex, at most
+	// ONE edge of the class stage -- a capping edge needs a non-empty bracket list, a simplifying edge an empty one
+	const size_t T = 2 * V + Cmax, NB = E + V + T, S = V + 1;
 	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.cov, &pw.psA,
 			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
 			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.vals_t, &pw.vals_t2})
@@ -1197,6 +1199,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	pw.nb0 = NB0;
 	pw.ncap = ncap;
 	pw.nsimp = nsimp;
+	if ((size_t)NB > (size_t)sw.E + V + T) // (the bracket arrays are carved for E + V + T entries, see for_each_span)
+		throw HipError("class stage: more brackets than the workspace was sized for (internal sizing bug)");
 	// Classes of the black tree edges only (the candidate stack holds no others: half the vertices to look up, sort and
 	// number).  Per top bracket the reference walks ALL vertices that have it on top, deepest first, and opens a class
 	// whenever the list size differs from the one before (recent_size, flubbles.cpp:668-676); leaving the gray edges'

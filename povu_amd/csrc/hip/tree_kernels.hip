@@ -1573,8 +1573,11 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
 	const size_t NSL = std::max<size_t>(2 * V + 2 * E, 4 * V) + 16; // scan slots of all sides / events of the second ranking
 	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
 	take((void **)&tw.dist, NSL * 4);
-	take((void **)&tw.xval, (NA + 2) * 16);
-	take((void **)&tw.xps, (NA + 2) * 16);
+	// one 16-byte value per segment that carries one (K <= V), and their running xor; on hub graphs the same two blocks hold
+	// the two key and the two value buffers of the slot sort (2E four-byte words each)
+	const size_t XV = std::max<size_t>(V + 2, E + 8) + 8;
+	take((void **)&tw.xval, XV * 16);
+	take((void **)&tw.xps, XV * 16);
 	take((void **)&tw.xrec, (NA / 64 + 4) * 16);
 	take((void **)&tw.xrank, (NA / 64 + 4) * 4);
 	take((void **)&tw.evt, NA * 8);
