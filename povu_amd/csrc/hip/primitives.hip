@@ -55,26 +55,65 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_partials(const ScanJobs jobs)
 	const size_t n = J.n, chunk = J.chunk;
 	const size_t b0 = (size_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
 	uint32_t acc = 0;
-	if (J.in8) { // chunks start on multiples of the tile: four bytes per load
+	// chunks start on multiples of the tile and every operand is 16-byte aligned: sixteen bytes per load (four words, or
+	// sixteen one-byte elements), the tail of the last chunk element by element
+	auto fold4 = [&](const uint4 &a) { acc = sc_op<MAX>(acc, sc_op<MAX>(sc_op<MAX>(a.x, a.y), sc_op<MAX>(a.z, a.w))); };
+	if (J.in8) {
 		const uint8_t *__restrict__ in8 = J.in8;
-		const size_t w1 = b0 + ((b1 - b0) & ~size_t(3));
-		for (size_t i = b0 + 4 * (size_t)threadIdx.x; i < w1; i += 4 * SC_TPB) {
-			const uint32_t w = *reinterpret_cast<const uint32_t *>(in8 + i);
-			acc = sc_op<MAX>(sc_op<MAX>(sc_op<MAX>(acc, w & 0xFFu), sc_op<MAX>((w >> 8) & 0xFFu, (w >> 16) & 0xFFu)), w >> 24);
+		const size_t w1 = b0 + ((b1 - b0) & ~size_t(15));
+		auto bytes4 = [](uint32_t w) {
+			return sc_op<MAX>(sc_op<MAX>(w & 0xFFu, (w >> 8) & 0xFFu), sc_op<MAX>((w >> 16) & 0xFFu, w >> 24));
+		};
+		for (size_t i = b0 + 16 * (size_t)threadIdx.x; i < w1; i += 16 * SC_TPB) {
+			const uint4 a = *reinterpret_cast<const uint4 *>(in8 + i);
+			fold4(make_uint4(bytes4(a.x), bytes4(a.y), bytes4(a.z), bytes4(a.w)));
 		}
 		for (size_t i = w1 + threadIdx.x; i < b1; i += SC_TPB)
 			acc = sc_op<MAX>(acc, in8[i]);
-	} else if (J.sub) {
-		const uint32_t *__restrict__ sub = J.sub;
-		for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
-			acc = sc_op<MAX>(acc, in[i] - sub[i]);
 	} else {
-		for (size_t i = b0 + threadIdx.x; i < b1; i += SC_TPB)
-			acc = sc_op<MAX>(acc, in[i]);
+		const uint32_t *__restrict__ sub = J.sub;
+		const size_t w1 = b0 + ((b1 - b0) & ~size_t(3));
+		if (sub) {
+			for (size_t i = b0 + 4 * (size_t)threadIdx.x; i < w1; i += 4 * SC_TPB) {
+				const uint4 a = *reinterpret_cast<const uint4 *>(in + i), c = *reinterpret_cast<const uint4 *>(sub + i);
+				fold4(make_uint4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w));
+			}
+		} else {
+			for (size_t i = b0 + 4 * (size_t)threadIdx.x; i < w1; i += 4 * SC_TPB)
+				fold4(*reinterpret_cast<const uint4 *>(in + i));
+		}
+		for (size_t i = w1 + threadIdx.x; i < b1; i += SC_TPB)
+			acc = sc_op<MAX>(acc, in[i] - (sub ? sub[i] : 0u));
 	}
 	acc = sc_block_reduce<MAX>(acc, sh);
 	if (threadIdx.x == 0)
 		partial[blockIdx.x] = acc;
+}
+// eight consecutive elements of a job starting at e0 (zeros behind b1)
+__device__ __forceinline__ void sc_load_tile(const ScanJob &J, size_t e0, size_t b1, uint32_t (&v)[SC_ITEMS])
+{
+	if (J.in8) {
+		const uint8_t *__restrict__ in8 = J.in8;
+		if (e0 + SC_ITEMS <= b1) {
+			const uint2 a = *reinterpret_cast<const uint2 *>(in8 + e0);
+			v[0] = a.x & 0xFFu, v[1] = (a.x >> 8) & 0xFFu, v[2] = (a.x >> 16) & 0xFFu, v[3] = a.x >> 24;
+			v[4] = a.y & 0xFFu, v[5] = (a.y >> 8) & 0xFFu, v[6] = (a.y >> 16) & 0xFFu, v[7] = a.y >> 24;
+		} else {
+			for (int k = 0; k < SC_ITEMS; k++)
+				v[k] = e0 + k < b1 ? in8[e0 + k] : 0u;
+		}
+	} else if (e0 + SC_ITEMS <= b1) {
+		const uint32_t *__restrict__ in = J.in;
+		const uint4 a = *reinterpret_cast<const uint4 *>(in + e0), b = *reinterpret_cast<const uint4 *>(in + e0 + 4);
+		v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+		if (J.sub) {
+			const uint4 c = *reinterpret_cast<const uint4 *>(J.sub + e0), d = *reinterpret_cast<const uint4 *>(J.sub + e0 + 4);
+			v[0] -= c.x, v[1] -= c.y, v[2] -= c.z, v[3] -= c.w, v[4] -= d.x, v[5] -= d.y, v[6] -= d.z, v[7] -= d.w;
+		}
+	} else {
+		for (int k = 0; k < SC_ITEMS; k++)
+			v[k] = e0 + k < b1 ? J.in[e0 + k] - (J.sub ? J.sub[e0 + k] : 0u) : 0u;
+	}
 }
 template <int MAX>
 __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
@@ -84,7 +123,6 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 	const ScanJob &J = jobs.j[blockIdx.y];
 	if (blockIdx.x >= J.blocks)
 		return;
-	const uint32_t *__restrict__ in = J.in;
 	uint32_t *__restrict__ out = J.out;
 	const uint32_t *__restrict__ partial = J.partial;
 	const size_t n = J.n, chunk = J.chunk;
@@ -94,30 +132,15 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 	uint32_t carry = sc_block_reduce<MAX>(base, sh);
 	const size_t b0 = (size_t)blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// the next tile's loads are issued before this tile's exchange through LDS: two tiles of a block are in flight
+	uint32_t v[SC_ITEMS], nx[SC_ITEMS];
+	if (b0 < b1)
+		sc_load_tile(J, b0 + (size_t)threadIdx.x * SC_ITEMS, b1, v);
 	for (size_t t0 = b0; t0 < b1; t0 += SC_TILE) {
 		const size_t e0 = t0 + (size_t)threadIdx.x * SC_ITEMS;
-		uint32_t v[SC_ITEMS];
-		if (J.in8) {
-			const uint8_t *__restrict__ in8 = J.in8;
-			if (e0 + SC_ITEMS <= b1) {
-				const uint2 a = *reinterpret_cast<const uint2 *>(in8 + e0);
-				v[0] = a.x & 0xFFu, v[1] = (a.x >> 8) & 0xFFu, v[2] = (a.x >> 16) & 0xFFu, v[3] = a.x >> 24;
-				v[4] = a.y & 0xFFu, v[5] = (a.y >> 8) & 0xFFu, v[6] = (a.y >> 16) & 0xFFu, v[7] = a.y >> 24;
-			} else {
-				for (int k = 0; k < SC_ITEMS; k++)
-					v[k] = e0 + k < b1 ? in8[e0 + k] : 0u;
-			}
-		} else if (e0 + SC_ITEMS <= b1) {
-			const uint4 a = *reinterpret_cast<const uint4 *>(in + e0), b = *reinterpret_cast<const uint4 *>(in + e0 + 4);
-			v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
-			if (J.sub) {
-				const uint4 c = *reinterpret_cast<const uint4 *>(J.sub + e0), d = *reinterpret_cast<const uint4 *>(J.sub + e0 + 4);
-				v[0] -= c.x, v[1] -= c.y, v[2] -= c.z, v[3] -= c.w, v[4] -= d.x, v[5] -= d.y, v[6] -= d.z, v[7] -= d.w;
-			}
-		} else {
-			for (int k = 0; k < SC_ITEMS; k++)
-				v[k] = e0 + k < b1 ? in[e0 + k] - (J.sub ? J.sub[e0 + k] : 0u) : 0u;
-		}
+		const bool more = t0 + SC_TILE < b1;
+		if (more)
+			sc_load_tile(J, e0 + SC_TILE, b1, nx);
 		uint32_t tot = 0; // lane-local exclusive scan
 		for (int k = 0; k < SC_ITEMS; k++) {
 			const uint32_t x = v[k];
@@ -153,6 +176,9 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 		}
 		carry = sc_op<MAX>(carry, tile_tot);
 		__syncthreads();
+		if (more)
+			for (int k = 0; k < SC_ITEMS; k++)
+				v[k] = nx[k];
 	}
 }
 

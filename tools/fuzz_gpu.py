@@ -10,7 +10,7 @@ from povu_amd.hip import (F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
 hip = HipDecomposer(0)
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 12345)  # (argv[3]: another stream of graphs)
 t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0; n_redo = 0; n_leaf = 0; n_leaf_redo = 0
 last = t0
 while time.time() - t0 < budget:
