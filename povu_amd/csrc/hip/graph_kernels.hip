@@ -326,15 +326,24 @@ __global__ void k_comp_of(uint32_t V, const uint32_t *__restrict__ label, const 
 			  uint32_t *__restrict__ comp_of, uint32_t *__restrict__ iota, uint32_t C,
 			  unsigned long long *__restrict__ start_key)
 {
-	uint32_t v = BIDX * blockDim.x + threadIdx.x;
-	if (v >= V)
+	const uint32_t v0 = (BIDX * blockDim.x + threadIdx.x) * 4u; // (four vertices a lane, 16-byte loads and stores)
+	if (v0 >= V)
 		return;
-	comp_of[v] = crank[label[v]];
-	if (iota)
-		iota[v] = v;
-	if (v <= C) // "no tip yet" for k_sorted_vertices' atomicMin; C <= V, and the last lane closes the array
-		start_key[v] = ~0ull;
-	if (v == V - 1)
+	if (v0 + 4 <= V) {
+		const uint4 l = *reinterpret_cast<const uint4 *>(label + v0);
+		*reinterpret_cast<uint4 *>(comp_of + v0) = make_uint4(crank[l.x], crank[l.y], crank[l.z], crank[l.w]);
+		if (iota)
+			*reinterpret_cast<uint4 *>(iota + v0) = make_uint4(v0, v0 + 1, v0 + 2, v0 + 3);
+	} else {
+		for (uint32_t v = v0; v < V; v++) {
+			comp_of[v] = crank[label[v]];
+			if (iota)
+				iota[v] = v;
+		}
+	}
+	for (uint32_t v = v0; v < v0 + 4 && v <= C; v++) // "no tip yet" for k_sorted_vertices' atomicMin; C <= V: v = C is
+		start_key[v] = ~0ull;			      // reached by the lane that holds it, or written by the last lane
+	if (v0 + 4 >= V)
 		start_key[C] = ~0ull;
 }
 
@@ -349,26 +358,35 @@ __global__ void k_sorted_vertices(uint32_t V, uint32_t C, const uint32_t *__rest
 				  uint32_t *__restrict__ gid_s, uint8_t *__restrict__ tip_s,
 				  unsigned long long *__restrict__ start_key, uint32_t *__restrict__ stats)
 {
-	uint32_t i = BIDX * blockDim.x + threadIdx.x;
-	if (i >= V)
+	const uint32_t i0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (i0 >= V)
 		return;
-	if (i < 4)
-		stats[i] = 0; // stats[0] = most links on one side (k_mark_first2 / k_max_u32)
-	const uint32_t v = perm ? perm[i] : i, c = ckey[i];
-	if (i == 0 || ckey[i - 1] != c)
-		voff[c] = i;
-	if (i == V - 1)
-		voff[C] = V;
-	const uint8_t t = tip[v];
-	if (perm) {
-		pos[v] = i;
-		vdeg[i] = off[2 * v + 2] - off[2 * v];
-		gid_s[i] = vid[v];
-		tip_s[i] = t;
+	// sorted space = global space: four vertices that sit inside one component and hold no tip -- almost every lane's --
+	// have nothing to record (two 16-byte loads and a word of tip flags say so)
+	if (!perm && i0 > 0 && i0 + 4 < V) {
+		const uint4 c4 = *reinterpret_cast<const uint4 *>(ckey + i0);
+		if (ckey[i0 - 1] == c4.x && c4.x == c4.w && *reinterpret_cast<const uint32_t *>(tip + i0) == 0u)
+			return;
 	}
-	// start of the spanning tree = *tips().begin(): smallest (id, then l<r), types.cpp:60-68
-	if (t)
-		atomicMin(&start_key[c], ((unsigned long long)vid[v] << 32) | (unsigned long long)(2u * i + (t == 1 ? 0u : 1u)));
+	for (uint32_t i = i0; i < V && i < i0 + 4; i++) {
+		if (i < 4)
+			stats[i] = 0; // stats[0] = most links on one side (k_mark_first2 / k_max_u32)
+		const uint32_t v = perm ? perm[i] : i, c = ckey[i];
+		if (i == 0 || ckey[i - 1] != c)
+			voff[c] = i;
+		if (i == V - 1)
+			voff[C] = V;
+		const uint8_t t = tip[v];
+		if (perm) {
+			pos[v] = i;
+			vdeg[i] = off[2 * v + 2] - off[2 * v];
+			gid_s[i] = vid[v];
+			tip_s[i] = t;
+		}
+		// start of the spanning tree = *tips().begin(): smallest (id, then l<r), types.cpp:60-68
+		if (t)
+			atomicMin(&start_key[c], ((unsigned long long)vid[v] << 32) | (unsigned long long)(2u * i + (t == 1 ? 0u : 1u)));
+	}
 }
 
 // slot order of componetize's edge loop: vertices ascending, e_l then e_r ascending
@@ -795,7 +813,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	// space is the global vertex space.  The sort-free builder then needs no permutation, position, slot-base, id or tip
 	// array at all -- it reads the resident graph's own (slot base of vertex i = off[2 i]).
 	st.lean_identity = identity && sort_free;
-	KLAUNCH(k_comp_of, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.lean_identity ? nullptr : st.tmp_a, C,
+	KLAUNCH(k_comp_of, dim3(nblk(((size_t)V + 3) / 4)), dim3(TPB), 0, s, V, st.label, st.crank, st.comp_of, st.lean_identity ? nullptr : st.tmp_a, C,
 			   (unsigned long long *)st.start_key);
 	if (identity) { // the key / permutation arrays simply alias what k_comp_of wrote (component ranks, identity permutation)
 		st.ckey = st.comp_of;
@@ -807,7 +825,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		st.gid_s = g.vid;
 		st.tip_s = g.tip;
 	}
-	KLAUNCH(k_sorted_vertices, dim3(nblk(V)), dim3(TPB), 0, s, V, C, st.ckey, st.lean_identity ? nullptr : st.perm, g.off, g.vid, g.tip,
+	KLAUNCH(k_sorted_vertices, dim3(nblk(((size_t)V + 3) / 4)), dim3(TPB), 0, s, V, C, st.ckey, st.lean_identity ? nullptr : st.perm, g.off, g.vid, g.tip,
 			   st.pos, st.voff, st.vdeg, st.gid_s, st.tip_s, (unsigned long long *)st.start_key, st.stats);
 	if (!st.lean_identity)
 		scan_exclusive_u32(st.vdeg, st.sbase, (size_t)V + 1, st.scan_tmp, st.scan_tmp_bytes, s);
