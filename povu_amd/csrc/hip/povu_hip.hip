@@ -1046,60 +1046,73 @@ extern "C" char *povu_hip_pvst_format_fam(uint32_t n_pvst, const uint32_t *a_id,
 			return nullptr; // a PVST parent always precedes its children (emission order)
 	const uint32_t n = t.n_pvst;
 	// children of every PVST vertex in emission order (children_v push_back, pvst.hpp:882-892)
-	std::vector<uint32_t> coff(n + 1, 0), cadj(n);
+	std::unique_ptr<uint32_t[]> coff(new uint32_t[(size_t)n + 2]), cadj(new uint32_t[n]); // (uninitialised)
+	std::fill(coff.get(), coff.get() + n + 2, 0u);
 	for (uint32_t v = 1; v < n; v++)
-		coff[t.parent[v] + 1]++;
-	for (uint32_t v = 0; v < n; v++)
-		coff[v + 1] += coff[v];
-	{
-		std::vector<uint32_t> cur(coff.begin(), coff.end() - 1);
-		for (uint32_t v = 1; v < n; v++)
-			cadj[cur[t.parent[v]]++] = v;
-	}
-	std::string out;
-	out.reserve((size_t)n * 36 + 64);
-	out += "H\t0.0.3\t.\t.\t.\n"; // to_pvst.cpp:23-28
-	char num[16];
-	auto put = [&](uint32_t v) {
-		int l = snprintf(num, sizeof num, "%u", v);
-		out.append(num, (size_t)l);
-	};
-	for (uint32_t v = 0; v < n; v++) {
-		if (fam) { // to_pvst.cpp:52-79: the line identifier follows the vertex family
-			out += (char)fam[v];
-			out += '\t';
-		} else {
-			out += v == 0 ? "D\t" : "F\t";
-		}
-		put(v);
-		out += '\t';
-		if (v == 0) {
-			out += '.';
-		} else { // id_or_t::as_str, include/povu/graph/types.hpp:85-95
-			out += t.a_or[v] ? '<' : '>';
-			put(t.a_id[v]);
-			out += t.z_or[v] ? '<' : '>';
-			put(t.z_id[v]);
-		}
-		out += '\t';
-		if (coff[v] == coff[v + 1]) {
-			out += '.';
-		} else { // print_with_comma, include/povu/common/utils.hpp:44-55
-			for (uint32_t k = coff[v]; k < coff[v + 1]; k++) {
-				put(cadj[k]);
-				if (k + 1 < coff[v + 1])
-					out += ", ";
-			}
-		}
-		out += v == 0 ? "\t.\n" : "\tL\n";
-	}
-	char *buf = (char *)malloc(out.size() + 1);
+		coff[t.parent[v] + 2]++; // (shifted by one: after the sums coff[p + 1] is where p's children start, and the fill
+	for (uint32_t v = 0; v < n; v++) //  below advances it to where they end = where those of p + 1 start)
+		coff[v + 2] += coff[v + 1];
+	for (uint32_t v = 1; v < n; v++)
+		cadj[coff[t.parent[v] + 1]++] = v;
+	// One buffer of the largest size the text can have, written front to back (a 10^6-vertex PVST is 5 * 10^6 numbers: a
+	// library call per number and a growing string were most of the CLI's write time).  Per line at most: letter + tab 2,
+	// vertex 10, tab 1, the two oriented endpoints 22, tab 1, '.' 1, closing field 3; per child entry 10 + ", ".
+	const size_t cap = 16 + (size_t)n * 40 + (size_t)n * 12 + 1;
+	char *buf = (char *)malloc(cap);
 	if (!buf)
 		return nullptr;
-	memcpy(buf, out.data(), out.size());
-	buf[out.size()] = 0;
+	static const char D2[] = "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+				 "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+	char *o = buf;
+	auto put = [&](uint32_t v) {
+		const int len = v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6 :
+				v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+		char *e = o + len;
+		o = e;
+		while (v >= 100u) {
+			const uint32_t r = v % 100u;
+			v /= 100u;
+			e -= 2;
+			e[0] = D2[2 * r], e[1] = D2[2 * r + 1];
+		}
+		if (v >= 10u)
+			e[-2] = D2[2 * v], e[-1] = D2[2 * v + 1];
+		else
+			e[-1] = (char)('0' + v);
+	};
+	memcpy(o, "H\t0.0.3\t.\t.\t.\n", 14); // to_pvst.cpp:23-28
+	o += 14;
+	for (uint32_t v = 0; v < n; v++) {
+		*o++ = fam ? (char)fam[v] : (v == 0 ? 'D' : 'F'); // to_pvst.cpp:52-79: the line identifier follows the vertex family
+		*o++ = '\t';
+		put(v);
+		*o++ = '\t';
+		if (v == 0) {
+			*o++ = '.';
+		} else { // id_or_t::as_str, include/povu/graph/types.hpp:85-95
+			*o++ = t.a_or[v] ? '<' : '>';
+			put(t.a_id[v]);
+			*o++ = t.z_or[v] ? '<' : '>';
+			put(t.z_id[v]);
+		}
+		*o++ = '\t';
+		const uint32_t c0 = coff[v], c1 = coff[v + 1];
+		if (c0 == c1) {
+			*o++ = '.';
+		} else { // print_with_comma, include/povu/common/utils.hpp:44-55
+			for (uint32_t k = c0; k < c1; k++) {
+				put(cadj[k]);
+				if (k + 1 < c1)
+					*o++ = ',', *o++ = ' ';
+			}
+		}
+		*o++ = '\t';
+		*o++ = v == 0 ? '.' : 'L';
+		*o++ = '\n';
+	}
+	*o = 0;
 	if (len)
-		*len = out.size();
+		*len = (size_t)(o - buf);
 	return buf;
 }
 

@@ -28,45 +28,6 @@ double now_ms()
 }
 } // namespace
 
-namespace
-{
-// S and L records of a GFA file, estimated from 64 samples of 64 KiB spread over the file (+3 %): {0, 0} when the file cannot
-// be read.  Only used to start reserving device memory early; the tokenizer's exact counts follow.
-std::pair<size_t, size_t> estimate_gfa_counts(const std::string &path)
-{
-	FILE *f = fopen(path.c_str(), "rb");
-	if (!f)
-		return {0, 0};
-	std::pair<size_t, size_t> out{0, 0};
-	if (fseeko(f, 0, SEEK_END) == 0) {
-		const size_t size = (size_t)ftello(f), chunk = size_t(64) << 10, n_samples = 64;
-		if (size <= chunk * n_samples) { // a small file: no hurry
-			fclose(f);
-			return {0, 0};
-		}
-		std::vector<char> buf(chunk);
-		size_t ns = 0, nl = 0, seen = 0;
-		for (size_t k = 0; k < n_samples; k++) {
-			const size_t at = (size - chunk) / (n_samples - 1) * k;
-			if (fseeko(f, (off_t)at, SEEK_SET) != 0 || fread(buf.data(), 1, chunk, f) != chunk)
-				break;
-			for (size_t i = 0; i + 1 < chunk; i++)
-				if (buf[i] == '\n') {
-					ns += buf[i + 1] == 'S';
-					nl += buf[i + 1] == 'L';
-				}
-			seen += chunk;
-		}
-		if (seen) {
-			const double scale = (double)size / (double)seen * 1.03;
-			out = {(size_t)((double)ns * scale) + 1024, (size_t)((double)nl * scale) + 1024};
-		}
-	}
-	fclose(f);
-	return out;
-}
-} // namespace
-
 void do_decompose(const Config &cfg)
 {
 	const int ll = cfg.verbosity;
@@ -76,30 +37,42 @@ void do_decompose(const Config &cfg)
 	const double t0 = now_ms();
 	// the HIP runtime comes up (~0.1 s) while the GFA is being parsed
 	char err[512] = {0}, cerr_buf[512] = {0};
-	// ... and the same thread reserves the device memory the graph will need (povu_hip_prewarm) while the parse goes on:
-	// first for an ESTIMATE of the segment and link counts (64 samples of the file, a few milliseconds), then, should the
-	// tokenizer find more than that, for the exact numbers
-	const std::pair<size_t, size_t> guess = estimate_gfa_counts(cfg.input_gfa);
+	// ... and the same thread reserves the device memory the graph will need (povu_hip_prewarm) while the parse goes on: the
+	// loader's counting pass knows the segment and link counts a few ten milliseconds in, before the runtime is up
 	std::promise<std::pair<size_t, size_t>> counts_p;
 	std::future<std::pair<size_t, size_t>> counts_f = counts_p.get_future();
 	std::future<povu_hip_ctx *> ctx_f = std::async(std::launch::async, [&]() {
 		povu_hip_ctx *c = povu_hip_create(cfg.device, cerr_buf, sizeof cerr_buf);
 		char perr[256];
 		auto fits = [](size_t n) { return n && n < 0xFFFFFFFFull; };
-		if (c && fits(guess.first) && fits(guess.second + 1))
-			(void)povu_hip_prewarm(c, (uint32_t)guess.first, (uint32_t)guess.second, perr, sizeof perr); // (best effort)
 		const std::pair<size_t, size_t> n = counts_f.get(); // ({0, 0}: the parse failed before it knew)
-		if (c && fits(n.first) && fits(n.second + 1) && (n.first > guess.first || n.second > guess.second))
-			(void)povu_hip_prewarm(c, (uint32_t)n.first, (uint32_t)n.second, perr, sizeof perr);
+		if (c && fits(n.first) && fits(n.second + 1))
+			(void)povu_hip_prewarm(c, (uint32_t)n.first, (uint32_t)n.second, perr, sizeof perr); // (best effort)
 		return c;
 	});
+	// what the loader only needed while it ran (the file mapping, gigabytes of temporaries) is given back to the system on
+	// a thread of its own, off the path to the first kernel
+	struct Releaser {
+		GfaScratch scratch;
+		std::thread th;
+		void start()
+		{
+			th = std::thread([this]() { scratch.held.reset(); });
+		}
+		~Releaser()
+		{
+			if (th.joinable())
+				th.join();
+		}
+	} releaser;
 	GfaGraph g;
 	bool counted = false;
 	try {
 		g = load_gfa(cfg.input_gfa, false, false, cfg.threads, [&](size_t v, size_t e) {
 			counted = true;
 			counts_p.set_value({v, e});
-		});
+		}, &releaser.scratch);
+		releaser.start();
 	} catch (...) {
 		if (!counted)
 			counts_p.set_value({0, 0});

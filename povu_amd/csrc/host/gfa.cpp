@@ -1,8 +1,12 @@
 #include "gfa.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
+#include <memory>
 #include <stdexcept>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -72,19 +76,56 @@ struct Seg {
 	uint32_t id;
 	const char *sb, *se;
 };
-// what one tokenizer thread found in its slice of the file (whole lines, in file order)
+// what the loader needs only while it runs (see GfaScratch in gfa.hpp)
+struct Scratch {
+	std::unique_ptr<Mapped> file;
+	U32Vec la, lb; // link ends as segment ids
+	U32Vec table;  // id -> idx
+	std::vector<Seg> segs;
+};
+// what one tokenizer thread does with its slice of the file (whole lines, in file order): the counting pass fills
+// n_seg / n_link, the tokenizing pass writes the records at their final places in the graph's arrays
 struct Slice {
-	std::vector<uint32_t> ids;  // segment ids in file order
-	std::vector<Seg> segs;	    // ... with their sequences (only with want_labels)
-	bool ascending = true;	    // ids strictly ascending inside the slice
-	std::vector<uint32_t> la, lb;
-	std::vector<uint8_t> sa, sb;
+	size_t n_seg = 0, n_link = 0; // S and L lines of the slice
+	uint32_t *ids = nullptr;      // [n_seg] segment ids in file order
+	Seg *segs = nullptr;	      // ... with their sequences (only with want_labels)
+	uint32_t *la = nullptr, *lb = nullptr;
+	uint8_t *sa = nullptr, *sb = nullptr;
+	bool ascending = true; // ids strictly ascending inside the slice
 	std::vector<GfaPath> paths;
 	size_t lines = 0;	  // lines seen (all of the slice unless an error stopped it)
 	size_t err_line = 0;	  // 1-based line inside the slice of the first malformed record, 0 = none
 	int err_kind = 0;	  // see slice_error
 	char err_char = 0;
 };
+
+// S and L lines of a slice (the record type is the first byte of a line): what sizes the graph's arrays before any
+// record is parsed, so that every tokenizer writes its records where they stay
+__attribute__((optimize("O3"))) void count_slice(const char *p, const char *end, Slice &out)
+{
+	// a record starts the slice or follows a line feed: every byte pair is looked at without a branch (the loop
+	// vectorises; a search for the next line feed per 20-byte line was four times slower)
+	size_t ns = 0, nl = 0;
+	if (p < end) {
+		ns += *p == 'S';
+		nl += *p == 'L';
+	}
+	const size_t n = (size_t)(end - p);
+	for (size_t i0 = 0; i0 + 1 < n;) {
+		const size_t i1 = std::min(n - 1, i0 + 4096);
+		uint32_t cs = 0, cl = 0;
+		for (size_t i = i0; i < i1; i++) {
+			const bool lf = p[i] == '\n';
+			cs += lf & (p[i + 1] == 'S');
+			cl += lf & (p[i + 1] == 'L');
+		}
+		ns += cs;
+		nl += cl;
+		i0 = i1;
+	}
+	out.n_seg = ns;
+	out.n_link = nl;
+}
 
 std::string slice_error(const std::string &fp, int kind, size_t line, char c)
 {
@@ -108,6 +149,10 @@ std::string slice_error(const std::string &fp, int kind, size_t line, char c)
 void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_labels, Slice &out)
 {
 	size_t line_no = 1;
+	uint32_t *ids = out.ids, *la = out.la, *lb = out.lb; // (the counting pass saw the same lines: the cursors end where
+	uint8_t *sa = out.sa, *sb = out.sb;		       //  the next slice's records begin)
+	Seg *segs = out.segs;
+	uint32_t last_id = 0;
 	auto fail = [&](int kind, char c = 0) {
 		out.err_kind = kind;
 		out.err_line = line_no;
@@ -154,11 +199,12 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_l
 			uint32_t id;
 			if (!parse_id(fb[1], fe[1], id))
 				return fail(4);
-			if (!out.ids.empty() && id <= out.ids.back())
+			if (ids != out.ids && id <= last_id)
 				out.ascending = false;
-			out.ids.push_back(id);
+			last_id = id;
+			*ids++ = id;
 			if (want_labels)
-				out.segs.push_back({id, fb[2], fe[2]});
+				*segs++ = Seg{id, fb[2], fe[2]};
 			break;
 		}
 		case 'L': {
@@ -166,10 +212,10 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_l
 			if (nf < 5 || !parse_id(fb[1], fe[1], a) || !parse_id(fb[3], fe[3], b) || fe[2] - fb[2] != 1 ||
 			    fe[4] - fb[4] != 1 || (*fb[2] != '+' && *fb[2] != '-') || (*fb[4] != '+' && *fb[4] != '-'))
 				return fail(5);
-			out.la.push_back(a);
-			out.lb.push_back(b);
-			out.sa.push_back(*fb[2] == '+' ? 1 : 0);
-			out.sb.push_back(*fb[4] == '+' ? 0 : 1);
+			*la++ = a;
+			*lb++ = b;
+			*sa++ = *fb[2] == '+' ? 1 : 0;
+			*sb++ = *fb[4] == '+' ? 0 : 1;
 			break;
 		}
 		case 'P':
@@ -240,11 +286,25 @@ void parallel_ranges(size_t T, size_t n, F &&fn)
 } // namespace
 
 GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int threads,
-		  const std::function<void(size_t, size_t)> &on_counts)
+		  const std::function<void(size_t, size_t)> &on_counts, GfaScratch *keep)
 {
-	Mapped f(fp);
+	// POVU_GFA_TIMING=1: the loader's phases on stderr (tools/first_call_cost.py and DESIGN.md section 6 quote them)
+	const bool timing = std::getenv("POVU_GFA_TIMING") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto phase = [&](const char *what) {
+		if (!timing)
+			return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "gfa %-12s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+		t_last = now;
+	};
+	auto scratch = std::make_shared<Scratch>();
+	scratch->file = std::make_unique<Mapped>(fp);
+	if (keep)
+		keep->held = scratch; // (on every path out of here, errors included, the caller decides when it goes)
+	const Mapped &f = *scratch->file;
 	GfaGraph g;
-	// slices of whole lines, one tokenizer thread each; results are stitched together in file order
+	// slices of whole lines, one thread each: a counting pass sizes the arrays, the tokenizing pass fills them in place
 	const size_t TH = (size_t)std::max(1, threads);
 	size_t T = std::min<size_t>(TH, std::max<size_t>(1, f.n >> 22)); // at least 4 MiB per thread
 	std::vector<const char *> cut(T + 1);
@@ -257,67 +317,68 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 		const char *nl = (const char *)memchr(q, '\n', (size_t)(cut[T] - q));
 		cut[t] = nl ? nl + 1 : cut[T];
 	}
-	std::vector<Slice> slices(T);
-	if (T == 1) {
-		tokenize_slice(cut[0], cut[1], want_paths, want_labels, slices[0]);
-	} else {
+	phase("map");
+	auto for_slices = [&](auto &&fn) {
+		if (T == 1) {
+			fn(0);
+			return;
+		}
 		std::vector<std::thread> pool;
 		for (size_t t = 0; t < T; t++)
-			pool.emplace_back([&, t]() { tokenize_slice(cut[t], cut[t + 1], want_paths, want_labels, slices[t]); });
+			pool.emplace_back([&, t]() { fn(t); });
 		for (auto &th : pool)
 			th.join();
-	}
-	size_t lines_before = 0;
+	};
+	std::vector<Slice> slices(T);
+	for_slices([&](size_t t) { count_slice(cut[t], cut[t + 1], slices[t]); });
 	std::vector<size_t> seg_at(T + 1, 0), link_at(T + 1, 0);
+	for (size_t t = 0; t < T; t++) {
+		seg_at[t + 1] = seg_at[t] + slices[t].n_seg;
+		link_at[t + 1] = link_at[t] + slices[t].n_link;
+	}
+	const size_t n_seg = seg_at[T], E = link_at[T];
+	phase("count");
+	if (on_counts && n_seg)
+		on_counts(n_seg, E);
+	// the graph's arrays at their final size (uninitialised: every element is written, and its page first touched, by the
+	// thread that owns the slice); la / lb hold the link ends as segment ids until the id table exists
+	Scratch &sc = *scratch;
+	sc.la.resize(E);
+	sc.lb.resize(E);
+	g.vid.resize(n_seg);
+	g.s1.resize(E);
+	g.s2.resize(E);
+	sc.segs.resize(want_labels ? n_seg : 0);
+	U32Vec &la = sc.la, &lb = sc.lb;
+	std::vector<Seg> &segs = sc.segs;
+	for_slices([&](size_t t) {
+		Slice &sl = slices[t];
+		sl.ids = g.vid.data() + seg_at[t];
+		sl.segs = want_labels ? segs.data() + seg_at[t] : nullptr;
+		sl.la = la.data() + link_at[t];
+		sl.lb = lb.data() + link_at[t];
+		sl.sa = g.s1.data() + link_at[t];
+		sl.sb = g.s2.data() + link_at[t];
+		tokenize_slice(cut[t], cut[t + 1], want_paths, want_labels, sl);
+	});
+	phase("tokenize");
+	size_t lines_before = 0;
 	bool ascending = true; // segment ids strictly ascending over the whole file (what GFA writers usually produce)
 	for (size_t t = 0; t < T; t++) { // the first malformed record in file order
 		const Slice &sl = slices[t];
 		if (sl.err_kind)
 			throw std::runtime_error(slice_error(fp, sl.err_kind, lines_before + sl.err_line, sl.err_char));
 		lines_before += sl.lines;
-		seg_at[t + 1] = seg_at[t] + sl.ids.size();
-		link_at[t + 1] = link_at[t] + sl.la.size();
 		ascending = ascending && sl.ascending;
 	}
-	{ // (slices without segments do not break the order)
-		uint32_t last = 0;
-		bool any = false;
-		for (const Slice &sl : slices)
-			if (!sl.ids.empty()) {
-				if (any && sl.ids.front() <= last)
-					ascending = false;
-				last = sl.ids.back();
-				any = true;
-			}
-	}
-	const size_t n_seg = seg_at[T], E = link_at[T];
 	if (n_seg == 0)
 		throw std::runtime_error(invalid(fp, "liteseq returned no vertices"));
-	if (on_counts)
-		on_counts(n_seg, E);
-	// every thread moves its slice to its place in the final arrays
-	U32Vec la(E), lb(E); // (uninitialised: every element is written by the thread that owns its slice)
-	g.vid.resize(n_seg);
-	g.s1.resize(E);
-	g.s2.resize(E);
-	std::vector<Seg> segs(want_labels ? n_seg : 0);
-	{
-		std::vector<std::thread> pool;
-		for (size_t t = 0; t < T; t++)
-			pool.emplace_back([&, t]() {
-				Slice &sl = slices[t];
-				std::copy(sl.ids.begin(), sl.ids.end(), g.vid.begin() + seg_at[t]);
-				std::copy(sl.la.begin(), sl.la.end(), la.begin() + link_at[t]);
-				std::copy(sl.lb.begin(), sl.lb.end(), lb.begin() + link_at[t]);
-				std::copy(sl.sa.begin(), sl.sa.end(), g.s1.begin() + link_at[t]);
-				std::copy(sl.sb.begin(), sl.sb.end(), g.s2.begin() + link_at[t]);
-				if (want_labels)
-					std::copy(sl.segs.begin(), sl.segs.end(), segs.begin() + seg_at[t]);
-				sl.ids = {}, sl.la = {}, sl.lb = {}, sl.sa = {}, sl.sb = {}, sl.segs = {};
-			});
-		for (auto &th : pool)
-			th.join();
-	}
+	for (size_t t = 0, last_t = T; t < T; t++) // (slices without segments do not break the order)
+		if (slices[t].n_seg) {
+			if (last_t != T && g.vid[seg_at[t]] <= g.vid[seg_at[last_t + 1] - 1])
+				ascending = false;
+			last_t = t;
+		}
 	for (Slice &sl : slices)
 		for (auto &pa : sl.paths)
 			g.paths.push_back(std::move(pa));
@@ -341,7 +402,7 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	}
 	// id -> idx: direct table when ids are dense, binary search otherwise
 	const uint32_t max_id = g.vid.back();
-	U32Vec table;
+	U32Vec &table = sc.table;
 	if ((uint64_t)max_id < 4 * (uint64_t)V + 1024) {
 		table.resize((size_t)max_id + 1);
 		parallel_ranges(TH, table.size(), [&](size_t, size_t lo, size_t hi) { std::fill(table.begin() + lo, table.begin() + hi, 0xFFFFFFFFu); });
@@ -350,6 +411,7 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 				table[g.vid[i]] = (uint32_t)i;
 		});
 	}
+	phase("id table");
 	g.v1.resize(E);
 	g.v2.resize(E);
 	std::vector<size_t> bad(TH, (size_t)-1); // first link of a range that names an unknown segment
@@ -368,6 +430,7 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 			g.v2[e] = b;
 		}
 	});
+	phase("link ends");
 	size_t first_bad = (size_t)-1;
 	for (size_t b : bad)
 		first_bad = std::min(first_bad, b);

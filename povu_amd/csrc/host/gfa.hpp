@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <new>
 #include <string>
 #include <utility>
@@ -64,11 +65,20 @@ struct GfaGraph {
 	std::vector<GfaPath> paths;	 // only with want_paths (P and W records)
 };
 
+// What the loader needs only while it runs -- the file mapping, the link ends as segment ids, the id table: gigabytes on a
+// whole-genome graph, and giving them back to the system (munmap) takes a few hundred milliseconds.  A caller that passes a
+// GfaScratch receives them instead of having them released before load_gfa returns, and drops them when and where it
+// suits (the CLI: on a thread of its own, while the graph is uploaded).
+struct GfaScratch {
+	std::shared_ptr<void> held;
+};
+
 // throws std::runtime_error("Invalid GFA '<path>': ...") for the first malformed record in file order;
-// `threads` tokenizer threads share the file (slices of whole lines, >= 4 MiB each)
-// on_counts(segments, links), when given, is called once as soon as the tokenizer knows both numbers (the stitching and
-// the link mapping still lie ahead): the CLI uses it to have the device memory reserved meanwhile
+// `threads` threads share the file (slices of whole lines, >= 4 MiB each): a counting pass, then every thread tokenizes
+// its slice straight into the graph's arrays.
+// on_counts(segments, links), when given, is called once after the counting pass (the tokenizing and the link mapping
+// still lie ahead; a malformed record may yet make the load fail): the CLI has the device memory reserved meanwhile
 GfaGraph load_gfa(const std::string &path, bool want_labels = false, bool want_paths = false, int threads = 1,
-		  const std::function<void(size_t, size_t)> &on_counts = nullptr);
+		  const std::function<void(size_t, size_t)> &on_counts = nullptr, GfaScratch *keep = nullptr);
 
 } // namespace povu_host

@@ -209,6 +209,45 @@ def test_gfa_loader_with_several_tokenizer_threads(tmp_path):
         assert err.message == f"Invalid GFA '{path}': malformed L record on line {bad_line}".encode(), err.message
 
 
+def test_gfa_loader_line_shapes_across_slices(tmp_path):
+    """The counting pass and the tokenizing pass must agree on what a record is, wherever the slices are cut: CRLF line ends,
+    blank lines, L records ahead of their S records, descending ids, a header in the middle, no line feed at the end."""
+    lib = _ffi()
+    rng = np.random.default_rng(11)
+    n = 250000
+    ids = rng.permutation(np.arange(1, 3 * n, 3))[:n]  # sparse, unordered
+    rows = []
+    links = []
+    for k in range(n):
+        if k and k % 3 == 0:  # a link between two segments, possibly ahead of both S lines
+            a, b = int(ids[rng.integers(0, n)]), int(ids[rng.integers(0, n)])
+            sa, sb = "+-"[int(rng.integers(0, 2))], "+-"[int(rng.integers(0, 2))]
+            rows.append(f"L\t{a}\t{sa}\t{b}\t{sb}\t0M" + ("\r" if k % 7 == 0 else ""))
+            links.append((a, 1 if sa == "+" else 0, b, 0 if sb == "+" else 1))
+        if k % 1000 == 0:
+            rows.append("")  # blank line
+        if k % 5000 == 1:
+            rows.append("H\tVN:Z:1.0")
+        rows.append(f"S\t{int(ids[k])}\t{'ACGT' * int(rng.integers(1, 20))}" + ("\tLN:i:4" if k % 13 == 0 else "") + ("\r" if k % 11 == 0 else ""))
+    text = "\n".join(rows)  # (no line feed behind the last record)
+    assert len(text) > 3 * (4 << 20)
+    path = tmp_path / "shapes.gfa"
+    path.write_bytes(text.encode())
+    err = _Err(0, None)
+    h = lib.povu_graph_from_gfa(str(path).encode(), C.byref(err))
+    assert h, err.message
+    nv = C.c_size_t(0)
+    v = lib.povu_graph_get_vertices(h, C.byref(nv))
+    assert [v[i].id for i in range(nv.value)] == sorted(int(x) for x in ids)
+    lib.povu_vertices_free(v, nv)
+    ne = C.c_size_t(0)
+    e = lib.povu_graph_get_edges(h, C.byref(ne))
+    assert ne.value == len(links)
+    assert [(e[i].from_id, e[i].from_o, e[i].to_id, e[i].to_o) for i in range(ne.value)] == links
+    lib.povu_edges_free(e, ne)
+    lib.povu_graph_free(h)
+
+
 def test_compute_entry_points_fail_loudly_without_gpu():
     lib = _ffi()
     hl = H.load_lib()
@@ -254,6 +293,48 @@ def test_pvst_serialiser_matches_to_pvst(golden_dir):
         got = C.string_at(ptr, ln.value).decode()
         hl.povu_hip_buffer_free(ptr)
         assert got == want
+
+
+def test_pvst_serialiser_number_widths_and_fanout():
+    """Every decimal width of a u32 id (1 .. 10 digits), a vertex with many children, a wide tree and a path: the text the
+    serialiser writes into its one buffer against the same lines formatted here (to_pvst.cpp:23-109)."""
+    hl = H.load_lib()
+    hl.povu_hip_pvst_format.restype = C.c_void_p
+    hl.povu_hip_pvst_format.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_size_t)]
+    rng = np.random.default_rng(5)
+    edge_ids = [0, 9, 10, 99, 100, 999, 1000, 9999, 10000, 99999, 100000, 999999, 1000000, 9999999, 10000000, 99999999,
+                100000000, 999999999, 1000000000, 4294967294]
+    for n, shape in ((1, "path"), (2, "path"), (len(edge_ids) + 1, "star"), (1200, "path"), (5000, "random"), (100001, "star")):
+        parent = np.zeros(n, dtype=np.uint32)
+        for v in range(1, n):
+            parent[v] = 0 if shape == "star" else v - 1 if shape == "path" else int(rng.integers(0, v))
+        a = rng.integers(0, 2 ** 32 - 1, n, dtype=np.uint64).astype(np.uint32)
+        z = rng.integers(0, 2 ** 32 - 1, n, dtype=np.uint64).astype(np.uint32)
+        if n > len(edge_ids):
+            a[1:len(edge_ids) + 1] = np.array(edge_ids, dtype=np.uint32)
+            z[1:len(edge_ids) + 1] = np.array(edge_ids[::-1], dtype=np.uint32)
+        ao, zo = rng.integers(0, 2, n).astype(np.uint8), rng.integers(0, 2, n).astype(np.uint8)
+        kids = [[] for _ in range(n)]
+        for v in range(1, n):
+            kids[parent[v]].append(v)
+        want = ["H\t0.0.3\t.\t.\t."]
+        for v in range(n):
+            ch = ", ".join(map(str, kids[v])) if kids[v] else "."
+            if v == 0:
+                want.append(f"D\t0\t.\t{ch}\t.")
+            else:
+                want.append(f"F\t{v}\t{'<' if ao[v] else '>'}{a[v]}{'<' if zo[v] else '>'}{z[v]}\t{ch}\tL")
+        ln = C.c_size_t(0)
+        ptr = hl.povu_hip_pvst_format(n, a.ctypes.data, z.ctypes.data, ao.ctypes.data, zo.ctypes.data, parent.ctypes.data, C.byref(ln))
+        assert ptr
+        got = C.string_at(ptr, ln.value).decode()
+        hl.povu_hip_buffer_free(ptr)
+        assert got == "\n".join(want) + "\n"
+    # a parent that does not precede its child is refused
+    bad = np.array([0, 2, 1], dtype=np.uint32)
+    z3, o3 = np.zeros(3, dtype=np.uint32), np.zeros(3, dtype=np.uint8)
+    assert not hl.povu_hip_pvst_format(3, z3.ctypes.data, z3.ctypes.data, o3.ctypes.data, o3.ctypes.data, bad.ctypes.data, None)
 
 
 def test_cli_surface(tmp_path, golden_dir):
