@@ -158,7 +158,59 @@ void tokenize_slice(const char *p, const char *end, bool want_paths, bool want_l
 		out.err_line = line_no;
 		out.err_char = c;
 	};
+	// digits at q (at least one, value below 2^32 - 1) followed by a tab: the value, q behind the tab; false = not that shape
+	auto id_tab = [&](const char *&q, uint32_t &v) {
+		uint64_t x = 0;
+		const char *q0 = q;
+		while (q < end && (unsigned)(*q - '0') < 10u && q - q0 < 10) {
+			x = x * 10 + (uint64_t)(*q - '0');
+			q++;
+		}
+		if (q == q0 || q >= end || *q != '\t' || x > 0xFFFFFFFEull)
+			return false;
+		v = (uint32_t)x;
+		q++;
+		return true;
+	};
 	while (p < end) {
+		// The two records a pangenome GFA consists of, in the shape every writer gives them, are read front to back in one
+		// go (the id is evaluated while its end is being looked for; what follows the last field the path needs is skipped
+		// with a library search for the line feed).  Anything else about a line -- other records, missing fields, ids that
+		// are not numbers -- is left to the general code below, which also words the errors.
+		if (p + 1 < end && p[1] == '\t') {
+			const char *q = p + 2;
+			uint32_t a, b;
+			if (*p == 'L') {
+				if (id_tab(q, a) && q + 1 < end && (*q == '+' || *q == '-') && q[1] == '\t') {
+					const char oa = *q;
+					q += 2;
+					if (id_tab(q, b) && q < end && (*q == '+' || *q == '-') &&
+					    (q + 1 == end || q[1] == '\t' || q[1] == '\n' ||
+					     (q[1] == '\r' && (q + 2 == end || q[2] == '\n')))) {
+						const char ob = *q;
+						const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+						*la++ = a;
+						*lb++ = b;
+						*sa++ = oa == '+' ? 1 : 0;
+						*sb++ = ob == '+' ? 0 : 1;
+						line_no++;
+						p = nl ? nl + 1 : end;
+						continue;
+					}
+				}
+			} else if (*p == 'S' && !want_labels) {
+				if (id_tab(q, a) && q < end && *q != '\t' && *q != '\n' && *q != '\r') { // (a sequence of at least one byte)
+					const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+					if (ids != out.ids && a <= last_id)
+						out.ascending = false;
+					last_id = a;
+					*ids++ = a;
+					line_no++;
+					p = nl ? nl + 1 : end;
+					continue;
+				}
+			}
+		}
 		// one pass over the line: its end and the first eight tab-separated fields (S and L lines of a pangenome GFA are
 		// 13 - 30 bytes long: a library call per field cost more than the bytes)
 		const char *fb[8], *fe[8];
