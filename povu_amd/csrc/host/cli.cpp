@@ -150,6 +150,7 @@ int main(int argc, char **argv)
 			povu_host::do_gfa2vcf(cfg, call_args);
 		else {
 			povu_host::reset_debug_sidecar(cfg);
+			cfg.exit_when_done = true;
 			povu_host::do_decompose(cfg);
 		}
 	} catch (const std::exception &e) {

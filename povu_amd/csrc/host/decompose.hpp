@@ -22,6 +22,9 @@ struct Config {
 	int device = 0;
 	// --structure-export <path>: also write <path>.flubble-debug.jsonl (one frame per decomposed component)
 	std::string structure_export;
+	// the decompose command itself: once the files are written the process ends without releasing device and host memory
+	// piece by piece (do_decompose does not return then); callers that go on afterwards (gfa2vcf) leave it off
+	bool exit_when_done = false;
 };
 
 // Loads the GFA, decomposes it on the GPU and writes <output_dir>/<component id>.pvst.
