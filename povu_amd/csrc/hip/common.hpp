@@ -111,6 +111,14 @@ public:
 	static size_t padded(size_t n, size_t elem) { return ((n * elem) + 255) & ~size_t(255); }
 	size_t capacity() const { return cap_; }
 	size_t used() const { return top_; }
+	// two groups of arrays that are never live together share a stretch: carve one, rewind to where it began, carve the
+	// other, continue behind the longer of the two (rewind(m); ...; advance_to(end of the first))
+	void rewind(size_t mark) { top_ = mark; }
+	void advance_to(size_t mark)
+	{
+		if (mark > top_)
+			top_ = mark;
+	}
 
 private:
 	void *base_ = nullptr;

@@ -1025,21 +1025,43 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 
 // ------------------------------------------------------------- workspace
 template <typename F>
-static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
+static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups, F &&take_any)
 {
+	// Group 1: what the TREE stage already writes (its tree arrays in the layout the class stage reads, the back edges, the
+	// scratch of the primitives).  Group 2: everything first written by the class stage and later -- by then the tree
+	// stage's own workspace is dead but for a few arrays (tree_spans, group 1), and group 2 lies over the rest of it
+	// (stage_workspace_carve).
+	auto take1 = [&](void **p, size_t bytes) {
+		if (groups & 1)
+			take_any(p, bytes);
+	};
+	auto take = [&](void **p, size_t bytes) {
+		if (groups & 2)
+			take_any(p, bytes);
+	};
 	// brackets: the back edges of from_bd (links outside the tree, one per side without links) and, per tree vertex, at most
 	// ONE edge of the class stage -- a capping edge needs a non-empty bracket list, a simplifying edge an empty one
 	const size_t T = 2 * V + Cmax, NB = E + V + T, S = V + 1;
-	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.hi0, &pw.cov, &pw.psA,
-			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.mpre, &pw.dlt, &pw.dlt_ps, &pw.incnt,
-			     &pw.psin, &pw.topi, &pw.lsz, &pw.gcls, &pw.vals_t, &pw.vals_t2})
+	for (uint32_t **p : {&pw.hi0, &pw.mpre, &pw.dlt, &pw.incnt, &pw.lsz})
+		take1((void **)p, (T + 2) * 4);
+	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_ord})
+		take1((void **)p, (NB + 2) * 4);
+	take1((void **)&pw.err, 64);
+	take1((void **)&pw.comp_bad, (Cmax + 2) * 4); // (zeroed when the pass starts, ahead of the tree stage)
+	pw.scan_tmp_bytes = std::max(scan_tmp_bytes(std::max(T, NB) + 4), 2 * compact_tmp_bytes(std::max(T, NB) + 4));
+	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), std::max(4 * V, 2 * E) + 8) + 4);
+	take1(&pw.scan_tmp, pw.scan_tmp_bytes);
+	take1(&pw.sort_tmp, pw.sort_tmp_bytes);
+	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.cov, &pw.psA,
+			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.dlt_ps,
+			     &pw.psin, &pw.topi, &pw.gcls, &pw.vals_t, &pw.vals_t2})
 		take((void **)p, (T + 2) * 4);
 	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c, &pw.f8d})
 		take((void **)p, T + 32);
 	take((void **)&pw.keys_t, (T + 2) * 8);
 	take((void **)&pw.keys_t2, (T + 2) * 8);
 	take((void **)&pw.dbo, (Cmax + 2) * 4);
-	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_val, &pw.b_val2, &pw.tgtR, &pw.b_ord})
+	for (uint32_t **p : {&pw.b_val, &pw.b_val2, &pw.tgtR})
 		take((void **)p, (NB + 2) * 4);
 	take((void **)&pw.b_key, (NB + 2) * 8);
 	take((void **)&pw.b_key2, (NB + 2) * 8);
@@ -1049,10 +1071,8 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.walk, (S + 4) * 4);
 	take((void **)&pw.walk_ps, (S + 4) * 4);
 	take((void **)&pw.wrun, (S + 4) * 4);
-	take((void **)&pw.comp_bad, (Cmax + 2) * 4);
 	take((void **)&pw.cproc_ps, (Cmax + 2) * 4);
 	take((void **)&pw.doff, (Cmax + 2) * 4);
-	take((void **)&pw.err, 64);
 	take((void **)&pw.segA.tree, SegTree::tree_words(T + 1) * 4);
 	take((void **)&pw.segB.tree, SegTree::tree_words(NB + 1) * 4);
 	take((void **)&pw.segP.tree, SegTree::tree_words(S + 1) * 4);
@@ -1064,23 +1084,19 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, F &&take)
 	take((void **)&pw.segH1.tree, SegTree::tree_words(T + 1) * 4);
 	take((void **)&pw.segH2.tree, SegTree::tree_words(T + 1) * 4);
 	take((void **)&pw.segH3.tree, SegTree::tree_words(T + 1) * 4);
-	pw.scan_tmp_bytes = std::max(scan_tmp_bytes(std::max(T, NB) + 4), 2 * compact_tmp_bytes(std::max(T, NB) + 4));
-	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), std::max(4 * V, 2 * E) + 8) + 4);
-	take(&pw.scan_tmp, pw.scan_tmp_bytes);
-	take(&pw.sort_tmp, pw.sort_tmp_bytes);
 }
 
-size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax)
+size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups)
 {
 	ParWs tmp{};
 	size_t total = 0;
-	for_each_span(tmp, V, E, Cmax, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
+	for_each_span(tmp, V, E, Cmax, groups, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
 	return total + (1 << 20);
 }
 
-void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax)
+void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups)
 {
-	for_each_span(pw, V, E, Cmax, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+	for_each_span(pw, V, E, Cmax, groups, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
 }
 
 // ------------------------------------------------------------- driver

@@ -80,8 +80,9 @@ struct SideStream {
 	hipEvent_t fork = nullptr, join = nullptr;
 };
 
-size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax);
-void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax);
+// groups: bit 0 = the arrays the tree stage already writes, bit 1 = those first written by the class stage (see for_each_span)
+size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups = 3);
+void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups = 3);
 
 // Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
 // left in `sw`.  Components whose candidate stack is not laminar are flagged in pw.comp_bad (see pass_summary).

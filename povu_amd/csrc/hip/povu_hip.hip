@@ -390,8 +390,7 @@ extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links
 		z.Cmax = n_components ? n_components : n_vtx;
 		z.T = 2 * z.V + z.Cmax;
 		z.B = z.E + z.V + 2 * z.T;
-		total += carve_workspace(nullptr, 1, z, cs, sw, false) + par_workspace_bytes(z.V, z.E, z.Cmax) +
-			 tree_workspace_bytes(z.V, z.E, z.Cmax);
+		total += carve_workspace(nullptr, 1, z, cs, sw, false) + stage_workspace_bytes(z.V, z.E, z.Cmax);
 		return total;
 	} catch (...) {
 		return 0;
@@ -429,7 +428,7 @@ extern "C" int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_li
 		z.Cmax = std::min<size_t>(V, std::max<size_t>(1024, V / 64));
 		z.T = 2 * V + z.Cmax;
 		z.B = E + V + 2 * z.T;
-		const size_t ws2_b = carve_workspace(nullptr, 1, z, cs, sw, false) + par_workspace_bytes(V, E, z.Cmax) + tree_workspace_bytes(V, E, z.Cmax);
+		const size_t ws2_b = carve_workspace(nullptr, 1, z, cs, sw, false) + stage_workspace_bytes(V, E, z.Cmax);
 		const size_t need = graph_b + tmp_b + ws_b + ws2_b;
 		if (need + need / 8 + (size_t(64) << 20) > free_b)
 			return 0; // the worst case does not fit beside what is there: let the real calls size things
@@ -523,11 +522,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		z.T = 2 * z.V + C;
 		z.B = z.E + z.V + 2 * z.T;
 		ctx->ws2.reserve(carve_workspace(nullptr, 1, z, cs, sw, hairpins) +
-				 (all_seq ? 0 : par_workspace_bytes(z.V, z.E, C) + tree_workspace_bytes(z.V, z.E, C)));
+				 (all_seq ? 0 : stage_workspace_bytes(z.V, z.E, C)));
 		carve_workspace(&ctx->ws2, 1, z, cs, sw, hairpins);
 		if (!all_seq) {
-			par_carve(ctx->ws2, ctx->pw, z.V, z.E, C);
-			tree_carve(ctx->ws2, ctx->tw, z.V, z.E, C);
+			stage_workspace_carve(ctx->ws2, ctx->pw, ctx->tw, z.V, z.E, C);
 		}
 		bool seq_ws_ready = false;
 		auto need_seq_workspace = [&]() { // the one-lane kernels' lists live in their own arena

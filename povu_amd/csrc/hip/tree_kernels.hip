@@ -1567,50 +1567,93 @@ __global__ void k_dup_flags(uint32_t n, const uint32_t *__restrict__ skey, const
 
 // ------------------------------------------------------------------ workspace
 template <typename F>
-static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, F &&take)
+static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, F &&take_any)
 {
+	// Group 1: what outlives the tree stage (the debug hook that recomputes the edge-id weights after a pass reads the DFS
+	// records, the tree index of every side and the duplicate-slot flags).  Group 2: the rest -- dead once the class stage
+	// starts, whose own arrays lie over it (stage_workspace_carve).
+	auto take1 = [&](void **p, size_t bytes) {
+		if (groups & 1)
+			take_any(p, bytes);
+	};
+	auto take = [&](void **p, size_t bytes) {
+		if (groups & 2)
+			take_any(p, bytes);
+	};
 	const size_t nS = 2 * V + 2, NA = std::max<size_t>(4 * V, 2 * E) + 8; // tour positions; the 8-byte arrays double as slot buffers
 	const size_t NSL = std::max<size_t>(2 * V + 2 * E, 4 * V) + 16; // scan slots of all sides / events of the second ranking
-	take((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
+	take1((void **)&tw.dvis_slots, std::max(2 * E, 2 * V) + 16); // per-slot duplicate flags (hub graphs); earlier: per-side class flags
+	take1((void **)&tw.side_tidx, nS * 4);
+	take1((void **)&tw.dps, nS * 8);
 	take((void **)&tw.dist, NSL * 4);
-	// one 16-byte value per segment that carries one (K <= V), and their running xor; on hub graphs the same two blocks hold
-	// the two key and the two value buffers of the slot sort (2E four-byte words each)
-	const size_t XV = std::max<size_t>(V + 2, E + 8) + 8;
-	take((void **)&tw.xval, XV * 16);
-	take((void **)&tw.xps, XV * 16);
 	take((void **)&tw.xrec, (NA / 64 + 4) * 16);
 	take((void **)&tw.xrank, (NA / 64 + 4) * 4);
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0seg, (V + 2) * 16);
-	for (uint32_t **p : {&tw.pbr,
-			     &tw.entry_ps, &tw.entry_list,
-			     &tw.side_tidx, &tw.be_cnt})
+	for (uint32_t **p : {&tw.pbr, &tw.entry_ps, &tw.entry_list, &tw.be_cnt})
 		take((void **)p, nS * 4);
-	take((void **)&tw.dps, nS * 8);
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.entry_flag, nS + 16);
 	take((void **)&tw.wadj, (nS + 2 * E + 8) * 8); // wave walk: class-filtered scan lists (4 bytes a slot); earlier in the pass: twin slots [2E]
-	take((void **)&tw.wrec, nS * 32);	       // 32-byte record per side
-	take((void **)&tw.wstk, 3 * nS * 8 + 64);      // stack pool: chunks double in size, a class takes less than three entries per side
-	take((void **)&tw.wpar, nS * 4);
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	take((void **)&tw.rk_pk, NSL * 4);
 	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
-	for (uint32_t **p : {&tw.rk_nx, &tw.rk_wa, &tw.rk_wb, &tw.rk_tA, &tw.rk_tB, &tw.rk_tC})
-		take((void **)p, rank_pool_words(NSL, Cmax + 1) * 4);
+	// One block, three tenants that are never at home together: the six level pools of the list rankings (the tour's at the
+	// start, the pre-order's after the class walks); behind the pools the bridge test's values -- one 16-byte value per
+	// segment that carries one (K <= V) and their running xor, live between the first ranking and the class walks, and on
+	// hub graphs once more after the second ranking as the key and value buffers of the slot sort (2E four-byte words each);
+	// and, over all of it, the wave walk's per-side records, stack pool and parents (only while the large classes are
+	// walked).  ~12 GB instead of 21 on the whole-genome workload.
+	auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+	const size_t pool_b = pad(rank_pool_words(NSL, Cmax + 1) * 4);
+	const size_t xv_b = pad((std::max<size_t>(V + 2, E + 8) + 8) * 16);
+	const size_t wrec_b = pad(nS * 32);	     // 32-byte record per side
+	const size_t wstk_b = pad(3 * nS * 8 + 64); // stack pool: chunks double in size, a class takes less than three entries per side
+	const size_t wpar_b = pad(nS * 4);
+	char *blk = nullptr;
+	take((void **)&blk, std::max(6 * pool_b + 2 * xv_b, wrec_b + wstk_b + wpar_b));
+	if (blk) {
+		uint32_t **pools[6] = {&tw.rk_nx, &tw.rk_wa, &tw.rk_wb, &tw.rk_tA, &tw.rk_tB, &tw.rk_tC};
+		for (int k = 0; k < 6; k++)
+			*pools[k] = reinterpret_cast<uint32_t *>(blk + (size_t)k * pool_b);
+		tw.xval = reinterpret_cast<decltype(tw.xval)>(blk + 6 * pool_b);
+		tw.xps = reinterpret_cast<decltype(tw.xps)>(blk + 6 * pool_b + xv_b);
+		tw.wrec = reinterpret_cast<decltype(tw.wrec)>(blk);
+		tw.wstk = reinterpret_cast<decltype(tw.wstk)>(blk + wrec_b);
+		tw.wpar = reinterpret_cast<decltype(tw.wpar)>(blk + wrec_b + wstk_b);
+	}
 }
 
-size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax)
+size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups)
 {
 	TreeWs tmp{};
 	size_t total = 0;
-	tree_spans(tmp, V, E, Cmax, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
+	tree_spans(tmp, V, E, Cmax, groups, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
 	return total + (1 << 20);
 }
 
-void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax)
+void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups)
 {
-	tree_spans(tw, V, E, Cmax, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+	tree_spans(tw, V, E, Cmax, groups, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+}
+
+// The workspace of the parallel stages: what the tree stage hands to the class stage and what outlives the tree stage side
+// by side; then ONE stretch that holds the tree stage's own arrays first and the class stage's afterwards.
+size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax)
+{
+	return par_workspace_bytes(V, E, Cmax, 1) + tree_workspace_bytes(V, E, Cmax, 1) +
+	       std::max(tree_workspace_bytes(V, E, Cmax, 2), par_workspace_bytes(V, E, Cmax, 2));
+}
+void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax)
+{
+	par_carve(ar, pw, V, E, Cmax, 1);
+	tree_carve(ar, tw, V, E, Cmax, 1);
+	const size_t shared = ar.used();
+	tree_carve(ar, tw, V, E, Cmax, 2);
+	const size_t tree_end = ar.used();
+	ar.rewind(shared);
+	par_carve(ar, pw, V, E, Cmax, 2);
+	ar.advance_to(tree_end);
 }
 
 // ------------------------------------------------------------------ driver

@@ -36,8 +36,12 @@ struct TreeWs {
 	const uint8_t *last_dupflag;			  // dvis_slots when the last pass filled it, else null
 };
 
-size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax);
-void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax);
+// groups: bit 0 = the arrays that outlive the tree stage, bit 1 = those that are dead when the class stage starts (tree_spans)
+size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups = 3);
+void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups = 3);
+// both parallel stages in one arena, the class stage's own arrays over the tree stage's dead ones
+size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax);
+void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax);
 
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.
