@@ -74,11 +74,13 @@ public:
 		top_ = 0;
 	}
 	// make sure `bytes` are available from offset 0; invalidates earlier spans
-	void reserve(size_t bytes)
+	// (head_room: an eighth more than asked for, so that the next, slightly larger graph of a long-lived context does not
+	// cost a new allocation; a caller that knows there will be no next graph asks for none)
+	void reserve(size_t bytes, bool head_room = true)
 	{
 		if (bytes > cap_) {
 			release();
-			size_t want = bytes + bytes / 8 + (1u << 20);
+			size_t want = head_room ? bytes + bytes / 8 + (1u << 20) : bytes + 4096;
 			if (hipMalloc(&base_, want) != hipSuccess) {
 				(void)hipGetLastError();
 				base_ = nullptr;

@@ -432,10 +432,11 @@ extern "C" int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_li
 		const size_t need = graph_b + tmp_b + ws_b + ws2_b;
 		if (need + need / 8 + (size_t(64) << 20) > free_b)
 			return 0; // the worst case does not fit beside what is there: let the real calls size things
-		ctx->graph_arena.reserve(graph_b);
-		ctx->upload_tmp.reserve(tmp_b);
-		ctx->ws.reserve(ws_b);
-		ctx->ws2.reserve(ws2_b);
+		// (exact sizes: a context that is warmed for one graph is usually there for that graph only)
+		ctx->graph_arena.reserve(graph_b, false);
+		ctx->upload_tmp.reserve(tmp_b, false);
+		ctx->ws.reserve(ws_b, false);
+		ctx->ws2.reserve(ws2_b, false);
 		return 0;
 	} catch (const std::exception &e) {
 		set_err(err, errlen, e.what());

@@ -46,7 +46,7 @@ void do_decompose(const Config &cfg)
 		char perr[256];
 		auto fits = [](size_t n) { return n && n < 0xFFFFFFFFull; };
 		const std::pair<size_t, size_t> n = counts_f.get(); // ({0, 0}: the parse failed before it knew)
-		if (c && fits(n.first) && fits(n.second + 1))
+		if (c && fits(n.first) && fits(n.second + 1) && !std::getenv("POVU_CLI_NO_PREWARM"))
 			(void)povu_hip_prewarm(c, (uint32_t)n.first, (uint32_t)n.second, perr, sizeof perr); // (best effort)
 		return c;
 	});
