@@ -19,30 +19,72 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 // (also validates the operands: the first link that names an unknown vertex or side lands in *bad)
 __global__ void k_side_degree(uint32_t E, uint32_t V, const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1,
 			      const uint32_t *__restrict__ v2, const uint8_t *__restrict__ s2,
-			      uint32_t *__restrict__ deg, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-			      uint32_t sentinel, uint32_t *__restrict__ bad)
+			      uint32_t *__restrict__ deg, uint32_t *__restrict__ bad)
 {
 	uint32_t e = BIDX * blockDim.x + threadIdx.x;
 	if (e >= E)
 		return;
 	if (v1[e] >= V || v2[e] >= V || s1[e] > 1 || s2[e] > 1) {
-		atomicMin(bad, e);
-		keys[2 * e] = keys[2 * e + 1] = sentinel;
-		vals[2 * e] = vals[2 * e + 1] = e;
+		atomicMin(bad, e); // (the host stops the upload before anything reads the degrees)
 		return;
 	}
 	uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
 	atomicAdd(&deg[a], 1u);
-	keys[2 * e] = a;
-	vals[2 * e] = e;
-	// a same-side self loop sits once in the side's std::set (bidirected.cpp:324-333)
-	if (b != a) {
+	if (b != a) // a same-side self loop sits once in the side's std::set (bidirected.cpp:324-333)
 		atomicAdd(&deg[b], 1u);
-		keys[2 * e + 1] = b;
-	} else {
-		keys[2 * e + 1] = sentinel;
+}
+// The adjacency lists without a sort (every side has at most FILL_MAX_SIDE_DEGREE links): a link takes the next free
+// slot of either of its sides, in whatever order the lanes arrive, and k_side_sort then puts every list in ascending link
+// order -- the order a stable sort of the (side, link) pairs gives, at a third of its cost.  The links are valid here.
+static constexpr uint32_t FILL_MAX_SIDE_DEGREE = 64;
+__global__ void k_slot_fill(uint32_t E, const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1,
+			    const uint32_t *__restrict__ v2, const uint8_t *__restrict__ s2, const uint32_t *__restrict__ off,
+			    uint32_t *__restrict__ cursor, uint32_t *__restrict__ adj)
+{
+	uint32_t e = BIDX * blockDim.x + threadIdx.x;
+	if (e >= E)
+		return;
+	const uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
+	adj[off[a] + atomicAdd(&cursor[a], 1u)] = e;
+	if (b != a)
+		adj[off[b] + atomicAdd(&cursor[b], 1u)] = e;
+}
+__global__ void k_side_sort(uint32_t nS, const uint32_t *__restrict__ off, uint32_t *__restrict__ adj)
+{
+	uint32_t S = BIDX * blockDim.x + threadIdx.x;
+	if (S >= nS)
+		return;
+	const uint32_t lo = off[S], n = off[S + 1] - lo;
+	if (n < 2)
+		return;
+	if (n == 2) {
+		const uint32_t x = adj[lo], y = adj[lo + 1];
+		if (y < x)
+			adj[lo] = y, adj[lo + 1] = x;
+		return;
 	}
-	vals[2 * e + 1] = e;
+	for (uint32_t i = 1; i < n; i++) { // (n <= FILL_MAX_SIDE_DEGREE)
+		const uint32_t x = adj[lo + i];
+		uint32_t j = i;
+		while (j > 0 && adj[lo + j - 1] > x) {
+			adj[lo + j] = adj[lo + j - 1];
+			j--;
+		}
+		adj[lo + j] = x;
+	}
+}
+// hub graphs: the (side, link) pairs of the stable radix sort
+__global__ void k_side_pairs(uint32_t E, const uint32_t *__restrict__ v1, const uint8_t *__restrict__ s1,
+			     const uint32_t *__restrict__ v2, const uint8_t *__restrict__ s2, uint32_t *__restrict__ keys,
+			     uint32_t *__restrict__ vals, uint32_t sentinel)
+{
+	uint32_t e = BIDX * blockDim.x + threadIdx.x;
+	if (e >= E)
+		return;
+	const uint32_t a = 2 * v1[e] + s1[e], b = 2 * v2[e] + s2[e];
+	keys[2 * e] = a;
+	keys[2 * e + 1] = b != a ? b : sentinel; // (the sentinel sorts behind every side: the slot count leaves it out)
+	vals[2 * e] = vals[2 * e + 1] = e;
 }
 
 // other end of every adjacency slot, as a global side id
@@ -707,7 +749,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	uint32_t *deg = tmp_arena.take<uint32_t>(nS + 1);
 	size_t sb = sort_tmp_bytes(2 * (size_t)E), cb = scan_tmp_bytes(std::max<size_t>(nS, E) + 2);
 	void *stmp = tmp_arena.take<char>(sb), *ctmp = tmp_arena.take<char>(cb);
-	uint32_t *word = tmp_arena.take<uint32_t>(8); // [0] max degree, [1] first bad link, [2] first bad tip
+	uint32_t *word = tmp_arena.take<uint32_t>(8); // [0] max vertex degree, [1] first bad link, [2] first bad tip, [3] max side degree
 	hipEvent_t ev[3];
 	for (auto &e : ev)
 		HIP_CHECK(hipEventCreate(&e));
@@ -723,26 +765,35 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	HIP_CHECK(hipMemsetAsync(deg, 0, (nS + 1) * 4, s));
 	HIP_CHECK(hipMemsetAsync(word, 0, 4, s));
 	HIP_CHECK(hipMemsetAsync(word + 1, 0xFF, 8, s));
+	HIP_CHECK(hipMemsetAsync(word + 3, 0, 4, s));
 	if (E) {
-		KLAUNCH(k_side_degree, dim3(nblk(E)), dim3(TPB), 0, s, E, V, g.v1, g.s1, g.v2, g.s2, deg, keys, vals,
-				   (uint32_t)nS, word + 1);
+		KLAUNCH(k_side_degree, dim3(nblk(E)), dim3(TPB), 0, s, E, V, g.v1, g.s1, g.v2, g.s2, deg, word + 1);
 	}
 	if (g.tips_given) {
 		KLAUNCH(k_check_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.tip, word + 2);
 	}
 	scan_exclusive_u32(deg, g.off, nS + 1, ctmp, cb, s);
-	sort_pairs_u32(keys, keys2, vals, vals2, 2 * (size_t)E, bits_for(nS), stmp, sb, s);
-	uint32_t hw[4] = {0, 0, 0, 0};
+	if (nS) {
+		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, deg, word + 3);
+	}
+	uint32_t hw[4] = {0, 0, 0, 0}; // slots, first bad link, first bad tip, most links on one side
 	HIP_CHECK(hipMemcpyAsync(&hw[0], g.off + nS, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(&hw[1], word + 1, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(&hw[1], word + 1, 12, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (hw[1] != POVU_NIL)
 		throw HipError("link " + std::to_string(hw[1]) + " references an unknown vertex or side");
 	if (hw[2] != POVU_NIL)
 		throw HipError("bad tip mark");
 	g.n_slots = hw[0];
-	if (g.n_slots)
+	if (g.n_slots && hw[3] <= FILL_MAX_SIDE_DEGREE) {
+		HIP_CHECK(hipMemsetAsync(deg, 0, (nS + 1) * 4, s)); // (the degrees live on in g.off: the array now counts filled slots)
+		KLAUNCH(k_slot_fill, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.s1, g.v2, g.s2, g.off, deg, g.adj);
+		KLAUNCH(k_side_sort, dim3(nblk(nS)), dim3(TPB), 0, s, (uint32_t)nS, g.off, g.adj);
+	} else if (g.n_slots) {
+		KLAUNCH(k_side_pairs, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.s1, g.v2, g.s2, keys, vals, (uint32_t)nS);
+		sort_pairs_u32(keys, keys2, vals, vals2, 2 * (size_t)E, bits_for(nS), stmp, sb, s);
 		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)g.n_slots * 4, hipMemcpyDeviceToDevice, s));
+	}
 	if (!g.tips_given && V) {
 		KLAUNCH(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
 	}
