@@ -757,6 +757,23 @@ def test_hub_with_many_parallel_links(hip):
         hip.debug_edge_ids(0)
 
 
+@pytest.mark.parametrize("fan", [2, 3, 17, 63, 64, 65, 66, 200])
+def test_side_degrees_around_the_csr_builders_switch(hip, fan):
+    """The adjacency at upload is filled through atomic cursors and sorted per side while no side has more than 64 links
+    (k_slot_fill / k_side_sort), and by the stable radix sort of (side, link) pairs beyond: the same graph either way.  A
+    fan of `fan` links on one side of a segment -- links of that side given in DESCENDING order of their far ends, some
+    twice -- with bubbles behind the fan."""
+    n = fan + 4
+    links = [(0, W.R, k, W.L) for k in range(fan, 0, -1)]
+    links += [(0, W.R, k, W.L) for k in range(1, fan, 7)]  # repeated links: same sides, later link index
+    links += [(k, W.R, fan + 1, W.L) for k in range(1, fan + 1)]
+    links += [(fan + 1, W.R, fan + 2, W.L), (fan + 1, W.R, fan + 3, W.L), (fan + 2, W.R, fan + 3, W.L)]
+    g = _mk(list(range(1, n + 1)), links)
+    want = O.decompose(g)
+    assert gpu_texts(hip, g) == want
+    assert np.array_equal(hip.debug_edge_ids(0), dump_component(g, 0)["pe_id"])
+
+
 def _read_sidecar(path):
     with open(path) as fh:
         return [json.loads(l) for l in fh if l.strip()]
