@@ -399,7 +399,7 @@ extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links
 
 // Reserve, ahead of time, the device arenas a graph of this size will need (the resident graph, the CSR build's scratch and
 // the decompose workspace for a graph of few components): the first upload + decompose on a fresh context otherwise
-// pay for ~2 KB of device memory per segment being mapped (0.5 - 3 s for a whole-genome graph).  The CLI calls this on
+// pay for ~1 KB of device memory per segment being mapped (0.3 s and more for a whole-genome graph).  The CLI calls this on
 // the thread that brought HIP up, as soon as the tokenizer knows the counts and while the rest of the parse runs.
 // Best effort: when that does not fit, the arenas are left alone and the real calls allocate exactly.
 extern "C" int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_links, char *err, size_t errlen)

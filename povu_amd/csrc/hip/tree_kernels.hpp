@@ -12,7 +12,7 @@ struct TreeWs {
 	HostScratch *host; // pinned read-back scratch of the owning context
 	// unrooted spanning forest of the biedged graph H, as arcs
 	uint32_t *dist;					  // [2E] arcs behind an adjacency slot in its Euler tour (slots of hooked links = arcs, see tree_kernels.hip)
-	ulonglong2 *xval, *xps;				  // [4V+4] xor values (two 64-bit hashes) of the segments that have any, in tour order, and their running xor
+	ulonglong2 *xval, *xps;				  // [max(V, E) + 16] xor values (two 64-bit hashes) of the segments that have any, in tour order, and their running xor (inside the shared block, see tree_spans)
 	uint4 *xrec;					  // [(4V+8)/64 + 4] per 64 tour positions {which of them carry a value (64 bits), set bits in front of the word, -}
 	uint32_t *xrank;				  // [(4V+8)/64 + 4] scan buffer of the bit counts (the last entry: their total)
 	uint4 *t0seg;					  // [V] rooted forest, per segment: {parent of the entered side, link to it | r bit, tour position in, out}

@@ -11,7 +11,7 @@ scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 worlds = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["2", "4", "8"])]
 g = W.hprc_whole_genome(1e8 * scale)
 out = {"links": g.n_links, "segments": g.n_vtx, "runs": []}
-# 1-GPU reference on the same box (its own context: the workspace of a whole-genome pass is ~185 GB)
+# 1-GPU reference on the same box (its own context: the workspace of a whole-genome pass is ~80 GB)
 ref = HipDecomposer(0)
 ref.upload(g)
 f = None
