@@ -79,7 +79,6 @@ struct Seg {
 // what the loader needs only while it runs (see GfaScratch in gfa.hpp)
 struct Scratch {
 	std::unique_ptr<Mapped> file;
-	U32Vec la, lb; // link ends as segment ids
 	U32Vec table;  // id -> idx
 	std::vector<Seg> segs;
 };
@@ -393,15 +392,15 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 	if (on_counts && n_seg)
 		on_counts(n_seg, E);
 	// the graph's arrays at their final size (uninitialised: every element is written, and its page first touched, by the
-	// thread that owns the slice); la / lb hold the link ends as segment ids until the id table exists
+	// thread that owns the slice); v1 / v2 hold the link ends as segment ids until the ids can be mapped, in place
 	Scratch &sc = *scratch;
-	sc.la.resize(E);
-	sc.lb.resize(E);
+	g.v1.resize(E);
+	g.v2.resize(E);
 	g.vid.resize(n_seg);
 	g.s1.resize(E);
 	g.s2.resize(E);
 	sc.segs.resize(want_labels ? n_seg : 0);
-	U32Vec &la = sc.la, &lb = sc.lb;
+	U32Vec &la = g.v1, &lb = g.v2;
 	std::vector<Seg> &segs = sc.segs;
 	for_slices([&](size_t t) {
 		Slice &sl = slices[t];
@@ -452,10 +451,12 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 		for (size_t i = 0; i < V; i++)
 			g.seq[i].assign(segs[i].sb, segs[i].se);
 	}
-	// id -> idx: direct table when ids are dense, binary search otherwise
-	const uint32_t max_id = g.vid.back();
+	// id -> idx: plain arithmetic when the ids are consecutive (what graph builders write: 1 .. V), a direct table when they
+	// are dense, binary search otherwise
+	const uint32_t min_id = g.vid.front(), max_id = g.vid.back();
+	const bool consecutive = (uint64_t)max_id - min_id + 1 == (uint64_t)V; // (the ids are distinct and ascending here)
 	U32Vec &table = sc.table;
-	if ((uint64_t)max_id < 4 * (uint64_t)V + 1024) {
+	if (!consecutive && (uint64_t)max_id < 4 * (uint64_t)V + 1024) {
 		table.resize((size_t)max_id + 1);
 		parallel_ranges(TH, table.size(), [&](size_t, size_t lo, size_t hi) { std::fill(table.begin() + lo, table.begin() + hi, 0xFFFFFFFFu); });
 		parallel_ranges(TH, V, [&](size_t, size_t lo, size_t hi) {
@@ -464,10 +465,25 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 		});
 	}
 	phase("id table");
-	g.v1.resize(E);
-	g.v2.resize(E);
-	std::vector<size_t> bad(TH, (size_t)-1); // first link of a range that names an unknown segment
+	struct Bad {
+		size_t link = (size_t)-1; // first link of a range that names an unknown segment
+		uint32_t id = 0;	  // ... and the name
+	};
+	std::vector<Bad> bad(TH);
 	parallel_ranges(TH, E, [&](size_t t, size_t lo, size_t hi) {
+		Bad first;
+		if (consecutive) {
+			const uint32_t span = max_id - min_id; // (id - min_id wraps for ids below min_id: beyond span as well)
+			for (size_t e = hi; e-- > lo;) { // (descending, so that the first bad link of the range is the one that stays)
+				const uint32_t ia = la[e], ib = lb[e], a = ia - min_id, b = ib - min_id;
+				la[e] = a <= span ? a : 0xFFFFFFFFu;
+				lb[e] = b <= span ? b : 0xFFFFFFFFu;
+				if (a > span || b > span)
+					first = Bad{e, a > span ? ia : ib};
+			}
+			bad[t] = first;
+			return;
+		}
 		auto idx_of = [&](uint32_t id) -> uint32_t {
 			if (!table.empty())
 				return id <= max_id ? table[id] : 0xFFFFFFFFu;
@@ -475,22 +491,22 @@ GfaGraph load_gfa(const std::string &fp, bool want_labels, bool want_paths, int 
 			return (it != g.vid.end() && *it == id) ? (uint32_t)(it - g.vid.begin()) : 0xFFFFFFFFu;
 		};
 		for (size_t e = lo; e < hi; e++) {
-			const uint32_t a = idx_of(la[e]), b = idx_of(lb[e]);
-			if ((a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) && bad[t] == (size_t)-1)
-				bad[t] = e;
-			g.v1[e] = a;
-			g.v2[e] = b;
+			const uint32_t ia = la[e], ib = lb[e], a = idx_of(ia), b = idx_of(ib);
+			if ((a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) && first.link == (size_t)-1)
+				first = Bad{e, a == 0xFFFFFFFFu ? ia : ib};
+			la[e] = a;
+			lb[e] = b;
 		}
+		bad[t] = first;
 	});
 	phase("link ends");
-	size_t first_bad = (size_t)-1;
-	for (size_t b : bad)
-		first_bad = std::min(first_bad, b);
-	if (first_bad != (size_t)-1) {
-		const uint32_t id = g.v1[first_bad] == 0xFFFFFFFFu ? la[first_bad] : lb[first_bad];
-		throw std::runtime_error(invalid(fp, "L record " + std::to_string(first_bad) + " references unknown segment " +
-							     std::to_string(id)));
-	}
+	Bad first_bad;
+	for (const Bad &b : bad)
+		if (b.link < first_bad.link)
+			first_bad = b;
+	if (first_bad.link != (size_t)-1)
+		throw std::runtime_error(invalid(fp, "L record " + std::to_string(first_bad.link) + " references unknown segment " +
+							     std::to_string(first_bad.id)));
 	return g;
 }
 

@@ -171,6 +171,13 @@ def test_ffi_gfa_errors(tmp_path):
     err = _Err(0, None)
     assert not lib.povu_graph_from_gfa(str(bad).encode(), C.byref(err))
     assert err.message == f"Invalid GFA '{bad}': S record on line 2 has an empty sequence".encode()
+    # a link to a segment the file does not define: consecutive ids (plain arithmetic), dense ids (table), sparse ids (search)
+    for ids, ghost in (((5, 6, 7), 4), ((5, 6, 7), 8), ((5, 6, 7), 4000000000), ((5, 7, 9), 6), ((5, 7, 900000), 8)):
+        body = "".join(f"S\t{i}\tA\n" for i in ids) + f"L\t{ids[0]}\t+\t{ids[1]}\t+\t0M\nL\t{ids[1]}\t+\t{ghost}\t-\t0M\n"
+        bad.write_text(body)
+        err = _Err(0, None)
+        assert not lib.povu_graph_from_gfa(str(bad).encode(), C.byref(err))
+        assert err.message == f"Invalid GFA '{bad}': L record 1 references unknown segment {ghost}".encode(), err.message
     bad.write_text("S\t1\tA\nX\tfoo\n")
     err = _Err(0, None)
     assert not lib.povu_graph_from_gfa(str(bad).encode(), C.byref(err))
