@@ -37,8 +37,10 @@ void do_decompose(const Config &cfg)
 	const double t0 = now_ms();
 	// the HIP runtime comes up (~0.1 s) while the GFA is being parsed
 	char err[512] = {0}, cerr_buf[512] = {0};
-	// ... and the same thread reserves the device memory the graph will need (povu_hip_prewarm) while the parse goes on: the
-	// loader's counting pass knows the segment and link counts a few ten milliseconds in, before the runtime is up
+	// With POVU_CLI_PREWARM=1 the same thread also reserves the device memory the graph will need (povu_hip_prewarm) as soon as
+	// the loader's counting pass knows the segment and link counts.  Off by default since the parse of a whole-genome GFA
+	// (0.2 s) stopped being longer than the bring-up itself: there is nothing left to hide the reservation behind, and made
+	// next to 32 tokenizer threads it took longer (0.6 s) than the same memory taken by upload and decompose when they need it.
 	std::promise<std::pair<size_t, size_t>> counts_p;
 	std::future<std::pair<size_t, size_t>> counts_f = counts_p.get_future();
 	std::future<povu_hip_ctx *> ctx_f = std::async(std::launch::async, [&]() {
@@ -46,7 +48,7 @@ void do_decompose(const Config &cfg)
 		char perr[256];
 		auto fits = [](size_t n) { return n && n < 0xFFFFFFFFull; };
 		const std::pair<size_t, size_t> n = counts_f.get(); // ({0, 0}: the parse failed before it knew)
-		if (c && fits(n.first) && fits(n.second + 1) && !std::getenv("POVU_CLI_NO_PREWARM"))
+		if (c && fits(n.first) && fits(n.second + 1) && std::getenv("POVU_CLI_PREWARM"))
 			(void)povu_hip_prewarm(c, (uint32_t)n.first, (uint32_t)n.second, perr, sizeof perr); // (best effort)
 		return c;
 	});
