@@ -291,7 +291,8 @@ int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t 
 uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components);
 /* Reserves the device memory a graph of this size will need (resident graph, CSR build scratch, decompose workspace for
  * the worst case of components) on a context that holds nothing yet, so that the first upload + decompose do not pay for
- * the allocation: meant to run on another thread while the caller still parses its input (the CLI does).  Best effort:
+ * the allocation: meant to run on another thread while the caller still parses its input, when that takes longer than
+ * bringing the runtime up (the CLI does so with POVU_CLI_PREWARM=1; exact sizes, no head room).  Best effort:
  * returns 0 and reserves nothing when the worst case does not fit; 1 + message only for bad arguments / HIP errors.  Must
  * not run concurrently with another call on the same context. */
 int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_links, char *err, size_t errlen);
