@@ -456,7 +456,16 @@ def test_host_code_under_address_and_ub_sanitizers(golden_dir, tmp_path):
     big.write_text(W.chain_of_bubbles(3000).to_gfa())
     bad = tmp_path / "bad.gfa"
     bad.write_text("S\t1\nL\t1\t+\t2\n")
-    files = sorted(glob.glob(os.path.join(golden_dir, "gfa", "*.gfa")) + glob.glob(os.path.join(golden_dir, "pvst", "*.pvst")))
+    # several tokenizer slices (>= 4 MiB each), and the same text cut off inside a record at a few places: the reading of S
+    # and L records front to back must stop at the end of the mapping whatever it is in the middle of
+    wide = W.chain_of_bubbles(110000).to_gfa().encode()
+    assert len(wide) > 4 * (4 << 20)
+    cuts = []
+    for k, n in enumerate((len(wide), len(wide) - 1, len(wide) - 2, len(wide) - 3, len(wide) - 5, len(wide) - 9, len(wide) // 2 + 1)):
+        q = tmp_path / f"wide{k}.gfa"
+        q.write_bytes(wide[:n])
+        cuts.append(str(q))
+    files = cuts + sorted(glob.glob(os.path.join(golden_dir, "gfa", "*.gfa")) + glob.glob(os.path.join(golden_dir, "pvst", "*.pvst")))
     r = subprocess.run([exe] + files + [str(big), str(bad)], capture_output=True, text=True,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0, r.stderr[-3000:]
