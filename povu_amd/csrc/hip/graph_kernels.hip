@@ -328,14 +328,6 @@ __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__r
 	}
 }
 
-__global__ void k_compact_pos(uint32_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ ps,
-			      uint32_t *__restrict__ out)
-{
-	uint32_t i = BIDX * blockDim.x + threadIdx.x;
-	if (i < n && flag[i])
-		out[ps[i]] = i;
-}
-
 __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__ is_root, uint32_t *__restrict__ unsorted)
 {
 	uint32_t v = BIDX * blockDim.x + threadIdx.x;

@@ -38,6 +38,18 @@ def test_golden_fixtures(hip, golden_dir):
         assert gpu_texts(hip, g) == {1: open(p).read()}, name
 
 
+def test_downstream_repetitive_inputs_match_oracle(hip, golden_dir):
+    """the reference's downstream_repetitive input graphs (no PVST answers there: HIP against the oracle)"""
+    files = sorted(glob.glob(os.path.join(golden_dir, "gfa", "downstream_repetitive", "*.gfa")))
+    assert len(files) == 5
+    for p in files:
+        g = _load_gfa_links(p)
+        want = O.decompose(g)
+        assert gpu_texts(hip, g) == want, p
+        from povu_amd.hip import F_SEQUENTIAL
+        assert gpu_texts(hip, g, flags=F_SEQUENTIAL) == want, p
+
+
 def test_lpa_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))
     g = _load_gfa_links(os.path.join(golden_dir, "gfa", "LPA.gfa"))

@@ -307,3 +307,26 @@ def test_rescan_from_start_equals_cursor_resume():
         lib.orc_set_faithful_rescan(0)
         b = O.decompose(g)
         assert a == b
+
+
+def test_downstream_repetitive_inputs(golden_dir, tmp_path):
+    """The five input graphs of the reference's tests/lean4_conformance/fixtures/downstream_repetitive (its own shapes:
+    popped-parent-child-rescue is exactly add_flubbles' pop-through rule, flubbles.cpp:326-343).  PARITY UNPINNED: the
+    reference holds no PVST for them -- their VCFs are hand-written expectations for future `povu call` profiles -- so the
+    check is the weak one those files allow: every flubble the oracle finds is a site id of the fixture's raw_graph.vcf."""
+    ids = json.load(open(os.path.join(golden_dir, "downstream_repetitive_raw_ids.json")))
+    files = sorted(glob.glob(os.path.join(golden_dir, "gfa", "downstream_repetitive", "*.gfa")))
+    assert len(files) == 5
+    for p in files:
+        name = os.path.basename(p)[:-4]
+        out = tmp_path / name
+        out.mkdir()
+        assert O.decompose_gfa(p, str(out)) == 1
+        text = open(out / "1.pvst").read()
+        assert O.decompose(_load_gfa_links(p)) == {1: text}  # the array entry point and the GFA loader agree
+        labels = [l.split("\t")[2] for l in text.splitlines() if l[0] == "F"]
+        if ids[name] is not None:
+            assert set(labels) <= set(ids[name]), (name, labels)
+    # the pop-through rule: >2>4 closes inside >0>5's span but is emitted at the root level (one climb per pop event)
+    pop = open(tmp_path / "popped-parent-child-rescue" / "1.pvst").read().splitlines()
+    assert pop[1:] == ["D\t0\t.\t1, 2\t.", "F\t1\t>0>5\t.\tL", "F\t2\t>2>4\t.\tL"]
