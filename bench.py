@@ -194,6 +194,84 @@ def end_to_end_cli(g, wl):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def main_one_process(args):
+    """--gpus N without a launcher: one process, N GPUs through the library's own engine (povu_hip_multi_*)."""
+    from povu_amd.hip import F_NO_STAGE_TIMES, MultiDecomposer, load_lib
+    n_dev = load_lib().povu_hip_device_count()
+    one = bool(os.environ.get("POVU_BENCH_ONE_DEVICE"))  # rehearsal on a one-GPU box: every rank on device 0
+    if not one and n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP devices are visible "
+                         f"(POVU_BENCH_ONE_DEVICE=1 rehearses the path on one)")
+    md = MultiDecomposer([0] * args.gpus if one else list(range(args.gpus)))
+    g, wl = build_workload(args.workload, args.scale)
+    E, V = g.n_links, g.n_vtx
+    md.upload(g)
+    del g
+    f = None
+    # ---- the whole job: label + LPT + partition on the root, scatter, CSR build and decompose on every GPU
+    for _ in range(args.warmup):
+        md.scatter()
+        f = md.decompose(F_NO_STAGE_TIMES)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        md.scatter()
+        f = md.decompose(F_NO_STAGE_TIMES)
+    dt = time.perf_counter() - t0
+    t_part = md.times()
+    ranks_whole = [md.rank_info(r) for r in range(args.gpus)]
+    # ---- the N = 1 line's definition: the shards of the last scatter stay resident as CSR; a step = every GPU decomposes its
+    # shard and lands its PVST block in host memory (md.decompose returns when every worker has; merging copies nothing)
+    f = md.decompose(F_NO_STAGE_TIMES)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f = md.decompose(F_NO_STAGE_TIMES)
+    dt_res = time.perf_counter() - t0
+    F, n_trees = count_flubbles(f), len(f)
+    ranks = [md.rank_info(r) for r in range(args.gpus)]
+    alg = algorithmic_bytes(E, V, F)
+    step_s = dt_res / args.steps
+    w = [r["n_links"] + r["n_vtx"] for r in ranks]
+    out = {
+        "metric": "edges/sec decomposed (flubble+PVST)",
+        "value": E * args.steps / dt_res,
+        "unit": "edges/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": wl, "links": E, "segments": V, "components": n_trees, "flubbles": F,
+                   "sharding": "strong scaling, one process: the root GPU labels the components, LPT bin-packing, device partition; "
+                               f"shards over xGMI ({md.transport}); every GPU lands its PVST block in host memory over its own PCIe "
+                               "link, the merged forest takes the blocks over (no gather transfer)"},
+        "roofline": {"bound": "hbm", "kernel": "per-shard decompose pass on every GPU (from resident shards)",
+                     "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS * args.gpus, "unit": "GB/s",
+                     "frac": alg / step_s / 1e9 / (HBM_PEAK_GBS * args.gpus), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "ms_per_launch": step_s * 1e3,
+                     "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d) over the aggregate peak of all GPUs"},
+        "value_from_resident_shards": E * args.steps / dt_res,
+        "value_whole_job": E * args.steps / dt,
+        "ms_per_step_whole_job": dt / args.steps * 1e3,
+        "launch": "one process, one thread + context per GPU (povu_hip_multi_*)" + (" -- REHEARSAL: all ranks on device 0" if one else ""),
+        "transport": md.transport,
+        "lpt_max_over_mean": max(w) / (sum(w) / len(w)),
+        "phase_ms": {"root": {k: t_part[k] for k in ("label_ms", "lpt_ms", "partition_ms", "scatter_wall_ms")},
+                     "merge_ms": md.times()["merge_ms"],
+                     "per_rank_whole_job": [{k: r[k] for k in ("recv_ms", "csr_ms", "decompose_ms")} for r in ranks_whole],
+                     "per_rank_resident": [{"decompose_ms": r["decompose_ms"]} for r in ranks]},
+        "shards": [{k: r[k] for k in ("device", "n_vtx", "n_links", "n_components", "shard_bytes")} for r in ranks],
+        # bytes per rank since the job began: host->device, device->host (its own PVST blocks), xGMI out / in
+        "transfer_bytes": [{k: r[k] for k in ("h2d", "d2h", "peer_out", "peer_in")} for r in ranks],
+    }
+    del f
+    md.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,11 +286,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # `python bench.py --gpus N` without a launcher: ONE process drives the N GPUs (povu_hip_multi_*: one context and
+        # one host thread per device, the engine behind `povu decompose --gpus N`); nothing here has touched a GPU yet
+        return main_one_process(args)
     if args.gpus != world:
-        # never report a 1-GPU number as an N-GPU one: the launcher provides the ranks
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; launch with "
-                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                         f"bench.py --gpus {args.gpus} ...`")
+        # never report a 1-GPU number as an N-GPU one
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import numpy as np  # noqa: F401
     import torch
@@ -348,12 +428,15 @@ def main():
             achieved = alg / step_s / 1e9
             out = {
                 "metric": "edges/sec decomposed (flubble+PVST)",
-                "value": E * args.steps / dt,
+                # the N = 1 line's definition: from "CSR resident in HBM" (here: every rank's shard) to "PVST arrays on the
+                # host", K timed steps; the whole job (label + partition + scatter + CSR build on top) is value_whole_job,
+                # like-for-like with the N = 1 line's key of that name
+                "value": E * args.steps / dt_res,
                 "unit": "edges/s",
                 "n_gpus": world,
                 "steps": args.steps,
                 "warmup": args.warmup,
-                "ms_per_step": step_s * 1e3,
+                "ms_per_step": dt_res / args.steps * 1e3,
                 "higher_is_better": True,
                 "scaling": "strong",
                 "vs_baseline": None,
@@ -361,9 +444,10 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": info["workload"], "links": E, "segments": V, "components": info["components"], "flubbles": F,
                            "sharding": info["sharding"]},
-                "roofline": {"bound": "hbm", "kernel": "whole job: label + partition + scatter + per-shard decompose + gather",
-                             "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world),
-                             "traffic": None, "algorithmic_bytes_per_launch": alg, "ms_per_launch": step_s * 1e3,
+                "roofline": {"bound": "hbm", "kernel": "per-shard decompose pass on every GPU + gather (from resident shards)",
+                             "achieved": alg / (dt_res / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": alg / (dt_res / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+                             "traffic": None, "algorithmic_bytes_per_launch": alg, "ms_per_launch": dt_res / args.steps * 1e3,
                              "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d) over the aggregate peak of all GPUs"},
                 # like-for-like with the N = 1 line's `value` (graph / shards resident as CSR -> forest on rank 0's host); `value`
                 # above is the whole job (label + partition + scatter + CSR build + decompose + gather), like-for-like with
@@ -371,6 +455,8 @@ def main():
                 "value_from_resident_shards": E * args.steps / dt_res,
                 "ms_per_step_from_resident_shards": dt_res / args.steps * 1e3,
                 "value_whole_job": E * args.steps / dt,
+                "ms_per_step_whole_job": step_s * 1e3,
+                "launch": "one process per GPU (torch.distributed launcher)",
                 "shards": info["shards"],
                 "lpt_max_over_mean": info["lpt_max_over_mean"],
                 "phase_ms": info["phase_ms"],

@@ -138,7 +138,8 @@ uint32_t povu_hip_shards_total_components(const povu_hip_shards *s);
 int povu_hip_shards_get(const povu_hip_shards *s, uint32_t rank, povu_hip_shard_info *out);
 /* device time of the partition (HIP events, ms): [0] labelling, [1] weights + LPT, [2] partition kernels */
 int povu_hip_shards_times(const povu_hip_shards *s, double out_ms[3]);
-/* copies packed shard `rank` to host memory (`dst` holds info.bytes) -- for transports other than RCCL */
+/* (the packed shards live in an arena of `ctx`: they stay valid until the next partition on that context or its destruction)
+ * copies packed shard `rank` to host memory (`dst` holds info.bytes) -- for transports other than RCCL */
 int povu_hip_shards_export(const povu_hip_shards *s, povu_hip_ctx *ctx, uint32_t rank, void *dst);
 void povu_hip_shards_free(povu_hip_shards *s);
 /* Makes a packed shard the resident graph of `ctx` (CSR built on the device).  `packed` is host memory
@@ -177,6 +178,72 @@ int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *shards, povu_
 povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen);
 /* wall time of the last scatter / gather on this rank, milliseconds */
 int povu_hip_comm_times(const povu_hip_comm *c, double out_ms[2]);
+
+/* ---- gather without a second PCIe crossing (several processes on one node) ----
+ * A rank's decompose already lands its PVST block in page-locked HOST memory over its own GPU's PCIe link.  After
+ * povu_hip_share_results the blocks of a context's forests are POSIX shared-memory segments ("/povu.<tag>.<k>",
+ * page-locked and mapped for the device): the root maps a rank's segment by name and reads the arrays where they are.
+ * What the ranks exchange is one 64-byte descriptor each (RCCL all-gather, torch.distributed, a pipe ...).
+ * Replaces the per-thread ownership of do_decompose's workers (app/subcommand/decompose.cpp:116-157), which write from
+ * their own memory. */
+/* from now on this context's result blocks are shared segments named after `tag` (at most 96 characters, no '/');
+ * the multi-process convention is tag = "<job>.<rank>" */
+int povu_hip_share_results(povu_hip_ctx *ctx, const char *tag, char *err, size_t errlen);
+/* describes the block of `f` for another process: desc = [magic, segment k, segment bytes, trees, entries, components of the
+ * whole graph, offset of the tree table, 0 (the caller stores the sender's rank here)]; the tree table is written into
+ * the segment behind the arrays.  A forest whose trees sit in several blocks is first brought into one.  Returns 2 when the
+ * forest's block is no shared segment, 4 for hairpin boundaries / subflubble labels (they do not travel). */
+int povu_hip_forest_share(povu_hip_forest *f, uint64_t desc[8]);
+/* Root: the merged forest of `n` descriptors (8 words each, word 7 = sender rank; segments "/povu.<job_tag>.<rank>.<k>"
+ * are mapped read-only and stay mapped in `ctx`) and of its own forest `own` (taken over, may be NULL; the descriptor
+ * with rank `own_rank` is skipped).  The other ranks' arrays stay THEIR memory: the merged forest is valid until the
+ * sender frees the forest it described -- in a collective loop, until the sender's next gather. */
+povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_forest *own, uint32_t own_rank, const char *job_tag,
+					const uint64_t *descs, uint32_t n, char *err, size_t errlen);
+/* bytes this context has moved since it was created: [0] host to device, [1] device to host (copies and results kernels
+ * write straight into page-locked memory), [2] sent to / [3] received from other GPUs (xGMI) */
+int povu_hip_transfer_bytes(const povu_hip_ctx *ctx, uint64_t out[4]);
+
+/* ---- one process, N GPUs (`povu decompose --gpus N`) ----
+ * The multi-threaded form of do_decompose (app/subcommand/decompose.cpp:116-157: every worker owns its components from
+ * graph to file) with GPUs for workers: one context and one host thread per device.  The root device labels the
+ * components, bin-packs them (LPT) and partitions the links; the shards travel over xGMI (RCCL ncclSend / ncclRecv, one
+ * communicator per device); every GPU decomposes its shard and copies its PVST block into page-locked host memory over
+ * ITS OWN PCIe link -- the one address space makes that the gather; nothing returns through the root's link. */
+typedef struct povu_hip_multi povu_hip_multi;
+/* devices[n]: HIP device of every rank (rank 0 = root).  The same device may be named more than once (rehearsal on a
+ * one-GPU box: shards are then loaded straight from the partition, no RCCL). */
+povu_hip_multi *povu_hip_multi_create(const int *devices, uint32_t n, char *err, size_t errlen);
+void povu_hip_multi_destroy(povu_hip_multi *m);
+uint32_t povu_hip_multi_world(const povu_hip_multi *m);
+/* the whole graph to the root device (povu_hip_graph_upload on the root's graph context) */
+int povu_hip_multi_upload(povu_hip_multi *m, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links, const uint32_t *v1,
+			  const uint8_t *s1, const uint32_t *v2, const uint8_t *s2, const uint8_t *tips, char *err, size_t errlen);
+/* label + LPT + partition on the root, shards to their devices, every rank builds its CSR.  With keep_graph = 0 the
+ * root gives the whole graph's memory back first-thing after the partition (a CLI run never needs it again). */
+int povu_hip_multi_scatter(povu_hip_multi *m, int keep_graph, char *err, size_t errlen);
+/* Every rank decomposes its resident shard on its own thread (flags: POVU_HIP_F_*).  `sink`, when given, runs ON THE
+ * WORKER'S THREAD with that rank's forest (global component ids) as soon as it is done -- a CLI formats and writes its
+ * files there, like the reference's workers; a non-zero return fails the call.  Returns the merged forest (no array is
+ * copied: it takes over every rank's blocks). */
+typedef int (*povu_hip_multi_sink)(uint32_t rank, const povu_hip_forest *f, void *user);
+povu_hip_forest *povu_hip_multi_decompose(povu_hip_multi *m, uint32_t flags, povu_hip_multi_sink sink, void *user, char *err,
+					  size_t errlen);
+typedef struct {
+	int device;
+	uint32_t n_vtx, n_links, n_components; /* of the rank's shard */
+	uint64_t shard_bytes;
+	double recv_ms, csr_ms;		 /* last scatter: until the shard was there; CSR build */
+	double decompose_ms, sink_ms;	 /* last decompose */
+	uint64_t h2d, d2h, peer_out, peer_in; /* povu_hip_transfer_bytes of the rank's context */
+} povu_hip_multi_rank_info;
+int povu_hip_multi_rank(const povu_hip_multi *m, uint32_t rank, povu_hip_multi_rank_info *out);
+/* [0] label, [1] weights + LPT, [2] partition kernels (device time on the root), [3] wall of the last scatter, [4] wall of
+ * the last decompose (slowest rank + merge), [5] merge alone */
+int povu_hip_multi_times(const povu_hip_multi *m, double out_ms[6]);
+/* "none" (one rank), "rccl", "peer-copy" (hipMemcpyPeerAsync; also the fallback when RCCL cannot be initialised: the
+ * reason is appended) or "same-device" */
+const char *povu_hip_multi_transport(const povu_hip_multi *m);
 
 /* components of the WHOLE graph (all shards), including skipped ones */
 uint32_t povu_hip_forest_total_components(const povu_hip_forest *f);

@@ -59,6 +59,27 @@ struct HipError : std::runtime_error {
 		HIP_CHECK(hipGetLastError());                                                     \
 	} while (0)
 
+// Bytes that cross PCIe, tallied per thread (a context is used by one thread at a time; the C ABI entry points add the
+// difference over a call to their context's totals, povu_hip_transfer_bytes).  Every host<->device copy of the library goes
+// through copy_async; results that kernels write straight into page-locked host memory are counted where they are sized.
+struct XferTally {
+	uint64_t h2d = 0, d2h = 0;
+};
+inline XferTally &xfer_tally()
+{
+	static thread_local XferTally t;
+	return t;
+}
+inline hipError_t copy_async(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s)
+{
+	if (kind == hipMemcpyHostToDevice)
+		xfer_tally().h2d += n;
+	else if (kind == hipMemcpyDeviceToHost)
+		xfer_tally().d2h += n;
+	return hipMemcpyAsync(dst, src, n, kind, s);
+}
+inline void count_kernel_d2h(size_t n) { xfer_tally().d2h += n; }
+
 // One growable device arena per context: stages carve typed spans with a bump
 // pointer, nothing is hipMalloc'd inside the timed path once the arena is warm.
 class Arena
@@ -162,7 +183,7 @@ public:
 	uint32_t read_u32(const uint32_t *dptr, hipStream_t s)
 	{
 		uint32_t *h = take<uint32_t>(1);
-		HIP_CHECK(hipMemcpyAsync(h, dptr, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(h, dptr, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		return *h;
 	}

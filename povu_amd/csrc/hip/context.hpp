@@ -9,47 +9,40 @@
 #include "seq_kernels.hpp"
 #include "tree_kernels.hpp"
 
+#include <map>
 #include <memory>
 #include <mutex>
+#include <string>
 
 using namespace povu_hip;
 
 // Pinned host blocks for the PVST arrays: D2H into page-locked memory runs at PCIe speed, and a
 // block returns to its context's pool when the forest is freed (steady state: no allocation).
+// In SHARED mode (povu_hip_share_results) a block is a POSIX shared-memory segment "/povu.<tag>.<k>", page-locked and
+// mapped for the device with hipHostRegister: another process of the node maps it by name and reads the PVST arrays where
+// this GPU's copy engine put them -- a multi-process gather without a second trip over PCIe (shard.hip).
 struct PinnedPool {
+	struct Block {
+		void *p;
+		size_t cap;
+		int seg; // shared mode: k of the segment name, else -1
+	};
 	std::mutex m;
-	std::vector<std::pair<void *, size_t>> free_blocks;
-	~PinnedPool()
-	{
-		for (auto &b : free_blocks)
-			(void)hipHostFree(b.first);
-	}
-	void *get(size_t bytes, size_t &cap)
-	{
-		{
-			std::lock_guard<std::mutex> g(m);
-			for (size_t i = 0; i < free_blocks.size(); i++)
-				if (free_blocks[i].second >= bytes) {
-					void *p = free_blocks[i].first;
-					cap = free_blocks[i].second;
-					free_blocks.erase(free_blocks.begin() + i);
-					return p;
-				}
-		}
-		void *p = nullptr;
-		cap = bytes + bytes / 4 + 4096;
-		if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
-			throw HipError("hipHostMalloc failed for the PVST result block");
-		return p;
-	}
-	void put(void *p, size_t cap)
+	std::vector<Block> free_blocks;
+	std::vector<Block> segments; // every segment this pool created (shared mode): unmapped and unlinked with the pool
+	std::string shared_tag;	     // empty: plain hipHostMalloc blocks
+	int next_seg = 0;
+	~PinnedPool();
+	void *get(size_t bytes, size_t &cap, int *seg = nullptr);
+	void put(void *p, size_t cap, int seg = -1)
 	{
 		std::lock_guard<std::mutex> g(m);
-		if (free_blocks.size() < 24) // (a gather on 8+ ranks cycles through one block per rank)
-			free_blocks.emplace_back(p, cap);
+		if (seg >= 0 || free_blocks.size() < 24) // (a gather on 8+ ranks cycles through one block per rank)
+			free_blocks.push_back(Block{p, cap, seg}); // (a segment stays mapped until the pool goes)
 		else
 			(void)hipHostFree(p);
 	}
+	static std::string segment_name(const std::string &tag, int k) { return "/povu." + tag + "." + std::to_string(k); }
 };
 
 template <typename T>
@@ -65,11 +58,14 @@ struct povu_hip_forest {
 	std::shared_ptr<PinnedPool> pool;
 	void *block = nullptr;
 	size_t block_cap = 0, block_bytes = 0, total_entries = 0;
+	int block_seg = -1;	 // shared-memory segment of the block (PinnedPool shared mode), else -1
+	size_t meta_reserve = 0; // trees the block leaves room for behind the arrays (povu_hip_forest_share writes their table there)
+	static size_t meta_bytes(size_t n_trees) { return 64 + 32 * n_trees; }
 	void alloc(size_t total)
 	{
 		total_entries = total;
-		const size_t bytes = ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64;
-		block = pool->get(bytes, block_cap);
+		const size_t bytes = ((total * 4 + 63) & ~size_t(63)) * 3 + ((total + 63) & ~size_t(63)) * 2 + 64 + meta_bytes(meta_reserve);
+		block = pool->get(bytes, block_cap, &block_seg);
 		char *q = static_cast<char *>(block);
 		auto carve = [&](size_t b) {
 			char *r = q;
@@ -86,16 +82,18 @@ struct povu_hip_forest {
 	void release_block()
 	{
 		if (block && pool)
-			pool->put(block, block_cap);
+			pool->put(block, block_cap, block_seg);
 		block = nullptr;
 		block_cap = block_bytes = total_entries = 0;
+		block_seg = -1;
 	}
 	// more page-locked blocks with the same five arrays: taken over from other forests or received from other ranks
 	// (povu_hip_forest_merge / povu_hip_comm_gather), so that merging never copies a PVST array
 	struct ExtraBlock {
 		void *p = nullptr;
 		size_t cap = 0, total = 0;
-		std::shared_ptr<PinnedPool> pool;
+		int seg = -1;
+		std::shared_ptr<PinnedPool> pool; // null: the memory is not this forest's (a segment of another rank, mapped by the context)
 		uint32_t *a = nullptr, *z = nullptr, *parent = nullptr;
 		uint8_t *aor = nullptr, *zor = nullptr;
 		std::vector<uint32_t> sub_ai, sub_zi; // with POVU_HIP_F_LEAF_SUBFLUBBLES (see the forest's own sub_ai)
@@ -123,7 +121,7 @@ struct povu_hip_forest {
 		release_block();
 		for (auto &b : extra)
 			if (b.p && b.pool)
-				b.pool->put(b.p, b.cap);
+				b.pool->put(b.p, b.cap, b.seg);
 	}
 	struct Tree {
 		uint32_t component_id, n_vtx, n_links, n_pvst;
@@ -172,6 +170,30 @@ struct povu_hip_ctx {
 	uint32_t shard_total_components = 0;
 	Arena shard_buf;   // a shard received from another rank
 	Arena graph_arena; // backs the resident graph
+	Arena part_arena;  // the packed shards of the last povu_hip_shard_partition (kept warm: a step of a sharded job re-partitions)
+	// bytes this context moved over PCIe / to peers since it was created (povu_hip_transfer_bytes)
+	uint64_t xfer_h2d = 0, xfer_d2h = 0, xfer_peer_out = 0, xfer_peer_in = 0;
+	// result segments of other ranks, mapped read-only by name (povu_hip_forest_attach); unmapped with the context
+	struct Mapped {
+		void *p;
+		size_t bytes;
+	};
+	std::map<std::string, Mapped> attached;
+};
+
+// adds what the calling thread moved over PCIe during one C ABI call to the context's totals
+struct XferScope {
+	povu_hip_ctx *ctx;
+	XferTally at;
+	explicit XferScope(povu_hip_ctx *c) : ctx(c), at(xfer_tally()) {}
+	~XferScope()
+	{
+		if (!ctx)
+			return;
+		const XferTally now = xfer_tally();
+		ctx->xfer_h2d += now.h2d - at.h2d;
+		ctx->xfer_d2h += now.d2h - at.d2h;
+	}
 };
 
 

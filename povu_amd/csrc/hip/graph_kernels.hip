@@ -769,8 +769,8 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, deg, word + 3);
 	}
 	uint32_t hw[4] = {0, 0, 0, 0}; // slots, first bad link, first bad tip, most links on one side
-	HIP_CHECK(hipMemcpyAsync(&hw[0], g.off + nS, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(&hw[1], word + 1, 12, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&hw[0], g.off + nS, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&hw[1], word + 1, 12, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (hw[1] != POVU_NIL)
 		throw HipError("link " + std::to_string(hw[1]) + " references an unknown vertex or side");
@@ -784,7 +784,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	} else if (g.n_slots) {
 		KLAUNCH(k_side_pairs, dim3(nblk(E)), dim3(TPB), 0, s, E, g.v1, g.s1, g.v2, g.s2, keys, vals, (uint32_t)nS);
 		sort_pairs_u32(keys, keys2, vals, vals2, 2 * (size_t)E, bits_for(nS), stmp, sb, s);
-		HIP_CHECK(hipMemcpyAsync(g.adj, vals2, (size_t)g.n_slots * 4, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(copy_async(g.adj, vals2, (size_t)g.n_slots * 4, hipMemcpyDeviceToDevice, s));
 	}
 	if (!g.tips_given && V) {
 		KLAUNCH(k_infer_tips, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, g.tip);
@@ -795,7 +795,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 				   g.aoth);
 		KLAUNCH(k_vertex_degree, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, deg);
 		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(V), 1024)), dim3(TPB), 0, s, V, deg, word);
-		HIP_CHECK(hipMemcpyAsync(&g.max_vdeg, word, 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(&g.max_vdeg, word, 4, hipMemcpyDeviceToHost, s));
 	}
 	HIP_CHECK(hipEventRecord(ev[1], s));
 	if (V && E) { // reverse-slot table: where the same link sits in the list of its other end
@@ -831,9 +831,9 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	scan_exclusive_u8(is_root, st.crank, (size_t)V + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(7);
 	uint32_t *h = st.host->take<uint32_t>(3); // component count, the order flag and the self-loop flag in one round trip
-	HIP_CHECK(hipMemcpyAsync(h, st.crank + V, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(h + 1, st.stats + 9, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(h + 2, any_loop, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(h, st.crank + V, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(h + 1, st.stats + 9, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(h + 2, any_loop, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	st.comp_sorted = h[1] == 0;
 	st.has_self_loops = h[2] != 0;
@@ -882,7 +882,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 		// vertices also keep their places the local offsets ARE the CSR's (no degree pass, no scan, no array)
 		if (st.lean_identity && !st.has_self_loops) {
 			st.loff = g.off;
-			HIP_CHECK(hipMemcpyAsync(st.stats, &g.max_vdeg, 4, hipMemcpyHostToDevice, s)); // (an upper bound of the most links on one side)
+			HIP_CHECK(copy_async(st.stats, &g.max_vdeg, 4, hipMemcpyHostToDevice, s)); // (an upper bound of the most links on one side)
 		} else {
 			KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
 			scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);

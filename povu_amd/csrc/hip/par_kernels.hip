@@ -1207,9 +1207,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan_exclusive_u32_pair(tsimp, tsimp, (size_t)ntiles + 1, tcap, tcap, (size_t)ntiles + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	uint32_t *extra = pw.host->take<uint32_t>(3);
-	HIP_CHECK(hipMemcpyAsync(&extra[0], tcap + ntiles, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(&extra[1], tsimp + ntiles, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(&extra[2], pw.err + 5, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&extra[0], tcap + ntiles, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&extra[1], tsimp + ntiles, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&extra[2], pw.err + 5, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
 	pw.nb0 = NB0;
@@ -1315,6 +1315,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	const size_t total = (size_t)NE + n_processed, p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
 	char *host_blk = static_cast<char *>(alloc_result_block(total));
 	const bool staged = total >= PVST_STAGE_MIN && side.stream != nullptr;
+	if (!staged)
+		count_kernel_d2h(total * 14); // (the emit kernels write the five arrays straight into the page-locked block)
 	char *blk = staged ? reinterpret_cast<char *>(pw.stage) : host_blk;
 	pw.d_a = reinterpret_cast<uint32_t *>(blk);
 	pw.d_z = reinterpret_cast<uint32_t *>(blk + p4);
@@ -1330,8 +1332,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		KLAUNCH(k_emit_endpoints, dim3(staged ? nblk((S + 3) / 4) : std::min<unsigned>(nblk((S + 3) / 4), 160)), dim3(TPB), 0, side.stream, S, dflag, pw.erank,
 			pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 		if (staged) {
-			HIP_CHECK(hipMemcpyAsync(host_blk, blk, 2 * p4, hipMemcpyDeviceToHost, side.stream));
-			HIP_CHECK(hipMemcpyAsync(host_blk + 3 * p4, blk + 3 * p4, 2 * p1, hipMemcpyDeviceToHost, side.stream));
+			HIP_CHECK(copy_async(host_blk, blk, 2 * p4, hipMemcpyDeviceToHost, side.stream));
+			HIP_CHECK(copy_async(host_blk + 3 * p4, blk + 3 * p4, 2 * p1, hipMemcpyDeviceToHost, side.stream));
 		}
 		HIP_CHECK(hipEventRecord(side.join, side.stream));
 	} else if (S) {
@@ -1355,7 +1357,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
 	       pw.d_parent);
 	if (staged)
-		HIP_CHECK(hipMemcpyAsync(host_blk + 2 * p4, blk + 2 * p4, p4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(host_blk + 2 * p4, blk + 2 * p4, p4, hipMemcpyDeviceToHost, s));
 	if (S && side.stream)
 		HIP_CHECK(hipStreamWaitEvent(s, side.join, 0)); // the pass is complete when both streams are
 	pw.n_stack = S; // export_parallel_stack copies the stack into the per-component layout when a debug hook asks

@@ -10,7 +10,107 @@
 #include <numeric>
 #include <type_traits>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 using namespace povu_hip;
+
+// ---- page-locked result blocks (context.hpp)
+PinnedPool::~PinnedPool()
+{
+	for (auto &b : free_blocks)
+		if (b.seg < 0)
+			(void)hipHostFree(b.p);
+	for (auto &sg : segments) {
+		(void)hipHostUnregister(sg.p);
+		(void)munmap(sg.p, sg.cap);
+		(void)shm_unlink(segment_name(shared_tag, sg.seg).c_str());
+	}
+}
+
+void *PinnedPool::get(size_t bytes, size_t &cap, int *seg)
+{
+	const bool shared = !shared_tag.empty();
+	{
+		std::lock_guard<std::mutex> g(m);
+		for (size_t i = 0; i < free_blocks.size(); i++)
+			if (free_blocks[i].cap >= bytes && (free_blocks[i].seg >= 0) == shared) {
+				const Block b = free_blocks[i];
+				free_blocks.erase(free_blocks.begin() + i);
+				cap = b.cap;
+				if (seg)
+					*seg = b.seg;
+				return b.p;
+			}
+	}
+	void *p = nullptr;
+	cap = bytes + bytes / 4 + 4096;
+	if (!shared) {
+		if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess)
+			throw HipError("hipHostMalloc failed for the PVST result block");
+		if (seg)
+			*seg = -1;
+		return p;
+	}
+	// a named segment, page-locked and mapped for the device where it is
+	cap = (cap + 4095) & ~size_t(4095);
+	int k;
+	{
+		std::lock_guard<std::mutex> g(m);
+		k = next_seg++;
+	}
+	const std::string name = segment_name(shared_tag, k);
+	(void)shm_unlink(name.c_str()); // (a stale segment of a crashed job with the same tag)
+	const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+	if (fd < 0)
+		throw HipError("shm_open failed for the shared PVST result block " + name);
+	if (ftruncate(fd, (off_t)cap) != 0) {
+		(void)close(fd);
+		(void)shm_unlink(name.c_str());
+		throw HipError("not enough shared memory for the PVST result block " + name + " (" + std::to_string(cap >> 20) + " MiB)");
+	}
+	p = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd, 0);
+	(void)close(fd);
+	if (p == MAP_FAILED) {
+		(void)shm_unlink(name.c_str());
+		throw HipError("mmap failed for the shared PVST result block " + name);
+	}
+	if (hipHostRegister(p, cap, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+		(void)hipGetLastError();
+		(void)munmap(p, cap);
+		(void)shm_unlink(name.c_str());
+		throw HipError("hipHostRegister failed for the shared PVST result block " + name);
+	}
+	{
+		std::lock_guard<std::mutex> g(m);
+		segments.push_back(Block{p, cap, k});
+	}
+	if (seg)
+		*seg = k;
+	return p;
+}
+
+extern "C" int povu_hip_share_results(povu_hip_ctx *ctx, const char *tag, char *err, size_t errlen)
+{
+	if (!ctx || !tag || !*tag || strlen(tag) > 96 || strchr(tag, '/')) {
+		set_err(err, errlen, "share_results: bad tag");
+		return 1;
+	}
+	// a fresh pool: blocks of the old one go back to it as their forests are freed
+	auto pool = std::make_shared<PinnedPool>();
+	pool->shared_tag = tag;
+	ctx->pool = pool;
+	return 0;
+}
+
+extern "C" int povu_hip_transfer_bytes(const povu_hip_ctx *ctx, uint64_t out[4])
+{
+	if (!ctx || !out)
+		return 1;
+	out[0] = ctx->xfer_h2d, out[1] = ctx->xfer_d2h, out[2] = ctx->xfer_peer_out, out[3] = ctx->xfer_peer_in;
+	return 0;
+}
 
 void set_err(char *err, size_t errlen, const std::string &msg)
 {
@@ -69,6 +169,9 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	ctx->upload_tmp.release();
 	ctx->shard_buf.release();
 	ctx->graph_arena.release();
+	ctx->part_arena.release();
+	for (auto &kv : ctx->attached)
+		(void)munmap(kv.second.p, kv.second.bytes);
 	if (ctx->stream)
 		(void)hipStreamDestroy(ctx->stream);
 	if (ctx->side.stream)
@@ -119,6 +222,7 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 				     const uint8_t *tips, char *err, size_t errlen)
 {
 	ResidentGraph g;
+	XferScope xfer(ctx);
 	try {
 		if (!ctx)
 			throw HipError("null context");
@@ -136,15 +240,15 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 		HIP_CHECK(hipEventCreate(&e0));
 		HIP_CHECK(hipEventCreate(&e1));
 		HIP_CHECK(hipEventRecord(e0, s));
-		HIP_CHECK(hipMemcpyAsync(g.vid, vid, V * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(g.vid, vid, V * 4, hipMemcpyHostToDevice, s));
 		if (E) {
-			HIP_CHECK(hipMemcpyAsync(g.v1, v1, E * 4, hipMemcpyHostToDevice, s));
-			HIP_CHECK(hipMemcpyAsync(g.v2, v2, E * 4, hipMemcpyHostToDevice, s));
-			HIP_CHECK(hipMemcpyAsync(g.s1, s1, E, hipMemcpyHostToDevice, s));
-			HIP_CHECK(hipMemcpyAsync(g.s2, s2, E, hipMemcpyHostToDevice, s));
+			HIP_CHECK(copy_async(g.v1, v1, E * 4, hipMemcpyHostToDevice, s));
+			HIP_CHECK(copy_async(g.v2, v2, E * 4, hipMemcpyHostToDevice, s));
+			HIP_CHECK(copy_async(g.s1, s1, E, hipMemcpyHostToDevice, s));
+			HIP_CHECK(copy_async(g.s2, s2, E, hipMemcpyHostToDevice, s));
 		}
 		if (tips)
-			HIP_CHECK(hipMemcpyAsync(g.tip, tips, V, hipMemcpyHostToDevice, s));
+			HIP_CHECK(copy_async(g.tip, tips, V, hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipEventRecord(e1, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		(void)hipEventElapsedTime(&g.h2d_ms, e0, e1);
@@ -339,13 +443,13 @@ extern "C" povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *er
 		o->vid.resize(V);
 		o->tip.resize(V);
 		std::vector<uint32_t> la(E), lb(E);
-		HIP_CHECK(hipMemcpyAsync(o->voff.data(), cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(o->eoff.data(), cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(o->vid.data(), cs.gid_s, V * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(o->tip.data(), cs.tip_s, V, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(o->voff.data(), cs.voff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(o->eoff.data(), cs.eoff, (size_t)(C + 1) * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(o->vid.data(), cs.gid_s, V * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(o->tip.data(), cs.tip_s, V, hipMemcpyDeviceToHost, s));
 		if (E) {
-			HIP_CHECK(hipMemcpyAsync(la.data(), cs.la, E * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(lb.data(), cs.lb, E * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(la.data(), cs.la, E * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(lb.data(), cs.lb, E * 4, hipMemcpyDeviceToHost, s));
 		}
 		HIP_CHECK(hipStreamSynchronize(s));
 		o->v1.resize(E);
@@ -455,6 +559,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 	// declared outside the try block: on a failure the stream is drained BEFORE the forest returns its pinned
 	// result block to the pool (kernels that write into it may still be queued)
 	std::unique_ptr<povu_hip_forest> f;
+	XferScope xfer(ctx);
 	try {
 		if (ctx && !ctx->g.block && ctx->shard_total_components) { // a shard without components: nothing to do
 			f = std::make_unique<povu_hip_forest>();
@@ -515,6 +620,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		// re-index kernel writes them into pinned memory itself
 		uint32_t *pub = ctx->host.take<uint32_t>(2 * ((size_t)C + 1) + 4);
 		HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&cs.host_pub), pub, 0));
+		count_kernel_d2h((2 * ((size_t)C + 1) + 4) * 4);
 		reindex_components(g, cs, C, tm, s, (o.flags & POVU_HIP_F_SORTED_ADJ) != 0);
 		HIP_CHECK(hipStreamSynchronize(s));
 		const uint32_t *voff = pub, *eoff = pub + (size_t)C + 1, *gstats = pub + 2 * ((size_t)C + 1);
@@ -579,7 +685,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		}
 		stack_off[C] = n_stack;
 		const uint32_t n_processed = pc[C];
-		HIP_CHECK(hipMemcpyAsync(sw.tables, tab_h, 5 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(sw.tables, tab_h, 5 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
 
 		// ---- rows C-G
 		sw.V = g.V;
@@ -612,6 +718,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		// the parallel stages write it straight into pinned host memory, there is no device-to-host copy
 		f = std::make_unique<povu_hip_forest>();
 		f->pool = ctx->pool;
+		f->meta_reserve = (size_t)C + 1; // room behind the arrays for the tree table of povu_hip_forest_share
 		auto alloc_result_block = [&](size_t total) -> void * {
 			f->release_block();
 			f->alloc(total);
@@ -622,6 +729,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		const uint32_t *sum = nullptr; // outcome of the pass in pinned memory (pass_summary)
 		auto read_summary = [&](bool with_par) -> const uint32_t * {
 			uint32_t *h = ctx->host.take<uint32_t>(5 * (size_t)C + 8);
+			count_kernel_d2h((5 * (size_t)C + 8) * 4);
 			pass_summary(sw, with_par ? &ctx->pw : nullptr, C, h, s);
 			HIP_CHECK(hipEventRecord(ev_all1, s)); // (recorded again if more work follows)
 			HIP_CHECK(hipStreamSynchronize(s));
@@ -692,9 +800,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				f->sub_zi.resize(n);
 				f->sub_fam.resize(n);
 				if (n) {
-					HIP_CHECK(hipMemcpyAsync(f->sub_ai.data(), leaf_state.dense.ai, n * 4, hipMemcpyDeviceToHost, s));
-					HIP_CHECK(hipMemcpyAsync(f->sub_zi.data(), leaf_state.dense.zi, n * 4, hipMemcpyDeviceToHost, s));
-					HIP_CHECK(hipMemcpyAsync(f->sub_fam.data(), leaf_state.dense.fam, n, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(f->sub_ai.data(), leaf_state.dense.ai, n * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(f->sub_zi.data(), leaf_state.dense.zi, n * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(f->sub_fam.data(), leaf_state.dense.fam, n, hipMemcpyDeviceToHost, s));
 				}
 				tm.end(16);
 				HIP_CHECK(hipStreamSynchronize(s));
@@ -785,12 +893,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			if (ts.size() <= 32) { // few trees: copy exactly their spans
 				for (const auto *t : ts) {
 					const size_t pb = (size_t)voff[t->component_id - 1] + (t->component_id - 1);
-					HIP_CHECK(hipMemcpyAsync(da + t->off, sw.p_a + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
-					HIP_CHECK(hipMemcpyAsync(dz + t->off, sw.p_z + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
-					HIP_CHECK(hipMemcpyAsync(dp + t->off, sw.p_parent + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
-					HIP_CHECK(hipMemcpyAsync(ors.data() + t->off, sw.p_or + pb, t->n_pvst, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(da + t->off, sw.p_a + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(dz + t->off, sw.p_z + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(dp + t->off, sw.p_parent + pb, (size_t)t->n_pvst * 4, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(ors.data() + t->off, sw.p_or + pb, t->n_pvst, hipMemcpyDeviceToHost, s));
 					if (t->n_hairpins)
-						HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t->hp_off, sw.hairpins + 2 * pb,
+						HIP_CHECK(copy_async(f->hairpins.data() + 2 * t->hp_off, sw.hairpins + 2 * pb,
 									 (size_t)t->n_hairpins * 16, hipMemcpyDeviceToHost, s));
 				}
 				HIP_CHECK(hipEventRecord(ev_all1, s));
@@ -800,12 +908,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				std::vector<uint32_t> ha(P), hz(P), hp(P);
 				std::vector<uint8_t> ho(P);
 				std::vector<uint64_t> hh(hairpins ? 2 * P : 0);
-				HIP_CHECK(hipMemcpyAsync(ha.data(), sw.p_a, P * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(hz.data(), sw.p_z, P * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(hp.data(), sw.p_parent, P * 4, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipMemcpyAsync(ho.data(), sw.p_or, P, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(copy_async(ha.data(), sw.p_a, P * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(copy_async(hz.data(), sw.p_z, P * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(copy_async(hp.data(), sw.p_parent, P * 4, hipMemcpyDeviceToHost, s));
+				HIP_CHECK(copy_async(ho.data(), sw.p_or, P, hipMemcpyDeviceToHost, s));
 				if (hairpins)
-					HIP_CHECK(hipMemcpyAsync(hh.data(), sw.hairpins, 2 * P * 8, hipMemcpyDeviceToHost, s));
+					HIP_CHECK(copy_async(hh.data(), sw.hairpins, 2 * P * 8, hipMemcpyDeviceToHost, s));
 				HIP_CHECK(hipEventRecord(ev_all1, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 				for (const auto *t : ts) {
@@ -832,9 +940,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			const size_t P = (size_t)g.V + C;
 			std::vector<uint32_t> ha(P), hz(P);
 			std::vector<uint8_t> hf(P);
-			HIP_CHECK(hipMemcpyAsync(ha.data(), leaf_state.p_ai, P * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(hz.data(), leaf_state.p_zi, P * 4, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(hf.data(), leaf_state.p_fam, P, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(ha.data(), leaf_state.p_ai, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(hz.data(), leaf_state.p_zi, P * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(hf.data(), leaf_state.p_fam, P, hipMemcpyDeviceToHost, s));
 			HIP_CHECK(hipStreamSynchronize(s));
 			for (const auto *t : ts) {
 				const size_t pb = (size_t)voff[t->component_id - 1] + (t->component_id - 1);
@@ -864,7 +972,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			for (const auto &t : f->trees)
 				if (t.n_hairpins) {
 					const size_t pb = (size_t)voff[t.component_id - 1] + (t.component_id - 1);
-					HIP_CHECK(hipMemcpyAsync(f->hairpins.data() + 2 * t.hp_off, sw.hairpins + 2 * pb,
+					HIP_CHECK(copy_async(f->hairpins.data() + 2 * t.hp_off, sw.hairpins + 2 * pb,
 								 (size_t)t.n_hairpins * 16, hipMemcpyDeviceToHost, s));
 					more = true;
 				}
@@ -1145,18 +1253,18 @@ extern "C" int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in
 		uint32_t *di = ar.take<uint32_t>(n + 16), *dout = ar.take<uint32_t>(n + 16);
 		uint32_t *di2 = ar.take<uint32_t>(n2 + 16), *dout2 = ar.take<uint32_t>(n2 + 16);
 		void *tmp = ar.take<char>(tb);
-		HIP_CHECK(hipMemcpyAsync(di, in, n * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(di, in, n * 4, hipMemcpyHostToDevice, s));
 		if (in2)
-			HIP_CHECK(hipMemcpyAsync(di2, in2, n2 * 4, hipMemcpyHostToDevice, s));
+			HIP_CHECK(copy_async(di2, in2, n2 * 4, hipMemcpyHostToDevice, s));
 		if (in2 && op == 0)
 			scan_exclusive_u32_pair(di, dout, n, di2, dout2, n2, tmp, tb, s);
 		else if (op == 0)
 			scan_exclusive_u32(di, dout, n, tmp, tb, s);
 		else
 			scan_exclusive_max_u32(di, dout, n, tmp, tb, s);
-		HIP_CHECK(hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(out, dout, n * 4, hipMemcpyDeviceToHost, s));
 		if (in2 && op == 0)
-			HIP_CHECK(hipMemcpyAsync(out2, dout2, n2 * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(out2, dout2, n2 * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		return 0;
 	} catch (const std::exception &) {
@@ -1247,9 +1355,9 @@ extern "C" int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_
 		HIP_CHECK(hipMemsetAsync(dw, 0, 2 * T * 4, ctx->stream));
 		debug_edge_id_weights(ctx->cs, ctx->sw, ctx->tw, dw, dw + T, ctx->stream);
 		std::vector<uint32_t> w(N), tail(N), size(N);
-		HIP_CHECK(hipMemcpyAsync(w.data(), dw + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_CHECK(hipMemcpyAsync(tail.data(), dw + T + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_CHECK(hipMemcpyAsync(size.data(), ctx->sw.t_size + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(copy_async(w.data(), dw + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(copy_async(tail.data(), dw + T + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(copy_async(size.data(), ctx->sw.t_size + tb, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		HIP_CHECK(hipFree(dw));
 		dw = nullptr;

@@ -4,13 +4,17 @@
 // communicator (ncclSend / ncclRecv over xGMI) behind povu_hip_comm_*.
 #include "context.hpp"
 
-#include <rccl/rccl.h>
+#include "rccl_api.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <numeric>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <thread>
+#include <unistd.h>
 
 namespace
 {
@@ -112,6 +116,20 @@ __global__ void k_part_links(uint32_t E, const uint32_t *__restrict__ key, const
 	t.s1[li] = s1[e];
 	t.s2[li] = s2[e];
 }
+// the bytes between the end of a section and the next 256-byte boundary travel with a shard: they are cleared (a few hundred
+// bytes per section) instead of clearing the whole block before it is written (gigabytes)
+struct PadSpan {
+	char *p;
+	uint32_t n;
+};
+__global__ void k_zero_pads(uint32_t n_spans, const PadSpan *__restrict__ spans)
+{
+	if (blockIdx.x >= n_spans)
+		return;
+	const PadSpan sp = spans[blockIdx.x];
+	if (threadIdx.x < sp.n)
+		sp.p[threadIdx.x] = 0;
+}
 } // namespace
 
 // ---------------------------------------------------------------- LPT (host)
@@ -139,7 +157,7 @@ extern "C" int povu_hip_lpt_assign(const uint64_t *weights, uint32_t n, uint32_t
 struct povu_hip_shards {
 	uint32_t world = 0, C = 0;
 	int device = 0;
-	void *block = nullptr;
+	void *block = nullptr; // in the context's partition arena: valid until the next partition on that context
 	struct Part {
 		uint32_t nv = 0, ne = 0, nc = 0;
 		uint64_t weight = 0;
@@ -147,18 +165,12 @@ struct povu_hip_shards {
 	};
 	std::vector<Part> parts;
 	double ms[3] = {0, 0, 0};
-	~povu_hip_shards()
-	{
-		if (block) {
-			(void)hipSetDevice(device);
-			(void)hipFree(block);
-		}
-	}
 };
 
 extern "C" povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t world, char *err, size_t errlen)
 {
 	std::unique_ptr<povu_hip_shards> sh;
+	XferScope xfer(ctx);
 	try {
 		if (!ctx || !ctx->g.block)
 			throw HipError("no graph resident: call povu_hip_graph_upload first");
@@ -200,8 +212,8 @@ extern "C" povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t
 		if (E)
 			KLAUNCH(k_comp_count, dim3(nblk(E)), dim3(TPB), 0, s, E, comp_of, g.v1, cnte);
 		uint32_t *hcnt = ctx->host.take<uint32_t>(2 * (size_t)C);
-		HIP_CHECK(hipMemcpyAsync(hcnt, cntv, (size_t)C * 4, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync(hcnt + C, cnte, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(hcnt, cntv, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(hcnt + C, cnte, (size_t)C * 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		// ---- bin packing on the host (components are few next to their size)
 		std::vector<uint64_t> w(C);
@@ -229,15 +241,17 @@ extern "C" povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t
 			p.bytes = ShardLayout(p.nv, p.ne, p.nc).bytes;
 			total += p.bytes;
 		}
-		if (hipMalloc(&sh->block, total) != hipSuccess) {
-			(void)hipGetLastError();
-			sh->block = nullptr;
-			throw HipError("not enough device memory for the packed shards (" + std::to_string(total >> 20) + " MiB)");
-		}
-		HIP_CHECK(hipMemsetAsync(sh->block, 0, total, s)); // (section padding travels too: keep it defined)
+		const size_t pads_off = total; // the table of padding spans sits behind the shards
+		total += pad256((size_t)world * 8 * sizeof(PadSpan));
+		// the block lives in an arena of the context (a step of a sharded job partitions again: no allocation, nothing to clear
+		// but the section padding, which travels too and stays defined)
+		ctx->part_arena.reserve(total + 512);
+		sh->block = ctx->part_arena.take<char>(total);
 		char *blk = static_cast<char *>(sh->block);
 		PartTable *htab = ctx->host.take<PartTable>(world);
-		uint64_t *hhdr = ctx->host.take<uint64_t>(8 * (size_t)world);
+		uint64_t *hhdr = ctx->host.take<uint64_t>(32 * (size_t)world); // (a whole 256-byte header per rank)
+		PadSpan *hpads = ctx->host.take<PadSpan>(8 * (size_t)world);
+		uint32_t n_pads = 0;
 		uint32_t vb = 0, eb = 0;
 		for (uint32_t r = 0; r < world; r++) {
 			const auto &p = sh->parts[r];
@@ -253,18 +267,31 @@ extern "C" povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t
 					    (uint8_t *)(b + L.tip)};
 			vb += p.nv;
 			eb += p.ne;
-			uint64_t *h = hhdr + 8 * (size_t)r;
-			h[0] = SHARD_MAGIC, h[1] = p.nv, h[2] = p.ne, h[3] = p.nc, h[4] = C, h[5] = h[6] = h[7] = 0;
-			HIP_CHECK(hipMemcpyAsync(b, h, 64, hipMemcpyHostToDevice, s));
+			uint64_t *h = hhdr + 32 * (size_t)r;
+			std::fill(h, h + 32, 0ull);
+			h[0] = SHARD_MAGIC, h[1] = p.nv, h[2] = p.ne, h[3] = p.nc, h[4] = C;
+			HIP_CHECK(copy_async(b, h, 256, hipMemcpyHostToDevice, s));
 			if (p.nc)
-				HIP_CHECK(hipMemcpyAsync(b + L.ids, ids[r].data(), (size_t)p.nc * 4, hipMemcpyHostToDevice, s));
+				HIP_CHECK(copy_async(b + L.ids, ids[r].data(), (size_t)p.nc * 4, hipMemcpyHostToDevice, s));
+			const size_t ends[7][2] = {{L.vid, (size_t)p.nv * 4}, {L.v1, (size_t)p.ne * 4}, {L.v2, (size_t)p.ne * 4}, {L.s1, p.ne},
+						   {L.s2, p.ne},	      {L.tip, p.nv},	      {L.ids, (size_t)p.nc * 4}};
+			for (const auto &e : ends) {
+				const size_t end = e[0] + e[1], n = pad256(end) - end;
+				if (n)
+					hpads[n_pads++] = PadSpan{b + end, (uint32_t)n};
+			}
+		}
+		if (n_pads) {
+			PadSpan *dpads = reinterpret_cast<PadSpan *>(blk + pads_off);
+			HIP_CHECK(copy_async(dpads, hpads, (size_t)n_pads * sizeof(PadSpan), hipMemcpyHostToDevice, s));
+			KLAUNCH(k_zero_pads, dim3(n_pads), dim3(256), 0, s, n_pads, dpads);
 		}
 		HIP_CHECK(hipEventRecord(ev[2], s));
 		// ---- partition on the device: a stable 1-pass radix sort by owner keeps vertex and link order
 		uint32_t *owner = cs.tmp_a; // [V+1] >= C
-		HIP_CHECK(hipMemcpyAsync(owner, howner, (size_t)C * 4, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(owner, howner, (size_t)C * 4, hipMemcpyHostToDevice, s));
 		PartTable *tab = reinterpret_cast<PartTable *>(sh->block);
-		HIP_CHECK(hipMemcpyAsync(tab, htab, (size_t)world * sizeof(PartTable), hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(tab, htab, (size_t)world * sizeof(PartTable), hipMemcpyHostToDevice, s));
 		const unsigned kbits = bits_for(world - 1);
 		uint32_t *kv = cs.ckey, *iv = cs.perm, *kv2 = cs.vdeg, *perm = cs.sbase, *newidx = cs.pos; // [V+1] each
 		KLAUNCH(k_owner_keys, dim3(nblk(V)), dim3(TPB), 0, s, V, comp_of, (const uint32_t *)nullptr, owner, kv, iv);
@@ -328,6 +355,7 @@ extern "C" void povu_hip_shards_free(povu_hip_shards *s) { delete s; }
 extern "C" int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed, size_t bytes, int on_device, char *err, size_t errlen)
 {
 	ResidentGraph g;
+	XferScope xfer(ctx);
 	try {
 		if (!ctx || !packed || bytes < 256)
 			throw HipError("bad shard");
@@ -361,17 +389,17 @@ extern "C" int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed
 		HIP_CHECK(hipEventCreate(&e0));
 		HIP_CHECK(hipEventCreate(&e1));
 		HIP_CHECK(hipEventRecord(e0, s));
-		HIP_CHECK(hipMemcpyAsync(g.vid, b + L.vid, (size_t)nv * 4, kind, s));
+		HIP_CHECK(copy_async(g.vid, b + L.vid, (size_t)nv * 4, kind, s));
 		if (ne) {
-			HIP_CHECK(hipMemcpyAsync(g.v1, b + L.v1, (size_t)ne * 4, kind, s));
-			HIP_CHECK(hipMemcpyAsync(g.v2, b + L.v2, (size_t)ne * 4, kind, s));
-			HIP_CHECK(hipMemcpyAsync(g.s1, b + L.s1, ne, kind, s));
-			HIP_CHECK(hipMemcpyAsync(g.s2, b + L.s2, ne, kind, s));
+			HIP_CHECK(copy_async(g.v1, b + L.v1, (size_t)ne * 4, kind, s));
+			HIP_CHECK(copy_async(g.v2, b + L.v2, (size_t)ne * 4, kind, s));
+			HIP_CHECK(copy_async(g.s1, b + L.s1, ne, kind, s));
+			HIP_CHECK(copy_async(g.s2, b + L.s2, ne, kind, s));
 		}
-		HIP_CHECK(hipMemcpyAsync(g.tip, b + L.tip, nv, kind, s));
+		HIP_CHECK(copy_async(g.tip, b + L.tip, nv, kind, s));
 		std::vector<uint32_t> ids(nc);
 		if (nc)
-			HIP_CHECK(hipMemcpyAsync(ids.data(), b + L.ids, (size_t)nc * 4, on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, s));
+			HIP_CHECK(copy_async(ids.data(), b + L.ids, (size_t)nc * 4, on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, s));
 		HIP_CHECK(hipEventRecord(e1, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		(void)hipEventElapsedTime(&g.h2d_ms, e0, e1);
@@ -558,58 +586,181 @@ extern "C" povu_hip_forest *povu_hip_forest_merge(povu_hip_ctx *ctx, const void 
 	}
 }
 
+// ---------------------------------------------------------------- merging without copies
+// `m`'s blocks, trees, hairpin boundaries and subflubble labels move into `out` (m is left empty): what the root does with
+// its own forest in every gather, and what the one-process engine (multi.hip) does with every worker's forest.
+void adopt_forest(povu_hip_forest &out, povu_hip_forest &m)
+{
+	const int base = (int)out.extra.size();
+	int own = -1;
+	if (m.block) {
+		povu_hip_forest::ExtraBlock b;
+		b.pool = m.pool;
+		b.p = m.block;
+		b.cap = m.block_cap;
+		b.seg = m.block_seg;
+		b.carve(m.total_entries);
+		b.sub_ai = std::move(m.sub_ai);
+		b.sub_zi = std::move(m.sub_zi);
+		b.sub_fam = std::move(m.sub_fam);
+		own = (int)out.extra.size() + (int)m.extra.size();
+		m.block = nullptr;
+		m.block_cap = m.block_bytes = m.total_entries = 0;
+		m.block_seg = -1;
+		for (auto &e : m.extra)
+			out.extra.push_back(std::move(e));
+		out.extra.push_back(std::move(b));
+	} else {
+		for (auto &e : m.extra)
+			out.extra.push_back(std::move(e));
+	}
+	m.extra.clear();
+	const size_t hp_base = out.hairpins.size() / 2;
+	out.hairpins.insert(out.hairpins.end(), m.hairpins.begin(), m.hairpins.end());
+	m.hairpins.clear();
+	for (auto t : m.trees) {
+		t.blk = t.blk < 0 ? own : base + t.blk;
+		t.hp_off += hp_base;
+		out.trees.push_back(t);
+	}
+	m.trees.clear();
+	out.total_components = std::max(out.total_components, m.total_components);
+	for (const auto &e : out.extra)
+		if (!e.sub_fam.empty() && out.sub_fam.empty())
+			out.sub_fam.assign(1, 0); // (povu_hip_forest_get_sub: "this forest carries labels"; the arrays are the blocks' own)
+}
+
+// ---------------------------------------------------------------- gather through shared memory (several processes, one node)
+// Every rank's PVST block already sits in page-locked HOST memory when its decompose returns -- copied there by its own
+// GPU over its own PCIe link.  When that memory is a named shared-memory segment (povu_hip_share_results) the root only
+// has to MAP it: no block goes back to a device, over xGMI and down the root's link again.  What travels between the
+// processes is one 64-byte descriptor per rank (any transport: an RCCL all-gather, torch.distributed, a pipe).
+static constexpr uint64_t SHARE_MAGIC = 0x3165726168735F76ull; // "v_share1"
+static constexpr uint64_t SHARE_EMPTY = ~0ull;
+
+// a forest whose trees sit in several blocks -> one block of its own pool, trees back to back (in place)
+static void compact_in_place(povu_hip_forest &f);
+
+extern "C" int povu_hip_forest_share(povu_hip_forest *f, uint64_t desc[8])
+{
+	if (!f || !desc)
+		return 1;
+	try {
+		if (!f->hairpins.empty() || !f->sub_fam.empty())
+			return 4; // (like the wire format: boundaries and labels do not travel)
+		std::fill(desc, desc + 8, 0ull);
+		desc[0] = SHARE_MAGIC;
+		desc[1] = SHARE_EMPTY;
+		desc[5] = f->total_components;
+		if (f->trees.empty())
+			return 0;
+		if (!f->extra.empty())
+			compact_in_place(*f);
+		if (f->block_seg < 0)
+			return 2; // the block is no shared segment: povu_hip_share_results was not called on the context
+		const size_t nt = f->trees.size(), meta_off = f->block_bytes;
+		if (meta_off + povu_hip_forest::meta_bytes(nt) > f->block_cap)
+			return 3;
+		char *b = static_cast<char *>(f->block);
+		uint32_t *meta = reinterpret_cast<uint32_t *>(b + meta_off + 64);
+		for (size_t i = 0; i < nt; i++) {
+			const auto &t = f->trees[i];
+			if (t.blk >= 0 || t.off + t.n_pvst > f->total_entries)
+				return 3;
+			uint32_t *q = meta + 8 * i;
+			q[0] = t.component_id, q[1] = t.n_vtx, q[2] = t.n_links, q[3] = t.n_pvst;
+			q[4] = (uint32_t)(t.off & 0xFFFFFFFFu), q[5] = (uint32_t)((uint64_t)t.off >> 32), q[6] = q[7] = 0;
+		}
+		uint64_t *mh = reinterpret_cast<uint64_t *>(b + meta_off);
+		mh[0] = SHARE_MAGIC, mh[1] = nt, mh[2] = f->total_entries;
+		__atomic_thread_fence(__ATOMIC_RELEASE); // (the descriptor leaves through a system call anyway)
+		desc[1] = (uint64_t)f->block_seg;
+		desc[2] = f->block_cap;
+		desc[3] = nt;
+		desc[4] = f->total_entries;
+		desc[6] = meta_off;
+		return 0;
+	} catch (const std::exception &) {
+		return 5;
+	}
+}
+
+extern "C" povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_forest *own, uint32_t own_rank, const char *job_tag,
+						   const uint64_t *descs, uint32_t n, char *err, size_t errlen)
+{
+	try {
+		if (!ctx || !job_tag || (n && !descs))
+			throw HipError("attach: bad arguments");
+		auto out = std::make_unique<povu_hip_forest>();
+		out->pool = ctx->pool;
+		for (uint32_t i = 0; i < n; i++) {
+			const uint64_t *d = descs + 8 * (size_t)i;
+			if (d[0] != SHARE_MAGIC)
+				throw HipError("attach: bad descriptor from rank " + std::to_string(d[7]));
+			out->total_components = std::max<uint32_t>(out->total_components, (uint32_t)d[5]);
+			if (own && d[7] == own_rank)
+				continue; // the root's own trees stay where they are (below)
+			if (d[1] == SHARE_EMPTY)
+				continue;
+			const std::string name = PinnedPool::segment_name(std::string(job_tag) + "." + std::to_string(d[7]), (int)d[1]);
+			const size_t seg_bytes = d[2], nt = d[3], total = d[4], meta_off = d[6];
+			// (numbers from another process: bound them before any arithmetic on them)
+			if (nt == 0 || nt > seg_bytes / 32 || total > seg_bytes / 4 || meta_off > seg_bytes ||
+			    meta_off + povu_hip_forest::meta_bytes(nt) > seg_bytes || povu_hip_forest::ExtraBlock::bytes_for(total) - 64 > meta_off)
+				throw HipError("attach: descriptor of rank " + std::to_string(d[7]) + " does not fit its segment");
+			auto it = ctx->attached.find(name);
+			if (it == ctx->attached.end()) {
+				const int fd = shm_open(name.c_str(), O_RDONLY, 0);
+				if (fd < 0)
+					throw HipError("attach: cannot open the result segment " + name);
+				struct stat st;
+				if (fstat(fd, &st) != 0 || (size_t)st.st_size < seg_bytes) {
+					(void)close(fd);
+					throw HipError("attach: the result segment " + name + " is smaller than its descriptor says");
+				}
+				void *p = mmap(nullptr, seg_bytes, PROT_READ, MAP_SHARED, fd, 0);
+				(void)close(fd);
+				if (p == MAP_FAILED)
+					throw HipError("attach: cannot map the result segment " + name);
+				it = ctx->attached.emplace(name, povu_hip_ctx::Mapped{p, seg_bytes}).first;
+			} else if (it->second.bytes < seg_bytes) {
+				throw HipError("attach: the result segment " + name + " changed its size");
+			}
+			const char *b = static_cast<const char *>(it->second.p);
+			const uint64_t *mh = reinterpret_cast<const uint64_t *>(b + meta_off);
+			if (mh[0] != SHARE_MAGIC || mh[1] != nt || mh[2] != total)
+				throw HipError("attach: the tree table of rank " + std::to_string(d[7]) + " does not match its descriptor");
+			povu_hip_forest::ExtraBlock blk; // (no pool: the memory is the other rank's)
+			blk.p = const_cast<char *>(b);
+			blk.cap = seg_bytes;
+			blk.carve(total);
+			const int bi = (int)out->extra.size();
+			out->extra.push_back(blk);
+			const uint32_t *meta = reinterpret_cast<const uint32_t *>(b + meta_off + 64);
+			for (size_t k = 0; k < nt; k++) {
+				const uint32_t *q = meta + 8 * k;
+				povu_hip_forest::Tree t{};
+				t.component_id = q[0], t.n_vtx = q[1], t.n_links = q[2], t.n_pvst = q[3];
+				t.off = (size_t)q[4] | ((size_t)q[5] << 32);
+				t.blk = bi;
+				if (t.off > total || t.n_pvst > total - t.off)
+					throw HipError("attach: a tree of rank " + std::to_string(d[7]) + " lies outside its block");
+				out->trees.push_back(t);
+			}
+		}
+		if (own)
+			adopt_forest(*out, *own);
+		sort_trees(*out);
+		return out.release();
+	} catch (const std::exception &e) {
+		set_err(err, errlen, e.what());
+		return nullptr;
+	}
+}
+
 // ---------------------------------------------------------------- RCCL (loaded on first use)
 namespace
 {
-struct Rccl {
-	void *h = nullptr;
-	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-	ncclResult_t (*GroupStart)() = nullptr;
-	ncclResult_t (*GroupEnd)() = nullptr;
-	ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-	const char *(*GetErrorString)(ncclResult_t) = nullptr;
-};
-Rccl &rccl()
-{
-	static Rccl r = [] {
-		Rccl x;
-		// inside a process that already loaded RCCL (PyTorch) the soname resolves to that copy
-		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-			x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-			if (x.h)
-				break;
-		}
-		if (!x.h)
-			return x;
-		auto sym = [&](const char *n) { return dlsym(x.h, n); };
-		x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
-		x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
-		x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
-		x.Send = (decltype(x.Send))sym("ncclSend");
-		x.Recv = (decltype(x.Recv))sym("ncclRecv");
-		x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
-		x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
-		x.Broadcast = (decltype(x.Broadcast))sym("ncclBroadcast");
-		x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
-		x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
-		return x;
-	}();
-	if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd ||
-	    !r.Broadcast || !r.AllGather || !r.GetErrorString)
-		throw HipError("RCCL (librccl.so.1) could not be loaded");
-	return r;
-}
-#define NCCL_CHECK(expr)                                                                                   \
-	do {                                                                                               \
-		ncclResult_t r__ = (expr);                                                                 \
-		if (r__ != ncclSuccess)                                                                    \
-			throw HipError(std::string(#expr) + ": " + rccl().GetErrorString(r__));            \
-	} while (0)
 static_assert(sizeof(ncclUniqueId) == POVU_HIP_COMM_ID_BYTES, "ncclUniqueId size");
 } // namespace
 
@@ -707,9 +858,9 @@ extern "C" int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *sh
 		if (root)
 			for (uint32_t r = 0; r < c->world; r++)
 				h[r] = root_ok ? shards->parts[r].bytes : ~0ull;
-		HIP_CHECK(hipMemcpyAsync(c->dsmall, h, 8 * (size_t)c->world, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(c->dsmall, h, 8 * (size_t)c->world, hipMemcpyHostToDevice, s));
 		NCCL_CHECK(R.Broadcast(c->dsmall, c->dsmall, c->world, ncclUint64, 0, c->comm, s));
-		HIP_CHECK(hipMemcpyAsync(h, c->dsmall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(h, c->dsmall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (h[c->rank] == ~0ull)
 			throw HipError("scatter: the root needs a partition for exactly `world` ranks");
@@ -728,9 +879,9 @@ extern "C" int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *sh
 		}
 		h[0] = ok;
 		uint64_t *dmy = c->dsmall, *dall = c->dsmall + 4;
-		HIP_CHECK(hipMemcpyAsync(dmy, h, 8, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(dmy, h, 8, hipMemcpyHostToDevice, s));
 		NCCL_CHECK(R.AllGather(dmy, dall, 1, ncclUint64, c->comm, s));
-		HIP_CHECK(hipMemcpyAsync(h + 4, dall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(h + 4, dall, 8 * (size_t)c->world, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		for (uint32_t r = 0; r < c->world; r++)
 			if (!h[4 + r])
@@ -783,6 +934,7 @@ static std::unique_ptr<povu_hip_forest> compact_forest(const povu_hip_forest *f)
 	size_t total = 0;
 	for (const auto &t : f->trees)
 		total += t.n_pvst;
+	out->meta_reserve = f->trees.size() + 1;
 	out->alloc(total);
 	size_t at = 0;
 	for (size_t i = 0; i < f->trees.size(); i++) {
@@ -801,6 +953,22 @@ static std::unique_ptr<povu_hip_forest> compact_forest(const povu_hip_forest *f)
 		at += t.n_pvst;
 	}
 	return out;
+}
+
+static void compact_in_place(povu_hip_forest &f)
+{
+	std::unique_ptr<povu_hip_forest> c = compact_forest(&f);
+	f.release_block();
+	for (auto &b : f.extra)
+		if (b.p && b.pool)
+			b.pool->put(b.p, b.cap, b.seg);
+	f.extra.clear();
+	f.block = c->block, f.block_cap = c->block_cap, f.block_bytes = c->block_bytes, f.total_entries = c->total_entries;
+	f.block_seg = c->block_seg;
+	f.a_id = c->a_id, f.z_id = c->z_id, f.parent = c->parent, f.a_or = c->a_or, f.z_or = c->z_or;
+	f.trees = std::move(c->trees);
+	c->block = nullptr;
+	c->block_cap = c->block_bytes = c->total_entries = 0;
 }
 
 extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hip_forest *mine, char *err, size_t errlen)
@@ -859,9 +1027,9 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 		uint64_t *h = c->hsmall;
 		h[0] = nt, h[1] = nt ? total : 0, h[2] = mine ? mine->total_components : 0, h[3] = my_error.empty() ? 0 : 1;
 		uint64_t *dmy = c->dsmall, *dall = c->dsmall + 4;
-		HIP_CHECK(hipMemcpyAsync(dmy, h, 32, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(dmy, h, 32, hipMemcpyHostToDevice, s));
 		NCCL_CHECK(R.AllGather(dmy, dall, 4, ncclUint64, c->comm, s));
-		HIP_CHECK(hipMemcpyAsync(h + 4, dall, 32 * (size_t)c->world, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(h + 4, dall, 32 * (size_t)c->world, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		const uint64_t *all = h + 4;
 		if (!my_error.empty())
@@ -901,9 +1069,9 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 		}
 		uint64_t *hgo = c->hsmall + 4 + 4 * (size_t)c->world, *dgo = c->dsmall + 4 + 4 * (size_t)c->world;
 		*hgo = go;
-		HIP_CHECK(hipMemcpyAsync(dgo, hgo, 8, hipMemcpyHostToDevice, s));
+		HIP_CHECK(copy_async(dgo, hgo, 8, hipMemcpyHostToDevice, s));
 		NCCL_CHECK(R.Broadcast(dgo, dgo, 1, ncclUint64, 0, c->comm, s));
-		HIP_CHECK(hipMemcpyAsync(hgo, dgo, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(copy_async(hgo, dgo, 8, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (!*hgo)
 			throw HipError("gather: the root has no room for the ranks' forests");
@@ -911,8 +1079,8 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 		out->pool = ctx->pool;
 		if (!root) {
 			if (nt) {
-				HIP_CHECK(hipMemcpyAsync(dmeta, hmeta, nt * 32, hipMemcpyHostToDevice, s));
-				HIP_CHECK(hipMemcpyAsync(dblk, mine->block, bb, hipMemcpyHostToDevice, s));
+				HIP_CHECK(copy_async(dmeta, hmeta, nt * 32, hipMemcpyHostToDevice, s));
+				HIP_CHECK(copy_async(dblk, mine->block, bb, hipMemcpyHostToDevice, s));
 				NCCL_CHECK(R.GroupStart());
 				in_group = true;
 				NCCL_CHECK(R.Send(dmeta, mb, ncclChar, 0, c->comm, s));
@@ -943,8 +1111,8 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			out->extra.push_back(blk);
 			uint32_t *hm = ctx->host.take<uint32_t>(8 * x.nt);
 			hmetas.push_back(hm);
-			HIP_CHECK(hipMemcpyAsync(hm, x.dmeta, x.nt * 32, hipMemcpyDeviceToHost, s));
-			HIP_CHECK(hipMemcpyAsync(blk.p, x.dblk, x.bb, hipMemcpyDeviceToHost, s)); // same layout as the sender's block
+			HIP_CHECK(copy_async(hm, x.dmeta, x.nt * 32, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(copy_async(blk.p, x.dblk, x.bb, hipMemcpyDeviceToHost, s)); // same layout as the sender's block
 			tc = std::max<uint32_t>(tc, (uint32_t)all[4 * x.rank + 2]);
 		}
 		// the root's own trees stay where they are: the merged forest takes over the block of `mine`
@@ -954,6 +1122,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			own.pool = m->pool;
 			own.p = m->block;
 			own.cap = m->block_cap;
+			own.seg = m->block_seg;
 			own.carve(m->total_entries);
 			const int bi = (int)out->extra.size();
 			out->extra.push_back(own);
@@ -963,6 +1132,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			}
 			m->block = nullptr;
 			m->block_cap = m->block_bytes = m->total_entries = 0;
+			m->block_seg = -1;
 			m->trees.clear();
 		}
 		HIP_CHECK(hipStreamSynchronize(s));

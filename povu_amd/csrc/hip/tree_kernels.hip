@@ -562,16 +562,16 @@ static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *o
 		KLAUNCH((k_rank_top<TWO>), dim3(1), dim3(1024), 0, s, nt, nxp[levels], wap[levels], wbp[levels]);
 	} else {
 		LAUNCH(k_rank_unpack_next, nt, s, nt, nxp[levels], rb.tA);
-		HIP_CHECK(hipMemcpyAsync(rb.tB, wap[levels], (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+		HIP_CHECK(copy_async(rb.tB, wap[levels], (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
 		if (TWO)
-			HIP_CHECK(hipMemcpyAsync(rb.tC, wbp[levels], (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+			HIP_CHECK(copy_async(rb.tC, wbp[levels], (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
 		// ping-pong partners: the level's own arrays (their contents were just copied out)
 		uint32_t *nA = rb.tA, *nB = nxp[levels], *aA = rb.tB, *aB = wap[levels], *bA = rb.tC, *bB = wbp[levels];
 		const int side = list_rank(nt, bits_for(nt) + 1, nA, nB, aA, aB, TWO ? bA : nullptr, TWO ? bB : nullptr, s);
 		if (side == 0) { // result in the A set: bring it home
-			HIP_CHECK(hipMemcpyAsync(wap[levels], aA, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+			HIP_CHECK(copy_async(wap[levels], aA, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
 			if (TWO)
-				HIP_CHECK(hipMemcpyAsync(wbp[levels], bA, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
+				HIP_CHECK(copy_async(wbp[levels], bA, (size_t)nt * 4, hipMemcpyDeviceToDevice, s));
 		}
 	}
 	for (int L = levels - 1; L >= 0; L--) {

@@ -39,6 +39,8 @@ static void usage(std::ostream &os)
 	      "                                          (refused: only its first two passes are built, see --leaf-subflubbles)\n"
 	      "        --leaf-subflubbles                Relabel leaf flubbles as tiny (T) / parallel (O): the find_tiny and\n"
 	      "                                          find_parallel passes of -s, without its three inserting passes\n"
+	      "        --gpus=[n]                        Shard the components over n GPUs of this node, one worker per GPU\n"
+	      "                                          [default: 1; devices 0..n-1 or $POVU_HIP_DEVICES]\n"
 	      "        --structure-export=[structure_json]\n"
 	      "                                          Write the flubble debug sidecar <structure_json>.flubble-debug.jsonl\n"
 	      "                                          [conformance]\n";
@@ -96,6 +98,12 @@ int main(int argc, char **argv)
 			cfg.subflubbles = true;
 		} else if ((command == "decompose" || command == "gfa2vcf") && !strcmp(a, "--leaf-subflubbles")) {
 			cfg.leaf_subflubbles = true;
+		} else if (command == "decompose" && value(i, a, "--gpus", "--gpus", v)) {
+			cfg.gpus = atoi(v.c_str());
+			if (cfg.gpus < 1 || cfg.gpus > 64) {
+				std::cerr << "Flag '--gpus' expects a number of GPUs between 1 and 64" << std::endl;
+				return 1;
+			}
 		} else if ((command == "decompose" || command == "gfa2vcf") && !strncmp(a, "--structure-export", 18) &&
 			   (a[18] == 0 || a[18] == '=')) {
 			if (a[18] == '=') {

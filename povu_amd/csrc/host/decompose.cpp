@@ -16,6 +16,7 @@
 
 namespace povu_host
 {
+std::vector<int> multi_devices(int gpus, const char *env, int visible);
 namespace
 {
 // INFO lines of include/povu/common/log.hpp:18-39 (no colours)
@@ -26,11 +27,201 @@ double now_ms()
 	using namespace std::chrono;
 	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
+
+// one <output_dir>/<component id>.pvst per tree of `f` (mto::to_pvst::write_pvst, src/mto/to_pvst.cpp:30-109), formatting and
+// writing spread over `nt` threads
+void write_forest(const povu_hip_forest *f, const Config &cfg, unsigned nt, std::atomic<bool> &failed)
+{
+	const int ll = cfg.verbosity;
+	const uint32_t n = povu_hip_forest_tree_count(f);
+	nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
+	nt = std::min<unsigned>(nt, std::max(1u, n));
+	std::atomic<uint32_t> next{0};
+	auto worker = [&]() {
+		for (;;) {
+			uint32_t i = next.fetch_add(1);
+			if (i >= n)
+				break;
+			povu_hip_tree t;
+			povu_hip_forest_get(f, i, &t);
+			if (ll)
+				info("Handling component: " + std::to_string(t.component_id));
+			size_t len = 0;
+			char *txt = povu_hip_forest_pvst_text(f, i, &len);
+			if (!txt) {
+				std::cerr << "ERR Could not serialise the PVST of component " << t.component_id << std::endl;
+				failed = true;
+				break;
+			}
+			const std::string fn = cfg.output_dir + "/" + std::to_string(t.component_id) + ".pvst";
+			FILE *o = fopen(fn.c_str(), "wb");
+			if (!o) {
+				std::cerr << "ERR Could not open file " << fn << std::endl;
+				failed = true;
+				povu_hip_buffer_free(txt);
+				break;
+			}
+			const bool short_write = fwrite(txt, 1, len, o) != len;
+			if ((fclose(o) != 0) | short_write) {
+				std::cerr << "ERR Could not write file " << fn << std::endl;
+				failed = true;
+			}
+			povu_hip_buffer_free(txt);
+		}
+	};
+	std::vector<std::thread> th;
+	for (unsigned k = 1; k < nt; k++)
+		th.emplace_back(worker);
+	worker();
+	for (auto &x : th)
+		x.join();
+}
+
+// `povu decompose --gpus N` (additive): the reference's workers each own their components from graph to file
+// (app/subcommand/decompose.cpp:116-157); here a worker is a GPU with a host thread (povu_hip_multi_*).  The root GPU labels
+// and partitions, the shards travel over xGMI, and every worker formats and writes the <id>.pvst files of ITS components
+// as soon as its own decompose is done.
+struct MultiSink {
+	const Config *cfg;
+	unsigned threads_per_rank;
+	std::atomic<bool> failed{false};
+};
+int multi_sink(uint32_t, const povu_hip_forest *f, void *user)
+{
+	MultiSink *s = static_cast<MultiSink *>(user);
+	write_forest(f, *s->cfg, s->threads_per_rank, s->failed);
+	return s->failed ? 1 : 0;
+}
+
+void do_decompose_multi(const Config &cfg)
+{
+	const int ll = cfg.verbosity;
+	if (!cfg.structure_export.empty())
+		throw std::runtime_error("--structure-export reads the device state of ONE context: run it without --gpus");
+	const double t0 = now_ms();
+	const std::vector<int> devs = multi_devices(cfg.gpus, std::getenv("POVU_HIP_DEVICES"), povu_hip_device_count());
+	char err[512] = {0};
+	std::future<povu_hip_multi *> mf = std::async(std::launch::async, [&]() { // the runtime comes up while the GFA is parsed
+		return povu_hip_multi_create(devs.data(), (uint32_t)devs.size(), err, sizeof err);
+	});
+	GfaGraph g;
+	try {
+		g = load_gfa(cfg.input_gfa, false, false, cfg.threads);
+	} catch (...) {
+		if (povu_hip_multi *m = mf.get())
+			povu_hip_multi_destroy(m);
+		throw;
+	}
+	const double t1 = now_ms();
+	povu_hip_multi *m = mf.get();
+	if (!m)
+		throw std::runtime_error(std::string("povu_hip: ") + err);
+	auto fail = [&](const char *what) {
+		const std::string msg = std::string("povu_hip: ") + what;
+		povu_hip_multi_destroy(m);
+		throw std::runtime_error(msg);
+	};
+	if (povu_hip_multi_upload(m, (uint32_t)g.vid.size(), g.vid.data(), (uint32_t)g.v1.size(), g.v1.data(), g.s1.data(), g.v2.data(),
+				  g.s2.data(), nullptr, err, sizeof err) != 0)
+		fail(err);
+	if (ll > 1)
+		info("Finding components");
+	if (povu_hip_multi_scatter(m, /*keep_graph=*/0, err, sizeof err) != 0)
+		fail(err);
+	const double t2 = now_ms();
+	MultiSink sink{&cfg, (unsigned)std::max<size_t>(1, (size_t)std::max(1, cfg.threads) / devs.size())};
+	const uint32_t flags = (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | POVU_HIP_F_NO_STAGE_TIMES |
+			       (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u);
+	povu_hip_forest *f = povu_hip_multi_decompose(m, flags, multi_sink, &sink, err, sizeof err);
+	const double t3 = now_ms();
+	if (!f) {
+		if (sink.failed) { // unwritable output: message already printed, exit like the reference (to_pvst.cpp:39-42)
+			povu_hip_multi_destroy(m);
+			std::exit(EXIT_FAILURE);
+		}
+		fail(err);
+	}
+	if (ll > 1)
+		info("Found " + std::to_string(povu_hip_forest_total_components(f)) + " components");
+	const uint32_t n = povu_hip_forest_tree_count(f);
+	if (cfg.hairpins) // flubbles.cpp:712-717 (in component order, after the workers are done)
+		for (uint32_t i = 0; i < n; i++) {
+			povu_hip_tree t;
+			povu_hip_forest_get(f, i, &t);
+			for (uint32_t k = 0; k < t.n_hairpins; k++)
+				std::cerr << "Boundary: " << t.hairpins[2 * k] << " " << t.hairpins[2 * k + 1] << std::endl;
+		}
+	if (std::getenv("POVU_STAGE_COST_TRACE")) {
+		double ms[6] = {0};
+		povu_hip_multi_times(m, ms);
+		fprintf(stderr, "povu-stage-cost contract=host:gfa_parse calls=1 input_items=%zu output_items=%zu elapsed_ns=%.0f\n", g.v1.size(),
+			g.vid.size(), (t1 - t0) * 1e6);
+		fprintf(stderr, "povu-stage-cost contract=host:upload_partition_scatter calls=1 input_items=%zu output_items=%zu elapsed_ns=%.0f\n",
+			g.v1.size(), devs.size(), (t2 - t1) * 1e6);
+		fprintf(stderr, "povu-stage-cost contract=host:decompose_and_write calls=%zu input_items=%zu output_items=%u elapsed_ns=%.0f\n",
+			devs.size(), g.v1.size(), n, (t3 - t2) * 1e6);
+		fprintf(stderr, "povu-stage-cost contract=hip:multi transport=%s label_ns=%.0f lpt_ns=%.0f partition_ns=%.0f\n",
+			povu_hip_multi_transport(m), ms[0] * 1e6, ms[1] * 1e6, ms[2] * 1e6);
+		for (uint32_t r = 0; r < devs.size(); r++) {
+			povu_hip_multi_rank_info ri;
+			povu_hip_multi_rank(m, r, &ri);
+			fprintf(stderr,
+				"povu-stage-cost contract=hip:rank%u device=%d input_items=%u csr_ns=%.0f decompose_ns=%.0f write_ns=%.0f "
+				"d2h_bytes=%llu xgmi_in_bytes=%llu\n",
+				r, ri.device, ri.n_links, ri.csr_ms * 1e6, ri.decompose_ms * 1e6, ri.sink_ms * 1e6, (unsigned long long)ri.d2h,
+				(unsigned long long)ri.peer_in);
+		}
+	}
+	if (cfg.exit_when_done && !std::getenv("POVU_CLI_ORDERLY_EXIT")) { // every output file is closed by now (see do_decompose)
+		std::cout.flush();
+		std::cerr.flush();
+		fflush(nullptr);
+		std::_Exit(0);
+	}
+	povu_hip_forest_free(f);
+	povu_hip_multi_destroy(m);
+}
 } // namespace
+
+// which HIP device every rank of `--gpus N` runs on: POVU_HIP_DEVICES="3,1,2" names them (N entries), else 0 .. N-1; with
+// fewer visible devices than ranks the call fails -- unless POVU_HIP_DEVICES repeats a device on purpose (rehearsal)
+std::vector<int> multi_devices(int gpus, const char *env, int visible)
+{
+	if (gpus < 1 || gpus > 64)
+		throw std::runtime_error("--gpus expects 1 .. 64");
+	std::vector<int> d;
+	if (env && *env) {
+		const char *p = env;
+		while (*p) {
+			char *e = nullptr;
+			const long v = strtol(p, &e, 10);
+			if (e == p || v < 0 || v > 4096)
+				throw std::runtime_error("POVU_HIP_DEVICES: expected a comma-separated list of device indices");
+			d.push_back((int)v);
+			p = *e == ',' ? e + 1 : e;
+			if (*e && *e != ',')
+				throw std::runtime_error("POVU_HIP_DEVICES: expected a comma-separated list of device indices");
+		}
+		if ((int)d.size() != gpus)
+			throw std::runtime_error("POVU_HIP_DEVICES names " + std::to_string(d.size()) + " devices but --gpus is " + std::to_string(gpus));
+	} else {
+		for (int i = 0; i < gpus; i++)
+			d.push_back(i);
+	}
+	for (int v : d)
+		if (v >= visible)
+			throw std::runtime_error("--gpus " + std::to_string(gpus) + ": device " + std::to_string(v) + " is not visible (" +
+						 std::to_string(visible) + " HIP devices)");
+	return d;
+}
 
 void do_decompose(const Config &cfg)
 {
 	const int ll = cfg.verbosity;
+	if (cfg.gpus > 1 && !cfg.subflubbles) {
+		do_decompose_multi(cfg);
+		return;
+	}
 	if (cfg.subflubbles)
 		throw std::runtime_error("-s/--subflubbles is not part of the MI355X decompose path: of its five passes only find_tiny and "
 					 "find_parallel are built (--leaf-subflubbles); concealed, midi and smothered are not");
@@ -124,49 +315,8 @@ void do_decompose(const Config &cfg)
 			append_debug_sidecar_frame(cfg, ctx, t.component_id - 1);
 		}
 	// one <id>.pvst per component; formatting + writing spread over -t threads
-	unsigned nt = (unsigned)std::max(1, cfg.threads);
-	nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
-	nt = std::min<unsigned>(nt, std::max(1u, n));
-	std::atomic<uint32_t> next{0};
 	std::atomic<bool> failed{false};
-	auto worker = [&]() {
-		for (;;) {
-			uint32_t i = next.fetch_add(1);
-			if (i >= n)
-				break;
-			povu_hip_tree t;
-			povu_hip_forest_get(f, i, &t);
-			if (ll)
-				info("Handling component: " + std::to_string(t.component_id));
-			size_t len = 0;
-			char *txt = povu_hip_forest_pvst_text(f, i, &len);
-			if (!txt) {
-				std::cerr << "ERR Could not serialise the PVST of component " << t.component_id << std::endl;
-				failed = true;
-				break;
-			}
-			const std::string fn = cfg.output_dir + "/" + std::to_string(t.component_id) + ".pvst";
-			FILE *o = fopen(fn.c_str(), "wb");
-			if (!o) {
-				std::cerr << "ERR Could not open file " << fn << std::endl;
-				failed = true;
-				povu_hip_buffer_free(txt);
-				break;
-			}
-			const bool short_write = fwrite(txt, 1, len, o) != len;
-			if ((fclose(o) != 0) | short_write) {
-				std::cerr << "ERR Could not write file " << fn << std::endl;
-				failed = true;
-			}
-			povu_hip_buffer_free(txt);
-		}
-	};
-	std::vector<std::thread> th;
-	for (unsigned k = 1; k < nt; k++)
-		th.emplace_back(worker);
-	worker();
-	for (auto &x : th)
-		x.join();
+	write_forest(f, cfg, (unsigned)std::max(1, cfg.threads), failed);
 	const double t4 = now_ms();
 
 	// per-stage cost lines, same shape as povu::stage_cost::write_report (stage_cost.cpp:59-78)

@@ -20,6 +20,7 @@ struct Config {
 	bool subflubbles = false;
 	bool leaf_subflubbles = false; // --leaf-subflubbles: find_tiny + find_parallel only (the two passes of -s that relabel leaf flubbles)
 	int device = 0;
+	int gpus = 1; // --gpus N (additive): components sharded over N GPUs of this node, one worker thread per GPU
 	// --structure-export <path>: also write <path>.flubble-debug.jsonl (one frame per decomposed component)
 	std::string structure_export;
 	// the decompose command itself: once the files are written the process ends without releasing device and host memory
@@ -47,5 +48,8 @@ void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t c
 // povu binary named by POVU_CALL_EXE on it (a child process); `call_args` are handed to it unchanged.
 void do_gfa2vcf(const Config &cfg, const std::vector<std::string> &call_args);
 void do_prune(const Config &cfg);
+
+// device of every rank of `--gpus N` (POVU_HIP_DEVICES or 0 .. N-1), checked against the number of visible devices
+std::vector<int> multi_devices(int gpus, const char *env, int visible);
 
 } // namespace povu_host

@@ -39,6 +39,13 @@ class _ShardInfo(C.Structure):
                 ("bytes", C.c_size_t), ("device_ptr", C.c_void_p)]
 
 
+class _MultiRank(C.Structure):
+    _fields_ = [("device", C.c_int), ("n_vtx", C.c_uint32), ("n_links", C.c_uint32), ("n_components", C.c_uint32),
+                ("shard_bytes", C.c_uint64), ("recv_ms", C.c_double), ("csr_ms", C.c_double), ("decompose_ms", C.c_double),
+                ("sink_ms", C.c_double), ("h2d", C.c_uint64), ("d2h", C.c_uint64), ("peer_out", C.c_uint64),
+                ("peer_in", C.c_uint64)]
+
+
 class _StageTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32)]
 
@@ -165,6 +172,34 @@ def load_lib():
     l.povu_hip_comm_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     l.povu_hip_comm_times.restype = C.c_int
     l.povu_hip_comm_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    l.povu_hip_share_results.restype = C.c_int
+    l.povu_hip_share_results.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_forest_share.restype = C.c_int
+    l.povu_hip_forest_share.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    l.povu_hip_forest_attach.restype = C.c_void_p
+    l.povu_hip_forest_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint32, C.c_char_p,
+                                         C.c_size_t]
+    l.povu_hip_transfer_bytes.restype = C.c_int
+    l.povu_hip_transfer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    # ---- one process, N GPUs
+    l.povu_hip_multi_create.restype = C.c_void_p
+    l.povu_hip_multi_create.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.c_char_p, C.c_size_t]
+    l.povu_hip_multi_destroy.argtypes = [C.c_void_p]
+    l.povu_hip_multi_world.restype = C.c_uint32
+    l.povu_hip_multi_world.argtypes = [C.c_void_p]
+    l.povu_hip_multi_upload.restype = C.c_int
+    l.povu_hip_multi_upload.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_multi_scatter.restype = C.c_int
+    l.povu_hip_multi_scatter.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    l.povu_hip_multi_decompose.restype = C.c_void_p
+    l.povu_hip_multi_decompose.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    l.povu_hip_multi_rank.restype = C.c_int
+    l.povu_hip_multi_rank.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_MultiRank)]
+    l.povu_hip_multi_times.restype = C.c_int
+    l.povu_hip_multi_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    l.povu_hip_multi_transport.restype = C.c_char_p
+    l.povu_hip_multi_transport.argtypes = [C.c_void_p]
     l.povu_hip_gfa_write.restype = C.c_int
     l.povu_hip_gfa_write.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_char_p, C.c_size_t]
@@ -291,6 +326,18 @@ class Forest:
         if self._lib.povu_hip_forest_pack(self._h, buf.ctypes.data, n) != 0:
             raise RuntimeError("forest pack failed")
         return buf
+
+    def share(self, rank: int) -> np.ndarray:
+        """Descriptor (8 x uint64, word 7 = `rank`) of this forest's block in shared memory for the root of a multi-process
+        job (povu_hip_forest_share; the context must have been put into shared-results mode)."""
+        d = (C.c_uint64 * 8)()
+        rc = self._lib.povu_hip_forest_share(self._h, d)
+        if rc != 0:
+            raise RuntimeError({2: "the forest's block is no shared segment: call HipDecomposer.share_results first",
+                                4: "hairpin boundaries / subflubble labels do not travel"}.get(rc, f"forest share failed ({rc})"))
+        out = np.array(list(d), dtype=np.uint64)
+        out[7] = rank
+        return out
 
     def component_ids(self) -> List[int]:
         t = _Tree()
@@ -430,6 +477,30 @@ class HipDecomposer:
         if self._lib.povu_hip_graph_upload_shard(self._ctx, ptr, n, 1 if on_device else 0, err, 512) != 0:
             raise RuntimeError(err.value.decode())
 
+    def share_results(self, tag: str) -> None:
+        """From now on the PVST blocks of this context's forests are shared-memory segments "/povu.<tag>.<k>" (the
+        multi-process convention: tag = "<job>.<rank>"), see povu_hip_share_results."""
+        err = C.create_string_buffer(512)
+        if self._lib.povu_hip_share_results(self._ctx, tag.encode(), err, 512) != 0:
+            raise RuntimeError(err.value.decode())
+
+    def attach_forests(self, own: Optional["Forest"], own_rank: int, job_tag: str, descs) -> "Forest":
+        """Root of a multi-process job: the merged forest of every rank's descriptor (Forest.share) and of its own forest,
+        which it takes over.  No PVST array is copied: the other ranks' blocks are mapped where their GPUs put them."""
+        d = np.ascontiguousarray(np.asarray(descs, dtype=np.uint64).reshape(-1, 8))
+        err = C.create_string_buffer(512)
+        h = self._lib.povu_hip_forest_attach(self._ctx, own._h if own is not None else None, own_rank, job_tag.encode(),
+                                             d.ctypes.data, d.shape[0], err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return Forest(self._lib, h)
+
+    def transfer_bytes(self) -> dict:
+        """Bytes this context moved since it was created: over PCIe in either direction, to and from other GPUs."""
+        b = (C.c_uint64 * 4)()
+        self._lib.povu_hip_transfer_bytes(self._ctx, b)
+        return dict(h2d=int(b[0]), d2h=int(b[1]), peer_out=int(b[2]), peer_in=int(b[3]))
+
     def shard_total_components(self) -> int:
         return int(self._lib.povu_hip_shard_total_components(self._ctx))
 
@@ -541,3 +612,69 @@ class HipDecomposer:
         ns = np.zeros(n.value, dtype=np.uint32)
         self._lib.povu_hip_debug_stack(self._ctx, comp, C.byref(n), vtx.ctypes.data, cls.ctypes.data, ns.ctypes.data)
         return dict(tree_vtx=vtx, cls=cls, next_seen=ns)
+
+
+class MultiDecomposer:
+    """One process, N GPUs (povu_hip_multi_*): one context and one host thread per device; the root device partitions, the
+    shards travel over xGMI (RCCL), every GPU lands its PVST block in host memory over its own PCIe link."""
+
+    def __init__(self, devices):
+        self._lib = load_lib()
+        if self._lib.povu_hip_device_count() <= 0:
+            raise HipUnavailable("no HIP device visible: the decompose path has no CPU fallback")
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        err = C.create_string_buffer(512)
+        self._h = self._lib.povu_hip_multi_create(devs, len(devices), err, 512)
+        if not self._h:
+            raise HipUnavailable(err.value.decode())
+        self.world = len(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.povu_hip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def transport(self) -> str:
+        return self._lib.povu_hip_multi_transport(self._h).decode()
+
+    def upload(self, links, tips=None):
+        vid = np.ascontiguousarray(links.vid, dtype=np.uint32)
+        v1 = np.ascontiguousarray(links.v1, dtype=np.uint32)
+        v2 = np.ascontiguousarray(links.v2, dtype=np.uint32)
+        s1 = np.ascontiguousarray(links.s1, dtype=np.uint8)
+        s2 = np.ascontiguousarray(links.s2, dtype=np.uint8)
+        tp = None
+        if tips is not None:
+            tips = np.ascontiguousarray(tips, dtype=np.uint8)
+            tp = tips.ctypes.data
+        err = C.create_string_buffer(512)
+        if self._lib.povu_hip_multi_upload(self._h, len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
+                                           v2.ctypes.data, s2.ctypes.data, tp, err, 512) != 0:
+            raise RuntimeError(err.value.decode())
+
+    def scatter(self, keep_graph: bool = True):
+        err = C.create_string_buffer(512)
+        if self._lib.povu_hip_multi_scatter(self._h, 1 if keep_graph else 0, err, 512) != 0:
+            raise RuntimeError(err.value.decode())
+
+    def decompose(self, flags: int = 0) -> Forest:
+        err = C.create_string_buffer(512)
+        h = self._lib.povu_hip_multi_decompose(self._h, flags, None, None, err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return Forest(self._lib, h)
+
+    def rank_info(self, rank: int) -> dict:
+        r = _MultiRank()
+        if self._lib.povu_hip_multi_rank(self._h, rank, C.byref(r)) != 0:
+            raise IndexError(rank)
+        return {k: getattr(r, k) for k, _ in _MultiRank._fields_}
+
+    def times(self) -> dict:
+        t = (C.c_double * 6)()
+        self._lib.povu_hip_multi_times(self._h, t)
+        return dict(label_ms=t[0], lpt_ms=t[1], partition_ms=t[2], scatter_wall_ms=t[3], decompose_wall_ms=t[4], merge_ms=t[5])

@@ -238,6 +238,28 @@ def gather_over_dist(work: "_hip.HipDecomposer", forest: "_hip.Forest", rank: in
     return work.merge_forests(parts)
 
 
+def gather_shared(work: "_hip.HipDecomposer", forest: "_hip.Forest", rank: int, world: int, device, job_tag: str):
+    """PVST gather to rank 0 WITHOUT moving a block: every rank's decompose has already copied its PVST arrays into
+    page-locked host memory over its own GPU's PCIe link, and with `HipDecomposer.share_results` that memory is a named
+    shared-memory segment.  The ranks exchange one 64-byte descriptor each (an all-gather on whatever backend the job runs:
+    RCCL on GPUs, gloo in the CPU-side rehearsals) and the root maps the segments (`povu_hip_forest_attach`).  Nothing goes
+    back to a device, over xGMI, or through the root's PCIe link.
+
+    The caller keeps `forest` alive until its NEXT gather (the root reads the arrays in place); the root gets the merged
+    forest, which takes over the arrays of its own `forest`, the others get None."""
+    import torch
+    import torch.distributed as dist
+
+    d = forest.share(rank)
+    mine = torch.from_numpy(d.view(np.int64).copy()).to(device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    if rank != 0:
+        return None
+    descs = np.stack([p.cpu().numpy().view(np.uint64) for p in parts])
+    return work.attach_forests(forest, 0, job_tag, descs)
+
+
 # ---------------------------------------------------------------- strong-scaling bench driver
 class ShardedBench:
     """bench.py --gpus N: the SAME graph every step, sharded over N ranks.  Rank 0 keeps the whole graph resident in
@@ -253,6 +275,16 @@ class ShardedBench:
         # no multi-GPU box has run yet
         import os
         self.native = comm_device.type == "cuda" and os.environ.get("POVU_BENCH_NATIVE_RCCL") == "1"
+        # Gather: through shared memory by default (`gather_shared`: no PVST block crosses PCIe twice); POVU_BENCH_GATHER=wire
+        # takes the packed forests over the backend instead (what a job across nodes would need)
+        self.shared = os.environ.get("POVU_BENCH_GATHER", "shared") == "shared" and not self.native
+        self.job = None
+        if self.shared:
+            tag = [f"{os.getpid()}x{int(time.time() * 1e3) & 0xFFFFFFF:x}" if rank == 0 else None]
+            dist.broadcast_object_list(tag, src=0)
+            self.job = tag[0]
+            work.share_results(f"{self.job}.{rank}")
+        self._mine = None  # this rank's last forest: the root reads its arrays in place until the next gather
         self.full = None
         self.meta = None
         if rank == 0:
@@ -284,7 +316,7 @@ class ShardedBench:
         t2 = time.perf_counter()
         f = self.work.decompose_shard(flags=_hip.F_NO_STAGE_TIMES)
         t3 = time.perf_counter()
-        merged = self.comm.gather(f) if self.native else gather_over_dist(self.work, f, self.rank, self.world, self.dev)
+        merged = self._gather(f)
         t4 = time.perf_counter()
         self.phase["partition"] += t1 - t0
         self.phase["scatter"] += t2 - t1
@@ -293,17 +325,24 @@ class ShardedBench:
         self.steps += 1
         if self.rank == 0:
             self.last, self.last_shards = merged, shards
-        del f
         return merged
+
+    def _gather(self, f):
+        if self.native:
+            return self.comm.gather(f)
+        if self.shared:
+            merged = gather_shared(self.work, f, self.rank, self.world, self.dev, self.job)
+            self._mine = f  # (replaces the forest of the step before: every rank has passed this step's all-gather, so the
+            return merged   #  root is done with that one)
+        return gather_over_dist(self.work, f, self.rank, self.world, self.dev)
 
     def step_resident(self):
         """The part of a step that starts from "every rank's shard CSR resident" (what the last scatter left) and ends with
         "forest merged on rank 0": per-shard decompose + gather.  Same start and end as the N = 1 measurement of bench.py."""
         f = self.work.decompose_shard(flags=_hip.F_NO_STAGE_TIMES)
-        merged = self.comm.gather(f) if self.native else gather_over_dist(self.work, f, self.rank, self.world, self.dev)
+        merged = self._gather(f)
         if self.rank == 0:
             self.last = merged
-        del f
         return merged
 
     def sync(self):
@@ -349,9 +388,11 @@ class ShardedBench:
                    sharding=("strong scaling: rank 0 labels the components on its GPU, LPT bin-packing, device partition, "
                              + ("RCCL ncclSend/ncclRecv scatter of the packed shards and gather of the PVST blocks from C++ (shard.hip)"
                                 if self.native else
-                                ("RCCL send/recv (torch.distributed, backend nccl) of the packed shards out of the partition block in HBM "
-                                 "and of the packed forests back" if self.dev.type == "cuda" else
-                                 "scatter / gather over torch.distributed through host memory (rehearsal)"))
+                                (("RCCL send/recv (torch.distributed, backend nccl) of the packed shards out of the partition block in HBM"
+                                  if self.dev.type == "cuda" else "scatter over torch.distributed through host memory (rehearsal)")
+                                 + ("; gather: every rank's PVST block lands in shared page-locked host memory over its own PCIe link, "
+                                    "the ranks all-gather one 64-byte descriptor each and the root maps the blocks"
+                                    if self.shared else "; gather: packed forests back over the same backend")))
                              + "; all inside the timed region"),
                    phase_ms={"per_rank": [dict(zip(("partition", "scatter", "decompose", "gather"), [float(x) for x in p.tolist()]))
                                           for p in allp],
@@ -359,6 +400,8 @@ class ShardedBench:
         return out
 
     def close(self):
+        self.last = None   # (the merged forest reads the other ranks' segments: gone before they are)
+        self._mine = None
         if self.comm:
             self.comm.close()
         if self.full:

@@ -363,6 +363,31 @@ def test_cli_surface(tmp_path, golden_dir):
         assert not list(tmp_path.glob("*.pvst"))
 
 
+def test_cli_gpus_flag_arguments(tmp_path, golden_dir):
+    """`--gpus N` (additive; default 1): which device every worker gets is settled on the host before anything touches a
+    GPU -- 0 .. N-1 or the N entries of POVU_HIP_DEVICES, each checked against the visible devices -- and a multi-GPU run
+    without GPUs fails as loudly as the single-GPU one."""
+    _built()
+    gfa = os.path.join(golden_dir, "gfa", "LPA.gfa")
+    run = lambda args, **env: subprocess.run([POVU] + args, capture_output=True, text=True, env=dict(os.environ, **env))  # noqa: E731
+    r = run(["decompose", "--gpus", "0", "-i", gfa])
+    assert r.returncode == 1 and "between 1 and 64" in r.stderr
+    r = run(["decompose", "--gpus=65", "-i", gfa])
+    assert r.returncode == 1 and "between 1 and 64" in r.stderr
+    r = run(["decompose", "--gpus"])
+    assert r.returncode == 1 and "requires an argument" in r.stderr
+    r = run(["decompose", "--gpus", "2", "-i", gfa, "-o", str(tmp_path)], POVU_HIP_DEVICES="0,0,0")
+    assert r.returncode == 1 and "names 3 devices but --gpus is 2" in r.stderr
+    r = run(["decompose", "--gpus", "2", "-i", gfa, "-o", str(tmp_path)], POVU_HIP_DEVICES="0;1")
+    assert r.returncode == 1 and "comma-separated" in r.stderr
+    n = H.load_lib().povu_hip_device_count()
+    r = run(["decompose", "--gpus", str(max(n, 1) + 1), "-i", gfa, "-o", str(tmp_path)])
+    assert r.returncode == 1 and f"device {n} is not visible ({n} HIP devices)" in r.stderr
+    assert not list(tmp_path.glob("*.pvst"))
+    r = run(["info", "--gpus", "2", "-i", gfa])  # only `decompose` takes the flag
+    assert r.returncode == 1 and "could not be matched" in r.stderr
+
+
 class _Doc(C.Structure):
     _fields_ = [("n", C.c_uint32), ("type", C.POINTER(C.c_char)), ("file_id", C.POINTER(C.c_uint32)),
                 ("a_id", C.POINTER(C.c_uint32)), ("z_id", C.POINTER(C.c_uint32)), ("a_or", C.POINTER(C.c_uint8)),

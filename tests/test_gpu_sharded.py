@@ -168,8 +168,161 @@ def test_bench_rehearsal_two_ranks_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["components"] == 2024 and len(line["shards"]) == 2
     assert sum(s["n_links"] for s in line["shards"]) == line["config"]["links"]
-    # both definitions of the rate: the whole job, and from resident shards (what the N = 1 line's `value` measures)
-    assert line["value_whole_job"] == line["value"] and line["value_from_resident_shards"] > line["value"] > 0
+    # both definitions of the rate: from resident shards (`value`: what the N = 1 line's `value` measures) and the whole job
+    assert line["value_from_resident_shards"] == line["value"] > line["value_whole_job"] > 0
+    assert "shared" in line["config"]["sharding"]  # the gather maps the ranks' blocks, it does not move them
+
+
+def test_bench_plain_launch_drives_the_gpus_itself(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher must not die: one process drives the ranks through povu_hip_multi_*
+    (here both ranks on the one GPU of the test box)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["POVU_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.002"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["transport"] == "same-device"
+    assert line["config"]["components"] == 2024 and len(line["shards"]) == 2
+    assert sum(s["n_links"] for s in line["shards"]) == line["config"]["links"]
+    assert line["value_from_resident_shards"] == line["value"] > line["value_whole_job"] > 0
+
+
+def _pvst_block_bytes(entries):
+    return 3 * ((entries * 4 + 63) & ~63) + 2 * ((entries + 63) & ~63)
+
+
+def _shared_worker(rank, world, port, out_path):
+    import json
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    from povu_amd import HipDecomposer
+    work = HipDecomposer(0)
+    tag = [f"t{os.getpid()}" if rank == 0 else None]
+    dist.broadcast_object_list(tag, src=0)
+    work.share_results(f"{tag[0]}.{rank}")
+    full = None
+    if rank == 0:
+        full = HipDecomposer(0)
+        full.upload(_graph())
+    keep, merged, rec = None, None, []
+    for _ in range(3):  # later rounds reuse the segments
+        sharded.scatter_over_dist(full, work, rank, world, dev)
+        b0 = work.transfer_bytes()
+        f = work.decompose_shard()
+        own, trees = sum(f.pvst_sizes()), len(f)
+        merged = sharded.gather_shared(work, f, rank, world, dev, tag[0])
+        b1 = work.transfer_bytes()
+        keep = f  # the root reads this rank's arrays in place until the next gather
+        rec.append(dict(rank=rank, own_entries=own, trees=trees, d2h=b1["d2h"] - b0["d2h"], h2d=b1["h2d"] - b0["h2d"],
+                        peer=b1["peer_out"] + b1["peer_in"]))
+    allrec = [None] * world
+    dist.gather_object(rec, allrec if rank == 0 else None, dst=0)
+    if rank == 0:
+        assert len(keep) == 0  # the root's own trees moved into the merged forest
+        texts = merged.texts()  # (reads rank 1's arrays from ITS shared segment)
+        json.dump(dict(texts={str(k): v for k, v in texts.items()}, rec=allrec), open(out_path, "w"))
+    dist.barrier()  # rank 1 keeps its forest until the root is done reading
+    del merged, keep
+    work.close()
+    if full:
+        full.close()
+    dist.destroy_process_group()
+
+
+def test_shared_memory_gather_crosses_pcie_once(tmp_path):
+    """Two ranks on the one GPU of the box (gloo for the descriptors): every PVST block crosses PCIe exactly ONCE, over
+    the link of the GPU that computed it -- counted per rank by the library (povu_hip_transfer_bytes) around decompose +
+    gather: device-to-host = the rank's own block (+ the small counts a pass reads back), host-to-device = the small tables
+    of a pass; nothing is sent back to a device, nothing goes to a peer, and the root's traffic does not grow with the
+    other ranks' results."""
+    import json
+    out = str(tmp_path / "shared.json")
+    mp.spawn(_shared_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = json.load(open(out))
+    assert {int(k): v for k, v in got["texts"].items()} == O.decompose(_graph())
+    for per_rank in got["rec"]:
+        for r in per_rank:
+            blk = _pvst_block_bytes(r["own_entries"])
+            slack = 8192 + 64 * r["trees"]  # counts and per-component tables of a pass
+            assert 14 * r["own_entries"] <= r["d2h"] <= blk + slack, r
+            assert r["h2d"] <= slack, r
+            assert r["peer"] == 0, r
+    assert all(r["own_entries"] > 0 for per_rank in got["rec"] for r in per_rank)
+
+
+def test_one_process_engine_three_ranks_on_one_device():
+    """povu_hip_multi_*: one process, a context + host thread per rank (all three on the one GPU here, shards loaded straight
+    from the partition block); the merged forest takes the workers' blocks over."""
+    from povu_amd import HipDecomposer
+    from povu_amd.hip import F_HAIRPINS, F_LEAF_SUBFLUBBLES, MultiDecomposer
+    g = _graph()
+    want = O.decompose(g)
+    md = MultiDecomposer([0, 0, 0])
+    assert md.transport == "same-device"
+    md.upload(g)
+    for _ in range(2):
+        md.scatter()
+        f = md.decompose()
+        assert f.texts() == want
+        ids = f.component_ids()
+        assert ids == sorted(ids)
+    info = [md.rank_info(r) for r in range(3)]
+    assert sum(i["n_links"] for i in info) == g.n_links and sum(i["n_vtx"] for i in info) == g.n_vtx
+    assert all(i["peer_in"] == 0 and i["peer_out"] == 0 for i in info)
+    # resident shards: decompose again without a scatter; the forest of the step before stays valid
+    f2 = md.decompose()
+    assert f2.texts() == want and f.texts() == want
+    # what does not travel between processes does move inside one: subflubble labels and hairpin boundaries
+    assert md.decompose(F_LEAF_SUBFLUBBLES).texts() == O.decompose(g, leaf=True)
+    one = HipDecomposer(0)
+    one.upload(g)
+    fh1, fhm = one.decompose(flags=F_HAIRPINS), md.decompose(F_HAIRPINS)
+    assert fhm.texts() == want
+    hp = lambda fo: {fo.tree(i).component_id: fo.tree(i).hairpins.tolist() for i in range(len(fo))}  # noqa: E731
+    assert hp(fh1) == hp(fhm)
+    one.close()
+    del f, f2, fh1, fhm
+    md.close()
+    # more ranks than components, and a world of one
+    small = W.hprc_shaped([700, 300], seed=2, tiny=3)
+    for devs in ([0] * 9, [0]):
+        md = MultiDecomposer(devs)
+        md.upload(small)
+        md.scatter(keep_graph=False)
+        assert md.decompose().texts() == O.decompose(small)
+        md.close()
+
+
+def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
+    """`povu decompose --gpus 2` (both workers on the one GPU via POVU_HIP_DEVICES): every worker writes the files of its
+    components; together they are what the single-GPU run writes."""
+    import subprocess
+    from povu_amd import hip as H
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    povu = os.path.join(root, "povu_amd", "bin", "povu")
+    g = _graph()
+    gfa = str(tmp_path / "g.gfa")
+    H.write_gfa(g, gfa)
+    outs = {}
+    for name, extra, env in (("one", [], {}), ("two", ["--gpus", "2"], {"POVU_HIP_DEVICES": "0,0"}),
+                             ("two_leaf", ["--gpus=2", "--leaf-subflubbles"], {"POVU_HIP_DEVICES": "0,0"})):
+        d = tmp_path / name
+        d.mkdir()
+        r = subprocess.run([povu, "-t", "4", "decompose", "-i", gfa, "-o", str(d)] + extra, env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1000:]
+        outs[name] = {int(p.name[:-5]): p.read_text() for p in d.glob("*.pvst")}
+    assert outs["one"] == O.decompose(g) == outs["two"]
+    assert outs["two_leaf"] == O.decompose(g, leaf=True)
+    r = subprocess.run([povu, "decompose", "-i", gfa, "-o", str(tmp_path), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "device 1 is not visible" in r.stderr  # a one-GPU box has no second device
 
 
 def test_shards_leave_the_partition_block_without_a_copy():
