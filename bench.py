@@ -79,20 +79,33 @@ def count_flubbles(forest):
     return sum(n - 1 for n in forest.pvst_sizes())
 
 
-def time_single(hip, g, steps, warmup, flags):
-    """warmup + `steps` timed passes on one context; returns (seconds, HIP-event ms per pass, last forest)."""
+def time_single(hip, g, steps, warmup, flags, overlap=True):
+    """warmup + `steps` timed passes on one context; returns (seconds, HIP-event ms per pass, last forest, mean latency of a
+    pass in ms).  With `overlap` the passes are issued back to back (POVU_HIP_F_ASYNC): a pass returns when its forest is laid
+    out, and the copy engine moves its PVST arrays over PCIe while the kernels of the next pass run; the timed region ends
+    when the LAST pass's arrays are in host memory, so every step's work is inside it.  ms per pass = HIP-event time from
+    the first kernel of the first timed pass to the last byte of the last one, divided by the steps."""
     import torch
+    from povu_amd.hip import F_ASYNC
     f = None
     for _ in range(warmup):
         f = hip.decompose(flags=flags)
     torch.cuda.synchronize()
-    ev = 0.0
+    fl = flags | (F_ASYNC if overlap else 0)
     t0 = time.perf_counter()
+    first = prev = None
+    lat = 0.0
     for _ in range(steps):
-        f = hip.decompose(flags=flags)
-        ev += next(st["ms"] for st in hip.stage_times() if st["name"] == "total")
+        f = hip.decompose(flags=fl)
+        if first is None:
+            first = f
+        if prev is not None:
+            lat += prev.pass_ms()  # (waits for the pass before: long complete by now)
+        prev = f
+    lat += prev.pass_ms()  # waits for the last pass: its arrays are in host memory
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, ev / max(1, steps), f
+    dt = time.perf_counter() - t0
+    return dt, first.span_ms(prev) / max(1, steps), f, lat / max(1, steps)
 
 
 def cpu_baseline(g, wl):
@@ -280,6 +293,7 @@ def main():
     ap.add_argument("--workload", default="hprc-wg", choices=["hprc-wg", "chain", "hprc-chr", "nest", "tangled"])
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the workload (1.0 = BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="time the passes one at a time instead of back to back")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs 2 / 3 / 5")
     args = ap.parse_args()
 
@@ -322,7 +336,10 @@ def main():
         hip.upload(g)  # inputs resident in HBM before the timed region
         upload_s = time.perf_counter() - t_up
         up = hip.upload_times()
-        dt, pass_ms, f = time_single(hip, g, args.steps, args.warmup, F_NO_STAGE_TIMES)
+        dt, pass_ms, f, lat_ms = time_single(hip, g, args.steps, args.warmup, F_NO_STAGE_TIMES, overlap=not args.no_overlap)
+        # the same passes one at a time (each complete before the next starts): what a single decompose call costs
+        dt1, pass1_ms, _f1, _ = time_single(hip, g, 3, 0, F_NO_STAGE_TIMES, overlap=False)
+        del _f1
         E, V, F = g.n_links, g.n_vtx, count_flubbles(f)
         n_trees = len(f)
         del f
@@ -361,6 +378,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg,
                          "ms_per_launch": pass_ms, "formula": "48*E + 108*V + 16*F bytes (SURVEY 8d)",
+                         "launch": ("passes issued back to back: the copy of a pass's PVST arrays to the host (PCIe) overlaps the "
+                                    "kernels of the next pass; ms_per_launch = HIP events from the first kernel of the first timed "
+                                    "pass to the last byte of the last, / steps" if not args.no_overlap else
+                                    "one pass at a time"),
+                         "pass_latency_ms": lat_ms, "ms_per_launch_one_pass_at_a_time": pass1_ms,
                          "dominant_stage": {"name": dom, "ms": stages[dom]}},
             "stage_ms": stages,
             # what happens before the timed region (povu_hip_graph_upload), split by HIP events:
@@ -374,6 +396,7 @@ def main():
             "value_from_resident_shards": E * args.steps / dt,
             "value_whole_job": E / (step_s + (up["csr_ms"] + up["twin_ms"]) * 1e-3),
             "pcie_inclusive_value": E / (step_s + upload_s),
+            "ms_per_step_one_pass_at_a_time": dt1 / 3 * 1e3,
         }
         if not args.no_secondary and args.workload == "hprc-wg":
             sec = {}
@@ -381,11 +404,15 @@ def main():
                                       ("tangled_hprc_shape", "tangled", 2)):
                 g2, wl2 = build_workload(name, 1.0)
                 hip.upload(g2)
-                dt2, ms2, f2 = time_single(hip, g2, k_steps, 1 if k_steps < 5 else 2, F_NO_STAGE_TIMES)
+                dt2, ms2, f2, lat2 = time_single(hip, g2, k_steps, 1 if k_steps < 5 else 2, F_NO_STAGE_TIMES, overlap=not args.no_overlap)
                 a2 = algorithmic_bytes(g2.n_links, g2.n_vtx, count_flubbles(f2))
                 hip.decompose()  # untimed: per-stage HIP events
                 sec[key] = {"workload": wl2, "value": g2.n_links * k_steps / dt2, "ms_per_step": dt2 / k_steps * 1e3, "ms_per_launch": ms2,
-                            "roofline_frac": a2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "roofline_frac": a2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "pass_latency_ms": lat2,
+                            # which path the pass took: components redone by the one-lane stack machine, whether the class pass
+                            # ran over the black tree edges only, whether the laminarity check ran ("Row G")
+                            "seq_redo": hip.seq_redo_count(), "black_only_classes": hip.last_black_only_classes(),
+                            "laminar_check_ran": hip.last_laminar_check_ran(),
                             "stage_ms": {st["name"]: round(st["ms"], 4) for st in hip.stage_times()}}
                 del f2, g2
             out["secondary"] = sec

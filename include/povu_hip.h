@@ -82,6 +82,7 @@ typedef struct {
 #define POVU_HIP_F_ALL_VERTEX_CLASSES 512u /* number the cycle classes of all tree edges, not just the black ones the candidate stack holds (A/B testing) */
 #define POVU_HIP_F_CHECK_LAMINAR 1024u /* always run the laminarity check of the candidate stack's (prev, i) intervals; by default it only runs when the literal hi_2 rule capped differently from the second-highest reach, DESIGN.md section 4 has the proof for the other case (A/B testing, fuzzing) */
 #define POVU_HIP_F_LEAF_SUBFLUBBLES 2048u /* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) and find_parallel (parallel.cpp:263-287) on every PVST; the forest then also carries ai / zi and the line letter of every vertex (povu_hip_forest_get_sub).  Not the reference's whole `-s`: its three inserting passes are not built */
+#define POVU_HIP_F_ASYNC 4096u /* povu_hip_decompose returns as soon as the forest is laid out -- tree table, sizes, the page-locked result block -- while the last kernels and the copy of the PVST arrays to the host are still in flight; povu_hip_forest_wait (or any accessor of the forest: they wait by themselves) completes it.  A second povu_hip_decompose on the same context may start at once: its kernels run while the copy engine still moves the first result over PCIe.  Ignored (the call completes before it returns) without POVU_HIP_F_NO_STAGE_TIMES, with hairpins, subflubble labels, the test modes, and when the pass needs the laminarity check */
 #define POVU_HIP_F_SORTED_ADJ 16u /* build the local adjacency with the radix sort hub graphs use (A/B testing) */
 
 /*
@@ -245,6 +246,15 @@ int povu_hip_multi_times(const povu_hip_multi *m, double out_ms[6]);
  * reason is appended) or "same-device" */
 const char *povu_hip_multi_transport(const povu_hip_multi *m);
 
+/* Completes a forest of a POVU_HIP_F_ASYNC decompose (no-op otherwise): returns when its arrays are in host memory. */
+int povu_hip_forest_wait(povu_hip_forest *f);
+/* HIP-event time of the pass that produced `f`, from its first kernel to the last byte in host memory, milliseconds
+ * (waits for the forest first; < 0 when the forest carries none: merged forests, empty shards) */
+double povu_hip_forest_pass_ms(povu_hip_forest *f);
+/* HIP-event time from the first kernel of the pass behind `first` to the last byte of the pass behind `last` (both of one
+ * context): what a run of overlapped passes took on the device */
+double povu_hip_forest_span_ms(povu_hip_forest *first, povu_hip_forest *last);
+
 /* components of the WHOLE graph (all shards), including skipped ones */
 uint32_t povu_hip_forest_total_components(const povu_hip_forest *f);
 /* PVSTs held by this forest (this shard's components with >= 3 vertices) */
@@ -326,6 +336,9 @@ uint32_t povu_hip_last_seq_redo(const povu_hip_ctx *ctx);
  * literal hi_2 rule of flubbles.cpp:566-574 picked the second-highest reach everywhere and no hairpins were asked
  * for), 0 when it went over all tree edges */
 int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx);
+/* 1 when the last decompose ran the laminarity check of the candidate stack's (prev, i) intervals (only when the literal
+ * hi_2 rule capped differently from the second-highest reach somewhere, or with POVU_HIP_F_CHECK_LAMINAR) */
+int povu_hip_last_laminar_check_ran(const povu_hip_ctx *ctx);
 /* number of links in the components this shard processed in the last decompose */
 uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx);
 

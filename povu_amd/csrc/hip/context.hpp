@@ -55,6 +55,24 @@ struct Span { // just enough of std::vector's surface for the code below
 
 struct povu_hip_forest {
 	uint32_t total_components = 0;
+	// the pass that fills this forest: ev0 at its first kernel, ev1 behind its last copy.  `pending` while the arrays may
+	// still be on their way (POVU_HIP_F_ASYNC); every accessor calls ready() first
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool pending = false;
+	double pass_ms = -1.0;
+	bool *ctx_tail_flag = nullptr; // the context's "a tail is in flight" flag while this forest is the one in flight
+	void ready()
+	{
+		if (pending) {
+			(void)hipEventSynchronize(ev1);
+			pending = false;
+		}
+		if (ev0 && ev1 && pass_ms < 0) {
+			float ms = 0;
+			if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
+				pass_ms = ms;
+		}
+	}
 	std::shared_ptr<PinnedPool> pool;
 	void *block = nullptr;
 	size_t block_cap = 0, block_bytes = 0, total_entries = 0;
@@ -118,6 +136,12 @@ struct povu_hip_forest {
 	std::vector<ExtraBlock> extra;
 	~povu_hip_forest()
 	{
+		if (pending)
+			(void)hipEventSynchronize(ev1); // the copy engine may still be writing the block
+		if (ev0)
+			(void)hipEventDestroy(ev0);
+		if (ev1)
+			(void)hipEventDestroy(ev1);
 		release_block();
 		for (auto &b : extra)
 			if (b.p && b.pool)
@@ -170,6 +194,24 @@ struct povu_hip_ctx {
 	uint32_t shard_total_components = 0;
 	Arena shard_buf;   // a shard received from another rank
 	Arena graph_arena; // backs the resident graph
+	// the tail of the last POVU_HIP_F_ASYNC pass (side-stream kernels and copies that read the stage workspace): recorded
+	// behind it; the next pass waits for it before it touches that workspace, every other entry point before anything
+	hipEvent_t tail_done = nullptr;
+	bool tail_pending = false;
+	void wait_tail()
+	{
+		if (tail_pending) {
+			(void)hipEventSynchronize(tail_done);
+			tail_pending = false;
+		}
+	}
+	void quiesce() // debug hooks: nothing of the last pass may still be running
+	{
+		if (tail_pending) {
+			(void)hipStreamSynchronize(stream);
+			wait_tail();
+		}
+	}
 	Arena part_arena;  // the packed shards of the last povu_hip_shard_partition (kept warm: a step of a sharded job re-partitions)
 	// bytes this context moved over PCIe / to peers since it was created (povu_hip_transfer_bytes)
 	uint64_t xfer_h2d = 0, xfer_d2h = 0, xfer_peer_out = 0, xfer_peer_in = 0;

@@ -895,31 +895,37 @@ __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const
 	uint64_t pb = (uint64_t)jb + cproc_ps[c]; // dense: flubbles emitted before + one root per earlier component
 	p_parent[pb + 1 + (j - jb)] = jp == NIL ? 0u : 1 + (jp - jb);
 }
-__global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ c_ntree,
-			     const uint32_t *__restrict__ soff, const uint32_t *__restrict__ erank,
-			     const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ doff,
-			     uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
-			     uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor, uint32_t *__restrict__ c_npvst,
-			     uint32_t *__restrict__ c_nstack)
+// per component: where its PVST starts in the dense output, its size, its stack entries -- everything the host needs for
+// the forest's tree table, known as soon as the "opens a flubble" flags are ranked (before the result block exists)
+__global__ void k_pvst_counts(uint32_t C, const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ soff,
+			      const uint32_t *__restrict__ erank, const uint32_t *__restrict__ cproc_ps, uint32_t *__restrict__ doff,
+			      uint32_t *__restrict__ c_npvst, uint32_t *__restrict__ c_nstack)
 {
 	uint32_t c = BIDX * blockDim.x + threadIdx.x;
 	if (c > C)
 		return;
-	(void)voff;
-	const uint32_t first = erank[soff[c]] + cproc_ps[c];
-	doff[c] = first;
+	doff[c] = erank[soff[c]] + cproc_ps[c];
 	if (c == C)
 		return;
 	if (c_ntree[c] == 0) {
 		c_npvst[c] = 0;
 		return;
 	}
-	uint64_t pb = first;
+	c_npvst[c] = 1 + (erank[soff[c + 1]] - erank[soff[c]]);
+	c_nstack[c] = soff[c + 1] - soff[c];
+}
+// the root vertex of every PVST (flubbles.cpp:736-741)
+__global__ void k_pvst_roots(uint32_t C, const uint32_t *__restrict__ c_ntree, const uint32_t *__restrict__ doff,
+			     uint32_t *__restrict__ p_parent, uint32_t *__restrict__ p_a, uint32_t *__restrict__ p_z,
+			     uint8_t *__restrict__ p_aor, uint8_t *__restrict__ p_zor)
+{
+	uint32_t c = BIDX * blockDim.x + threadIdx.x;
+	if (c >= C || c_ntree[c] == 0)
+		return;
+	const uint64_t pb = doff[c];
 	p_parent[pb] = NIL;
 	p_a[pb] = p_z[pb] = NIL;
 	p_aor[pb] = p_zor[pb] = 0;
-	c_npvst[c] = 1 + (erank[soff[c + 1]] - erank[soff[c]]);
-	c_nstack[c] = soff[c + 1] - soff[c];
 }
 // copies of the parallel results into the per-component layout the debug hooks read
 __global__ void k_export_stack(uint32_t S, const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff,
@@ -1135,7 +1141,7 @@ void pass_summary(const SeqWs &sw, const ParWs *pw, uint32_t C, uint32_t *host_o
 
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
 		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s,
-		     const SideStream &side)
+		     const SideStream &side, PassTail &tail)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const bool want_hp = sw.hairpins != nullptr;
@@ -1305,14 +1311,31 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// ---- row G
 	tm.begin("par_pvst");
 	scan8(dflag, pw.erank, (size_t)S + 1);
-	const uint32_t NE = pw.host->read_u32(pw.erank + S, s);
+	// What the host needs to lay out the forest -- PVST size and offset of every component, the error words -- goes back in
+	// ONE read together with the PVST count: after this synchronisation only the PVST arrays themselves are still to come.
+	LAUNCH(k_pvst_counts, (size_t)C + 1, s, C, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, sw.c_npvst, sw.c_nstack);
+	uint32_t *early = pw.host->take<uint32_t>(5 * (size_t)C + 8);
+	count_kernel_d2h((5 * (size_t)C + 8) * 4);
+	pass_summary(sw, &pw, C, early, s);
+	HIP_CHECK(hipStreamSynchronize(s));
+	const size_t total = early[4 + 4 * (size_t)C + C]; // doff[C] = flubbles + one root per processed component
+	if (total < n_processed || total - n_processed > S)
+		throw HipError("internal error: PVST size out of range");
+	const uint32_t NE = (uint32_t)(total - n_processed);
 	pw.n_emitted = NE;
+	// The laminarity check only runs when the literal hi_2 rule capped differently from the second-highest reach (extra[2]),
+	// i.e. when the classes may not be the exact ones ("Row G") -- or when a caller asks for it.  Without
+	// it nothing that follows can flag a component: the summary just read is the final one.
+	pw.laminar_checked = pw.check_laminar || extra[2] != 0;
+	tail.early_summary = early;
+	tail.summary_final = !pw.laminar_checked;
+	tail.overlapped = tail.want_overlap && tail.summary_final;
 	// The five PVST arrays back to back (povu_hip_forest::alloc has the same layout).  Small results are written by the
 	// emit kernels straight into the forest's page-locked host block (no copy, no extra launch).  Large ones go
 	// through a device block of the same layout: the scattered 4- and 1-byte stores of the emit kernels make poor PCIe
-	// packets (~25 GB/s measured), the copy engine moves the finished arrays at link speed -- endpoints and
-	// orientations on the side stream while this one still works out levels and parents.
-	const size_t total = (size_t)NE + n_processed, p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
+	// packets (~25 GB/s measured), the copy engine moves the finished arrays at link speed -- all copies on the side
+	// stream: endpoints and orientations while this one still works out levels and parents, the parents behind them.
+	const size_t p4 = (total * 4 + 63) & ~size_t(63), p1 = (total + 63) & ~size_t(63);
 	char *host_blk = static_cast<char *>(alloc_result_block(total));
 	const bool staged = total >= PVST_STAGE_MIN && side.stream != nullptr;
 	if (!staged)
@@ -1324,9 +1347,9 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	pw.d_aor = reinterpret_cast<uint8_t *>(blk + 3 * p4);
 	pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
 	pw.d_total = total;
-	LAUNCH(k_pvst_roots, (size_t)C + 1, s, C, cs.voff, sw.c_ntree, pw.soff, pw.erank, pw.cproc_ps, pw.doff, pw.d_parent,
-	       pw.d_a, pw.d_z, pw.d_aor, pw.d_zor, sw.c_npvst, sw.c_nstack);
-	if (S && side.stream) {
+	LAUNCH(k_pvst_roots, (size_t)C, s, C, sw.c_ntree, pw.doff, pw.d_parent, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+	const bool use_side = S && side.stream;
+	if (use_side) {
 		HIP_CHECK(hipEventRecord(side.fork, s));
 		HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork, 0));
 		KLAUNCH(k_emit_endpoints, dim3(staged ? nblk((S + 3) / 4) : std::min<unsigned>(nblk((S + 3) / 4), 160)), dim3(TPB), 0, side.stream, S, dflag, pw.erank,
@@ -1335,7 +1358,6 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 			HIP_CHECK(copy_async(host_blk, blk, 2 * p4, hipMemcpyDeviceToHost, side.stream));
 			HIP_CHECK(copy_async(host_blk + 3 * p4, blk + 3 * p4, 2 * p1, hipMemcpyDeviceToHost, side.stream));
 		}
-		HIP_CHECK(hipEventRecord(side.join, side.stream));
 	} else if (S) {
 		KLAUNCH(k_emit_endpoints, dim3(nblk((S + 3) / 4)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
 			sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
@@ -1343,7 +1365,6 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// The (prev, i) intervals of exact cycle-equivalence classes never cross ("Row G"): the check is
 	// only needed when the literal hi_2 rule capped differently from the second-highest reach (extra[2]), i.e. when the
 	// classes may not be the exact ones -- or when a caller asks for it.
-	pw.laminar_checked = pw.check_laminar || extra[2] != 0;
 	if (pw.laminar_checked)
 		seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
 	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, pw.comp_bad, dflag, pw.walk);
@@ -1356,10 +1377,33 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
 	       pw.d_parent);
-	if (staged)
+	// the parents follow the endpoints on the side stream (the copy engine takes one array after the other anyway): the main
+	// stream ends with its last kernel
+	hipStream_t last = s;
+	if (use_side) {
+		if (staged) {
+			HIP_CHECK(hipEventRecord(side.fork2, s));
+			HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork2, 0));
+			HIP_CHECK(copy_async(host_blk + 2 * p4, blk + 2 * p4, p4, hipMemcpyDeviceToHost, side.stream));
+		}
+		HIP_CHECK(hipEventRecord(side.join, side.stream));
+		if (!tail.overlapped)
+			HIP_CHECK(hipStreamWaitEvent(s, side.join, 0)); // the pass is complete when both streams are
+		else
+			last = side.stream; // (the side stream's last work waited for the main stream's last kernel when the result is staged;
+					    //  when it is not, `done` below is recorded on both -- see the caller)
+	} else if (staged) {
 		HIP_CHECK(copy_async(host_blk + 2 * p4, blk + 2 * p4, p4, hipMemcpyDeviceToHost, s));
-	if (S && side.stream)
-		HIP_CHECK(hipStreamWaitEvent(s, side.join, 0)); // the pass is complete when both streams are
+	}
+	if (tail.done) {
+		if (tail.overlapped && !staged && use_side) { // both streams carry kernels that write the host block: join them on the side
+			HIP_CHECK(hipEventRecord(side.fork2, s));
+			HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork2, 0));
+		}
+		HIP_CHECK(hipEventRecord(tail.done, last));
+		if (tail.done2)
+			HIP_CHECK(hipEventRecord(tail.done2, last));
+	}
 	pw.n_stack = S; // export_parallel_stack copies the stack into the per-component layout when a debug hook asks
 	tm.end(12 + 3 * 22);
 }

@@ -78,6 +78,22 @@ struct ParWs {
 struct SideStream {
 	hipStream_t stream = nullptr;
 	hipEvent_t fork = nullptr, join = nullptr;
+	hipEvent_t fork2 = nullptr; // main -> side a second time: the PVST parents are ready for their copy
+};
+
+// The end of a pass (run_parallel_dg).  The pass reads everything the host needs to build the forest's tree table
+// back TOGETHER with the PVST count (one synchronisation), so nothing but the PVST arrays themselves is still in
+// flight when run_parallel_dg returns: the emit kernels and the copies of the finished arrays to the host, ALL of the
+// copies on the side stream.  `done` is recorded behind the last of them.  With want_overlap the main stream does not
+// wait for the side stream: the caller may start the next pass on it while the copy engine still moves this one's
+// result over PCIe (povu_hip_decompose: POVU_HIP_F_ASYNC).
+struct PassTail {
+	bool want_overlap = false;		 // in
+	hipEvent_t done = nullptr;		 // in: recorded when all work of the pass (kernels and copies) is complete
+	hipEvent_t done2 = nullptr;		 // in: a second event recorded at the same point (the context's own)
+	const uint32_t *early_summary = nullptr; // out: pass_summary's words in page-locked host memory, as of the PVST count
+	bool summary_final = false;		 // out: nothing after the count changes them (no laminarity check ran)
+	bool overlapped = false;		 // out: the main stream was left free (want_overlap and summary_final)
 };
 
 // groups: bit 0 = the arrays the tree stage already writes, bit 1 = those first written by the class stage (see for_each_span)
@@ -91,7 +107,7 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups
 // z_or (each padded to 64 B) for `total` PVST vertices; the emit kernels write into it.
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
 		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s,
-		     const SideStream &side);
+		     const SideStream &side, PassTail &tail);
 
 // Hairpin boundaries (`--hairpins`, flubbles.cpp:531-535, 621-656, 712-717) from the parallel class stage's
 // per-vertex flags; writes sw.hairpins / sw.c_nbry like the sequential kernels do.

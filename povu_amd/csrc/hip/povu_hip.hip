@@ -144,6 +144,8 @@ extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
 		HIP_CHECK(hipStreamCreateWithFlags(&ctx->side.stream, hipStreamNonBlocking));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.fork2, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->tail_done, hipEventDisableTiming));
 		ctx->timer.stream = ctx->stream;
 		return ctx.release();
 	} catch (const std::exception &e) {
@@ -162,6 +164,7 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	if (!ctx)
 		return;
 	(void)hipSetDevice(ctx->device);
+	ctx->wait_tail();
 	free_resident_graph(ctx->g);
 	ctx->ws.release();
 	ctx->ws2.release();
@@ -180,6 +183,10 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 		(void)hipEventDestroy(ctx->side.fork);
 	if (ctx->side.join)
 		(void)hipEventDestroy(ctx->side.join);
+	if (ctx->side.fork2)
+		(void)hipEventDestroy(ctx->side.fork2);
+	if (ctx->tail_done)
+		(void)hipEventDestroy(ctx->tail_done);
 	delete ctx;
 }
 
@@ -226,6 +233,7 @@ extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const ui
 	try {
 		if (!ctx)
 			throw HipError("null context");
+		ctx->wait_tail(); // (an overlapped pass may still be reading its workspace)
 		// the old graph (or shard) goes first, whatever happens next: a failed upload leaves the context without a graph
 		free_resident_graph(ctx->g);
 		ctx->have_state = false;
@@ -412,6 +420,7 @@ extern "C" povu_hip_components *povu_hip_componetize(povu_hip_ctx *ctx, char *er
 		if (!ctx || !ctx->g.block)
 			throw HipError("no graph resident: call povu_hip_graph_upload first");
 		HIP_CHECK(hipSetDevice(ctx->device));
+		ctx->wait_tail();
 		const ResidentGraph &g = ctx->g;
 		hipStream_t s = ctx->stream;
 		Sizes z;
@@ -511,6 +520,7 @@ extern "C" int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_li
 	try {
 		if (!ctx)
 			throw HipError("null context");
+		ctx->wait_tail();
 		if (ctx->g.block || ctx->have_state)
 			return 0; // (only for a context that holds nothing yet: a reserve invalidates what an arena holds)
 		check_graph_size(n_vtx, n_links);
@@ -582,6 +592,21 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		if (o.rank >= o.world)
 			throw HipError("shard rank >= world");
 		const bool hairpins = (o.flags & POVU_HIP_F_HAIRPINS) != 0;
+		// POVU_HIP_F_ASYNC: the pass may leave its last kernels and the copies of the PVST arrays in flight when it returns
+		// (and the next pass may then start under them).  Only the plain all-parallel pass has that form.
+		const bool want_async = (o.flags & POVU_HIP_F_ASYNC) && (o.flags & POVU_HIP_F_NO_STAGE_TIMES) && !hairpins &&
+					!(o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE | POVU_HIP_F_FORCE_REDO | POVU_HIP_F_REDO_ODD |
+						     POVU_HIP_F_LEAF_SUBFLUBBLES | POVU_HIP_F_CHECK_LAMINAR));
+		// The tail of the pass before (POVU_HIP_F_ASYNC) reads the stage workspace (ws2) from the side stream.  A pass that may
+		// itself overlap waits for it ON THE STREAM, right before its own first write there (below); every other pass -- and
+		// any pass whose arenas must grow, which frees them -- waits here.
+		auto reserve = [&](Arena &ar, size_t bytes) {
+			if (bytes > ar.capacity())
+				ctx->wait_tail();
+			ar.reserve(bytes);
+		};
+		if (!want_async)
+			ctx->wait_tail();
 
 		Sizes z;
 		z.V = g.V;
@@ -605,14 +630,17 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		LeafState leaf_state;
 		if (leaf_sub && (o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE)))
 			throw HipError("the leaf subflubble passes read the state of the parallel stages: not with the sequential tree / all-sequential test modes");
-		ctx->ws.reserve(carve_workspace(nullptr, 0, z, cs, sw, hairpins));
+		reserve(ctx->ws, carve_workspace(nullptr, 0, z, cs, sw, hairpins));
 		carve_workspace(&ctx->ws, 0, z, cs, sw, hairpins);
 
 		StageTimer &tm = ctx->timer;
 		tm.reset();
 		tm.enabled = (o.flags & POVU_HIP_F_NO_STAGE_TIMES) == 0;
-		hipEvent_t ev_all0 = tm.get(), ev_all1 = tm.get();
-		HIP_CHECK(hipEventRecord(ev_all0, s));
+		// the forest owns the two events that time its pass: ev0 at the first kernel, ev1 behind the last byte that reaches the host
+		f = std::make_unique<povu_hip_forest>();
+		HIP_CHECK(hipEventCreate(&f->ev0));
+		HIP_CHECK(hipEventCreate(&f->ev1));
+		HIP_CHECK(hipEventRecord(f->ev0, s));
 
 		// ---- row B
 		const uint32_t C = label_components(g, cs, tm, s);
@@ -628,8 +656,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		z.Cmax = C;
 		z.T = 2 * z.V + C;
 		z.B = z.E + z.V + 2 * z.T;
-		ctx->ws2.reserve(carve_workspace(nullptr, 1, z, cs, sw, hairpins) +
-				 (all_seq ? 0 : stage_workspace_bytes(z.V, z.E, C)));
+		reserve(ctx->ws2, carve_workspace(nullptr, 1, z, cs, sw, hairpins) + (all_seq ? 0 : stage_workspace_bytes(z.V, z.E, C)));
 		carve_workspace(&ctx->ws2, 1, z, cs, sw, hairpins);
 		if (!all_seq) {
 			stage_workspace_carve(ctx->ws2, ctx->pw, ctx->tw, z.V, z.E, C);
@@ -638,6 +665,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		auto need_seq_workspace = [&]() { // the one-lane kernels' lists live in their own arena
 			if (seq_ws_ready)
 				return;
+			ctx->wait_tail();
 			ctx->ws_seq.reserve(carve_workspace(nullptr, 2, z, cs, sw, hairpins));
 			carve_workspace(&ctx->ws_seq, 2, z, cs, sw, hairpins);
 			seq_ws_ready = true;
@@ -685,6 +713,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		}
 		stack_off[C] = n_stack;
 		const uint32_t n_processed = pc[C];
+		if (ctx->tail_pending) // first write into the stage workspace: behind the tail of the pass before (see above)
+			HIP_CHECK(hipStreamWaitEvent(s, ctx->tail_done, 0));
 		HIP_CHECK(copy_async(sw.tables, tab_h, 5 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
 
 		// ---- rows C-G
@@ -716,7 +746,6 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		};
 		// the result block is allocated as soon as the number of PVST vertices is known (before the emit kernel):
 		// the parallel stages write it straight into pinned host memory, there is no device-to-host copy
-		f = std::make_unique<povu_hip_forest>();
 		f->pool = ctx->pool;
 		f->meta_reserve = (size_t)C + 1; // room behind the arrays for the tree table of povu_hip_forest_share
 		auto alloc_result_block = [&](size_t total) -> void * {
@@ -727,11 +756,13 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			return dev;
 		};
 		const uint32_t *sum = nullptr; // outcome of the pass in pinned memory (pass_summary)
+		PassTail tail;
+		bool fast_tail = false; // the summary came with the PVST count: nothing was synchronised after the tail was enqueued
 		auto read_summary = [&](bool with_par) -> const uint32_t * {
 			uint32_t *h = ctx->host.take<uint32_t>(5 * (size_t)C + 8);
 			count_kernel_d2h((5 * (size_t)C + 8) * 4);
 			pass_summary(sw, with_par ? &ctx->pw : nullptr, C, h, s);
-			HIP_CHECK(hipEventRecord(ev_all1, s)); // (recorded again if more work follows)
+			HIP_CHECK(hipEventRecord(f->ev1, s)); // (recorded again if more work follows)
 			HIP_CHECK(hipStreamSynchronize(s));
 			return h;
 		};
@@ -767,12 +798,19 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			}
 			ctx->pw.all_vertex_classes = (o.flags & POVU_HIP_F_ALL_VERTEX_CLASSES) != 0;
 			ctx->pw.check_laminar = (o.flags & POVU_HIP_F_CHECK_LAMINAR) != 0;
-			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side);
+			tail.want_overlap = want_async;
+			tail.done = f->ev1;
+			tail.done2 = ctx->tail_done;
+			run_parallel_dg(cs, sw, ctx->pw, C, n_processed, n_stack, dense_nb0, alloc_result_block, tm, s, ctx->side, tail);
 			ctx->stack_export_pending = true;
 			ctx->classes_in_par = true;
 			if (o.flags & POVU_HIP_F_REDO_ODD) // (tests: flag every other component as if its stack were not laminar)
 				mark_odd_u32(ctx->pw.comp_bad, C, s);
-			sum = read_summary(true);
+			// Everything the host needs came back with the PVST count, unless something after it can still flag a component
+			// (the laminarity check, the test modes) or add to the result (labels, boundaries): then the summary is read again
+			// when all of that is done.
+			fast_tail = tail.summary_final && !leaf_sub && !hairpins && !(o.flags & (POVU_HIP_F_FORCE_REDO | POVU_HIP_F_REDO_ODD));
+			sum = fast_tail ? tail.early_summary : read_summary(true);
 			if (sum[0])
 				throw HipError("parallel class stage: a tree vertex has no live bracket (internal invariant broken)");
 			if (sum[1] & 1u)
@@ -901,7 +939,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 						HIP_CHECK(copy_async(f->hairpins.data() + 2 * t->hp_off, sw.hairpins + 2 * pb,
 									 (size_t)t->n_hairpins * 16, hipMemcpyDeviceToHost, s));
 				}
-				HIP_CHECK(hipEventRecord(ev_all1, s));
+				HIP_CHECK(hipEventRecord(f->ev1, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 			} else { // many trees: one bulk copy per array, sliced on the host
 				const size_t P = (size_t)g.V + C;
@@ -914,7 +952,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				HIP_CHECK(copy_async(ho.data(), sw.p_or, P, hipMemcpyDeviceToHost, s));
 				if (hairpins)
 					HIP_CHECK(copy_async(hh.data(), sw.hairpins, 2 * P * 8, hipMemcpyDeviceToHost, s));
-				HIP_CHECK(hipEventRecord(ev_all1, s));
+				HIP_CHECK(hipEventRecord(f->ev1, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 				for (const auto *t : ts) {
 					const size_t pb = (size_t)voff[t->component_id - 1] + (t->component_id - 1);
@@ -988,8 +1026,16 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				fetch_seq(redo, blk.a, blk.z, blk.parent, blk.aor, blk.zor, redo_total);
 				if (leaf_sub)
 					fetch_seq_sub(redo, f->extra[0].sub_ai, f->extra[0].sub_zi, f->extra[0].sub_fam, redo_total);
-			} else if (more || tm.enabled) { // (the stage events themselves have to complete before they are read)
-				HIP_CHECK(hipEventRecord(ev_all1, s));
+			} else if (fast_tail && tail.overlapped && !more) {
+				// the arrays are still on their way: the caller (or the next accessor of the forest) waits for ev1
+				f->pending = true;
+				ctx->tail_pending = true;
+			} else if (fast_tail && !more) {
+				HIP_CHECK(hipEventSynchronize(f->ev1)); // (recorded behind the last copy by run_parallel_dg)
+				if (tm.enabled)
+					HIP_CHECK(hipStreamSynchronize(s)); // (the stage events themselves have to complete before they are read)
+			} else if (more || tm.enabled || fast_tail) {
+				HIP_CHECK(hipEventRecord(f->ev1, s));
 				HIP_CHECK(hipStreamSynchronize(s));
 			}
 		} else {
@@ -1018,12 +1064,11 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			st.launches = r.launches;
 			ctx->last_times.push_back(st);
 		}
-		{
+		if (!f->pending) {
 			povu_hip_stage_time st{};
 			snprintf(st.name, sizeof st.name, "total");
-			float ms = 0;
-			HIP_CHECK(hipEventElapsedTime(&ms, ev_all0, ev_all1));
-			st.ms = ms;
+			f->ready();
+			st.ms = f->pass_ms;
 			ctx->last_times.push_back(st);
 		}
 		ctx->C = C;
@@ -1043,10 +1088,36 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 extern "C" uint32_t povu_hip_forest_total_components(const povu_hip_forest *f) { return f ? f->total_components : 0; }
 extern "C" uint32_t povu_hip_forest_tree_count(const povu_hip_forest *f) { return f ? (uint32_t)f->trees.size() : 0; }
 
+extern "C" int povu_hip_forest_wait(povu_hip_forest *f)
+{
+	if (!f)
+		return 1;
+	f->ready();
+	return 0;
+}
+extern "C" double povu_hip_forest_pass_ms(povu_hip_forest *f)
+{
+	if (!f)
+		return -1.0;
+	f->ready();
+	return f->pass_ms;
+}
+
+extern "C" double povu_hip_forest_span_ms(povu_hip_forest *first, povu_hip_forest *last)
+{
+	if (!first || !last || !first->ev0 || !last->ev1)
+		return -1.0;
+	first->ready();
+	last->ready();
+	float ms = 0;
+	return hipEventElapsedTime(&ms, first->ev0, last->ev1) == hipSuccess ? (double)ms : -1.0;
+}
+
 extern "C" int povu_hip_forest_get(const povu_hip_forest *f, uint32_t i, povu_hip_tree *out)
 {
 	if (!f || !out || i >= f->trees.size())
 		return 1;
+	const_cast<povu_hip_forest *>(f)->ready(); // (the arrays of a POVU_HIP_F_ASYNC forest may still be on their way)
 	const auto &t = f->trees[i];
 	out->component_id = t.component_id;
 	out->n_vtx = t.n_vtx;
@@ -1076,6 +1147,7 @@ extern "C" int povu_hip_forest_raw(const povu_hip_forest *f, const void **block,
 {
 	if (!f || !block || !bytes || !total || !offsets || !f->extra.empty())
 		return 1; // (a merged forest has one block per rank: no single raw view)
+	const_cast<povu_hip_forest *>(f)->ready();
 	*block = f->block;
 	*bytes = f->block_bytes;
 	*total = f->total_entries;
@@ -1277,6 +1349,7 @@ extern "C" int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, u
 {
 	if (!ctx || !ctx->have_state)
 		return 1;
+	ctx->quiesce();
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
 		const uint32_t V = ctx->g.V, C = ctx->C;
@@ -1302,6 +1375,7 @@ extern "C" int povu_hip_debug_tree(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n
 		return 1;
 	if (cls && ctx->last_mixed)
 		return 4; // classes of a mixed pass sit in two layouts (parallel stage / one-lane kernels): not exported
+	ctx->quiesce();
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
 		uint32_t voff = 0, N = 0;
@@ -1333,6 +1407,11 @@ extern "C" int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx)
 	return ctx && ctx->have_state && ctx->classes_in_par && ctx->pw.black_only_used ? 1 : 0;
 }
 
+extern "C" int povu_hip_last_laminar_check_ran(const povu_hip_ctx *ctx)
+{
+	return ctx && ctx->have_state && ctx->classes_in_par && ctx->pw.laminar_checked ? 1 : 0;
+}
+
 extern "C" int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n_tree, uint32_t *tree_edge_id)
 {
 	if (!ctx || !ctx->have_state || comp >= ctx->C || !n_tree)
@@ -1342,6 +1421,7 @@ extern "C" int povu_hip_debug_edge_ids(povu_hip_ctx *ctx, uint32_t comp, uint32_
 	if (ctx->last_mixed)
 		return 4; // (see povu_hip_debug_tree)
 	uint32_t *dw = nullptr;
+	ctx->quiesce();
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
 		uint32_t voff = 0, N = 0;
@@ -1388,6 +1468,7 @@ extern "C" int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *
 		return 1;
 	if (ctx->last_mixed)
 		return 4; // the candidate stacks of a mixed pass sit in two layouts: not exported (see povu_hip_debug_tree)
+	ctx->quiesce();
 	try {
 		HIP_CHECK(hipSetDevice(ctx->device));
 		if (ctx->stack_export_pending && ctx->last_seq_redo == 0) {

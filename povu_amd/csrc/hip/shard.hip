@@ -177,6 +177,7 @@ extern "C" povu_hip_shards *povu_hip_shard_partition(povu_hip_ctx *ctx, uint32_t
 		if (world == 0 || world > 4096)
 			throw HipError("bad world size");
 		HIP_CHECK(hipSetDevice(ctx->device));
+		ctx->wait_tail();
 		const ResidentGraph &g = ctx->g;
 		hipStream_t s = ctx->stream;
 		const uint32_t V = g.V, E = g.E;
@@ -360,6 +361,7 @@ extern "C" int povu_hip_graph_upload_shard(povu_hip_ctx *ctx, const void *packed
 		if (!ctx || !packed || bytes < 256)
 			throw HipError("bad shard");
 		HIP_CHECK(hipSetDevice(ctx->device));
+		ctx->wait_tail();
 		hipStream_t s = ctx->stream;
 		const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
 		uint64_t h[8];
@@ -591,6 +593,7 @@ extern "C" povu_hip_forest *povu_hip_forest_merge(povu_hip_ctx *ctx, const void 
 // its own forest in every gather, and what the one-process engine (multi.hip) does with every worker's forest.
 void adopt_forest(povu_hip_forest &out, povu_hip_forest &m)
 {
+	m.ready(); // (a POVU_HIP_F_ASYNC forest: its arrays must have arrived before they change hands)
 	const int base = (int)out.extra.size();
 	int own = -1;
 	if (m.block) {
@@ -648,6 +651,7 @@ extern "C" int povu_hip_forest_share(povu_hip_forest *f, uint64_t desc[8])
 	try {
 		if (!f->hairpins.empty() || !f->sub_fam.empty())
 			return 4; // (like the wire format: boundaries and labels do not travel)
+		f->ready();
 		std::fill(desc, desc + 8, 0ull);
 		desc[0] = SHARE_MAGIC;
 		desc[1] = SHARE_EMPTY;
@@ -994,6 +998,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 		try {
 			if (!mine)
 				throw HipError("gather: bad arguments");
+			const_cast<povu_hip_forest *>(mine)->ready();
 			if (!mine->hairpins.empty())
 				throw HipError("gather: hairpin boundaries do not travel");
 			if (!mine->sub_fam.empty())

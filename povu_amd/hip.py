@@ -62,6 +62,7 @@ F_REDO_ODD = 256
 F_ALL_VERTEX_CLASSES = 512
 F_CHECK_LAMINAR = 1024
 F_LEAF_SUBFLUBBLES = 2048
+F_ASYNC = 4096
 
 _lib = None
 
@@ -93,6 +94,12 @@ def load_lib():
     l.povu_hip_forest_get.restype = C.c_int
     l.povu_hip_forest_get.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Tree)]
     l.povu_hip_forest_free.argtypes = [C.c_void_p]
+    l.povu_hip_forest_wait.restype = C.c_int
+    l.povu_hip_forest_wait.argtypes = [C.c_void_p]
+    l.povu_hip_forest_pass_ms.restype = C.c_double
+    l.povu_hip_forest_pass_ms.argtypes = [C.c_void_p]
+    l.povu_hip_forest_span_ms.restype = C.c_double
+    l.povu_hip_forest_span_ms.argtypes = [C.c_void_p, C.c_void_p]
     l.povu_hip_forest_get_sub.restype = C.c_int
     l.povu_hip_forest_get_sub.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)),
                                           C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint8))]
@@ -117,6 +124,8 @@ def load_lib():
                                       C.c_void_p, C.c_void_p]
     l.povu_hip_last_black_only_classes.restype = C.c_int
     l.povu_hip_last_black_only_classes.argtypes = [C.c_void_p]
+    l.povu_hip_last_laminar_check_ran.restype = C.c_int
+    l.povu_hip_last_laminar_check_ran.argtypes = [C.c_void_p]
     l.povu_hip_debug_edge_ids.restype = C.c_int
     l.povu_hip_debug_edge_ids.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
     l.povu_hip_debug_stack.restype = C.c_int
@@ -254,6 +263,19 @@ class Forest:
         if getattr(self, "_h", None):
             self._lib.povu_hip_forest_free(self._h)
             self._h = None
+
+    def wait(self) -> "Forest":
+        """Completes a forest of a decompose with F_ASYNC (its arrays may still be on their way to the host)."""
+        self._lib.povu_hip_forest_wait(self._h)
+        return self
+
+    def pass_ms(self) -> float:
+        """HIP-event time of the pass that produced this forest: first kernel to last byte on the host (waits first)."""
+        return float(self._lib.povu_hip_forest_pass_ms(self._h))
+
+    def span_ms(self, last: "Forest") -> float:
+        """HIP-event time from this forest's first kernel to the last byte of `last` (a later pass of the same context)."""
+        return float(self._lib.povu_hip_forest_span_ms(self._h, last._h))
 
     @property
     def total_components(self) -> int:
@@ -591,6 +613,10 @@ class HipDecomposer:
     def last_black_only_classes(self) -> bool:
         """True when the last pass numbered the cycle classes of the black tree edges only (the fast path)."""
         return bool(self._lib.povu_hip_last_black_only_classes(self._ctx))
+
+    def last_laminar_check_ran(self) -> bool:
+        """True when the last pass ran the laminarity check (the literal hi_2 rule deviated somewhere, or it was forced)."""
+        return bool(self._lib.povu_hip_last_laminar_check_ran(self._ctx))
 
     def debug_edge_ids(self, comp: int):
         """Id of the tree edge into every tree vertex ([0] = 0xFFFFFFFF), Tree::add_tree_edge's shared counter."""

@@ -50,6 +50,54 @@ def test_downstream_repetitive_inputs_match_oracle(hip, golden_dir):
         assert gpu_texts(hip, g, flags=F_SEQUENTIAL) == want, p
 
 
+def test_overlapped_passes_are_bit_exact(hip, golden_dir):
+    """POVU_HIP_F_ASYNC: decompose returns when the forest is laid out; the last kernels and the copies of the PVST arrays
+    run under the next pass.  Forests of several passes in flight, uploads between them, a result large enough for the
+    staged copies, and a graph whose pass needs the laminarity check (which completes before it returns) all equal the
+    oracle / the one-pass-at-a-time result."""
+    from povu_amd.hip import F_ASYNC, F_NO_STAGE_TIMES
+    fl = F_ASYNC | F_NO_STAGE_TIMES
+    # small results (the emit kernels write straight into the page-locked block), a new graph every pass
+    graphs = [W.random_bidirected(400 + 90 * k, 700 + 130 * k, 300 + k) for k in range(6)] + [W.chain_of_bubbles(3000), W.nested_towers(40, 7)]
+    forests = []
+    for g in graphs:
+        hip.upload(g)  # (waits for the tail of the pass before: the graph arena is about to change)
+        forests.append(hip.decompose(flags=fl))
+    for g, f in zip(graphs, forests):
+        assert f.texts() == O.decompose(g)
+    # the same graph, passes back to back, nobody waits in between
+    g = W.hprc_shaped([30000, 9000, 200], seed=12, tiny=30)
+    want = O.decompose(g)
+    hip.upload(g)
+    forests = [hip.decompose(flags=fl) for _ in range(5)]
+    assert forests[-1].pass_ms() > 0 and forests[0].span_ms(forests[-1]) >= forests[-1].pass_ms()
+    for f in forests:
+        assert f.texts() == want
+    # a result of more than 2^20 PVST vertices: the arrays go through the device block and the copy engine
+    big = W.chain_of_bubbles(1_150_000)
+    hip.upload(big)
+    sync = hip.decompose(flags=F_NO_STAGE_TIMES)
+    a = json.load(open(os.path.join(golden_dir, "anchors.json")))
+    forests = [hip.decompose(flags=fl) for _ in range(3)]
+    other = hip.decompose()  # a plain pass behind overlapped ones
+    ref = sync.tree(0)
+    assert ref.a_id.size == 1_150_001
+    for f in forests + [other]:
+        t = f.tree(0)
+        for k in ("a_id", "z_id", "a_or", "z_or", "parent"):
+            assert np.array_equal(getattr(t, k), getattr(ref, k)), k
+    assert md5(sync.text(0)) == md5(O.decompose(big)[1])
+    del forests, sync, other
+    # a pass that needs the laminarity check is completed before it returns, whatever the flag says
+    z = np.load(os.path.join(golden_dir, "literal_hi2_crossing_stack.npz"))
+    bad = W.Links(z["vid"], z["v1"], z["s1"], z["v2"], z["s2"])
+    hip.upload(bad)
+    f = hip.decompose(flags=fl)
+    assert hip.last_laminar_check_ran() and hip.seq_redo_count() >= 1
+    assert f.texts() == O.decompose(bad)
+    assert a  # (anchors loaded: keeps the fixture dir in use)
+
+
 def test_lpa_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))
     g = _load_gfa_links(os.path.join(golden_dir, "gfa", "LPA.gfa"))
