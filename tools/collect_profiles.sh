@@ -13,7 +13,7 @@ for WL in hprc-wg chain; do
   else
     python3 $R/bench.py --workload $WL --no-secondary > $O/bench.json 2> $O/bench.err || exit 1
   fi
-  A="--workload $WL --no-cpu-baseline --no-secondary --steps 2 --warmup 1"   # 4 decompose passes + one upload
+  A="--workload $WL --no-cpu-baseline --no-secondary --no-overlap --no-latency-leg --steps 2 --warmup 1"   # 4 decompose passes + one upload
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py $A > $O/bench_under_rocprof.json 2> $O/kt.err || exit 2
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $A > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 3
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $A > $O/pmc_write.json 2> $O/pmc_write.err || exit 4
