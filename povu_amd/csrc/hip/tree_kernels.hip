@@ -979,46 +979,152 @@ __device__ __forceinline__ uint32_t wrec_cand(const uint4 &r0, const uint4 &r1, 
 {
 	return k == 0 ? r0.z : k == 1 ? r0.w : k == 2 ? r1.x : k == 3 ? r1.y : k == 4 ? r1.z : r1.w;
 }
+// A WINDOW of the side index space lives in LDS beside the stack: the records and the parent words of W_WIN consecutive
+// sides.  The sides of a class mostly are neighbours in the index space too (a pangenome graph is numbered along its
+// backbone), and a walk that moves on to a neighbouring index finds the candidate's visited word AND its record in LDS: no
+// round trip to memory at all.  The window is refilled, by all 64 lanes with 16-byte loads, when the walk steps outside
+// it; a class whose links lead all over the index space (the tangled workload) gets few hits per refill and backs off to
+// refilling rarely.  This wave is the only writer of the parent words of its class and mirrors every write into the
+// window, so the copy in LDS never goes stale for the sides it is asked about.
+//
+// What bounds the walk when thousands of classes are walked at once (BASELINE config 5: 3 333 classes of 4 002 sides, a
+// wave each, 13 waves per CU) is neither memory latency nor bandwidth but INSTRUCTION ISSUE: three lanes of a wave have
+// work, every instruction of the step is issued for all 64, and 13 waves share a CU's issue slots.  Measured there with a
+// cycle counter per kind of step (build with EXTRA=-DPOVU_WALK_STATS): ~1 300 cycles a step, with or without a load in it,
+// with one or three dependent LDS reads in it.  What did change the time: see the last point.  The step:
+//  * what is the same in all lanes (current side and its record, stack depth, window) lives in scalar registers (readlane);
+//  * a lane fetches the visited word AND the record of its candidate in one go (out of the window, or out of memory in one
+//    round trip): the chosen lane then holds the next step's record -- the one dependent access of a step.  On a class that
+//    is walked alone (the tangled workload: one wave, latency-bound) every further dependent LDS read cost 8 %;
+//  * the stack remembers {side, next candidate} only -- eight bytes a push; a pop fetches the record again, 64 entries at once;
+//  * no store in the step: on gfx950 a wait for ANY vector-memory result also waits for every older store of the wave
+//    (one counter, in issue order), so a store per step makes every later wait as long as a trip to memory.  The parent
+//    words written into the window go out together when the window moves on (one dirty bit per slot), and the stack
+//    spills half of its LDS cache at a time.
+static constexpr uint32_t W_WIN = 128;	// sides in the window: 4.6 KB of LDS per wave
+static constexpr uint32_t W_WIN_BACK = 16; // sides kept behind the side the window is refilled at
+__device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t lane_val(uint32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+struct URec { // a side's record in scalar registers
+	uint32_t n, begin, c0, c1, c2, c3, c4, c5;
+};
+__device__ __forceinline__ URec urec_lane(const uint4 a, const uint4 b, int l)
+{
+	return URec{lane_val(a.x, l), lane_val(a.y, l), lane_val(a.z, l), lane_val(a.w, l),
+		    lane_val(b.x, l), lane_val(b.y, l), lane_val(b.z, l), lane_val(b.w, l)};
+}
 __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const uint32_t *__restrict__ entry_list,
 							 const uint4 *__restrict__ wrec, const uint32_t *__restrict__ wadj,
 							 uint32_t *wpar, uint2 *wstk, uint32_t *__restrict__ pool_top, uint32_t pool_cap,
-							 uint32_t *__restrict__ err)
+							 uint32_t *__restrict__ err, uint32_t nS)
 {
-	__shared__ WalkStackEntry ring[64];
+	__shared__ uint4 win_rec[W_WIN][2]; // {n, overflow begin, c0, c1}, {c2 .. c5}
+	__shared__ uint32_t win_par[W_WIN];
+	__shared__ uint2 ring[64]; // the top of the stack: {side, first candidate index still to look at}
 	__shared__ uint32_t chunk_base[32];
 	const uint32_t lane = threadIdx.x;
 	if (blockIdx.x >= n_entry)
 		return;
-	uint32_t u = entry_list[blockIdx.x]; // (uniform)
-	uint4 r0 = wrec[2 * (size_t)u], r1 = wrec[2 * (size_t)u + 1];
+	uint32_t u = sgpr(entry_list[blockIdx.x]);
+	URec r;
+	{
+		const uint4 a = wrec[2 * (size_t)u], b = wrec[2 * (size_t)u + 1];
+		r = urec_lane(a, b, 0);
+	}
 	uint32_t j0 = 0;
 	uint32_t depth = 0, lds_lo = 0, n_chunks = 0; // stack entries; first entry cached in LDS; chunks taken from the pool
+	uint32_t win_lo = 0xFFFFFF00u; // (no window yet: no side id comes within W_WIN of this)
+	bool have_win = false;
+	uint32_t win_hits = 0, win_wait = 0, win_penalty = 0; // hits since the last refill; steps until the next refill is allowed
+	unsigned long long dirty0 = 0, dirty1 = 0; // window slots whose parent word is not in memory yet
+	auto flush_window = [&]() {
+		for (uint32_t k = lane; k < W_WIN; k += 64)
+			if (((k < 64 ? dirty0 >> k : dirty1 >> (k - 64)) & 1ull))
+				wpar[win_lo + k] = win_par[k];
+		dirty0 = dirty1 = 0;
+	};
+#ifdef POVU_WALK_STATS
+	uint32_t st_fast = 0, st_slow = 0, st_refill = 0, st_pop = 0;
+	const long long st_t0 = clock64();
+	long long st_mark = st_t0, cy_fast = 0, cy_slow = 0, cy_refill = 0, cy_pop = 0;
+#define WSTAT(x) (x)++
+#define WCYC(acc)                                                                                                             \
+	do {                                                                                                                  \
+		const long long now__ = clock64();                                                                            \
+		acc += now__ - st_mark;                                                                                       \
+		st_mark = now__;                                                                                              \
+	} while (0)
+#define WSTAT_DONE()                                                                                                          \
+	do {                                                                                                                  \
+		if (lane == 0 && blockIdx.x < 2)                                                                              \
+			printf("walk %u: fast %u slow %u refills %u pops %u cycles %lld = fast %lld slow %lld refill %lld pop %lld\n", blockIdx.x, st_fast, st_slow, st_refill, st_pop, \
+			       clock64() - st_t0, cy_fast, cy_slow, cy_refill, cy_pop);                                          \
+	} while (0)
+#else
+#define WSTAT(x)
+#define WCYC(acc)
+#define WSTAT_DONE()
+#endif
 	for (;;) {
-		// ---- look at the candidates [j0, j0 + 64) of u: one level for visited words and records together
-		const uint32_t n = r0.x, idx = j0 + lane;
-		uint32_t cand = NIL;
-		if (idx < n)
-			cand = n <= W_INLINE ? wrec_cand(r0, r1, idx) : wadj[r0.y + idx];
+		// ---- look at the candidates [j0, j0 + 64) of u: lane l takes candidate j0 + l -- out of the scalar record when the
+		// list is short (a handful of selects, no memory), else out of the overflow list
+		const uint32_t idx = j0 + lane;
+		uint32_t cand;
+		if (r.n <= W_INLINE) {
+			uint32_t v = r.c0;
+			v = idx == 1 ? r.c1 : v;
+			v = idx == 2 ? r.c2 : v;
+			v = idx == 3 ? r.c3 : v;
+			v = idx == 4 ? r.c4 : v;
+			v = idx == 5 ? r.c5 : v;
+			cand = idx < r.n ? v : NIL;
+		} else {
+			cand = NIL;
+			if (idx < r.n)
+				cand = __builtin_nontemporal_load(wadj + r.begin + idx);
+		}
+		// its visited word AND its record, out of the window: one LDS round trip serves this step and the next
+		const bool inw = cand - win_lo < W_WIN; // (false for NIL and while there is no window: see win_lo)
 		uint32_t vp = 0;
 		uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-		if (cand != NIL) {
-			vp = wpar[cand];
-			c0 = wrec[2 * (size_t)cand];
-			c1 = wrec[2 * (size_t)cand + 1];
+		if (inw) {
+			vp = win_par[cand - win_lo];
+			c0 = win_rec[cand - win_lo][0];
+			c1 = win_rec[cand - win_lo][1];
 		}
-		const unsigned long long m = __ballot(cand != NIL && vp == W_UNVIS);
-		const bool beyond = j0 + 64 < n; // (sides with more than 64 class neighbours: the next window)
+		// When the first unvisited candidate the window knows of has no candidate OUTSIDE the window in front of it, it is the
+		// child -- decided from LDS alone, no load is even issued.  (Whether an unvisited candidate follows it is then not known
+		// for those outside: the side is remembered on the stack as if one did, which costs a look at it on the way back.)
+		const unsigned long long miss = __ballot(cand != NIL && !inw);
+		const unsigned long long unv_in = __ballot(inw && vp == W_UNVIS);
+		const bool fast = unv_in && !(miss & ((unv_in & (0ull - unv_in)) - 1ull));
+		unsigned long long m = unv_in;
+		if (!fast && miss) { // the candidates outside the window: visited word and record in one round trip to memory
+			if (cand != NIL && !inw) {
+				vp = wpar[cand];
+				c0 = wrec[2 * (size_t)cand];
+				c1 = wrec[2 * (size_t)cand + 1];
+			}
+			m = __ballot(cand != NIL && vp == W_UNVIS);
+		}
+		if (fast)
+			WSTAT(st_fast);
+		else
+			WSTAT(st_slow);
+		const bool beyond = j0 + 64 < r.n; // (sides with more than 64 class neighbours: the next window)
 		if (m) {
 			const int f = __ffsll((long long)m) - 1;
-			const uint32_t child = __shfl(cand, f);
+			const uint32_t child = lane_val(cand, f);
+			const bool child_in = (unv_in >> f) & 1ull; // its words are in the window
 			// another unvisited candidate behind the chosen one (a second slot of the same side counts: harmless)?
-			if ((m & (m - 1)) || beyond) {
+			if ((m & (m - 1)) || beyond || (fast && (miss >> f))) {
 				const uint32_t d = depth;
 				if (d - lds_lo == 64) {
-					// the cache is full: its oldest entry moves out to the HBM array (a stack that never holds more than
-					// 64 entries -- every small class -- never touches the pool)
+					// the cache is full: its older half moves out to the HBM array, 32 entries in one store instruction (a
+					// stack that never holds more than 64 entries -- every small class -- never touches the pool); every entry
+					// finds its own chunk, the 32 may straddle two
 					const uint32_t ev = lds_lo;
-					if (ev == (n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : 0u)) { // the array grows into a new chunk
+					if (ev + 32 > (n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : 0u)) { // the array grows into a new chunk (>= 64 entries: one is enough)
 						uint32_t base = 0;
 						if (lane == 0) {
 							const uint32_t sz = n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : W_CHUNK0;
@@ -1029,32 +1135,86 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 							}
 							chunk_base[n_chunks] = base;
 						}
-						base = __shfl(base, 0);
+						base = sgpr(base);
 						if (base == NIL)
 							return; // (cannot happen: see the pool's size; the host stops the pass on err)
 						n_chunks++;
 					}
-					if (lane == 0) {
-						const WalkStackEntry &o = ring[ev & 63u];
-						wstk[wstk_addr(ev, chunk_base)] = make_uint2(o.u, o.j);
-					}
-					lds_lo = ev + 1;
+					__syncthreads(); // (one wave: lane 0 wrote the entries and the chunk table the other lanes now read)
+					if (lane < 32)
+						wstk[wstk_addr(ev + lane, chunk_base)] = ring[(ev + lane) & 63u];
+					lds_lo = ev + 32;
 				}
-				if (lane == 0) {
-					WalkStackEntry &e = ring[d & 63u];
-					e.u = u;
-					e.j = j0 + (uint32_t)f + 1u;
-					e.r0 = r0;
-					e.r1 = r1;
-				}
+				if (lane == 0)
+					ring[d & 63u] = make_uint2(u, j0 + (uint32_t)f + 1u);
 				depth = d + 1;
 			}
-			if (lane == 0)
-				wpar[child] = u;
+			const uint32_t child_par = u;
 			u = child;
-			r0.x = __shfl(c0.x, f), r0.y = __shfl(c0.y, f), r0.z = __shfl(c0.z, f), r0.w = __shfl(c0.w, f);
-			r1.x = __shfl(c1.x, f), r1.y = __shfl(c1.y, f), r1.z = __shfl(c1.z, f), r1.w = __shfl(c1.w, f);
 			j0 = 0;
+			r = urec_lane(c0, c1, f); // (the chosen lane holds the child's record: out of the window or out of memory)
+			if (child_in) { // the parent word: into the window now, into memory when the window moves on
+				const uint32_t k = child - win_lo;
+				if (lane == 0)
+					win_par[k] = child_par;
+				if (k < 64)
+					dirty0 |= 1ull << k;
+				else
+					dirty1 |= 1ull << (k - 64);
+				win_hits++;
+				WCYC(cy_fast);
+				continue;
+			}
+			if (lane == 0)
+				wpar[child] = child_par;
+			// ---- the window follows the walk
+			if (win_wait) {
+				win_wait--;
+				WCYC(cy_slow);
+				continue;
+			}
+			// few hits out of the last window: the class does not sit together in the index space, try again later
+			// (twice as much later every time, up to 1024 steps)
+			if (have_win && win_hits < 4)
+				win_penalty = min(win_penalty ? 2 * win_penalty : 8u, 1024u);
+			else
+				win_penalty = 0;
+			win_wait = win_penalty;
+			win_hits = 0;
+			WSTAT(st_refill);
+			__syncthreads(); // (one wave: the window's readers above are done)
+			// The parent words of the new window: those the old window holds come out of LDS (the only copy that is surely
+			// current: some were never written to memory), the others out of memory -- where every word this wave ever wrote
+			// outside a window, or flushed out of an earlier one, has long arrived (a wave's stores and loads of one address
+			// stay in order; an agent-scope fence here cost 50 us a refill: it writes the L2 back).
+			const uint32_t new_lo = child > W_WIN_BACK ? child - W_WIN_BACK : 0u;
+			uint32_t keep[W_WIN / 64];
+#pragma unroll
+			for (uint32_t q = 0; q < W_WIN / 64; q++) {
+				const uint32_t x = new_lo + lane + 64 * q;
+				keep[q] = (have_win && x - win_lo < W_WIN) ? win_par[x - win_lo] : NIL; // (NIL is no parent word: "not in the old window")
+			}
+			if (have_win)
+				flush_window();
+			__syncthreads();
+			win_lo = new_lo;
+			have_win = true;
+#pragma unroll
+			for (uint32_t q = 0; q < W_WIN / 64; q++) {
+				const uint32_t k = lane + 64 * q, x = win_lo + k;
+				if (x < nS) {
+					win_rec[k][0] = wrec[2 * (size_t)x];
+					win_rec[k][1] = wrec[2 * (size_t)x + 1];
+					win_par[k] = keep[q] != NIL ? keep[q] : wpar[x];
+				} else {
+					win_par[k] = 0u; // (never asked for)
+				}
+			}
+			__syncthreads();
+			if (lane == 0)
+				win_par[child - win_lo] = child_par; // (stored a moment ago: not left to the order of that store and this load)
+			__syncthreads();
+			WCYC(cy_refill);
 			continue;
 		}
 		if (beyond) {
@@ -1064,19 +1224,22 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		// ---- u is finished: back to the nearest remembered side that still has an unvisited candidate
 		bool found = false;
 		while (!found) {
-			if (depth == 0)
+			if (depth == 0) {
+				WCYC(cy_pop);
+				WSTAT_DONE();
+				if (have_win) {
+					__syncthreads();
+					flush_window();
+				}
 				return; // the class is walked
+			}
+			WSTAT(st_pop);
 			__syncthreads(); // (one wave: orders lane 0's LDS writes of the pushes before the reads below)
-			if (lds_lo >= depth) { // nothing cached: fetch the top entries (two levels per 64 pops)
+			if (lds_lo >= depth) { // nothing cached: fetch the top entries
 				const uint32_t cnt = min(depth, 64u);
 				if (lane < cnt) {
 					const uint32_t d = depth - 1 - lane;
-					const uint2 e = wstk[wstk_addr(d, chunk_base)];
-					WalkStackEntry &w = ring[d & 63u];
-					w.u = e.x;
-					w.j = e.y;
-					w.r0 = wrec[2 * (size_t)e.x];
-					w.r1 = wrec[2 * (size_t)e.x + 1];
+					ring[d & 63u] = wstk[wstk_addr(d, chunk_base)];
 				}
 				lds_lo = depth - cnt;
 				__syncthreads();
@@ -1086,15 +1249,28 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			uint32_t eu = 0, ej = 0;
 			uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
 			if (lane < cnt) {
-				const WalkStackEntry &w = ring[(depth - 1 - lane) & 63u];
-				eu = w.u, ej = w.j, e0 = w.r0, e1 = w.r1;
+				const uint2 w = ring[(depth - 1 - lane) & 63u];
+				eu = w.x, ej = w.y;
+				if (eu - win_lo < W_WIN) {
+					e0 = win_rec[eu - win_lo][0];
+					e1 = win_rec[eu - win_lo][1];
+				} else {
+					e0 = wrec[2 * (size_t)eu];
+					e1 = wrec[2 * (size_t)eu + 1];
+				}
 				if (e0.x > W_INLINE) {
 					has = true; // a long list: let the window scan above decide
 				} else {
+					// the visited words of its remaining candidates: those in the window from LDS, the others in one round trip
 					uint32_t v[W_INLINE];
 #pragma unroll
-					for (uint32_t k = 0; k < W_INLINE; k++)
-						v[k] = (k >= ej && k < e0.x) ? wpar[wrec_cand(e0, e1, k)] : 0u;
+					for (uint32_t k = 0; k < W_INLINE; k++) {
+						const uint32_t x = wrec_cand(e0, e1, k);
+						const bool want = k >= ej && k < e0.x, w_in = want && x - win_lo < W_WIN;
+						v[k] = w_in ? win_par[x - win_lo] : 0u;
+						if (want && !w_in)
+							v[k] = wpar[x];
+					}
 #pragma unroll
 					for (uint32_t k = 0; k < W_INLINE; k++)
 						has = has || v[k] == W_UNVIS;
@@ -1107,13 +1283,13 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			}
 			const int l = __ffsll((long long)hm) - 1;
 			depth -= (uint32_t)l + 1u; // the entries above it are done for good; it is re-pushed if it keeps a candidate
-			u = __shfl(eu, l);
-			j0 = __shfl(ej, l);
-			r0.x = __shfl(e0.x, l), r0.y = __shfl(e0.y, l), r0.z = __shfl(e0.z, l), r0.w = __shfl(e0.w, l);
-			r1.x = __shfl(e1.x, l), r1.y = __shfl(e1.y, l), r1.z = __shfl(e1.z, l), r1.w = __shfl(e1.w, l);
+			u = lane_val(eu, l);
+			j0 = lane_val(ej, l);
+			r = urec_lane(e0, e1, l);
 			if (lds_lo > depth)
 				lds_lo = depth;
 			found = true;
+			WCYC(cy_pop);
 		}
 	}
 }
@@ -1731,7 +1907,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		uint32_t *pool_top = pw.err + 7, *walk_err = pw.err + 8; // (cleared with the other counters at the start of the pass)
 		LAUNCH(k_class_recs, nS, s, nS, cs.loff, cs.ladj, tw.pbr, cs.ckey, tw.cproc, tw.wadj, tw.wrec, tw.wpar);
 		KLAUNCH(k_class_walk_wave, dim3(n_big), dim3(64), 0, s, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top,
-			(uint32_t)std::min<size_t>(3 * (size_t)nS, 0xFFFFFFF0u), walk_err);
+			(uint32_t)std::min<size_t>(3 * (size_t)nS, 0xFFFFFFF0u), walk_err, nS);
 		LAUNCH(k_walk_finish, nS, s, nS, tw.wpar, tw.pbr, cs.loff, cs.ladj, tw.dps);
 		if (tw.host->read_u32(walk_err, s)) // (an unfinished walk leaves a broken tree: nothing downstream may run on it)
 			throw HipError("class walk: stack pool exhausted (internal sizing bug)");
