@@ -330,7 +330,8 @@ typedef struct {
 } povu_hip_stage_time;
 /* stage timings of the last povu_hip_decompose on this context */
 int povu_hip_last_stage_times(const povu_hip_ctx *ctx, povu_hip_stage_time *out, int max);
-/* components the parallel kernels handed to the sequential redo in the last decompose */
+/* components redone by the one-lane kernels in the last decompose (only the test modes POVU_HIP_F_FORCE_REDO / _REDO_ODD
+ * send any: crossing candidate-stack intervals, the one case that used to, are resolved by the parallel stage itself) */
 uint32_t povu_hip_last_seq_redo(const povu_hip_ctx *ctx);
 /* 1 when the last decompose numbered the cycle classes of the black tree edges only (the default whenever the
  * literal hi_2 rule of flubbles.cpp:566-574 picked the second-highest reach everywhere and no hairpins were asked
@@ -339,6 +340,10 @@ int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx);
 /* 1 when the last decompose ran the laminarity check of the candidate stack's (prev, i) intervals (only when the literal
  * hi_2 rule capped differently from the second-highest reach somewhere, or with POVU_HIP_F_CHECK_LAMINAR) */
 int povu_hip_last_laminar_check_ran(const povu_hip_ctx *ctx);
+/* after a pass that ran the laminarity check: out[0] = candidate-stack entries whose (previous occurrence, this occurrence)
+ * interval holds an entry that reaches back beyond it, out[1] = those whose class had really been popped off
+ * add_flubbles' stack by then (flubbles.cpp:326-343) -- decided in place by the parallel stage, no sequential redo */
+int povu_hip_last_crossings(povu_hip_ctx *ctx, uint32_t out[2]);
 /* number of links in the components this shard processed in the last decompose */
 uint64_t povu_hip_last_links_processed(const povu_hip_ctx *ctx);
 

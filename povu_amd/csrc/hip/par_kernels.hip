@@ -745,8 +745,18 @@ __global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx,
 // component, the first step of component c also drops by B_c = 2 * (entries of the component before it) + 2: further
 // than that component's walk can have climbed or fallen, so nothing in front of c ever is the minimum again (and the
 // zero of component c is simply the walk's value at its first entry, whose own U is 0).
+//
+// CROSSING intervals (only possible when the literal hi_2 rule made the classes inexact, DESIGN.md section 4 "Row G").  The
+// machine's U at entry i is "class(i) is on its stack", i.e. the entry pushed at p = prev[i] is still there: no entry k in
+// (p, i) popped through a class that was pushed before p -- no k in (p, i) with prev[k] < p whose own class was open at k.
+// With laminar intervals no such k exists and U = "has a previous occurrence".  Otherwise the entries whose interval holds
+// a smaller prev are FLAGGED here (the range-min test), and k_resolve_crossings decides them, in stack order, one lane per
+// component: U(i) = has-prev and not crossed(i), crossed(i) = some k in (p, i) with prev[k] < p that is not itself crossed
+// (an unflagged entry with a previous occurrence is always open).  The U / D events are then the machine's own -- and they
+// are all the PVST depends on --, so such a component needs no sequential redo (until round 4 it took one: 0.66 s per
+// 10^6 segments).  tests/test_laminar_fuzz.py checks the rule against the machine on arbitrary label sequences.
 __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const SegTree segP, bool check,
-			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint32_t *__restrict__ comp_bad,
+			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint8_t *__restrict__ xflag,
 			       const uint8_t *__restrict__ dflag, uint32_t *__restrict__ walk)
 {
 	uint32_t i = BIDX * blockDim.x + threadIdx.x;
@@ -772,7 +782,47 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 		lowest = seg_min(segP, p + 1, i);
 	}
 	if (lowest < p)
-		comp_bad[s_comp[i]] = 1;
+		xflag[i] = 1; // (cleared by the caller)
+}
+// the flagged entries of every component, in stack order (xlist is ascending): crossed ones get xflag 2 and their U undone
+__global__ void k_resolve_crossings(uint32_t C, const uint32_t *__restrict__ soff, const uint32_t *__restrict__ n_x,
+				    const uint32_t *__restrict__ xlist, const uint32_t *__restrict__ prev, const SegTree segP,
+				    uint8_t *xflag, uint32_t *__restrict__ walk, uint32_t *__restrict__ n_crossed)
+{
+	const uint32_t nx = *n_x;
+	for (uint32_t c = BIDX * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+		// this component's stretch of the list
+		uint32_t lo = 0, hi = nx;
+		const uint32_t b = soff[c], e = soff[c + 1];
+		while (lo < hi) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (xlist[mid] < b)
+				lo = mid + 1;
+			else
+				hi = mid;
+		}
+		uint32_t crossed = 0;
+		for (uint32_t t = lo; t < nx; t++) {
+			const uint32_t i = xlist[t];
+			if (i >= e)
+				break;
+			const uint32_t p = prev[i];
+			for (uint32_t k = p + 1;;) {
+				k = seg_first_less(segP, k, i, p); // next entry inside (p, i) that reaches back beyond p
+				if (k == NIL)
+					break;
+				if (xflag[k] != 2) { // it was open at k (prev[k] < p: it has a previous occurrence): it popped p's entry
+					xflag[i] = 2;
+					walk[i] += 1u; // the U of entry i does not happen
+					crossed++;
+					break;
+				}
+				k++;
+			}
+		}
+		if (crossed)
+			atomicAdd(n_crossed, crossed);
+	}
 }
 // inclusive prefix sums of the walk, biased so that u32 order = int order; neg = their complement (a running
 // maximum of the complement is the running minimum of the walk)
@@ -1328,7 +1378,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// it nothing that follows can flag a component: the summary just read is the final one.
 	pw.laminar_checked = pw.check_laminar || extra[2] != 0;
 	tail.early_summary = early;
-	tail.summary_final = !pw.laminar_checked;
+	tail.summary_final = true; // (nothing after the count flags a component any more: crossings are resolved in place)
 	tail.overlapped = tail.want_overlap && tail.summary_final;
 	// The five PVST arrays back to back (povu_hip_forest::alloc has the same layout).  Small results are written by the
 	// emit kernels straight into the forest's page-locked host block (no copy, no extra launch).  Large ones go
@@ -1365,9 +1415,18 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// The (prev, i) intervals of exact cycle-equivalence classes never cross ("Row G"): the check is
 	// only needed when the literal hi_2 rule capped differently from the second-highest reach (extra[2]), i.e. when the
 	// classes may not be the exact ones -- or when a caller asks for it.
-	if (pw.laminar_checked)
+	uint8_t *xflag = pw.f8d; // [T + 32] >= S (the branching flags are long compacted)
+	if (pw.laminar_checked) {
 		seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
-	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, pw.comp_bad, dflag, pw.walk);
+		HIP_CHECK(hipMemsetAsync(xflag, 0, (size_t)S + 1, s));
+	}
+	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, xflag, dflag, pw.walk);
+	if (pw.laminar_checked && S) { // the entries whose interval is crossed: decided in stack order, U undone where the class was popped
+		uint32_t *xlist = pw.wrun, *n_x = pw.err + 11, *n_crossed = pw.err + 12; // (wrun is written by the max-scan below; err words cleared at the start of the pass)
+		compact_flagged_u8(xflag, S, xlist, n_x, pw.scan_tmp, pw.scan_tmp_bytes, s);
+		KLAUNCH(k_resolve_crossings, dim3(std::min<unsigned>(nblk(C), 1024)), dim3(TPB), 0, s, C, pw.soff, n_x, xlist, pw.prev, pw.segP, xflag,
+			pw.walk, n_crossed);
+	}
 	scan(pw.walk, pw.walk_ps, (size_t)S);
 	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
 	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them

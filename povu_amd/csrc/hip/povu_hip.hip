@@ -1407,6 +1407,19 @@ extern "C" int povu_hip_last_black_only_classes(const povu_hip_ctx *ctx)
 	return ctx && ctx->have_state && ctx->classes_in_par && ctx->pw.black_only_used ? 1 : 0;
 }
 
+extern "C" int povu_hip_last_crossings(povu_hip_ctx *ctx, uint32_t out[2])
+{
+	if (!ctx || !out)
+		return 1;
+	out[0] = out[1] = 0;
+	if (!ctx->have_state || !ctx->classes_in_par || !ctx->pw.laminar_checked)
+		return 0;
+	ctx->quiesce();
+	if (hipSetDevice(ctx->device) != hipSuccess)
+		return 2;
+	return hipMemcpy(out, ctx->pw.err + 11, 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+
 extern "C" int povu_hip_last_laminar_check_ran(const povu_hip_ctx *ctx)
 {
 	return ctx && ctx->have_state && ctx->classes_in_par && ctx->pw.laminar_checked ? 1 : 0;

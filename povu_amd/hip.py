@@ -124,6 +124,8 @@ def load_lib():
                                       C.c_void_p, C.c_void_p]
     l.povu_hip_last_black_only_classes.restype = C.c_int
     l.povu_hip_last_black_only_classes.argtypes = [C.c_void_p]
+    l.povu_hip_last_crossings.restype = C.c_int
+    l.povu_hip_last_crossings.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     l.povu_hip_last_laminar_check_ran.restype = C.c_int
     l.povu_hip_last_laminar_check_ran.argtypes = [C.c_void_p]
     l.povu_hip_debug_edge_ids.restype = C.c_int
@@ -613,6 +615,14 @@ class HipDecomposer:
     def last_black_only_classes(self) -> bool:
         """True when the last pass numbered the cycle classes of the black tree edges only (the fast path)."""
         return bool(self._lib.povu_hip_last_black_only_classes(self._ctx))
+
+    def last_crossings(self):
+        """(flagged, crossed): candidate-stack entries whose interval is crossed, and those of them whose class was no longer
+        open (povu_hip_last_crossings); (0, 0) when the laminarity check did not run."""
+        o = (C.c_uint32 * 2)()
+        if self._lib.povu_hip_last_crossings(self._ctx, o) != 0:
+            raise RuntimeError("povu_hip_last_crossings failed")
+        return int(o[0]), int(o[1])
 
     def last_laminar_check_ran(self) -> bool:
         """True when the last pass ran the laminarity check (the literal hi_2 rule deviated somewhere, or it was forced)."""

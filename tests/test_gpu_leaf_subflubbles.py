@@ -135,14 +135,14 @@ def test_config4_whole_genome_full_size(hip):
 
 
 def test_components_that_went_through_the_redo(hip, golden_dir):
-    """A component whose add_flubbles went through the sequential redo (a candidate stack with a crossing pair,
-    tests/golden/literal_hi2_crossing_stack.npz; one of the reference's own fixture graphs needs it too) has its PVST in
-    the one-lane kernels' layout: seq_pvst leaves ai / zi there and the passes label it in place."""
+    """A candidate stack with a crossing pair (tests/golden/literal_hi2_crossing_stack.npz): resolved in place by the parallel
+    stage since round 4 (no redo), labels as the oracle's; the redo path itself (seq_pvst leaves ai / zi in the one-lane
+    kernels' layout, the passes label the PVST in place) is covered by the forced modes below."""
     d = np.load(os.path.join(golden_dir, "literal_hi2_crossing_stack.npz"))
     g = W._mk(d["vid"], d["v1"], d["s1"], d["v2"], d["s2"])
     hip.upload(g)
     f = hip.decompose(flags=F_LEAF_SUBFLUBBLES)
-    assert hip.seq_redo_count() == 1
+    assert hip.seq_redo_count() == 0 and hip.last_crossings() == (1, 1)
     assert f.texts() == O.decompose(g, leaf=True)
     want = list(components(g))
     ai, zi, fam = f.sub(0)

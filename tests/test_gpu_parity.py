@@ -53,8 +53,8 @@ def test_downstream_repetitive_inputs_match_oracle(hip, golden_dir):
 def test_overlapped_passes_are_bit_exact(hip, golden_dir):
     """POVU_HIP_F_ASYNC: decompose returns when the forest is laid out; the last kernels and the copies of the PVST arrays
     run under the next pass.  Forests of several passes in flight, uploads between them, a result large enough for the
-    staged copies, and a graph whose pass needs the laminarity check (which completes before it returns) all equal the
-    oracle / the one-pass-at-a-time result."""
+    staged copies, and a graph whose pass runs the laminarity check and resolves a crossing all equal the oracle / the
+    one-pass-at-a-time result."""
     from povu_amd.hip import F_ASYNC, F_NO_STAGE_TIMES
     fl = F_ASYNC | F_NO_STAGE_TIMES
     # small results (the emit kernels write straight into the page-locked block), a new graph every pass
@@ -88,12 +88,12 @@ def test_overlapped_passes_are_bit_exact(hip, golden_dir):
             assert np.array_equal(getattr(t, k), getattr(ref, k)), k
     assert md5(sync.text(0)) == md5(O.decompose(big)[1])
     del forests, sync, other
-    # a pass that needs the laminarity check is completed before it returns, whatever the flag says
+    # a pass that runs the laminarity check (and resolves a crossing pair in place)
     z = np.load(os.path.join(golden_dir, "literal_hi2_crossing_stack.npz"))
     bad = W.Links(z["vid"], z["v1"], z["s1"], z["v2"], z["s2"])
     hip.upload(bad)
     f = hip.decompose(flags=fl)
-    assert hip.last_laminar_check_ran() and hip.seq_redo_count() >= 1
+    assert hip.last_laminar_check_ran() and hip.seq_redo_count() == 0 and hip.last_crossings()[1] >= 1
     assert f.texts() == O.decompose(bad)
     assert a  # (anchors loaded: keeps the fixture dir in use)
 
@@ -300,18 +300,32 @@ def test_laminar_check_on_demand_never_fires(hip, seed):
     assert hip.decompose().texts() == want and hip.seq_redo_count() == 0
 
 
-def test_non_laminar_stack_takes_the_redo(hip, golden_dir):
-    """The guard path on a real case (tests/test_laminar_fuzz.py::test_the_literal_hi2_rule_can_cross_intervals): the
-    literal hi_2 rule deviates, the pass numbers all tree vertices, the laminarity check runs by itself, finds the crossing
-    pair and the component goes through the sequential kernels -- bit-exact either way."""
-    from povu_amd.hip import F_CHECK_LAMINAR
+def test_non_laminar_stack_is_resolved_in_place(hip, golden_dir):
+    """A real crossing pair (tests/test_laminar_fuzz.py::test_the_literal_hi2_rule_can_cross_intervals): the literal hi_2 rule
+    deviates, the pass numbers all tree vertices, the laminarity check runs by itself, flags the entry whose interval is
+    crossed, and k_resolve_crossings finds that its class had been popped off add_flubbles' stack: its U event is dropped and
+    the closed form goes on -- bit-exact, and no component is redone by the one-lane kernels (until round 4 this one was)."""
+    from povu_amd.hip import F_CHECK_LAMINAR, F_FORCE_REDO
     d = np.load(os.path.join(golden_dir, "literal_hi2_crossing_stack.npz"))
     g = W._mk(d["vid"], d["v1"], d["s1"], d["v2"], d["s2"])
     want = O.decompose(g)
     hip.upload(g)
     for flags in (0, F_CHECK_LAMINAR):
         assert hip.decompose(flags=flags).texts() == want
-        assert hip.seq_redo_count() == 1 and not hip.last_black_only_classes()
+        assert hip.seq_redo_count() == 0 and not hip.last_black_only_classes() and hip.last_laminar_check_ran()
+        assert hip.last_crossings() == (1, 1)
+    assert hip.decompose(flags=F_FORCE_REDO).texts() == want and hip.seq_redo_count() == 1  # (the one-lane machine agrees)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_heavily_crossing_candidate_stacks(hip, seed):
+    """Tangled graphs on which the literal hi_2 rule deviates in many places: whatever the laminarity check flags is resolved
+    in place; the PVSTs equal the oracle's (which runs the literal stack machine) and nothing is redone."""
+    g = W.hprc_tangled(6000 + 900 * seed, seed=100 + seed, tangle_every=400, max_tangle=350)
+    hip.upload(g)
+    f = hip.decompose()
+    assert f.texts() == O.decompose(g)
+    assert hip.seq_redo_count() == 0
 
 
 def test_sequential_redo_of_a_million_segment_component(hip, golden_dir):
