@@ -370,10 +370,18 @@ int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t
 int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t *out, size_t n, const uint32_t *in2,
 			uint32_t *out2, size_t n2);
 
-/* device workspace (bytes) one povu_hip_decompose call reserves for a graph of this size, excluding the
- * resident graph itself (~42 B/link + 13 B/segment) and the sequential kernels' lists; n_components = 0
- * assumes the worst case (every segment its own component); 0 when it cannot be computed */
+/* device workspace (bytes) one plain povu_hip_decompose call reserves for a graph of this size whose vertices come grouped
+ * by component and that has no hub vertex (> 48 links) and no self loop -- a pangenome GFA --, excluding the resident graph
+ * itself (~42 B/link + 13 B/segment), the one-lane kernels' lists and the wave walk's arrays (44 B per side, taken by the
+ * first pass that meets a 2-edge-connected class of more than 256 sides); sides without links are assumed to number two per
+ * component and one segment in 64.  The general case: povu_hip_workspace_breakdown.  n_components = 0 assumes the worst
+ * case (every segment its own component); 0 when it cannot be computed */
 uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components);
+/* the parts of that estimate: [0] rows A/B state of a graph whose vertices come grouped by component, without hub vertices
+ * or self loops ([6]: the general case), [1] tree / result arrays all execution modes share, [2] / [3] class stage: arrays
+ * the tree stage already writes / arrays first written by the class stage, [4] / [5] tree stage: arrays that outlive it / its
+ * own.  [3] and [5] share one stretch (the larger of the two counts) */
+int povu_hip_workspace_breakdown(uint32_t n_vtx, uint32_t n_links, uint32_t n_components, uint64_t out[7]);
 /* Reserves the device memory a graph of this size will need (resident graph, CSR build scratch, decompose workspace for
  * the worst case of components) on a context that holds nothing yet, so that the first upload + decompose do not pay for
  * the allocation: meant to run on another thread while the caller still parses its input, when that takes longer than

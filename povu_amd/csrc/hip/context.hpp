@@ -169,7 +169,7 @@ struct povu_hip_ctx {
 	hipStream_t stream = nullptr;
 	SideStream side; // PCIe-bound result writes run beside the main stream's kernels
 	ResidentGraph g;
-	Arena ws, ws2, ws_seq, ws_leaf, upload_tmp;
+	Arena ws, ws_b, ws2, ws_seq, ws_leaf, ws_walk, upload_tmp; // (ws_b: what the re-index needs beyond the labelling's arrays; // (ws_walk: the wave walk's arrays, taken by the first pass that meets large classes)
 	HostScratch host;
 	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();
 	StageTimer timer;
@@ -248,5 +248,16 @@ void set_err(char *err, size_t errlen, const std::string &msg);
 struct Sizes {
 	size_t V, E, Cmax, T, B, nS, slots;
 };
+// Rows A/B in two steps (povu_hip_decompose): before the components are labelled only what the labelling writes is carved
+// (rowb_carve_label); what the re-index needs follows when the component count, the order of the vertices and the
+// builder are known (rowb_carve_reindex, from a second arena) -- a graph whose vertices already come grouped by component,
+// without hub vertices and self loops (a pangenome GFA), needs a quarter of what the general case does.
+struct RowBNeeds {
+	bool identity;	// one component, or the vertices already in (component, idx) order
+	bool sort_free; // no hub vertex: the builder that needs no sort
+	bool self_loops;
+};
+size_t rowb_carve_label(Arena *ar, const Sizes &z, CompState &cs);
+size_t rowb_carve_reindex(Arena *ar, const Sizes &z, size_t C, const RowBNeeds &need, CompState &cs);
 // Workspace carving (or just measuring when `ar` is null); part 0 = rows A/B state (CompState), see povu_hip.hip
 size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs &sw, bool hairpins);

@@ -665,21 +665,32 @@ __global__ void k_local_slots(uint32_t n, const uint32_t *__restrict__ origin, c
 	lle[k] = le | (tgray[le] ? LLE_TREE : 0u); // (here the id is the dense first-encounter rank: same order, same agreement)
 }
 
-__global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *out)
+// maximum of v[0..n); with `zeros` also the number of entries that are 0 (sides without links)
+__global__ void k_max_u32(uint32_t n, const uint32_t *__restrict__ v, uint32_t *out, uint32_t *zeros)
 {
-	__shared__ uint32_t sh[4];
-	uint32_t m = 0;
-	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-		m = max(m, v[i]);
-	for (int off = 32; off; off >>= 1)
+	__shared__ uint32_t sh[4], shz[4];
+	uint32_t m = 0, z = 0;
+	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t x = v[i];
+		m = max(m, x);
+		z += x == 0 ? 1u : 0u;
+	}
+	for (int off = 32; off; off >>= 1) {
 		m = max(m, __shfl_down(m, off));
-	if ((threadIdx.x & 63) == 0)
+		z += __shfl_down(z, off);
+	}
+	if ((threadIdx.x & 63) == 0) {
 		sh[threadIdx.x >> 6] = m;
+		shz[threadIdx.x >> 6] = z;
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
 		if (m > *(volatile uint32_t *)out) // few blocks ever need the atomic
 			atomicMax(out, m);
+		z = shz[0] + shz[1] + shz[2] + shz[3];
+		if (zeros && z)
+			atomicAdd(zeros, z);
 	}
 }
 
@@ -741,7 +752,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	uint32_t *deg = tmp_arena.take<uint32_t>(nS + 1);
 	size_t sb = sort_tmp_bytes(2 * (size_t)E), cb = scan_tmp_bytes(std::max<size_t>(nS, E) + 2);
 	void *stmp = tmp_arena.take<char>(sb), *ctmp = tmp_arena.take<char>(cb);
-	uint32_t *word = tmp_arena.take<uint32_t>(8); // [0] max vertex degree, [1] first bad link, [2] first bad tip, [3] max side degree
+	uint32_t *word = tmp_arena.take<uint32_t>(8); // [0] max vertex degree, [1] first bad link, [2] first bad tip, [3] max side degree, [4] sides without links
 	hipEvent_t ev[3];
 	for (auto &e : ev)
 		HIP_CHECK(hipEventCreate(&e));
@@ -757,7 +768,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	HIP_CHECK(hipMemsetAsync(deg, 0, (nS + 1) * 4, s));
 	HIP_CHECK(hipMemsetAsync(word, 0, 4, s));
 	HIP_CHECK(hipMemsetAsync(word + 1, 0xFF, 8, s));
-	HIP_CHECK(hipMemsetAsync(word + 3, 0, 4, s));
+	HIP_CHECK(hipMemsetAsync(word + 3, 0, 8, s));
 	if (E) {
 		KLAUNCH(k_side_degree, dim3(nblk(E)), dim3(TPB), 0, s, E, V, g.v1, g.s1, g.v2, g.s2, deg, word + 1);
 	}
@@ -766,12 +777,13 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 	}
 	scan_exclusive_u32(deg, g.off, nS + 1, ctmp, cb, s);
 	if (nS) {
-		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, deg, word + 3);
+		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, deg, word + 3, word + 4);
 	}
-	uint32_t hw[4] = {0, 0, 0, 0}; // slots, first bad link, first bad tip, most links on one side
+	uint32_t hw[5] = {0, 0, 0, 0, 0}; // slots, first bad link, first bad tip, most links on one side, sides without links
 	HIP_CHECK(copy_async(&hw[0], g.off + nS, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(copy_async(&hw[1], word + 1, 12, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&hw[1], word + 1, 16, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
+	g.n_empty_sides = hw[4];
 	if (hw[1] != POVU_NIL)
 		throw HipError("link " + std::to_string(hw[1]) + " references an unknown vertex or side");
 	if (hw[2] != POVU_NIL)
@@ -794,7 +806,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 		KLAUNCH(k_slot_other, dim3(nblk(nS)), dim3(TPB), 0, s, (uint32_t)nS, g.off, g.adj, g.v1, g.s1, g.v2, g.s2,
 				   g.aoth);
 		KLAUNCH(k_vertex_degree, dim3(nblk(V)), dim3(TPB), 0, s, V, g.off, deg);
-		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(V), 1024)), dim3(TPB), 0, s, V, deg, word);
+		KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(V), 1024)), dim3(TPB), 0, s, V, deg, word, (uint32_t *)nullptr);
 		HIP_CHECK(copy_async(&g.max_vdeg, word, 4, hipMemcpyDeviceToHost, s));
 	}
 	HIP_CHECK(hipEventRecord(ev[1], s));
@@ -906,7 +918,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg, st.hook, st.la, st.lb,
 			   st.tgray);
 	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
-	KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats);
+	KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats, (uint32_t *)nullptr);
 	scan_exclusive_u32(st.ldeg, st.loff, nS + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats, st.host_pub);
 	st.dense_edges = true; // la / lb hold the links in local edge order (povu_hip_componetize)

@@ -20,6 +20,7 @@ struct ResidentGraph {
 						    //           link; a self loop points back into its own vertex
 	uint32_t *atwin = nullptr;		    // [n_slots] the slot of the same link at its other end (itself for a same-side self loop)
 	uint32_t max_vdeg = 0;			    // most links on one vertex (both sides)
+	uint32_t n_empty_sides = 0;		    // sides without links (each may start one back edge to the root, spanning_tree.cpp:433-438)
 	// device time of the last upload, by HIP events: host-to-device copies, CSR build, reverse-slot table
 	float h2d_ms = 0, csr_ms = 0, twin_ms = 0;
 	void *block = nullptr;			    // one allocation backing all of the above
@@ -62,5 +63,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);
 uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
 			bool force_sorted_adjacency = false);
+// which builder the re-index will take for this graph (known from the upload: most links on one vertex)
+bool sort_free_adjacency(const ResidentGraph &g, bool force_sorted_adjacency);
 
 } // namespace povu_hip

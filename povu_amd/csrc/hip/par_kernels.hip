@@ -1070,7 +1070,9 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 	seg_build(pw.segH3, pw.hp3, T, s);
 	uint8_t *push = pw.f8a;
 	uint32_t *pps = pw.psA;
-	unsigned long long *b12 = (unsigned long long *)pw.b_key; // free after the class stage, >= 2T entries
+	unsigned long long *b12 = pw.hp_b12; // [2T] boundary pairs
+	if (!b12 || !pw.hpf || !pw.t_comp)
+		throw HipError("hairpin report: its arrays were not carved (internal)");
 	LAUNCH(k_hp_close, T, s, T, pw.gsize, pw.t_root, pw.t_comp, sw.c_ntree, sw.t_gid, pw.hp3, pw.segH1, pw.segH2, pw.segH3, push,
 	       b12);
 	scan_exclusive_u8(push, pps, (size_t)T + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
@@ -1081,7 +1083,7 @@ void run_parallel_hairpins(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C
 
 // ------------------------------------------------------------- workspace
 template <typename F>
-static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups, F &&take_any)
+static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups, const StageWsOpts &o, F &&take_any)
 {
 	// Group 1: what the TREE stage already writes (its tree arrays in the layout the class stage reads, the back edges, the
 	// scratch of the primitives).  Group 2: everything first written by the class stage and later -- by then the tree
@@ -1097,7 +1099,9 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups
 	};
 	// brackets: the back edges of from_bd (links outside the tree, one per side without links) and, per tree vertex, at most
 	// ONE edge of the class stage -- a capping edge needs a non-empty bracket list, a simplifying edge an empty one
-	const size_t T = 2 * V + Cmax, NB = E + V + T, S = V + 1;
+	const size_t T = 2 * V + Cmax, NB = o.nb_cap ? std::min(o.nb_cap, E + V + T) : E + V + T, S = V + 1;
+	pw.nb_cap = NB;
+	auto skip = [](auto **p) { *p = nullptr; };
 	for (uint32_t **p : {&pw.hi0, &pw.mpre, &pw.dlt, &pw.incnt, &pw.lsz})
 		take1((void **)p, (T + 2) * 4);
 	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_ord})
@@ -1108,21 +1112,29 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups
 	pw.sort_tmp_bytes = sort_tmp_bytes(std::max(std::max(T, NB), std::max(4 * V, 2 * E) + 8) + 4);
 	take1(&pw.scan_tmp, pw.scan_tmp_bytes);
 	take1(&pw.sort_tmp, pw.sort_tmp_bytes);
-	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.cov, &pw.psA,
-			     &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.dlt_ps,
-			     &pw.psin, &pw.topi, &pw.gcls, &pw.vals_t, &pw.vals_t2})
+	for (uint32_t **p : {&pw.t_comp, &pw.t_root, &pw.gpar, &pw.gsize, &pw.cov}) {
+		if (o.full_t)
+			take((void **)p, (T + 2) * 4);
+		else if (groups & 2)
+			skip(p);
+	}
+	for (uint32_t **p : {&pw.psA, &pw.psB, &pw.flagC, &pw.psC, &pw.cap_tgt, &pw.dlt_ps, &pw.psin, &pw.topi, &pw.gcls, &pw.vals_t,
+			     &pw.vals_t2})
 		take((void **)p, (T + 2) * 4);
 	for (uint8_t **p : {&pw.f8a, &pw.f8b, &pw.f8c, &pw.f8d})
 		take((void **)p, T + 32);
-	take((void **)&pw.keys_t, (T + 2) * 8);
-	take((void **)&pw.keys_t2, (T + 2) * 8);
+	take((void **)&pw.keys_t, (T + 2) * 4);
+	take((void **)&pw.keys_t2, (T + 2) * 4);
 	take((void **)&pw.dbo, (Cmax + 2) * 4);
-	for (uint32_t **p : {&pw.b_val, &pw.b_val2, &pw.tgtR})
+	for (uint32_t **p : {&pw.b_val2, &pw.tgtR})
 		take((void **)p, (NB + 2) * 4);
-	take((void **)&pw.b_key, (NB + 2) * 8);
-	take((void **)&pw.b_key2, (NB + 2) * 8);
-	for (uint32_t **p : {&pw.s_vtx, &pw.s_cls, &pw.s_comp, &pw.ns, &pw.prev, &pw.s_key, &pw.s_key2, &pw.s_val, &pw.s_val2,
-			     &pw.erank, &pw.lev, &pw.e_i})
+	for (uint32_t **p : {&pw.b_val, &pw.b_key, &pw.b_key2}) { // (the bracket sort: only behind a sequential tree stage)
+		if (o.sorted_brackets)
+			take((void **)p, (NB + 2) * 4);
+		else if (groups & 2)
+			skip(p);
+	}
+	for (uint32_t **p : {&pw.s_vtx, &pw.s_cls, &pw.s_comp, &pw.ns, &pw.prev, &pw.erank, &pw.lev, &pw.e_i})
 		take((void **)p, (S + 2) * 4);
 	take((void **)&pw.walk, (S + 4) * 4);
 	take((void **)&pw.walk_ps, (S + 4) * 4);
@@ -1134,25 +1146,33 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups
 	take((void **)&pw.segP.tree, SegTree::tree_words(S + 1) * 4);
 	take((void **)&pw.segL.tree, SegTree::tree_words(S + 1) * 4);
 	take((void **)&pw.stage, ((S + Cmax + 2) * 4 + 64) * 3 + ((S + Cmax + 2) + 64) * 2 + 256);
-	take((void **)&pw.hpf, T + 2);
-	for (uint32_t **p : {&pw.hp1, &pw.hp2, &pw.hp3})
-		take((void **)p, (T + 2) * 4);
-	take((void **)&pw.segH1.tree, SegTree::tree_words(T + 1) * 4);
-	take((void **)&pw.segH2.tree, SegTree::tree_words(T + 1) * 4);
-	take((void **)&pw.segH3.tree, SegTree::tree_words(T + 1) * 4);
+	if (o.hairpins) {
+		take((void **)&pw.hp_b12, (2 * T + 4) * 8);
+		take((void **)&pw.hpf, T + 2);
+		for (uint32_t **p : {&pw.hp1, &pw.hp2, &pw.hp3})
+			take((void **)p, (T + 2) * 4);
+		take((void **)&pw.segH1.tree, SegTree::tree_words(T + 1) * 4);
+		take((void **)&pw.segH2.tree, SegTree::tree_words(T + 1) * 4);
+		take((void **)&pw.segH3.tree, SegTree::tree_words(T + 1) * 4);
+	} else if (groups & 2) {
+		pw.hpf = nullptr;
+		pw.hp_b12 = nullptr;
+		pw.hp1 = pw.hp2 = pw.hp3 = nullptr;
+		pw.segH1.tree = pw.segH2.tree = pw.segH3.tree = nullptr;
+	}
 }
 
-size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups)
+size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups, const StageWsOpts &o)
 {
 	ParWs tmp{};
 	size_t total = 0;
-	for_each_span(tmp, V, E, Cmax, groups, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
+	for_each_span(tmp, V, E, Cmax, groups, o, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
 	return total + (1 << 20);
 }
 
-void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups)
+void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups, const StageWsOpts &o)
 {
-	for_each_span(pw, V, E, Cmax, groups, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+	for_each_span(pw, V, E, Cmax, groups, o, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
 }
 
 // ------------------------------------------------------------- driver
@@ -1271,8 +1291,12 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	pw.nb0 = NB0;
 	pw.ncap = ncap;
 	pw.nsimp = nsimp;
-	if ((size_t)NB > (size_t)sw.E + V + T) // (the bracket arrays are carved for E + V + T entries, see for_each_span)
+	if ((size_t)NB > pw.nb_cap) // (the bracket arrays are carved for that many entries, see for_each_span)
 		throw HipError("class stage: more brackets than the workspace was sized for (internal sizing bug)");
+	if (dense_nb0 < 0 && !pw.b_key)
+		throw HipError("class stage: the bracket sort's buffers were not carved for a sequential tree stage (internal)");
+	if (!lean && !pw.t_comp)
+		throw HipError("class stage: the per-vertex tables were not carved (internal)");
 	// Classes of the black tree edges only (the candidate stack holds no others: half the vertices to look up, sort and
 	// number).  Per top bracket the reference walks ALL vertices that have it on top, deepest first, and opens a class
 	// whenever the list size differs from the one before (recent_size, flubbles.cpp:668-676); leaving the gray edges'
@@ -1290,14 +1314,14 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		LAUNCH(k_bracket_place, NB, s, NB, NB0, ncap, pw.b_src, pw.b_tgt, pw.b_ord, pw.mpre, bstart, capf, simp, pw.tgtR,
 		       pw.b_val2);
 	} else {
-		uint32_t *bk = (uint32_t *)pw.b_key, *bk2 = (uint32_t *)pw.b_key2;
+		uint32_t *bk = pw.b_key, *bk2 = pw.b_key2;
 		LAUNCH(k_bracket_order, NB, s, NB, NB0, ncap, nsimp, pw.b_src, pw.b_tgt, pw.mpre, bk, pw.b_val, pw.incnt, srccnt);
 		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
 		sort_pairs_u32(bk, bk2, pw.b_val, pw.b_val2, NB, bits_for(T), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		LAUNCH(k_gather_u32, NB, s, NB, pw.b_val2, pw.b_tgt, pw.tgtR);
 	}
 	seg_build(pw.segB, pw.tgtR, NB, s);
-	uint32_t *ck = (uint32_t *)pw.keys_t, *ck2 = (uint32_t *)pw.keys_t2;
+	uint32_t *ck = pw.keys_t, *ck2 = pw.keys_t2;
 	const uint32_t NC = black_only ? V : T; // vertices that get a class
 	const uint32_t S = n_stack;
 	uint8_t *cflag = pw.f8a; // bridge flags are dead by now
@@ -1474,7 +1498,7 @@ static void stack_class_ids(ParWs &pw, hipStream_t s)
 		return;
 	const uint32_t V = pw.V;
 	scan_exclusive_u8(pw.f8a, pw.psA, (size_t)V + 1, nullptr, nullptr, 0, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	LAUNCH(k_class_ids_black, V, s, V, (const uint32_t *)pw.keys_t2, pw.vals_t2, pw.f8a, pw.psA, pw.s_cls);
+	LAUNCH(k_class_ids_black, V, s, V, pw.keys_t2, pw.vals_t2, pw.f8a, pw.psA, pw.s_cls);
 	pw.s_cls_valid = true;
 }
 void classes_to_tree_space(ParWs &pw, hipStream_t s)

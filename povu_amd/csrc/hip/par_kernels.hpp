@@ -43,15 +43,15 @@ struct ParWs {
 	uint8_t *f8a, *f8b, *f8c, *f8d; // [T+1] one-byte flags (bridge / simplifying / capping / branching vertex, class and stack flags)
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
 	uint32_t *vals_t, *vals_t2;
-	uint64_t *keys_t, *keys_t2; // [T]
+	uint32_t *keys_t, *keys_t2; // [T]
 	// dense back edges / brackets
 	uint32_t *dbo;			 // [C+1]
 	uint32_t *b_src, *b_tgt, *b_val, *b_val2, *tgtR, *b_ord; // [NBmax]; b_ord = rank among the source's ordinary edges, bottom first
-	uint64_t *b_key, *b_key2;	 // [NBmax]
+	uint32_t *b_key, *b_key2;	 // [NBmax] (only behind a sequential tree stage)
+	size_t nb_cap = 0;		 // entries the bracket arrays were carved for
 	// candidate stack space
 	uint32_t *s_vtx, *s_cls, *s_comp, *ns, *prev; // [V+1]
 	uint32_t *soff;				     // [C+1] first stack entry of a component (host-built table, set by the caller)
-	uint32_t *s_key, *s_key2, *s_val, *s_val2;
 	uint32_t *walk, *walk_ps, *wrun; // [V+2] steps of the stack machine (one per entry), their prefix sums, running minimum (complemented)
 	uint32_t *erank, *lev, *e_i;	 // [V+1]
 	uint32_t *comp_bad;		 // [C+1] components that must be redone sequentially
@@ -69,6 +69,7 @@ struct ParWs {
 	// --hairpins on the parallel path
 	uint8_t *hpf;			 // [T] bit0 simplifying vertex, bit1 top bracket is a simplifying edge
 	uint32_t *hp1, *hp2, *hp3;	 // [T+1] segment-tree inputs / push flags
+	unsigned long long *hp_b12;	 // [2T] boundary pairs before they are compacted
 	SegTree segH1, segH2, segH3;
 	void *scan_tmp, *sort_tmp;
 	size_t scan_tmp_bytes, sort_tmp_bytes;
@@ -96,9 +97,18 @@ struct PassTail {
 	bool overlapped = false;		 // out: the main stream was left free (want_overlap and summary_final)
 };
 
+// What a pass will NOT need is not carved (the arrays' pointers are then null): the default is everything.
+struct StageWsOpts {
+	size_t nb_cap = 0;	     // brackets the pass can have at most (0: the loose bound E + V + T)
+	bool full_t = true;	     // per-vertex component / root / parent / size tables: a sequential tree stage or the hairpin report
+	bool sorted_brackets = true; // keys of the bracket sort: only behind a sequential tree stage
+	bool hairpins = true;	     // the hairpin report's arrays
+	bool walk_inline = true;     // the wave walk's records / stack pool / parents inside the tree stage's block (else taken from
+				     // TreeWs::walk_arena when a pass has large classes)
+};
 // groups: bit 0 = the arrays the tree stage already writes, bit 1 = those first written by the class stage (see for_each_span)
-size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups = 3);
-void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups = 3);
+size_t par_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups = 3, const StageWsOpts &o = StageWsOpts{});
+void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups = 3, const StageWsOpts &o = StageWsOpts{});
 
 // Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
 // left in `sw`.  Components whose candidate stack is not laminar are flagged in pw.comp_bad (see pass_summary).

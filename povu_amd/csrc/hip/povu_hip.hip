@@ -169,6 +169,8 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 	ctx->ws.release();
 	ctx->ws2.release();
 	ctx->ws_seq.release();
+	ctx->ws_walk.release();
+	ctx->ws_b.release();
 	ctx->upload_tmp.release();
 	ctx->shard_buf.release();
 	ctx->graph_arena.release();
@@ -405,6 +407,86 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 	return total + (1 << 20);
 }
 
+size_t rowb_carve_label(Arena *ar, const Sizes &z, CompState &cs)
+{
+	size_t total = 0;
+	auto take = [&](auto **dst, size_t n, size_t elem) {
+		total += Arena::padded(n, elem) + 256;
+		if (ar) {
+			using P = std::remove_reference_t<decltype(*dst)>;
+			*dst = reinterpret_cast<P>(ar->take<char>(n * elem));
+		}
+	};
+	const size_t V = z.V, E = z.E;
+	take(&cs.label, V + 1, 4);
+	take(&cs.flag, V / 4 + 16, 4); // (one byte per vertex: is-root flags)
+	take(&cs.crank, V + 2, 4);
+	take(&cs.comp_of, V + 1, 4);
+	take(&cs.keys, 2 * E + 2, 4); // the cross list of the union-find tiles: [E] pairs
+	take(&cs.hook, E + 32, 1);
+	take(&cs.stats, 16, 4);
+	cs.scan_tmp_bytes = scan_tmp_bytes(std::max<size_t>(z.nS, z.slots) + 2);
+	take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);
+	if (ar) { // (what rowb_carve_reindex adds; null until then so that a use before it is a clean failure, not a stale pointer)
+		cs.tmp_a = cs.ckey = cs.perm = cs.pos = cs.voff = cs.eoff = cs.vdeg = cs.sbase = cs.first = cs.erank = cs.ldeg = cs.loff =
+			cs.ladj = cs.vals = cs.keys2 = cs.vals2 = cs.la = cs.lb = cs.lle = cs.gid_s = nullptr;
+		cs.tgray = cs.tip_s = nullptr;
+		cs.start_key = nullptr;
+		cs.sort_tmp = nullptr;
+		cs.sort_tmp_bytes = 0;
+	}
+	return total + (1 << 16);
+}
+
+size_t rowb_carve_reindex(Arena *ar, const Sizes &z, size_t C, const RowBNeeds &need, CompState &cs)
+{
+	size_t total = 0;
+	auto take = [&](auto **dst, size_t n, size_t elem) {
+		total += Arena::padded(n, elem) + 256;
+		if (ar) {
+			using P = std::remove_reference_t<decltype(*dst)>;
+			*dst = reinterpret_cast<P>(ar->take<char>(n * elem));
+		}
+	};
+	const size_t V = z.V, E = z.E, nS = z.nS;
+	const bool lean = need.identity && need.sort_free; // sorted space = global vertex space, nothing is renumbered
+	take(&cs.voff, C + 2, 4);
+	take(&cs.eoff, C + 2, 4);
+	take(&cs.start_key, C + 2, 8);
+	take(&cs.ladj, 2 * E + 8, 4); // (+8: the class walk reads a side's list words four at a time)
+	take(&cs.lle, 2 * E + 8, 4);  // (+8: the tour kernel reads a segment's slot words four at a time)
+	if (!lean) { // the vertices are renumbered (or the sorting builder wants the tables anyway)
+		take(&cs.tmp_a, V + 1, 4);
+		take(&cs.ckey, V + 1, 4);
+		take(&cs.perm, V + 1, 4);
+		take(&cs.pos, V + 1, 4);
+		take(&cs.vdeg, V + 2, 4);
+		take(&cs.sbase, V + 2, 4);
+		take(&cs.gid_s, V + 1, 4);
+		take(&cs.tip_s, V + 1, 1);
+	}
+	if (!(lean && !need.self_loops)) { // local degrees and offsets of the sides (else the CSR's own)
+		take(&cs.ldeg, nS + 2, 4);
+		take(&cs.loff, nS + 2, 4);
+	}
+	if (!need.sort_free) { // the builder that numbers the local edges densely (hub vertices; povu_hip_componetize takes the full set)
+		take(&cs.flag, std::max(V, z.slots) + 2, 4);
+		take(&cs.first, E + 1, 4);
+		take(&cs.erank, z.slots + 2, 4);
+		take(&cs.vals, 2 * E + 2, 4);
+		take(&cs.keys2, 2 * E + 2, 4);
+		take(&cs.vals2, 2 * E + 2, 4);
+		take(&cs.la, E + 2, 4);
+		take(&cs.lb, E + 2, 4);
+		take(&cs.tgray, E + 32, 1);
+	}
+	if (!need.identity || !need.sort_free) {
+		cs.sort_tmp_bytes = sort_tmp_bytes(std::max<size_t>(2 * E, V) + 2);
+		take((char **)&cs.sort_tmp, cs.sort_tmp_bytes, 1);
+	}
+	return total + (1 << 16);
+}
+
 namespace
 {
 struct ComponentsOwner {
@@ -487,6 +569,23 @@ extern "C" void povu_hip_components_free(povu_hip_components *c)
 	delete reinterpret_cast<ComponentsOwner *>(c);
 }
 
+// What the stage workspace of a pass has to hold (par_kernels.hpp: StageWsOpts).  The plain all-parallel pass needs neither
+// the per-vertex tables of a sequential tree stage, nor the keys of its bracket sort, nor the hairpin report's arrays, and
+// takes the wave walk's arrays only when it meets large classes.  Brackets: every link outside the spanning forest of
+// the segments starts at most one back edge (E - (V - C) of them), every side without links at most one to the root
+// (spanning_tree.cpp:433-438), and the class stage adds at most one capping or simplifying edge per tree vertex.
+static StageWsOpts stage_opts(size_t V, size_t E, size_t C, size_t empty_sides, bool seq_tree, bool hairpins)
+{
+	StageWsOpts o;
+	const size_t T = 2 * V + C;
+	o.nb_cap = std::min(E + V + T, (E + C > V ? E + C - V : 0) + empty_sides + T + 64);
+	o.full_t = seq_tree || hairpins;
+	o.sorted_brackets = seq_tree;
+	o.hairpins = hairpins;
+	o.walk_inline = false;
+	return o;
+}
+
 extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links, uint32_t n_components)
 {
 	try {
@@ -499,14 +598,47 @@ extern "C" uint64_t povu_hip_workspace_estimate(uint32_t n_vtx, uint32_t n_links
 		SeqWs sw{};
 		z.Cmax = n_vtx;
 		z.T = z.B = 0;
-		uint64_t total = carve_workspace(nullptr, 0, z, cs, sw, false);
+		// (rows A/B of a graph whose vertices come grouped by component, without hub vertices or self loops: the pangenome
+		// case; povu_hip_workspace_breakdown's out[6] has the general case)
+		const RowBNeeds lean{true, true, false};
+		uint64_t total = rowb_carve_label(nullptr, z, cs) + rowb_carve_reindex(nullptr, z, n_components ? n_components : n_vtx, lean, cs);
 		z.Cmax = n_components ? n_components : n_vtx;
 		z.T = 2 * z.V + z.Cmax;
 		z.B = z.E + z.V + 2 * z.T;
-		total += carve_workspace(nullptr, 1, z, cs, sw, false) + stage_workspace_bytes(z.V, z.E, z.Cmax);
+		// (sides without links: two per component and a few more -- an estimate; a graph full of tips reserves more)
+		total += carve_workspace(nullptr, 1, z, cs, sw, false) +
+			 stage_workspace_bytes(z.V, z.E, z.Cmax, stage_opts(z.V, z.E, z.Cmax, 2 * z.Cmax + z.V / 64, false, false));
 		return total;
 	} catch (...) {
 		return 0;
+	}
+}
+
+extern "C" int povu_hip_workspace_breakdown(uint32_t n_vtx, uint32_t n_links, uint32_t n_components, uint64_t out[7])
+{
+	try {
+		Sizes z;
+		z.V = n_vtx, z.E = n_links, z.nS = 2 * z.V, z.slots = 2 * z.E;
+		CompState cs{};
+		SeqWs sw{};
+		z.Cmax = n_vtx;
+		z.T = z.B = 0;
+		const RowBNeeds lean{true, true, false}, general{false, false, true};
+		const size_t Cn = n_components ? n_components : n_vtx;
+		out[0] = rowb_carve_label(nullptr, z, cs) + rowb_carve_reindex(nullptr, z, Cn, lean, cs);
+		out[6] = rowb_carve_label(nullptr, z, cs) + rowb_carve_reindex(nullptr, z, Cn, general, cs);
+		z.Cmax = Cn;
+		z.T = 2 * z.V + z.Cmax;
+		z.B = z.E + z.V + 2 * z.T;
+		out[1] = carve_workspace(nullptr, 1, z, cs, sw, false);
+		const StageWsOpts so = stage_opts(z.V, z.E, z.Cmax, 2 * z.Cmax + z.V / 64, false, false);
+		out[2] = par_workspace_bytes(z.V, z.E, z.Cmax, 1, so);
+		out[3] = par_workspace_bytes(z.V, z.E, z.Cmax, 2, so);
+		out[4] = tree_workspace_bytes(z.V, z.E, z.Cmax, 1, so);
+		out[5] = tree_workspace_bytes(z.V, z.E, z.Cmax, 2, so);
+		return 0;
+	} catch (...) {
+		return 1;
 	}
 }
 
@@ -538,18 +670,20 @@ extern "C" int povu_hip_prewarm(povu_hip_ctx *ctx, uint32_t n_vtx, uint32_t n_li
 		z.V = V, z.E = E, z.nS = nS, z.slots = 2 * E, z.Cmax = V, z.T = z.B = 0; // (rows A/B are sized before the count is known)
 		CompState cs{};
 		SeqWs sw{};
-		const size_t ws_b = carve_workspace(nullptr, 0, z, cs, sw, false);
 		z.Cmax = std::min<size_t>(V, std::max<size_t>(1024, V / 64));
+		const size_t ws_b = rowb_carve_label(nullptr, z, cs), ws_b2 = rowb_carve_reindex(nullptr, z, z.Cmax, RowBNeeds{true, true, false}, cs);
 		z.T = 2 * V + z.Cmax;
 		z.B = E + V + 2 * z.T;
-		const size_t ws2_b = carve_workspace(nullptr, 1, z, cs, sw, false) + stage_workspace_bytes(V, E, z.Cmax);
-		const size_t need = graph_b + tmp_b + ws_b + ws2_b;
+		const size_t ws2_b = carve_workspace(nullptr, 1, z, cs, sw, false) +
+				     stage_workspace_bytes(V, E, z.Cmax, stage_opts(V, E, z.Cmax, 2 * z.Cmax + V / 64, false, false));
+		const size_t need = graph_b + tmp_b + ws_b + ws_b2 + ws2_b;
 		if (need + need / 8 + (size_t(64) << 20) > free_b)
 			return 0; // the worst case does not fit beside what is there: let the real calls size things
 		// (exact sizes: a context that is warmed for one graph is usually there for that graph only)
 		ctx->graph_arena.reserve(graph_b, false);
 		ctx->upload_tmp.reserve(tmp_b, false);
 		ctx->ws.reserve(ws_b, false);
+		ctx->ws_b.reserve(ws_b2, false);
 		ctx->ws2.reserve(ws2_b, false);
 		return 0;
 	} catch (const std::exception &e) {
@@ -630,8 +764,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		LeafState leaf_state;
 		if (leaf_sub && (o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE)))
 			throw HipError("the leaf subflubble passes read the state of the parallel stages: not with the sequential tree / all-sequential test modes");
-		reserve(ctx->ws, carve_workspace(nullptr, 0, z, cs, sw, hairpins));
-		carve_workspace(&ctx->ws, 0, z, cs, sw, hairpins);
+		reserve(ctx->ws, rowb_carve_label(nullptr, z, cs));
+		rowb_carve_label(&ctx->ws, z, cs);
 
 		StageTimer &tm = ctx->timer;
 		tm.reset();
@@ -644,6 +778,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 
 		// ---- row B
 		const uint32_t C = label_components(g, cs, tm, s);
+		{ // what the re-index of THIS graph needs, now that the count, the order and the self loops are known
+			const bool force_sorted = (o.flags & POVU_HIP_F_SORTED_ADJ) != 0;
+			const RowBNeeds need{C == 1 || cs.comp_sorted, sort_free_adjacency(g, force_sorted), cs.has_self_loops};
+			reserve(ctx->ws_b, rowb_carve_reindex(nullptr, z, C, need, cs));
+			rowb_carve_reindex(&ctx->ws_b, z, C, need, cs);
+		}
 		// component sizes on the host (shard assignment = LPT over link counts, launch order): the last
 		// re-index kernel writes them into pinned memory itself
 		uint32_t *pub = ctx->host.take<uint32_t>(2 * ((size_t)C + 1) + 4);
@@ -656,10 +796,12 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		z.Cmax = C;
 		z.T = 2 * z.V + C;
 		z.B = z.E + z.V + 2 * z.T;
-		reserve(ctx->ws2, carve_workspace(nullptr, 1, z, cs, sw, hairpins) + (all_seq ? 0 : stage_workspace_bytes(z.V, z.E, C)));
+		const StageWsOpts so = stage_opts(z.V, z.E, C, g.n_empty_sides, (o.flags & POVU_HIP_F_SEQ_TREE) != 0, hairpins);
+		reserve(ctx->ws2, carve_workspace(nullptr, 1, z, cs, sw, hairpins) + (all_seq ? 0 : stage_workspace_bytes(z.V, z.E, C, so)));
 		carve_workspace(&ctx->ws2, 1, z, cs, sw, hairpins);
 		if (!all_seq) {
-			stage_workspace_carve(ctx->ws2, ctx->pw, ctx->tw, z.V, z.E, C);
+			stage_workspace_carve(ctx->ws2, ctx->pw, ctx->tw, z.V, z.E, C, so);
+			ctx->tw.walk_arena = &ctx->ws_walk;
 		}
 		bool seq_ws_ready = false;
 		auto need_seq_workspace = [&]() { // the one-lane kernels' lists live in their own arena

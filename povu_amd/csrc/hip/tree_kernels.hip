@@ -1574,7 +1574,8 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 						     const uint32_t *__restrict__ t_par, uint32_t *__restrict__ total_out,
 						     uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
 						     uint32_t *__restrict__ b_ord, const uint8_t *__restrict__ dupflag,
-						     uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0, uint32_t *__restrict__ incnt)
+						     uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0, uint32_t *__restrict__ incnt,
+						     uint32_t cap)
 {
 	const uint32_t S0 = BIDX * BE_SIDES + threadIdx.x;
 	__shared__ uint32_t first2[BE_ITER][TPB][2]; // the first two targets of every side of the chunk
@@ -1617,7 +1618,7 @@ __global__ void __launch_bounds__(TPB) k_back_edges(uint32_t nS, const uint32_t 
 	if (threadIdx.x == 0)
 		base = all ? atomicAdd(total_out, all) : 0u;
 	__syncthreads();
-	if (!n)
+	if (!n || base + all > cap) // (more back edges than the list was carved for cannot happen -- the host checks the total --, and must not write)
 		return;
 	uint32_t at = base + before + inc - n;
 	for (uint32_t it = 0; it < BE_ITER; it++) {
@@ -1743,7 +1744,7 @@ __global__ void k_dup_flags(uint32_t n, const uint32_t *__restrict__ skey, const
 
 // ------------------------------------------------------------------ workspace
 template <typename F>
-static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, F &&take_any)
+static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, const StageWsOpts &o, F &&take_any)
 {
 	// Group 1: what outlives the tree stage (the debug hook that recomputes the edge-id weights after a pass reads the DFS
 	// records, the tree index of every side and the duplicate-slot flags).  Group 2: the rest -- dead once the class stage
@@ -1770,7 +1771,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, 
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.entry_flag, nS + 16);
-	take((void **)&tw.wadj, (nS + 2 * E + 8) * 8); // wave walk: class-filtered scan lists (4 bytes a slot); earlier in the pass: twin slots [2E]
+	take((void **)&tw.wadj, (nS + 2 * E + 8) * 4); // wave walk: class-filtered scan lists (4 bytes a slot); earlier in the pass: twin slots [2E]
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	take((void **)&tw.rk_pk, NSL * 4);
 	take((void **)&tw.rk_heads, (Cmax + 2) * 4);
@@ -1787,48 +1788,65 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, 
 	const size_t wstk_b = pad(3 * nS * 8 + 64); // stack pool: chunks double in size, a class takes less than three entries per side
 	const size_t wpar_b = pad(nS * 4);
 	char *blk = nullptr;
-	take((void **)&blk, std::max(6 * pool_b + 2 * xv_b, wrec_b + wstk_b + wpar_b));
+	// (the walk's third of it is 12 GB on the whole-genome workload against 9 for the other two, and most graphs never need
+	// it: with !walk_inline it comes out of an arena of its own when a pass does have large classes)
+	take((void **)&blk, o.walk_inline ? std::max(6 * pool_b + 2 * xv_b, wrec_b + wstk_b + wpar_b) : 6 * pool_b + 2 * xv_b);
+	if (groups & 2)
+		tw.walk_inline = o.walk_inline;
 	if (blk) {
 		uint32_t **pools[6] = {&tw.rk_nx, &tw.rk_wa, &tw.rk_wb, &tw.rk_tA, &tw.rk_tB, &tw.rk_tC};
 		for (int k = 0; k < 6; k++)
 			*pools[k] = reinterpret_cast<uint32_t *>(blk + (size_t)k * pool_b);
 		tw.xval = reinterpret_cast<decltype(tw.xval)>(blk + 6 * pool_b);
 		tw.xps = reinterpret_cast<decltype(tw.xps)>(blk + 6 * pool_b + xv_b);
-		tw.wrec = reinterpret_cast<decltype(tw.wrec)>(blk);
-		tw.wstk = reinterpret_cast<decltype(tw.wstk)>(blk + wrec_b);
-		tw.wpar = reinterpret_cast<decltype(tw.wpar)>(blk + wrec_b + wstk_b);
+		if (o.walk_inline) {
+			tw.wrec = reinterpret_cast<decltype(tw.wrec)>(blk);
+			tw.wstk = reinterpret_cast<decltype(tw.wstk)>(blk + wrec_b);
+			tw.wpar = reinterpret_cast<decltype(tw.wpar)>(blk + wrec_b + wstk_b);
+		} else {
+			tw.wrec = nullptr;
+			tw.wstk = nullptr;
+			tw.wpar = nullptr;
+		}
 	}
 }
 
-size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups)
+size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups, const StageWsOpts &o)
 {
 	TreeWs tmp{};
 	size_t total = 0;
-	tree_spans(tmp, V, E, Cmax, groups, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
+	tree_spans(tmp, V, E, Cmax, groups, o, [&](void **, size_t bytes) { total += ((bytes + 255) & ~size_t(255)) + 256; });
 	return total + (1 << 20);
 }
 
-void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups)
+void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, const StageWsOpts &o)
 {
-	tree_spans(tw, V, E, Cmax, groups, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+	tree_spans(tw, V, E, Cmax, groups, o, [&](void **dst, size_t bytes) { *dst = ar.take<char>(bytes); });
+}
+
+size_t walk_workspace_bytes(size_t V)
+{
+	const size_t nS = 2 * V + 2;
+	auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+	return pad(nS * 32) + pad(3 * nS * 8 + 64) + pad(nS * 4) + 4096;
 }
 
 // The workspace of the parallel stages: what the tree stage hands to the class stage and what outlives the tree stage side
 // by side; then ONE stretch that holds the tree stage's own arrays first and the class stage's afterwards.
-size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax)
+size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax, const StageWsOpts &o)
 {
-	return par_workspace_bytes(V, E, Cmax, 1) + tree_workspace_bytes(V, E, Cmax, 1) +
-	       std::max(tree_workspace_bytes(V, E, Cmax, 2), par_workspace_bytes(V, E, Cmax, 2));
+	return par_workspace_bytes(V, E, Cmax, 1, o) + tree_workspace_bytes(V, E, Cmax, 1, o) +
+	       std::max(tree_workspace_bytes(V, E, Cmax, 2, o), par_workspace_bytes(V, E, Cmax, 2, o));
 }
-void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax)
+void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax, const StageWsOpts &o)
 {
-	par_carve(ar, pw, V, E, Cmax, 1);
-	tree_carve(ar, tw, V, E, Cmax, 1);
+	par_carve(ar, pw, V, E, Cmax, 1, o);
+	tree_carve(ar, tw, V, E, Cmax, 1, o);
 	const size_t shared = ar.used();
-	tree_carve(ar, tw, V, E, Cmax, 2);
+	tree_carve(ar, tw, V, E, Cmax, 2, o);
 	const size_t tree_end = ar.used();
 	ar.rewind(shared);
-	par_carve(ar, pw, V, E, Cmax, 2);
+	par_carve(ar, pw, V, E, Cmax, 2, o);
 	ar.advance_to(tree_end);
 }
 
@@ -1904,6 +1922,15 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		big_list = over_list;
 	}
 	if (n_big) { // large classes: one wave each (see section 6)
+		if (!tw.walk_inline) { // the records of all sides, the stack pool and the parents: taken when a pass needs them
+			if (!tw.walk_arena)
+				throw HipError("class walk: no arena for the wave walk's arrays (internal)");
+			const size_t nSw = 2 * (size_t)V + 2;
+			tw.walk_arena->reserve(walk_workspace_bytes(V));
+			tw.wrec = reinterpret_cast<decltype(tw.wrec)>(tw.walk_arena->take<char>(nSw * 32));
+			tw.wstk = reinterpret_cast<decltype(tw.wstk)>(tw.walk_arena->take<char>(3 * nSw * 8 + 64));
+			tw.wpar = reinterpret_cast<decltype(tw.wpar)>(tw.walk_arena->take<char>(nSw * 4));
+		}
 		uint32_t *pool_top = pw.err + 7, *walk_err = pw.err + 8; // (cleared with the other counters at the start of the pass)
 		LAUNCH(k_class_recs, nS, s, nS, cs.loff, cs.ladj, tw.pbr, cs.ckey, tw.cproc, tw.wadj, tw.wrec, tw.wpar);
 		KLAUNCH(k_class_walk_wave, dim3(n_big), dim3(64), 0, s, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top,
@@ -1949,8 +1976,11 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	tw.last_dupflag = dupflag;
 	uint32_t *nb0_dev = pw.err + 6; // (cleared with the other counters at the start of the pass)
 	KLAUNCH(k_back_edges, dim3((nS + BE_SIDES - 1) / BE_SIDES), dim3(TPB), 0, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey,
-		cs.voff, sw.t_par, nb0_dev, pw.b_src, pw.b_tgt, pw.b_ord, dupflag, pw.lsz, pw.hi0, pw.incnt);
+		cs.voff, sw.t_par, nb0_dev, pw.b_src, pw.b_tgt, pw.b_ord, dupflag, pw.lsz, pw.hi0, pw.incnt,
+		(uint32_t)std::min<size_t>(pw.nb_cap, 0xFFFFFFFFu));
 	const uint32_t NB0 = tw.host->read_u32(nb0_dev, s);
+	if (NB0 > pw.nb_cap)
+		throw HipError("spanning tree: more back edges than links outside the tree and sides without links (internal sizing bug)");
 	tm.end(6);
 	return NB0;
 }

@@ -34,14 +34,18 @@ struct TreeWs {
 	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
 	const uint8_t *last_dupflag;			  // dvis_slots when the last pass filled it, else null
+	Arena *walk_arena = nullptr;			  // where the wave walk's arrays are taken from when the pass needs them and they are not inside the stage block
+	bool walk_inline = true;
 };
 
 // groups: bit 0 = the arrays that outlive the tree stage, bit 1 = those that are dead when the class stage starts (tree_spans)
-size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups = 3);
-void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups = 3);
+size_t tree_workspace_bytes(size_t V, size_t E, size_t Cmax, int groups = 3, const StageWsOpts &o = StageWsOpts{});
+void tree_carve(Arena &ar, TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups = 3, const StageWsOpts &o = StageWsOpts{});
 // both parallel stages in one arena, the class stage's own arrays over the tree stage's dead ones
-size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax);
-void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax);
+size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax, const StageWsOpts &o = StageWsOpts{});
+void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax, const StageWsOpts &o = StageWsOpts{});
+// the wave walk's arrays (records of all sides, stack pool, parents): only a pass with large 2-edge-connected classes needs them
+size_t walk_workspace_bytes(size_t V);
 
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.

@@ -363,6 +363,26 @@ def test_cli_surface(tmp_path, golden_dir):
         assert not list(tmp_path.glob("*.pvst"))
 
 
+def test_workspace_estimate_of_the_headline_graph():
+    """What one plain decompose reserves beside the resident graph, for BASELINE config 4 at full size: under 50 GB (round 3:
+    80 GB) -- the parts add up, and the general case (renumbered vertices, hub vertices, self loops) costs rows A/B four
+    times as much.  Host arithmetic only: no GPU."""
+    lib = C.CDLL(os.path.join(LIB, "libpovu_hip.so"))
+    lib.povu_hip_workspace_estimate.restype = C.c_uint64
+    lib.povu_hip_workspace_estimate.argtypes = [C.c_uint32] * 3
+    lib.povu_hip_workspace_breakdown.argtypes = [C.c_uint32] * 3 + [C.POINTER(C.c_uint64)]
+    V, E, Cn = 99860187, 122435438, 2024
+    total = lib.povu_hip_workspace_estimate(V, E, Cn)
+    assert 30e9 < total < 50e9
+    o = (C.c_uint64 * 7)()
+    assert lib.povu_hip_workspace_breakdown(V, E, Cn, o) == 0
+    assert o[0] + o[1] + o[2] + o[4] + max(o[3], o[5]) == total
+    assert o[6] > 3 * o[0]
+    assert lib.povu_hip_workspace_estimate(V, E, 0) > total  # (component count unknown: every segment its own)
+    small = lib.povu_hip_workspace_estimate(1000, 1500, 1)
+    assert 0 < small < 64 << 20
+
+
 def test_cli_gpus_flag_arguments(tmp_path, golden_dir):
     """`--gpus N` (additive; default 1): which device every worker gets is settled on the host before anything touches a
     GPU -- 0 .. N-1 or the N entries of POVU_HIP_DEVICES, each checked against the visible devices -- and a multi-GPU run
