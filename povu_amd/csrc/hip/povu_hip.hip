@@ -220,10 +220,11 @@ void check_graph_size(uint32_t n_vtx, uint32_t n_links)
 {
 	if (n_vtx == 0)
 		throw HipError("graph has no vertices");
-	// 32-bit index spaces: the packed list-ranking words hold 29-bit successors -- 3 events per segment and 2 adjacency
-	// slots per link must stay below 2^29.  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21).
-	if (3ull * n_vtx >= (1u << 29) || 2ull * n_links >= (1u << 29))
-		throw HipError("graph too large for this build: at most 178 956 970 segments and 268 435 455 links");
+	// 32-bit index spaces: the packed list-ranking words hold 30-bit successors -- 3 events per segment and 2 adjacency
+	// slots per link must stay below 2^30 (round 3: 2^29).  The reference's own limit is 2V+1 < 2^32 (core.hpp:20-21); at
+	// ~54 GB of HBM per 10^8 segments the card's 288 GB run out near 5 * 10^8, just above this limit.
+	if (3ull * n_vtx >= (1u << 30) || 2ull * n_links >= (1u << 30))
+		throw HipError("graph too large for this build: at most 357 913 941 segments and 536 870 911 links");
 }
 
 extern "C" int povu_hip_graph_upload(povu_hip_ctx *ctx, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links,

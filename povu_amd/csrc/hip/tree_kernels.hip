@@ -63,7 +63,12 @@ static unsigned rank_bucket_bits(size_t n)
 	(void)n;
 	return 3u; // (1 in 16 measured 0.2 ms slower on 2.4e8 slots once the other kernels had changed; POVU_HIP_F_SPARSE_SPLITTERS still forces it)
 }
-static constexpr uint32_t PK_END = 0x1FFFFFFFu, PK_HEAD = 0x40000000u, PK_STOP = 0x80000000u;
+static constexpr uint32_t PK_END = 0x1FFFFFFFu, PK_STOP = 0x80000000u; // words of the levels above the list (their elements number an eighth of it)
+// words of the list itself (level 0): bits 0..29 successor (P0_END = none), bit 30 = the element's 0/1 weight, bit 31 = the
+// element heads a list.  Whether the walk stops behind an element -- its successor is a splitter, or there is none -- is
+// worked out from the successor (three integer operations), not stored: the bit it would take is the difference between
+// 1.8 * 10^8 and 3.6 * 10^8 segments a graph may have.
+static constexpr uint32_t P0_END = 0x3FFFFFFFu, P0_W = 0x40000000u, P0_HEAD = 0x80000000u;
 static constexpr uint32_t FT_NONE = 0x7FFFFFFFu, FT_HASH = 0x80000000u; // ft words: first arc of a side | "its hash word was written"
 __device__ __forceinline__ uint32_t bucket_splitter(uint32_t q, unsigned b) { return (q << b) | ((q * 0x9E3779B1u) >> (32u - b)); }
 __device__ __forceinline__ bool is_splitter(uint32_t i, unsigned b) { return bucket_splitter(i >> b, b) == i; }
@@ -72,12 +77,10 @@ __device__ __forceinline__ bool is_splitter(uint32_t i, unsigned b) { return buc
 // know the heads), bit 31 = stop after this element (the successor is a splitter, or there is none).
 __device__ __forceinline__ uint32_t rank_pack(uint32_t nx, uint32_t w, unsigned b)
 {
-	uint32_t p = nx == NIL ? PK_END : nx;
-	p |= (w & 1u) << 29;
-	if (nx == NIL || is_splitter(nx, b))
-		p |= PK_STOP;
-	return p;
+	(void)b;
+	return (nx == NIL ? P0_END : nx) | ((w & 1u) ? P0_W : 0u);
 }
+__device__ __forceinline__ bool rank_l0_stop(uint32_t nx, unsigned b) { return nx == P0_END || is_splitter(nx, b); }
 
 // ------------------------------------------------------------------ 1. Euler tour of the spanning forest
 // The forest = every black edge + the links that won a hook in the union-find over the segments.  A black edge never
@@ -192,7 +195,7 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 				break;
 			const uint32_t at = at0 + q, lw = lws[q], le = lw & LLE_ID;
 			if (!tree[q]) {
-				pk[at] = PK_END | PK_STOP;
+				pk[at] = P0_END;
 				h = hx(h, link_hash(le));
 				continue;
 			}
@@ -275,8 +278,8 @@ __global__ void k_tour_ends(uint32_t C, const uint32_t *__restrict__ voff, const
 	heads[c] = a_first;
 	if (a_first == NIL)
 		return;
-	pk[arc_twin(loff, ladj, lle, a_last)] = PK_END | PK_STOP; // no successor, weight 0
-	atomicOr(&pk[a_first], PK_HEAD);			       // (k_tour_words wrote the word in an earlier launch)
+	pk[arc_twin(loff, ladj, lle, a_last)] = P0_END; // no successor, weight 0
+	atomicOr(&pk[a_first], P0_HEAD);		 // (k_tour_words wrote the word in an earlier launch)
 }
 // one launch = several rounds of pointer jumping with two accumulators (suffix sums along the list):
 // HOPS = 3 covers two rounds (every pointer then spans 4x as far), HOPS = 7 three rounds (8x).  More
@@ -349,14 +352,14 @@ __device__ __forceinline__ uint32_t rank_lane_start(uint32_t id, const RankLevel
 		if (x >= A.n)
 			return NIL;
 		if (L0)
-			return (pk0[x] & PK_HEAD) ? NIL : x;
+			return (pk0[x] & P0_HEAD) ? NIL : x;
 		return x >= A.hbase ? NIL : x;
 	}
 	return L0 ? heads[id - A.m] : A.hbase + (id - A.m);
 }
 // EVT3 (level 0 only, with TWO): the elements are the events of the pre-order ranking, three per segment, and an
 // element's two weights follow from its index: 3g = enter both sides of segment g (+2 entered, depth +2), 3g + 1 =
-// leave the far side (depth -1, or -2 when bit 29 says the entered side is left with it), 3g + 2 = leave the
+// leave the far side (depth -1, or -2 when the weight bit says the entered side is left with it), 3g + 2 = leave the
 // entered side (depth -1).
 template <bool EVT3>
 __device__ __forceinline__ void rank_l0_weights(uint32_t x, uint32_t p, uint32_t &wa, uint32_t &wb)
@@ -364,9 +367,9 @@ __device__ __forceinline__ void rank_l0_weights(uint32_t x, uint32_t p, uint32_t
 	if (EVT3) {
 		const uint32_t t = x % 3u;
 		wa = t == 0 ? 2u : 0u;
-		wb = t == 0 ? 2u : ((t == 1 && (p & (1u << 29))) ? 0u - 2u : 0u - 1u);
+		wb = t == 0 ? 2u : ((t == 1 && (p & P0_W)) ? 0u - 2u : 0u - 1u);
 	} else {
-		wa = (p >> 29) & 1u;
+		wa = (p & P0_W) ? 1u : 0u;
 		wb = wa ? 1u : 0xFFFFFFFFu;
 	}
 }
@@ -382,6 +385,7 @@ __global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restric
 	uint32_t sa = 0, sb = 0, out = PK_END | PK_STOP;
 	if (x != NIL) {
 		uint32_t p;
+		bool stop;
 		do {
 			p = nx_in[x];
 			if (L0) {
@@ -390,14 +394,17 @@ __global__ void k_rank_up(RankLevelArgs A, unsigned b, const uint32_t *__restric
 				sa += wa;
 				if (TWO)
 					sb += wb;
+				x = p & P0_END;
+				stop = rank_l0_stop(x, b);
 			} else {
 				sa += a_in[x];
 				if (TWO)
 					sb += b_in[x];
+				x = p & PK_END;
+				stop = (p & PK_STOP) != 0;
 			}
-			x = p & PK_END;
-		} while (!(p & PK_STOP));
-		if (x != PK_END) { // the successor is the splitter of its bucket: that bucket is its idx one level up
+		} while (!stop);
+		if (x != (L0 ? P0_END : PK_END)) { // the successor is the splitter of its bucket: that bucket is its idx one level up
 			const uint32_t q = x >> b;
 			out = q | (is_splitter(q, b) ? PK_STOP : 0u);
 		}
@@ -443,8 +450,16 @@ __global__ void k_rank_down(RankLevelArgs A, unsigned b, const uint32_t *__restr
 				sb -= wb;
 			}
 		}
-		x = p & PK_END;
-	} while (!(p & PK_STOP));
+		if (L0) {
+			x = p & P0_END;
+			if (rank_l0_stop(x, b))
+				break;
+		} else {
+			x = p & PK_END;
+			if (p & PK_STOP)
+				break;
+		}
+	} while (true);
 }
 // top level: inclusive suffix sums of at most RANK_TOP elements by pointer jumping in LDS, one workgroup
 template <bool TWO>
@@ -520,8 +535,8 @@ static size_t rank_pool_words(size_t n, size_t nh) { return n / 2 + 4 * nh + 64;
 template <bool TWO, bool EVT3 = false>
 static void list_rank_splitters(uint32_t n, unsigned b, uint32_t *out1, uint2 *out12, uint32_t nh, RankBufs &rb, hipStream_t s)
 {
-	if (n >= PK_END)
-		throw HipError("list ranking: more than 2^29 elements (graph too large for the packed walk)");
+	if (n >= P0_END)
+		throw HipError("list ranking: more than 2^30 elements (graph too large for the packed walk)");
 	// plan: level L has lv[L].n elements; its walk has lv[L].M lanes = the elements of level L + 1
 	RankLevelArgs lv[RANK_MAX_LEVELS];
 	uint32_t *nxp[RANK_MAX_LEVELS + 1], *wap[RANK_MAX_LEVELS + 1], *wbp[RANK_MAX_LEVELS + 1];
@@ -1340,7 +1355,7 @@ __global__ void k_events(uint32_t V, const uint2 *__restrict__ dps, const uint32
 	const uint32_t A = 3 * g;
 	const uint4 d4 = *reinterpret_cast<const uint4 *>(dps + 2 * g);
 	if (d4.x != 2 * g + 1 && d4.z != 2 * g) { // a segment outside the decomposed components: three inert words
-		pk[A] = pk[A + 1] = pk[A + 2] = PK_END | PK_STOP;
+		pk[A] = pk[A + 1] = pk[A + 2] = P0_END;
 		merged[g] = 1;
 		return;
 	}
@@ -1384,7 +1399,7 @@ __global__ void k_events(uint32_t V, const uint2 *__restrict__ dps, const uint32
 	if (p == NIL) {
 		const uint32_t comp = ckey[g];
 		if (cproc[comp]) {
-			enter |= PK_HEAD;
+			enter |= P0_HEAD;
 			heads[comp] = A;
 		}
 	}
@@ -1395,7 +1410,7 @@ __global__ void k_events(uint32_t V, const uint2 *__restrict__ dps, const uint32
 		merged[g] = 0;
 	} else {
 		pk[A + 1] = rank_pack(after_e, 1u, b); // both leaves in one
-		pk[A + 2] = PK_END | PK_STOP;
+		pk[A + 2] = P0_END;
 		merged[g] = 1;
 	}
 }
@@ -1866,8 +1881,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
 	ulonglong2 *hside = reinterpret_cast<ulonglong2 *>(tw.evt); // [nS] 16-byte words (evt, [max(4V, 2E)] 8-byte words, is free until the second ranking)
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
-	if (n_slots >= PK_END || 3 * (size_t)V >= PK_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
-		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^29");
+	if (n_slots >= P0_END || 3 * (size_t)V >= P0_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
+		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^30");
 	uint32_t *twin = tw.wadj; // [2E] (the filtered scan lists come much later)
 	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, rb.pk, bitsA, hside, ft, twin);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, rb.pk, rb.heads);
