@@ -79,7 +79,7 @@ def count_flubbles(forest):
     return sum(n - 1 for n in forest.pvst_sizes())
 
 
-def time_single(hip, g, steps, warmup, flags, overlap=True):
+def time_single(hip, g, steps, warmup, flags, overlap=True, pool_warm=True):
     """warmup + `steps` timed passes on one context; returns (seconds, HIP-event ms per pass, last forest, mean latency of a
     pass in ms).  With `overlap` the passes are issued back to back (POVU_HIP_F_ASYNC): a pass returns when its forest is laid
     out, and the copy engine moves its PVST arrays over PCIe while the kernels of the next pass run; the timed region ends
@@ -90,7 +90,7 @@ def time_single(hip, g, steps, warmup, flags, overlap=True):
     f = None
     # (the warm-up forests are alive together: the timed loop holds up to three result blocks at a time -- first, previous,
     # current -- and the context's pool of page-locked blocks must have them before the clock starts)
-    keep = [hip.decompose(flags=flags) for _ in range(max(warmup, 3 if steps > 1 else 1))]
+    keep = [hip.decompose(flags=flags) for _ in range(max(warmup, 3 if (steps > 1 and pool_warm) else 1))]
     del keep
     torch.cuda.synchronize()
     fl = flags | (F_ASYNC if overlap else 0)
@@ -179,7 +179,7 @@ def end_to_end_cli(g, wl):
             subprocess.run([povu, "decompose", "-i", tiny, "-o", o], capture_output=True, text=True, env=env)
             dt = time.perf_counter() - t0
             t_start = dt if t_start is None else min(t_start, dt)
-        best, parts = None, {}
+        best, parts, walls = None, {}, []
         for _ in range(2):
             o = os.path.join(d, "out")
             shutil.rmtree(o, ignore_errors=True)
@@ -189,6 +189,7 @@ def end_to_end_cli(g, wl):
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
+            walls.append(dt)
             if best is None or dt < best:
                 best = dt
                 parts = {m.group(1): float(m.group(2)) / 1e6 for m in
@@ -196,12 +197,14 @@ def end_to_end_cli(g, wl):
         outs = [f for f in os.listdir(os.path.join(d, "out")) if f.endswith(".pvst")]
         out_bytes = sum(os.path.getsize(os.path.join(d, "out", f)) for f in outs)
         return {"workload": f"{wl} as GFA text ({size} bytes) -> {len(outs)} .pvst files ({out_bytes} bytes)",
-                "wall_s": best, "value": g.n_links / best, "unit": "edges/s", "threads": int(threads),
+                "wall_s": best, "wall_s_runs": walls, "value": g.n_links / best, "unit": "edges/s", "threads": int(threads),
                 "process_start_and_hip_bringup_s": t_start,
                 "value_without_process_start": g.n_links / max(1e-9, best - t_start),
                 "host_ms": {k: round(v, 2) for k, v in parts.items()},
                 "gfa_written_in_s": t_write_gfa, "files_on": base or tempfile.gettempdir(),
-                "note": "best of 2 runs of the CLI as a child process; process_start_and_hip_bringup_s = the same CLI on a "
+                "note": "best of 2 runs of the CLI as a child process (both in wall_s_runs; a CLI process that starts right after "
+                        "another one released tens of gigabytes of device memory can spend seconds more in hipMalloc: DESIGN.md "
+                        "section 6 -- the workspace of this graph is 46 GB since round 4, below where that was ever seen); process_start_and_hip_bringup_s = the same CLI on a "
                         "one-segment graph (process start, library load, HIP context, nothing else); host_ms = the CLI's own "
                         "stage-cost lines (gfa_parse, upload_csr, decompose_call, write_pvst); the GFA text is written "
                         "before the timed runs"}
@@ -236,10 +239,20 @@ def main_one_process(args):
     ranks_whole = [md.rank_info(r) for r in range(args.gpus)]
     # ---- the N = 1 line's definition: the shards of the last scatter stay resident as CSR; a step = every GPU decomposes its
     # shard and lands its PVST block in host memory (md.decompose returns when every worker has; merging copies nothing)
-    f = md.decompose(F_NO_STAGE_TIMES)
+    # (passes issued back to back, like the N = 1 line's: a step returns while the copy engines still move its PVST arrays, the
+    # next step's kernels run under the copies; the clock stops when the LAST step's arrays are in host memory)
+    from povu_amd.hip import F_ASYNC
+    keep = [md.decompose(F_NO_STAGE_TIMES) for _ in range(3)]  # (the timed loop holds up to three result blocks per rank)
+    del keep
+    fl = F_NO_STAGE_TIMES | (0 if args.no_overlap else F_ASYNC)
     t0 = time.perf_counter()
+    prev = None
     for _ in range(args.steps):
-        f = md.decompose(F_NO_STAGE_TIMES)
+        f = md.decompose(fl)
+        if prev is not None:
+            prev.wait()
+        prev = f
+    prev.wait()
     dt_res = time.perf_counter() - t0
     F, n_trees = count_flubbles(f), len(f)
     ranks = [md.rank_info(r) for r in range(args.gpus)]
@@ -339,7 +352,8 @@ def main():
         hip.upload(g)  # inputs resident in HBM before the timed region
         upload_s = time.perf_counter() - t_up
         up = hip.upload_times()
-        dt, pass_ms, f, lat_ms = time_single(hip, g, args.steps, args.warmup, F_NO_STAGE_TIMES, overlap=not args.no_overlap)
+        dt, pass_ms, f, lat_ms = time_single(hip, g, args.steps, args.warmup, F_NO_STAGE_TIMES, overlap=not args.no_overlap,
+                                             pool_warm=not args.no_latency_leg)  # (profiling runs: exactly warmup + steps + 1 passes)
         # the same passes one at a time (each complete before the next starts): what a single decompose call costs
         if args.no_latency_leg:
             dt1, pass1_ms = (dt, pass_ms) if args.no_overlap else (float("nan"), float("nan"))

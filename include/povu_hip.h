@@ -170,8 +170,12 @@ void povu_hip_comm_destroy(povu_hip_comm *c);
 /* Scatter: on the root (rank 0) `shards` is the partition of its resident graph, elsewhere NULL.  On return every
  * rank's context holds its shard as resident graph (on the root it replaces the whole graph; a root that wants to
  * keep the whole graph resident scatters from a second context).  Collective: every rank of the communicator must
- * call it; a rank that cannot take part (no partition on the root, no room for its shard) makes the call fail on ALL
- * ranks before any shard moves.  Every RCCL call of a communicator runs on the communicator's own stream. */
+ * call it.  Two failures travel in the handshake and make the call fail on ALL ranks before any shard moves: the root has
+ * no partition for exactly `world` ranks, a receiver has no room for its shard.  Bad ARGUMENTS (a null handle, a
+ * destination context that is not the communicator's) fail on the calling rank alone, before its first collective: the
+ * other ranks then wait -- a caller's bug, not a run-time condition.  EXPERIMENTAL: the library's own RCCL transfers have
+ * never run on more than one GPU (the one-process engine below and the torch.distributed path of bench.py are what is
+ * rehearsed).  Every RCCL call of a communicator runs on the communicator's own stream. */
 int povu_hip_comm_scatter(povu_hip_comm *c, const povu_hip_shards *shards, povu_hip_ctx *dst_ctx, char *err, size_t errlen);
 /* Gather: every rank passes the (globalized) forest of its shard; the root gets the merged forest, the others an
  * empty one.  Collective like the scatter: a forest that cannot travel (hairpin boundaries, a merged forest) or a root
@@ -226,7 +230,9 @@ int povu_hip_multi_scatter(povu_hip_multi *m, int keep_graph, char *err, size_t 
 /* Every rank decomposes its resident shard on its own thread (flags: POVU_HIP_F_*).  `sink`, when given, runs ON THE
  * WORKER'S THREAD with that rank's forest (global component ids) as soon as it is done -- a CLI formats and writes its
  * files there, like the reference's workers; a non-zero return fails the call.  Returns the merged forest (no array is
- * copied: it takes over every rank's blocks). */
+ * copied: it takes over every rank's blocks).  With POVU_HIP_F_ASYNC | POVU_HIP_F_NO_STAGE_TIMES in `flags` (and no sink) the
+ * call returns while the ranks' PVST arrays are still on their way to the host -- the merged forest waits for them like any
+ * POVU_HIP_F_ASYNC forest -- and the next call's kernels run under those copies. */
 typedef int (*povu_hip_multi_sink)(uint32_t rank, const povu_hip_forest *f, void *user);
 povu_hip_forest *povu_hip_multi_decompose(povu_hip_multi *m, uint32_t flags, povu_hip_multi_sink sink, void *user, char *err,
 					  size_t errlen);

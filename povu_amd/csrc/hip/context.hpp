@@ -60,11 +60,15 @@ struct povu_hip_forest {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool pending = false;
 	double pass_ms = -1.0;
-	bool *ctx_tail_flag = nullptr; // the context's "a tail is in flight" flag while this forest is the one in flight
+	// a merged forest took over blocks whose arrays were still on their way: the events behind those passes (owned here)
+	std::vector<hipEvent_t> more_events;
 	void ready()
 	{
 		if (pending) {
-			(void)hipEventSynchronize(ev1);
+			if (ev1)
+				(void)hipEventSynchronize(ev1);
+			for (hipEvent_t e : more_events)
+				(void)hipEventSynchronize(e);
 			pending = false;
 		}
 		if (ev0 && ev1 && pass_ms < 0) {
@@ -136,12 +140,18 @@ struct povu_hip_forest {
 	std::vector<ExtraBlock> extra;
 	~povu_hip_forest()
 	{
-		if (pending)
-			(void)hipEventSynchronize(ev1); // the copy engine may still be writing the block
+		if (pending) { // the copy engine may still be writing the blocks
+			if (ev1)
+				(void)hipEventSynchronize(ev1);
+			for (hipEvent_t e : more_events)
+				(void)hipEventSynchronize(e);
+		}
 		if (ev0)
 			(void)hipEventDestroy(ev0);
 		if (ev1)
 			(void)hipEventDestroy(ev1);
+		for (hipEvent_t e : more_events)
+			(void)hipEventDestroy(e);
 		release_block();
 		for (auto &b : extra)
 			if (b.p && b.pool)

@@ -383,6 +383,7 @@ extern "C" povu_hip_forest *povu_hip_multi_decompose(povu_hip_multi *m, uint32_t
 			x.sink_ms = 0;
 			if (sink) {
 				const double t2 = now_ms();
+				povu_hip_forest_wait(f); // (the sink reads the arrays)
 				if (sink(r, f, user) != 0)
 					throw HipError("the result sink failed");
 				x.sink_ms = now_ms() - t2;

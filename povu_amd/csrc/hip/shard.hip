@@ -593,7 +593,19 @@ extern "C" povu_hip_forest *povu_hip_forest_merge(povu_hip_ctx *ctx, const void 
 // its own forest in every gather, and what the one-process engine (multi.hip) does with every worker's forest.
 void adopt_forest(povu_hip_forest &out, povu_hip_forest &m)
 {
-	m.ready(); // (a POVU_HIP_F_ASYNC forest: its arrays must have arrived before they change hands)
+	// a POVU_HIP_F_ASYNC forest whose arrays are still on their way: the blocks change hands now, the event behind their
+	// copies goes with them (the merged forest waits for it before anybody reads)
+	if (m.pending) {
+		if (m.ev1) {
+			out.more_events.push_back(m.ev1);
+			m.ev1 = nullptr;
+		}
+		for (hipEvent_t e : m.more_events)
+			out.more_events.push_back(e);
+		m.more_events.clear();
+		m.pending = false;
+		out.pending = true;
+	}
 	const int base = (int)out.extra.size();
 	int own = -1;
 	if (m.block) {
@@ -651,7 +663,9 @@ extern "C" int povu_hip_forest_share(povu_hip_forest *f, uint64_t desc[8])
 	try {
 		if (!f->hairpins.empty() || !f->sub_fam.empty())
 			return 4; // (like the wire format: boundaries and labels do not travel)
-		f->ready();
+		// (no wait for a POVU_HIP_F_ASYNC forest here: the descriptor and the tree table do not depend on the arrays still in
+		// flight.  The READER must not look at them before this rank has waited for the forest -- povu_hip_forest_wait --
+		// and told it so: in a loop of collectives, by taking part in the next one.)
 		std::fill(desc, desc + 8, 0ull);
 		desc[0] = SHARE_MAGIC;
 		desc[1] = SHARE_EMPTY;
@@ -961,6 +975,7 @@ static std::unique_ptr<povu_hip_forest> compact_forest(const povu_hip_forest *f)
 
 static void compact_in_place(povu_hip_forest &f)
 {
+	f.ready();
 	std::unique_ptr<povu_hip_forest> c = compact_forest(&f);
 	f.release_block();
 	for (auto &b : f.extra)

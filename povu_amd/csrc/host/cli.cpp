@@ -6,6 +6,8 @@
 #include "decompose.hpp"
 
 #include <cstdlib>
+#include <cxxabi.h>
+#include <typeinfo>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -162,7 +164,13 @@ int main(int argc, char **argv)
 			povu_host::do_decompose(cfg);
 		}
 	} catch (const std::exception &e) {
-		std::cerr << "terminate called after throwing an instance of 'std::runtime_error'\n  what():  " << e.what() << std::endl;
+		// (the line libstdc++'s terminate handler prints, with the exception's real dynamic type; the exit code is 1 where the
+		// reference's abort gives 134 -- documented in DESIGN.md section 1)
+		int status = 0;
+		char *name = abi::__cxa_demangle(typeid(e).name(), nullptr, nullptr, &status);
+		std::cerr << "terminate called after throwing an instance of '" << (status == 0 && name ? name : typeid(e).name())
+			  << "'\n  what():  " << e.what() << std::endl;
+		free(name);
 		return EXIT_FAILURE;
 	}
 	return 0;

@@ -340,6 +340,9 @@ void do_decompose(const Config &cfg)
 	// piece took 0.06 - 0.9 s on the whole-genome workload (tools/cli_phases.py); the process ends here anyway, so that is
 	// left to its exit -- unless POVU_CLI_ORDERLY_EXIT asks for the orderly release (leak checkers, the stage-cost line).
 	if (cfg.exit_when_done && !failed && !std::getenv("POVU_CLI_ORDERLY_EXIT")) {
+		// INVARIANT: every output of the command is written AND closed above (write_forest closes each file, the sidecar frames
+		// are appended and closed one by one): _Exit runs no destructor and flushes no stream of its own.  A buffered writer
+		// added later must be closed before this line (the tests keep the orderly path alive with POVU_CLI_ORDERLY_EXIT).
 		std::cout.flush();
 		std::cerr.flush();
 		fflush(nullptr);

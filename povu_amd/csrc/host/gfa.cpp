@@ -100,7 +100,10 @@ struct Slice {
 
 // S and L lines of a slice (the record type is the first byte of a line): what sizes the graph's arrays before any
 // record is parsed, so that every tokenizer writes its records where they stay
-__attribute__((optimize("O3"))) void count_slice(const char *p, const char *end, Slice &out)
+#if defined(__GNUC__) && !defined(__clang__)
+__attribute__((optimize("O3"))) // (GCC only: the counting pass is built at -O3 whatever the file's level)
+#endif
+void count_slice(const char *p, const char *end, Slice &out)
 {
 	// a record starts the slice or follows a line feed: every byte pair is looked at without a branch (the loop
 	// vectorises; a search for the next line feed per 20-byte line was four times slower)

@@ -33,7 +33,12 @@ struct NoInitAlloc {
 	template <class U>
 	NoInitAlloc(const NoInitAlloc<U> &)
 	{}
-	T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+	T *allocate(size_t n)
+	{
+		if (n > size_t(-1) / sizeof(T))
+			throw std::bad_array_new_length();
+		return static_cast<T *>(::operator new(n * sizeof(T)));
+	}
 	void deallocate(T *p, size_t) { ::operator delete(p); }
 	template <class U, class... A>
 	void construct(U *p, A &&...a)

@@ -339,7 +339,11 @@ class ShardedBench:
     def step_resident(self):
         """The part of a step that starts from "every rank's shard CSR resident" (what the last scatter left) and ends with
         "forest merged on rank 0": per-shard decompose + gather.  Same start and end as the N = 1 measurement of bench.py."""
-        f = self.work.decompose_shard(flags=_hip.F_NO_STAGE_TIMES)
+        # (with the shared-memory gather the passes overlap: a rank's decompose returns while the copy engine still moves its PVST
+        # arrays to the host -- POVU_HIP_F_ASYNC --, the descriptors travel at once, and this rank's next pass runs under the
+        # copies.  Nobody reads the arrays before `sync`, which waits for them on every rank.)
+        fl = _hip.F_NO_STAGE_TIMES | (_hip.F_ASYNC if self.shared else 0)
+        f = self.work.decompose_shard(flags=fl)
         merged = self._gather(f)
         if self.rank == 0:
             self.last = merged
@@ -349,6 +353,8 @@ class ShardedBench:
         import torch
         import torch.distributed as dist
 
+        if self._mine is not None:
+            self._mine.wait()  # this rank's last PVST arrays are in (shared) host memory
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
