@@ -7,7 +7,7 @@ import bench  # kernel_source_digest
 F = os.path.join(ROOT, "gpurun_out", "final")
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-PASSES = 4  # bench.py --steps 2 --warmup 1: 1 warm-up + 2 timed + 1 stage-breakdown pass
+PASSES = 4  # bench.py --no-overlap --no-latency-leg --steps 2 --warmup 1: 1 warm-up + 2 timed + 1 stage-breakdown pass, one at a time
 
 
 def short(n):
@@ -68,7 +68,7 @@ for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline work
              f"the pass {bench_line['roofline']['ms_per_launch']:.2f} ms, roofline frac {bench_line['roofline']['frac']:.4f} (algorithmic 48E+108V+16F = "
              f"{alg/1e9:.3f} GB per pass)" + (f"; CPU port on the box: {cb['value']:.3e} links/s on {cb['cores']} threads (reference scheme), "
                                               f"{cb['value_lpt_threads']:.3e} bin-packed, {cb['value_one_thread']:.3e} on one thread ({cb.get('one_thread_sample', '')})" if cb else "") + ".\n")
-    L.append(f"### Kernel trace\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --no-cpu-baseline --no-secondary --steps 2 --warmup 1` "
+    L.append(f"### Kernel trace\n\n`rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --no-cpu-baseline --no-secondary --no-overlap --no-latency-leg --steps 2 --warmup 1` "
              f"({passes} passes + one upload): sum of kernel durations {tot_ns/1e6:.2f} ms over {calls} launches; the last pass: "
              f"`{open(os.path.join(D, 'timeline_summary.txt')).read().strip()}` (HIP-event time of a pass in that run: {under['roofline']['ms_per_launch']:.2f} ms).\n")
     agg = {}
