@@ -1524,6 +1524,8 @@ char *orc_pvst_text(const orc_pvst *p, size_t *len)
 	return s.b;
 }
 
+#include "povu_oracle_sub.inc" /* the three inserting passes of -s and the writer of their PVST */
+
 /* ------------------------------------------------------------ orchestration
  * do_decompose, app/subcommand/decompose.cpp:94-160: component id = position
  * + 1 (:129), components with < 3 vertices are skipped (:135-142). */
@@ -1548,11 +1550,11 @@ static void decompose_one(const orc_graph *cg, uint32_t c, orc_forest *f, int wa
 	t[1] += d - b;
 	t[2] += e - d;
 	t[3] += h - e;
-	if (g_leaf_sub)
+	if (g_leaf_sub == 1)
 		orc_leaf_subflubbles(tr, p);
 	f->n_pvst[c] = p->n;
 	if (want_text)
-		f->text[c] = orc_pvst_text(p, &f->text_len[c]);
+		f->text[c] = g_leaf_sub == 2 ? orc_subflubbles_text(tr, p, &f->text_len[c]) : orc_pvst_text(p, &f->text_len[c]);
 	free(st);
 	free(ns);
 	orc_pvst_free(p);
@@ -1879,9 +1881,11 @@ int orc_decompose_gfa(const char *gfa, const char *outdir, char *err, size_t err
 int main(int argc, char **argv)
 {
 	if (argc < 3) {
-		fprintf(stderr, "usage: %s in.gfa outdir\n", argv[0]);
+		fprintf(stderr, "usage: %s in.gfa outdir [0|1|2: passes of -s]\n", argv[0]);
 		return 2;
 	}
+	if (argc > 3)
+		orc_set_leaf_subflubbles(atoi(argv[3]));
 	char err[512] = {0};
 	int n = orc_decompose_gfa(argv[1], argv[2], err, sizeof err);
 	if (n < 0) {

@@ -122,7 +122,11 @@ orc_pvst *orc_find_flubbles(orc_tree *t);
  * PARITY UNPINNED (the reference holds no T / O line anywhere). */
 void orc_leaf_subflubbles(const orc_tree *t, orc_pvst *p);
 /* when on, the decompose entry points and orc_dump_component run orc_leaf_subflubbles on every PVST */
-void orc_set_leaf_subflubbles(int on);
+void orc_set_leaf_subflubbles(int on); /* 0 = plain, 1 = the two relabelling passes, 2 = all five passes of -s in the PVST text */
+/* all five passes of `povu decompose -s` (app/subcommand/decompose.cpp:63-70) on one component and the text write_pvst
+ * makes of the result (povu_oracle_sub.inc: find_concealed, find_midi, find_smothered; PARITY UNPINNED).  Fills p->fam. */
+char *orc_subflubbles_text(const orc_tree *t, orc_pvst *p, size_t *len);
+
 /* which rule decided, counted since the last reset (tests: does the fuzz reach every rule?): out[11] = leaves whose Y is
  * empty, tiny by a bracket to ai, tiny by an ordinary / a capping-or-simplifying back-edge INDEX equal to ai, parallel by
  * in_branch with ai / with zi, by in_trunk with ai / with zi, inspect_trunk's cond_b, leaves looked at, times the index comparison was reached with a

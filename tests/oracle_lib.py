@@ -60,7 +60,7 @@ def decompose(links, tips=None, want_text=True, timings=False, threads=1, lpt=Fa
     if tips is not None:
         tips = np.ascontiguousarray(tips, dtype=np.uint8)
         tp = tips.ctypes.data
-    l.orc_set_leaf_subflubbles(1 if leaf else 0)
+    l.orc_set_leaf_subflubbles(int(leaf))  # (True = 1: the two relabelling passes; 2: all five passes of -s)
     try:
         f = l.orc_decompose_arrays_mt(len(vid), vid.ctypes.data, len(v1), v1.ctypes.data, s1.ctypes.data,
                                       v2.ctypes.data, s2.ctypes.data, tp, 1 if want_text else 0, int(threads),
