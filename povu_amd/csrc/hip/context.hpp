@@ -7,6 +7,7 @@
 #include "leaf_kernels.hpp"
 #include "par_kernels.hpp"
 #include "seq_kernels.hpp"
+#include "sub_kernels.hpp"
 #include "tree_kernels.hpp"
 
 #include <map>
@@ -120,6 +121,7 @@ struct povu_hip_forest {
 		uint8_t *aor = nullptr, *zor = nullptr;
 		std::vector<uint32_t> sub_ai, sub_zi; // with POVU_HIP_F_LEAF_SUBFLUBBLES (see the forest's own sub_ai)
 		std::vector<uint8_t> sub_fam;
+		std::shared_ptr<SubForest> subx;
 		void carve(size_t total_entries)
 		{
 			total = total_entries;
@@ -163,6 +165,7 @@ struct povu_hip_forest {
 		size_t hp_off;	// into hairpins (pairs)
 		uint32_t n_hairpins;
 		int blk = -1;	// -1: the arrays of this forest's own block, else extra[blk]
+		uint32_t sub_c = 0; // with POVU_HIP_F_SUBFLUBBLES: its component in `subx` (of the forest, or of extra[blk])
 	};
 	std::vector<Tree> trees;
 	Span<uint32_t> a_id, z_id, parent;
@@ -172,6 +175,7 @@ struct povu_hip_forest {
 	// like the arrays of this forest's own block
 	std::vector<uint32_t> sub_ai, sub_zi;
 	std::vector<uint8_t> sub_fam;
+	std::shared_ptr<SubForest> subx; // with POVU_HIP_F_SUBFLUBBLES: the trees after all five passes of -s
 };
 
 struct povu_hip_ctx {

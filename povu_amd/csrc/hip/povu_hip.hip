@@ -731,7 +731,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		// (and the next pass may then start under them).  Only the plain all-parallel pass has that form.
 		const bool want_async = (o.flags & POVU_HIP_F_ASYNC) && (o.flags & POVU_HIP_F_NO_STAGE_TIMES) && !hairpins &&
 					!(o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE | POVU_HIP_F_FORCE_REDO | POVU_HIP_F_REDO_ODD |
-						     POVU_HIP_F_LEAF_SUBFLUBBLES | POVU_HIP_F_CHECK_LAMINAR));
+						     POVU_HIP_F_LEAF_SUBFLUBBLES | POVU_HIP_F_SUBFLUBBLES | POVU_HIP_F_CHECK_LAMINAR));
 		// The tail of the pass before (POVU_HIP_F_ASYNC) reads the stage workspace (ws2) from the side stream.  A pass that may
 		// itself overlap waits for it ON THE STREAM, right before its own first write there (below); every other pass -- and
 		// any pass whose arenas must grow, which frees them -- waits here.
@@ -761,7 +761,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		ctx->host.reset();
 		cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
 		const bool all_seq = (o.flags & POVU_HIP_F_SEQUENTIAL) != 0;
-		const bool leaf_sub = (o.flags & POVU_HIP_F_LEAF_SUBFLUBBLES) != 0;
+		const bool all_sub = (o.flags & POVU_HIP_F_SUBFLUBBLES) != 0; // all five passes of -s
+		const bool leaf_sub = all_sub || (o.flags & POVU_HIP_F_LEAF_SUBFLUBBLES) != 0;
 		LeafState leaf_state;
 		if (leaf_sub && (o.flags & (POVU_HIP_F_SEQUENTIAL | POVU_HIP_F_SEQ_TREE)))
 			throw HipError("the leaf subflubble passes read the state of the parallel stages: not with the sequential tree / all-sequential test modes");
@@ -867,6 +868,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		sw.rank = o.rank;
 		sw.world = o.world;
 		sw.flags = o.flags;
+		sw.want_depth = all_sub;
 		sw.voff = cs.voff;
 		sw.eoff = cs.eoff;
 		sw.loff = cs.loff;
@@ -987,6 +989,17 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				}
 				tm.end(16);
 				HIP_CHECK(hipStreamSynchronize(s));
+				if (all_sub) {
+					// find_concealed, find_midi, find_smothered insert vertices (sub_kernels.hip); they read the dense PVST the
+					// parallel stages wrote, so a component that needs the sequential redo has no place here
+					if (nbad || (o.flags & (POVU_HIP_F_FORCE_REDO | POVU_HIP_F_REDO_ODD)))
+						throw HipError("subflubble passes: a component went (or was sent) through the sequential redo of add_flubbles, "
+							       "whose PVST layout the inserting passes do not read");
+					tm.begin("subflubbles_insert");
+					f->subx = std::make_shared<SubForest>();
+					run_subflubbles(cs, sw, ctx->pw, ctx->tw, leaf_state, C, ctx->host, *f->subx, s);
+					tm.end(40);
+				}
 				sum = nullptr; // (read again below: the pass total then includes this stage)
 			}
 			if (hairpins && !nbad) {
@@ -1061,6 +1074,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			t.off = total;
 			t.hp_off = total_hp;
 			t.n_hairpins = hairpins ? nbry[c] : 0;
+			t.sub_c = c;
 			total += npvst[c];
 			total_hp += t.n_hairpins;
 			f->trees.push_back(t);
@@ -1332,8 +1346,85 @@ extern "C" int povu_hip_forest_get_sub(const povu_hip_forest *f, uint32_t i, con
 	return 0;
 }
 
+extern "C" int povu_hip_forest_get_subtree(const povu_hip_forest *f, uint32_t i, povu_hip_subtree *out)
+{
+	if (!f || !out || i >= f->trees.size())
+		return 1;
+	const_cast<povu_hip_forest *>(f)->ready();
+	const auto &t = f->trees[i];
+	const SubForest *x = t.blk < 0 ? f->subx.get() : f->extra[(size_t)t.blk].subx.get();
+	if (!x || t.sub_c + 1 >= x->voff.size())
+		return 3; // the forest was not decomposed with POVU_HIP_F_SUBFLUBBLES
+	const uint64_t b = x->voff[t.sub_c], e = x->voff[t.sub_c + 1];
+	out->n_total = (uint32_t)(e - b);
+	out->n_flubble_like = t.n_pvst;
+	out->n_concealed = x->counts[3 * (size_t)t.sub_c];
+	out->n_midi = x->counts[3 * (size_t)t.sub_c + 1];
+	out->n_smothered = x->counts[3 * (size_t)t.sub_c + 2];
+	out->fam = x->fam.data() + b;
+	out->or1 = x->or1.data() + b;
+	out->or2 = x->or2.data() + b;
+	out->route = x->route.data() + b;
+	out->id1 = x->id1.data() + b;
+	out->id2 = x->id2.data() + b;
+	out->child_off = x->coff.data() + b;
+	out->child = x->child.data();
+	return 0;
+}
+
+// write_pvst, src/mto/to_pvst.cpp:31-109, of a tree with its -s vertices
+extern "C" char *povu_hip_pvst_format_subtree(const povu_hip_subtree *t, size_t *len)
+{
+	if (!t)
+		return nullptr;
+	std::string o;
+	o.reserve(32 * (size_t)t->n_total + 64);
+	o += "H\t0.0.3\t.\t.\t.\n";
+	for (uint32_t v = 0; v < t->n_total; v++) {
+		o += (char)t->fam[v];
+		o += '\t';
+		o += std::to_string(v);
+		o += '\t';
+		if (t->fam[v] == 'D') {
+			o += '.';
+		} else { // id_or_t::as_str, include/povu/graph/types.hpp:85-95
+			o += t->or1[v] ? '<' : '>';
+			o += std::to_string(t->id1[v]);
+			o += t->or2[v] ? '<' : '>';
+			o += std::to_string(t->id2[v]);
+		}
+		o += '\t';
+		const uint64_t c0 = t->child_off[v], c1 = t->child_off[v + 1];
+		if (c0 == c1) {
+			o += '.';
+		} else { // print_with_comma, include/povu/common/utils.hpp:44-55
+			for (uint64_t k = c0; k < c1; k++) {
+				o += std::to_string(t->child[k]);
+				if (k + 1 < c1)
+					o += ", ";
+			}
+		}
+		o += '\t';
+		if (t->route[v])
+			o += (char)t->route[v];
+		else
+			o += '.';
+		o += '\n';
+	}
+	char *buf = static_cast<char *>(malloc(o.size() + 1));
+	if (!buf)
+		return nullptr;
+	memcpy(buf, o.data(), o.size() + 1);
+	if (len)
+		*len = o.size();
+	return buf;
+}
+
 extern "C" char *povu_hip_forest_pvst_text(const povu_hip_forest *f, uint32_t i, size_t *len)
 {
+	povu_hip_subtree st;
+	if (povu_hip_forest_get_subtree(f, i, &st) == 0)
+		return povu_hip_pvst_format_subtree(&st, len);
 	povu_hip_tree t;
 	if (povu_hip_forest_get(f, i, &t) != 0)
 		return nullptr;

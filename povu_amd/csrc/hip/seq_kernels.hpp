@@ -36,6 +36,7 @@ struct SeqWs {
 	uint32_t *tables;      // [5(C+1)] order | owner | processed-before | processed | stack entries before: one upload per pass
 	// spanning tree
 	uint32_t *t_gid, *t_par, *t_cls, *t_hi, *first_child, *next_sib, *last_child; // [T]
+	bool want_depth = false; // the parallel tree stage writes t_depth only for its readers: hairpin reports, the inserting passes of -s
 	uint32_t *t_size, *t_depth;						       // [T] subtree sizes, depths
 	uint8_t *t_flags;							       // [T]
 	uint32_t *ctr, *cur;							       // [2V]

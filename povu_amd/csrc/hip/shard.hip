@@ -618,6 +618,7 @@ void adopt_forest(povu_hip_forest &out, povu_hip_forest &m)
 		b.sub_ai = std::move(m.sub_ai);
 		b.sub_zi = std::move(m.sub_zi);
 		b.sub_fam = std::move(m.sub_fam);
+		b.subx = std::move(m.subx);
 		own = (int)out.extra.size() + (int)m.extra.size();
 		m.block = nullptr;
 		m.block_cap = m.block_bytes = m.total_entries = 0;

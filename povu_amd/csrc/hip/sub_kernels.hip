@@ -1,0 +1,1365 @@
+// sub_kernels.hip -- the three INSERTING passes of `povu decompose -s` on the state of an all-parallel pass:
+// find_concealed (src/povu/algorithms/concealed.cpp:1198-1243), find_midi (midi.cpp:225-268) and find_smothered
+// (smothered.cpp:385-432), after find_tiny / find_parallel (leaf_kernels.hip) have relabelled the leaves.
+//
+// The reference walks every flubble of a PVST and asks its spanning tree and gen_tree_meta (src/povu/graph/
+// tree_utils.cpp:674-688: depths, LoA, LCA, the per-vertex bracket table) a few dozen questions; what it finds it then
+// splices into the PVST one vertex after the other.  Here:
+//   tables    depth (the tree stage writes it), literal hi (flubbles.cpp:552,640: a simplifying edge resets it to the root,
+//             which every ancestor then inherits), back edges by source and by target (all three types), the bracket table
+//             MATERIALISED as the reference does (count_brackets / collect_backedges_by_vertex, tree_utils.cpp:167-216,
+//             531-574: one lane per back edge walks from parent(src) up to the target) with every row sorted into the order
+//             the reference's rows have (back-edge idx = creation order in from_bd, see "creation key"), LoA by the
+//             reference's own heap, one lane per component (tree_utils.cpp:224-273; a closed form holds only without
+//             self-loop back edges, oracle/povu_oracle_sub.inc), LCA = parent of the shallowest vertex of an index range
+//             (a segment tree over the depths: vertex idx = pre-order rank);
+//   search    one lane per flubble (concealed.cpp:234-921) and one per concealed vertex (smothered.cpp:61-318), each run
+//             twice -- count, scan, emit;
+//   splice    add_concealed, find_midi / add_midi and add_smothered change the children vectors of the PVST in an order
+//             that shows in the output (vector::push_back / erase, pvst.hpp:860-885) and reach across families (a
+//             concealed vertex is appended to the children of a CHILD flubble, concealed.cpp:1077): they run literally,
+//             one lane per component, over vectors in a bump arena -- linear work, 25 lanes on a whole genome.
+// Accidents of the reference that are kept and behaviour it leaves undefined are those listed at the top of
+// oracle/povu_oracle_sub.inc, decided the same way here.  PARITY UNPINNED: the reference holds no C / M / S line; the
+// tests compare with the oracle's sequential restatement.
+//
+// Creation key of an ordinary back edge (the reference's rows are in back-edge idx order = the order from_bd created
+// them): an edge of source u is created while u's adjacency is scanned -- between the discoveries of two of its children,
+// or behind the last.  tn = the next vertex discovered after it (the child, or the vertex behind u's subtree); edges with
+// the same tn were created while the recursion unwound towards parent(tn): deeper sources first, then in the source's own
+// scan order (b_ord).  So (tn ascending, source descending, b_ord ascending) is the idx order.
+#include "sub_kernels.hpp"
+
+#include "segtree.hpp"
+
+#include <deque>
+#include <string>
+
+namespace povu_hip
+{
+
+#ifndef NIL
+#define NIL POVU_NIL
+#endif
+static constexpr int TPB = 256;
+static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); }
+#define LAUNCH(k, n, s, ...)                                                                     \
+	do {                                                                                     \
+		if ((n) > 0) {                                                                   \
+			hipLaunchKernelGGL(k, dim3(nblk(n)), dim3(TPB), 0, s, __VA_ARGS__);      \
+			HIP_CHECK(hipGetLastError());                                            \
+		}                                                                                \
+	} while (0)
+
+namespace
+{
+struct DevBuf { // a device allocation of data-dependent size (this stage is not on the timed path)
+	void *p = nullptr;
+	~DevBuf()
+	{
+		if (p)
+			(void)hipFree(p);
+	}
+	template <typename T>
+	T *get(size_t n)
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		HIP_CHECK(hipMalloc(&p, (n + 16) * sizeof(T)));
+		return static_cast<T *>(p);
+	}
+};
+
+enum : uint32_t { CL_AI_TRUNK = 0, CL_AI_BRANCH = 1, CL_ZI_TRUNK = 2, CL_ZI_BRANCH = 3 };
+enum : uint32_t { E_BR_ROW = 1u, E_POOL = 2u, E_SET = 4u, E_LAYOUT = 8u };
+
+// device view of the spanning forest (T-space: global tree vertex idx) and of the dense PVST output
+struct SubT {
+	uint32_t T, C, NB0, NB;
+	const uint32_t *voff, *c_ntree, *doff, *c_npvst;
+	const uint32_t *size, *gp, *nchild, *depth, *gid;
+	const uint8_t *flags;
+	const uint32_t *b_src, *b_tgt, *b_ord;
+	const uint32_t *o_off, *o_adj, *i_off, *i_adj; // back edges of all types by source / by target (edge = slot of the dense list)
+	const uint32_t *br_off, *br_be;		       // bracket table
+	const uint32_t *lo, *hi;
+	const unsigned long long *ekey; // [NB0] creation key: tn << 32 | ~source
+	SegTree segD;
+	const uint32_t *p_ai, *p_zi, *p_parent, *p_a, *p_z;
+	const uint8_t *p_fam, *p_aor, *p_zor;
+	uint32_t *err;
+	__device__ __forceinline__ uint32_t base_of(uint32_t c) const { return 2 * voff[c] + c; }
+	__device__ __forceinline__ bool ordinary(uint32_t j) const { return j < NB0; }
+	__device__ __forceinline__ uint32_t dep(uint32_t v) const { return (v < T && size[v]) ? depth[v] : 0xFFFFFFFFu; }
+	// pst::Tree::is_desc, spanning_tree.cpp:560-566: d is a proper descendant of a
+	__device__ __forceinline__ bool is_desc(uint32_t a, uint32_t d) const { return a < d && d < a + size[a]; }
+	__device__ __forceinline__ uint32_t n_br(uint32_t v) const { return br_off[v + 1] - br_off[v]; }
+	__device__ uint32_t lca(uint32_t a, uint32_t b) const
+	{
+		if (a == b)
+			return a;
+		if (a > b) {
+			const uint32_t x = a;
+			a = b;
+			b = x;
+		}
+		if (is_desc(a, b))
+			return a;
+		const uint32_t m = seg_min(segD, a + 1, b + 1);
+		const uint32_t c = seg_first_less(segD, a + 1, b + 1, m + 1);
+		return gp[c];
+	}
+	__device__ uint32_t count_ord(const uint32_t *off, const uint32_t *adj, uint32_t v) const
+	{
+		uint32_t k = 0;
+		for (uint32_t b = off[v]; b < off[v + 1]; b++)
+			k += ordinary(adj[b]) ? 1u : 0u;
+		return k;
+	}
+	// creation order of two ordinary back edges
+	__device__ __forceinline__ bool created_before(uint32_t j1, uint32_t j2) const
+	{
+		const unsigned long long k1 = ekey[j1], k2 = ekey[j2];
+		return k1 != k2 ? k1 < k2 : b_ord[j1] < b_ord[j2];
+	}
+};
+struct CompAt { // component of a global tree vertex / of a dense PVST slot
+	const uint32_t *voff, *doff;
+	uint32_t C;
+	__device__ __forceinline__ uint32_t of_tree(uint32_t t) const
+	{
+		uint32_t lo = 0, hi = C;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (2 * voff[mid] + mid <= t)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		return lo;
+	}
+	__device__ __forceinline__ uint32_t of_slot(uint32_t q) const // last c with doff[c] <= q (components without a PVST own no slot)
+	{
+		uint32_t lo = 0, hi = C;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (doff[mid] <= q)
+				lo = mid;
+			else
+				hi = mid;
+		}
+		return lo;
+	}
+};
+
+// ------------------------------------------------------------------ tables
+__global__ void k_sub_depth_hi0(uint32_t T, const uint32_t *__restrict__ t_size, const uint32_t *__restrict__ t_depth,
+				uint32_t *__restrict__ depth, uint32_t *__restrict__ hi0, uint32_t *__restrict__ eat)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t > T)
+		return;
+	depth[t] = (t < T && t_size[t]) ? t_depth[t] : 0xFFFFFFFFu;
+	hi0[t] = NIL;
+	eat[t] = NIL;
+}
+// by-source and by-target counts of all back edges; hi_0 of every vertex (ordinary edges only: the others do not exist yet
+// when handle_vertex reads OBE, flubbles.cpp:515-519); first slot of every source's ordinary edges in the dense list
+__global__ void k_sub_edge_counts(uint32_t NB, uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
+				  const uint32_t *__restrict__ b_ord, uint32_t *__restrict__ ocnt, uint32_t *__restrict__ icnt,
+				  uint32_t *__restrict__ hi0, uint32_t *__restrict__ eat)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB)
+		return;
+	const uint32_t u = b_src[j], w = b_tgt[j];
+	atomicAdd(&ocnt[u], 1u);
+	atomicAdd(&icnt[w], 1u);
+	if (j < NB0) {
+		atomicMin(&hi0[u], w);
+		if (b_ord[j] == 0)
+			eat[u] = j;
+	}
+}
+__global__ void k_sub_edge_fill(uint32_t NB, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
+				const uint32_t *__restrict__ o_off, const uint32_t *__restrict__ i_off, uint32_t *__restrict__ ocur,
+				uint32_t *__restrict__ icur, uint32_t *__restrict__ o_adj, uint32_t *__restrict__ i_adj)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB)
+		return;
+	const uint32_t u = b_src[j], w = b_tgt[j];
+	o_adj[o_off[u] + atomicAdd(&ocur[u], 1u)] = j;
+	i_adj[i_off[w] + atomicAdd(&icur[w], 1u)] = j;
+}
+// in-place sort of a row by one lane: insertion sort while the row is short, heapsort beyond (rows of thousands of entries
+// exist on tangled graphs; their order out of the atomics is arbitrary)
+template <typename Less>
+__device__ void sort_row(uint32_t *a, uint32_t n, Less less)
+{
+	if (n <= 24) {
+		for (uint32_t i = 1; i < n; i++) {
+			const uint32_t y = a[i];
+			uint32_t k = i;
+			while (k > 0 && less(y, a[k - 1])) {
+				a[k] = a[k - 1];
+				k--;
+			}
+			a[k] = y;
+		}
+		return;
+	}
+	auto sift = [&](uint32_t root, uint32_t end) {
+		const uint32_t v = a[root];
+		for (;;) {
+			uint32_t c = 2 * root + 1;
+			if (c >= end)
+				break;
+			if (c + 1 < end && less(a[c], a[c + 1]))
+				c++;
+			if (!less(v, a[c]))
+				break;
+			a[root] = a[c];
+			root = c;
+		}
+		a[root] = v;
+	};
+	for (uint32_t i = n / 2; i-- > 0;)
+		sift(i, n);
+	for (uint32_t end = n - 1; end > 0; end--) {
+		const uint32_t x = a[0];
+		a[0] = a[end];
+		a[end] = x;
+		sift(0, end);
+	}
+}
+// rows in ascending slot order (the fill above is in whatever order the atomics came)
+__global__ void k_sub_sort_rows_u32(uint32_t T, const uint32_t *__restrict__ off, uint32_t *__restrict__ adj)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	sort_row(adj + off[v], off[v + 1] - off[v], [](uint32_t x, uint32_t y) { return x < y; });
+}
+// literal hi of every vertex: min over the subtree of hi_0, the root once a simplifying edge was added at or below
+__global__ void k_sub_hi(uint32_t T, const uint32_t *__restrict__ size, const SegTree segH, const uint32_t *__restrict__ simp_ps,
+			 const CompAt comp, uint32_t *__restrict__ hi)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	const uint32_t sz = size[v];
+	if (!sz) {
+		hi[v] = NIL;
+		return;
+	}
+	if (simp_ps[v + sz] != simp_ps[v]) {
+		const uint32_t c = comp.of_tree(v);
+		hi[v] = 2 * comp.voff[c] + c;
+		return;
+	}
+	hi[v] = seg_min(segH, v, v + sz);
+}
+// creation keys: one lane per vertex hands its ordinary edges (a stretch of the dense list in scan order) their tn
+__global__ void k_sub_edge_keys(uint32_t T, const uint32_t *__restrict__ size, const uint32_t *__restrict__ out_ord,
+				const uint32_t *__restrict__ eat, const uint32_t *__restrict__ wbefore, unsigned long long *__restrict__ ekey)
+{
+	const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+	if (u >= T || !size[u] || !out_ord[u])
+		return;
+	const uint32_t at = eat[u], n = out_ord[u], end = u + size[u];
+	uint32_t r = 0;
+	for (uint32_t c = u + 1; c < end && r < n; c += max(size[c], 1u)) {
+		const uint32_t k = min(wbefore[c], n - r); // edges of u created right before c was discovered
+		for (uint32_t x = 0; x < k; x++)
+			ekey[at + r + x] = ((unsigned long long)c << 32) | (0xFFFFFFFFu - u);
+		r += k;
+	}
+	for (; r < n; r++)
+		ekey[at + r] = ((unsigned long long)end << 32) | (0xFFFFFFFFu - u);
+}
+// |brackets(v)| (count_brackets, tree_utils.cpp:531-574): ordinary edges from strictly below v to strictly above it; the
+// root has none (the fill loop stops at it), self loops are in nobody's table (oracle: "leaf subflubble passes")
+__global__ void k_sub_br_counts(uint32_t T, const uint32_t *__restrict__ size, const uint32_t *__restrict__ gp, const uint32_t *__restrict__ P,
+				const uint32_t *__restrict__ out_ord, const uint32_t *__restrict__ nself, uint32_t *__restrict__ cnt)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v > T)
+		return;
+	uint32_t n = 0;
+	if (v < T && size[v] && gp[v] != NIL)
+		n = (P[v + size[v]] - P[v]) - (out_ord[v] - nself[v]);
+	cnt[v] = n;
+}
+__global__ void k_sub_br_fill(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
+			      const uint32_t *__restrict__ gp, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ cur,
+			      uint32_t *__restrict__ br_be, uint32_t *__restrict__ err)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB0)
+		return;
+	const uint32_t u = b_src[j], w = b_tgt[j];
+	if (u == w || gp[u] == NIL)
+		return;
+	for (uint32_t v = gp[u]; gp[v] != NIL && v != w; v = gp[v]) {
+		const uint32_t k = atomicAdd(&cur[v], 1u);
+		if (k >= br_off[v + 1] - br_off[v]) {
+			atomicOr(err, E_BR_ROW);
+			return;
+		}
+		br_be[br_off[v] + k] = j;
+	}
+}
+__global__ void k_sub_br_sort(uint32_t T, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ br_be,
+			      const unsigned long long *__restrict__ ekey, const uint32_t *__restrict__ b_ord)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	sort_row(br_be + br_off[v], br_off[v + 1] - br_off[v], [&](uint32_t x, uint32_t y) {
+		const unsigned long long kx = ekey[x], ky = ekey[y];
+		return kx != ky ? kx < ky : b_ord[x] < b_ord[y];
+	});
+}
+// compute_LoA, tree_utils.cpp:224-273, with the heap steps of libstdc++ (push_heap; pop_heap = __adjust_heap to the bottom,
+// then __push_heap): one lane per component, its heap in the stretch of `heap` its ordinary edges number
+__global__ void k_sub_lo(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ c_ntree,
+			 const uint32_t *__restrict__ size, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ out_ord,
+			 const uint32_t *__restrict__ eat, const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ O,
+			 uint32_t *__restrict__ heap_all, uint32_t *__restrict__ lo)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C || !c_ntree[c])
+		return;
+	const uint32_t base = 2 * voff[c] + c, N = c_ntree[c];
+	uint32_t *heap = heap_all + O[base];
+	uint32_t hn = 0;
+	for (uint32_t v = base + N; v-- > base;) {
+		if (!size[v]) {
+			lo[v] = NIL;
+			continue;
+		}
+		while (hn && heap[0] == v) {
+			const uint32_t value = heap[hn - 1], len = hn - 1;
+			hn = len;
+			if (!len)
+				break;
+			uint32_t hole = 0, child = 0;
+			while (child < (len - 1) / 2) {
+				child = 2 * (child + 1);
+				if (depth[heap[child]] < depth[heap[child - 1]])
+					child--;
+				heap[hole] = heap[child];
+				hole = child;
+			}
+			if ((len & 1) == 0 && child == (len - 2) / 2) {
+				child = 2 * (child + 1);
+				heap[hole] = heap[child - 1];
+				hole = child - 1;
+			}
+			while (hole > 0 && depth[heap[(hole - 1) / 2]] < depth[value]) {
+				heap[hole] = heap[(hole - 1) / 2];
+				hole = (hole - 1) / 2;
+			}
+			heap[hole] = value;
+		}
+		lo[v] = hn ? heap[0] : NIL;
+		const uint32_t n = out_ord[v], at = eat[v];
+		for (uint32_t r = 0; r < n; r++) { // OBE(v) in back-edge idx order = the source's scan order
+			const uint32_t x = b_tgt[at + r];
+			uint32_t i = hn++;
+			while (i && depth[heap[(i - 1) / 2]] < depth[x]) {
+				heap[i] = heap[(i - 1) / 2];
+				i = (i - 1) / 2;
+			}
+			heap[i] = x;
+		}
+	}
+}
+
+// ------------------------------------------------------------------ find_concealed: the search (concealed.cpp:234-921)
+struct Slub {
+	uint32_t q, loc, sl, be_src; // flubble (dense slot), cl_e, the slubble's tree vertex, ai_trunk: the back edge's source
+};
+// compute_m, concealed.cpp:234-283
+__device__ uint32_t cn_compute_m(const SubT &t, uint32_t ii, uint32_t ji)
+{
+	if (t.i_off[ii + 1] == t.i_off[ii])
+		return ii;
+	uint32_t best = NIL, best_h = 0;
+	for (uint32_t b = t.i_off[ii]; b < t.i_off[ii + 1]; b++) {
+		const uint32_t j = t.i_adj[b];
+		if (!t.ordinary(j))
+			continue;
+		const uint32_t l = t.lca(t.b_src[j], ji);
+		if (t.depth[l] >= t.depth[ji])
+			continue;
+		if (t.depth[l] > best_h) {
+			best = l;
+			best_h = t.depth[l];
+		}
+	}
+	return best == NIL ? ii : best;
+}
+// compute_n, concealed.cpp:285-328
+__device__ uint32_t cn_compute_n(const SubT &t, uint32_t ii, uint32_t ji)
+{
+	if (t.count_ord(t.o_off, t.o_adj, ji) == 0)
+		return ji;
+	uint32_t lowest = ii;
+	for (uint32_t b = t.o_off[ji]; b < t.o_off[ji + 1]; b++) {
+		const uint32_t j = t.o_adj[b];
+		if (!t.ordinary(j))
+			continue;
+		if (t.depth[t.b_tgt[j]] > t.depth[lowest])
+			lowest = t.b_tgt[j];
+	}
+	return lowest == ii ? ji : lowest;
+}
+// can_contain, concealed.cpp:348-384
+__device__ bool cn_can_contain(const SubT &t, uint32_t ii, uint32_t ji, uint32_t m, uint32_t n)
+{
+	if (t.dep(t.lo[ji]) < t.depth[ii])
+		return false;
+	uint32_t ibe_ii = 0;
+	for (uint32_t b = t.i_off[ii]; b < t.i_off[ii + 1]; b++) {
+		const uint32_t j = t.i_adj[b];
+		ibe_ii += (t.ordinary(j) && t.b_src[j] != ji) ? 1u : 0u;
+	}
+	if (m == ii && n == ji && ibe_ii < 2 && t.count_ord(t.i_off, t.i_adj, ji) == 0 && t.nchild[ji] < 3)
+		return false;
+	return true;
+}
+// ai_trunk, concealed.cpp:388-522
+__device__ bool cn_ai_trunk(const SubT &t, uint32_t m, uint32_t n, uint32_t ai, uint32_t zi, uint32_t &be_src, uint32_t &l_out)
+{
+	if (t.depth[m] > t.depth[n])
+		return false;
+	uint32_t best_l = NIL, best_src = NIL;
+	for (uint32_t b = t.i_off[ai]; b < t.i_off[ai + 1]; b++) {
+		const uint32_t j = t.i_adj[b];
+		if (!t.ordinary(j))
+			continue;
+		const uint32_t src = t.b_src[j], l = t.lca(src, zi);
+		if (t.depth[l] > t.depth[m])
+			continue;
+		bool ell_br = true;
+		for (uint32_t q = t.br_off[l]; q < t.br_off[l + 1] && ell_br; q++)
+			ell_br = t.depth[t.b_tgt[t.br_be[q]]] <= t.depth[ai];
+		const bool cond_iii = t.o_off[l + 1] > t.o_off[l] || t.nchild[l] > 1;
+		if (!ell_br && cond_iii)
+			continue;
+		if (best_l == NIL || l >= best_l) {
+			best_l = l;
+			best_src = src;
+		}
+	}
+	if (best_l == NIL)
+		return false;
+	be_src = best_src;
+	l_out = best_l;
+	return true;
+}
+__device__ uint32_t lca_of_bracket_srcs(const SubT &t, uint32_t c)
+{
+	uint32_t d = NIL;
+	for (uint32_t q = t.br_off[c]; q < t.br_off[c + 1]; q++) {
+		const uint32_t src = t.b_src[t.br_be[q]];
+		d = d == NIL ? src : t.lca(d, src);
+	}
+	return d;
+}
+// the searches push their slubbles through this: out == null counts
+struct SlubOut {
+	Slub *out;
+	uint32_t n;
+	__device__ __forceinline__ void push(uint32_t q, uint32_t loc, uint32_t sl, uint32_t be_src)
+	{
+		if (out)
+			out[n] = Slub{q, loc, sl, be_src};
+		n++;
+	}
+};
+// ai_branches, concealed.cpp:525-583
+__device__ void cn_ai_branches(const SubT &t, uint32_t q, uint32_t ai, uint32_t zi, SlubOut &o)
+{
+	if (t.nchild[zi] < 2)
+		return;
+	const uint32_t end = zi + t.size[zi];
+	for (uint32_t c = zi + 1; c < end; c += max(t.size[c], 1u)) {
+		if (!(t.hi[c] == t.lo[c] && t.hi[c] == ai))
+			continue;
+		if (t.n_br(c) < 2)
+			continue;
+		const uint32_t d = lca_of_bracket_srcs(t, c);
+		if (t.n_br(d) > 0)
+			o.push(q, CL_AI_BRANCH, d, NIL);
+	}
+}
+// override_ji_trunk, concealed.cpp:617-697
+__device__ uint32_t cn_override_ji_trunk(const SubT &t, uint32_t m, uint32_t n, uint32_t ii, uint32_t ji)
+{
+	if (t.depth[m] > t.depth[n])
+		return NIL;
+	uint32_t min_v = n;
+	const uint32_t end = ji + t.size[ji];
+	for (uint32_t c = ji + 1; c < end; c += max(t.size[c], 1u)) {
+		if (t.dep(t.hi[c]) < t.depth[ii])
+			continue;
+		if (t.n_br(c) != 1)
+			continue;
+		const uint32_t y = t.b_tgt[t.br_be[t.br_off[c]]];
+		if (!(t.depth[m] < t.depth[y] && t.depth[n] > t.depth[y]))
+			continue;
+		bool valid = true;
+		for (uint32_t k = t.br_off[y]; k < t.br_off[y + 1] && valid; k++) {
+			const uint32_t j = t.br_be[k];
+			if (t.depth[t.b_src[j]] < t.depth[ji] || t.depth[t.b_tgt[j]] > t.depth[ii])
+				valid = false;
+		}
+		if (valid && t.depth[y] < t.depth[min_v])
+			min_v = y;
+	}
+	return min_v == n ? NIL : min_v;
+}
+// ji_trunk, concealed.cpp:699-760 (the rest of the function is behind a return)
+__device__ uint32_t cn_ji_trunk(const SubT &t, uint32_t m, uint32_t n, uint32_t ii, uint32_t ji)
+{
+	if (t.depth[m] > t.depth[n])
+		return NIL;
+	const uint32_t r = cn_override_ji_trunk(t, m, n, ii, ji);
+	if (r != NIL)
+		return r;
+	uint32_t best = NIL;
+	for (uint32_t b = t.o_off[ji]; b < t.o_off[ji + 1]; b++) {
+		const uint32_t j = t.o_adj[b];
+		if (!t.ordinary(j))
+			continue;
+		const uint32_t x = t.b_tgt[j];
+		if (t.depth[x] < t.depth[n])
+			continue;
+		if (best == NIL || t.depth[x] < t.depth[best])
+			best = x;
+	}
+	return best;
+}
+// ji_branches, concealed.cpp:790-921
+__device__ void cn_ji_branches(const SubT &t, uint32_t q, uint32_t ii, uint32_t ji, uint32_t n, SlubOut &o)
+{
+	if (t.nchild[ji] < 2 || ji == n)
+		return;
+	bool have_main = false;
+	for (uint32_t b = t.i_off[ii]; b < t.i_off[ii + 1] && !have_main; b++) {
+		const uint32_t j = t.i_adj[b];
+		have_main = t.ordinary(j) && t.b_src[j] == ji;
+	}
+	const uint32_t end = ji + t.size[ji];
+	for (int pass = 0; pass < 2; pass++) {
+		for (uint32_t c = ji + 1; c < end; c += max(t.size[c], 1u)) {
+			uint32_t count = 0;
+			bool into_ji = false;
+			for (uint32_t k = t.br_off[c]; k < t.br_off[c + 1]; k++) {
+				if (t.b_tgt[t.br_be[k]] != ji)
+					count++;
+				else
+					into_ji = true;
+			}
+			if (count != 1 || into_ji != (pass == 0))
+				continue;
+			if (pass == 0) {
+				uint32_t lowest = c;
+				for (uint32_t k = t.br_off[c]; k < t.br_off[c + 1]; k++) {
+					const uint32_t j = t.br_be[k];
+					if (t.b_tgt[j] == ji && t.depth[t.b_src[j]] > t.depth[lowest])
+						lowest = t.b_src[j];
+				}
+				o.push(q, CL_ZI_BRANCH, lowest, NIL);
+			} else {
+				const uint32_t j = t.br_be[t.br_off[c]];
+				const uint32_t src = t.b_src[j], tgt = t.b_tgt[j];
+				bool cond_i = false;
+				uint32_t d = src;
+				while (d != ji) {
+					if (t.nchild[d] > 1) {
+						cond_i = true;
+						break;
+					}
+					d = t.gp[d];
+				}
+				const uint32_t alpha = t.n_br(tgt);
+				if (alpha != 0 && have_main)
+					continue;
+				if (alpha != 1)
+					continue;
+				if (cond_i)
+					o.push(q, CL_ZI_BRANCH, d, NIL);
+			}
+		}
+	}
+}
+// find_concealed's loop body for the flubble in dense slot q (concealed.cpp:1203-1237); returns its slubbles
+__device__ uint32_t cn_search(const SubT &t, const CompAt &comp, uint32_t q, Slub *out, uint32_t *mn)
+{
+	if (t.p_fam[q] != FAM_FLUBBLE)
+		return 0;
+	const uint32_t c = comp.of_slot(q), base = t.base_of(c);
+	const uint32_t ai = base + t.p_ai[q], zi = base + t.p_zi[q];
+	const uint32_t m = cn_compute_m(t, ai, zi), n = cn_compute_n(t, ai, zi);
+	if (mn) {
+		mn[2 * (size_t)q] = m;
+		mn[2 * (size_t)q + 1] = n;
+	}
+	if (!cn_can_contain(t, ai, zi, m, n))
+		return 0;
+	SlubOut o{out, 0};
+	uint32_t be_src, l;
+	if (cn_ai_trunk(t, m, n, ai, zi, be_src, l))
+		o.push(q, CL_AI_TRUNK, l, be_src);
+	cn_ai_branches(t, q, ai, zi, o);
+	const uint32_t tb = cn_ji_trunk(t, m, n, ai, zi);
+	if (tb != NIL)
+		o.push(q, CL_ZI_TRUNK, tb, NIL);
+	cn_ji_branches(t, q, ai, zi, n, o);
+	return o.n;
+}
+__global__ void k_sub_cn_count(uint32_t Q, const SubT t, const CompAt comp, uint32_t *__restrict__ cnt, uint32_t *__restrict__ mn)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q > Q)
+		return;
+	cnt[q] = q < Q ? cn_search(t, comp, q, nullptr, mn) : 0u;
+}
+__global__ void k_sub_cn_emit(uint32_t Q, const SubT t, const CompAt comp, const uint32_t *__restrict__ off, Slub *__restrict__ out)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= Q || off[q + 1] == off[q])
+		return;
+	cn_search(t, comp, q, out + off[q], nullptr);
+}
+
+// ------------------------------------------------------------------ find_smothered: the search (smothered.cpp:61-318)
+struct Smo {
+	uint32_t sm_st, b_up, b_lo, flags; // flags: 1 = cn_b is the ancestor, 2 = the concealed vertex is a g
+};
+struct SmoOut {
+	Smo *out;
+	uint32_t n;
+	__device__ __forceinline__ void push(uint32_t sm_st, bool anc, bool is_g, uint32_t up, uint32_t lo)
+	{
+		if (out)
+			out[n] = Smo{sm_st, up, lo, (anc ? 1u : 0u) | (is_g ? 2u : 0u)};
+		n++;
+	}
+};
+// compute_bounds, smothered.cpp:37-48
+__device__ __forceinline__ void smo_bounds(const SubT &t, uint32_t cn_st, uint32_t sm_st, uint32_t &up, uint32_t &lo)
+{
+	if (t.is_desc(cn_st, sm_st))
+		up = cn_st, lo = sm_st;
+	else
+		up = sm_st, lo = cn_st;
+}
+// the next distinct value above `last` of key[adj[..]] over a row, NIL when there is none (std::set iteration without a set)
+__device__ uint32_t next_distinct(const uint32_t *off, const uint32_t *adj, const uint32_t *key, uint32_t v, uint32_t last, bool first)
+{
+	uint32_t best = NIL;
+	for (uint32_t b = off[v]; b < off[v + 1]; b++) {
+		const uint32_t x = key[adj[b]];
+		if ((first || x > last) && (best == NIL || x < best))
+			best = x;
+	}
+	return best;
+}
+__device__ uint32_t smo_search(const SubT &t, const CompAt &comp, const Slub &cn, Smo *out)
+{
+	SmoOut o{out, 0};
+	const uint32_t c = comp.of_slot(cn.q), base = t.base_of(c);
+	const uint32_t ai = base + t.p_ai[cn.q], zi = base + t.p_zi[cn.q], sl = cn.sl;
+	switch (cn.loc) {
+	case CL_AI_TRUNK: { // g::trunk, smothered.cpp:61-134
+		const uint32_t end = sl + t.size[sl];
+		for (uint32_t ch = sl + 1; ch < end; ch += max(t.size[ch], 1u)) {
+			if (t.n_br(ch) == 0)
+				continue;
+			const uint32_t last = t.br_be[t.br_off[ch + 1] - 1], src = t.b_src[last], tgt = t.b_tgt[last];
+			bool one_src = true;
+			for (uint32_t k = t.br_off[ch]; k < t.br_off[ch + 1] && one_src; k++)
+				one_src = t.b_src[t.br_be[k]] == src;
+			if (!(one_src && t.depth[tgt] > t.depth[ai]))
+				continue;
+			const uint32_t brch = t.lca(zi, src);
+			if (t.n_br(src) == 0)
+				o.push(tgt, false, true, brch, src);
+			else
+				o.push(src, true, true, brch, src);
+		}
+		break;
+	}
+	case CL_AI_BRANCH: { // g::branch, :136-199
+		const uint32_t t0 = next_distinct(t.o_off, t.o_adj, t.b_tgt, sl, 0, true);
+		if (t0 == NIL || t0 != ai || next_distinct(t.o_off, t.o_adj, t.b_tgt, sl, t0, false) != NIL)
+			break;
+		for (uint32_t k = t.br_off[sl]; k < t.br_off[sl + 1]; k++) {
+			const uint32_t j = t.br_be[k];
+			if (t.b_tgt[j] != ai)
+				continue;
+			const uint32_t src = t.b_src[j];
+			for (uint32_t r = t.br_off[src]; r < t.br_off[src + 1]; r++)
+				if (t.b_tgt[t.br_be[r]] == sl) {
+					uint32_t up, lo;
+					smo_bounds(t, sl, src, up, lo);
+					o.push(src, true, true, up, lo);
+				}
+		}
+		break;
+	}
+	case CL_ZI_TRUNK: { // s::trunk, :217-270: the sources by their LCA with zi, ascending; an LCA with one source gives a vertex
+		uint32_t last_l = 0;
+		bool first_l = true;
+		for (;;) {
+			// the next LCA value above last_l among the kept sources
+			uint32_t best_l = NIL;
+			for (uint32_t b = t.i_off[sl]; b < t.i_off[sl + 1]; b++) {
+				const uint32_t src = t.b_src[t.i_adj[b]];
+				if (t.depth[src] >= t.depth[zi])
+					continue;
+				const uint32_t l = t.lca(zi, src);
+				if (l == src)
+					continue;
+				if ((first_l || l > last_l) && (best_l == NIL || l < best_l))
+					best_l = l;
+			}
+			if (best_l == NIL)
+				break;
+			// its distinct sources
+			uint32_t cnt = 0, only = NIL, last_s = 0;
+			bool first_s = true;
+			for (;;) {
+				uint32_t best_s = NIL;
+				for (uint32_t b = t.i_off[sl]; b < t.i_off[sl + 1]; b++) {
+					const uint32_t src = t.b_src[t.i_adj[b]];
+					if (t.depth[src] >= t.depth[zi])
+						continue;
+					const uint32_t l = t.lca(zi, src);
+					if (l != best_l || l == src)
+						continue;
+					if ((first_s || src > last_s) && (best_s == NIL || src < best_s))
+						best_s = src;
+				}
+				if (best_s == NIL)
+					break;
+				cnt++;
+				only = best_s;
+				last_s = best_s;
+				first_s = false;
+			}
+			if (cnt == 1)
+				o.push(only, false, false, best_l, only);
+			last_l = best_l;
+			first_l = false;
+		}
+		break;
+	}
+	case CL_ZI_BRANCH: { // s::branch, :272-318
+		uint32_t last = 0;
+		bool first = true;
+		for (;;) {
+			const uint32_t src = next_distinct(t.i_off, t.i_adj, t.b_src, sl, last, first);
+			if (src == NIL)
+				break;
+			uint32_t l2 = 0;
+			bool f2 = true;
+			for (;;) {
+				const uint32_t x = next_distinct(t.i_off, t.i_adj, t.b_src, src, l2, f2);
+				if (x == NIL)
+					break;
+				uint32_t up, lo;
+				smo_bounds(t, x, sl, up, lo);
+				o.push(x, true, false, up, lo);
+				l2 = x;
+				f2 = false;
+			}
+			l2 = 0;
+			f2 = true;
+			for (;;) {
+				const uint32_t x = next_distinct(t.o_off, t.o_adj, t.b_tgt, src, l2, f2);
+				if (x == NIL)
+					break;
+				if (x != zi) {
+					uint32_t up, lo;
+					smo_bounds(t, x, sl, up, lo);
+					o.push(x, false, false, up, lo);
+				}
+				l2 = x;
+				f2 = false;
+			}
+			last = src;
+			first = false;
+		}
+		break;
+	}
+	}
+	return o.n;
+}
+__global__ void k_sub_smo_count(uint32_t NC, const SubT t, const CompAt comp, const Slub *__restrict__ cn, uint32_t *__restrict__ cnt)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k > NC)
+		return;
+	cnt[k] = k < NC ? smo_search(t, comp, cn[k], nullptr) : 0u;
+}
+__global__ void k_sub_smo_emit(uint32_t NC, const SubT t, const CompAt comp, const Slub *__restrict__ cn, const uint32_t *__restrict__ off,
+			       Smo *__restrict__ out)
+{
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= NC || off[k + 1] == off[k])
+		return;
+	smo_search(t, comp, cn[k], out + off[k]);
+}
+
+// ------------------------------------------------------------------ the splice, one lane per component
+// The extended PVST of component c lives in X-space: x = xoff[c] + (index inside the component).  Children of a vertex: a
+// vector {begin, size, capacity} in the component's stretch of the pool, doubled when full (pvst.hpp:860-885).
+struct XArrays {
+	uint8_t *fam, *or1, *or2, *route, *loc;
+	uint32_t *id1, *id2, *ai, *zi, *sl, *b_up, *b_lo; // ai / zi: global tree vertex; b_up / b_lo: bounds_t (global tree vertex, or PVST idx for a midi)
+	uint32_t *vbeg, *vn, *vcap;
+	uint32_t *pool;
+};
+struct Splice {
+	XArrays x;
+	uint32_t xb;		   // first X slot of the component
+	uint32_t pool_top, pool_end; // bump pointer inside the pool
+	uint32_t *err;
+	__device__ void push(uint32_t parent, uint32_t child)
+	{
+		const uint32_t p = xb + parent;
+		if (x.vn[p] == x.vcap[p]) {
+			const uint32_t cap = x.vcap[p] ? 2 * x.vcap[p] : 4;
+			if (pool_top + cap > pool_end) {
+				atomicOr(err, E_POOL);
+				return;
+			}
+			for (uint32_t k = 0; k < x.vn[p]; k++)
+				x.pool[pool_top + k] = x.pool[x.vbeg[p] + k];
+			x.vbeg[p] = pool_top;
+			x.vcap[p] = cap;
+			pool_top += cap;
+		}
+		x.pool[x.vbeg[p] + x.vn[p]++] = child;
+	}
+	// del_edge: erase the first match; the slot behind the new end keeps its old value, as vector::erase leaves it
+	__device__ void erase(uint32_t parent, uint32_t child)
+	{
+		const uint32_t p = xb + parent, b = x.vbeg[p], n = x.vn[p];
+		for (uint32_t k = 0; k < n; k++)
+			if (x.pool[b + k] == child) {
+				for (uint32_t a = k; a + 1 < n; a++)
+					x.pool[b + a] = x.pool[b + a + 1];
+				x.vn[p] = n - 1;
+				return;
+			}
+	}
+	__device__ __forceinline__ bool fl_like(uint32_t v) const
+	{
+		const uint8_t f = x.fam[xb + v];
+		return f == FAM_FLUBBLE || f == FAM_TINY || f == FAM_PARALLEL;
+	}
+};
+__device__ __forceinline__ void side_id_or(const SubT &t, uint32_t v, bool fwd_is_r, uint32_t &id, uint8_t &orr)
+{
+	id = t.gid[v];
+	const bool is_r = (t.flags[v] & TF_TYPE_MASK) == 1u;
+	orr = (is_r == fwd_is_r) ? 0 : 1;
+}
+__global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ poff,
+			     const uint32_t *__restrict__ cn_off, const Slub *__restrict__ cn, const uint32_t *__restrict__ mn,
+			     const uint32_t *__restrict__ smo_off, const Smo *__restrict__ smo, XArrays X, uint32_t *__restrict__ counts)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	const uint32_t n0 = t.c_npvst[c];
+	counts[3 * c] = counts[3 * c + 1] = counts[3 * c + 2] = 0;
+	if (!n0)
+		return;
+	const uint32_t q0 = t.doff[c], base = t.base_of(c), N = t.c_ntree[c];
+	Splice S{X, xoff[c], poff[c], poff[c + 1], t.err};
+	const uint32_t xb = S.xb, cap_x = xoff[c + 1] - xoff[c];
+	// the PVST as find_flubbles left it (children in ascending idx: add_flubbles attaches them in that order)
+	for (uint32_t v = 0; v < n0; v++) {
+		const uint32_t q = q0 + v, x = xb + v;
+		X.fam[x] = t.p_fam[q];
+		X.vn[x] = X.vcap[x] = 0;
+		X.vbeg[x] = 0;
+		X.loc[x] = 0;
+		X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
+		if (v) {
+			X.id1[x] = t.p_a[q], X.or1[x] = t.p_aor[q];
+			X.id2[x] = t.p_z[q], X.or2[x] = t.p_zor[q];
+			X.route[x] = 'L';
+			X.ai[x] = base + t.p_ai[q], X.zi[x] = base + t.p_zi[q];
+		} else {
+			X.id1[x] = X.id2[x] = NIL;
+			X.or1[x] = X.or2[x] = 0;
+			X.route[x] = 0;
+			X.ai[x] = X.zi[x] = NIL;
+		}
+	}
+	// exact capacities for the initial vectors
+	for (uint32_t v = 1; v < n0; v++)
+		X.vcap[xb + t.p_parent[q0 + v]]++;
+	for (uint32_t v = 0; v < n0; v++) {
+		const uint32_t x = xb + v, k = X.vcap[x];
+		if (S.pool_top + k > S.pool_end) {
+			atomicOr(t.err, E_POOL);
+			return;
+		}
+		X.vbeg[x] = S.pool_top;
+		S.pool_top += k;
+	}
+	for (uint32_t v = 1; v < n0; v++) {
+		const uint32_t p = xb + t.p_parent[q0 + v];
+		X.pool[X.vbeg[p] + X.vn[p]++] = v;
+	}
+	uint32_t nx = n0; // vertices so far
+	auto new_vertex = [&](uint8_t fam) -> uint32_t {
+		if (nx >= cap_x) {
+			atomicOr(t.err, E_LAYOUT);
+			return NIL;
+		}
+		const uint32_t x = xb + nx;
+		X.fam[x] = fam;
+		X.vn[x] = X.vcap[x] = 0;
+		X.vbeg[x] = 0;
+		X.ai[x] = X.zi[x] = X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
+		X.loc[x] = 0;
+		return nx++;
+	};
+	// ---- add_concealed, concealed.cpp:925-1196, flubbles in ascending idx
+	const uint32_t cn_b = cn_off[q0], cn_e = cn_off[q0 + n0];
+	for (uint32_t k = cn_b; k < cn_e;) {
+		const uint32_t q = cn[k].q, f = q - q0;
+		uint32_t ke = k;
+		while (ke < cn_e && cn[ke].q == q)
+			ke++;
+		const uint32_t ai = X.ai[xb + f], zi = X.zi[xb + f], n_of_f = mn[2 * (size_t)q + 1];
+		const bool is_leaf = f < N && t.nchild[base + f] == 0; // (sic) the SPANNING TREE's vertex f, concealed.cpp:1188
+		for (; k < ke; k++) {
+			const Slub &sl = cn[k];
+			const uint32_t v = new_vertex(FAM_CONCEALED);
+			if (v == NIL)
+				return;
+			const uint32_t x = xb + v;
+			// gen_ai_slubble, concealed.cpp:70-152 / gen_zi_slubble, :154-206
+			const bool sl_r = (t.flags[sl.sl] & TF_TYPE_MASK) == 1u, black = (t.flags[sl.sl] & TF_BLACK) != 0;
+			uint32_t fl_id;
+			uint8_t fl_o;
+			const uint32_t sl_id = t.gid[sl.sl];
+			X.loc[x] = (uint8_t)sl.loc;
+			X.sl[x] = sl.sl;
+			if (sl.loc == CL_AI_TRUNK || sl.loc == CL_AI_BRANCH) {
+				side_id_or(t, ai, true, fl_id, fl_o);
+				const bool fwd_if_r = (sl.loc == CL_AI_TRUNK) == black;
+				const uint8_t sl_o = (sl_r == fwd_if_r) ? 0 : 1;
+				if (sl_o == 1 && fl_o == 1) {
+					X.id1[x] = sl_id, X.or1[x] = 0;
+					X.id2[x] = fl_id, X.or2[x] = 0;
+				} else {
+					X.id1[x] = fl_id, X.or1[x] = fl_o;
+					X.id2[x] = sl_id, X.or2[x] = sl_o;
+				}
+				X.route[x] = 'R';
+				if (sl.loc == CL_AI_TRUNK) {
+					if (t.is_desc(ai, sl.be_src))
+						X.b_up[x] = ai, X.b_lo[x] = sl.be_src;
+					else
+						X.b_up[x] = sl.be_src, X.b_lo[x] = ai;
+				} else {
+					X.b_up[x] = sl.sl, X.b_lo[x] = NIL;
+				}
+			} else {
+				side_id_or(t, zi, false, fl_id, fl_o);
+				const uint8_t sl_o = (sl_r == black) ? 0 : 1;
+				X.id1[x] = sl_id, X.or1[x] = (sl_o == 1 && fl_o == 1) ? 0 : sl_o;
+				X.id2[x] = fl_id, X.or2[x] = (sl_o == 1 && fl_o == 1) ? 0 : fl_o;
+				X.route[x] = 'L';
+				if (t.is_desc(zi, sl.sl))
+					X.b_up[x] = zi, X.b_lo[x] = sl.sl;
+				else
+					X.b_up[x] = sl.sl, X.b_lo[x] = zi;
+			}
+			S.push(f, v);
+			if (is_leaf)
+				continue;
+			// The nestings run over a COPY of the children and erase the ones that leave: a stable filter of the first nch
+			// entries (one pass; erasing them one by one is quadratic on a flubble with very many children)
+			const uint32_t nch = X.vn[xb + f], fb = X.vbeg[xb + f];
+			uint32_t w = 0;
+			for (uint32_t r = 0; r < nch; r++) {
+				const uint32_t ch = X.pool[fb + r];
+				bool moved = false;
+				if (S.fl_like(ch)) {
+					const uint32_t c_ai = X.ai[xb + ch], c_zi = X.zi[xb + ch];
+					if (sl.loc == CL_AI_TRUNK) { // nest_trunk_ai, :945-979
+						if (t.depth[sl.sl] > t.depth[c_zi] || t.is_desc(sl.sl, c_ai)) {
+							S.push(v, ch);
+							moved = true;
+						}
+					} else if (sl.loc == CL_AI_BRANCH) { // nest_branch_ai, :984-1034
+						bool has_br = false; // a bracket of the child's zi that STARTS at ai (sic: get_src, :1006)
+						for (uint32_t b = t.br_off[c_zi]; b < t.br_off[c_zi + 1] && !has_br; b++)
+							has_br = t.b_src[t.br_be[b]] == ai;
+						if (t.is_desc(sl.sl, c_ai) && has_br) {
+							S.push(v, ch);
+							moved = true;
+						}
+					} else if (sl.loc == CL_ZI_TRUNK) { // nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
+						if (t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi)) {
+							S.push(ch, v);
+							moved = true;
+						}
+					}
+					// zi_branch: add_conc_zi asks for ai_branch (:1134) and ends in "sl type: unknown"
+				}
+				if (!moved)
+					X.pool[X.vbeg[xb + f] + w++] = ch; // (vbeg again: f's own vector never moves here, but stay literal about it)
+			}
+			X.vn[xb + f] = w;
+		}
+	}
+	const uint32_t n_cn = nx - n0;
+	// ---- find_midi, midi.cpp:225-268 (the branch case is undefined in the reference: nothing comes of it), add_midi :19-61
+	const uint32_t n1 = nx;
+	for (uint32_t f = 1; f < n0; f++) {
+		if (X.fam[xb + f] != FAM_FLUBBLE)
+			continue;
+		uint32_t n_c = 0, n_trunk = 0, trunk[2] = {NIL, NIL};
+		const uint32_t zi = X.zi[xb + f];
+		for (uint32_t k = 0; k < X.vn[xb + f]; k++) {
+			const uint32_t ch = X.pool[X.vbeg[xb + f] + k];
+			if (X.fam[xb + ch] != FAM_CONCEALED)
+				continue;
+			n_c++;
+			if (X.sl[xb + ch] < zi) { // in_trunk, :163-166
+				if (n_trunk < 2)
+					trunk[n_trunk] = ch;
+				n_trunk++;
+			}
+		}
+		if (n_c < 2 || n_trunk != 2)
+			continue;
+		uint32_t g_idx = NIL, s_idx = NIL;
+		for (int k = 0; k < 2; k++) {
+			const uint8_t loc = X.loc[xb + trunk[k]];
+			if (loc == CL_AI_BRANCH || loc == CL_AI_TRUNK)
+				g_idx = trunk[k];
+			else
+				s_idx = trunk[k];
+		}
+		if (g_idx == NIL || s_idx == NIL)
+			continue;
+		// (all midi bubbles are found before the first is added: remember the pair in the flubble's spare fields)
+		X.b_up[xb + f] = g_idx;
+		X.b_lo[xb + f] = s_idx;
+	}
+	for (uint32_t f = 1; f < n0; f++) {
+		if (X.fam[xb + f] != FAM_FLUBBLE || X.b_up[xb + f] == NIL)
+			continue;
+		const uint32_t g_idx = X.b_up[xb + f], s_idx = X.b_lo[xb + f];
+		const uint32_t up = min(g_idx, s_idx), lo = max(g_idx, s_idx);
+		const uint32_t nch = X.vn[xb + f]; // children before the midi bubble is attached
+		const uint32_t v = new_vertex(FAM_MIDI);
+		if (v == NIL)
+			return;
+		const uint32_t x = xb + v;
+		// cn_b of a concealed vertex: the second boundary when it was formed with a, the first with z (Concealed::as_str)
+		X.id1[x] = X.id2[xb + g_idx], X.or1[x] = X.or2[xb + g_idx];
+		X.id2[x] = X.id1[xb + s_idx], X.or2[x] = X.or1[xb + s_idx];
+		X.route[x] = 'L';
+		X.b_up[x] = up, X.b_lo[x] = lo;
+		S.push(f, v);
+		// (sic) spanning-tree depths at the PVST indices of the two concealed vertices; past the tree: +infinity
+		const uint32_t d_up = up < N ? t.dep(base + up) : 0xFFFFFFFFu, d_lo = lo < N ? t.dep(base + lo) : 0xFFFFFFFFu;
+		// the children before the bubble (a copy in the reference), filtered in one pass; the bubble itself sits behind them
+		uint32_t w = 0;
+		for (uint32_t r = 0; r < nch; r++) {
+			const uint32_t ch = X.pool[X.vbeg[xb + f] + r];
+			if (X.fam[xb + ch] == FAM_FLUBBLE && d_up < t.depth[X.ai[xb + ch]] && d_lo > t.depth[X.zi[xb + ch]])
+				S.push(v, ch);
+			else
+				X.pool[X.vbeg[xb + f] + w++] = ch;
+		}
+		X.pool[X.vbeg[xb + f] + w++] = v;
+		X.vn[xb + f] = w;
+	}
+	const uint32_t n_md = nx - n1;
+	// ---- add_smothered, smothered.cpp:349-383: the concealed vertices in ascending idx, their records in search order
+	const uint32_t n2 = nx;
+	for (uint32_t k = cn_b; k < cn_e; k++) {
+		const uint32_t cv = n0 + (k - cn_b); // the k-th slubble became the k-th concealed vertex
+		const bool is_g = cn[k].loc == CL_AI_TRUNK || cn[k].loc == CL_AI_BRANCH;
+		const uint32_t cnb_id = is_g ? X.id2[xb + cv] : X.id1[xb + cv];
+		const uint8_t cnb_or = is_g ? X.or2[xb + cv] : X.or1[xb + cv];
+		for (uint32_t r = smo_off[k]; r < smo_off[k + 1]; r++) {
+			const Smo &m = smo[r];
+			const uint32_t v = new_vertex(FAM_SMOTHERED);
+			if (v == NIL)
+				return;
+			const uint32_t x = xb + v;
+			const uint32_t sm_id = t.gid[m.sm_st];
+			const uint8_t sm_or = (t.flags[m.sm_st] & TF_TYPE_MASK) == 0u ? 1 : 0; // comp_e / comp_w: type l -> reverse
+			if ((m.flags & 2u) && (m.flags & 1u)) { // Smothered::as_str, pvst.hpp:612-636
+				X.id1[x] = cnb_id, X.or1[x] = cnb_or;
+				X.id2[x] = sm_id, X.or2[x] = sm_or;
+			} else {
+				X.id1[x] = sm_id, X.or1[x] = sm_or;
+				X.id2[x] = cnb_id, X.or2[x] = cnb_or;
+			}
+			X.route[x] = (m.flags & 2u) ? 'L' : 'R';
+			X.b_up[x] = m.b_up, X.b_lo[x] = m.b_lo;
+			S.push(cv, v);
+			// nest, :332-347: a range-for over children_v[cv] while del_edge erases from it, as libstdc++ runs it: the loop
+			// goes to the OLD end, the slots behind the live end hold what erase left there
+			const uint32_t old_end = X.vn[xb + cv];
+			for (uint32_t i = 0; i < old_end; i++) {
+				const uint32_t ch = X.pool[X.vbeg[xb + cv] + i];
+				uint32_t c_up, c_lo;
+				if (S.fl_like(ch))
+					c_up = X.ai[xb + ch], c_lo = X.zi[xb + ch];
+				else if (X.fam[xb + ch] == FAM_CONCEALED)
+					c_up = X.b_up[xb + ch], c_lo = X.b_lo[xb + ch];
+				else
+					continue;
+				if (c_up == NIL || c_lo == NIL)
+					continue;
+				if (t.is_desc(m.b_up, c_up) && t.is_desc(c_lo, m.b_lo)) {
+					S.erase(cv, ch);
+					S.push(v, ch);
+				}
+			}
+		}
+	}
+	counts[3 * c] = n_cn;
+	counts[3 * c + 1] = n_md;
+	counts[3 * c + 2] = nx - n2;
+}
+// sizes of the final children lists (one lane per X slot), then the lists themselves into one compact array
+__global__ void k_sub_child_counts(uint32_t NX, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ counts,
+				   const uint32_t *__restrict__ c_npvst, const CompAt comp_x, const uint32_t *__restrict__ vn,
+				   uint32_t *__restrict__ out)
+{
+	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x > NX)
+		return;
+	uint32_t n = 0;
+	if (x < NX) {
+		const uint32_t c = comp_x.of_slot(x); // (doff = xoff here)
+		const uint32_t nt = c_npvst[c] ? c_npvst[c] + counts[3 * c] + counts[3 * c + 1] + counts[3 * c + 2] : 0;
+		if (x - xoff[c] < nt)
+			n = vn[x];
+	}
+	out[x] = n;
+}
+__global__ void k_sub_child_gather(uint32_t NX, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ vbeg,
+				   const uint32_t *__restrict__ pool, uint32_t *__restrict__ out)
+{
+	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= NX)
+		return;
+	const uint32_t b = coff[x], n = coff[x + 1] - b;
+	for (uint32_t k = 0; k < n; k++)
+		out[b + k] = pool[vbeg[x] + k];
+}
+} // namespace
+
+void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, const TreeWs &tw, const LeafState &ls, uint32_t C,
+		     HostScratch &host, SubForest &out, hipStream_t s)
+{
+	const uint32_t V = sw.V, T = 2 * V + C;
+	const uint32_t NB0 = pw.nb0, NB = pw.nb0 + pw.ncap + pw.nsimp;
+	const uint32_t Q = (uint32_t)pw.d_total; // dense PVST slots
+	const LeafIn &in = ls.in;
+	std::deque<DevBuf> bufs; // (freed when the stage returns or throws)
+	auto dev32 = [&](size_t n) { return bufs.emplace_back().get<uint32_t>(n); };
+	auto dev8 = [&](size_t n) { return bufs.emplace_back().get<uint8_t>(n); };
+	const size_t tmp_bytes = scan_tmp_bytes(std::max<size_t>(std::max<size_t>(T, NB), Q) + 8);
+	void *tmp = bufs.emplace_back().get<char>(tmp_bytes);
+	uint32_t *err = dev32(4);
+	HIP_CHECK(hipMemsetAsync(err, 0, 16, s));
+
+	// ---- tables
+	uint32_t *depth = dev32((size_t)T + 16), *hi0 = dev32((size_t)T + 16), *eat = dev32((size_t)T + 16);
+	LAUNCH(k_sub_depth_hi0, (size_t)T + 1, s, T, sw.t_size, sw.t_depth, depth, hi0, eat);
+	uint32_t *ocnt = dev32((size_t)T + 2), *icnt = dev32((size_t)T + 2), *o_off = dev32((size_t)T + 2), *i_off = dev32((size_t)T + 2);
+	HIP_CHECK(hipMemsetAsync(ocnt, 0, ((size_t)T + 2) * 4, s));
+	HIP_CHECK(hipMemsetAsync(icnt, 0, ((size_t)T + 2) * 4, s));
+	LAUNCH(k_sub_edge_counts, NB, s, NB, NB0, pw.b_src, pw.b_tgt, pw.b_ord, ocnt, icnt, hi0, eat);
+	scan_exclusive_u32(ocnt, o_off, (size_t)T + 1, tmp, tmp_bytes, s);
+	scan_exclusive_u32(icnt, i_off, (size_t)T + 1, tmp, tmp_bytes, s);
+	uint32_t *o_adj = dev32((size_t)NB + 1), *i_adj = dev32((size_t)NB + 1);
+	HIP_CHECK(hipMemsetAsync(ocnt, 0, ((size_t)T + 2) * 4, s));
+	HIP_CHECK(hipMemsetAsync(icnt, 0, ((size_t)T + 2) * 4, s));
+	LAUNCH(k_sub_edge_fill, NB, s, NB, pw.b_src, pw.b_tgt, o_off, i_off, ocnt, icnt, o_adj, i_adj);
+	LAUNCH(k_sub_sort_rows_u32, T, s, T, o_off, o_adj);
+	LAUNCH(k_sub_sort_rows_u32, T, s, T, i_off, i_adj);
+	// literal hi
+	SegTree segH, segD;
+	segH.tree = dev32(SegTree::tree_words((size_t)T + 1) + 16);
+	segD.tree = dev32(SegTree::tree_words((size_t)T + 1) + 16);
+	seg_build(segH, hi0, (size_t)T + 1, s);
+	seg_build(segD, depth, (size_t)T + 1, s);
+	uint32_t *simp_ps = dev32((size_t)T + 4), *hi = dev32((size_t)T + 4);
+	scan_exclusive_u8(in.simp, simp_ps, (size_t)T + 1, nullptr, nullptr, 0, tmp, tmp_bytes, s);
+	const CompAt comp{cs.voff, pw.doff, C};
+	LAUNCH(k_sub_hi, T, s, T, sw.t_size, segH, simp_ps, comp, hi);
+	// creation keys of the ordinary edges
+	unsigned long long *ekey = bufs.emplace_back().get<unsigned long long>((size_t)NB0 + 2);
+	uint32_t *wbefore = dev32((size_t)T + 8), *wtail = dev32((size_t)T + 8);
+	HIP_CHECK(hipMemsetAsync(wbefore, 0, ((size_t)T + 8) * 4, s));
+	HIP_CHECK(hipMemsetAsync(wtail, 0, ((size_t)T + 8) * 4, s));
+	debug_edge_id_weights(cs, sw, tw, wbefore, wtail, s);
+	LAUNCH(k_sub_edge_keys, T, s, T, sw.t_size, in.out_ord, eat, wbefore, ekey);
+	// LoA
+	uint32_t *lo = dev32((size_t)T + 4), *heap = dev32((size_t)NB0 + 4);
+	LAUNCH(k_sub_lo, C, s, C, cs.voff, sw.c_ntree, sw.t_size, depth, in.out_ord, eat, pw.b_tgt, in.O, heap, lo);
+	// bracket table
+	uint32_t *br_cnt = dev32((size_t)T + 4), *br_off = dev32((size_t)T + 4);
+	LAUNCH(k_sub_br_counts, (size_t)T + 1, s, T, sw.t_size, in.gp, in.P, in.out_ord, in.nself, br_cnt);
+	scan_exclusive_u32(br_cnt, br_off, (size_t)T + 1, tmp, tmp_bytes, s);
+	const uint32_t n_br = host.read_u32(br_off + T, s);
+	if (n_br > 0x7FFFFFF0u)
+		throw HipError("subflubble passes: the bracket table (tree_utils.cpp:167-216 is quadratic on deep trees) has more than 2^31 entries");
+	uint32_t *br_be = dev32((size_t)n_br + 4);
+	HIP_CHECK(hipMemsetAsync(br_cnt, 0, ((size_t)T + 4) * 4, s));
+	LAUNCH(k_sub_br_fill, NB0, s, NB0, pw.b_src, pw.b_tgt, in.gp, br_off, br_cnt, br_be, err);
+	LAUNCH(k_sub_br_sort, T, s, T, br_off, br_be, ekey, pw.b_ord);
+
+	SubT t{};
+	t.T = T, t.C = C, t.NB0 = NB0, t.NB = NB;
+	t.voff = cs.voff, t.c_ntree = sw.c_ntree, t.doff = pw.doff, t.c_npvst = sw.c_npvst;
+	t.size = sw.t_size, t.gp = in.gp, t.nchild = in.nchild, t.depth = depth, t.gid = sw.t_gid, t.flags = sw.t_flags;
+	t.b_src = pw.b_src, t.b_tgt = pw.b_tgt, t.b_ord = pw.b_ord;
+	t.o_off = o_off, t.o_adj = o_adj, t.i_off = i_off, t.i_adj = i_adj;
+	t.br_off = br_off, t.br_be = br_be, t.lo = lo, t.hi = hi, t.ekey = ekey;
+	segD.val = depth;
+	t.segD = segD;
+	t.p_ai = ls.dense.ai, t.p_zi = ls.dense.zi, t.p_fam = ls.dense.fam;
+	t.p_parent = pw.d_parent, t.p_a = pw.d_a, t.p_z = pw.d_z, t.p_aor = pw.d_aor, t.p_zor = pw.d_zor;
+	t.err = err;
+
+	// ---- find_concealed: count, scan, emit
+	uint32_t *cn_cnt = dev32((size_t)Q + 4), *cn_off = dev32((size_t)Q + 4), *mn = dev32(2 * (size_t)Q + 4);
+	LAUNCH(k_sub_cn_count, (size_t)Q + 1, s, Q, t, comp, cn_cnt, mn);
+	scan_exclusive_u32(cn_cnt, cn_off, (size_t)Q + 1, tmp, tmp_bytes, s);
+	const uint32_t NC = host.read_u32(cn_off + Q, s);
+	Slub *cn = bufs.emplace_back().get<Slub>((size_t)NC + 1);
+	LAUNCH(k_sub_cn_emit, Q, s, Q, t, comp, cn_off, cn);
+	// ---- find_smothered: count, scan, emit
+	uint32_t *sm_cnt = dev32((size_t)NC + 4), *sm_off = dev32((size_t)NC + 4);
+	LAUNCH(k_sub_smo_count, (size_t)NC + 1, s, NC, t, comp, cn, sm_cnt);
+	scan_exclusive_u32(sm_cnt, sm_off, (size_t)NC + 1, tmp, tmp_bytes, s);
+	const uint32_t NS = host.read_u32(sm_off + NC, s);
+	Smo *smo = bufs.emplace_back().get<Smo>((size_t)NS + 1);
+	LAUNCH(k_sub_smo_emit, NC, s, NC, t, comp, cn, sm_off, smo);
+
+	// ---- layout of the splice: per component its stretch of X-space and of the vector pool
+	std::vector<uint32_t> h_doff((size_t)C + 1), h_np((size_t)C + 1), h_cnoff((size_t)Q + 1), h_smoff((size_t)NC + 1);
+	HIP_CHECK(hipMemcpyAsync(h_doff.data(), pw.doff, ((size_t)C + 1) * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(h_np.data(), sw.c_npvst, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(h_cnoff.data(), cn_off, ((size_t)Q + 1) * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(h_smoff.data(), sm_off, ((size_t)NC + 1) * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	std::vector<uint32_t> h_xoff((size_t)C + 1), h_poff((size_t)C + 1);
+	uint64_t xs = 0, ps = 0;
+	for (uint32_t c = 0; c < C; c++) {
+		h_xoff[c] = (uint32_t)xs;
+		h_poff[c] = (uint32_t)ps;
+		const uint64_t n0 = h_np[c];
+		if (n0) {
+			const uint32_t q0 = h_doff[c];
+			const uint64_t ncn = h_cnoff[q0 + n0] - h_cnoff[q0];
+			const uint64_t nsm = h_smoff[h_cnoff[q0 + n0]] - h_smoff[h_cnoff[q0]];
+			xs += 2 * n0 + ncn + nsm;
+			ps += 32 * n0 + 16 * (ncn + nsm) + 256;
+		}
+		if (xs > 0xFFFFFFF0ull || ps > 0xFFFFFFF0ull)
+			throw HipError("subflubble passes: more than 2^32 PVST vertices or child slots in one pass");
+	}
+	h_xoff[C] = (uint32_t)xs;
+	h_poff[C] = (uint32_t)ps;
+	const uint32_t NX = (uint32_t)xs;
+	uint32_t *xoff = dev32((size_t)C + 2), *poff = dev32((size_t)C + 2);
+	HIP_CHECK(hipMemcpyAsync(xoff, h_xoff.data(), ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemcpyAsync(poff, h_poff.data(), ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
+	XArrays X{};
+	X.fam = dev8((size_t)NX + 4), X.or1 = dev8((size_t)NX + 4), X.or2 = dev8((size_t)NX + 4), X.route = dev8((size_t)NX + 4);
+	X.loc = dev8((size_t)NX + 4);
+	X.id1 = dev32((size_t)NX + 4), X.id2 = dev32((size_t)NX + 4), X.ai = dev32((size_t)NX + 4), X.zi = dev32((size_t)NX + 4);
+	X.sl = dev32((size_t)NX + 4), X.b_up = dev32((size_t)NX + 4), X.b_lo = dev32((size_t)NX + 4);
+	X.vbeg = dev32((size_t)NX + 4), X.vn = dev32((size_t)NX + 4), X.vcap = dev32((size_t)NX + 4);
+	X.pool = dev32((size_t)ps + 4);
+	HIP_CHECK(hipMemsetAsync(X.vn, 0, ((size_t)NX + 4) * 4, s));
+	uint32_t *counts = dev32(3 * (size_t)C + 4);
+	LAUNCH(k_sub_splice, C, s, C, t, xoff, poff, cn_off, cn, mn, sm_off, smo, X, counts);
+	const uint32_t e = host.read_u32(err, s);
+	if (e & E_BR_ROW)
+		throw HipError("subflubble passes: a bracket row outgrew its count (internal)");
+	if (e & E_POOL)
+		throw HipError("subflubble passes: the children vectors outgrew their pool (internal sizing bug)");
+	if (e & E_LAYOUT)
+		throw HipError("subflubble passes: more inserted vertices than the layout has room for (internal sizing bug)");
+	// ---- the children lists, compact
+	uint32_t *ccnt = dev32((size_t)NX + 4), *coff = dev32((size_t)NX + 4);
+	const CompAt comp_x{cs.voff, xoff, C};
+	LAUNCH(k_sub_child_counts, (size_t)NX + 1, s, NX, xoff, counts, sw.c_npvst, comp_x, X.vn, ccnt);
+	scan_exclusive_u32(ccnt, coff, (size_t)NX + 1, tmp, tmp_bytes, s);
+	const uint32_t NCH = host.read_u32(coff + NX, s);
+	uint32_t *child = dev32((size_t)NCH + 4);
+	LAUNCH(k_sub_child_gather, NX, s, NX, coff, X.vbeg, X.pool, child);
+
+	// ---- to the host, one stretch per component
+	std::vector<uint8_t> h_fam(NX), h_or1(NX), h_or2(NX), h_route(NX);
+	std::vector<uint32_t> h_id1(NX), h_id2(NX), h_coff((size_t)NX + 1), h_child(NCH), h_counts(3 * (size_t)C);
+	auto d2h = [&](void *dst, const void *src, size_t bytes) {
+		if (bytes)
+			HIP_CHECK(copy_async(dst, src, bytes, hipMemcpyDeviceToHost, s));
+	};
+	d2h(h_fam.data(), X.fam, NX);
+	d2h(h_or1.data(), X.or1, NX);
+	d2h(h_or2.data(), X.or2, NX);
+	d2h(h_route.data(), X.route, NX);
+	d2h(h_id1.data(), X.id1, (size_t)NX * 4);
+	d2h(h_id2.data(), X.id2, (size_t)NX * 4);
+	d2h(h_coff.data(), coff, ((size_t)NX + 1) * 4);
+	d2h(h_child.data(), child, (size_t)NCH * 4);
+	d2h(h_counts.data(), counts, 3 * (size_t)C * 4);
+	HIP_CHECK(hipStreamSynchronize(s));
+	out = SubForest{};
+	out.voff.assign((size_t)C + 1, 0);
+	out.counts = h_counts;
+	out.coff.push_back(0);
+	for (uint32_t c = 0; c < C; c++) {
+		out.voff[c] = out.fam.size();
+		const uint32_t n0 = h_np[c];
+		if (!n0)
+			continue;
+		const uint32_t nt = n0 + h_counts[3 * c] + h_counts[3 * c + 1] + h_counts[3 * c + 2], xb = h_xoff[c];
+		for (uint32_t v = 0; v < nt; v++) {
+			const uint32_t x = xb + v;
+			out.fam.push_back(h_fam[x]);
+			out.or1.push_back(h_or1[x]);
+			out.or2.push_back(h_or2[x]);
+			out.route.push_back(h_route[x]);
+			out.id1.push_back(h_id1[x]);
+			out.id2.push_back(h_id2[x]);
+			for (uint32_t k = h_coff[x]; k < h_coff[x + 1]; k++)
+				out.child.push_back(h_child[k]);
+			out.coff.push_back(out.child.size());
+		}
+	}
+	out.voff[C] = out.fam.size();
+}
+
+} // namespace povu_hip

@@ -1,0 +1,31 @@
+// sub_kernels.hpp -- the three inserting passes of `povu decompose -s`: find_concealed, find_midi,
+// find_smothered, see sub_kernels.hip
+#pragma once
+#include "leaf_kernels.hpp"
+
+#include <vector>
+
+namespace povu_hip
+{
+
+// PVST line letters of the inserted vertices (include/povu/common/constants.hpp:53-60)
+static constexpr uint8_t FAM_CONCEALED = 'C', FAM_MIDI = 'M', FAM_SMOTHERED = 'S';
+
+// The PVSTs of one pass after all five passes of -s, on the host: component c owns the vertices [voff[c], voff[c + 1])
+// (its own numbering starts at 0 = the dummy root; the flubble-like vertices keep their indices, the inserted ones
+// follow) and every vertex its children in the reference's order.
+struct SubForest {
+	std::vector<uint64_t> voff;	     // [C + 1]
+	std::vector<uint8_t> fam, or1, or2, route; // per vertex: line letter, orientations ('>' = 0), 'L' / 'R' / 0
+	std::vector<uint32_t> id1, id2;	     // the two boundaries in print order
+	std::vector<uint64_t> coff;	     // [vertices + 1] children of a vertex: child[coff[x] .. coff[x + 1])
+	std::vector<uint32_t> child;	     // PVST indices inside the component
+	std::vector<uint32_t> counts;	     // [3 C] concealed, midi, smothered vertices per component
+};
+
+// Runs find_concealed, find_midi and find_smothered on the state leaf_prepare / leaf_dense left (an all-parallel pass whose
+// tree stage also wrote the depths).  Throws HipError when a table outgrows its bound.
+void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, const TreeWs &tw, const LeafState &ls, uint32_t C,
+		     HostScratch &host, SubForest &out, hipStream_t s);
+
+} // namespace povu_hip

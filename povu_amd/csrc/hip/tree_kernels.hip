@@ -1972,7 +1972,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
 	LAUNCH(k_tree_emit, std::max(V, C), s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
-	       sw.t_par, sw.t_size, sw.hairpins ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
+	       sw.t_par, sw.t_size, (sw.hairpins || sw.want_depth) ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
 	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags

@@ -38,7 +38,7 @@ static void usage(std::ostream &os)
 	      "        --output-dir=[output_dir]         Output directory [default: .]\n"
 	      "        -h, --hairpins                    Find hairpins in the variation graph [default: false]\n"
 	      "        -s, --subflubbles                 Find subflubbles in the variation graph [default: false]\n"
-	      "                                          (refused: only its first two passes are built, see --leaf-subflubbles)\n"
+	      "                                          (tiny, parallel, concealed, midi and smothered: T O C M S lines)\n"
 	      "        --leaf-subflubbles                Relabel leaf flubbles as tiny (T) / parallel (O): the find_tiny and\n"
 	      "                                          find_parallel passes of -s, without its three inserting passes\n"
 	      "        --gpus=[n]                        Shard the components over n GPUs of this node, one worker per GPU\n"

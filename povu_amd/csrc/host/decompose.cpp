@@ -131,7 +131,7 @@ void do_decompose_multi(const Config &cfg)
 	const double t2 = now_ms();
 	MultiSink sink{&cfg, (unsigned)std::max<size_t>(1, (size_t)std::max(1, cfg.threads) / devs.size())};
 	const uint32_t flags = (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | POVU_HIP_F_NO_STAGE_TIMES |
-			       (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u);
+			       (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u) | (cfg.subflubbles ? POVU_HIP_F_SUBFLUBBLES : 0u);
 	povu_hip_forest *f = povu_hip_multi_decompose(m, flags, multi_sink, &sink, err, sizeof err);
 	const double t3 = now_ms();
 	if (!f) {
@@ -218,13 +218,10 @@ std::vector<int> multi_devices(int gpus, const char *env, int visible)
 void do_decompose(const Config &cfg)
 {
 	const int ll = cfg.verbosity;
-	if (cfg.gpus > 1 && !cfg.subflubbles) {
+	if (cfg.gpus > 1) {
 		do_decompose_multi(cfg);
 		return;
 	}
-	if (cfg.subflubbles)
-		throw std::runtime_error("-s/--subflubbles is not part of the MI355X decompose path: of its five passes only find_tiny and "
-					 "find_parallel are built (--leaf-subflubbles); concealed, midi and smothered are not");
 	const double t0 = now_ms();
 	// the HIP runtime comes up (~0.1 s) while the GFA is being parsed
 	char err[512] = {0}, cerr_buf[512] = {0};
@@ -289,7 +286,7 @@ void do_decompose(const Config &cfg)
 		info("Finding components");
 	// per-stage HIP events only when the stage-cost lines will be printed
 	povu_hip_opts opts{0, 1, (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | (ll ? 0u : POVU_HIP_F_NO_STAGE_TIMES) |
-				    (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u)};
+				    (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u) | (cfg.subflubbles ? POVU_HIP_F_SUBFLUBBLES : 0u)};
 	const double t2 = now_ms();
 	povu_hip_forest *f = povu_hip_decompose(ctx, &opts, err, sizeof err);
 	const double t3 = now_ms();

@@ -27,6 +27,13 @@ class _Opts(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class _SubTree(C.Structure):
+    _fields_ = [("n_total", C.c_uint32), ("n_flubble_like", C.c_uint32), ("n_concealed", C.c_uint32), ("n_midi", C.c_uint32),
+                ("n_smothered", C.c_uint32), ("fam", C.POINTER(C.c_uint8)), ("or1", C.POINTER(C.c_uint8)),
+                ("or2", C.POINTER(C.c_uint8)), ("route", C.POINTER(C.c_uint8)), ("id1", C.POINTER(C.c_uint32)),
+                ("id2", C.POINTER(C.c_uint32)), ("child_off", C.POINTER(C.c_uint64)), ("child", C.POINTER(C.c_uint32))]
+
+
 class _Tree(C.Structure):
     _fields_ = [("component_id", C.c_uint32), ("n_vtx", C.c_uint32), ("n_links", C.c_uint32),
                 ("n_pvst", C.c_uint32), ("a_id", C.POINTER(C.c_uint32)), ("z_id", C.POINTER(C.c_uint32)),
@@ -63,6 +70,7 @@ F_ALL_VERTEX_CLASSES = 512
 F_CHECK_LAMINAR = 1024
 F_LEAF_SUBFLUBBLES = 2048
 F_ASYNC = 4096
+F_SUBFLUBBLES = 8192  # all five passes of -s (implies F_LEAF_SUBFLUBBLES): Forest.texts() then carry C / M / S lines
 
 _lib = None
 
@@ -100,6 +108,8 @@ def load_lib():
     l.povu_hip_forest_pass_ms.argtypes = [C.c_void_p]
     l.povu_hip_forest_span_ms.restype = C.c_double
     l.povu_hip_forest_span_ms.argtypes = [C.c_void_p, C.c_void_p]
+    l.povu_hip_forest_get_subtree.restype = C.c_int
+    l.povu_hip_forest_get_subtree.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     l.povu_hip_forest_get_sub.restype = C.c_int
     l.povu_hip_forest_get_sub.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)),
                                           C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint8))]
@@ -323,6 +333,24 @@ class Forest:
         n = t.n_pvst
         return (np.ctypeslib.as_array(ai, shape=(n,)).copy(), np.ctypeslib.as_array(zi, shape=(n,)).copy(),
                 np.ctypeslib.as_array(fam, shape=(n,)).copy())
+
+    def subtree(self, i: int):
+        """Tree i after all five passes of -s (a decompose with F_SUBFLUBBLES): dict of n_total, n_flubble_like, n_concealed,
+        n_midi, n_smothered, fam / or1 / or2 / route (uint8) and id1 / id2 (uint32) per vertex, child_off (uint64, relative) and
+        child (uint32): children of vertex v = child[child_off[v]:child_off[v + 1]]."""
+        st = _SubTree()
+        rc = self._lib.povu_hip_forest_get_subtree(self._h, i, C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"forest carries no subflubble trees (rc {rc})")
+        n = st.n_total
+        a8 = lambda p: np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+        a32 = lambda p: np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        off = np.ctypeslib.as_array(st.child_off, shape=(n + 1,)).copy()
+        lo, hi = int(off[0]), int(off[-1])
+        child = np.ctypeslib.as_array(st.child, shape=(max(hi, 1),))[lo:hi].copy()
+        return dict(n_total=n, n_flubble_like=st.n_flubble_like, n_concealed=st.n_concealed, n_midi=st.n_midi,
+                    n_smothered=st.n_smothered, fam=a8(st.fam), or1=a8(st.or1), or2=a8(st.or2), route=a8(st.route),
+                    id1=a32(st.id1), id2=a32(st.id2), child_off=off - lo, child=child)
 
     def raw(self):
         """Zero-copy view of the whole result: (uint8 block over the pinned host memory, total entries,

@@ -198,6 +198,4 @@ def test_cli_leaf_subflubbles(tmp_path):
     want = O.decompose(g, leaf=True)
     got = {int(p.stem): p.read_text() for p in out.glob("*.pvst")}
     assert got == want and any("\nT\t" in t for t in got.values())
-    # -s itself stays refused, and says which part exists
-    r = subprocess.run([POVU, "decompose", "-i", str(gfa), "-o", str(out), "-s"], capture_output=True, text=True)
-    assert r.returncode != 0 and "--leaf-subflubbles" in r.stderr
+    # (-s itself = all five passes: tests/test_gpu_subflubbles.py)

@@ -1,0 +1,120 @@
+"""GPU parity of ALL five passes of `povu decompose -s` (app/subcommand/decompose.cpp:63-70): POVU_HIP_F_SUBFLUBBLES through
+the C ABI against the oracle's sequential restatement (oracle/povu_oracle_sub.inc) -- the PVST text write_pvst makes of
+every tree after find_tiny, find_parallel, find_concealed, find_midi and find_smothered.  PARITY UNPINNED: the reference
+holds no T / O / C / M / S line anywhere; tests/test_oracle_subflubbles.py has the hand-traced case."""
+import collections
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from povu_amd import HipDecomposer, workloads as W
+from povu_amd.hip import F_SUBFLUBBLES
+from test_oracle import _load_gfa_links
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+POVU = os.path.join(ROOT, "povu_amd", "bin", "povu")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    d = HipDecomposer(0)
+    yield d
+    d.close()
+
+
+def check(hip, g):
+    hip.upload(g)
+    f = hip.decompose(flags=F_SUBFLUBBLES)
+    got, want = f.texts(), O.decompose(g, leaf=2)
+    assert got.keys() == want.keys()
+    seen = collections.Counter()
+    for c in want:
+        assert got[c] == want[c], f"component {c}:\n--- HIP\n{got[c]}\n--- oracle\n{want[c]}"
+        seen.update(l[0] for l in want[c].splitlines())
+    return seen
+
+
+def test_the_references_own_graphs(hip, golden_dir):
+    seen = collections.Counter()
+    for path in sorted(glob.glob(os.path.join(golden_dir, "gfa", "**", "*.gfa"), recursive=True)):
+        seen += check(hip, _load_gfa_links(path))
+    assert seen["C"] >= 10 and seen["M"] >= 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_small_random_graphs(hip, seed):
+    rng = np.random.default_rng(1000 + seed)
+    seen = collections.Counter()
+    for it in range(250):
+        nv = int(rng.integers(5, 30))
+        seen += check(hip, W.random_bidirected(nv, int(rng.integers(nv, 3 * nv)), int(rng.integers(1 << 30)), self_loops=bool(it % 2)))
+    assert seen["C"], seen
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bubble_zoo_and_hprc_shapes(hip, seed):
+    check(hip, W.bubble_zoo(20, 8, seed))
+    check(hip, W.hprc_shaped([3000, 1500], seed=seed))
+    check(hip, W.nested_towers(6, 3))
+    check(hip, W.chain_of_bubbles(200))
+
+
+def test_all_three_kinds_are_reached(hip):
+    """5 000 seeded random graphs: concealed, midi and smothered vertices all occur (and match)."""
+    rng = np.random.default_rng(3)
+    seen = collections.Counter()
+    for it in range(5000):
+        nv = int(rng.integers(5, 30))
+        seen += check(hip, W.random_bidirected(nv, int(rng.integers(nv, 3 * nv)), int(rng.integers(1 << 30)), self_loops=bool(it % 2)))
+    assert seen["C"] and seen["M"] and seen["S"], seen
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_larger_random_graphs_with_many_components(hip, seed):
+    rng = np.random.default_rng(50 + seed)
+    for nv, ne in [(300, 420), (2000, 2600), (2000, 5000), (20000, 26000)]:
+        check(hip, W.random_bidirected(nv, ne, int(rng.integers(1 << 30)), self_loops=bool(seed % 2)))
+
+
+def test_config_sized_graphs(hip):
+    """BASELINE configs 2 and 3 (chain of 10^6 segments; HPRC-shaped chromosome) and a tangled one: text of every PVST."""
+    check(hip, W.chain_of_bubbles(250000))
+    check(hip, W.hprc_shaped([600000, 200000], seed=5))
+    check(hip, W.hprc_tangled(100000, seed=7, tangle_every=5000, max_tangle=2000))
+
+
+def test_subtree_arrays_and_the_plain_forest(hip):
+    """povu_hip_forest_get_subtree: counts and letters agree with the text; without the flag the forest carries none."""
+    g = _load_gfa_links(os.path.join(ROOT, "tests", "golden", "gfa", "downstream_repetitive", "vcfwave-complex-decomposition.gfa"))
+    hip.upload(g)
+    f = hip.decompose(flags=F_SUBFLUBBLES)
+    st = f.subtree(0)
+    lines = [l.split("\t") for l in f.texts()[1].splitlines()[1:]]
+    assert st["n_total"] == len(lines) and bytes(st["fam"]).decode() == "".join(l[0] for l in lines)
+    assert (st["n_concealed"], st["n_midi"], st["n_smothered"]) == tuple(sum(l[0] == k for l in lines) for k in "CMS")
+    assert st["n_midi"] == 1  # (the reference's own graph with a midi bubble)
+    f0 = hip.decompose()
+    with pytest.raises(RuntimeError):
+        f0.subtree(0)
+
+
+def test_cli_subflubbles(tmp_path):
+    g = W.random_bidirected(400, 560, 11)
+    gfa = tmp_path / "g.gfa"
+    gfa.write_text(g.to_gfa())
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([POVU, "decompose", "-i", str(gfa), "-o", str(out), "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = O.decompose(g, leaf=2)
+    got = {int(p.stem): p.read_text() for p in out.glob("*.pvst")}
+    assert got == want
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    r = subprocess.run([POVU, "decompose", "-i", str(gfa), "-o", str(out2), "-s", "--gpus", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
