@@ -81,7 +81,7 @@ typedef struct {
 #define POVU_HIP_F_SPARSE_SPLITTERS 128u /* list ranking with 1-in-16 splitters instead of 1-in-8 (A/B testing) */
 #define POVU_HIP_F_ALL_VERTEX_CLASSES 512u /* number the cycle classes of all tree edges, not just the black ones the candidate stack holds (A/B testing) */
 #define POVU_HIP_F_CHECK_LAMINAR 1024u /* always run the laminarity check of the candidate stack's (prev, i) intervals; by default it only runs when the literal hi_2 rule capped differently from the second-highest reach, DESIGN.md section 4 has the proof for the other case (A/B testing, fuzzing) */
-#define POVU_HIP_F_LEAF_SUBFLUBBLES 2048u /* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) and find_parallel (parallel.cpp:263-287) on every PVST; the forest then also carries ai / zi and the line letter of every vertex (povu_hip_forest_get_sub).  Not the reference's whole `-s`: its three inserting passes are not built */
+#define POVU_HIP_F_LEAF_SUBFLUBBLES 2048u /* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) and find_parallel (parallel.cpp:263-287) on every PVST; the forest then also carries ai / zi and the line letter of every vertex (povu_hip_forest_get_sub).  Not the reference's whole `-s`: that is POVU_HIP_F_SUBFLUBBLES */
 #define POVU_HIP_F_SUBFLUBBLES 8192u /* all five passes of `-s` (app/subcommand/decompose.cpp:63-70): implies POVU_HIP_F_LEAF_SUBFLUBBLES, then find_concealed (concealed.cpp:1198-1243), find_midi (midi.cpp:225-268) and find_smothered (smothered.cpp:385-432) INSERT vertices into every PVST; the forest carries the extended trees (povu_hip_forest_get_subtree) and povu_hip_forest_pvst_text prints them.  Parity unpinned: the reference holds no T / O / C / M / S line; undefined behaviour of the reference is decided as oracle/povu_oracle_sub.inc lists */
 #define POVU_HIP_F_ASYNC 4096u /* povu_hip_decompose returns as soon as the forest is laid out -- tree table, sizes, the page-locked result block -- while the last kernels and the copy of the PVST arrays to the host are still in flight; povu_hip_forest_wait (or any accessor of the forest: they wait by themselves) completes it.  A second povu_hip_decompose on the same context may start at once: its kernels run while the copy engine still moves the first result over PCIe.  Ignored (the call completes before it returns) without POVU_HIP_F_NO_STAGE_TIMES, with hairpins, subflubble labels, the test modes, and when the pass needs the laminarity check */
 #define POVU_HIP_F_SORTED_ADJ 16u /* build the local adjacency with the radix sort hub graphs use (A/B testing) */

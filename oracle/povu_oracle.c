@@ -1178,9 +1178,8 @@ orc_pvst *orc_find_flubbles(orc_tree *t)
  *   - a back edge whose source is its target (a self loop on one side, spanning_tree.cpp:387-395) makes
  *     count_brackets subtract one at the vertex without ever adding it and sends the fill loop past the target to the
  *     root, over the ends of the blocks: here such an edge is in nobody's bracket table.
- * The three later passes (find_concealed, find_midi, find_smothered) insert vertices and are NOT restated (DESIGN.md
- * section 8): a PVST relabelled by these two passes is not the reference's `-s` output.  PARITY UNPINNED: no test,
- * fixture or golden file of the reference holds a T or O line. */
+ * The three later passes (find_concealed, find_midi, find_smothered) insert vertices: povu_oracle_sub.inc, included
+ * below.  PARITY UNPINNED: no test, fixture or golden file of the reference holds a T or O line. */
 /* which rule decided, summed over all calls since the last orc_leaf_stats(reset) -- coverage evidence for the tests */
 enum { LS_TINY_NO_Y, LS_TINY_BRACKET, LS_TINY_IDX_ORD, LS_TINY_IDX_EXTRA, LS_PAR_BRANCH_AI, LS_PAR_BRANCH_ZI, LS_PAR_TRUNK_AI,
        LS_PAR_TRUNK_ZI, LS_TRUNK_COND_B, LS_LEAVES, LS_TINY_IDX_ASKED, LS_N };

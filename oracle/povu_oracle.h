@@ -118,7 +118,7 @@ void orc_pvst_free(orc_pvst *p);
 /* find_flubbles, flubbles.cpp:721-745 */
 orc_pvst *orc_find_flubbles(orc_tree *t);
 /* the two relabelling passes of `-s`: find_tiny (tiny.cpp:100-129) + find_parallel (parallel.cpp:263-287) over
- * gen_tree_meta's bracket table (tree_utils.cpp:531-690); the three inserting passes are not restated.  Fills p->fam.
+ * gen_tree_meta's bracket table (tree_utils.cpp:531-690); the three inserting passes: orc_subflubbles_text.  Fills p->fam.
  * PARITY UNPINNED (the reference holds no T / O line anywhere). */
 void orc_leaf_subflubbles(const orc_tree *t, orc_pvst *p);
 /* when on, the decompose entry points and orc_dump_component run orc_leaf_subflubbles on every PVST */

@@ -19,7 +19,7 @@
 //
 // Undefined behaviour of the reference that the oracle DEFINES and this file follows (oracle/povu_oracle.c, "leaf
 // subflubble passes"): in_branch without a gray child of zi answers "no"; a back edge whose source is its target is in
-// no bracket table.  The three inserting passes (concealed, midi, smothered) are not built.
+// no bracket table.  The three inserting passes (concealed, midi, smothered) run after these two: sub_kernels.hip.
 // PARITY UNPINNED: the reference holds no T or O line anywhere; tests compare with the oracle's literal restatement.
 #include "leaf_kernels.hpp"
 

@@ -32,6 +32,10 @@
 
 #include "segtree.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <string>
 
@@ -292,24 +296,49 @@ __global__ void k_sub_br_counts(uint32_t T, const uint32_t *__restrict__ size, c
 		n = (P[v + size[v]] - P[v]) - (out_ord[v] - nself[v]);
 	cnt[v] = n;
 }
-__global__ void k_sub_br_fill(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt,
-			      const uint32_t *__restrict__ gp, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ cur,
-			      uint32_t *__restrict__ br_be, uint32_t *__restrict__ err)
+// the ordinary edges in source order (a source's edges are a stretch of the dense list in scan order; the stretches
+// themselves lie in no order): position O[u] + r holds the r-th edge of u
+__global__ void k_sub_edges_by_source(uint32_t T, const uint32_t *__restrict__ size, const uint32_t *__restrict__ out_ord,
+				      const uint32_t *__restrict__ eat, const uint32_t *__restrict__ O, const uint32_t *__restrict__ b_tgt,
+				      uint32_t *__restrict__ tgt_s, uint32_t *__restrict__ slot_s)
 {
-	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= NB0)
+	const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+	if (u >= T || !size[u])
 		return;
-	const uint32_t u = b_src[j], w = b_tgt[j];
-	if (u == w || gp[u] == NIL)
+	const uint32_t n = out_ord[u], at = eat[u], o = O[u];
+	for (uint32_t r = 0; r < n; r++) {
+		tgt_s[o + r] = b_tgt[at + r];
+		slot_s[o + r] = at + r;
+	}
+}
+// collect_backedges_by_vertex (tree_utils.cpp:167-216) from the vertex's side: the brackets of v are the edges whose source
+// lies strictly below v and whose target lies above it -- among the edges of the sources (v, v + size) those with a target
+// idx below v, found one after the other in a segment tree over the targets (a walk from every edge up its path, as the
+// reference does it, leaves one lane with a million steps when a link spans a chromosome)
+__global__ void k_sub_br_fill(uint32_t T, const uint32_t *__restrict__ size, const uint32_t *__restrict__ O, const SegTree segT,
+			      const uint32_t *__restrict__ slot_s, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ br_be,
+			      uint32_t *__restrict__ err)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
 		return;
-	for (uint32_t v = gp[u]; gp[v] != NIL && v != w; v = gp[v]) {
-		const uint32_t k = atomicAdd(&cur[v], 1u);
-		if (k >= br_off[v + 1] - br_off[v]) {
+	const uint32_t n = br_off[v + 1] - br_off[v];
+	if (!n)
+		return;
+	const uint32_t hi = O[v + size[v]];
+	uint32_t k = 0;
+	for (uint32_t p = O[v + 1]; p < hi; p++) {
+		p = seg_first_less(segT, p, hi, v);
+		if (p == NIL)
+			break;
+		if (k >= n) {
 			atomicOr(err, E_BR_ROW);
 			return;
 		}
-		br_be[br_off[v] + k] = j;
+		br_be[br_off[v] + k++] = slot_s[p];
 	}
+	if (k != n)
+		atomicOr(err, E_BR_ROW);
 }
 __global__ void k_sub_br_sort(uint32_t T, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ br_be,
 			      const unsigned long long *__restrict__ ekey, const uint32_t *__restrict__ b_ord)
@@ -322,15 +351,52 @@ __global__ void k_sub_br_sort(uint32_t T, const uint32_t *__restrict__ br_off, u
 		return kx != ky ? kx < ky : b_ord[x] < b_ord[y];
 	});
 }
+// LoA without self-loop back edges (see the proof in oracle/povu_oracle_sub.inc): lo[v] = the deepest target t < v of an
+// ordinary edge whose source lies behind v -- the largest left end among the intervals (t, s) that hold v.  Every edge marks
+// the canonical nodes of its interval in a max-tree over the vertex indices, every vertex reads the nodes above its leaf.
+__global__ void k_sub_lo_mark(uint32_t NB0, const uint32_t *__restrict__ b_src, const uint32_t *__restrict__ b_tgt, uint32_t P2,
+			      uint32_t *__restrict__ tree)
+{
+	const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= NB0)
+		return;
+	const uint32_t sv = b_src[j], tv = b_tgt[j];
+	if (sv <= tv + 1)
+		return;
+	for (uint32_t l = tv + 1 + P2, r = sv + P2; l < r; l >>= 1, r >>= 1) {
+		if (l & 1)
+			atomicMax(&tree[l++], tv + 1);
+		if (r & 1)
+			atomicMax(&tree[--r], tv + 1);
+	}
+}
+__global__ void k_sub_lo_query(uint32_t T, const uint32_t *__restrict__ size, uint32_t P2, const uint32_t *__restrict__ tree,
+			       const uint32_t *__restrict__ nself, const CompAt comp, uint32_t *__restrict__ lo, uint32_t *__restrict__ has_self)
+{
+	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= T)
+		return;
+	if (!size[v]) {
+		lo[v] = NIL;
+		return;
+	}
+	if (nself[v])
+		has_self[comp.of_tree(v)] = 1; // (this component's values are overwritten by the literal heap below)
+	uint32_t m = 0;
+	for (uint32_t x = v + P2; x >= 1; x >>= 1)
+		m = max(m, tree[x]);
+	lo[v] = m ? m - 1 : NIL;
+}
 // compute_LoA, tree_utils.cpp:224-273, with the heap steps of libstdc++ (push_heap; pop_heap = __adjust_heap to the bottom,
-// then __push_heap): one lane per component, its heap in the stretch of `heap` its ordinary edges number
+// then __push_heap): one lane per component THAT HAS a self-loop back edge, its heap in the stretch of `heap` its ordinary
+// edges number
 __global__ void k_sub_lo(uint32_t C, const uint32_t *__restrict__ voff, const uint32_t *__restrict__ c_ntree,
 			 const uint32_t *__restrict__ size, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ out_ord,
 			 const uint32_t *__restrict__ eat, const uint32_t *__restrict__ b_tgt, const uint32_t *__restrict__ O,
-			 uint32_t *__restrict__ heap_all, uint32_t *__restrict__ lo)
+			 const uint32_t *__restrict__ has_self, uint32_t *__restrict__ heap_all, uint32_t *__restrict__ lo)
 {
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= C || !c_ntree[c])
+	if (c >= C || !c_ntree[c] || !has_self[c])
 		return;
 	const uint32_t base = 2 * voff[c] + c, N = c_ntree[c];
 	uint32_t *heap = heap_all + O[base];
@@ -873,6 +939,63 @@ __device__ __forceinline__ void side_id_or(const SubT &t, uint32_t v, bool fwd_i
 	const bool is_r = (t.flags[v] & TF_TYPE_MASK) == 1u;
 	orr = (is_r == fwd_is_r) ? 0 : 1;
 }
+// the PVST as find_flubbles left it, in X-space: fields of every vertex and the capacity of its children vector (one lane
+// per dense PVST slot); then the vectors themselves, children in ascending idx (add_flubbles attaches them in that order)
+__global__ void k_sub_x_init(uint32_t Q, const SubT t, const CompAt comp, const uint32_t *__restrict__ xoff, XArrays X)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= Q)
+		return;
+	const uint32_t c = comp.of_slot(q), v = q - t.doff[c], x = xoff[c] + v, base = t.base_of(c);
+	X.fam[x] = t.p_fam[q];
+	X.loc[x] = 0;
+	X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
+	if (v) {
+		X.id1[x] = t.p_a[q], X.or1[x] = t.p_aor[q];
+		X.id2[x] = t.p_z[q], X.or2[x] = t.p_zor[q];
+		X.route[x] = 'L';
+		X.ai[x] = base + t.p_ai[q], X.zi[x] = base + t.p_zi[q];
+		atomicAdd(&X.vcap[xoff[c] + t.p_parent[q]], 1u);
+	} else {
+		X.id1[x] = X.id2[x] = NIL;
+		X.or1[x] = X.or2[x] = 0;
+		X.route[x] = 0;
+		X.ai[x] = X.zi[x] = NIL;
+	}
+}
+__global__ void k_sub_x_vbeg(uint32_t Q, const SubT t, const CompAt comp, const uint32_t *__restrict__ xoff,
+			     const uint32_t *__restrict__ poff, const uint32_t *__restrict__ cap_ps, XArrays X)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= Q)
+		return;
+	const uint32_t c = comp.of_slot(q), x = xoff[c] + (q - t.doff[c]);
+	X.vbeg[x] = poff[c] + (cap_ps[x] - cap_ps[xoff[c]]);
+	X.vn[x] = X.vcap[x];
+}
+// children in ascending idx: a stable sort of (X slot of the parent, child) over the dense slots, which are in ascending
+// idx already (one lane sorting the million children of a chromosome's root took seconds)
+__global__ void k_sub_x_keys(uint32_t Q, uint32_t NX, const SubT t, const CompAt comp, const uint32_t *__restrict__ xoff,
+			     uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= Q)
+		return;
+	const uint32_t c = comp.of_slot(q), v = q - t.doff[c];
+	key[q] = v ? xoff[c] + t.p_parent[q] : NX; // (the roots have no parent: behind everything)
+	val[q] = v;
+}
+__global__ void k_sub_x_place(uint32_t Q, uint32_t NX, const uint32_t *__restrict__ key, const uint32_t *__restrict__ val,
+			      const uint32_t *__restrict__ cap_ps, XArrays X)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= Q)
+		return;
+	const uint32_t x = key[i];
+	if (x >= NX)
+		return;
+	X.pool[X.vbeg[x] + (i - cap_ps[x])] = val[i];
+}
 __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ poff,
 			     const uint32_t *__restrict__ cn_off, const Slub *__restrict__ cn, const uint32_t *__restrict__ mn,
 			     const uint32_t *__restrict__ smo_off, const Smo *__restrict__ smo, XArrays X, uint32_t *__restrict__ counts)
@@ -887,42 +1010,22 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 	const uint32_t q0 = t.doff[c], base = t.base_of(c), N = t.c_ntree[c];
 	Splice S{X, xoff[c], poff[c], poff[c + 1], t.err};
 	const uint32_t xb = S.xb, cap_x = xoff[c + 1] - xoff[c];
-	// the PVST as find_flubbles left it (children in ascending idx: add_flubbles attaches them in that order)
-	for (uint32_t v = 0; v < n0; v++) {
-		const uint32_t q = q0 + v, x = xb + v;
-		X.fam[x] = t.p_fam[q];
-		X.vn[x] = X.vcap[x] = 0;
-		X.vbeg[x] = 0;
-		X.loc[x] = 0;
-		X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
-		if (v) {
-			X.id1[x] = t.p_a[q], X.or1[x] = t.p_aor[q];
-			X.id2[x] = t.p_z[q], X.or2[x] = t.p_zor[q];
-			X.route[x] = 'L';
-			X.ai[x] = base + t.p_ai[q], X.zi[x] = base + t.p_zi[q];
-		} else {
-			X.id1[x] = X.id2[x] = NIL;
-			X.or1[x] = X.or2[x] = 0;
-			X.route[x] = 0;
-			X.ai[x] = X.zi[x] = NIL;
+	// (the vertices of find_flubbles and their children vectors are in place: k_sub_x_init .. k_sub_x_sort)  Behind them in the
+	// pool: the list of the flubbles that got a concealed vertex as a child (find_midi looks at no others)
+	S.pool_top += n0 - 1;
+	uint32_t *touched = X.pool + S.pool_top;
+	uint32_t n_touched = 0;
+	S.pool_top += n0;
+	if (S.pool_top > S.pool_end) {
+		atomicOr(t.err, E_POOL);
+		return;
+	}
+	auto touch = [&](uint32_t f) {
+		if (!X.loc[xb + f]) {
+			X.loc[xb + f] = 1;
+			touched[n_touched++] = f;
 		}
-	}
-	// exact capacities for the initial vectors
-	for (uint32_t v = 1; v < n0; v++)
-		X.vcap[xb + t.p_parent[q0 + v]]++;
-	for (uint32_t v = 0; v < n0; v++) {
-		const uint32_t x = xb + v, k = X.vcap[x];
-		if (S.pool_top + k > S.pool_end) {
-			atomicOr(t.err, E_POOL);
-			return;
-		}
-		X.vbeg[x] = S.pool_top;
-		S.pool_top += k;
-	}
-	for (uint32_t v = 1; v < n0; v++) {
-		const uint32_t p = xb + t.p_parent[q0 + v];
-		X.pool[X.vbeg[p] + X.vn[p]++] = v;
-	}
+	};
 	uint32_t nx = n0; // vertices so far
 	auto new_vertex = [&](uint8_t fam) -> uint32_t {
 		if (nx >= cap_x) {
@@ -991,6 +1094,7 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 					X.b_up[x] = sl.sl, X.b_lo[x] = zi;
 			}
 			S.push(f, v);
+			touch(f);
 			if (is_leaf)
 				continue;
 			// The nestings run over a COPY of the children and erase the ones that leave: a stable filter of the first nch
@@ -1018,6 +1122,7 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 					} else if (sl.loc == CL_ZI_TRUNK) { // nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
 						if (t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi)) {
 							S.push(ch, v);
+							touch(ch);
 							moved = true;
 						}
 					}
@@ -1032,7 +1137,9 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 	const uint32_t n_cn = nx - n0;
 	// ---- find_midi, midi.cpp:225-268 (the branch case is undefined in the reference: nothing comes of it), add_midi :19-61
 	const uint32_t n1 = nx;
-	for (uint32_t f = 1; f < n0; f++) {
+	sort_row(touched, n_touched, [](uint32_t a, uint32_t b) { return a < b; });
+	for (uint32_t k_t = 0; k_t < n_touched; k_t++) {
+		const uint32_t f = touched[k_t];
 		if (X.fam[xb + f] != FAM_FLUBBLE)
 			continue;
 		uint32_t n_c = 0, n_trunk = 0, trunk[2] = {NIL, NIL};
@@ -1064,7 +1171,8 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 		X.b_up[xb + f] = g_idx;
 		X.b_lo[xb + f] = s_idx;
 	}
-	for (uint32_t f = 1; f < n0; f++) {
+	for (uint32_t k_t = 0; k_t < n_touched; k_t++) {
+		const uint32_t f = touched[k_t];
 		if (X.fam[xb + f] != FAM_FLUBBLE || X.b_up[xb + f] == NIL)
 			continue;
 		const uint32_t g_idx = X.b_up[xb + f], s_idx = X.b_lo[xb + f];
@@ -1181,6 +1289,18 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	const uint32_t NB0 = pw.nb0, NB = pw.nb0 + pw.ncap + pw.nsimp;
 	const uint32_t Q = (uint32_t)pw.d_total; // dense PVST slots
 	const LeafIn &in = ls.in;
+	// POVU_HIP_SUB_TIMES=1: wall-clock of the phases on stderr (each mark synchronises the stream)
+	const bool times = getenv("POVU_HIP_SUB_TIMES") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_prev = now();
+	auto mark = [&](const char *what) {
+		if (!times)
+			return;
+		HIP_CHECK(hipStreamSynchronize(s));
+		const double t_now = now();
+		fprintf(stderr, "[subflubbles] %-22s %9.1f ms\n", what, t_now - t_prev);
+		t_prev = t_now;
+	};
 	std::deque<DevBuf> bufs; // (freed when the stage returns or throws)
 	auto dev32 = [&](size_t n) { return bufs.emplace_back().get<uint32_t>(n); };
 	auto dev8 = [&](size_t n) { return bufs.emplace_back().get<uint8_t>(n); };
@@ -1214,6 +1334,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	scan_exclusive_u8(in.simp, simp_ps, (size_t)T + 1, nullptr, nullptr, 0, tmp, tmp_bytes, s);
 	const CompAt comp{cs.voff, pw.doff, C};
 	LAUNCH(k_sub_hi, T, s, T, sw.t_size, segH, simp_ps, comp, hi);
+	mark("edge tables, hi");
 	// creation keys of the ordinary edges
 	unsigned long long *ekey = bufs.emplace_back().get<unsigned long long>((size_t)NB0 + 2);
 	uint32_t *wbefore = dev32((size_t)T + 8), *wtail = dev32((size_t)T + 8);
@@ -1222,8 +1343,17 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	debug_edge_id_weights(cs, sw, tw, wbefore, wtail, s);
 	LAUNCH(k_sub_edge_keys, T, s, T, sw.t_size, in.out_ord, eat, wbefore, ekey);
 	// LoA
-	uint32_t *lo = dev32((size_t)T + 4), *heap = dev32((size_t)NB0 + 4);
-	LAUNCH(k_sub_lo, C, s, C, cs.voff, sw.c_ntree, sw.t_size, depth, in.out_ord, eat, pw.b_tgt, in.O, heap, lo);
+	uint32_t *lo = dev32((size_t)T + 4), *heap = dev32((size_t)NB0 + 4), *has_self = dev32((size_t)C + 4);
+	{
+		const uint32_t P2 = SegTree::pow2((size_t)T + 1);
+		uint32_t *mx = dev32(2 * (size_t)P2 + 4);
+		HIP_CHECK(hipMemsetAsync(mx, 0, (2 * (size_t)P2 + 4) * 4, s));
+		HIP_CHECK(hipMemsetAsync(has_self, 0, ((size_t)C + 4) * 4, s));
+		LAUNCH(k_sub_lo_mark, NB0, s, NB0, pw.b_src, pw.b_tgt, P2, mx);
+		LAUNCH(k_sub_lo_query, T, s, T, sw.t_size, P2, mx, in.nself, comp, lo, has_self);
+		LAUNCH(k_sub_lo, C, s, C, cs.voff, sw.c_ntree, sw.t_size, depth, in.out_ord, eat, pw.b_tgt, in.O, has_self, heap, lo);
+	}
+	mark("creation keys, lo");
 	// bracket table
 	uint32_t *br_cnt = dev32((size_t)T + 4), *br_off = dev32((size_t)T + 4);
 	LAUNCH(k_sub_br_counts, (size_t)T + 1, s, T, sw.t_size, in.gp, in.P, in.out_ord, in.nself, br_cnt);
@@ -1232,9 +1362,14 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	if (n_br > 0x7FFFFFF0u)
 		throw HipError("subflubble passes: the bracket table (tree_utils.cpp:167-216 is quadratic on deep trees) has more than 2^31 entries");
 	uint32_t *br_be = dev32((size_t)n_br + 4);
-	HIP_CHECK(hipMemsetAsync(br_cnt, 0, ((size_t)T + 4) * 4, s));
-	LAUNCH(k_sub_br_fill, NB0, s, NB0, pw.b_src, pw.b_tgt, in.gp, br_off, br_cnt, br_be, err);
+	uint32_t *tgt_s = dev32((size_t)NB0 + 32), *slot_s = dev32((size_t)NB0 + 32);
+	LAUNCH(k_sub_edges_by_source, T, s, T, sw.t_size, in.out_ord, eat, in.O, pw.b_tgt, tgt_s, slot_s);
+	SegTree segT;
+	segT.tree = dev32(SegTree::tree_words((size_t)NB0 + 1) + 16);
+	seg_build(segT, tgt_s, NB0, s);
+	LAUNCH(k_sub_br_fill, T, s, T, sw.t_size, in.O, segT, slot_s, br_off, br_be, err);
 	LAUNCH(k_sub_br_sort, T, s, T, br_off, br_be, ekey, pw.b_ord);
+	mark("bracket table");
 
 	SubT t{};
 	t.T = T, t.C = C, t.NB0 = NB0, t.NB = NB;
@@ -1256,6 +1391,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	const uint32_t NC = host.read_u32(cn_off + Q, s);
 	Slub *cn = bufs.emplace_back().get<Slub>((size_t)NC + 1);
 	LAUNCH(k_sub_cn_emit, Q, s, Q, t, comp, cn_off, cn);
+	mark("find_concealed search");
 	// ---- find_smothered: count, scan, emit
 	uint32_t *sm_cnt = dev32((size_t)NC + 4), *sm_off = dev32((size_t)NC + 4);
 	LAUNCH(k_sub_smo_count, (size_t)NC + 1, s, NC, t, comp, cn, sm_cnt);
@@ -1263,6 +1399,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	const uint32_t NS = host.read_u32(sm_off + NC, s);
 	Smo *smo = bufs.emplace_back().get<Smo>((size_t)NS + 1);
 	LAUNCH(k_sub_smo_emit, NC, s, NC, t, comp, cn, sm_off, smo);
+	mark("find_smothered search");
 
 	// ---- layout of the splice: per component its stretch of X-space and of the vector pool
 	std::vector<uint32_t> h_doff((size_t)C + 1), h_np((size_t)C + 1), h_cnoff((size_t)Q + 1), h_smoff((size_t)NC + 1);
@@ -1301,8 +1438,26 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	X.vbeg = dev32((size_t)NX + 4), X.vn = dev32((size_t)NX + 4), X.vcap = dev32((size_t)NX + 4);
 	X.pool = dev32((size_t)ps + 4);
 	HIP_CHECK(hipMemsetAsync(X.vn, 0, ((size_t)NX + 4) * 4, s));
+	HIP_CHECK(hipMemsetAsync(X.vcap, 0, ((size_t)NX + 4) * 4, s));
+	const CompAt comp_q{cs.voff, pw.doff, C};
+	uint32_t *cap_ps = dev32((size_t)NX + 4);
+	const size_t tmpx_bytes = scan_tmp_bytes((size_t)NX + 8);
+	void *tmpx = bufs.emplace_back().get<char>(tmpx_bytes);
+	LAUNCH(k_sub_x_init, Q, s, Q, t, comp_q, xoff, X);
+	scan_exclusive_u32(X.vcap, cap_ps, (size_t)NX + 1, tmpx, tmpx_bytes, s);
+	LAUNCH(k_sub_x_vbeg, Q, s, Q, t, comp_q, xoff, poff, cap_ps, X);
+	{
+		uint32_t *k0 = dev32((size_t)Q + 4), *k1 = dev32((size_t)Q + 4), *v0 = dev32((size_t)Q + 4), *v1 = dev32((size_t)Q + 4);
+		const size_t sort_bytes = sort_tmp_bytes((size_t)Q + 8);
+		void *sort_tmp = bufs.emplace_back().get<char>(sort_bytes);
+		LAUNCH(k_sub_x_keys, Q, s, Q, NX, t, comp_q, xoff, k0, v0);
+		sort_pairs_u32(k0, k1, v0, v1, Q, bits_for(NX), sort_tmp, sort_bytes, s);
+		LAUNCH(k_sub_x_place, Q, s, Q, NX, k1, v1, cap_ps, X);
+	}
+	mark("layout, PVST vectors");
 	uint32_t *counts = dev32(3 * (size_t)C + 4);
 	LAUNCH(k_sub_splice, C, s, C, t, xoff, poff, cn_off, cn, mn, sm_off, smo, X, counts);
+	mark("splice");
 	const uint32_t e = host.read_u32(err, s);
 	if (e & E_BR_ROW)
 		throw HipError("subflubble passes: a bracket row outgrew its count (internal)");
@@ -1314,10 +1469,11 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	uint32_t *ccnt = dev32((size_t)NX + 4), *coff = dev32((size_t)NX + 4);
 	const CompAt comp_x{cs.voff, xoff, C};
 	LAUNCH(k_sub_child_counts, (size_t)NX + 1, s, NX, xoff, counts, sw.c_npvst, comp_x, X.vn, ccnt);
-	scan_exclusive_u32(ccnt, coff, (size_t)NX + 1, tmp, tmp_bytes, s);
+	scan_exclusive_u32(ccnt, coff, (size_t)NX + 1, tmpx, tmpx_bytes, s);
 	const uint32_t NCH = host.read_u32(coff + NX, s);
 	uint32_t *child = dev32((size_t)NCH + 4);
 	LAUNCH(k_sub_child_gather, NX, s, NX, coff, X.vbeg, X.pool, child);
+	mark("children lists");
 
 	// ---- to the host, one stretch per component
 	std::vector<uint8_t> h_fam(NX), h_or1(NX), h_or2(NX), h_route(NX);
@@ -1339,27 +1495,37 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	out = SubForest{};
 	out.voff.assign((size_t)C + 1, 0);
 	out.counts = h_counts;
-	out.coff.push_back(0);
+	uint64_t n_vtx = 0, n_child = 0;
 	for (uint32_t c = 0; c < C; c++) {
-		out.voff[c] = out.fam.size();
-		const uint32_t n0 = h_np[c];
-		if (!n0)
+		out.voff[c] = n_vtx;
+		if (!h_np[c])
 			continue;
-		const uint32_t nt = n0 + h_counts[3 * c] + h_counts[3 * c + 1] + h_counts[3 * c + 2], xb = h_xoff[c];
-		for (uint32_t v = 0; v < nt; v++) {
-			const uint32_t x = xb + v;
-			out.fam.push_back(h_fam[x]);
-			out.or1.push_back(h_or1[x]);
-			out.or2.push_back(h_or2[x]);
-			out.route.push_back(h_route[x]);
-			out.id1.push_back(h_id1[x]);
-			out.id2.push_back(h_id2[x]);
-			for (uint32_t k = h_coff[x]; k < h_coff[x + 1]; k++)
-				out.child.push_back(h_child[k]);
-			out.coff.push_back(out.child.size());
-		}
+		const uint32_t nt = h_np[c] + h_counts[3 * c] + h_counts[3 * c + 1] + h_counts[3 * c + 2], xb = h_xoff[c];
+		n_vtx += nt;
+		n_child += h_coff[xb + nt] - h_coff[xb];
 	}
-	out.voff[C] = out.fam.size();
+	out.voff[C] = n_vtx;
+	out.fam.resize(n_vtx), out.or1.resize(n_vtx), out.or2.resize(n_vtx), out.route.resize(n_vtx);
+	out.id1.resize(n_vtx), out.id2.resize(n_vtx), out.coff.resize(n_vtx + 1), out.child.resize(n_child);
+	uint64_t cw = 0;
+	for (uint32_t c = 0; c < C; c++) { // a component's vertices and children are one stretch each (the slots behind its last vertex hold no list)
+		if (!h_np[c])
+			continue;
+		const uint64_t vb = out.voff[c], nt = out.voff[c + 1] - vb;
+		const uint32_t xb = h_xoff[c], c0 = h_coff[xb], c1 = h_coff[xb + nt];
+		memcpy(out.fam.data() + vb, h_fam.data() + xb, nt);
+		memcpy(out.or1.data() + vb, h_or1.data() + xb, nt);
+		memcpy(out.or2.data() + vb, h_or2.data() + xb, nt);
+		memcpy(out.route.data() + vb, h_route.data() + xb, nt);
+		memcpy(out.id1.data() + vb, h_id1.data() + xb, nt * 4);
+		memcpy(out.id2.data() + vb, h_id2.data() + xb, nt * 4);
+		for (uint64_t v = 0; v < nt; v++)
+			out.coff[vb + v] = cw + (h_coff[xb + v] - c0);
+		memcpy(out.child.data() + cw, h_child.data() + c0, (size_t)(c1 - c0) * 4);
+		cw += c1 - c0;
+	}
+	out.coff[n_vtx] = cw;
+	mark("to the host");
 }
 
 } // namespace povu_hip

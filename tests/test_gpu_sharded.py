@@ -281,6 +281,8 @@ def test_one_process_engine_three_ranks_on_one_device():
     assert f2.texts() == want and f.texts() == want
     # what does not travel between processes does move inside one: subflubble labels and hairpin boundaries
     assert md.decompose(F_LEAF_SUBFLUBBLES).texts() == O.decompose(g, leaf=True)
+    from povu_amd.hip import F_SUBFLUBBLES
+    assert md.decompose(F_SUBFLUBBLES).texts() == O.decompose(g, leaf=2)  # all five passes of -s: the extended trees move too
     one = HipDecomposer(0)
     one.upload(g)
     fh1, fhm = one.decompose(flags=F_HAIRPINS), md.decompose(F_HAIRPINS)

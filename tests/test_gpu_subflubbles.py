@@ -4,6 +4,7 @@ every tree after find_tiny, find_parallel, find_concealed, find_midi and find_sm
 holds no T / O / C / M / S line anywhere; tests/test_oracle_subflubbles.py has the hand-traced case."""
 import collections
 import glob
+import hashlib
 import os
 import subprocess
 
@@ -118,3 +119,17 @@ def test_cli_subflubbles(tmp_path):
     out2.mkdir()
     r = subprocess.run([POVU, "decompose", "-i", str(gfa), "-o", str(out2), "-s", "--gpus", "1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_config4_whole_genome_full_size_all_five_passes(hip):
+    """BASELINE config 4 at full size (10^8 segments, 2 024 components): the text of every PVST after all five passes, by
+    md5, against the oracle on all host cores."""
+    g = W.hprc_whole_genome(1e8)
+    hip.upload(g)
+    f = hip.decompose(flags=F_SUBFLUBBLES)
+    got = {k: hashlib.md5(v.encode()).hexdigest() for k, v in f.texts().items()}
+    n_c = sum(f.subtree(i)["n_concealed"] for i in range(len(f)))
+    del f
+    want = {k: hashlib.md5(v.encode()).hexdigest() for k, v in O.decompose(g, threads=os.cpu_count() or 1, lpt=True, leaf=2).items()}
+    assert got == want
+    assert n_c > 100000
