@@ -126,6 +126,13 @@ void orc_set_leaf_subflubbles(int on); /* 0 = plain, 1 = the two relabelling pas
 /* all five passes of `povu decompose -s` (app/subcommand/decompose.cpp:63-70) on one component and the text write_pvst
  * makes of the result (povu_oracle_sub.inc: find_concealed, find_midi, find_smothered; PARITY UNPINNED).  Fills p->fam. */
 char *orc_subflubbles_text(const orc_tree *t, orc_pvst *p, size_t *len);
+/* which rule of the three inserting passes fired, counted since the last reset: out[23] = slubbles by kind (ai trunk, ai
+ * branch, zi trunk, zi branch), children moved by nest_trunk_ai / nest_branch_ai / nest_trunk_zi, zi-branch slubbles left
+ * unnested, slubbles of a flubble that is a "leaf" by the tree-index accident, midi bubbles, pairs of one kind (no bubble),
+ * children moved under a midi bubble, smothered vertices by rule (g trunk target / source, g branch, s trunk, s branch source /
+ * target), children moved under one, reads of the stale tail in smothered::nest, depth[] of an invalid index, self-loop
+ * targets pushed by compute_LoA, override_ji_trunk answers */
+void orc_sub_stats(uint64_t *out, int reset);
 
 /* which rule decided, counted since the last reset (tests: does the fuzz reach every rule?): out[11] = leaves whose Y is
  * empty, tiny by a bracket to ai, tiny by an ordinary / a capping-or-simplifying back-edge INDEX equal to ai, parallel by

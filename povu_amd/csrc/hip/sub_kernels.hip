@@ -1351,6 +1351,8 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 		HIP_CHECK(hipMemsetAsync(has_self, 0, ((size_t)C + 4) * 4, s));
 		LAUNCH(k_sub_lo_mark, NB0, s, NB0, pw.b_src, pw.b_tgt, P2, mx);
 		LAUNCH(k_sub_lo_query, T, s, T, sw.t_size, P2, mx, in.nself, comp, lo, has_self);
+		if (getenv("POVU_HIP_SUB_LITERAL_LOA")) // (tests: the reference's heap on every component, whatever its edges)
+			fill_u32(has_self, C, 1u, s);
 		LAUNCH(k_sub_lo, C, s, C, cs.voff, sw.c_ntree, sw.t_size, depth, in.out_ord, eat, pw.b_tgt, in.O, has_self, heap, lo);
 	}
 	mark("creation keys, lo");

@@ -15,6 +15,7 @@ import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import F_SUBFLUBBLES
 from test_oracle import _load_gfa_links
+from test_oracle_subflubbles import RULE_SEEDS, rule_graph
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -133,3 +134,23 @@ def test_config4_whole_genome_full_size_all_five_passes(hip):
     want = {k: hashlib.md5(v.encode()).hexdigest() for k, v in O.decompose(g, threads=os.cpu_count() or 1, lpt=True, leaf=2).items()}
     assert got == want
     assert n_c > 100000
+
+
+@pytest.mark.parametrize("rule", sorted(RULE_SEEDS))
+def test_every_rule_the_search_found(hip, rule):
+    """One small graph per rule of the three passes (which slubble, which nesting, which smothered vertex ...: the oracle
+    counts them, tests/test_oracle_subflubbles.py checks that these graphs reach them)."""
+    check(hip, rule_graph(rule))
+
+
+def test_the_literal_heap_of_lo_gives_the_closed_form(hip, monkeypatch):
+    """LoA: the device uses a closed form (max-tree over the edges' intervals) and keeps the reference's heap, one lane per
+    component, for components with a self-loop back edge -- which no generator here produces.  POVU_HIP_SUB_LITERAL_LOA sends
+    every component through the heap: same PVSTs."""
+    monkeypatch.setenv("POVU_HIP_SUB_LITERAL_LOA", "1")
+    rng = np.random.default_rng(77)
+    for it in range(300):
+        nv = int(rng.integers(5, 40))
+        check(hip, W.random_bidirected(nv, int(rng.integers(nv, 3 * nv)), int(rng.integers(1 << 30)), self_loops=bool(it % 2)))
+    check(hip, W.hprc_tangled(20000, seed=3, tangle_every=2000, max_tangle=500))
+    check(hip, W.bubble_zoo(20, 8, 5))

@@ -3,6 +3,7 @@ find_concealed, find_midi, find_smothered).  PARITY UNPINNED: the reference hold
 can be checked is (a) a case traced by hand through the reference's code, (b) the shape of the output on the
 reference's own input graphs, (c) that seeded random graphs reach all three kinds of vertices."""
 import collections
+import ctypes as C
 import glob
 import os
 
@@ -11,6 +12,56 @@ import numpy as np
 import oracle_lib as O
 from povu_amd import workloads as W
 from test_oracle import _load_gfa_links
+
+
+RULES = ("ai_trunk ai_branch zi_trunk zi_branch nest_trunk_ai nest_branch_ai nest_trunk_zi zi_branch_unnested leaf_by_tree_idx midi "
+         "midi_same_kind midi_nest smo_g_trunk_tgt smo_g_trunk_src smo_g_branch smo_s_trunk smo_s_branch_src smo_s_branch_tgt smo_nest "
+         "smo_stale_read depth_of_invalid self_loop_in_loa override_ji").split()
+# small random graphs (n_vtx, n_links, seed, self_loops, connected of workloads.random_bidirected) that reach a rule of the
+# three inserting passes, found by search (the oracle counts which rule fires: orc_sub_stats)
+RULE_SEEDS = {
+    "ai_trunk": (6, 8, 320817378, False, False), "ai_branch": (4, 6, 171298024, True, False),
+    "zi_trunk": (17, 22, 445721484, True, False), "zi_branch": (7, 8, 225429374, False, False),
+    "nest_trunk_ai": (9, 14, 263055830, False, False), "nest_trunk_zi": (12, 18, 733972094, False, False),
+    "zi_branch_unnested": (9, 22, 72618221, False, False), "midi": (20, 48, 779247219, False, False),
+    "midi_same_kind": (14, 27, 70283665, False, False), "smo_g_trunk_tgt": (7, 10, 556213187, False, False),
+    "smo_g_trunk_src": (9, 18, 141043583, True, False), "smo_g_branch": (8, 12, 302624343, False, True),
+    "smo_s_trunk": (13, 20, 573077957, False, True), "smo_s_branch_src": (15, 20, 600991250, True, False),
+    "smo_s_branch_tgt": (10, 12, 521325456, True, True), "depth_of_invalid": (12, 13, 528241921, False, True),
+    "override_ji": (7, 13, 811069680, True, True),
+    # a chain of bubbles / a bubble zoo with a few random extra links: (family, size..., fraction of extra links, seed)
+    "smo_nest": ("chain", 11, 0.2333583231116823, 996436063), "smo_stale_read": ("chain", 32, 0.053941270117384026, 485877343),
+    "leaf_by_tree_idx": ("zoo", 1, 9, 0.09662316694210007, 282500235),
+}
+# Never reached by 10^7 searched graphs, and for a reason: nest_branch_ai wants a bracket of a child's zi that STARTS at the
+# flubble's ai (concealed.cpp:1006 reads get_src where get_tgt is meant: a bracket's source lies below, ai above);
+# midi_nest wants spanning-tree depths at two PVST indices a few apart to differ by more than the indices do;
+# self_loop_in_loa wants a back edge whose source is its target, which from_bd's self-loop rewrite does not leave.
+UNREACHED_RULES = ("nest_branch_ai", "midi_nest", "self_loop_in_loa")
+
+
+def _with_extra(base, frac, seed):
+    extra = W.random_bidirected(base.n_vtx, max(1, int(base.n_vtx * frac)), seed, self_loops=False)
+    return W._mk(base.vid, np.concatenate([base.v1, extra.v1]), np.concatenate([base.s1, extra.s1]),
+                 np.concatenate([base.v2, extra.v2]), np.concatenate([base.s2, extra.s2]))
+
+
+def rule_graph(rule):
+    p = RULE_SEEDS[rule]
+    if p[0] == "chain":
+        return _with_extra(W.chain_of_bubbles(p[1]), p[2], p[3])
+    if p[0] == "zoo":
+        return _with_extra(W.bubble_zoo(p[1], p[2], p[4]), p[3], p[4] + 1)
+    nv, ne, seed, sl, conn = p
+    return W.random_bidirected(nv, ne, seed, self_loops=sl, connected=conn)
+
+
+def sub_stats(reset=True):
+    lib = O.lib()
+    lib.orc_sub_stats.argtypes = [C.c_void_p, C.c_int]
+    out = (C.c_uint64 * len(RULES))()
+    lib.orc_sub_stats(out, 1 if reset else 0)
+    return dict(zip(RULES, list(out)))
 
 
 def _lines(text):
@@ -82,3 +133,11 @@ def test_seeded_random_graphs_reach_all_three_kinds():
         for c in plain:
             seen += _check_shape(plain[c], full[c])
     assert seen["C"] and seen["M"] and seen["S"], seen
+
+
+def test_rule_seeds_reach_their_rules():
+    assert set(RULE_SEEDS) | set(UNREACHED_RULES) == set(RULES)
+    for rule in RULE_SEEDS:
+        sub_stats()
+        O.decompose(rule_graph(rule), leaf=2)
+        assert sub_stats()[rule] >= 1, rule

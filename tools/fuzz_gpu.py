@@ -5,13 +5,13 @@ import numpy as np
 import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import (F_HAIRPINS, F_SEQ_TREE, F_SORTED_ADJ, F_NO_STAGE_TIMES, F_BIG_CLASS_DFS, F_SPARSE_SPLITTERS,
-                          F_ALL_VERTEX_CLASSES, F_CHECK_LAMINAR, F_LEAF_SUBFLUBBLES)
+                          F_ALL_VERTEX_CLASSES, F_CHECK_LAMINAR, F_LEAF_SUBFLUBBLES, F_SUBFLUBBLES)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 big = len(sys.argv) > 2 and sys.argv[2] == "big"  # only the mid-size kinds, 10x larger
 hip = HipDecomposer(0)
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 12345)  # (argv[3]: another stream of graphs)
-t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0; n_redo = 0; n_leaf = 0; n_leaf_redo = 0; n_flagged = 0; n_crossed = 0; n_cross_graphs = 0
+t0 = time.time(); n_graphs = 0; n_links = 0; n_black_only = 0; n_redo = 0; n_leaf = 0; n_leaf_redo = 0; n_flagged = 0; n_crossed = 0; n_cross_graphs = 0; n_sub = 0; sub_kinds = {'C': 0, 'M': 0, 'S': 0}
 last = t0
 while time.time() - t0 < budget:
     if time.time() - last > 60:
@@ -86,5 +86,18 @@ while time.time() - t0 < budget:
             np.savez('gpurun_out/fuzz_leaf_fail.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
             sys.exit(3)
         n_leaf += 1; n_leaf_redo += int(hip.seq_redo_count() > 0)
+        # ... and all five passes (find_concealed, find_midi, find_smothered insert vertices)
+        want_sub = O.decompose(g, tips=tips, leaf=2)
+        sf = F_SUBFLUBBLES | [0, F_BIG_CLASS_DFS, F_CHECK_LAMINAR, F_SORTED_ADJ][(n_graphs // 2) % 4]
+        got_sub = hip.decompose(flags=sf).texts()
+        if got_sub != want_sub:
+            print('SUBFLUBBLE MISMATCH kind', kind, 'seed', seed, 'n', g.n_vtx, g.n_links, 'flags', sf, 'tips', tips is not None)
+            np.savez('gpurun_out/fuzz_sub_fail.npz', vid=g.vid, v1=g.v1, s1=g.s1, v2=g.v2, s2=g.s2)
+            sys.exit(4)
+        n_sub += 1
+        for t in want_sub.values():
+            for line in t.splitlines():
+                if line[0] in sub_kinds:
+                    sub_kinds[line[0]] += 1
     n_graphs += 1; n_links += g.n_links
-print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only;', n_cross_graphs, 'passes met crossing candidate-stack intervals (all with the literal hi_2 rule deviating):', n_flagged, 'entries flagged,', n_crossed, 'resolved as popped, none redone;', n_leaf, 'graphs also through the leaf subflubble passes (', n_leaf_redo, 'of them with a redone component)')
+print('fuzz ok:', n_graphs, 'graphs,', n_links, 'links in', round(time.time() - t0, 1), 's;', n_black_only, 'passes numbered black edges only;', n_cross_graphs, 'passes met crossing candidate-stack intervals (all with the literal hi_2 rule deviating):', n_flagged, 'entries flagged,', n_crossed, 'resolved as popped, none redone;', n_leaf, 'graphs also through the leaf subflubble passes (', n_leaf_redo, 'of them with a redone component);', n_sub, 'through all five passes of -s:', sub_kinds)
