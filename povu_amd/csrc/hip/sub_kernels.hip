@@ -1270,15 +1270,23 @@ __global__ void k_sub_child_counts(uint32_t NX, const uint32_t *__restrict__ xof
 	}
 	out[x] = n;
 }
-__global__ void k_sub_child_gather(uint32_t NX, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ vbeg,
+// one lane per child entry (a chromosome's root has a million children: one lane per LIST took 0.1 s): the list that owns
+// output slot i is the last vertex whose offset is <= i
+__global__ void k_sub_child_gather(uint32_t NCH, uint32_t NX, const uint32_t *__restrict__ coff, const uint32_t *__restrict__ vbeg,
 				   const uint32_t *__restrict__ pool, uint32_t *__restrict__ out)
 {
-	const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-	if (x >= NX)
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= NCH)
 		return;
-	const uint32_t b = coff[x], n = coff[x + 1] - b;
-	for (uint32_t k = 0; k < n; k++)
-		out[b + k] = pool[vbeg[x] + k];
+	uint32_t lo = 0, hi = NX; // coff[lo] <= i < coff[hi]
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (coff[mid] <= i)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	out[i] = pool[vbeg[lo] + (i - coff[lo])];
 }
 } // namespace
 
@@ -1474,7 +1482,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	scan_exclusive_u32(ccnt, coff, (size_t)NX + 1, tmpx, tmpx_bytes, s);
 	const uint32_t NCH = host.read_u32(coff + NX, s);
 	uint32_t *child = dev32((size_t)NCH + 4);
-	LAUNCH(k_sub_child_gather, NX, s, NX, coff, X.vbeg, X.pool, child);
+	LAUNCH(k_sub_child_gather, NCH, s, NCH, NX, coff, X.vbeg, X.pool, child);
 	mark("children lists");
 
 	// ---- to the host, one stretch per component
