@@ -342,7 +342,7 @@ def main():
     comm_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     from povu_amd import HipDecomposer
-    from povu_amd.hip import F_NO_STAGE_TIMES
+    from povu_amd.hip import F_NO_STAGE_TIMES, F_SUBFLUBBLES
 
     hip = HipDecomposer(local_rank)
     out = None
@@ -420,6 +420,22 @@ def main():
             "ms_per_step_one_pass_at_a_time": dt1 / args.steps * 1e3,
         }
         if not args.no_secondary and args.workload == "hprc-wg":
+            # `povu decompose -s` on the same graph: all five subflubble passes on top of the pass (not part of `value`)
+            hip.decompose(flags=F_SUBFLUBBLES)  # (untimed: the stage's tables are allocated per call)
+            t_s = time.perf_counter()
+            f_s = hip.decompose(flags=F_SUBFLUBBLES)
+            dt_s = time.perf_counter() - t_s
+            st_s = {st["name"]: round(st["ms"], 3) for st in hip.stage_times()}
+            kinds = [0, 0, 0]
+            for i in range(len(f_s)):
+                sub_t = f_s.subtree(i)
+                kinds = [kinds[0] + sub_t["n_concealed"], kinds[1] + sub_t["n_midi"], kinds[2] + sub_t["n_smothered"]]
+            out["subflubbles"] = {"wall_ms": dt_s * 1e3, "leaf_passes_ms": st_s.get("leaf_subflubbles"),
+                                  "inserting_passes_ms": st_s.get("subflubbles_insert"), "pass_total_ms": st_s.get("total"),
+                                  "concealed": int(kinds[0]), "midi": int(kinds[1]), "smothered": int(kinds[2]),
+                                  "note": "POVU_HIP_F_SUBFLUBBLES: find_tiny, find_parallel, find_concealed, find_midi, find_smothered on "
+                                          "every PVST, extended trees copied to the host; parity unpinned (DESIGN.md section 4)"}
+            del f_s
             sec = {}
             for key, name, k_steps in (("config2_chain_1M", "chain", 5), ("config3_hprc_chr", "hprc-chr", 5), ("config5_nest_10M", "nest", 5),
                                       ("tangled_hprc_shape", "tangled", 2)):
