@@ -131,6 +131,7 @@ public:
 		top_ = off + bytes;
 		return reinterpret_cast<T *>(static_cast<char *>(base_) + off);
 	}
+	bool fits(size_t bytes) const { return ((top_ + 255) & ~size_t(255)) + bytes <= cap_; }
 	static size_t padded(size_t n, size_t elem) { return ((n * elem) + 255) & ~size_t(255); }
 	size_t capacity() const { return cap_; }
 	size_t used() const { return top_; }

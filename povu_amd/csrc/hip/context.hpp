@@ -183,6 +183,8 @@ struct povu_hip_ctx {
 	hipStream_t stream = nullptr;
 	SideStream side; // PCIe-bound result writes run beside the main stream's kernels
 	ResidentGraph g;
+	Arena ws_sub;		// tables of the inserting passes of -s (sub_kernels.hip), reserved for what the call before needed
+	size_t ws_sub_hint = 0;
 	Arena ws, ws_b, ws2, ws_seq, ws_leaf, ws_walk, upload_tmp; // (ws_b: what the re-index needs beyond the labelling's arrays; // (ws_walk: the wave walk's arrays, taken by the first pass that meets large classes)
 	HostScratch host;
 	std::shared_ptr<PinnedPool> pool = std::make_shared<PinnedPool>();

@@ -997,7 +997,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 							       "whose PVST layout the inserting passes do not read");
 					tm.begin("subflubbles_insert");
 					f->subx = std::make_shared<SubForest>();
-					run_subflubbles(cs, sw, ctx->pw, ctx->tw, leaf_state, C, ctx->host, *f->subx, s);
+					run_subflubbles(cs, sw, ctx->pw, ctx->tw, leaf_state, C, ctx->host, *f->subx, s, &ctx->ws_sub, &ctx->ws_sub_hint);
 					tm.end(40);
 				}
 				sum = nullptr; // (read again below: the pass total then includes this stage)

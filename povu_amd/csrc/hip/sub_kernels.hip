@@ -57,20 +57,29 @@ static inline unsigned nblk(size_t n) { return (unsigned)((n + TPB - 1) / TPB); 
 
 namespace
 {
-struct DevBuf { // a device allocation of data-dependent size (this stage is not on the timed path)
+// A table of this stage.  Their sizes come out one after the other (the bracket table's from a scan, the records' from the
+// searches ...), so they are taken from the context's arena for this stage while it has room -- it is reserved for what the
+// call before needed -- and from hipMalloc beyond (freed when the stage returns).
+struct DevBuf {
 	void *p = nullptr;
+	bool own = false;
 	~DevBuf()
 	{
-		if (p)
+		if (p && own)
 			(void)hipFree(p);
 	}
 	template <typename T>
-	T *get(size_t n)
+	T *get(size_t n, Arena *ar, size_t &need)
 	{
-		if (p)
-			(void)hipFree(p);
-		p = nullptr;
-		HIP_CHECK(hipMalloc(&p, (n + 16) * sizeof(T)));
+		const size_t bytes = (n + 16) * sizeof(T);
+		need += ((bytes + 255) & ~size_t(255)) + 256;
+		if (ar && ar->fits(bytes)) {
+			p = ar->take<char>(bytes);
+			own = false;
+		} else {
+			HIP_CHECK(hipMalloc(&p, bytes));
+			own = true;
+		}
 		return static_cast<T *>(p);
 	}
 };
@@ -1291,7 +1300,7 @@ __global__ void k_sub_child_gather(uint32_t NCH, uint32_t NX, const uint32_t *__
 } // namespace
 
 void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, const TreeWs &tw, const LeafState &ls, uint32_t C,
-		     HostScratch &host, SubForest &out, hipStream_t s)
+		     HostScratch &host, SubForest &out, hipStream_t s, Arena *arena, size_t *arena_hint)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const uint32_t NB0 = pw.nb0, NB = pw.nb0 + pw.ncap + pw.nsimp;
@@ -1309,11 +1318,14 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 		fprintf(stderr, "[subflubbles] %-22s %9.1f ms\n", what, t_now - t_prev);
 		t_prev = t_now;
 	};
-	std::deque<DevBuf> bufs; // (freed when the stage returns or throws)
-	auto dev32 = [&](size_t n) { return bufs.emplace_back().get<uint32_t>(n); };
-	auto dev8 = [&](size_t n) { return bufs.emplace_back().get<uint8_t>(n); };
+	std::deque<DevBuf> bufs; // (what came from hipMalloc is freed when the stage returns or throws)
+	size_t need = 0;
+	if (arena)
+		arena->reserve(arena_hint ? *arena_hint : 0);
+	auto dev32 = [&](size_t n) { return bufs.emplace_back().get<uint32_t>(n, arena, need); };
+	auto dev8 = [&](size_t n) { return bufs.emplace_back().get<uint8_t>(n, arena, need); };
 	const size_t tmp_bytes = scan_tmp_bytes(std::max<size_t>(std::max<size_t>(T, NB), Q) + 8);
-	void *tmp = bufs.emplace_back().get<char>(tmp_bytes);
+	void *tmp = bufs.emplace_back().get<char>(tmp_bytes, arena, need);
 	uint32_t *err = dev32(4);
 	HIP_CHECK(hipMemsetAsync(err, 0, 16, s));
 
@@ -1344,7 +1356,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	LAUNCH(k_sub_hi, T, s, T, sw.t_size, segH, simp_ps, comp, hi);
 	mark("edge tables, hi");
 	// creation keys of the ordinary edges
-	unsigned long long *ekey = bufs.emplace_back().get<unsigned long long>((size_t)NB0 + 2);
+	unsigned long long *ekey = bufs.emplace_back().get<unsigned long long>((size_t)NB0 + 2, arena, need);
 	uint32_t *wbefore = dev32((size_t)T + 8), *wtail = dev32((size_t)T + 8);
 	HIP_CHECK(hipMemsetAsync(wbefore, 0, ((size_t)T + 8) * 4, s));
 	HIP_CHECK(hipMemsetAsync(wtail, 0, ((size_t)T + 8) * 4, s));
@@ -1399,7 +1411,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	LAUNCH(k_sub_cn_count, (size_t)Q + 1, s, Q, t, comp, cn_cnt, mn);
 	scan_exclusive_u32(cn_cnt, cn_off, (size_t)Q + 1, tmp, tmp_bytes, s);
 	const uint32_t NC = host.read_u32(cn_off + Q, s);
-	Slub *cn = bufs.emplace_back().get<Slub>((size_t)NC + 1);
+	Slub *cn = bufs.emplace_back().get<Slub>((size_t)NC + 1, arena, need);
 	LAUNCH(k_sub_cn_emit, Q, s, Q, t, comp, cn_off, cn);
 	mark("find_concealed search");
 	// ---- find_smothered: count, scan, emit
@@ -1407,7 +1419,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	LAUNCH(k_sub_smo_count, (size_t)NC + 1, s, NC, t, comp, cn, sm_cnt);
 	scan_exclusive_u32(sm_cnt, sm_off, (size_t)NC + 1, tmp, tmp_bytes, s);
 	const uint32_t NS = host.read_u32(sm_off + NC, s);
-	Smo *smo = bufs.emplace_back().get<Smo>((size_t)NS + 1);
+	Smo *smo = bufs.emplace_back().get<Smo>((size_t)NS + 1, arena, need);
 	LAUNCH(k_sub_smo_emit, NC, s, NC, t, comp, cn, sm_off, smo);
 	mark("find_smothered search");
 
@@ -1452,14 +1464,14 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	const CompAt comp_q{cs.voff, pw.doff, C};
 	uint32_t *cap_ps = dev32((size_t)NX + 4);
 	const size_t tmpx_bytes = scan_tmp_bytes((size_t)NX + 8);
-	void *tmpx = bufs.emplace_back().get<char>(tmpx_bytes);
+	void *tmpx = bufs.emplace_back().get<char>(tmpx_bytes, arena, need);
 	LAUNCH(k_sub_x_init, Q, s, Q, t, comp_q, xoff, X);
 	scan_exclusive_u32(X.vcap, cap_ps, (size_t)NX + 1, tmpx, tmpx_bytes, s);
 	LAUNCH(k_sub_x_vbeg, Q, s, Q, t, comp_q, xoff, poff, cap_ps, X);
 	{
 		uint32_t *k0 = dev32((size_t)Q + 4), *k1 = dev32((size_t)Q + 4), *v0 = dev32((size_t)Q + 4), *v1 = dev32((size_t)Q + 4);
 		const size_t sort_bytes = sort_tmp_bytes((size_t)Q + 8);
-		void *sort_tmp = bufs.emplace_back().get<char>(sort_bytes);
+		void *sort_tmp = bufs.emplace_back().get<char>(sort_bytes, arena, need);
 		LAUNCH(k_sub_x_keys, Q, s, Q, NX, t, comp_q, xoff, k0, v0);
 		sort_pairs_u32(k0, k1, v0, v1, Q, bits_for(NX), sort_tmp, sort_bytes, s);
 		LAUNCH(k_sub_x_place, Q, s, Q, NX, k1, v1, cap_ps, X);
@@ -1535,6 +1547,8 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 		cw += c1 - c0;
 	}
 	out.coff[n_vtx] = cw;
+	if (arena_hint)
+		*arena_hint = need; // (the next call on this context reserves that much up front)
 	mark("to the host");
 }
 

@@ -24,8 +24,9 @@ struct SubForest {
 };
 
 // Runs find_concealed, find_midi and find_smothered on the state leaf_prepare / leaf_dense left (an all-parallel pass whose
-// tree stage also wrote the depths).  Throws HipError when a table outgrows its bound.
+// tree stage also wrote the depths).  Throws HipError when a table outgrows its bound.  `arena` (optional): where the
+// stage's tables go while it has room; *arena_hint = bytes to reserve there up front, updated to what this call needed.
 void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, const TreeWs &tw, const LeafState &ls, uint32_t C,
-		     HostScratch &host, SubForest &out, hipStream_t s);
+		     HostScratch &host, SubForest &out, hipStream_t s, Arena *arena = nullptr, size_t *arena_hint = nullptr);
 
 } // namespace povu_hip
