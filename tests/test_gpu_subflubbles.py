@@ -15,7 +15,7 @@ import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import F_SUBFLUBBLES
 from test_oracle import _load_gfa_links
-from test_oracle_subflubbles import RULE_SEEDS, rule_graph
+from test_oracle_subflubbles import RULE_SEEDS, rule_graph, rule_tips
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,10 +29,10 @@ def hip():
     d.close()
 
 
-def check(hip, g):
-    hip.upload(g)
+def check(hip, g, tips=None):
+    hip.upload(g, tips)
     f = hip.decompose(flags=F_SUBFLUBBLES)
-    got, want = f.texts(), O.decompose(g, leaf=2)
+    got, want = f.texts(), O.decompose(g, tips=tips, leaf=2)
     assert got.keys() == want.keys()
     seen = collections.Counter()
     for c in want:
@@ -140,13 +140,14 @@ def test_config4_whole_genome_full_size_all_five_passes(hip):
 def test_every_rule_the_search_found(hip, rule):
     """One small graph per rule of the three passes (which slubble, which nesting, which smothered vertex ...: the oracle
     counts them, tests/test_oracle_subflubbles.py checks that these graphs reach them)."""
-    check(hip, rule_graph(rule))
+    g = rule_graph(rule)
+    check(hip, g, rule_tips(rule, g))
 
 
 def test_the_literal_heap_of_lo_gives_the_closed_form(hip, monkeypatch):
     """LoA: the device uses a closed form (max-tree over the edges' intervals) and keeps the reference's heap, one lane per
-    component, for components with a self-loop back edge -- which no generator here produces.  POVU_HIP_SUB_LITERAL_LOA sends
-    every component through the heap: same PVSTs."""
+    component, for components with a self-loop back edge (the root of a tip-less component has one: rule self_loop_in_loa).
+    POVU_HIP_SUB_LITERAL_LOA sends every component through the heap: same PVSTs."""
     monkeypatch.setenv("POVU_HIP_SUB_LITERAL_LOA", "1")
     rng = np.random.default_rng(77)
     for it in range(300):
