@@ -1297,6 +1297,27 @@ __global__ void k_sub_child_gather(uint32_t NCH, uint32_t NX, const uint32_t *__
 	}
 	out[i] = pool[vbeg[lo] + (i - coff[lo])];
 }
+// the vertices of every component without the spare slots of X-space: dense slot d = dvoff[c] + (index inside the component)
+__global__ void k_sub_compact(uint32_t NV, uint32_t C, const uint32_t *__restrict__ dvoff, const uint32_t *__restrict__ xoff, const XArrays X,
+			      const uint32_t *__restrict__ coff, uint8_t *__restrict__ fam, uint8_t *__restrict__ or1, uint8_t *__restrict__ or2,
+			      uint8_t *__restrict__ route, uint32_t *__restrict__ id1, uint32_t *__restrict__ id2, uint32_t *__restrict__ coff_d)
+{
+	const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+	if (d >= NV)
+		return;
+	uint32_t lo = 0, hi = C; // last c with dvoff[c] <= d (components without a PVST own no slot)
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (dvoff[mid] <= d)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	const uint32_t x = xoff[lo] + (d - dvoff[lo]);
+	fam[d] = X.fam[x], or1[d] = X.or1[x], or2[d] = X.or2[x], route[d] = X.route[x];
+	id1[d] = X.id1[x], id2[d] = X.id2[x];
+	coff_d[d] = coff[x];
+}
 } // namespace
 
 void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, const TreeWs &tw, const LeafState &ls, uint32_t C,
@@ -1497,56 +1518,49 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	LAUNCH(k_sub_child_gather, NCH, s, NCH, NX, coff, X.vbeg, X.pool, child);
 	mark("children lists");
 
-	// ---- to the host, one stretch per component
-	std::vector<uint8_t> h_fam(NX), h_or1(NX), h_or2(NX), h_route(NX);
-	std::vector<uint32_t> h_id1(NX), h_id2(NX), h_coff((size_t)NX + 1), h_child(NCH), h_counts(3 * (size_t)C);
+	// ---- to the host: the vertices compacted on the device (X-space has spare slots behind every component), then one copy
+	// per array straight into the forest's vectors
+	std::vector<uint32_t> h_counts(3 * (size_t)C), h_dvoff((size_t)C + 1);
+	if (C)
+		HIP_CHECK(copy_async(h_counts.data(), counts, 3 * (size_t)C * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	out = SubForest{};
+	out.voff.assign((size_t)C + 1, 0);
+	uint64_t n_vtx = 0;
+	for (uint32_t c = 0; c < C; c++) {
+		out.voff[c] = n_vtx;
+		h_dvoff[c] = (uint32_t)n_vtx;
+		if (h_np[c])
+			n_vtx += (uint64_t)h_np[c] + h_counts[3 * c] + h_counts[3 * c + 1] + h_counts[3 * c + 2];
+	}
+	out.voff[C] = n_vtx;
+	h_dvoff[C] = (uint32_t)n_vtx;
+	out.counts = h_counts;
+	const uint32_t NV = (uint32_t)n_vtx;
+	uint32_t *dvoff = dev32((size_t)C + 2);
+	HIP_CHECK(hipMemcpyAsync(dvoff, h_dvoff.data(), ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
+	uint8_t *d_fam = dev8((size_t)NV + 4), *d_or1 = dev8((size_t)NV + 4), *d_or2 = dev8((size_t)NV + 4), *d_route = dev8((size_t)NV + 4);
+	uint32_t *d_id1 = dev32((size_t)NV + 4), *d_id2 = dev32((size_t)NV + 4), *d_coff = dev32((size_t)NV + 4);
+	LAUNCH(k_sub_compact, NV, s, NV, C, dvoff, xoff, X, coff, d_fam, d_or1, d_or2, d_route, d_id1, d_id2, d_coff);
+	out.fam.resize(n_vtx), out.or1.resize(n_vtx), out.or2.resize(n_vtx), out.route.resize(n_vtx);
+	out.id1.resize(n_vtx), out.id2.resize(n_vtx), out.coff.resize(n_vtx + 1), out.child.resize(NCH);
+	std::vector<uint32_t> h_coff(n_vtx);
 	auto d2h = [&](void *dst, const void *src, size_t bytes) {
 		if (bytes)
 			HIP_CHECK(copy_async(dst, src, bytes, hipMemcpyDeviceToHost, s));
 	};
-	d2h(h_fam.data(), X.fam, NX);
-	d2h(h_or1.data(), X.or1, NX);
-	d2h(h_or2.data(), X.or2, NX);
-	d2h(h_route.data(), X.route, NX);
-	d2h(h_id1.data(), X.id1, (size_t)NX * 4);
-	d2h(h_id2.data(), X.id2, (size_t)NX * 4);
-	d2h(h_coff.data(), coff, ((size_t)NX + 1) * 4);
-	d2h(h_child.data(), child, (size_t)NCH * 4);
-	d2h(h_counts.data(), counts, 3 * (size_t)C * 4);
+	d2h(out.fam.data(), d_fam, NV);
+	d2h(out.or1.data(), d_or1, NV);
+	d2h(out.or2.data(), d_or2, NV);
+	d2h(out.route.data(), d_route, NV);
+	d2h(out.id1.data(), d_id1, (size_t)NV * 4);
+	d2h(out.id2.data(), d_id2, (size_t)NV * 4);
+	d2h(h_coff.data(), d_coff, (size_t)NV * 4);
+	d2h(out.child.data(), child, (size_t)NCH * 4); // (the lists are compact already, in vertex order)
 	HIP_CHECK(hipStreamSynchronize(s));
-	out = SubForest{};
-	out.voff.assign((size_t)C + 1, 0);
-	out.counts = h_counts;
-	uint64_t n_vtx = 0, n_child = 0;
-	for (uint32_t c = 0; c < C; c++) {
-		out.voff[c] = n_vtx;
-		if (!h_np[c])
-			continue;
-		const uint32_t nt = h_np[c] + h_counts[3 * c] + h_counts[3 * c + 1] + h_counts[3 * c + 2], xb = h_xoff[c];
-		n_vtx += nt;
-		n_child += h_coff[xb + nt] - h_coff[xb];
-	}
-	out.voff[C] = n_vtx;
-	out.fam.resize(n_vtx), out.or1.resize(n_vtx), out.or2.resize(n_vtx), out.route.resize(n_vtx);
-	out.id1.resize(n_vtx), out.id2.resize(n_vtx), out.coff.resize(n_vtx + 1), out.child.resize(n_child);
-	uint64_t cw = 0;
-	for (uint32_t c = 0; c < C; c++) { // a component's vertices and children are one stretch each (the slots behind its last vertex hold no list)
-		if (!h_np[c])
-			continue;
-		const uint64_t vb = out.voff[c], nt = out.voff[c + 1] - vb;
-		const uint32_t xb = h_xoff[c], c0 = h_coff[xb], c1 = h_coff[xb + nt];
-		memcpy(out.fam.data() + vb, h_fam.data() + xb, nt);
-		memcpy(out.or1.data() + vb, h_or1.data() + xb, nt);
-		memcpy(out.or2.data() + vb, h_or2.data() + xb, nt);
-		memcpy(out.route.data() + vb, h_route.data() + xb, nt);
-		memcpy(out.id1.data() + vb, h_id1.data() + xb, nt * 4);
-		memcpy(out.id2.data() + vb, h_id2.data() + xb, nt * 4);
-		for (uint64_t v = 0; v < nt; v++)
-			out.coff[vb + v] = cw + (h_coff[xb + v] - c0);
-		memcpy(out.child.data() + cw, h_child.data() + c0, (size_t)(c1 - c0) * 4);
-		cw += c1 - c0;
-	}
-	out.coff[n_vtx] = cw;
+	for (uint64_t v = 0; v < n_vtx; v++)
+		out.coff[v] = h_coff[v];
+	out.coff[n_vtx] = NCH;
 	if (arena_hint)
 		*arena_hint = need; // (the next call on this context reserves that much up front)
 	mark("to the host");
