@@ -701,7 +701,8 @@ __global__ void k_tour_values(uint32_t V, const uint4 *__restrict__ t0seg, const
 	const ulonglong2 z = make_ulonglong2(0ull, 0ull);
 	xval[tour_rank(xrec, r.z)] = hx((f2.x & FT_HASH) ? hside[2 * g] : z, (f2.y & FT_HASH) ? hside[2 * g + 1] : z);
 }
-// pbr[S] = parent of S in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree)
+// parent word of side S: its parent in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree).
+// It lives in cstate[S] (below) next to the visited bit -- a separate array of them was 0.8 GB written and read once more.
 static constexpr uint32_t PB_BRIDGE = 0x80000000u;
 // Also, while parent and bridge bit of a side are in hand, what the class walks start from (section 5): the side's state word
 // cstate (forest parent, bridge bit, visited bit: one load tells a walk "not yet visited", which covers "not across a
@@ -717,7 +718,7 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 			  const ulonglong2 *__restrict__ hside, const uint32_t *__restrict__ ft,
 			  const uint32_t *__restrict__ dist, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ lle,
 			  const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, const uint32_t *__restrict__ voff,
-			  uint32_t *__restrict__ pbr, uint8_t *multi, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
+			  uint8_t *multi, uint32_t *__restrict__ cstate, uint2 *__restrict__ dps)
 {
 	const uint32_t g = BIDX * blockDim.x + threadIdx.x;
 	if (g >= V)
@@ -785,7 +786,6 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 	if (entryF)
 		recF.x = Se; // (the black edge: slot 0, scanned first)
 	const bool e_first = !(Se & 1u);
-	*reinterpret_cast<uint2 *>(pbr + 2 * g) = e_first ? make_uint2(pvE, pvF) : make_uint2(pvF, pvE);
 	*reinterpret_cast<uint2 *>(cstate + 2 * g) = e_first ? make_uint2(csE, csF) : make_uint2(csF, csE);
 	*reinterpret_cast<uint4 *>(dps + 2 * g) = e_first ? make_uint4(recE.x, recE.y, recF.x, recF.y) : make_uint4(recF.x, recF.y, recE.x, recE.y);
 }
@@ -804,7 +804,7 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 // is alone in its class has nothing to walk: the walks start from the entries that share their class (multi)
 // (four sides a lane: one 16-byte, one 4-byte and one 8-byte load instead of twelve 4- and 1-byte ones -- a kernel of a few
 // loads per element is bound by the number of memory instructions its CU can retire, not by their bytes)
-__global__ void k_entry_flags(uint32_t nS, const uint32_t *__restrict__ pbr, const uint8_t *__restrict__ multi,
+__global__ void k_entry_flags(uint32_t nS, const uint32_t *__restrict__ pbr /* = cstate: only the bridge bit is read */, const uint8_t *__restrict__ multi,
 			      const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, uint8_t *__restrict__ entry_flag)
 {
 	const uint32_t S0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
@@ -862,10 +862,10 @@ __global__ void k_class_recs(uint32_t nS, const uint32_t *__restrict__ loff, con
 	uint32_t n = 0, c[W_INLINE] = {NIL, NIL, NIL, NIL, NIL, NIL};
 	uint32_t vis = W_UNVIS;
 	if (cproc[ckey[u >> 1]]) {
-		const uint32_t mine = pbr[u];
+		const uint32_t mine = pbr[u] & ~CS_VISITED; // (pbr = cstate: the small walks have set visited bits by now)
 		if (mine & PB_BRIDGE)
 			vis = 0u; // the entry of its class (or a DFS start): never walked into
-		auto same_class = [&](uint32_t o) { return o != u && mine != (o | PB_BRIDGE) && pbr[o] != (u | PB_BRIDGE); }; // no bridge between
+		auto same_class = [&](uint32_t o) { return o != u && mine != (o | PB_BRIDGE) && (pbr[o] & ~CS_VISITED) != (u | PB_BRIDGE); }; // no bridge between
 		auto put = [&](uint32_t o) {
 			if (n < W_INLINE) {
 #pragma unroll
@@ -1782,7 +1782,7 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, 
 	take((void **)&tw.xrank, (NA / 64 + 4) * 4);
 	take((void **)&tw.evt, NA * 8);
 	take((void **)&tw.t0seg, (V + 2) * 16);
-	for (uint32_t **p : {&tw.pbr, &tw.entry_ps, &tw.entry_list, &tw.be_cnt})
+	for (uint32_t **p : {&tw.entry_ps, &tw.entry_list, &tw.be_cnt})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
 	take((void **)&tw.entry_flag, nS + 16);
@@ -1907,12 +1907,12 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
 	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
 	uint32_t *cstate = sw.cur; // [nS+1]
-	LAUNCH(k_bridges, V, s, V, tw.t0seg, tw.xps, tw.xrec, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, tw.pbr, multi, cstate, tw.dps);
+	LAUNCH(k_bridges, V, s, V, tw.t0seg, tw.xps, tw.xrec, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, multi, cstate, tw.dps);
 	tm.end(8 + 44);
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
-	LAUNCH(k_entry_flags, (nS + 3) / 4, s, nS, tw.pbr, multi, cs.ckey, tw.cproc, tw.entry_flag);
+	LAUNCH(k_entry_flags, (nS + 3) / 4, s, nS, cstate, multi, cs.ckey, tw.cproc, tw.entry_flag);
 	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
 	compact_flagged_u8(tw.entry_flag, nS, tw.entry_list, n_entry_dev, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
@@ -1947,10 +1947,10 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 			tw.wpar = reinterpret_cast<decltype(tw.wpar)>(tw.walk_arena->take<char>(nSw * 4));
 		}
 		uint32_t *pool_top = pw.err + 7, *walk_err = pw.err + 8; // (cleared with the other counters at the start of the pass)
-		LAUNCH(k_class_recs, nS, s, nS, cs.loff, cs.ladj, tw.pbr, cs.ckey, tw.cproc, tw.wadj, tw.wrec, tw.wpar);
+		LAUNCH(k_class_recs, nS, s, nS, cs.loff, cs.ladj, cstate, cs.ckey, tw.cproc, tw.wadj, tw.wrec, tw.wpar);
 		KLAUNCH(k_class_walk_wave, dim3(n_big), dim3(64), 0, s, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top,
 			(uint32_t)std::min<size_t>(3 * (size_t)nS, 0xFFFFFFF0u), walk_err, nS);
-		LAUNCH(k_walk_finish, nS, s, nS, tw.wpar, tw.pbr, cs.loff, cs.ladj, tw.dps);
+		LAUNCH(k_walk_finish, nS, s, nS, tw.wpar, cstate, cs.loff, cs.ladj, tw.dps);
 		if (tw.host->read_u32(walk_err, s)) // (an unfinished walk leaves a broken tree: nothing downstream may run on it)
 			throw HipError("class walk: stack pool exhausted (internal sizing bug)");
 	}

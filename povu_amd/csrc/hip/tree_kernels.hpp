@@ -16,7 +16,6 @@ struct TreeWs {
 	uint4 *xrec;					  // [(4V+8)/64 + 4] per 64 tour positions {which of them carry a value (64 bits), set bits in front of the word, -}
 	uint32_t *xrank;				  // [(4V+8)/64 + 4] scan buffer of the bit counts (the last entry: their total)
 	uint4 *t0seg;					  // [V] rooted forest, per segment: {parent of the entered side, link to it | r bit, tour position in, out}
-	uint32_t *pbr;					  // [2V] parent in the rooted forest | bit 31: the edge to it is a bridge
 	uint2 *dps;					  // [2V] {DFS parent side, scan slot of the parent it was found through}
 	uint8_t *dvis;					  // [2V]
 	// the wave-cooperative walk of large 2-edge-connected classes
