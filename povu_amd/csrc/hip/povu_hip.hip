@@ -1210,6 +1210,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		}
 		if (leaf_sub)
 			ctx->ws_leaf.release(); // (not part of the workspace a plain decompose keeps warm)
+		if (!all_sub)
+			ctx->ws_sub.release(); // (the inserting passes keep their tables' arena from one -s pass to the next, no longer)
 		// stage times
 		ctx->last_times.clear();
 		for (auto &r : tm.recs) {
