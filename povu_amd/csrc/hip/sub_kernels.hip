@@ -373,10 +373,17 @@ __global__ void k_sub_lo_mark(uint32_t NB0, const uint32_t *__restrict__ b_src, 
 	if (sv <= tv + 1)
 		return;
 	for (uint32_t l = tv + 1 + P2, r = sv + P2; l < r; l >>= 1, r >>= 1) {
-		if (l & 1)
-			atomicMax(&tree[l++], tv + 1);
-		if (r & 1)
-			atomicMax(&tree[--r], tv + 1);
+		// (the nodes near the root are everybody's: most edges find a larger mark there already and need no atomic)
+		if (l & 1) {
+			if (tree[l] < tv + 1)
+				atomicMax(&tree[l], tv + 1);
+			l++;
+		}
+		if (r & 1) {
+			--r;
+			if (tree[r] < tv + 1)
+				atomicMax(&tree[r], tv + 1);
+		}
 	}
 }
 __global__ void k_sub_lo_query(uint32_t T, const uint32_t *__restrict__ size, uint32_t P2, const uint32_t *__restrict__ tree,
@@ -964,7 +971,6 @@ __global__ void k_sub_x_init(uint32_t Q, const SubT t, const CompAt comp, const 
 		X.id2[x] = t.p_z[q], X.or2[x] = t.p_zor[q];
 		X.route[x] = 'L';
 		X.ai[x] = base + t.p_ai[q], X.zi[x] = base + t.p_zi[q];
-		atomicAdd(&X.vcap[xoff[c] + t.p_parent[q]], 1u);
 	} else {
 		X.id1[x] = X.id2[x] = NIL;
 		X.or1[x] = X.or2[x] = 0;
@@ -972,15 +978,31 @@ __global__ void k_sub_x_init(uint32_t Q, const SubT t, const CompAt comp, const 
 		X.ai[x] = X.zi[x] = NIL;
 	}
 }
+// where the children of X slot x begin among the sorted (parent slot, child) pairs = how many pairs have a smaller key: a
+// binary search per slot (counting them with atomics put a million adds on the word of a chromosome's root)
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__ a, uint32_t n, uint32_t x)
+{
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (a[mid] < x)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
 __global__ void k_sub_x_vbeg(uint32_t Q, const SubT t, const CompAt comp, const uint32_t *__restrict__ xoff,
-			     const uint32_t *__restrict__ poff, const uint32_t *__restrict__ cap_ps, XArrays X)
+			     const uint32_t *__restrict__ poff, const uint32_t *__restrict__ key, uint32_t *__restrict__ cap_ps, XArrays X)
 {
 	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= Q)
 		return;
 	const uint32_t c = comp.of_slot(q), x = xoff[c] + (q - t.doff[c]);
-	X.vbeg[x] = poff[c] + (cap_ps[x] - cap_ps[xoff[c]]);
-	X.vn[x] = X.vcap[x];
+	const uint32_t b = lower_bound_u32(key, Q, x), e = lower_bound_u32(key, Q, x + 1), b0 = lower_bound_u32(key, Q, xoff[c]);
+	cap_ps[x] = b;
+	X.vbeg[x] = poff[c] + (b - b0);
+	X.vn[x] = X.vcap[x] = e - b;
 }
 // children in ascending idx: a stable sort of (X slot of the parent, child) over the dense slots, which are in ascending
 // idx already (one lane sorting the million children of a chromosome's root took seconds)
@@ -1487,14 +1509,13 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	const size_t tmpx_bytes = scan_tmp_bytes((size_t)NX + 8);
 	void *tmpx = bufs.emplace_back().get<char>(tmpx_bytes, arena, need);
 	LAUNCH(k_sub_x_init, Q, s, Q, t, comp_q, xoff, X);
-	scan_exclusive_u32(X.vcap, cap_ps, (size_t)NX + 1, tmpx, tmpx_bytes, s);
-	LAUNCH(k_sub_x_vbeg, Q, s, Q, t, comp_q, xoff, poff, cap_ps, X);
 	{
 		uint32_t *k0 = dev32((size_t)Q + 4), *k1 = dev32((size_t)Q + 4), *v0 = dev32((size_t)Q + 4), *v1 = dev32((size_t)Q + 4);
 		const size_t sort_bytes = sort_tmp_bytes((size_t)Q + 8);
 		void *sort_tmp = bufs.emplace_back().get<char>(sort_bytes, arena, need);
 		LAUNCH(k_sub_x_keys, Q, s, Q, NX, t, comp_q, xoff, k0, v0);
 		sort_pairs_u32(k0, k1, v0, v1, Q, bits_for(NX), sort_tmp, sort_bytes, s);
+		LAUNCH(k_sub_x_vbeg, Q, s, Q, t, comp_q, xoff, poff, k1, cap_ps, X);
 		LAUNCH(k_sub_x_place, Q, s, Q, NX, k1, v1, cap_ps, X);
 	}
 	mark("layout, PVST vectors");

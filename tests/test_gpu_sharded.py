@@ -314,7 +314,8 @@ def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
     H.write_gfa(g, gfa)
     outs = {}
     for name, extra, env in (("one", [], {}), ("two", ["--gpus", "2"], {"POVU_HIP_DEVICES": "0,0"}),
-                             ("two_leaf", ["--gpus=2", "--leaf-subflubbles"], {"POVU_HIP_DEVICES": "0,0"})):
+                             ("two_leaf", ["--gpus=2", "--leaf-subflubbles"], {"POVU_HIP_DEVICES": "0,0"}),
+                             ("two_sub", ["--gpus=2", "-s"], {"POVU_HIP_DEVICES": "0,0"})):
         d = tmp_path / name
         d.mkdir()
         r = subprocess.run([povu, "-t", "4", "decompose", "-i", gfa, "-o", str(d)] + extra, env=dict(os.environ, **env),
@@ -323,6 +324,7 @@ def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
         outs[name] = {int(p.name[:-5]): p.read_text() for p in d.glob("*.pvst")}
     assert outs["one"] == O.decompose(g) == outs["two"]
     assert outs["two_leaf"] == O.decompose(g, leaf=True)
+    assert outs["two_sub"] == O.decompose(g, leaf=2)  # all five passes of -s, every worker on its own components
     r = subprocess.run([povu, "decompose", "-i", gfa, "-o", str(tmp_path), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "device 1 is not visible" in r.stderr  # a one-GPU box has no second device
 
