@@ -909,44 +909,119 @@ struct XArrays {
 	uint32_t *vbeg, *vn, *vcap;
 	uint32_t *pool;
 };
+// One WAVE splices one component.  The control flow is the reference's, followed by all 64 lanes alike (every decision is
+// read from the same address by every lane); lane 0 does the stores, and the two loops that are long on a flubble with very
+// many children -- copying a vector that grows, filtering the children that leave -- are shared out over the lanes.
 struct Splice {
 	XArrays x;
 	uint32_t xb;		   // first X slot of the component
-	uint32_t pool_top, pool_end; // bump pointer inside the pool
+	uint32_t pool_top, pool_end; // bump pointer inside the pool (the same in every lane)
 	uint32_t *err;
-	__device__ void push(uint32_t parent, uint32_t child)
+	uint32_t lane;
+	__device__ __forceinline__ void sync() const { __syncthreads(); } // (one wave a workgroup)
+	// room for `extra` more entries in the vector of `parent`
+	__device__ bool reserve(uint32_t parent, uint32_t extra)
 	{
-		const uint32_t p = xb + parent;
-		if (x.vn[p] == x.vcap[p]) {
-			const uint32_t cap = x.vcap[p] ? 2 * x.vcap[p] : 4;
-			if (pool_top + cap > pool_end) {
+		const uint32_t p = xb + parent, n = x.vn[p], cap = x.vcap[p];
+		if (n + extra <= cap)
+			return true;
+		uint32_t ncap = cap ? cap : 4;
+		while (ncap < n + extra)
+			ncap *= 2;
+		if (pool_top + ncap > pool_end || ncap < n) {
+			if (lane == 0)
 				atomicOr(err, E_POOL);
-				return;
-			}
-			for (uint32_t k = 0; k < x.vn[p]; k++)
-				x.pool[pool_top + k] = x.pool[x.vbeg[p] + k];
-			x.vbeg[p] = pool_top;
-			x.vcap[p] = cap;
-			pool_top += cap;
+			return false;
 		}
-		x.pool[x.vbeg[p] + x.vn[p]++] = child;
+		const uint32_t from = x.vbeg[p];
+		for (uint32_t k = lane; k < n; k += 64)
+			x.pool[pool_top + k] = x.pool[from + k];
+		sync();
+		if (lane == 0) {
+			x.vbeg[p] = pool_top;
+			x.vcap[p] = ncap;
+		}
+		pool_top += ncap;
+		sync();
+		return true;
+	}
+	__device__ bool push(uint32_t parent, uint32_t child)
+	{
+		if (!reserve(parent, 1))
+			return false;
+		const uint32_t p = xb + parent;
+		if (lane == 0) {
+			x.pool[x.vbeg[p] + x.vn[p]] = child;
+			x.vn[p] = x.vn[p] + 1;
+		}
+		sync();
+		return true;
 	}
 	// del_edge: erase the first match; the slot behind the new end keeps its old value, as vector::erase leaves it
 	__device__ void erase(uint32_t parent, uint32_t child)
 	{
 		const uint32_t p = xb + parent, b = x.vbeg[p], n = x.vn[p];
-		for (uint32_t k = 0; k < n; k++)
-			if (x.pool[b + k] == child) {
-				for (uint32_t a = k; a + 1 < n; a++)
-					x.pool[b + a] = x.pool[b + a + 1];
-				x.vn[p] = n - 1;
-				return;
-			}
+		if (lane == 0)
+			for (uint32_t k = 0; k < n; k++)
+				if (x.pool[b + k] == child) {
+					for (uint32_t a = k; a + 1 < n; a++)
+						x.pool[b + a] = x.pool[b + a + 1];
+					x.vn[p] = n - 1;
+					break;
+				}
+		sync();
 	}
 	__device__ __forceinline__ bool fl_like(uint32_t v) const
 	{
 		const uint8_t f = x.fam[xb + v];
 		return f == FAM_FLUBBLE || f == FAM_TINY || f == FAM_PARALLEL;
+	}
+	// The nestings of add_concealed / add_midi run over a COPY of the first nch children of f and move those that `leaves`
+	// says so, in order, under `dest` (to_child: the other way round -- `dest` is pushed into the vector of each of them,
+	// concealed.cpp:1077).  A stable filter, 64 children a round; returns false when the pool ran out.
+	template <typename Leaves, typename Touch>
+	__device__ bool filter(uint32_t f, uint32_t nch, uint32_t dest, bool to_child, Leaves &&leaves, Touch &&touch)
+	{
+		const uint32_t pf = xb + f;
+		uint32_t w = 0;
+		for (uint32_t r0 = 0; r0 < nch; r0 += 64) {
+			const uint32_t r = r0 + lane, fb = x.vbeg[pf];
+			const bool valid = r < nch;
+			const uint32_t ch = valid ? x.pool[fb + r] : 0u;
+			const bool moved = valid && leaves(ch);
+			const unsigned long long mm = __ballot(moved), km = __ballot(valid && !moved);
+			const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+			sync(); // (every lane holds its child: the slots may be written now)
+			if (valid && !moved)
+				x.pool[fb + w + (uint32_t)__popcll(km & below)] = ch;
+			w += (uint32_t)__popcll(km);
+			if (mm) {
+				if (!to_child) {
+					const uint32_t cnt = (uint32_t)__popcll(mm);
+					if (!reserve(dest, cnt))
+						return false;
+					const uint32_t pd = xb + dest;
+					if (moved)
+						x.pool[x.vbeg[pd] + x.vn[pd] + (uint32_t)__popcll(mm & below)] = ch;
+					sync();
+					if (lane == 0)
+						x.vn[pd] = x.vn[pd] + cnt;
+					sync();
+				} else {
+					for (unsigned long long m = mm; m; m &= m - 1) {
+						const uint32_t c2 = __shfl(ch, __ffsll((long long)m) - 1);
+						if (!push(c2, dest))
+							return false;
+						touch(c2);
+					}
+				}
+			}
+			sync();
+		}
+		if (lane == 0)
+			x.vn[pf] = w;
+		sync();
+		return true;
 	}
 };
 __device__ __forceinline__ void side_id_or(const SubT &t, uint32_t v, bool fwd_is_r, uint32_t &id, uint8_t &orr)
@@ -1027,48 +1102,58 @@ __global__ void k_sub_x_place(uint32_t Q, uint32_t NX, const uint32_t *__restric
 		return;
 	X.pool[X.vbeg[x] + (i - cap_ps[x])] = val[i];
 }
-__global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ poff,
-			     const uint32_t *__restrict__ cn_off, const Slub *__restrict__ cn, const uint32_t *__restrict__ mn,
-			     const uint32_t *__restrict__ smo_off, const Smo *__restrict__ smo, XArrays X, uint32_t *__restrict__ counts)
+__global__ void __launch_bounds__(64) k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ poff,
+						    const uint32_t *__restrict__ cn_off, const Slub *__restrict__ cn, const uint32_t *__restrict__ mn,
+						    const uint32_t *__restrict__ smo_off, const Smo *__restrict__ smo, XArrays X, uint32_t *__restrict__ counts)
 {
-	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t c = blockIdx.x, lane = threadIdx.x;
 	if (c >= C)
 		return;
 	const uint32_t n0 = t.c_npvst[c];
-	counts[3 * c] = counts[3 * c + 1] = counts[3 * c + 2] = 0;
+	if (lane == 0)
+		counts[3 * c] = counts[3 * c + 1] = counts[3 * c + 2] = 0;
 	if (!n0)
 		return;
 	const uint32_t q0 = t.doff[c], base = t.base_of(c), N = t.c_ntree[c];
-	Splice S{X, xoff[c], poff[c], poff[c + 1], t.err};
+	Splice S{X, xoff[c], poff[c], poff[c + 1], t.err, lane};
 	const uint32_t xb = S.xb, cap_x = xoff[c + 1] - xoff[c];
-	// (the vertices of find_flubbles and their children vectors are in place: k_sub_x_init .. k_sub_x_sort)  Behind them in the
-	// pool: the list of the flubbles that got a concealed vertex as a child (find_midi looks at no others)
+	// (the vertices of find_flubbles and their children vectors are in place: k_sub_x_init .. k_sub_x_place)  Behind them in
+	// the pool: the list of the flubbles that got a concealed vertex as a child (find_midi looks at no others)
 	S.pool_top += n0 - 1;
 	uint32_t *touched = X.pool + S.pool_top;
 	uint32_t n_touched = 0;
 	S.pool_top += n0;
 	if (S.pool_top > S.pool_end) {
-		atomicOr(t.err, E_POOL);
+		if (lane == 0)
+			atomicOr(t.err, E_POOL);
 		return;
 	}
 	auto touch = [&](uint32_t f) {
 		if (!X.loc[xb + f]) {
-			X.loc[xb + f] = 1;
-			touched[n_touched++] = f;
+			S.sync(); // (every lane has read the flag)
+			if (lane == 0) {
+				X.loc[xb + f] = 1;
+				touched[n_touched] = f;
+			}
+			n_touched++;
+			S.sync();
 		}
 	};
 	uint32_t nx = n0; // vertices so far
-	auto new_vertex = [&](uint8_t fam) -> uint32_t {
+	auto new_vertex = [&](uint8_t fam) -> uint32_t { // (the caller synchronises once it has filled the vertex in)
 		if (nx >= cap_x) {
-			atomicOr(t.err, E_LAYOUT);
+			if (lane == 0)
+				atomicOr(t.err, E_LAYOUT);
 			return NIL;
 		}
-		const uint32_t x = xb + nx;
-		X.fam[x] = fam;
-		X.vn[x] = X.vcap[x] = 0;
-		X.vbeg[x] = 0;
-		X.ai[x] = X.zi[x] = X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
-		X.loc[x] = 0;
+		if (lane == 0) {
+			const uint32_t x = xb + nx;
+			X.fam[x] = fam;
+			X.vn[x] = X.vcap[x] = 0;
+			X.vbeg[x] = 0;
+			X.ai[x] = X.zi[x] = X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
+			X.loc[x] = 0;
+		}
 		return nx++;
 	};
 	// ---- add_concealed, concealed.cpp:925-1196, flubbles in ascending idx
@@ -1081,108 +1166,102 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 		const uint32_t ai = X.ai[xb + f], zi = X.zi[xb + f], n_of_f = mn[2 * (size_t)q + 1];
 		const bool is_leaf = f < N && t.nchild[base + f] == 0; // (sic) the SPANNING TREE's vertex f, concealed.cpp:1188
 		for (; k < ke; k++) {
-			const Slub &sl = cn[k];
+			const Slub sl = cn[k];
 			const uint32_t v = new_vertex(FAM_CONCEALED);
 			if (v == NIL)
 				return;
-			const uint32_t x = xb + v;
-			// gen_ai_slubble, concealed.cpp:70-152 / gen_zi_slubble, :154-206
-			const bool sl_r = (t.flags[sl.sl] & TF_TYPE_MASK) == 1u, black = (t.flags[sl.sl] & TF_BLACK) != 0;
-			uint32_t fl_id;
-			uint8_t fl_o;
-			const uint32_t sl_id = t.gid[sl.sl];
-			X.loc[x] = (uint8_t)sl.loc;
-			X.sl[x] = sl.sl;
-			if (sl.loc == CL_AI_TRUNK || sl.loc == CL_AI_BRANCH) {
-				side_id_or(t, ai, true, fl_id, fl_o);
-				const bool fwd_if_r = (sl.loc == CL_AI_TRUNK) == black;
-				const uint8_t sl_o = (sl_r == fwd_if_r) ? 0 : 1;
-				if (sl_o == 1 && fl_o == 1) {
-					X.id1[x] = sl_id, X.or1[x] = 0;
-					X.id2[x] = fl_id, X.or2[x] = 0;
+			if (lane == 0) {
+				const uint32_t x = xb + v;
+				// gen_ai_slubble, concealed.cpp:70-152 / gen_zi_slubble, :154-206
+				const bool sl_r = (t.flags[sl.sl] & TF_TYPE_MASK) == 1u, black = (t.flags[sl.sl] & TF_BLACK) != 0;
+				uint32_t fl_id;
+				uint8_t fl_o;
+				const uint32_t sl_id = t.gid[sl.sl];
+				X.loc[x] = (uint8_t)sl.loc;
+				X.sl[x] = sl.sl;
+				if (sl.loc == CL_AI_TRUNK || sl.loc == CL_AI_BRANCH) {
+					side_id_or(t, ai, true, fl_id, fl_o);
+					const bool fwd_if_r = (sl.loc == CL_AI_TRUNK) == black;
+					const uint8_t sl_o = (sl_r == fwd_if_r) ? 0 : 1;
+					if (sl_o == 1 && fl_o == 1) {
+						X.id1[x] = sl_id, X.or1[x] = 0;
+						X.id2[x] = fl_id, X.or2[x] = 0;
+					} else {
+						X.id1[x] = fl_id, X.or1[x] = fl_o;
+						X.id2[x] = sl_id, X.or2[x] = sl_o;
+					}
+					X.route[x] = 'R';
+					if (sl.loc == CL_AI_TRUNK) {
+						if (t.is_desc(ai, sl.be_src))
+							X.b_up[x] = ai, X.b_lo[x] = sl.be_src;
+						else
+							X.b_up[x] = sl.be_src, X.b_lo[x] = ai;
+					} else {
+						X.b_up[x] = sl.sl, X.b_lo[x] = NIL;
+					}
 				} else {
-					X.id1[x] = fl_id, X.or1[x] = fl_o;
-					X.id2[x] = sl_id, X.or2[x] = sl_o;
-				}
-				X.route[x] = 'R';
-				if (sl.loc == CL_AI_TRUNK) {
-					if (t.is_desc(ai, sl.be_src))
-						X.b_up[x] = ai, X.b_lo[x] = sl.be_src;
+					side_id_or(t, zi, false, fl_id, fl_o);
+					const uint8_t sl_o = (sl_r == black) ? 0 : 1;
+					X.id1[x] = sl_id, X.or1[x] = (sl_o == 1 && fl_o == 1) ? 0 : sl_o;
+					X.id2[x] = fl_id, X.or2[x] = (sl_o == 1 && fl_o == 1) ? 0 : fl_o;
+					X.route[x] = 'L';
+					if (t.is_desc(zi, sl.sl))
+						X.b_up[x] = zi, X.b_lo[x] = sl.sl;
 					else
-						X.b_up[x] = sl.be_src, X.b_lo[x] = ai;
-				} else {
-					X.b_up[x] = sl.sl, X.b_lo[x] = NIL;
+						X.b_up[x] = sl.sl, X.b_lo[x] = zi;
 				}
-			} else {
-				side_id_or(t, zi, false, fl_id, fl_o);
-				const uint8_t sl_o = (sl_r == black) ? 0 : 1;
-				X.id1[x] = sl_id, X.or1[x] = (sl_o == 1 && fl_o == 1) ? 0 : sl_o;
-				X.id2[x] = fl_id, X.or2[x] = (sl_o == 1 && fl_o == 1) ? 0 : fl_o;
-				X.route[x] = 'L';
-				if (t.is_desc(zi, sl.sl))
-					X.b_up[x] = zi, X.b_lo[x] = sl.sl;
-				else
-					X.b_up[x] = sl.sl, X.b_lo[x] = zi;
 			}
-			S.push(f, v);
+			S.sync();
+			if (!S.push(f, v))
+				return;
 			touch(f);
-			if (is_leaf)
+			if (is_leaf || sl.loc == CL_ZI_BRANCH) // zi_branch: add_conc_zi asks for ai_branch (:1134) and ends in "sl type: unknown"
 				continue;
-			// The nestings run over a COPY of the children and erase the ones that leave: a stable filter of the first nch
-			// entries (one pass; erasing them one by one is quadratic on a flubble with very many children)
-			const uint32_t nch = X.vn[xb + f], fb = X.vbeg[xb + f];
-			uint32_t w = 0;
-			for (uint32_t r = 0; r < nch; r++) {
-				const uint32_t ch = X.pool[fb + r];
-				bool moved = false;
-				if (S.fl_like(ch)) {
+			// the nestings: which of the children (the new vertex among them: it is no flubble) leave for the slubble
+			const uint32_t nch = X.vn[xb + f];
+			const bool ok = S.filter(
+				f, nch, v, sl.loc == CL_ZI_TRUNK,
+				[&](uint32_t ch) {
+					if (!S.fl_like(ch))
+						return false;
 					const uint32_t c_ai = X.ai[xb + ch], c_zi = X.zi[xb + ch];
-					if (sl.loc == CL_AI_TRUNK) { // nest_trunk_ai, :945-979
-						if (t.depth[sl.sl] > t.depth[c_zi] || t.is_desc(sl.sl, c_ai)) {
-							S.push(v, ch);
-							moved = true;
-						}
-					} else if (sl.loc == CL_AI_BRANCH) { // nest_branch_ai, :984-1034
-						bool has_br = false; // a bracket of the child's zi that STARTS at ai (sic: get_src, :1006)
+					if (sl.loc == CL_AI_TRUNK) // nest_trunk_ai, :945-979
+						return t.depth[sl.sl] > t.depth[c_zi] || t.is_desc(sl.sl, c_ai);
+					if (sl.loc == CL_AI_BRANCH) { // nest_branch_ai, :984-1034
+						bool has_br = false;  // a bracket of the child's zi that STARTS at ai (sic: get_src, :1006)
 						for (uint32_t b = t.br_off[c_zi]; b < t.br_off[c_zi + 1] && !has_br; b++)
 							has_br = t.b_src[t.br_be[b]] == ai;
-						if (t.is_desc(sl.sl, c_ai) && has_br) {
-							S.push(v, ch);
-							moved = true;
-						}
-					} else if (sl.loc == CL_ZI_TRUNK) { // nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
-						if (t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi)) {
-							S.push(ch, v);
-							touch(ch);
-							moved = true;
-						}
+						return t.is_desc(sl.sl, c_ai) && has_br;
 					}
-					// zi_branch: add_conc_zi asks for ai_branch (:1134) and ends in "sl type: unknown"
-				}
-				if (!moved)
-					X.pool[X.vbeg[xb + f] + w++] = ch; // (vbeg again: f's own vector never moves here, but stay literal about it)
-			}
-			X.vn[xb + f] = w;
+					// nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
+					return t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi);
+				},
+				touch);
+			if (!ok)
+				return;
 		}
 	}
 	const uint32_t n_cn = nx - n0;
 	// ---- find_midi, midi.cpp:225-268 (the branch case is undefined in the reference: nothing comes of it), add_midi :19-61
 	const uint32_t n1 = nx;
-	sort_row(touched, n_touched, [](uint32_t a, uint32_t b) { return a < b; });
+	if (lane == 0)
+		sort_row(touched, n_touched, [](uint32_t a, uint32_t b) { return a < b; });
+	S.sync();
 	for (uint32_t k_t = 0; k_t < n_touched; k_t++) {
 		const uint32_t f = touched[k_t];
 		if (X.fam[xb + f] != FAM_FLUBBLE)
 			continue;
 		uint32_t n_c = 0, n_trunk = 0, trunk[2] = {NIL, NIL};
-		const uint32_t zi = X.zi[xb + f];
-		for (uint32_t k = 0; k < X.vn[xb + f]; k++) {
-			const uint32_t ch = X.pool[X.vbeg[xb + f] + k];
-			if (X.fam[xb + ch] != FAM_CONCEALED)
-				continue;
-			n_c++;
-			if (X.sl[xb + ch] < zi) { // in_trunk, :163-166
+		const uint32_t zi = X.zi[xb + f], nch = X.vn[xb + f], fb = X.vbeg[xb + f];
+		for (uint32_t r0 = 0; r0 < nch; r0 += 64) { // the concealed children, 64 children a round, in order
+			const uint32_t r = r0 + lane;
+			const uint32_t ch = r < nch ? X.pool[fb + r] : 0u;
+			const bool is_c = r < nch && X.fam[xb + ch] == FAM_CONCEALED;
+			const bool in_trunk = is_c && X.sl[xb + ch] < zi; // in_trunk, :163-166
+			n_c += (uint32_t)__popcll(__ballot(is_c));
+			for (unsigned long long m = __ballot(in_trunk); m; m &= m - 1) {
 				if (n_trunk < 2)
-					trunk[n_trunk] = ch;
+					trunk[n_trunk] = __shfl(ch, __ffsll((long long)m) - 1);
 				n_trunk++;
 			}
 		}
@@ -1199,9 +1278,12 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 		if (g_idx == NIL || s_idx == NIL)
 			continue;
 		// (all midi bubbles are found before the first is added: remember the pair in the flubble's spare fields)
-		X.b_up[xb + f] = g_idx;
-		X.b_lo[xb + f] = s_idx;
+		if (lane == 0) {
+			X.b_up[xb + f] = g_idx;
+			X.b_lo[xb + f] = s_idx;
+		}
 	}
+	S.sync();
 	for (uint32_t k_t = 0; k_t < n_touched; k_t++) {
 		const uint32_t f = touched[k_t];
 		if (X.fam[xb + f] != FAM_FLUBBLE || X.b_up[xb + f] == NIL)
@@ -1212,26 +1294,24 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 		const uint32_t v = new_vertex(FAM_MIDI);
 		if (v == NIL)
 			return;
-		const uint32_t x = xb + v;
-		// cn_b of a concealed vertex: the second boundary when it was formed with a, the first with z (Concealed::as_str)
-		X.id1[x] = X.id2[xb + g_idx], X.or1[x] = X.or2[xb + g_idx];
-		X.id2[x] = X.id1[xb + s_idx], X.or2[x] = X.or1[xb + s_idx];
-		X.route[x] = 'L';
-		X.b_up[x] = up, X.b_lo[x] = lo;
-		S.push(f, v);
+		if (lane == 0) {
+			const uint32_t x = xb + v;
+			// cn_b of a concealed vertex: the second boundary when it was formed with a, the first with z (Concealed::as_str)
+			X.id1[x] = X.id2[xb + g_idx], X.or1[x] = X.or2[xb + g_idx];
+			X.id2[x] = X.id1[xb + s_idx], X.or2[x] = X.or1[xb + s_idx];
+			X.route[x] = 'L';
+			X.b_up[x] = up, X.b_lo[x] = lo;
+		}
+		S.sync();
 		// (sic) spanning-tree depths at the PVST indices of the two concealed vertices; past the tree: +infinity
 		const uint32_t d_up = up < N ? t.dep(base + up) : 0xFFFFFFFFu, d_lo = lo < N ? t.dep(base + lo) : 0xFFFFFFFFu;
-		// the children before the bubble (a copy in the reference), filtered in one pass; the bubble itself sits behind them
-		uint32_t w = 0;
-		for (uint32_t r = 0; r < nch; r++) {
-			const uint32_t ch = X.pool[X.vbeg[xb + f] + r];
-			if (X.fam[xb + ch] == FAM_FLUBBLE && d_up < t.depth[X.ai[xb + ch]] && d_lo > t.depth[X.zi[xb + ch]])
-				S.push(v, ch);
-			else
-				X.pool[X.vbeg[xb + f] + w++] = ch;
-		}
-		X.pool[X.vbeg[xb + f] + w++] = v;
-		X.vn[xb + f] = w;
+		// the children before the bubble (a copy in the reference) are filtered, then the bubble itself goes behind them
+		const bool ok = S.filter(
+			f, nch, v, false,
+			[&](uint32_t ch) { return X.fam[xb + ch] == FAM_FLUBBLE && d_up < t.depth[X.ai[xb + ch]] && d_lo > t.depth[X.zi[xb + ch]]; },
+			touch);
+		if (!ok || !S.push(f, v))
+			return;
 	}
 	const uint32_t n_md = nx - n1;
 	// ---- add_smothered, smothered.cpp:349-383: the concealed vertices in ascending idx, their records in search order
@@ -1242,23 +1322,27 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 		const uint32_t cnb_id = is_g ? X.id2[xb + cv] : X.id1[xb + cv];
 		const uint8_t cnb_or = is_g ? X.or2[xb + cv] : X.or1[xb + cv];
 		for (uint32_t r = smo_off[k]; r < smo_off[k + 1]; r++) {
-			const Smo &m = smo[r];
+			const Smo m = smo[r];
 			const uint32_t v = new_vertex(FAM_SMOTHERED);
 			if (v == NIL)
 				return;
-			const uint32_t x = xb + v;
-			const uint32_t sm_id = t.gid[m.sm_st];
-			const uint8_t sm_or = (t.flags[m.sm_st] & TF_TYPE_MASK) == 0u ? 1 : 0; // comp_e / comp_w: type l -> reverse
-			if ((m.flags & 2u) && (m.flags & 1u)) { // Smothered::as_str, pvst.hpp:612-636
-				X.id1[x] = cnb_id, X.or1[x] = cnb_or;
-				X.id2[x] = sm_id, X.or2[x] = sm_or;
-			} else {
-				X.id1[x] = sm_id, X.or1[x] = sm_or;
-				X.id2[x] = cnb_id, X.or2[x] = cnb_or;
+			if (lane == 0) {
+				const uint32_t x = xb + v;
+				const uint32_t sm_id = t.gid[m.sm_st];
+				const uint8_t sm_or = (t.flags[m.sm_st] & TF_TYPE_MASK) == 0u ? 1 : 0; // comp_e / comp_w: type l -> reverse
+				if ((m.flags & 2u) && (m.flags & 1u)) { // Smothered::as_str, pvst.hpp:612-636
+					X.id1[x] = cnb_id, X.or1[x] = cnb_or;
+					X.id2[x] = sm_id, X.or2[x] = sm_or;
+				} else {
+					X.id1[x] = sm_id, X.or1[x] = sm_or;
+					X.id2[x] = cnb_id, X.or2[x] = cnb_or;
+				}
+				X.route[x] = (m.flags & 2u) ? 'L' : 'R';
+				X.b_up[x] = m.b_up, X.b_lo[x] = m.b_lo;
 			}
-			X.route[x] = (m.flags & 2u) ? 'L' : 'R';
-			X.b_up[x] = m.b_up, X.b_lo[x] = m.b_lo;
-			S.push(cv, v);
+			S.sync();
+			if (!S.push(cv, v))
+				return;
 			// nest, :332-347: a range-for over children_v[cv] while del_edge erases from it, as libstdc++ runs it: the loop
 			// goes to the OLD end, the slots behind the live end hold what erase left there
 			const uint32_t old_end = X.vn[xb + cv];
@@ -1275,14 +1359,17 @@ __global__ void k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restric
 					continue;
 				if (t.is_desc(m.b_up, c_up) && t.is_desc(c_lo, m.b_lo)) {
 					S.erase(cv, ch);
-					S.push(v, ch);
+					if (!S.push(v, ch))
+						return;
 				}
 			}
 		}
 	}
-	counts[3 * c] = n_cn;
-	counts[3 * c + 1] = n_md;
-	counts[3 * c + 2] = nx - n2;
+	if (lane == 0) {
+		counts[3 * c] = n_cn;
+		counts[3 * c + 1] = n_md;
+		counts[3 * c + 2] = nx - n2;
+	}
 }
 // sizes of the final children lists (one lane per X slot), then the lists themselves into one compact array
 __global__ void k_sub_child_counts(uint32_t NX, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ counts,
@@ -1520,7 +1607,8 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	}
 	mark("layout, PVST vectors");
 	uint32_t *counts = dev32(3 * (size_t)C + 4);
-	LAUNCH(k_sub_splice, C, s, C, t, xoff, poff, cn_off, cn, mn, sm_off, smo, X, counts);
+	if (C)
+		KLAUNCH(k_sub_splice, dim3(C), dim3(64), 0, s, C, t, xoff, poff, cn_off, cn, mn, sm_off, smo, X, counts);
 	mark("splice");
 	const uint32_t e = host.read_u32(err, s);
 	if (e & E_BR_ROW)
