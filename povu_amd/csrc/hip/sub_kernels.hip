@@ -8,17 +8,19 @@
 //   tables    depth (the tree stage writes it), literal hi (flubbles.cpp:552,640: a simplifying edge resets it to the root,
 //             which every ancestor then inherits), back edges by source and by target (all three types), the bracket table
 //             MATERIALISED as the reference does (count_brackets / collect_backedges_by_vertex, tree_utils.cpp:167-216,
-//             531-574: one lane per back edge walks from parent(src) up to the target) with every row sorted into the order
-//             the reference's rows have (back-edge idx = creation order in from_bd, see "creation key"), LoA by the
-//             reference's own heap, one lane per component (tree_utils.cpp:224-273; a closed form holds only without
-//             self-loop back edges, oracle/povu_oracle_sub.inc), LCA = parent of the shallowest vertex of an index range
-//             (a segment tree over the depths: vertex idx = pre-order rank);
+//             531-574), every vertex enumerating its own row through a segment tree over the edges' targets, with every row
+//             sorted into the order the reference's rows have (back-edge idx = creation order in from_bd, see "creation
+//             key"), LoA (tree_utils.cpp:224-273) in closed form from a max-tree over the edges' intervals -- by the
+//             reference's own heap, one lane per component, only where a self-loop back edge (the root of a tip-less
+//             component has one) leaves stale entries in it (oracle/povu_oracle_sub.inc) --, LCA = parent of the shallowest
+//             vertex of an index range (a segment tree over the depths: vertex idx = pre-order rank);
 //   search    one lane per flubble (concealed.cpp:234-921) and one per concealed vertex (smothered.cpp:61-318), each run
 //             twice -- count, scan, emit;
 //   splice    add_concealed, find_midi / add_midi and add_smothered change the children vectors of the PVST in an order
 //             that shows in the output (vector::push_back / erase, pvst.hpp:860-885) and reach across families (a
 //             concealed vertex is appended to the children of a CHILD flubble, concealed.cpp:1077): they run literally,
-//             one lane per component, over vectors in a bump arena -- linear work, 25 lanes on a whole genome.
+//             one WAVE per component, over vectors in a bump arena; the loops over a flubble's children are shared out
+//             over the lanes.
 // Accidents of the reference that are kept and behaviour it leaves undefined are those listed at the top of
 // oracle/povu_oracle_sub.inc, decided the same way here.  PARITY UNPINNED: the reference holds no C / M / S line; the
 // tests compare with the oracle's sequential restatement.
@@ -900,7 +902,7 @@ __global__ void k_sub_smo_emit(uint32_t NC, const SubT t, const CompAt comp, con
 	smo_search(t, comp, cn[k], out + off[k]);
 }
 
-// ------------------------------------------------------------------ the splice, one lane per component
+// ------------------------------------------------------------------ the splice, one wave per component
 // The extended PVST of component c lives in X-space: x = xoff[c] + (index inside the component).  Children of a vertex: a
 // vector {begin, size, capacity} in the component's stretch of the pool, doubled when full (pvst.hpp:860-885).
 struct XArrays {
