@@ -155,3 +155,12 @@ def test_the_literal_heap_of_lo_gives_the_closed_form(hip, monkeypatch):
         check(hip, W.random_bidirected(nv, int(rng.integers(nv, 3 * nv)), int(rng.integers(1 << 30)), self_loops=bool(it % 2)))
     check(hip, W.hprc_tangled(20000, seed=3, tangle_every=2000, max_tangle=500))
     check(hip, W.bubble_zoo(20, 8, 5))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_builder_style_graphs_without_tips(hip, seed):
+    """Uploaded with explicit all-zero tips (the library's builder API): the root of every component gets a back edge to
+    itself (spanning_tree.cpp:387-395) -- in nobody's bracket table (oracle: "leaf subflubble passes"), and the case where
+    compute_LoA's heap keeps a stale entry (the device then runs the literal heap for that component)."""
+    for g in (W.bubble_zoo(12, 8, 100 + seed), W.hprc_shaped([2000, 700], seed=seed), W.random_bidirected(300, 420, 900 + seed, self_loops=True)):
+        check(hip, g, np.zeros(g.n_vtx, dtype=np.uint8))
