@@ -179,54 +179,61 @@ extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *er
 		d->z_or[i] = r.label[last] == '>' ? 0 : 1;
 		d->route[i] = (!r.route.empty() && r.route[0] == 'L') ? 0 : 1;
 	}
-	// children column -> parent pointers, in listed order (:284-297, split_numbers :83-130)
-	for (uint32_t i = 0; i < n; i++) {
-		const std::string &ch = rows[i].children;
-		if (ch == ".")
-			continue;
-		size_t pos = 0;
-		while (pos < ch.size()) {
-			size_t comma = ch.find(',', pos);
-			std::string t = ch.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
-			char *e = nullptr;
-			long v = strtol(t.c_str(), &e, 10);
-			if (e != t.c_str()) {
-				auto it = by_file_id.find((uint32_t)v);
-				if (it != by_file_id.end())
-					d->parent[it->second] = i;
+	// children column -> add_edge(parent, child) in listed order (:284-297, split_numbers :83-130): the parent pointer of a
+	// vertex is its LAST lister, the children vectors hold every listing (`decompose -s` writes trees in which a concealed
+	// vertex is listed under two parents and a flubble under none: concealed.cpp:1077)
+	std::vector<uint32_t> coff(n + 1, 0), cadj;
+	for (int pass = 0; pass < 2; pass++) {
+		std::vector<uint32_t> cur(coff.begin(), coff.end() - 1);
+		for (uint32_t i = 0; i < n; i++) {
+			const std::string &ch = rows[i].children;
+			if (ch == ".")
+				continue;
+			size_t pos = 0;
+			while (pos < ch.size()) {
+				size_t comma = ch.find(',', pos);
+				std::string t = ch.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+				char *e = nullptr;
+				long v = strtol(t.c_str(), &e, 10);
+				if (e != t.c_str()) {
+					auto it = by_file_id.find((uint32_t)v);
+					if (it != by_file_id.end()) {
+						if (pass == 0) {
+							d->parent[it->second] = i;
+							coff[i + 1]++;
+						} else {
+							cadj[cur[i]++] = it->second;
+						}
+					}
+				}
+				if (comma == std::string::npos)
+					break;
+				pos = comma + 1;
 			}
-			if (comma == std::string::npos)
-				break;
-			pos = comma + 1;
+		}
+		if (pass == 0) {
+			for (uint32_t i = 0; i < n; i++)
+				coff[i + 1] += coff[i];
+			cadj.resize(coff[n] + 1);
 		}
 	}
-	// comp_heights (pvst.hpp:807-836): distance from the root by a traversal over the child lists -- a file may
-	// list a vertex before its parent; vertices the root does not reach keep height 0
+	// comp_heights (pvst.hpp:807-836), literally: a stack, every child of the popped vertex gets its height and is pushed --
+	// a vertex listed under two parents is walked twice and keeps the height of the last visit, vertices the root does not
+	// reach keep 0.  The reference does not end on a file whose listings form a cycle; here the walk stops after 64 n + 1024
+	// pushes.
 	if (root != POVU_HIP_NIL) {
-		std::vector<uint32_t> coff(n + 1, 0), cadj(n), stack;
-		for (uint32_t i = 0; i < n; i++)
-			if (d->parent[i] != POVU_HIP_NIL)
-				coff[d->parent[i] + 1]++;
-		for (uint32_t i = 0; i < n; i++)
-			coff[i + 1] += coff[i];
-		std::vector<uint32_t> cur(coff.begin(), coff.end() - 1);
-		for (uint32_t i = 0; i < n; i++)
-			if (d->parent[i] != POVU_HIP_NIL)
-				cadj[cur[d->parent[i]]++] = i;
-		// (a malformed file may list the root, or an ancestor, as somebody's child: every vertex is entered once)
-		std::vector<uint8_t> seen(n, 0);
-		seen[root] = 1;
+		std::vector<uint32_t> stack;
+		uint64_t pushes = 0;
+		const uint64_t limit = 64ull * n + 1024;
 		stack.push_back(root);
-		while (!stack.empty()) {
+		while (!stack.empty() && pushes < limit) {
 			const uint32_t v = stack.back();
 			stack.pop_back();
 			for (uint32_t k = coff[v]; k < coff[v + 1]; k++) {
 				const uint32_t c = cadj[k];
-				if (seen[c])
-					continue;
-				seen[c] = 1;
 				d->height[c] = d->height[v] + 1;
 				stack.push_back(c);
+				pushes++;
 			}
 		}
 	}

@@ -487,6 +487,15 @@ def test_pvst_reader_subflubble_lines():
     assert col("z_or")[1:] == [0, 0, 1, 0, 0, 0, 1, 0]
     assert col("route")[1:] == [0, 0, 1, 1, 0, 0, 1, 0]
     hl.povu_pvst_doc_free(d)
+    # what `decompose -s` really writes where find_concealed nests "in relation to z" (concealed.cpp:1077 hangs the concealed
+    # vertex below the child flubble): vertex 3 listed under 1 AND 2, vertex 2 under nobody.  add_edge makes the last lister
+    # the parent; comp_heights walks the children vectors from the root: 0 -> 1 -> 3, and never reaches 2
+    text = b"H\t0.0.3\t.\t.\t.\nD\t0\t.\t1\t.\nF\t1\t>1>7\t3\tL\nT\t2\t>4>6\t3\tL\nC\t3\t>4>7\t.\tL\n"
+    d = hl.povu_pvst_parse(text, len(text), err, 256)
+    assert d, err.value
+    assert [d.contents.parent[i] for i in range(4)] == [NIL, 0, NIL, 2]
+    assert [d.contents.height[i] for i in range(4)] == [0, 1, 0, 2]
+    hl.povu_pvst_doc_free(d)
     assert not hl.povu_pvst_parse(b"X\t1\t>1>2\t.\tL\n", 13, err, 256) and b"Unknown vertex type" in err.value
     assert not hl.povu_pvst_parse(b"T\t1\t12\t.\tL\n", 11, err, 256) and b"malformed vertex label" in err.value
 

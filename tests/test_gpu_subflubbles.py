@@ -164,3 +164,39 @@ def test_builder_style_graphs_without_tips(hip, seed):
     compute_LoA's heap keeps a stale entry (the device then runs the literal heap for that component)."""
     for g in (W.bubble_zoo(12, 8, 100 + seed), W.hprc_shaped([2000, 700], seed=seed), W.random_bidirected(300, 420, 900 + seed, self_loops=True)):
         check(hip, g, np.zeros(g.n_vtx, dtype=np.uint8))
+
+
+def test_reader_round_trip_on_the_extended_trees(hip):
+    """povu_pvst_parse (read_pvst + comp_heights, from_pvst.cpp:162-302, pvst.hpp:807-836) on what -s wrote: letters,
+    boundaries and routes come back, the parent of a vertex is its LAST lister (add_edge), a vertex nobody lists has none."""
+    import ctypes as C
+    from povu_amd import hip as H
+    from test_cabi_and_host import _Doc
+    hl = H.load_lib()
+    hl.povu_pvst_parse.restype = C.POINTER(_Doc)
+    hl.povu_pvst_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    hl.povu_pvst_doc_free.argtypes = [C.POINTER(_Doc)]
+    NIL = 0xFFFFFFFF
+    seen = collections.Counter()
+    for rule in ("nest_trunk_zi", "midi", "smo_g_trunk_src", "smo_nest", "zi_branch"):
+        g = rule_graph(rule)
+        hip.upload(g, rule_tips(rule, g))
+        for text in hip.decompose(flags=F_SUBFLUBBLES).texts().values():
+            rows = [l.split("\t") for l in text.splitlines()[1:]]
+            err = C.create_string_buffer(256)
+            raw = text.encode()
+            d = hl.povu_pvst_parse(raw, len(raw), err, 256)
+            assert d, err.value
+            doc = d.contents
+            assert doc.n == len(rows)
+            want_parent = [NIL] * len(rows)
+            for i, r in enumerate(rows):
+                if r[3] != ".":
+                    for c in r[3].split(", "):
+                        want_parent[int(c)] = i
+            assert [doc.parent[i] for i in range(doc.n)] == want_parent
+            assert b"".join(doc.type[i] for i in range(doc.n)).decode() == "".join(r[0] for r in rows)
+            assert [doc.route[i] for i in range(1, doc.n)] == [0 if r[4] == "L" else 1 for r in rows[1:]]
+            seen.update(r[0] for r in rows)
+            hl.povu_pvst_doc_free(d)
+    assert seen["C"] and seen["M"] and seen["S"]
