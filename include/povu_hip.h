@@ -294,7 +294,7 @@ typedef struct {
 	uint32_t n_total, n_flubble_like, n_concealed, n_midi, n_smothered;
 	const uint8_t *fam, *or1, *or2, *route;
 	const uint32_t *id1, *id2;
-	const uint64_t *child_off; /* [n_total + 1], offsets into `child` */
+	const uint32_t *child_off; /* [n_total + 1], offsets into `child` */
 	const uint32_t *child;
 } povu_hip_subtree;
 int povu_hip_forest_get_subtree(const povu_hip_forest *f, uint32_t i, povu_hip_subtree *out);

@@ -997,7 +997,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 							       "whose PVST layout the inserting passes do not read");
 					tm.begin("subflubbles_insert");
 					f->subx = std::make_shared<SubForest>();
-					run_subflubbles(cs, sw, ctx->pw, ctx->tw, leaf_state, C, ctx->host, *f->subx, s, &ctx->ws_sub, &ctx->ws_sub_hint);
+					run_subflubbles(cs, sw, ctx->pw, ctx->tw, leaf_state, C, ctx->host, *f->subx, ctx->pool, s, &ctx->ws_sub, &ctx->ws_sub_hint);
 					tm.end(40);
 				}
 				sum = nullptr; // (read again below: the pass total then includes this stage)
@@ -1363,14 +1363,14 @@ extern "C" int povu_hip_forest_get_subtree(const povu_hip_forest *f, uint32_t i,
 	out->n_concealed = x->counts[3 * (size_t)t.sub_c];
 	out->n_midi = x->counts[3 * (size_t)t.sub_c + 1];
 	out->n_smothered = x->counts[3 * (size_t)t.sub_c + 2];
-	out->fam = x->fam.data() + b;
-	out->or1 = x->or1.data() + b;
-	out->or2 = x->or2.data() + b;
-	out->route = x->route.data() + b;
-	out->id1 = x->id1.data() + b;
-	out->id2 = x->id2.data() + b;
-	out->child_off = x->coff.data() + b;
-	out->child = x->child.data();
+	out->fam = x->fam + b;
+	out->or1 = x->or1 + b;
+	out->or2 = x->or2 + b;
+	out->route = x->route + b;
+	out->id1 = x->id1 + b;
+	out->id2 = x->id2 + b;
+	out->child_off = x->coff + b;
+	out->child = x->child;
 	return 0;
 }
 
@@ -1396,11 +1396,11 @@ extern "C" char *povu_hip_pvst_format_subtree(const povu_hip_subtree *t, size_t 
 			o += std::to_string(t->id2[v]);
 		}
 		o += '\t';
-		const uint64_t c0 = t->child_off[v], c1 = t->child_off[v + 1];
+		const uint32_t c0 = t->child_off[v], c1 = t->child_off[v + 1];
 		if (c0 == c1) {
 			o += '.';
 		} else { // print_with_comma, include/povu/common/utils.hpp:44-55
-			for (uint64_t k = c0; k < c1; k++) {
+			for (uint32_t k = c0; k < c1; k++) {
 				o += std::to_string(t->child[k]);
 				if (k + 1 < c1)
 					o += ", ";

@@ -32,6 +32,8 @@
 // scan order (b_ord).  So (tn ascending, source descending, b_ord ascending) is the idx order.
 #include "sub_kernels.hpp"
 
+#include "context.hpp"
+
 #include "segtree.hpp"
 
 #include <chrono>
@@ -1431,8 +1433,15 @@ __global__ void k_sub_compact(uint32_t NV, uint32_t C, const uint32_t *__restric
 }
 } // namespace
 
+SubForest::~SubForest()
+{
+	if (blk && pool)
+		pool->put(blk, blk_cap, blk_seg);
+}
+
 void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, const TreeWs &tw, const LeafState &ls, uint32_t C,
-		     HostScratch &host, SubForest &out, hipStream_t s, Arena *arena, size_t *arena_hint)
+		     HostScratch &host, SubForest &out, const std::shared_ptr<::PinnedPool> &pool, hipStream_t s, Arena *arena,
+		     size_t *arena_hint)
 {
 	const uint32_t V = sw.V, T = 2 * V + C;
 	const uint32_t NB0 = pw.nb0, NB = pw.nb0 + pw.ncap + pw.nsimp;
@@ -1635,7 +1644,6 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	if (C)
 		HIP_CHECK(copy_async(h_counts.data(), counts, 3 * (size_t)C * 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	out = SubForest{};
 	out.voff.assign((size_t)C + 1, 0);
 	uint64_t n_vtx = 0;
 	for (uint32_t c = 0; c < C; c++) {
@@ -1653,25 +1661,35 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	uint8_t *d_fam = dev8((size_t)NV + 4), *d_or1 = dev8((size_t)NV + 4), *d_or2 = dev8((size_t)NV + 4), *d_route = dev8((size_t)NV + 4);
 	uint32_t *d_id1 = dev32((size_t)NV + 4), *d_id2 = dev32((size_t)NV + 4), *d_coff = dev32((size_t)NV + 4);
 	LAUNCH(k_sub_compact, NV, s, NV, C, dvoff, xoff, X, coff, d_fam, d_or1, d_or2, d_route, d_id1, d_id2, d_coff);
-	out.fam.resize(n_vtx), out.or1.resize(n_vtx), out.or2.resize(n_vtx), out.route.resize(n_vtx);
-	out.id1.resize(n_vtx), out.id2.resize(n_vtx), out.coff.resize(n_vtx + 1), out.child.resize(NCH);
-	std::vector<uint32_t> h_coff(n_vtx);
+	// one page-locked block: fam | or1 | or2 | route | id1 | id2 | coff (+ 1) | child
+	auto pad = [](size_t b) { return (b + 63) & ~size_t(63); };
+	const size_t b8 = pad((size_t)NV + 1), b32 = pad(((size_t)NV + 1) * 4), bch = pad(((size_t)NCH + 1) * 4);
+	const size_t total_bytes = 4 * b8 + 3 * b32 + bch + 64;
+	if (!pool)
+		throw HipError("subflubble passes: no pool of page-locked memory (internal)");
+	out.pool = pool;
+	out.blk = pool->get(total_bytes, out.blk_cap, &out.blk_seg);
+	char *hb = static_cast<char *>(out.blk);
+	uint8_t *o_fam = reinterpret_cast<uint8_t *>(hb), *o_or1 = o_fam + b8, *o_or2 = o_or1 + b8, *o_route = o_or2 + b8;
+	uint32_t *o_id1 = reinterpret_cast<uint32_t *>(hb + 4 * b8), *o_id2 = reinterpret_cast<uint32_t *>(hb + 4 * b8 + b32);
+	uint32_t *o_coff = reinterpret_cast<uint32_t *>(hb + 4 * b8 + 2 * b32), *o_child = reinterpret_cast<uint32_t *>(hb + 4 * b8 + 3 * b32);
 	auto d2h = [&](void *dst, const void *src, size_t bytes) {
 		if (bytes)
 			HIP_CHECK(copy_async(dst, src, bytes, hipMemcpyDeviceToHost, s));
 	};
-	d2h(out.fam.data(), d_fam, NV);
-	d2h(out.or1.data(), d_or1, NV);
-	d2h(out.or2.data(), d_or2, NV);
-	d2h(out.route.data(), d_route, NV);
-	d2h(out.id1.data(), d_id1, (size_t)NV * 4);
-	d2h(out.id2.data(), d_id2, (size_t)NV * 4);
-	d2h(h_coff.data(), d_coff, (size_t)NV * 4);
-	d2h(out.child.data(), child, (size_t)NCH * 4); // (the lists are compact already, in vertex order)
+	d2h(o_fam, d_fam, NV);
+	d2h(o_or1, d_or1, NV);
+	d2h(o_or2, d_or2, NV);
+	d2h(o_route, d_route, NV);
+	d2h(o_id1, d_id1, (size_t)NV * 4);
+	d2h(o_id2, d_id2, (size_t)NV * 4);
+	d2h(o_coff, d_coff, (size_t)NV * 4);
+	d2h(o_child, child, (size_t)NCH * 4); // (the lists are compact already, in vertex order)
 	HIP_CHECK(hipStreamSynchronize(s));
-	for (uint64_t v = 0; v < n_vtx; v++)
-		out.coff[v] = h_coff[v];
-	out.coff[n_vtx] = NCH;
+	o_coff[NV] = NCH;
+	out.n_vtx = n_vtx, out.n_child = NCH;
+	out.fam = o_fam, out.or1 = o_or1, out.or2 = o_or2, out.route = o_route;
+	out.id1 = o_id1, out.id2 = o_id2, out.coff = o_coff, out.child = o_child;
 	if (arena_hint)
 		*arena_hint = need; // (the next call on this context reserves that much up front)
 	mark("to the host");

@@ -31,7 +31,7 @@ class _SubTree(C.Structure):
     _fields_ = [("n_total", C.c_uint32), ("n_flubble_like", C.c_uint32), ("n_concealed", C.c_uint32), ("n_midi", C.c_uint32),
                 ("n_smothered", C.c_uint32), ("fam", C.POINTER(C.c_uint8)), ("or1", C.POINTER(C.c_uint8)),
                 ("or2", C.POINTER(C.c_uint8)), ("route", C.POINTER(C.c_uint8)), ("id1", C.POINTER(C.c_uint32)),
-                ("id2", C.POINTER(C.c_uint32)), ("child_off", C.POINTER(C.c_uint64)), ("child", C.POINTER(C.c_uint32))]
+                ("id2", C.POINTER(C.c_uint32)), ("child_off", C.POINTER(C.c_uint32)), ("child", C.POINTER(C.c_uint32))]
 
 
 class _Tree(C.Structure):
@@ -336,7 +336,7 @@ class Forest:
 
     def subtree(self, i: int):
         """Tree i after all five passes of -s (a decompose with F_SUBFLUBBLES): dict of n_total, n_flubble_like, n_concealed,
-        n_midi, n_smothered, fam / or1 / or2 / route (uint8) and id1 / id2 (uint32) per vertex, child_off (uint64, relative) and
+        n_midi, n_smothered, fam / or1 / or2 / route (uint8) and id1 / id2 (uint32) per vertex, child_off (uint32, relative) and
         child (uint32): children of vertex v = child[child_off[v]:child_off[v + 1]]."""
         st = _SubTree()
         rc = self._lib.povu_hip_forest_get_subtree(self._h, i, C.byref(st))

@@ -9,7 +9,7 @@ n = float(sys.argv[1]) if len(sys.argv) > 1 else 1e7
 g = W.hprc_whole_genome(n)
 hip = HipDecomposer(0)
 hip.upload(g)
-for rep in range(2):
+for rep in range(4):
     t0 = time.time(); f = hip.decompose(flags=F_SUBFLUBBLES); t1 = time.time()
     ms = hip.last_stage_times() if hasattr(hip, "last_stage_times") else {}
     print(f"segments {g.n_vtx} links {g.n_links}: decompose with -s {t1 - t0:.2f} s", {k: round(v, 1) for k, v in dict(ms).items() if "sub" in k or k == "total"}, flush=True)
