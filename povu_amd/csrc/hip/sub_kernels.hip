@@ -6,14 +6,16 @@
 // tree_utils.cpp:674-688: depths, LoA, LCA, the per-vertex bracket table) a few dozen questions; what it finds it then
 // splices into the PVST one vertex after the other.  Here:
 //   tables    depth (the tree stage writes it), literal hi (flubbles.cpp:552,640: a simplifying edge resets it to the root,
-//             which every ancestor then inherits), back edges by source and by target (all three types), the bracket table
-//             MATERIALISED as the reference does (count_brackets / collect_backedges_by_vertex, tree_utils.cpp:167-216,
-//             531-574), every vertex enumerating its own row through a segment tree over the edges' targets, with every row
-//             sorted into the order the reference's rows have (back-edge idx = creation order in from_bd, see "creation
-//             key"), LoA (tree_utils.cpp:224-273) in closed form from a max-tree over the edges' intervals -- by the
-//             reference's own heap, one lane per component, only where a self-loop back edge (the root of a tip-less
-//             component has one) leaves stale entries in it (oracle/povu_oracle_sub.inc) --, LCA = parent of the shallowest
-//             vertex of an index range (a segment tree over the depths: vertex idx = pre-order rank);
+//             which every ancestor then inherits), back edges by source and by target (all three types); the BRACKETS of a
+//             vertex (count_brackets / collect_backedges_by_vertex, tree_utils.cpp:167-216, 531-574) are not materialised
+//             as the reference's table is (one entry per back edge and vertex it spans: 10^10 on a graph with large
+//             tangles) but enumerated where a row is asked for, through a segment tree over the targets of the edges in
+//             source order; where the reference's row ORDER shows (back-edge idx = creation order in from_bd) the
+//             "creation key" below decides; LoA (tree_utils.cpp:224-273) in closed form from a max-tree over the edges'
+//             intervals -- by the reference's own heap, one lane per component, only where a self-loop back edge (the
+//             root of a tip-less component has one) leaves stale entries in it (oracle/povu_oracle_sub.inc) --, LCA =
+//             parent of the shallowest vertex of an index range (a segment tree over the depths: vertex idx = pre-order
+//             rank);
 //   search    one lane per flubble (concealed.cpp:234-921) and one per concealed vertex (smothered.cpp:61-318), each run
 //             twice -- count, scan, emit;
 //   splice    add_concealed, find_midi / add_midi and add_smothered change the children vectors of the PVST in an order
@@ -89,7 +91,7 @@ struct DevBuf {
 };
 
 enum : uint32_t { CL_AI_TRUNK = 0, CL_AI_BRANCH = 1, CL_ZI_TRUNK = 2, CL_ZI_BRANCH = 3 };
-enum : uint32_t { E_BR_ROW = 1u, E_POOL = 2u, E_SET = 4u, E_LAYOUT = 8u };
+enum : uint32_t { E_POOL = 2u, E_LAYOUT = 8u };
 
 // device view of the spanning forest (T-space: global tree vertex idx) and of the dense PVST output
 struct SubT {
@@ -99,7 +101,9 @@ struct SubT {
 	const uint8_t *flags;
 	const uint32_t *b_src, *b_tgt, *b_ord;
 	const uint32_t *o_off, *o_adj, *i_off, *i_adj; // back edges of all types by source / by target (edge = slot of the dense list)
-	const uint32_t *br_off, *br_be;		       // bracket table
+	const uint32_t *br_cnt;	       // |brackets(v)|
+	const uint32_t *O, *slot_s;	       // the ordinary edges in source order: position O[u] + r = the r-th edge of u, its slot in the dense list
+	SegTree segT;			       // over the targets of the edges in source order
 	const uint32_t *lo, *hi;
 	const unsigned long long *ekey; // [NB0] creation key: tn << 32 | ~source
 	SegTree segD;
@@ -111,7 +115,33 @@ struct SubT {
 	__device__ __forceinline__ uint32_t dep(uint32_t v) const { return (v < T && size[v]) ? depth[v] : 0xFFFFFFFFu; }
 	// pst::Tree::is_desc, spanning_tree.cpp:560-566: d is a proper descendant of a
 	__device__ __forceinline__ bool is_desc(uint32_t a, uint32_t d) const { return a < d && d < a + size[a]; }
-	__device__ __forceinline__ uint32_t n_br(uint32_t v) const { return br_off[v + 1] - br_off[v]; }
+	__device__ __forceinline__ uint32_t n_br(uint32_t v) const { return br_cnt[v]; }
+	// The brackets of v (tm.get_brackets, tree_utils.hpp:64-77): the ordinary edges whose source lies strictly below v and
+	// whose target lies above it = among the edges of the sources (v, v + size) those with a target idx below v, found one
+	// after the other in the segment tree over the targets.  The reference MATERIALISES the table, one entry per edge and
+	// vertex it spans -- 10^10 entries on a graph with large tangles; here a row is enumerated when it is asked for, in
+	// source order (what needs the reference's back-edge idx order asks created_before).  The root has none.
+	struct BrRange {
+		uint32_t pos, hi, v;
+	};
+	__device__ __forceinline__ BrRange brackets(uint32_t v) const
+	{
+		if (v >= T || !size[v] || gp[v] == NIL)
+			return BrRange{0u, 0u, v};
+		return BrRange{O[v + 1], O[v + size[v]], v};
+	}
+	__device__ __forceinline__ uint32_t br_next(BrRange &r) const // next bracket (slot of the dense list), NIL at the end
+	{
+		if (r.pos >= r.hi)
+			return NIL;
+		const uint32_t p = seg_first_less(segT, r.pos, r.hi, r.v);
+		if (p == NIL) {
+			r.pos = r.hi;
+			return NIL;
+		}
+		r.pos = p + 1;
+		return slot_s[p];
+	}
 	__device__ uint32_t lca(uint32_t a, uint32_t b) const
 	{
 		if (a == b)
@@ -324,46 +354,6 @@ __global__ void k_sub_edges_by_source(uint32_t T, const uint32_t *__restrict__ s
 		slot_s[o + r] = at + r;
 	}
 }
-// collect_backedges_by_vertex (tree_utils.cpp:167-216) from the vertex's side: the brackets of v are the edges whose source
-// lies strictly below v and whose target lies above it -- among the edges of the sources (v, v + size) those with a target
-// idx below v, found one after the other in a segment tree over the targets (a walk from every edge up its path, as the
-// reference does it, leaves one lane with a million steps when a link spans a chromosome)
-__global__ void k_sub_br_fill(uint32_t T, const uint32_t *__restrict__ size, const uint32_t *__restrict__ O, const SegTree segT,
-			      const uint32_t *__restrict__ slot_s, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ br_be,
-			      uint32_t *__restrict__ err)
-{
-	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
-		return;
-	const uint32_t n = br_off[v + 1] - br_off[v];
-	if (!n)
-		return;
-	const uint32_t hi = O[v + size[v]];
-	uint32_t k = 0;
-	for (uint32_t p = O[v + 1]; p < hi; p++) {
-		p = seg_first_less(segT, p, hi, v);
-		if (p == NIL)
-			break;
-		if (k >= n) {
-			atomicOr(err, E_BR_ROW);
-			return;
-		}
-		br_be[br_off[v] + k++] = slot_s[p];
-	}
-	if (k != n)
-		atomicOr(err, E_BR_ROW);
-}
-__global__ void k_sub_br_sort(uint32_t T, const uint32_t *__restrict__ br_off, uint32_t *__restrict__ br_be,
-			      const unsigned long long *__restrict__ ekey, const uint32_t *__restrict__ b_ord)
-{
-	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
-		return;
-	sort_row(br_be + br_off[v], br_off[v + 1] - br_off[v], [&](uint32_t x, uint32_t y) {
-		const unsigned long long kx = ekey[x], ky = ekey[y];
-		return kx != ky ? kx < ky : b_ord[x] < b_ord[y];
-	});
-}
 // LoA without self-loop back edges (see the proof in oracle/povu_oracle_sub.inc): lo[v] = the deepest target t < v of an
 // ordinary edge whose source lies behind v -- the largest left end among the intervals (t, s) that hold v.  Every edge marks
 // the canonical nodes of its interval in a max-tree over the vertex indices, every vertex reads the nodes above its leaf.
@@ -531,8 +521,11 @@ __device__ bool cn_ai_trunk(const SubT &t, uint32_t m, uint32_t n, uint32_t ai, 
 		if (t.depth[l] > t.depth[m])
 			continue;
 		bool ell_br = true;
-		for (uint32_t q = t.br_off[l]; q < t.br_off[l + 1] && ell_br; q++)
-			ell_br = t.depth[t.b_tgt[t.br_be[q]]] <= t.depth[ai];
+		{
+			SubT::BrRange br = t.brackets(l);
+			for (uint32_t e = t.br_next(br); e != NIL && ell_br; e = t.br_next(br))
+				ell_br = t.depth[t.b_tgt[e]] <= t.depth[ai];
+		}
 		const bool cond_iii = t.o_off[l + 1] > t.o_off[l] || t.nchild[l] > 1;
 		if (!ell_br && cond_iii)
 			continue;
@@ -550,8 +543,9 @@ __device__ bool cn_ai_trunk(const SubT &t, uint32_t m, uint32_t n, uint32_t ai, 
 __device__ uint32_t lca_of_bracket_srcs(const SubT &t, uint32_t c)
 {
 	uint32_t d = NIL;
-	for (uint32_t q = t.br_off[c]; q < t.br_off[c + 1]; q++) {
-		const uint32_t src = t.b_src[t.br_be[q]];
+	SubT::BrRange br = t.brackets(c);
+	for (uint32_t e = t.br_next(br); e != NIL; e = t.br_next(br)) {
+		const uint32_t src = t.b_src[e];
 		d = d == NIL ? src : t.lca(d, src);
 	}
 	return d;
@@ -595,15 +589,15 @@ __device__ uint32_t cn_override_ji_trunk(const SubT &t, uint32_t m, uint32_t n, 
 			continue;
 		if (t.n_br(c) != 1)
 			continue;
-		const uint32_t y = t.b_tgt[t.br_be[t.br_off[c]]];
+		SubT::BrRange br1 = t.brackets(c);
+		const uint32_t y = t.b_tgt[t.br_next(br1)];
 		if (!(t.depth[m] < t.depth[y] && t.depth[n] > t.depth[y]))
 			continue;
 		bool valid = true;
-		for (uint32_t k = t.br_off[y]; k < t.br_off[y + 1] && valid; k++) {
-			const uint32_t j = t.br_be[k];
+		SubT::BrRange bry = t.brackets(y);
+		for (uint32_t j = t.br_next(bry); j != NIL && valid; j = t.br_next(bry))
 			if (t.depth[t.b_src[j]] < t.depth[ji] || t.depth[t.b_tgt[j]] > t.depth[ii])
 				valid = false;
-		}
 		if (valid && t.depth[y] < t.depth[min_v])
 			min_v = y;
 	}
@@ -645,24 +639,35 @@ __device__ void cn_ji_branches(const SubT &t, uint32_t q, uint32_t ii, uint32_t 
 		for (uint32_t c = ji + 1; c < end; c += max(t.size[c], 1u)) {
 			uint32_t count = 0;
 			bool into_ji = false;
-			for (uint32_t k = t.br_off[c]; k < t.br_off[c + 1]; k++) {
-				if (t.b_tgt[t.br_be[k]] != ji)
-					count++;
-				else
-					into_ji = true;
+			{
+				SubT::BrRange br = t.brackets(c);
+				for (uint32_t e = t.br_next(br); e != NIL; e = t.br_next(br)) {
+					if (t.b_tgt[e] != ji)
+						count++;
+					else
+						into_ji = true;
+				}
 			}
 			if (count != 1 || into_ji != (pass == 0))
 				continue;
 			if (pass == 0) {
-				uint32_t lowest = c;
-				for (uint32_t k = t.br_off[c]; k < t.br_off[c + 1]; k++) {
-					const uint32_t j = t.br_be[k];
-					if (t.b_tgt[j] == ji && t.depth[t.b_src[j]] > t.depth[lowest])
-						lowest = t.b_src[j];
+				// the deepest source of a bracket into ji; among equally deep ones the reference keeps the first in back-edge
+				// idx order (depth[src] > depth[lowest], concealed.cpp:846)
+				uint32_t lowest = c, low_e = NIL;
+				SubT::BrRange br = t.brackets(c);
+				for (uint32_t j = t.br_next(br); j != NIL; j = t.br_next(br)) {
+					if (t.b_tgt[j] != ji)
+						continue;
+					const uint32_t sv = t.b_src[j];
+					if (t.depth[sv] > t.depth[lowest] || (low_e != NIL && t.depth[sv] == t.depth[lowest] && t.created_before(j, low_e))) {
+						lowest = sv;
+						low_e = j;
+					}
 				}
 				o.push(q, CL_ZI_BRANCH, lowest, NIL);
 			} else {
-				const uint32_t j = t.br_be[t.br_off[c]];
+				SubT::BrRange br = t.brackets(c);
+				const uint32_t j = t.br_next(br); // (its only bracket)
 				const uint32_t src = t.b_src[j], tgt = t.b_tgt[j];
 				bool cond_i = false;
 				uint32_t d = src;
@@ -768,10 +773,21 @@ __device__ uint32_t smo_search(const SubT &t, const CompAt &comp, const Slub &cn
 		for (uint32_t ch = sl + 1; ch < end; ch += max(t.size[ch], 1u)) {
 			if (t.n_br(ch) == 0)
 				continue;
-			const uint32_t last = t.br_be[t.br_off[ch + 1] - 1], src = t.b_src[last], tgt = t.b_tgt[last];
+			// the LAST bracket of the row in back-edge idx order (be_idx_, smothered.cpp:94-101) and whether all have its source
+			uint32_t last = NIL;
+			{
+				SubT::BrRange br = t.brackets(ch);
+				for (uint32_t e = t.br_next(br); e != NIL; e = t.br_next(br))
+					if (last == NIL || t.created_before(last, e))
+						last = e;
+			}
+			const uint32_t src = t.b_src[last], tgt = t.b_tgt[last];
 			bool one_src = true;
-			for (uint32_t k = t.br_off[ch]; k < t.br_off[ch + 1] && one_src; k++)
-				one_src = t.b_src[t.br_be[k]] == src;
+			{
+				SubT::BrRange br = t.brackets(ch);
+				for (uint32_t e = t.br_next(br); e != NIL && one_src; e = t.br_next(br))
+					one_src = t.b_src[e] == src;
+			}
 			if (!(one_src && t.depth[tgt] > t.depth[ai]))
 				continue;
 			const uint32_t brch = t.lca(zi, src);
@@ -786,13 +802,27 @@ __device__ uint32_t smo_search(const SubT &t, const CompAt &comp, const Slub &cn
 		const uint32_t t0 = next_distinct(t.o_off, t.o_adj, t.b_tgt, sl, 0, true);
 		if (t0 == NIL || t0 != ai || next_distinct(t.o_off, t.o_adj, t.b_tgt, sl, t0, false) != NIL)
 			break;
-		for (uint32_t k = t.br_off[sl]; k < t.br_off[sl + 1]; k++) {
-			const uint32_t j = t.br_be[k];
-			if (t.b_tgt[j] != ai)
-				continue;
-			const uint32_t src = t.b_src[j];
-			for (uint32_t r = t.br_off[src]; r < t.br_off[src + 1]; r++)
-				if (t.b_tgt[t.br_be[r]] == sl) {
+		// the brackets of sl that end at ai, in back-edge idx order (the row is enumerated in source order: the next one is
+		// the earliest created behind the last); each gives one vertex per bracket of its source that ends at sl
+		uint32_t prev_e = NIL;
+		for (;;) {
+			uint32_t best = NIL;
+			SubT::BrRange br = t.brackets(sl);
+			for (uint32_t j = t.br_next(br); j != NIL; j = t.br_next(br)) {
+				if (t.b_tgt[j] != ai)
+					continue;
+				if (prev_e != NIL && !t.created_before(prev_e, j))
+					continue;
+				if (best == NIL || t.created_before(j, best))
+					best = j;
+			}
+			if (best == NIL)
+				break;
+			prev_e = best;
+			const uint32_t src = t.b_src[best];
+			SubT::BrRange br2 = t.brackets(src);
+			for (uint32_t r = t.br_next(br2); r != NIL; r = t.br_next(br2))
+				if (t.b_tgt[r] == sl) {
 					uint32_t up, lo;
 					smo_bounds(t, sl, src, up, lo);
 					o.push(src, true, true, up, lo);
@@ -1233,8 +1263,9 @@ __global__ void __launch_bounds__(64) k_sub_splice(uint32_t C, const SubT t, con
 						return t.depth[sl.sl] > t.depth[c_zi] || t.is_desc(sl.sl, c_ai);
 					if (sl.loc == CL_AI_BRANCH) { // nest_branch_ai, :984-1034
 						bool has_br = false;  // a bracket of the child's zi that STARTS at ai (sic: get_src, :1006)
-						for (uint32_t b = t.br_off[c_zi]; b < t.br_off[c_zi + 1] && !has_br; b++)
-							has_br = t.b_src[t.br_be[b]] == ai;
+						SubT::BrRange br = t.brackets(c_zi);
+						for (uint32_t e = t.br_next(br); e != NIL && !has_br; e = t.br_next(br))
+							has_br = t.b_src[e] == ai;
 						return t.is_desc(sl.sl, c_ai) && has_br;
 					}
 					// nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
@@ -1517,22 +1548,15 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 		LAUNCH(k_sub_lo, C, s, C, cs.voff, sw.c_ntree, sw.t_size, depth, in.out_ord, eat, pw.b_tgt, in.O, has_self, heap, lo);
 	}
 	mark("creation keys, lo");
-	// bracket table
-	uint32_t *br_cnt = dev32((size_t)T + 4), *br_off = dev32((size_t)T + 4);
+	// bracket rows: counts in closed form, the edges in source order with a segment tree over their targets
+	uint32_t *br_cnt = dev32((size_t)T + 4);
 	LAUNCH(k_sub_br_counts, (size_t)T + 1, s, T, sw.t_size, in.gp, in.P, in.out_ord, in.nself, br_cnt);
-	scan_exclusive_u32(br_cnt, br_off, (size_t)T + 1, tmp, tmp_bytes, s);
-	const uint32_t n_br = host.read_u32(br_off + T, s);
-	if (n_br > 0x7FFFFFF0u)
-		throw HipError("subflubble passes: the bracket table (tree_utils.cpp:167-216 is quadratic on deep trees) has more than 2^31 entries");
-	uint32_t *br_be = dev32((size_t)n_br + 4);
 	uint32_t *tgt_s = dev32((size_t)NB0 + 32), *slot_s = dev32((size_t)NB0 + 32);
 	LAUNCH(k_sub_edges_by_source, T, s, T, sw.t_size, in.out_ord, eat, in.O, pw.b_tgt, tgt_s, slot_s);
 	SegTree segT;
 	segT.tree = dev32(SegTree::tree_words((size_t)NB0 + 1) + 16);
 	seg_build(segT, tgt_s, NB0, s);
-	LAUNCH(k_sub_br_fill, T, s, T, sw.t_size, in.O, segT, slot_s, br_off, br_be, err);
-	LAUNCH(k_sub_br_sort, T, s, T, br_off, br_be, ekey, pw.b_ord);
-	mark("bracket table");
+	mark("bracket rows");
 
 	SubT t{};
 	t.T = T, t.C = C, t.NB0 = NB0, t.NB = NB;
@@ -1540,7 +1564,7 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	t.size = sw.t_size, t.gp = in.gp, t.nchild = in.nchild, t.depth = depth, t.gid = sw.t_gid, t.flags = sw.t_flags;
 	t.b_src = pw.b_src, t.b_tgt = pw.b_tgt, t.b_ord = pw.b_ord;
 	t.o_off = o_off, t.o_adj = o_adj, t.i_off = i_off, t.i_adj = i_adj;
-	t.br_off = br_off, t.br_be = br_be, t.lo = lo, t.hi = hi, t.ekey = ekey;
+	t.br_cnt = br_cnt, t.O = in.O, t.slot_s = slot_s, t.segT = segT, t.lo = lo, t.hi = hi, t.ekey = ekey;
 	segD.val = depth;
 	t.segD = segD;
 	t.p_ai = ls.dense.ai, t.p_zi = ls.dense.zi, t.p_fam = ls.dense.fam;
@@ -1622,8 +1646,6 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 		KLAUNCH(k_sub_splice, dim3(C), dim3(64), 0, s, C, t, xoff, poff, cn_off, cn, mn, sm_off, smo, X, counts);
 	mark("splice");
 	const uint32_t e = host.read_u32(err, s);
-	if (e & E_BR_ROW)
-		throw HipError("subflubble passes: a bracket row outgrew its count (internal)");
 	if (e & E_POOL)
 		throw HipError("subflubble passes: the children vectors outgrew their pool (internal sizing bug)");
 	if (e & E_LAYOUT)
