@@ -1195,7 +1195,8 @@ void orc_leaf_stats(uint64_t *out, int reset)
 
 typedef struct {
 	uint32_t n;
-	uint32_t *off, *be; /* tm.off / tm.BE */
+	uint64_t *off;	    /* tm.off: 64-bit here (the table is quadratic on deep trees: 10^10 entries on a graph with large tangles) */
+	uint32_t *be;	    /* tm.BE */
 	uint32_t *c_off, *c_adj; /* children, ascending vertex idx (std::set order) */
 	uint32_t *o_off, *o_adj; /* OBE(v): back-edge idx ascending */
 	uint32_t *i_off, *i_adj; /* IBE(v) */
@@ -1252,19 +1253,19 @@ static void tree_meta_build(const orc_tree *t, tree_meta *m)
 	for (uint32_t v = n; v-- > 1;) /* children before parents: a child's idx is larger than its parent's */
 		if (t->par[v] != NIL)
 			cnt[t->par[v]] += cnt[v];
-	m->off = xcalloc((size_t)n + 2, 4);
+	m->off = xcalloc((size_t)n + 2, 8);
 	uint64_t total = 0;
 	for (uint32_t v = 0; v < n; v++) {
 		total += cnt[v];
-		if (total > 0x7FFFFFFFull) {
-			fprintf(stderr, "povu_oracle: bracket table of %" PRIu64 " entries (tree_utils.cpp:169-216 is quadratic on deep trees)\n", total);
-			abort();
-		}
-		m->off[v + 1] = (uint32_t)total;
+		m->off[v + 1] = total;
+	}
+	if (total > (1ull << 36)) { /* 256 GB of table: not on this machine either */
+		fprintf(stderr, "povu_oracle: bracket table of %" PRIu64 " entries (tree_utils.cpp:169-216 is quadratic on deep trees)\n", total);
+		abort();
 	}
 	m->be = xmalloc(((size_t)total + 1) * 4);
 	/* collect_backedges_by_vertex, tree_utils.cpp:169-216 */
-	uint32_t *cursor = xcalloc((size_t)n + 1, 4);
+	uint64_t *cursor = xcalloc((size_t)n + 1, 8);
 	for (uint32_t j = 0; j < t->n_be; j++) {
 		if (t->be_type[j] != ORC_BE_BACK || t->be_src[j] == t->be_tgt[j])
 			continue;
@@ -1296,7 +1297,7 @@ static int tiny_branches(const orc_tree *t, const tree_meta *m, uint32_t ai, uin
 		if (t->post[c] - t->pre[c] != 3) /* has_one_descendants */
 			return 0;
 		int hit = 0;
-		for (uint32_t b = m->off[c]; b < m->off[c + 1] && !hit; b++)
+		for (uint64_t b = m->off[c]; b < m->off[c + 1] && !hit; b++)
 			hit = t->be_tgt[m->be[b]] == ai;
 		if (hit)
 			LS_INC(LS_TINY_BRACKET);
@@ -1391,7 +1392,7 @@ static int par_in_branch(const orc_tree *t, const tree_meta *m, uint32_t ai, uin
 	}
 	if (c == NIL) /* undefined in the reference (see the header of this section) */
 		return 0;
-	uint32_t br = m->off[c + 1] - m->off[c], ch_obe = m->o_off[c + 1] - m->o_off[c];
+	const uint64_t br = m->off[c + 1] - m->off[c], ch_obe = m->o_off[c + 1] - m->o_off[c];
 	if (br <= 2)
 		return 0;
 	if (count_type(t, m->i_off, m->i_adj, ai, ORC_BE_BACK) >= br + ch_obe) {

@@ -204,9 +204,10 @@ def test_reader_round_trip_on_the_extended_trees(hip):
 
 def test_tangled_workload_whose_bracket_table_would_not_fit(hip):
     """bench.py's tangled workload (5.6 M segments, tangles of up to 3e5): gen_tree_meta's bracket table would hold 1.07e10
-    entries there (tree_utils.cpp:167-216) -- the oracle, which materialises it like the reference, gives up beyond 2^31.  The
-    device enumerates rows on demand: the pass completes; what can still be checked is its own consistency -- the flubble-like
-    vertices are those of the leaf passes alone, every inserted vertex hangs somewhere."""
+    entries there (tree_utils.cpp:167-216).  The oracle materialises it like the reference: 45 GB and 95 s, too much for this
+    suite -- `tools/tangled_sub.py compare` is that comparison (profiles/r04_sub_tangled_vs_oracle.log: equal).  The device
+    enumerates rows on demand; checked here: the pass completes and is consistent -- the flubble-like vertices are those of
+    the leaf passes alone, every inserted vertex hangs somewhere."""
     import bench
     from povu_amd.hip import F_LEAF_SUBFLUBBLES
     g, _ = bench.build_workload("tangled", 1.0)
