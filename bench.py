@@ -452,6 +452,14 @@ def main():
                             "seq_redo": hip.seq_redo_count(), "black_only_classes": hip.last_black_only_classes(),
                             "laminar_check_ran": hip.last_laminar_check_ran(),
                             "stage_ms": {st["name"]: round(st["ms"], 4) for st in hip.stage_times()}}
+                if name == "tangled":
+                    # all five passes of -s where the reference's bracket table would hold 1e10 entries
+                    hip.decompose(flags=F_SUBFLUBBLES)
+                    t_s = time.perf_counter()
+                    f_s = hip.decompose(flags=F_SUBFLUBBLES)
+                    sec[key]["subflubbles_wall_ms"] = (time.perf_counter() - t_s) * 1e3
+                    sec[key]["subflubbles_concealed"] = int(sum(f_s.subtree(i)["n_concealed"] for i in range(len(f_s))))
+                    del f_s
                 del f2, g2
             out["secondary"] = sec
         if not args.no_secondary:
