@@ -536,3 +536,24 @@ def test_gfa_writer_is_the_inverse_of_the_loader_contract(tmp_path):
         assert p.read_text() == g.to_gfa()
     with pytest.raises(RuntimeError):
         H.write_gfa(W.chain_of_bubbles(3), str(tmp_path / "no" / "such" / "dir.gfa"))
+
+
+def test_subtree_formatter_on_the_host():
+    """povu_hip_pvst_format_subtree (write_pvst, src/mto/to_pvst.cpp:31-109, of a tree with its -s vertices): host code, no GPU.
+    The tree of tests/test_oracle_subflubbles.py's hand-traced case: a concealed vertex listed under two parents."""
+    from povu_amd.hip import _SubTree
+    lib = C.CDLL(os.path.join(LIB, "libpovu_hip.so"))
+    lib.povu_hip_pvst_format_subtree.restype = C.c_void_p
+    lib.povu_hip_pvst_format_subtree.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.povu_hip_buffer_free.argtypes = [C.c_void_p]
+    u8 = lambda xs: (C.c_uint8 * len(xs))(*xs)    # noqa: E731
+    u32 = lambda xs: (C.c_uint32 * len(xs))(*xs)  # noqa: E731
+    fam, or1, or2, route = u8(list(b"DFTC")), u8([0, 0, 0, 0]), u8([0, 0, 0, 1]), u8([0, ord("L"), ord("L"), ord("R")])
+    id1, id2 = u32([0, 1, 4, 4]), u32([0, 7, 6, 7])
+    off, child = u32([0, 1, 2, 3, 3]), u32([1, 3, 3])
+    st = _SubTree(4, 3, 1, 0, 0, fam, or1, or2, route, id1, id2, off, child)
+    n = C.c_size_t(0)
+    p = lib.povu_hip_pvst_format_subtree(C.byref(st), C.byref(n))
+    text = C.string_at(p, n.value).decode()
+    lib.povu_hip_buffer_free(p)
+    assert text == "H\t0.0.3\t.\t.\t.\nD\t0\t.\t1\t.\nF\t1\t>1>7\t3\tL\nT\t2\t>4>6\t3\tL\nC\t3\t>4<7\t.\tR\n"
