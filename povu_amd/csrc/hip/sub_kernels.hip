@@ -281,14 +281,6 @@ __device__ void sort_row(uint32_t *a, uint32_t n, Less less)
 		sift(0, end);
 	}
 }
-// rows in ascending slot order (the fill above is in whatever order the atomics came)
-__global__ void k_sub_sort_rows_u32(uint32_t T, const uint32_t *__restrict__ off, uint32_t *__restrict__ adj)
-{
-	const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= T)
-		return;
-	sort_row(adj + off[v], off[v + 1] - off[v], [](uint32_t x, uint32_t y) { return x < y; });
-}
 // literal hi of every vertex: min over the subtree of hi_0, the root once a simplifying edge was added at or below
 __global__ void k_sub_hi(uint32_t T, const uint32_t *__restrict__ size, const SegTree segH, const uint32_t *__restrict__ simp_ps,
 			 const CompAt comp, uint32_t *__restrict__ hi)
@@ -529,7 +521,9 @@ __device__ bool cn_ai_trunk(const SubT &t, uint32_t m, uint32_t n, uint32_t ai, 
 		const bool cond_iii = t.o_off[l + 1] > t.o_off[l] || t.nchild[l] > 1;
 		if (!ell_br && cond_iii)
 			continue;
-		if (best_l == NIL || l >= best_l) {
+		// (the reference keeps the last of equal LCAs in back-edge idx order; which source survives shows nowhere -- it only
+		// enters Concealed::bounds_, oracle/povu_oracle_sub.inc -- so any fixed choice does: the largest source)
+		if (best_l == NIL || l > best_l || (l == best_l && src > best_src)) {
 			best_l = l;
 			best_src = src;
 		}
@@ -1514,8 +1508,8 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	HIP_CHECK(hipMemsetAsync(ocnt, 0, ((size_t)T + 2) * 4, s));
 	HIP_CHECK(hipMemsetAsync(icnt, 0, ((size_t)T + 2) * 4, s));
 	LAUNCH(k_sub_edge_fill, NB, s, NB, pw.b_src, pw.b_tgt, o_off, i_off, ocnt, icnt, o_adj, i_adj);
-	LAUNCH(k_sub_sort_rows_u32, T, s, T, o_off, o_adj);
-	LAUNCH(k_sub_sort_rows_u32, T, s, T, i_off, i_adj);
+	// (the rows are in whatever order the atomics came: every question asked of them is about a set -- any, count, deepest --
+	// and sorting them cost 0.6 s on a segment with 2*10^5 links, one lane on its row)
 	// literal hi
 	SegTree segH, segD;
 	segH.tree = dev32(SegTree::tree_words((size_t)T + 1) + 16);
