@@ -63,6 +63,9 @@ struct povu_hip_forest {
 	double pass_ms = -1.0;
 	// a merged forest took over blocks whose arrays were still on their way: the events behind those passes (owned here)
 	std::vector<hipEvent_t> more_events;
+	// (may be reached from several threads at once -- the writer threads of `povu decompose` read one forest: the waits are
+	// idempotent, and the pass time is taken exactly once)
+	std::once_flag pass_ms_once;
 	void ready()
 	{
 		if (pending) {
@@ -72,11 +75,12 @@ struct povu_hip_forest {
 				(void)hipEventSynchronize(e);
 			pending = false;
 		}
-		if (ev0 && ev1 && pass_ms < 0) {
-			float ms = 0;
-			if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
-				pass_ms = ms;
-		}
+		if (ev0 && ev1)
+			std::call_once(pass_ms_once, [this] {
+				float ms = 0;
+				if (pass_ms < 0 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess)
+					pass_ms = ms;
+			});
 	}
 	std::shared_ptr<PinnedPool> pool;
 	void *block = nullptr;

@@ -107,6 +107,24 @@ struct povu_hip_multi {
 	double ms[6] = {0, 0, 0, 0, 0, 0};
 	bool have_shards = false;
 
+	// ncclCommAbort on every communicator (from any thread, once): posted sends / receives end with an error instead of
+	// waiting for a partner that will never come
+	std::mutex abort_mu;
+	void abort_comms()
+	{
+		std::lock_guard<std::mutex> l(abort_mu);
+		try {
+			povu_hip::Rccl &R = povu_hip::rccl();
+			if (!R.CommAbort)
+				return;
+			for (auto &x : w)
+				if (x && x->comm) {
+					(void)R.CommAbort(x->comm);
+					x->comm = nullptr;
+				}
+		} catch (...) {
+		}
+	}
 	// runs fn(rank) on every worker's thread, returns the first error
 	std::string on_all(const std::function<void(uint32_t)> &fn)
 	{
@@ -184,7 +202,11 @@ extern "C" povu_hip_multi *povu_hip_multi_create(const int *devices, uint32_t n,
 				throw HipError(e2);
 			HIP_CHECK(hipSetDevice(devices[r]));
 			HIP_CHECK(hipStreamCreateWithFlags(&x->xstream, hipStreamNonBlocking));
+			// `arrived` is only ever recorded on the ROOT's transfer stream (peer-copy transport): an event and the stream it is
+			// recorded on must belong to one device (hipErrorInvalidHandle otherwise); any thread may wait for it
+			HIP_CHECK(hipSetDevice(devices[0]));
 			HIP_CHECK(hipEventCreateWithFlags(&x->arrived, hipEventDisableTiming));
+			HIP_CHECK(hipSetDevice(devices[r]));
 			m->w.push_back(std::move(x));
 		}
 		// transport of the scatter
@@ -278,8 +300,10 @@ extern "C" int povu_hip_multi_scatter(povu_hip_multi *m, int keep_graph, char *e
 		}
 		Worker &root = *m->w[0];
 		const Transport tr = m->transport;
-		if (tr == T_PEER) {
-			// receivers need their buffers before the root's copies are queued
+		if (tr == T_PEER || tr == T_RCCL) {
+			// Receivers take their buffers BEFORE any transfer is queued -- the step that can fail (device memory).  With RCCL a
+			// rank that threw before posting its receive would leave the root's grouped sends waiting for ever: nothing is
+			// sent unless every rank is ready (the status exchange of the multi-process path, shard.hip, in one process).
 			const std::string e = m->on_all([&](uint32_t r) {
 				Worker &x = *m->w[r];
 				if (r == 0)
@@ -290,6 +314,8 @@ extern "C" int povu_hip_multi_scatter(povu_hip_multi *m, int keep_graph, char *e
 			});
 			if (!e.empty())
 				throw HipError(e);
+		}
+		if (tr == T_PEER) {
 			HIP_CHECK(hipSetDevice(root.device));
 			for (uint32_t r = 1; r < m->world; r++) {
 				Worker &x = *m->w[r];
@@ -325,10 +351,14 @@ extern "C" int povu_hip_multi_scatter(povu_hip_multi *m, int keep_graph, char *e
 						throw HipError("scatter: ncclSend failed: " + (ok ? std::string(R.GetErrorString(rc)) : why));
 				}
 			} else if (tr == T_RCCL) {
-				x.ctx->shard_buf.reserve(x.shard_bytes + 256);
-				char *buf = x.ctx->shard_buf.take<char>(x.shard_bytes);
-				NCCL_CHECK(povu_hip::rccl().Recv(buf, x.shard_bytes, ncclChar, 0, x.comm, x.xstream));
-				HIP_CHECK(hipStreamSynchronize(x.xstream));
+				char *buf = const_cast<char *>(static_cast<const char *>(x.shard_ptr)); // (taken above, before anything was sent)
+				try {
+					NCCL_CHECK(povu_hip::rccl().Recv(buf, x.shard_bytes, ncclChar, 0, x.comm, x.xstream));
+					HIP_CHECK(hipStreamSynchronize(x.xstream));
+				} catch (...) {
+					m->abort_comms(); // the root's send to this rank would wait for ever: let every stream drain, then report
+					throw;
+				}
 				x.ctx->xfer_peer_in += x.shard_bytes;
 				src = buf;
 			} else { // T_PEER: wait for the root's copy
@@ -344,8 +374,15 @@ extern "C" int povu_hip_multi_scatter(povu_hip_multi *m, int keep_graph, char *e
 			if (r == 0 && tr != T_NONE && tr != T_SAME)
 				HIP_CHECK(hipStreamSynchronize(x.xstream)); // the partition may be overwritten once this returns
 		});
-		if (!e.empty())
+		if (!e.empty()) {
+			// a rank failed with transfers posted: its partner may wait for ever -- abort every communicator so that all
+			// streams drain, and say that the engine has to be created again
+			if (tr == T_RCCL) {
+				m->abort_comms();
+				m->transport = T_PEER, m->transport_name = "peer-copy (RCCL communicators aborted after: " + e + ")";
+			}
 			throw HipError(e);
+		}
 		m->have_shards = true;
 		m->ms[3] = now_ms() - t0;
 		return 0;

@@ -139,7 +139,7 @@ __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const ui
 }
 // bridge(v): no ordinary back edge out of subtree(v) reaches a proper ancestor of v (the bracket list of v would be
 // empty but for simplifying edges): the subtree sum of cov is zero
-// (four vertices a lane, 16-byte loads: see k_entry_flags)
+// (four vertices a lane, 16-byte loads: see k_entry_list)
 __global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
 			       const uint32_t *__restrict__ pscov, uint8_t *__restrict__ bridge)
 {
@@ -247,17 +247,16 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 // The sweep over a branching vertex's children is a chain of dependent gathers (child, its size, the flags behind its
 // subtree, the next child ...): it runs in a kernel of its own over the compacted list of branching vertices, every lane
 // busy with one of them -- inside this kernel the few lanes that had work left the rest of their workgroup waiting.
-__global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
-			  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
-			  uint8_t *__restrict__ capf, uint8_t *__restrict__ branching)
+__global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
+						  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
+						  uint8_t *__restrict__ capf, uint32_t *__restrict__ br_list, uint32_t *__restrict__ n_br)
 {
-	const uint32_t t0 = (BIDX * blockDim.x + threadIdx.x) * 4u; // (four vertices a lane, 16-byte loads: see k_entry_flags)
-	if (t0 >= T)
-		return;
+	const uint32_t t0 = (BIDX * blockDim.x + threadIdx.x) * 4u, lane = threadIdx.x & 63u; // (four vertices a lane, 16-byte loads: see k_entry_list)
 	auto one = [&](uint32_t t, uint32_t sz, uint32_t br, uint32_t p0, uint32_t sz_next, uint32_t &sm, uint32_t &bch) {
 		sm = (sz && br && psb[t + sz] - p0 == 1) ? 1u : 0u;
 		bch = (sz > 2 && t + 1 + max(sz_next, 1u) < t + sz) ? 1u : 0u; // the first child does not fill the subtree
 	};
+	uint32_t bw = 0; // bit j: vertex t0 + j branches
 	if (t0 + 4 < T) { // (strictly: the last of the four looks at its successor's size)
 		const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), p = *reinterpret_cast<const uint4 *>(psb + t0);
 		const uint32_t sz4 = gsize[t0 + 4], br = *reinterpret_cast<const uint32_t *>(bridge + t0);
@@ -271,19 +270,41 @@ __global__ void k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const 
 		if (hpf)
 			*reinterpret_cast<uint32_t *>(hpf + t0) = sw;
 		*reinterpret_cast<uint32_t *>(capf + t0) = 0u; // (cap_tgt is only read where capf says so)
-		*reinterpret_cast<uint32_t *>(branching + t0) = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-		return;
+		bw = c0 | (c1 << 1) | (c2 << 2) | (c3 << 3);
+	} else {
+		for (uint32_t t = t0; t < T; t++) {
+			uint32_t sm, bch;
+			one(t, gsize[t], bridge[t], psb[t], gsize[t + 1], sm, bch);
+			simp[t] = (uint8_t)sm;
+			if (t == T - 1)
+				simp[T] = 0;
+			if (hpf)
+				hpf[t] = (uint8_t)sm;
+			capf[t] = 0;
+			bw |= bch << (t - t0);
+		}
 	}
-	for (uint32_t t = t0; t < T; t++) {
-		uint32_t sm, bch;
-		one(t, gsize[t], bridge[t], psb[t], gsize[t + 1], sm, bch);
-		simp[t] = (uint8_t)sm;
-		if (t == T - 1)
-			simp[T] = 0;
-		if (hpf)
-			hpf[t] = (uint8_t)sm;
-		capf[t] = 0;
-		branching[t] = (uint8_t)bch;
+	// the branching vertices go straight onto the list k_capping works through (one atomic add per wave, as k_entry_list
+	// does; the order of the list shows nowhere: every vertex on it is decided on its own)
+	const uint32_t cnt = (uint32_t)__popc(bw);
+	uint32_t inc = cnt;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(inc, off);
+		if ((int)lane >= off)
+			inc += y;
+	}
+	const uint32_t total = __shfl(inc, 63);
+	if (!total)
+		return;
+	uint32_t base = 0;
+	if (lane == 63)
+		base = atomicAdd(n_br, total);
+	base = __shfl(base, 63);
+	uint32_t at = base + inc - cnt;
+	while (bw) {
+		const int k = __ffs((int)bw) - 1;
+		bw &= bw - 1;
+		br_list[at++] = t0 + (uint32_t)k;
 	}
 }
 __global__ void k_capping(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const uint32_t *__restrict__ gsize,
@@ -454,7 +475,8 @@ __global__ void k_bracket_place(uint32_t NB, uint32_t NB0, uint32_t ncap, const 
 		rank = 0;
 	const uint32_t pos = bstart[mpre[v]] + rank;
 	tgtR[pos] = b_tgt[j];
-	rid[pos] = j;
+	if (rid) // (which bracket sits at a list position: only the hairpin report asks, k_top_bracket)
+		rid[pos] = j;
 }
 __global__ void k_gather_u32(uint32_t n, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ src,
 			     uint32_t *__restrict__ dst)
@@ -1248,7 +1270,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// pw.comp_bad and pw.err are zeroed by the caller (zero_component_counters)
 	uint32_t NB0;
 	if (dense_nb0 >= 0) { // the parallel tree stage already left the back edges in b_src / b_tgt
-		NB0 = (uint32_t)dense_nb0;
+		NB0 = dense_nb0 == NB0_ON_DEVICE ? 0u : (uint32_t)dense_nb0; // (on the device: read below, nothing before that needs it)
 	} else {
 		scan(sw.c_nbe0, pw.dbo, (size_t)C + 1);
 		NB0 = pw.host->read_u32(pw.dbo + C, s);
@@ -1270,10 +1292,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		scan(pw.cov, pscov, (size_t)T + 1);
 	LAUNCH(k_bridge_flags, (T + 3) / 4, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
-	uint8_t *branching = pw.f8d;
-	uint32_t *br_list = pw.vals_t, *n_br = pw.err + 10; // (the sort's value buffer is free until the class pass)
-	LAUNCH(k_hi_simp, (T + 3) / 4, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, branching);
-	compact_flagged_u8(branching, T, br_list, n_br, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	uint32_t *br_list = pw.vals_t, *n_br = pw.err + 10; // (the sort's value buffer is free until the class pass; the count was cleared with the other counters)
+	KLAUNCH(k_hi_simp, dim3(nblk(((size_t)T + 3) / 4)), dim3(TPB), 0, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, br_list, n_br);
 	KLAUNCH(k_capping, dim3(std::min<unsigned>(nblk(T / 8 + 1), 16384)), dim3(TPB), 0, s, n_br, br_list, pw.gsize, pw.hi0, psb, root_of,
 		pw.segA, pw.cap_tgt, capf, pw.err + 5);
 	// capping / simplifying vertices per tile of k_bracket_extra, scanned: [ntiles + 1] each, the totals in the last word
@@ -1282,11 +1302,16 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	KLAUNCH(k_flag_tile_counts, dim3((ntiles + 1 + 15) / 16 + 1), dim3(TPB), 0, s, T, capf, simp, tcap, tsimp, ntiles);
 	scan_exclusive_u32_pair(tsimp, tsimp, (size_t)ntiles + 1, tcap, tcap, (size_t)ntiles + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
-	uint32_t *extra = pw.host->take<uint32_t>(3);
+	uint32_t *extra = pw.host->take<uint32_t>(4);
 	HIP_CHECK(copy_async(&extra[0], tcap + ntiles, 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(copy_async(&extra[1], tsimp + ntiles, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(copy_async(&extra[2], pw.err + 5, 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(copy_async(&extra[2], pw.err + 5, 8, hipMemcpyDeviceToHost, s)); // literal-rule flag | back edges of the tree stage
 	HIP_CHECK(hipStreamSynchronize(s));
+	if (dense_nb0 == NB0_ON_DEVICE) {
+		NB0 = extra[3];
+		if (NB0 > pw.nb_cap)
+			throw HipError("spanning tree: more back edges than links outside the tree and sides without links (internal sizing bug)");
+	}
 	const uint32_t ncap = extra[0], nsimp = extra[1], NB = NB0 + ncap + nsimp;
 	pw.nb0 = NB0;
 	pw.ncap = ncap;
@@ -1312,7 +1337,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	if (dense_nb0 >= 0) { // ranks inside every source and the counts per source are known: place directly
 		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
 		LAUNCH(k_bracket_place, NB, s, NB, NB0, ncap, pw.b_src, pw.b_tgt, pw.b_ord, pw.mpre, bstart, capf, simp, pw.tgtR,
-		       pw.b_val2);
+		       want_hp ? pw.b_val2 : nullptr);
 	} else {
 		uint32_t *bk = pw.b_key, *bk2 = pw.b_key2;
 		LAUNCH(k_bracket_order, NB, s, NB, NB0, ncap, nsimp, pw.b_src, pw.b_tgt, pw.mpre, bk, pw.b_val, pw.incnt, srccnt);

@@ -112,9 +112,12 @@ void par_carve(Arena &ar, ParWs &pw, size_t V, size_t E, size_t Cmax, int groups
 
 // Runs rows D-G for every processed component from the spanning trees / back edges the tree stage
 // left in `sw`.  Components whose candidate stack is not laminar are flagged in pw.comp_bad (see pass_summary).
-// dense_nb0 < 0: densify the back edges the sequential tree stage wrote; otherwise b_src/b_tgt hold them.
+// dense_nb0 < 0: densify the back edges the sequential tree stage wrote; otherwise b_src/b_tgt hold them -- NB0_ON_DEVICE:
+// their number still sits in pw.err[6] (the parallel tree stage does not wait for it: the class stage reads it with the
+// capping / simplifying counts, one host synchronisation instead of two).
 // alloc_result_block(total) returns the device view of a page-locked host block laid out a | z | parent | a_or |
 // z_or (each padded to 64 B) for `total` PVST vertices; the emit kernels write into it.
+static constexpr int64_t NB0_ON_DEVICE = int64_t(1) << 40;
 void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint32_t n_processed, uint32_t n_stack,
 		     int64_t dense_nb0, const std::function<void *(size_t)> &alloc_result_block, StageTimer &tm, hipStream_t s,
 		     const SideStream &side, PassTail &tail);

@@ -15,6 +15,7 @@ struct Rccl {
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
 	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // (optional: only used to unblock streams after a failure)
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*GroupStart)() = nullptr;
@@ -40,6 +41,7 @@ inline Rccl &rccl()
 		x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
 		x.CommInitAll = (decltype(x.CommInitAll))sym("ncclCommInitAll");
 		x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+		x.CommAbort = (decltype(x.CommAbort))sym("ncclCommAbort");
 		x.Send = (decltype(x.Send))sym("ncclSend");
 		x.Recv = (decltype(x.Recv))sym("ncclRecv");
 		x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");

@@ -710,12 +710,18 @@ extern "C" povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_f
 	try {
 		if (!ctx || !job_tag || (n && !descs))
 			throw HipError("attach: bad arguments");
+		// (the tag becomes part of a shared-memory name: the rule of povu_hip_share_results, which made the segments; the ranks'
+		// own tags are "<job>.<rank>", so the job's leaves room for the rank)
+		if (!*job_tag || strlen(job_tag) > 84 || strchr(job_tag, '/'))
+			throw HipError("attach: bad job tag");
 		auto out = std::make_unique<povu_hip_forest>();
 		out->pool = ctx->pool;
 		for (uint32_t i = 0; i < n; i++) {
 			const uint64_t *d = descs + 8 * (size_t)i;
 			if (d[0] != SHARE_MAGIC)
 				throw HipError("attach: bad descriptor from rank " + std::to_string(d[7]));
+			if (d[7] >= n) // (the rank word comes from another process and names a segment: it must be one of the n ranks)
+				throw HipError("attach: descriptor " + std::to_string(i) + " names rank " + std::to_string(d[7]) + " of " + std::to_string(n));
 			out->total_components = std::max<uint32_t>(out->total_components, (uint32_t)d[5]);
 			if (own && d[7] == own_rank)
 				continue; // the root's own trees stay where they are (below)

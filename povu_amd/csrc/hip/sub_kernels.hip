@@ -382,8 +382,16 @@ __global__ void k_sub_lo_query(uint32_t T, const uint32_t *__restrict__ size, ui
 		lo[v] = NIL;
 		return;
 	}
-	if (nself[v])
-		has_self[comp.of_tree(v)] = 1; // (this component's values are overwritten by the literal heap below)
+	// A back edge whose source is its own target stays in the reference's heap as a stale entry (it is pushed AFTER lo[v] is
+	// taken and never popped).  The only one from_bd ever makes is the 0 -> 0 edge of a tip-less root (spanning_tree.cpp:433-438;
+	// a self loop of the graph is stored as (side, other side): two vertices): pushed at the first tree vertex, which the
+	// descending sweep visits LAST -- nobody reads the heap after it, the closed form stands.  Only a self edge anywhere else
+	// (none can arise; kept as the defined answer should one ever) sends its component through the literal heap below.
+	if (nself[v]) {
+		const uint32_t c = comp.of_tree(v);
+		if (v != 2 * comp.voff[c] + c)
+			has_self[c] = 1; // (this component's values are overwritten by the literal heap below)
+	}
 	uint32_t m = 0;
 	for (uint32_t x = v + P2; x >= 1; x >>= 1)
 		m = max(m, tree[x]);
@@ -1539,6 +1547,14 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 		LAUNCH(k_sub_lo_query, T, s, T, sw.t_size, P2, mx, in.nself, comp, lo, has_self);
 		if (getenv("POVU_HIP_SUB_LITERAL_LOA")) // (tests: the reference's heap on every component, whatever its edges)
 			fill_u32(has_self, C, 1u, s);
+		if (getenv("POVU_HIP_SUB_FORBID_HEAP")) { // (tests: fail when any component would take the one-lane heap)
+			std::vector<uint32_t> hs(C);
+			HIP_CHECK(hipMemcpyAsync(hs.data(), has_self, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+			HIP_CHECK(hipStreamSynchronize(s));
+			for (uint32_t c = 0; c < C; c++)
+				if (hs[c])
+					throw HipError("subflubble passes: component " + std::to_string(c + 1) + " takes the literal LoA heap (POVU_HIP_SUB_FORBID_HEAP is set)");
+		}
 		LAUNCH(k_sub_lo, C, s, C, cs.voff, sw.c_ntree, sw.t_size, depth, in.out_ord, eat, pw.b_tgt, in.O, has_self, heap, lo);
 	}
 	mark("creation keys, lo");

@@ -26,7 +26,7 @@
 // vector-memory instructions its CU retires, so they issue few and wide ones -- one lane per SEGMENT where the two sides
 // ask different questions (k_bridges, k_tree_emit, k_t0_parents), four slots of an adjacency list a round with 16-byte
 // loads and the gathers they lead to issued together (k_tour_words, k_events, side_back_edges, k_class_dfs_small), four
-// elements a lane where a kernel only streams (k_entry_flags).
+// elements a lane where a kernel only streams (k_entry_list).
 #include "tree_kernels.hpp"
 
 #include <cstdlib>
@@ -150,7 +150,7 @@ __device__ __forceinline__ bool heq(const ulonglong2 a, const ulonglong2 b) { re
 // of a pangenome graph have no such link); ft[S] = its first arc (FT_NONE: none), bit 31 set when hside[S] was written.
 __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle, uint32_t *__restrict__ pk, unsigned b,
-			     ulonglong2 *__restrict__ hside, uint32_t *__restrict__ ft, uint32_t *__restrict__ twin)
+			     ulonglong2 *__restrict__ hside, uint32_t *__restrict__ ft)
 {
 	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= nS)
@@ -203,7 +203,7 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 				first = at;
 			const uint32_t w = ws[q], sb = o01[q].x;
 			const uint32_t wl = (w & 1u) ? o01[q].y : sb, wh = (w & 1u) ? se[q] : o01[q].y; // w's own slots
-			uint32_t t, nxt;
+			uint32_t nxt;
 			if (se[q] - sb <= 8) {
 				const uint32_t n = se[q] - sb, tl = wl - sb, th = wh - sb;
 				uint4 c = make_uint4(0u, 0u, 0u, 0u);
@@ -223,10 +223,9 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 						if (k > tk && after == NIL)
 							after = k;
 					}
-				t = sb + tk;
 				nxt = sb + (after != NIL ? after : (first_tree < tk ? first_tree : tk)); // (the twin itself is a forest slot: first_tree <= tk)
 			} else {
-				t = wl + find_link_slot(loff, lle, w, le) - 1;
+				const uint32_t t = wl + find_link_slot(loff, lle, w, le) - 1;
 				nxt = t;
 				for (uint32_t jj = t + 1; jj < se[q] && nxt == t; jj++)
 					if (lle[jj] & LLE_TREE)
@@ -235,7 +234,6 @@ __global__ void k_tour_words(uint32_t nS, const uint32_t *__restrict__ loff, con
 					if (lle[jj] & LLE_TREE)
 						nxt = jj;
 			}
-			twin[at] = t; // (k_t0_parents needs it again)
 			pk[at] = rank_pack(nxt, 1u, b); // every arc counts 1 (k_tour_ends fixes the closing arc)
 		}
 	}
@@ -625,7 +623,7 @@ __global__ void k_t0_parents(uint32_t V, const uint32_t *__restrict__ dist, cons
 			     const uint32_t *__restrict__ voff, const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
 			     const uint32_t *__restrict__ lle,
 			     const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
-			     const uint32_t *__restrict__ twin, uint4 *__restrict__ t0seg, uint4 *__restrict__ xrec, uint32_t C,
+			     uint4 *__restrict__ t0seg, uint4 *__restrict__ xrec, uint32_t C,
 			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
 {
 	uint32_t g = BIDX * blockDim.x + threadIdx.x;
@@ -639,28 +637,42 @@ __global__ void k_t0_parents(uint32_t V, const uint32_t *__restrict__ dist, cons
 	}
 	if (g >= V)
 		return;
-	// One lane per SEGMENT, from the child's end: of the forest slots of a segment exactly one belongs to the link it was
-	// entered through -- the one whose twin (the arc INTO the segment) comes before it in the tour; the slots to its
-	// children come before their twins, and the root has no such slot.  The segment's record is this lane's own 16 bytes
-	// (a lane per link, from the parent's end, scattered them).
+	// One lane per SEGMENT, from the child's end.  The tour enters a segment, takes its other forest slots in cyclic order
+	// (every one followed by the whole tour of the subtree behind it) and leaves through the slot it came in by: of the
+	// segment's forest slots the one back to the PARENT is the last in the tour (fewest arcs behind it), and the arc that
+	// enters the segment stands right in front of the first of them (one more arc behind it than behind that one).  So the
+	// distances of the segment's own slots -- one contiguous stretch -- say everything; no slot of another segment is
+	// looked at (until round 5 the twin of every forest slot was stored by k_tour_words and its distance gathered here:
+	// 1 GB written, 1 GB read and a scattered 4-byte gather per forest slot on the whole-genome workload).
 	const uint32_t sb = loff[2 * g], sm = loff[2 * g + 1], se = loff[2 * g + 2];
-	for (uint32_t at = sb; at < se; at++) {
-		const uint32_t lw = lle[at];
-		if (!(lw & LLE_TREE))
-			continue;
-		const uint32_t t = twin[at], da = dist[at], dt = dist[t];
-		if (dt < da)
-			continue; // a child: its own record names this slot
-		const uint32_t c = ckey[g], L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
-		const uint32_t p_in = abase + (L - 1 - dt), p_out = abase + (L - 1 - da); // tour positions of the arc in and the arc back
-		t0seg[g] = make_uint4(ladj[at], (lw & LLE_ID) | (at >= sm ? T0_RBIT : 0u), p_in, p_out);
-		// Most segments have no non-tree link, so the values are kept COMPACT (in tour order, only where a side carries
-		// one): here only the bit of the tour position is set; k_tour_values drops the value at its rank among the set bits.
-		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
-		if ((f2.x | f2.y) & FT_HASH)
-			atomicOr(reinterpret_cast<unsigned long long *>(&xrec[p_in >> 6]), 1ull << (p_in & 63u));
-		break;
+	uint32_t at_e = NIL, dmin = 0xFFFFFFFFu, dmax = 0u;
+	for (uint32_t at0 = sb; at0 < se; at0 += 4) {
+		const uint4 lw4 = load4_unaligned(lle + at0), d4 = load4_unaligned(dist + at0);
+		const uint32_t lws[4] = {lw4.x, lw4.y, lw4.z, lw4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+		for (uint32_t q = 0; q < 4; q++) {
+			if (at0 + q >= se || !(lws[q] & LLE_TREE))
+				continue;
+			if (ds[q] < dmin) {
+				dmin = ds[q];
+				at_e = at0 + q;
+			}
+			dmax = max(dmax, ds[q]);
+		}
 	}
+	if (at_e == NIL)
+		return; // a component of one segment: its record was written above
+	const uint32_t c = ckey[g];
+	if ((comp_root_side(start_key, voff, c) >> 1) == g)
+		return; // the root segment: all its slots lead to children (record written by the lane of its component)
+	const uint32_t L = 2 * (voff[c + 1] - voff[c] - 1), abase = 2 * (voff[c] - c);
+	const uint32_t p_in = abase + (L - 2 - dmax), p_out = abase + (L - 1 - dmin); // tour positions of the arc in and the arc back
+	t0seg[g] = make_uint4(ladj[at_e], (lle[at_e] & LLE_ID) | (at_e >= sm ? T0_RBIT : 0u), p_in, p_out);
+	// Most segments have no non-tree link, so the values are kept COMPACT (in tour order, only where a side carries
+	// one): here only the bit of the tour position is set; k_tour_values drops the value at its rank among the set bits.
+	const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
+	if ((f2.x | f2.y) & FT_HASH)
+		atomicOr(reinterpret_cast<unsigned long long *>(&xrec[p_in >> 6]), 1ull << (p_in & 63u));
 }
 // The running xor is only ever read at tour positions, but only the positions of segments with non-tree links carry a
 // value (about one in six of a pangenome graph): the values sit compact, in tour order, behind a bitmap of the positions
@@ -726,7 +738,12 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 	// multi[S] = 1: side S shares its 2-edge-connected class with another side, i.e. some tree edge at S is no bridge
 	// (cleared by the caller).  Most sides of a pangenome graph sit on bridges only and are classes of their own; those
 	// need no walk at all.
-	auto px = [&](uint32_t p) { return xps[tour_rank(xrec, p)]; }; // running xor in front of tour position p
+	// xor of the values at the tour positions [p, q): two look-ups into the running xor -- and none at all when no position in
+	// between carries a value (the ranks of both ends agree: the subtree of most segments holds no non-tree link)
+	auto stretch = [&](uint32_t p, uint32_t q) {
+		const uint32_t rp = tour_rank(xrec, p), rq = tour_rank(xrec, q);
+		return rp == rq ? make_ulonglong2(0ull, 0ull) : hx(xps[rp], xps[rq]);
+	};
 	const uint4 r = t0seg[g];
 	const uint32_t Se = (2 * g) | (r.y >> 31), Sf = Se ^ 1u, c = ckey[g]; // entered side, far side
 	const bool proc = cproc[c] != 0; // (components that are not decomposed here get inert words)
@@ -734,7 +751,7 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 	uint32_t pvE; // parent | bridge bit
 	if (r.x == NIL) {
 		pvE = NIL;
-	} else if (heq(px(r.z), px(r.w + 1))) {
+	} else if (hzero(stretch(r.z, r.w + 1))) {
 		pvE = r.x | PB_BRIDGE;
 	} else {
 		pvE = r.x;
@@ -756,7 +773,7 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 			end = abase + (L - 1 - dist[a3]);
 		else
 			end = r.w;
-		x = hx(x, hx(px(abase + (L - 1 - dist[a1])), px(end)));
+		x = hx(x, stretch(abase + (L - 1 - dist[a1]), end));
 	}
 	uint32_t pvF;
 	if (hzero(x)) {
@@ -804,25 +821,49 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 // is alone in its class has nothing to walk: the walks start from the entries that share their class (multi)
 // (four sides a lane: one 16-byte, one 4-byte and one 8-byte load instead of twelve 4- and 1-byte ones -- a kernel of a few
 // loads per element is bound by the number of memory instructions its CU can retire, not by their bytes)
-__global__ void k_entry_flags(uint32_t nS, const uint32_t *__restrict__ pbr /* = cstate: only the bridge bit is read */, const uint8_t *__restrict__ multi,
-			      const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc, uint8_t *__restrict__ entry_flag)
+__global__ void __launch_bounds__(TPB) k_entry_list(uint32_t nS, const uint32_t *__restrict__ pbr /* = cstate: only the bridge bit is read */,
+						     const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ckey,
+						     const uint32_t *__restrict__ cproc, uint32_t *__restrict__ entry_list,
+						     uint32_t *__restrict__ n_entry)
 {
-	const uint32_t S0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
-	if (S0 >= nS)
-		return;
-	// an entry: a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
+	// The entries go straight onto the list the walks start from: every wave counts its own (four sides a lane, a prefix
+	// over the lanes) and takes its stretch with ONE atomic add.  Waves are dispatched in grid order, so the list stays in
+	// side order up to the waves in flight -- all the walks want of it (neighbouring lanes on neighbouring classes); its
+	// exact order shows nowhere in the result.  Until round 5: a flag byte per side, written and then read twice by a
+	// count / scan / write compaction (four launches).
+	const uint32_t S0 = (BIDX * blockDim.x + threadIdx.x) * 4u, lane = threadIdx.x & 63u;
+	uint32_t fw = 0; // bit j: side S0 + j is an entry -- a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
 	if (S0 + 4 <= nS) {
 		const uint4 pb = *reinterpret_cast<const uint4 *>(pbr + S0);
 		const uint32_t mu = *reinterpret_cast<const uint32_t *>(multi + S0);
 		const uint2 ck = *reinterpret_cast<const uint2 *>(ckey + (S0 >> 1));
 		const uint32_t c0 = cproc[ck.x] ? 1u : 0u, c1 = cproc[ck.y] ? 1u : 0u;
-		const uint32_t f0 = ((mu & 0xFFu) && (pb.x & PB_BRIDGE)) ? c0 : 0u, f1 = ((mu & 0xFF00u) && (pb.y & PB_BRIDGE)) ? c0 : 0u;
-		const uint32_t f2 = ((mu & 0xFF0000u) && (pb.z & PB_BRIDGE)) ? c1 : 0u, f3 = ((mu & 0xFF000000u) && (pb.w & PB_BRIDGE)) ? c1 : 0u;
-		*reinterpret_cast<uint32_t *>(entry_flag + S0) = f0 | (f1 << 8) | (f2 << 16) | (f3 << 24);
-		return;
+		fw = (((mu & 0xFFu) && (pb.x & PB_BRIDGE)) ? c0 : 0u) | ((((mu & 0xFF00u) && (pb.y & PB_BRIDGE)) ? c0 : 0u) << 1) |
+		     ((((mu & 0xFF0000u) && (pb.z & PB_BRIDGE)) ? c1 : 0u) << 2) | ((((mu & 0xFF000000u) && (pb.w & PB_BRIDGE)) ? c1 : 0u) << 3);
+	} else {
+		for (uint32_t S = S0; S < nS; S++)
+			fw |= ((multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1u : 0u) << (S - S0);
 	}
-	for (uint32_t S = S0; S < nS; S++)
-		entry_flag[S] = (multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1 : 0;
+	const uint32_t cnt = (uint32_t)__popc(fw);
+	uint32_t inc = cnt;
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(inc, off);
+		if ((int)lane >= off)
+			inc += y;
+	}
+	const uint32_t total = __shfl(inc, 63);
+	if (!total)
+		return;
+	uint32_t base = 0;
+	if (lane == 63)
+		base = atomicAdd(n_entry, total);
+	base = __shfl(base, 63);
+	uint32_t at = base + inc - cnt;
+	while (fw) {
+		const int k = __ffs((int)fw) - 1;
+		fw &= fw - 1;
+		entry_list[at++] = S0 + (uint32_t)k;
+	}
 }
 
 // ------------------------------------------------------------------ 6. the DFS inside every class
@@ -1785,7 +1826,6 @@ static void tree_spans(TreeWs &tw, size_t V, size_t E, size_t Cmax, int groups, 
 	for (uint32_t **p : {&tw.entry_ps, &tw.entry_list, &tw.be_cnt})
 		take((void **)p, nS * 4);
 	take((void **)&tw.dvis, nS);
-	take((void **)&tw.entry_flag, nS + 16);
 	take((void **)&tw.wadj, (nS + 2 * E + 8) * 4); // wave walk: class-filtered scan lists (4 bytes a slot); earlier in the pass: twin slots [2E]
 	take((void **)&tw.cproc, (Cmax + 2) * 4);
 	take((void **)&tw.rk_pk, NSL * 4);
@@ -1866,7 +1906,7 @@ void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E,
 }
 
 // ------------------------------------------------------------------ driver
-uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
+int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   uint32_t max_side_links, bool force_big_class_dfs, bool force_sparse_splitters, StageTimer &tm,
 			   hipStream_t s)
 {
@@ -1883,8 +1923,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
 	if (n_slots >= P0_END || 3 * (size_t)V >= P0_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
 		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^30");
-	uint32_t *twin = tw.wadj; // [2E] (the filtered scan lists come much later)
-	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, rb.pk, bitsA, hside, ft, twin);
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, rb.pk, bitsA, hside, ft);
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, rb.pk, rb.heads);
 	if (n_slots)
 		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
@@ -1892,7 +1931,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	const uint32_t XW = NA / 64 + 1; // words of the position bitmap
 	HIP_CHECK(hipMemsetAsync(tw.xrec, 0, ((size_t)XW + 2) * 16, s));
 	LAUNCH(k_t0_parents, std::max(V, C), s, V, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, ft, rb.heads,
-	       twin, tw.t0seg, tw.xrec, C, start_key, pw.err + 2);
+	       tw.t0seg, tw.xrec, C, start_key, pw.err + 2);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
@@ -1912,9 +1951,8 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
-	LAUNCH(k_entry_flags, (nS + 3) / 4, s, nS, cstate, multi, cs.ckey, tw.cproc, tw.entry_flag);
 	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
-	compact_flagged_u8(tw.entry_flag, nS, tw.entry_list, n_entry_dev, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	KLAUNCH(k_entry_list, dim3(nblk((nS + 3) / 4)), dim3(TPB), 0, s, nS, cstate, multi, cs.ckey, tw.cproc, tw.entry_list, n_entry_dev);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
 	// gives up and reports the entry; those classes are then walked from the start by the walk with the short dependent
 	// chain, at the price of a filtering pass over the adjacency (it marks visits in its own bytes and rewrites the same
@@ -1930,7 +1968,7 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 		unsigned dfs_blocks = std::min(all_blocks, 3072u);
 		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
 			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
-		uint32_t *n_over = pw.err + 4, *over_list = tw.entry_ps; // (the scan of the entry flags is dead once compacted)
+		uint32_t *n_over = pw.err + 4, *over_list = tw.entry_ps; // (a spare array of the entries' size)
 		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry_dev, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps,
 			CLASS_BUDGET, n_over, over_list);
 		n_big = tw.host->read_u32(n_over, s);
@@ -1993,11 +2031,9 @@ uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw
 	KLAUNCH(k_back_edges, dim3((nS + BE_SIDES - 1) / BE_SIDES), dim3(TPB), 0, s, nS, cs.loff, cs.ladj, tw.dps, tw.side_tidx, cs.ckey,
 		cs.voff, sw.t_par, nb0_dev, pw.b_src, pw.b_tgt, pw.b_ord, dupflag, pw.lsz, pw.hi0, pw.incnt,
 		(uint32_t)std::min<size_t>(pw.nb_cap, 0xFFFFFFFFu));
-	const uint32_t NB0 = tw.host->read_u32(nb0_dev, s);
-	if (NB0 > pw.nb_cap)
-		throw HipError("spanning tree: more back edges than links outside the tree and sides without links (internal sizing bug)");
+	// (their number stays on the device: the class stage reads it together with its own counts)
 	tm.end(6);
-	return NB0;
+	return NB0_ON_DEVICE;
 }
 
 } // namespace povu_hip

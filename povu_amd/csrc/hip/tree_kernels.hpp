@@ -24,7 +24,6 @@ struct TreeWs {
 	uint2 *wstk;					  // [3 x 2V] pool of the walks' stacks {side, next candidate}
 	uint32_t *wpar;					  // [2V] DFS parent of a side the walk reached, W_UNVIS before
 	uint8_t *dvis_slots;				  // [2E] slot repeats an earlier link of its side (hub graphs)
-	uint8_t *entry_flag;				  // [2V+1] side starts the walk of its class
 	uint32_t *entry_ps, *entry_list;		  // [2V+1]
 	uint32_t *side_tidx;				  // [2V] tree vertex (T-space) of a side
 	uint32_t *be_cnt;				  // [2V+1] first arc of a side (tour); free afterwards
@@ -48,7 +47,7 @@ size_t walk_workspace_bytes(size_t V);
 
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.
-uint32_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
+int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   uint32_t max_side_links, bool force_big_class_dfs, bool force_sparse_splitters, StageTimer &tm,
 			   hipStream_t s);
 

@@ -219,8 +219,9 @@ extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *er
 	}
 	// comp_heights (pvst.hpp:807-836), literally: a stack, every child of the popped vertex gets its height and is pushed --
 	// a vertex listed under two parents is walked twice and keeps the height of the last visit, vertices the root does not
-	// reach keep 0.  The reference does not end on a file whose listings form a cycle; here the walk stops after 64 n + 1024
-	// pushes.
+	// reach keep 0.  The reference does not end on a file whose listings form a cycle (and takes 2^k steps on a chain of k
+	// doubly-listed diamonds); here the walk gives up after 64 n + 1024 pushes and the parse FAILS with a message -- heights
+	// that are half filled in are not handed out as if they were the reference's.
 	if (root != POVU_HIP_NIL) {
 		std::vector<uint32_t> stack;
 		uint64_t pushes = 0;
@@ -235,6 +236,12 @@ extern "C" povu_pvst_doc *povu_pvst_parse(const char *text, size_t len, char *er
 				stack.push_back(c);
 				pushes++;
 			}
+		}
+		if (!stack.empty()) {
+			povu_pvst_doc_free(d);
+			set_err(err, errlen, "the children listings form a cycle or list vertices under several parents too often: comp_heights "
+					     "(pvst.hpp:807-836) does not end on this file (gave up after " + std::to_string(limit) + " steps)");
+			return nullptr;
 		}
 	}
 	return d;

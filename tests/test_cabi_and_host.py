@@ -498,6 +498,25 @@ def test_pvst_reader_subflubble_lines():
     hl.povu_pvst_doc_free(d)
     assert not hl.povu_pvst_parse(b"X\t1\t>1>2\t.\tL\n", 13, err, 256) and b"Unknown vertex type" in err.value
     assert not hl.povu_pvst_parse(b"T\t1\t12\t.\tL\n", 11, err, 256) and b"malformed vertex label" in err.value
+    # comp_heights walks every listing (pvst.hpp:807-836): a chain of k doubly-listed diamonds takes 2^k steps, a cycle never
+    # ends.  A short chain is walked out (the last visit's height stands), a long one and a cycle FAIL the parse with a message
+    # instead of handing out half-filled heights
+    def diamonds(k):
+        rows = ["H\t0.0.3\t.\t.\t.", "D\t0\t.\t1\t."]
+        for j in range(k):  # vertex 3j+1 lists 3j+2 and 3j+3, both list 3j+4
+            a = 3 * j + 1
+            rows += [f"F\t{a}\t>1>2\t{a + 1}, {a + 2}\tL", f"F\t{a + 1}\t>1>2\t{a + 3}\tL", f"F\t{a + 2}\t>1>2\t{a + 3}\tL"]
+        rows.append(f"F\t{3 * k + 1}\t>1>2\t.\tL")
+        return ("\n".join(rows) + "\n").encode()
+    text = diamonds(5)
+    d = hl.povu_pvst_parse(text, len(text), err, 256)
+    assert d, err.value
+    assert d.contents.height[d.contents.n - 1] == 11 and d.contents.parent[d.contents.n - 1] == 15
+    hl.povu_pvst_doc_free(d)
+    text = diamonds(40)
+    assert not hl.povu_pvst_parse(text, len(text), err, 256) and b"comp_heights" in err.value
+    text = b"H\t0.0.3\t.\t.\t.\nD\t0\t.\t1\t.\nF\t1\t>1>7\t2\tL\nF\t2\t>4>6\t1\tL\n"
+    assert not hl.povu_pvst_parse(text, len(text), err, 256) and b"cycle" in err.value
 
 
 def test_host_code_under_address_and_ub_sanitizers(golden_dir, tmp_path):

@@ -302,6 +302,28 @@ def test_one_process_engine_three_ranks_on_one_device():
         md.close()
 
 
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+def test_one_process_engine_on_two_real_devices(transport, monkeypatch):
+    """Both transports of the one-process scatter between two DIFFERENT devices (skipped on a one-GPU box, which only ever
+    reaches the same-device path): peer copies (hipMemcpyPeerAsync + an event of the root's device per rank) and RCCL
+    send / receive with the receive buffers taken before anything is posted."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from povu_amd.hip import MultiDecomposer
+    monkeypatch.setenv("POVU_HIP_MULTI_TRANSPORT", transport)
+    g = _graph()
+    md = MultiDecomposer([0, 1])
+    assert md.transport.startswith("peer-copy" if transport == "peer" else "rccl"), md.transport
+    md.upload(g)
+    for _ in range(2):
+        md.scatter()
+        assert md.decompose().texts() == O.decompose(g)
+    info = [md.rank_info(r) for r in range(2)]
+    assert info[1]["peer_in"] == info[1]["shard_bytes"] * 2 and info[0]["peer_out"] == info[1]["peer_in"]
+    md.close()
+
+
 def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
     """`povu decompose --gpus 2` (both workers on the one GPU via POVU_HIP_DEVICES): every worker writes the files of its
     components; together they are what the single-GPU run writes."""

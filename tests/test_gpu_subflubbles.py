@@ -145,8 +145,8 @@ def test_every_rule_the_search_found(hip, rule):
 
 
 def test_the_literal_heap_of_lo_gives_the_closed_form(hip, monkeypatch):
-    """LoA: the device uses a closed form (max-tree over the edges' intervals) and keeps the reference's heap, one lane per
-    component, for components with a self-loop back edge (the root of a tip-less component has one: rule self_loop_in_loa).
+    """LoA: the device uses a closed form (max-tree over the edges' intervals); the reference's heap, one lane per
+    component, is kept for a back edge from a vertex to itself anywhere but at the root (none can arise).
     POVU_HIP_SUB_LITERAL_LOA sends every component through the heap: same PVSTs."""
     monkeypatch.setenv("POVU_HIP_SUB_LITERAL_LOA", "1")
     rng = np.random.default_rng(77)
@@ -158,12 +158,30 @@ def test_the_literal_heap_of_lo_gives_the_closed_form(hip, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_builder_style_graphs_without_tips(hip, seed):
+def test_builder_style_graphs_without_tips(hip, seed, monkeypatch):
     """Uploaded with explicit all-zero tips (the library's builder API): the root of every component gets a back edge to
-    itself (spanning_tree.cpp:387-395) -- in nobody's bracket table (oracle: "leaf subflubble passes"), and the case where
-    compute_LoA's heap keeps a stale entry (the device then runs the literal heap for that component)."""
+    itself (spanning_tree.cpp:433-438) -- in nobody's bracket table (oracle: "leaf subflubble passes"), and the one entry
+    compute_LoA's heap never pops.  It is pushed at tree vertex 0, which the descending sweep visits last (tree_utils.cpp:
+    250-271): nobody reads the heap after it, so the closed form holds for tip-less (circular) components too -- until round 5
+    they took the reference's heap on one lane, 4 s per 10^6 segments.  POVU_HIP_SUB_FORBID_HEAP makes the pass fail if any
+    component would still take the heap; the oracle runs the literal heap."""
+    monkeypatch.setenv("POVU_HIP_SUB_FORBID_HEAP", "1")
     for g in (W.bubble_zoo(12, 8, 100 + seed), W.hprc_shaped([2000, 700], seed=seed), W.random_bidirected(300, 420, 900 + seed, self_loops=True)):
         check(hip, g, np.zeros(g.n_vtx, dtype=np.uint8))
+
+
+def test_closed_form_lo_on_many_tip_less_components(hip, monkeypatch):
+    """The closed form of LoA against the oracle's literal heap on 1 500 random tip-less components (every one carries the
+    0 -> 0 back edge at its root), self loops and parallel links included, and on a circular chromosome-shaped component of
+    2 * 10^5 segments; no component may take the one-lane heap."""
+    monkeypatch.setenv("POVU_HIP_SUB_FORBID_HEAP", "1")
+    rng = np.random.default_rng(2025)
+    for it in range(1500):
+        nv = int(rng.integers(3, 60))
+        g = W.random_bidirected(nv, int(rng.integers(nv, 3 * nv)), int(rng.integers(1 << 30)), self_loops=bool(it % 3 == 0))
+        check(hip, g, np.zeros(g.n_vtx, dtype=np.uint8))
+    g = W.hprc_shaped([200000], seed=11)
+    check(hip, g, np.zeros(g.n_vtx, dtype=np.uint8))
 
 
 def test_reader_round_trip_on_the_extended_trees(hip):
