@@ -266,6 +266,13 @@ void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, vo
 size_t scan_tmp_bytes(size_t n);
 // indices of the non-zero bytes of flag[0..n), ascending, into out; their number into *count_dev (device memory).  No
 // prefix array is written: tiles are counted, the counts scanned, the tiles ranked again.
+// Up to 8 words of device memory into page-locked host memory by ONE single-lane kernel: a hipMemcpyAsync per word is a
+// copy submission each (3-4 us apiece on the stream; config 2's whole pass is 1.1 ms).  `host_dst` is the HOST pointer of
+// page-locked memory (HostScratch); read it after the stream is synchronised.
+struct WordSrc {
+	const uint32_t *p[8];
+};
+void publish_words(uint32_t *host_dst, const WordSrc &src, int n, hipStream_t s);
 void compact_flagged_u8(const uint8_t *flag, size_t n, uint32_t *out, uint32_t *count_dev, void *tmp, size_t tmp_bytes, hipStream_t s);
 size_t compact_tmp_bytes(size_t n);
 // exclusive running maximum (identity 0)

@@ -190,16 +190,25 @@ __device__ __forceinline__ uint32_t lds_find(uint32_t *par, uint32_t x)
 	}
 	return x;
 }
+// Inside a tile the roots are linked by a pseudo-random PRIORITY, not by their index: a pangenome tile is one long chain of
+// segments, all its links (i, i + 1) are united at the same moment by neighbouring lanes, and linking larger-under-smaller
+// then builds a parent chain as long as the tile -- every later find walked it (k_uf_tiles was bound by those walks:
+// 2.5 ms for 1.8 GB of input on the whole-genome graph).  With random priorities the same unions leave trees of
+// logarithmic depth.  A root is only ever hooked under a root of HIGHER priority (a bijection of the index: no ties), so
+// the pointers stay acyclic whatever the races; the smallest vertex of every set -- what the labels must name -- is
+// worked out at the end of the kernel.
+__device__ __forceinline__ uint32_t uf_prio(uint32_t x) { return x * 0x9E3779B1u; }
 __device__ __forceinline__ bool lds_union(uint32_t *par, uint32_t a, uint32_t b)
 {
 	uint32_t ra = lds_find(par, a), rb = lds_find(par, b);
 	while (ra != rb) {
-		const uint32_t hi = max(ra, rb), lo = min(ra, rb);
-		const uint32_t old = atomicCAS(&par[hi], hi, lo);
-		if (old == hi)
+		const bool a_low = uf_prio(ra) < uf_prio(rb);
+		const uint32_t child = a_low ? ra : rb, up = a_low ? rb : ra;
+		const uint32_t old = atomicCAS(&par[child], child, up);
+		if (old == child)
 			return true;
 		ra = lds_find(par, old);
-		rb = lds_find(par, lo);
+		rb = lds_find(par, up);
 	}
 	return false;
 }
@@ -223,11 +232,12 @@ __device__ __forceinline__ void wave_append(bool take, uint32_t v, uint32_t k, u
 // has exactly the global slots (a self loop is stored as (ve, complement(ve)) and owns a slot on either side,
 // bidirected.cpp:529-531), so its offsets are the CSR's own.
 __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t *__restrict__ off, const uint32_t *__restrict__ aoth,
-						  const uint32_t *__restrict__ adj, uint32_t *__restrict__ label,
+						  uint32_t *__restrict__ label,
 						  uint8_t *__restrict__ hook, uint32_t *__restrict__ xcount, uint2 *__restrict__ xlist,
 						  uint32_t *__restrict__ any_loop)
 {
 	__shared__ uint32_t par[UF_TILE];
+	__shared__ uint32_t minv2[UF_TILE / 2]; // smallest member of the set a root stands for, 16 bits each (filled at the end)
 	__shared__ uint32_t heavy[UF_HEAVY_CAP];
 	__shared__ uint32_t n_heavy;
 	const uint32_t v0 = BIDX * UF_TILE, v1 = min(V, v0 + UF_TILE);
@@ -237,6 +247,9 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		n_heavy = 0;
 	__syncthreads();
 	bool loop_seen = false;
+	// hook[k] = 1: the link of slot k merged two trees of the union-find (it is a link of the spanning forest).  The flag sits
+	// at the SLOT the link was united from -- the one of its smaller end --, not at the link's id: no adj[k] is loaded here,
+	// and the re-index reads the flag of a slot and of its twin (until round 5: one byte per link, found through adj[k]).
 	auto handle = [&](uint32_t v, uint32_t k, uint32_t o) -> bool { // o = aoth[k]; true: the slot leaves the tile upwards
 		const uint32_t vo = o >> 1;
 		if (vo <= v) {
@@ -246,29 +259,53 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 		if (vo >= v1)
 			return true;
 		if (lds_union(par, v - v0, vo - v0))
-			hook[adj[k]] = 1;
+			hook[k] = 1;
 		return false;
 	};
+	// A lane takes UF_BATCH sides at a time and keeps the loads of all of them in flight together: their offsets first (one
+	// round trip for the batch), then slot r of every side that has one (one round trip per r: sides have one to three
+	// slots).  The walk a side at a time that this replaces paid two dependent round trips PER SIDE, sixteen sides in a row
+	// per lane -- the kernel was bound by that chain, not by the bytes it reads (2.5 ms for 1.8 GB on the whole-genome graph).
+	constexpr uint32_t UF_BATCH = 8;
 	const uint32_t S0 = 2 * v0, S1 = 2 * v1;
-	for (uint32_t base = S0; base < S1; base += blockDim.x) { // uniform trip count: the ballots below need whole waves
-		const uint32_t S = base + threadIdx.x;
-		uint32_t k = 0, hi = 0;
-		if (S < S1) {
-			k = off[S];
-			hi = off[S + 1];
-			if (hi - k > UF_HEAVY) { // a hub side: the whole workgroup walks it below
-				const uint32_t q = atomicAdd(&n_heavy, 1u);
-				if (q < UF_HEAVY_CAP) {
-					heavy[q] = S;
-					hi = k;
-				}
+	for (uint32_t base = S0; base < S1; base += UF_BATCH * blockDim.x) { // uniform trip count: the ballots below need whole waves
+		uint32_t kb[UF_BATCH], ke[UF_BATCH];
+#pragma unroll
+		for (uint32_t j = 0; j < UF_BATCH; j++) {
+			const uint32_t S = base + j * blockDim.x + threadIdx.x;
+			kb[j] = ke[j] = 0;
+			if (S < S1) {
+				kb[j] = off[S];
+				ke[j] = off[S + 1];
 			}
 		}
-		while (__any(k < hi)) {
-			const bool live = k < hi;
-			const bool cross = live && handle(S >> 1, k, live ? aoth[k] : 0u);
-			wave_append(cross, S >> 1, k, xcount, xlist);
-			k++;
+#pragma unroll
+		for (uint32_t j = 0; j < UF_BATCH; j++)
+			if (ke[j] - kb[j] > UF_HEAVY) { // a hub side: the whole workgroup walks it below
+				const uint32_t q = atomicAdd(&n_heavy, 1u);
+				if (q < UF_HEAVY_CAP) {
+					heavy[q] = base + j * blockDim.x + threadIdx.x;
+					ke[j] = kb[j];
+				}
+			}
+		for (uint32_t r = 0;; r++) {
+			uint32_t o[UF_BATCH];
+			bool any = false;
+#pragma unroll
+			for (uint32_t j = 0; j < UF_BATCH; j++) {
+				const bool live = kb[j] + r < ke[j];
+				o[j] = live ? aoth[kb[j] + r] : 0u;
+				any = any || live;
+			}
+			if (!__any(any))
+				break;
+#pragma unroll
+			for (uint32_t j = 0; j < UF_BATCH; j++) {
+				const bool live = kb[j] + r < ke[j];
+				const uint32_t v = (base + j * blockDim.x + threadIdx.x) >> 1;
+				const bool cross = live && handle(v, kb[j] + r, o[j]);
+				wave_append(cross, v, kb[j] + r, xcount, xlist);
+			}
 		}
 	}
 	__syncthreads();
@@ -302,13 +339,35 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 			par[threadIdx.x + k * UF_TPB] = pp[k];
 		__syncthreads();
 	}
+	// the label of a vertex = the smallest vertex of its set (componetize orders the components by it, and the links that
+	// leave the tile are united larger-under-smaller in global memory on top of these labels)
+	static_assert(UF_TILE <= 65536, "tile-local indices are kept in 16 bits here");
+	for (uint32_t i = threadIdx.x; i < UF_TILE / 2; i += blockDim.x)
+		minv2[i] = (2 * i) | ((2 * i + 1) << 16);
+	__syncthreads();
+	auto min_of = [&](uint32_t r) { return (minv2[r >> 1] >> (16 * (r & 1u))) & 0xFFFFu; };
+	for (uint32_t i = threadIdx.x; i < UF_TILE; i += blockDim.x) {
+		const uint32_t r = par[i];
+		if (r == i)
+			continue;
+		const uint32_t sh = 16 * (r & 1u);
+		for (uint32_t old = minv2[r >> 1];;) { // 16-bit atomic minimum (most vertices are not the smallest of their set: read first)
+			if (((old >> sh) & 0xFFFFu) <= i)
+				break;
+			const uint32_t seen = atomicCAS(&minv2[r >> 1], old, (old & ~(0xFFFFu << sh)) | (i << sh));
+			if (seen == old)
+				break;
+			old = seen;
+		}
+	}
+	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < v1 - v0; i += blockDim.x)
-		label[v0 + i] = v0 + par[i];
+		label[v0 + i] = v0 + min_of(par[i]);
 }
 
 // the links that leave their tile, in global memory (grid-stride: their number only exists on the device)
 __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__restrict__ xlist,
-			   const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ adj, uint32_t *parent,
+			   const uint32_t *__restrict__ aoth, uint32_t *parent,
 			   uint8_t *__restrict__ hook)
 {
 	const uint32_t NX = *xcount;
@@ -319,7 +378,7 @@ __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__r
 			uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
 			uint32_t old = atomicCAS(&parent[hi], hi, lo);
 			if (old == hi) {
-				hook[adj[x.y]] = 1;
+				hook[x.y] = 1;
 				break;
 			}
 			ra = uf_find(parent, old);
@@ -459,8 +518,8 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 			      const uint32_t *__restrict__ erank, const uint32_t *__restrict__ v1,
 			      const uint8_t *__restrict__ s1, const uint32_t *__restrict__ v2,
 			      const uint8_t *__restrict__ s2, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-			      uint32_t *__restrict__ ldeg, const uint8_t *__restrict__ hook, uint32_t *__restrict__ la,
-			      uint32_t *__restrict__ lb, uint8_t *__restrict__ tgray)
+			      uint32_t *__restrict__ ldeg, const uint8_t *__restrict__ hook, const uint32_t *__restrict__ atwin,
+			      uint32_t *__restrict__ la, uint32_t *__restrict__ lb, uint8_t *__restrict__ tgray)
 {
 	uint32_t S = BIDX * blockDim.x + threadIdx.x;
 	if (S >= 2 * V)
@@ -487,7 +546,7 @@ __global__ void k_local_edges(uint32_t V, const uint32_t *__restrict__ perm, con
 		vals[2 * le + 1] = 2 * le + 1;
 		la[le] = S;
 		lb[le] = So;
-		tgray[le] = hook[e];
+		tgray[le] = hook[k] | hook[atwin[k]]; // (the flag sits at the slot of the link's smaller end, k_uf_tiles)
 		atomicAdd(&ldeg[S], 1u);
 		atomicAdd(&ldeg[So], 1u);
 	}
@@ -554,7 +613,7 @@ __global__ void k_local_degree(uint32_t V, const uint32_t *__restrict__ perm, co
 // twin slot's (atwin, built at upload) for the other end.  lle[slot] = that id | LLE_TREE when the link is in the spanning
 // forest of the segments (so that the tree kernels read the flag with the slot, not through the id).
 __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ pos,
-			    const uint32_t *__restrict__ off, const uint32_t *__restrict__ adj,
+			    const uint32_t *__restrict__ off,
 			    const uint32_t *__restrict__ aoth, const uint32_t *__restrict__ atwin,
 			    const uint32_t *__restrict__ sbase, const uint32_t *__restrict__ loff,
 			    const uint8_t *__restrict__ hook, uint32_t *ladj, uint32_t *lle, bool any_loop)
@@ -604,13 +663,15 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 		lle[base + j] = le;
 		ladj[base + j] = other;
 	};
-	// four slots a round: far sides, link ids and twin slots in one 16-byte load each, the forest flags of the four links in
-	// independent gathers (the global arrays carry slack behind their last slot)
+	// four slots a round: far sides and twin slots in one 16-byte load each; a link's forest flag sits at ONE of its two slots
+	// (the one the union-find united it from): the four own flags in four byte loads of one line, the twins' in independent
+	// gathers (the global arrays carry slack behind their last slot)
 	for (uint32_t k0 = lo; k0 < hi; k0 += 4) {
-		const uint4 o4 = load4_unaligned(aoth + k0), e4 = load4_unaligned(adj + k0), t4 = load4_unaligned(atwin + k0);
+		const uint4 o4 = load4_unaligned(aoth + k0), t4 = load4_unaligned(atwin + k0);
 		const uint32_t rem = hi - k0;
 		const uint32_t os[4] = {o4.x, o4.y, o4.z, o4.w}, ts[4] = {t4.x, t4.y, t4.z, t4.w};
-		const uint32_t hs[4] = {hook[e4.x], rem > 1 ? hook[e4.y] : 0u, rem > 2 ? hook[e4.z] : 0u, rem > 3 ? hook[e4.w] : 0u};
+		const uint32_t hs[4] = {(uint32_t)(hook[k0] | hook[t4.x]), rem > 1 ? (uint32_t)(hook[k0 + 1] | hook[t4.y]) : 0u,
+					rem > 2 ? (uint32_t)(hook[k0 + 2] | hook[t4.z]) : 0u, rem > 3 ? (uint32_t)(hook[k0 + 3] | hook[t4.w]) : 0u};
 #pragma unroll
 		for (uint32_t q = 0; q < 4; q++) {
 			if (q >= rem)
@@ -637,7 +698,7 @@ __global__ void k_local_adj(uint32_t V, const uint32_t *__restrict__ perm, const
 		for (uint32_t k = lo; k < hi; k++, P++) {
 			const uint32_t o = aoth[k];
 			if ((o >> 1) == v && slot_is_first(i, 1 - s, v, o, pos))
-				insert(P | (hook[adj[k]] ? LLE_TREE : 0u), S ^ 1u);
+				insert(P, S ^ 1u); // (a self loop is never a link of the forest)
 		}
 	}
 	if (n <= 4) { // never flushed: write the registers
@@ -825,16 +886,16 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
-	// one byte per link; the length of the cross list sits behind them (zeroed by the same memset)
-	const size_t xoff = ((size_t)E + 7) & ~size_t(7);
+	// one byte per adjacency slot; the length of the cross list sits behind them (zeroed by the same memset)
+	const size_t xoff = (2 * (size_t)E + 7) & ~size_t(7);
 	HIP_CHECK(hipMemsetAsync(st.hook, 0, xoff + 24, s));
 	uint32_t *xcount = reinterpret_cast<uint32_t *>(st.hook + xoff);
 	uint32_t *any_loop = xcount + 1; // cleared with the flags
 	uint2 *xlist = reinterpret_cast<uint2 *>(st.keys); // [E] pairs fit the 2E+2 words; free until the re-index
-	KLAUNCH(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, g.off, g.aoth, g.adj, st.label,
+	KLAUNCH(k_uf_tiles, dim3((V + UF_TILE - 1) / UF_TILE), dim3(UF_TPB), 0, s, V, g.off, g.aoth, st.label,
 			   st.hook, xcount, xlist, any_loop);
 	if (E) {
-		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, xcount, xlist, g.aoth, g.adj,
+		KLAUNCH(k_uf_cross, dim3(std::min<unsigned>(nblk(E), 2048)), dim3(TPB), 0, s, xcount, xlist, g.aoth,
 				   st.label, st.hook);
 	}
 	uint8_t *is_root = reinterpret_cast<uint8_t *>(st.flag);
@@ -843,9 +904,7 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	scan_exclusive_u8(is_root, st.crank, (size_t)V + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(7);
 	uint32_t *h = st.host->take<uint32_t>(3); // component count, the order flag and the self-loop flag in one round trip
-	HIP_CHECK(copy_async(h, st.crank + V, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(copy_async(h + 1, st.stats + 9, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(copy_async(h + 2, any_loop, 4, hipMemcpyDeviceToHost, s));
+	publish_words(h, WordSrc{{st.crank + V, st.stats + 9, any_loop}}, 3, s);
 	HIP_CHECK(hipStreamSynchronize(s));
 	st.comp_sorted = h[1] == 0;
 	st.has_self_loops = h[2] != 0;
@@ -899,7 +958,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
 			scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 		}
-		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.adj, g.aoth, g.atwin, sbase,
+		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, g.atwin, sbase,
 				   st.loff, st.hook, st.ladj, st.lle, st.has_self_loops);
 		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats,
 				   st.host_pub);
@@ -915,7 +974,7 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 	scan_exclusive_u32(st.flag, st.erank, (size_t)g.n_slots + 1, st.scan_tmp, st.scan_tmp_bytes, s);
 	HIP_CHECK(hipMemsetAsync(st.ldeg, 0, (nS + 1) * 4, s));
 	KLAUNCH(k_local_edges, dim3(nblk(nS)), dim3(TPB), 0, s, V, st.perm, st.pos, g.off, g.adj, st.sbase,
-			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg, st.hook, st.la, st.lb,
+			   st.first, st.erank, g.v1, g.s1, g.v2, g.s2, st.keys, st.vals, st.ldeg, st.hook, g.atwin, st.la, st.lb,
 			   st.tgray);
 	HIP_CHECK(hipMemsetAsync(st.stats, 0, 16, s));
 	KLAUNCH(k_max_u32, dim3(std::min<unsigned>(nblk(nS), 1024)), dim3(TPB), 0, s, (uint32_t)nS, st.ldeg, st.stats, (uint32_t *)nullptr);

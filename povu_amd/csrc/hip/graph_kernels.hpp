@@ -35,7 +35,7 @@ struct CompState {
 	uint32_t *label, *flag, *crank, *comp_of, *tmp_a, *ckey, *perm, *pos;
 	uint32_t *voff, *eoff, *vdeg, *sbase, *first, *erank, *ldeg, *loff, *ladj;
 	uint32_t *keys, *vals, *keys2, *vals2;
-	uint8_t *hook;	   // [E]  1 = the link merged two union-find trees (spanning forest of the segments)
+	uint8_t *hook;	   // [2E] per adjacency slot: 1 = the link was united from this slot and merged two union-find trees (spanning forest of the segments)
 	uint32_t *la, *lb; // [E]  sorted side ids of local edge le (la = first-encounter side); only the sorted-adjacency builder fills them
 	uint32_t *lle;	   // [2E] per local adjacency slot: the link's id (LLE_ID bits) | LLE_TREE.  Both ends of a link carry the same id
 			   //      and a side's slots ascend by it in first-encounter order: the position of the link's first-encounter slot

@@ -247,64 +247,77 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 // The sweep over a branching vertex's children is a chain of dependent gathers (child, its size, the flags behind its
 // subtree, the next child ...): it runs in a kernel of its own over the compacted list of branching vertices, every lane
 // busy with one of them -- inside this kernel the few lanes that had work left the rest of their workgroup waiting.
+static constexpr uint32_t HS_ITER = 16, HS_VERTS = TPB * 4 * HS_ITER; // vertices a workgroup of k_hi_simp takes: one atomic add for 16 384 of them
 __global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
 						  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
 						  uint8_t *__restrict__ capf, uint32_t *__restrict__ br_list, uint32_t *__restrict__ n_br)
 {
-	const uint32_t t0 = (BIDX * blockDim.x + threadIdx.x) * 4u, lane = threadIdx.x & 63u; // (four vertices a lane, 16-byte loads: see k_entry_list)
+	const uint32_t B0 = BIDX * HS_VERTS, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	auto one = [&](uint32_t t, uint32_t sz, uint32_t br, uint32_t p0, uint32_t sz_next, uint32_t &sm, uint32_t &bch) {
 		sm = (sz && br && psb[t + sz] - p0 == 1) ? 1u : 0u;
 		bch = (sz > 2 && t + 1 + max(sz_next, 1u) < t + sz) ? 1u : 0u; // the first child does not fill the subtree
 	};
-	uint32_t bw = 0; // bit j: vertex t0 + j branches
-	if (t0 + 4 < T) { // (strictly: the last of the four looks at its successor's size)
-		const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), p = *reinterpret_cast<const uint4 *>(psb + t0);
-		const uint32_t sz4 = gsize[t0 + 4], br = *reinterpret_cast<const uint32_t *>(bridge + t0);
-		uint32_t s0, s1, s2, s3, c0, c1, c2, c3;
-		one(t0, sz.x, br & 0xFFu, p.x, sz.y, s0, c0);
-		one(t0 + 1, sz.y, br & 0xFF00u, p.y, sz.z, s1, c1);
-		one(t0 + 2, sz.z, br & 0xFF0000u, p.z, sz.w, s2, c2);
-		one(t0 + 3, sz.w, br & 0xFF000000u, p.w, sz4, s3, c3);
-		const uint32_t sw = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
-		*reinterpret_cast<uint32_t *>(simp + t0) = sw;
-		if (hpf)
-			*reinterpret_cast<uint32_t *>(hpf + t0) = sw;
-		*reinterpret_cast<uint32_t *>(capf + t0) = 0u; // (cap_tgt is only read where capf says so)
-		bw = c0 | (c1 << 1) | (c2 << 2) | (c3 << 3);
-	} else {
-		for (uint32_t t = t0; t < T; t++) {
-			uint32_t sm, bch;
-			one(t, gsize[t], bridge[t], psb[t], gsize[t + 1], sm, bch);
-			simp[t] = (uint8_t)sm;
-			if (t == T - 1)
-				simp[T] = 0;
+	unsigned long long bw = 0; // bit 4 it + j: vertex B0 + it * 1024 + 4 tid + j branches
+#pragma unroll 4
+	for (uint32_t it = 0; it < HS_ITER; it++) {
+		const uint32_t t0 = B0 + it * (TPB * 4u) + threadIdx.x * 4u; // (four vertices a lane, 16-byte loads: see k_entry_list)
+		uint32_t b4 = 0;
+		if (t0 + 4 < T) { // (strictly: the last of the four looks at its successor's size)
+			const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), p = *reinterpret_cast<const uint4 *>(psb + t0);
+			const uint32_t sz4 = gsize[t0 + 4], br = *reinterpret_cast<const uint32_t *>(bridge + t0);
+			uint32_t s0, s1, s2, s3, c0, c1, c2, c3;
+			one(t0, sz.x, br & 0xFFu, p.x, sz.y, s0, c0);
+			one(t0 + 1, sz.y, br & 0xFF00u, p.y, sz.z, s1, c1);
+			one(t0 + 2, sz.z, br & 0xFF0000u, p.z, sz.w, s2, c2);
+			one(t0 + 3, sz.w, br & 0xFF000000u, p.w, sz4, s3, c3);
+			const uint32_t sw = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+			*reinterpret_cast<uint32_t *>(simp + t0) = sw;
 			if (hpf)
-				hpf[t] = (uint8_t)sm;
-			capf[t] = 0;
-			bw |= bch << (t - t0);
+				*reinterpret_cast<uint32_t *>(hpf + t0) = sw;
+			*reinterpret_cast<uint32_t *>(capf + t0) = 0u; // (cap_tgt is only read where capf says so)
+			b4 = c0 | (c1 << 1) | (c2 << 2) | (c3 << 3);
+		} else {
+			for (uint32_t t = t0; t < T; t++) {
+				uint32_t sm, bch;
+				one(t, gsize[t], bridge[t], psb[t], gsize[t + 1], sm, bch);
+				simp[t] = (uint8_t)sm;
+				if (t == T - 1)
+					simp[T] = 0;
+				if (hpf)
+					hpf[t] = (uint8_t)sm;
+				capf[t] = 0;
+				b4 |= bch << (t - t0);
+			}
 		}
+		bw |= (unsigned long long)b4 << (4 * it);
 	}
-	// the branching vertices go straight onto the list k_capping works through (one atomic add per wave, as k_entry_list
-	// does; the order of the list shows nowhere: every vertex on it is decided on its own)
-	const uint32_t cnt = (uint32_t)__popc(bw);
+	// the branching vertices go straight onto the list k_capping works through: one atomic add per workgroup, as
+	// k_entry_list does (the order of the list shows nowhere: every vertex on it is decided on its own)
+	const uint32_t cnt = (uint32_t)__popcll(bw);
 	uint32_t inc = cnt;
 	for (int off = 1; off < 64; off <<= 1) {
 		const uint32_t y = __shfl_up(inc, off);
 		if ((int)lane >= off)
 			inc += y;
 	}
-	const uint32_t total = __shfl(inc, 63);
-	if (!total)
-		return;
-	uint32_t base = 0;
+	__shared__ uint32_t wsum[TPB / 64], base;
 	if (lane == 63)
-		base = atomicAdd(n_br, total);
-	base = __shfl(base, 63);
-	uint32_t at = base + inc - cnt;
+		wsum[wave] = inc;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+	for (uint32_t w = 0; w < TPB / 64; w++) {
+		if (w < wave)
+			before += wsum[w];
+		all += wsum[w];
+	}
+	if (threadIdx.x == 0)
+		base = all ? atomicAdd(n_br, all) : 0u;
+	__syncthreads();
+	uint32_t at = base + before + inc - cnt;
 	while (bw) {
-		const int k = __ffs((int)bw) - 1;
+		const int k = __ffsll((long long)bw) - 1;
 		bw &= bw - 1;
-		br_list[at++] = t0 + (uint32_t)k;
+		br_list[at++] = B0 + (uint32_t)(k >> 2) * (TPB * 4u) + threadIdx.x * 4u + (uint32_t)(k & 3);
 	}
 }
 __global__ void k_capping(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const uint32_t *__restrict__ gsize,
@@ -1128,6 +1141,7 @@ static void for_each_span(ParWs &pw, size_t V, size_t E, size_t Cmax, int groups
 		take1((void **)p, (T + 2) * 4);
 	for (uint32_t **p : {&pw.b_src, &pw.b_tgt, &pw.b_ord})
 		take1((void **)p, (NB + 2) * 4);
+	take1((void **)&pw.sdl, (V + 4) * 4);
 	take1((void **)&pw.err, 64);
 	take1((void **)&pw.comp_bad, (Cmax + 2) * 4); // (zeroed when the pass starts, ahead of the tree stage)
 	pw.scan_tmp_bytes = std::max(scan_tmp_bytes(std::max(T, NB) + 4), 2 * compact_tmp_bytes(std::max(T, NB) + 4));
@@ -1293,7 +1307,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	LAUNCH(k_bridge_flags, (T + 3) / 4, s, T, pw.gsize, pw.gpar, pscov, bridge);
 	scan8(bridge, psb, (size_t)T + 1);
 	uint32_t *br_list = pw.vals_t, *n_br = pw.err + 10; // (the sort's value buffer is free until the class pass; the count was cleared with the other counters)
-	KLAUNCH(k_hi_simp, dim3(nblk(((size_t)T + 3) / 4)), dim3(TPB), 0, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, br_list, n_br);
+	KLAUNCH(k_hi_simp, dim3((unsigned)(((size_t)T + HS_VERTS - 1) / HS_VERTS)), dim3(TPB), 0, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, br_list,
+		n_br);
 	KLAUNCH(k_capping, dim3(std::min<unsigned>(nblk(T / 8 + 1), 16384)), dim3(TPB), 0, s, n_br, br_list, pw.gsize, pw.hi0, psb, root_of,
 		pw.segA, pw.cap_tgt, capf, pw.err + 5);
 	// capping / simplifying vertices per tile of k_bracket_extra, scanned: [ntiles + 1] each, the totals in the last word
@@ -1303,9 +1318,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	scan_exclusive_u32_pair(tsimp, tsimp, (size_t)ntiles + 1, tcap, tcap, (size_t)ntiles + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	uint32_t *extra = pw.host->take<uint32_t>(4);
-	HIP_CHECK(copy_async(&extra[0], tcap + ntiles, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(copy_async(&extra[1], tsimp + ntiles, 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(copy_async(&extra[2], pw.err + 5, 8, hipMemcpyDeviceToHost, s)); // literal-rule flag | back edges of the tree stage
+	publish_words(extra, WordSrc{{tcap + ntiles, tsimp + ntiles, pw.err + 5, pw.err + 6}}, 4, s); // counts | literal-rule flag | back edges of the tree stage
 	HIP_CHECK(hipStreamSynchronize(s));
 	if (dense_nb0 == NB0_ON_DEVICE) {
 		NB0 = extra[3];
@@ -1356,11 +1369,16 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		// row E first (it only needs the tree): the stack index of every black vertex, so that the class pass can work
 		// in stack order from the start -- the sort carries stack indices, and classes, next_seen and prev are written
 		// where rows F/G read them
-		HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)V + 2) * 4, s)); // (the bracket counts that lived here are dead)
-		LAUNCH(k_shift_delta, V, s, V, cs.ckey, sw.c_ntree, pw.gsize, pw.dlt);
+		uint32_t *sdl = pw.dlt;
+		if (pw.sdl_filled && dense_nb0 >= 0) {
+			sdl = pw.sdl; // the tree stage's emit kernel had both sizes of every segment in hand and left the differences there
+		} else {
+			HIP_CHECK(hipMemsetAsync(pw.dlt, 0, ((size_t)V + 2) * 4, s)); // (the bracket counts that lived here are dead)
+			LAUNCH(k_shift_delta, V, s, V, cs.ckey, sw.c_ntree, pw.gsize, pw.dlt);
+		}
 		uint32_t *shift_ps = pw.topi; // (dlt_ps still holds the bracket range starts; nobody needs vertex -> stack index here)
-		scan(pw.dlt, shift_ps, (size_t)V + 1);
-		const StackPlace sp{cs.voff, pw.soff, pw.dlt, shift_ps, pw.s_vtx, pw.s_comp};
+		scan(sdl, shift_ps, (size_t)V + 1);
+		const StackPlace sp{cs.voff, pw.soff, sdl, shift_ps, pw.s_vtx, pw.s_comp};
 		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB, pw.tgtR, pw.psin, ck,
 		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree, sp);
 		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);

@@ -42,6 +42,8 @@ struct ParWs {
 	uint32_t *hi0, *cov, *psA, *psB, *flagC, *psC; // exclusive scans of the byte flags below [T+1]; flagC: run marks
 	uint8_t *f8a, *f8b, *f8c, *f8d; // [T+1] one-byte flags (bridge / simplifying / capping / branching vertex, class and stack flags)
 	uint32_t *cap_tgt, *mpre, *dlt, *dlt_ps, *incnt, *psin, *topi, *lsz, *gcls;
+	uint32_t *sdl;		 // [V+2] row E's difference array (k_shift_delta) when the tree stage's emit kernel already filled it
+	bool sdl_filled = false; // ... which it says here
 	uint32_t *vals_t, *vals_t2;
 	uint32_t *keys_t, *keys_t2; // [T]
 	// dense back edges / brackets

@@ -325,7 +325,7 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take(&cs.vals, 2 * E + 2, 4);
 		take(&cs.keys2, 2 * E + 2, 4);
 		take(&cs.vals2, 2 * E + 2, 4);
-		take(&cs.hook, E + 32, 1);
+		take(&cs.hook, 2 * E + 32, 1);
 		take(&cs.la, E + 2, 4);
 		take(&cs.lb, E + 2, 4);
 		take(&cs.lle, 2 * E + 8, 4); // (+8: the tour kernel reads a segment's slot words four at a time)
@@ -424,7 +424,7 @@ size_t rowb_carve_label(Arena *ar, const Sizes &z, CompState &cs)
 	take(&cs.crank, V + 2, 4);
 	take(&cs.comp_of, V + 1, 4);
 	take(&cs.keys, 2 * E + 2, 4); // the cross list of the union-find tiles: [E] pairs
-	take(&cs.hook, E + 32, 1);
+	take(&cs.hook, 2 * E + 32, 1);
 	take(&cs.stats, 16, 4);
 	cs.scan_tmp_bytes = scan_tmp_bytes(std::max<size_t>(z.nS, z.slots) + 2);
 	take((char **)&cs.scan_tmp, cs.scan_tmp_bytes, 1);

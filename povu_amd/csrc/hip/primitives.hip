@@ -498,6 +498,20 @@ __global__ void __launch_bounds__(CP_TPB) k_cp_write(const uint8_t *__restrict__
 		out[at++] = (uint32_t)(e0 + k);
 	}
 }
+__global__ void k_publish_words(WordSrc src, int n, uint32_t *__restrict__ dst)
+{
+	if (threadIdx.x < (unsigned)n)
+		dst[threadIdx.x] = *src.p[threadIdx.x];
+}
+void publish_words(uint32_t *host_dst, const WordSrc &src, int n, hipStream_t s)
+{
+	if (n <= 0 || n > 8)
+		throw HipError("publish_words: 1..8 words");
+	uint32_t *dev = nullptr;
+	HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host_dst, 0));
+	count_kernel_d2h((size_t)n * 4);
+	KLAUNCH(k_publish_words, dim3(1), dim3(64), 0, s, src, n, dev);
+}
 size_t compact_tmp_bytes(size_t n) { return ((n + CP_TILE - 1) / CP_TILE + 1) * 4 + 256; }
 void compact_flagged_u8(const uint8_t *flag, size_t n, uint32_t *out, uint32_t *count_dev, void *tmp, size_t tmp_bytes, hipStream_t s)
 {

@@ -821,48 +821,64 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 // is alone in its class has nothing to walk: the walks start from the entries that share their class (multi)
 // (four sides a lane: one 16-byte, one 4-byte and one 8-byte load instead of twelve 4- and 1-byte ones -- a kernel of a few
 // loads per element is bound by the number of memory instructions its CU can retire, not by their bytes)
+static constexpr uint32_t EL_ITER = 16, EL_SIDES = TPB * 4 * EL_ITER; // sides a workgroup of k_entry_list lists: one atomic add for 16 384 of them
 __global__ void __launch_bounds__(TPB) k_entry_list(uint32_t nS, const uint32_t *__restrict__ pbr /* = cstate: only the bridge bit is read */,
 						     const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ckey,
 						     const uint32_t *__restrict__ cproc, uint32_t *__restrict__ entry_list,
 						     uint32_t *__restrict__ n_entry)
 {
-	// The entries go straight onto the list the walks start from: every wave counts its own (four sides a lane, a prefix
-	// over the lanes) and takes its stretch with ONE atomic add.  Waves are dispatched in grid order, so the list stays in
-	// side order up to the waves in flight -- all the walks want of it (neighbouring lanes on neighbouring classes); its
-	// exact order shows nowhere in the result.  Until round 5: a flag byte per side, written and then read twice by a
-	// count / scan / write compaction (four launches).
-	const uint32_t S0 = (BIDX * blockDim.x + threadIdx.x) * 4u, lane = threadIdx.x & 63u;
-	uint32_t fw = 0; // bit j: side S0 + j is an entry -- a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
-	if (S0 + 4 <= nS) {
-		const uint4 pb = *reinterpret_cast<const uint4 *>(pbr + S0);
-		const uint32_t mu = *reinterpret_cast<const uint32_t *>(multi + S0);
-		const uint2 ck = *reinterpret_cast<const uint2 *>(ckey + (S0 >> 1));
-		const uint32_t c0 = cproc[ck.x] ? 1u : 0u, c1 = cproc[ck.y] ? 1u : 0u;
-		fw = (((mu & 0xFFu) && (pb.x & PB_BRIDGE)) ? c0 : 0u) | ((((mu & 0xFF00u) && (pb.y & PB_BRIDGE)) ? c0 : 0u) << 1) |
-		     ((((mu & 0xFF0000u) && (pb.z & PB_BRIDGE)) ? c1 : 0u) << 2) | ((((mu & 0xFF000000u) && (pb.w & PB_BRIDGE)) ? c1 : 0u) << 3);
-	} else {
-		for (uint32_t S = S0; S < nS; S++)
-			fw |= ((multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1u : 0u) << (S - S0);
+	// The entries go straight onto the list the walks start from.  A workgroup looks at EL_SIDES consecutive sides (four a
+	// lane and round, the flags of all rounds kept in two registers), adds its counts up and takes its stretch of the list
+	// with ONE atomic add: atomic adds on one word retire at ~90 M/s on this chip (measured: one per wave of 256 sides made
+	// this kernel 8.9 ms), so they are kept to one per 16 384 sides.  Workgroups are dispatched in grid order: the list stays
+	// in side order up to the workgroups in flight and the interleaving of a workgroup's rounds -- all the walks want of it
+	// (neighbouring lanes on neighbouring classes); its exact order shows nowhere in the result.  Until round 5: a flag byte
+	// per side, written and then read twice by a count / scan / write compaction (four launches).
+	const uint32_t B0 = BIDX * EL_SIDES, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	unsigned long long fw = 0; // bit 4 it + j: side B0 + it * 1024 + 4 tid + j is an entry -- a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
+#pragma unroll
+	for (uint32_t it = 0; it < EL_ITER; it++) {
+		const uint32_t S0 = B0 + it * (TPB * 4u) + threadIdx.x * 4u;
+		uint32_t f = 0;
+		if (S0 + 4 <= nS) {
+			const uint4 pb = *reinterpret_cast<const uint4 *>(pbr + S0);
+			const uint32_t mu = *reinterpret_cast<const uint32_t *>(multi + S0);
+			const uint2 ck = *reinterpret_cast<const uint2 *>(ckey + (S0 >> 1));
+			const uint32_t c0 = cproc[ck.x] ? 1u : 0u, c1 = cproc[ck.y] ? 1u : 0u;
+			f = (((mu & 0xFFu) && (pb.x & PB_BRIDGE)) ? c0 : 0u) | ((((mu & 0xFF00u) && (pb.y & PB_BRIDGE)) ? c0 : 0u) << 1) |
+			    ((((mu & 0xFF0000u) && (pb.z & PB_BRIDGE)) ? c1 : 0u) << 2) | ((((mu & 0xFF000000u) && (pb.w & PB_BRIDGE)) ? c1 : 0u) << 3);
+		} else {
+			for (uint32_t S = S0; S < nS; S++)
+				f |= ((multi[S] && (pbr[S] & PB_BRIDGE) && cproc[ckey[S >> 1]]) ? 1u : 0u) << (S - S0);
+		}
+		fw |= (unsigned long long)f << (4 * it);
 	}
-	const uint32_t cnt = (uint32_t)__popc(fw);
+	// this lane's entries sit together in the list: prefix over the lanes of the workgroup
+	const uint32_t cnt = (uint32_t)__popcll(fw);
 	uint32_t inc = cnt;
 	for (int off = 1; off < 64; off <<= 1) {
 		const uint32_t y = __shfl_up(inc, off);
 		if ((int)lane >= off)
 			inc += y;
 	}
-	const uint32_t total = __shfl(inc, 63);
-	if (!total)
-		return;
-	uint32_t base = 0;
+	__shared__ uint32_t wsum[TPB / 64], base;
 	if (lane == 63)
-		base = atomicAdd(n_entry, total);
-	base = __shfl(base, 63);
-	uint32_t at = base + inc - cnt;
+		wsum[wave] = inc;
+	__syncthreads();
+	uint32_t before = 0, all = 0;
+	for (uint32_t w = 0; w < TPB / 64; w++) {
+		if (w < wave)
+			before += wsum[w];
+		all += wsum[w];
+	}
+	if (threadIdx.x == 0)
+		base = all ? atomicAdd(n_entry, all) : 0u;
+	__syncthreads();
+	uint32_t at = base + before + inc - cnt;
 	while (fw) {
-		const int k = __ffs((int)fw) - 1;
+		const int k = __ffsll((long long)fw) - 1;
 		fw &= fw - 1;
-		entry_list[at++] = S0 + (uint32_t)k;
+		entry_list[at++] = B0 + (uint32_t)(k >> 2) * (TPB * 4u) + threadIdx.x * 4u + (uint32_t)(k & 3);
 	}
 }
 
@@ -1464,7 +1480,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
 			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx,
 			    uint32_t C, uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0,
-			    uint32_t *__restrict__ mpre, uint32_t *__restrict__ srccnt)
+			    uint32_t *__restrict__ mpre, uint32_t *__restrict__ srccnt, uint32_t *__restrict__ sdl)
 {
 	// The class stage works on the tree in T-space (component c owns [2 voff[c] + c, 2 voff[c+1] + c]) and reads, per tree
 	// vertex: t_size (0 marks a slot without a vertex), t_par (NIL = root), mpre = mirror pre-order (children visited in
@@ -1542,6 +1558,17 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 		store2_unaligned(t_depth + t, depth_e + hd, depth_e + 1 + hd);
 	store2_unaligned(mpre + t, tb + (depth_e + hd) + (Nh + hd) - l - size_e, tb + (depth_e + 1 + hd) + (Nh + hd) - (l + 1) - size_o);
 	*reinterpret_cast<uint2 *>(side_tidx + 2 * g) = (e & 1u) ? make_uint2(t + 1, t) : make_uint2(t, t + 1);
+	// Row E's difference array (k_shift_delta, par_kernels.hip), while both sizes are in registers: under a branching entered
+	// side the black child's subtree goes behind the gray ones in the candidate stack (tree_utils.cpp:47-76).  In units of
+	// black vertices, over the segment slots of pre-order: this segment is slot v0 + pre_e / 2 (cleared by the caller).
+	if (sdl) {
+		const uint32_t gray = (size_e - 1 - size_o) / 2, black = (size_o + 1) / 2, gs = v0 + pre_e / 2;
+		if (gray) {
+			atomicAdd(&sdl[gs], gray);			   // the black subtree moves behind the gray ones
+			atomicAdd(&sdl[gs + black], 0u - gray - black); // the gray subtrees move forward by the black one's entries
+			atomicAdd(&sdl[gs + size_e / 2], black);
+		}
+	}
 }
 // back edges of from_bd out of side S, in scan order (process_edge, spanning_tree.cpp:360-398):
 //  - a side without links points back at the root unless the root is its tree parent (:433-438)
@@ -1554,7 +1581,10 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 // sides again (now from cache) and writes them.  The dense list is in no particular order -- nothing downstream needs one:
 // a bracket's place in its list follows from its source and b_ord, its rank among the ordinary edges of that source
 // (bottom first; k_bracket_place turns it round).
-static constexpr uint32_t BE_ITER = 8, BE_SIDES = TPB * BE_ITER;
+#ifndef POVU_BE_ITER
+#define POVU_BE_ITER 8
+#endif
+static constexpr uint32_t BE_ITER = POVU_BE_ITER, BE_SIDES = TPB * BE_ITER;
 template <bool EMIT>
 __device__ __forceinline__ uint32_t side_back_edges(uint32_t S, uint32_t p, uint32_t at,
 						    const uint32_t *__restrict__ loff, const uint32_t *__restrict__ ladj,
@@ -1952,7 +1982,7 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	// ---- 5-6. entries and the per-class DFS
 	tm.begin("tree_class_dfs");
 	uint32_t *n_entry_dev = pw.err + 9; // (cleared with the other counters at the start of the pass)
-	KLAUNCH(k_entry_list, dim3(nblk((nS + 3) / 4)), dim3(TPB), 0, s, nS, cstate, multi, cs.ckey, tw.cproc, tw.entry_list, n_entry_dev);
+	KLAUNCH(k_entry_list, dim3((nS + EL_SIDES - 1) / EL_SIDES), dim3(TPB), 0, s, nS, cstate, multi, cs.ckey, tw.cproc, tw.entry_list, n_entry_dev);
 	// Small classes are walked by the plain walk, one lane each.  A lane that finds its class larger than CLASS_BUDGET sides
 	// gives up and reports the entry; those classes are then walked from the start by the walk with the short dependent
 	// chain, at the price of a filtering pass over the adjacency (it marks visits in its own bytes and rewrites the same
@@ -2009,8 +2039,11 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
+	HIP_CHECK(hipMemsetAsync(pw.sdl, 0, ((size_t)V + 2) * 4, s));
 	LAUNCH(k_tree_emit, std::max(V, C), s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
-	       sw.t_par, sw.t_size, (sw.hairpins || sw.want_depth) ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt);
+	       sw.t_par, sw.t_size, (sw.hairpins || sw.want_depth) ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt,
+	       pw.sdl);
+	pw.sdl_filled = true;
 	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags

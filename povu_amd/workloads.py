@@ -186,6 +186,28 @@ def hprc_shaped(backbone_sizes, seed: int = 20260612, tiny: int = 0) -> Links:
                np.concatenate(s2_all))
 
 
+def hprc_circular(n_backbone: int, seed: int = 20260612) -> Links:
+    """One HPRC-shaped component closed into a ring (the last backbone segment links back to the first): no side is left
+    without a link, so the component has NO tip -- from_bd starts at (l, vertex 0) without a dummy root and gives that root a
+    back edge to itself (spanning_tree.cpp:433-438).  The shape of a circular chromosome / plasmid / mitochondrial genome."""
+    g = hprc_shaped([n_backbone], seed=seed)
+    last = g.n_vtx - 1
+    return _mk(g.vid, np.concatenate([g.v1, [last]]), np.concatenate([g.s1, np.array([R], dtype=np.uint8)]),
+               np.concatenate([g.v2, [0]]), np.concatenate([g.s2, np.array([L], dtype=np.uint8)]))
+
+
+def hub_on_chain(k_units: int = 100000, hub_links: int = 200000, seed: int = 1) -> Links:
+    """A chain of bubbles with ONE hub segment: `hub_links` links from the r side of segment 0 to the l sides of segments drawn
+    uniformly from the chain (repeats included): one side with 2 * 10^5 links, one 2-edge-connected class that holds most of
+    the graph.  Nothing like a pangenome; the shape that finds quadratic corners."""
+    base = chain_of_bubbles(k_units)
+    rng = np.random.default_rng(seed)
+    hv2 = rng.integers(1, base.n_vtx, size=hub_links)
+    return _mk(base.vid, np.concatenate([base.v1, np.zeros(hub_links, dtype=np.int64)]),
+               np.concatenate([base.s1, np.full(hub_links, R, dtype=np.uint8)]), np.concatenate([base.v2, hv2]),
+               np.concatenate([base.s2, np.full(hub_links, L, dtype=np.uint8)]))
+
+
 # chr1..22, X, Y lengths in Mbp: the relative sizes of the 24 large components of a whole-genome pangenome
 CHR_MBP = (248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57)
 
