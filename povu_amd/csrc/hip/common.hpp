@@ -266,6 +266,96 @@ void scan_exclusive_xor_u128(const ulonglong2 *in, ulonglong2 *out, size_t n, vo
 size_t scan_tmp_bytes(size_t n);
 // indices of the non-zero bytes of flag[0..n), ascending, into out; their number into *count_dev (device memory).  No
 // prefix array is written: tiles are counted, the counts scanned, the tiles ranked again.
+// ---- bit-rank directory: one 16-byte record per 64 flags = {bits 0..31, bits 32..63, set bits in front of the record, 0}.
+// rank(x) = flags set at positions < x is ONE 16-byte load and a popcount, and a table over 2 * 10^8 flags is 50 MB (it
+// stays in the Infinity Cache) where the byte flags + their 4-byte prefix sums were 1 GB.  The producer writes the bit
+// words (x, y); bitrank_build fills in z (three small launches over n / 64 records).  The array carries one record of
+// slack: rank(n) is asked for.
+__device__ __forceinline__ uint32_t bitrank(const uint4 *__restrict__ rec, uint32_t x)
+{
+	const uint4 r = rec[x >> 6];
+	const unsigned long long bits = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
+	return r.z + (uint32_t)__popcll(bits & ((1ull << (x & 63u)) - 1ull));
+}
+__device__ __forceinline__ bool bitrank_test(const uint4 *__restrict__ rec, uint32_t x)
+{
+	const uint4 r = rec[x >> 6];
+	return (((x & 32u) ? r.y : r.x) >> (x & 31u)) & 1u;
+}
+// spreads the low 16 bits of x to every fourth bit position (bit k -> bit 4 k)
+__device__ __forceinline__ unsigned long long spread4(unsigned long long x)
+{
+	x &= 0xFFFFull;
+	x = (x | (x << 24)) & 0x000000FF000000FFull;
+	x = (x | (x << 12)) & 0x000F000F000F000Full;
+	x = (x | (x << 6)) & 0x0303030303030303ull;
+	x = (x | (x << 3)) & 0x1111111111111111ull;
+	return x;
+}
+// A wave whose lane l holds four flags f (bits 0..3) of the positions 256 w + 4 l + {0..3} writes the four records of its
+// 256 positions (rec = the wave's first record; every lane of the wave calls this)
+__device__ __forceinline__ void bitrank_store_wave(uint4 *__restrict__ rec, uint32_t f, bool in_range)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const unsigned long long m0 = __ballot(f & 1u), m1 = __ballot(f & 2u), m2 = __ballot(f & 4u), m3 = __ballot(f & 8u);
+	if (lane < 4 && in_range) {
+		const unsigned sh = 16u * lane;
+		const unsigned long long w = spread4(m0 >> sh) | (spread4(m1 >> sh) << 1) | (spread4(m2 >> sh) << 2) | (spread4(m3 >> sh) << 3);
+		rec[lane] = make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
+	}
+}
+// fills the z words of `rec` (n_rec records + one closing record whose bits are cleared here); tmp: (n_rec + 2) words + the scan's scratch
+void bitrank_build(uint4 *rec, size_t n_rec, uint32_t *tmp_counts, void *scan_tmp, size_t scan_tmp_bytes, hipStream_t s);
+
+// ---- a workgroup of 256 lanes appends the flagged positions of LIST_ITER rounds x 1024 positions (four a lane and round, bit
+// 4 it + j of `fw`: position B0 + 1024 it + 4 tid + j) to a list, IN POSITION ORDER, with ONE atomic add on the list's
+// length.  Atomic adds on one word retire at ~90 M/s on this chip (one per wave of 256 positions made such a kernel 8.9 ms
+// on 2 * 10^8 positions), so they are kept to one per 16 384 positions.  The order matters for speed, not for results: the
+// kernels that work through these lists want neighbouring lanes on neighbouring positions (a list that interleaved a
+// workgroup's rounds made the class walks 35 % slower).
+static constexpr uint32_t LIST_ITER = 16, LIST_TPB = 256, LIST_SPAN = LIST_TPB * 4 * LIST_ITER;
+__device__ __forceinline__ void append_in_order(unsigned long long fw, uint32_t B0, uint32_t *__restrict__ list, uint32_t *__restrict__ n_list)
+{
+	__shared__ uint32_t tot[LIST_ITER * (LIST_TPB / 64)], base_sh;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+	for (uint32_t it = 0; it < LIST_ITER; it++) {
+		const uint32_t f = (uint32_t)(fw >> (4 * it)) & 15u;
+		const uint32_t t = (uint32_t)(__popcll(__ballot(f & 1u)) + __popcll(__ballot(f & 2u)) + __popcll(__ballot(f & 4u)) + __popcll(__ballot(f & 8u)));
+		if (lane == 0)
+			tot[it * (LIST_TPB / 64) + wave] = t;
+	}
+	__syncthreads();
+	if (threadIdx.x < 64) { // rounds first, waves inside a round: exclusive prefix of the 64 counts, the total to the list
+		const uint32_t v = tot[threadIdx.x];
+		uint32_t inc = v;
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t y = __shfl_up(inc, off);
+			if ((int)lane >= off)
+				inc += y;
+		}
+		tot[threadIdx.x] = inc - v;
+		if (lane == 63)
+			base_sh = inc ? atomicAdd(n_list, inc) : 0u;
+	}
+	__syncthreads();
+	const uint32_t base = base_sh;
+#pragma unroll
+	for (uint32_t it = 0; it < LIST_ITER; it++) {
+		uint32_t f = (uint32_t)(fw >> (4 * it)) & 15u;
+		// (every lane of the wave takes part in the ballots; lanes without a flag of this round only skip the stores)
+		const uint32_t before = (uint32_t)(__popcll(__ballot(f & 1u) & lt) + __popcll(__ballot(f & 2u) & lt) + __popcll(__ballot(f & 4u) & lt) +
+						   __popcll(__ballot(f & 8u) & lt));
+		uint32_t at = base + tot[it * (LIST_TPB / 64) + wave] + before;
+		while (f) {
+			const int k = __ffs((int)f) - 1;
+			f &= f - 1;
+			list[at++] = B0 + it * (LIST_TPB * 4u) + threadIdx.x * 4u + (uint32_t)k;
+		}
+	}
+}
+
 // Up to 8 words of device memory into page-locked host memory by ONE single-lane kernel: a hipMemcpyAsync per word is a
 // copy submission each (3-4 us apiece on the stream; config 2's whole pass is 1.1 ms).  `host_dst` is the HOST pointer of
 // page-locked memory (HostScratch); read it after the stream is synchronised.

@@ -173,7 +173,13 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 // handled from its smaller endpoint; when both ends fall inside the tile it is united there (LDS CAS, no
 // global atomics, no long global pointer chains), otherwise the slot goes onto the cross list -- wave ballot +
 // prefix popcount, one atomic per wave -- and k_uf_cross unites it in global memory afterwards.
-static constexpr uint32_t UF_TILE = 8192, UF_TPB = 1024, UF_HEAVY = 128, UF_HEAVY_CAP = 256;
+#ifndef POVU_UF_TILE
+#define POVU_UF_TILE 8192
+#endif
+#ifndef POVU_UF_TPB
+#define POVU_UF_TPB 1024
+#endif
+static constexpr uint32_t UF_TILE = POVU_UF_TILE, UF_TPB = POVU_UF_TPB, UF_HEAVY = 128, UF_HEAVY_CAP = 256;
 // vertices with more links than this take the radix-sorted adjacency path of the re-index (an insertion sort per side is
 // quadratic in the side's links)
 static constexpr uint32_t SORT_FREE_MAX_VDEG = 48;

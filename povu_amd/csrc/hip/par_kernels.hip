@@ -140,28 +140,26 @@ __global__ void k_hi0(uint32_t NB0, const uint32_t *__restrict__ b_src, const ui
 // bridge(v): no ordinary back edge out of subtree(v) reaches a proper ancestor of v (the bracket list of v would be
 // empty but for simplifying edges): the subtree sum of cov is zero
 // (four vertices a lane, 16-byte loads: see k_entry_list)
-__global__ void k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
-			       const uint32_t *__restrict__ pscov, uint8_t *__restrict__ bridge)
+__global__ void __launch_bounds__(TPB) k_bridge_flags(uint32_t T, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ gpar,
+						       const uint32_t *__restrict__ pscov, uint4 *__restrict__ brec)
 {
+	// the flags go out as BITS, 64 to a record of the bit-rank directory (common.hpp): "how many bridge vertices in front of x"
+	// is then one 16-byte look-up into a 50 MB table -- until round 5 a byte per vertex, scanned into a 4-byte prefix per vertex
 	const uint32_t t0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
-	if (t0 >= T)
-		return;
+	uint32_t f = 0;
 	if (t0 + 4 <= T) {
 		const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), gp = *reinterpret_cast<const uint4 *>(gpar + t0);
 		const uint4 pc = *reinterpret_cast<const uint4 *>(pscov + t0);
-		const uint32_t b0 = (sz.x && gp.x != NIL && pscov[t0 + sz.x] == pc.x) ? 1u : 0u;
-		const uint32_t b1 = (sz.y && gp.y != NIL && pscov[t0 + 1 + sz.y] == pc.y) ? 1u : 0u;
-		const uint32_t b2 = (sz.z && gp.z != NIL && pscov[t0 + 2 + sz.z] == pc.z) ? 1u : 0u;
-		const uint32_t b3 = (sz.w && gp.w != NIL && pscov[t0 + 3 + sz.w] == pc.w) ? 1u : 0u;
-		*reinterpret_cast<uint32_t *>(bridge + t0) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+		f = ((sz.x && gp.x != NIL && pscov[t0 + sz.x] == pc.x) ? 1u : 0u) | ((sz.y && gp.y != NIL && pscov[t0 + 1 + sz.y] == pc.y) ? 2u : 0u) |
+		    ((sz.z && gp.z != NIL && pscov[t0 + 2 + sz.z] == pc.z) ? 4u : 0u) | ((sz.w && gp.w != NIL && pscov[t0 + 3 + sz.w] == pc.w) ? 8u : 0u);
 	} else {
 		for (uint32_t t = t0; t < T; t++) {
 			const uint32_t sz = gsize[t];
-			bridge[t] = (sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1 : 0;
+			f |= ((sz && gpar[t] != NIL && pscov[t + sz] == pscov[t]) ? 1u : 0u) << (t - t0);
 		}
 	}
-	if (t0 + 4 >= T)
-		bridge[T] = 0;
+	const uint32_t w0 = (BIDX * blockDim.x + (threadIdx.x & ~63u)) / 16u; // first record of this wave's 256 vertices
+	bitrank_store_wave(brec + w0, f, w0 + (threadIdx.x & 63u) <= T / 64u);
 }
 // capping back edge v -> hi_2 when hi_2 < hi_0 (flubbles.cpp:555-574, 613-619).  Children of v in
 // ascending idx are v+1, then each next sibling at c + size(c).  hi(c) = min target of the back edges leaving
@@ -189,7 +187,7 @@ struct RootOf {
 	}
 };
 __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ hi0,
-					   const uint32_t *__restrict__ psb, const RootOf &root_of,
+					   const uint4 *__restrict__ brec, const RootOf &root_of,
 					   const SegTree &segA, uint32_t *__restrict__ cap_tgt,
 					   uint8_t *__restrict__ capf, uint32_t *__restrict__ literal_rule_seen)
 {
@@ -197,7 +195,7 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 	uint32_t root = NIL; // of v's tree, looked up at most once
 	auto hi_of = [&](uint32_t c) {
 		const uint32_t cs = max(gsize[c], 1u);
-		if (psb[c + cs] != psb[c]) {
+		if (bitrank(brec, c + cs) != bitrank(brec, c)) { // a bridge vertex in subtree(c): a simplifying edge sits at or below it
 			if (root == NIL)
 				root = root_of(v);
 			return root;
@@ -247,14 +245,16 @@ __device__ __forceinline__ void capping_of(uint32_t v, const uint32_t *__restric
 // The sweep over a branching vertex's children is a chain of dependent gathers (child, its size, the flags behind its
 // subtree, the next child ...): it runs in a kernel of its own over the compacted list of branching vertices, every lane
 // busy with one of them -- inside this kernel the few lanes that had work left the rest of their workgroup waiting.
-static constexpr uint32_t HS_ITER = 16, HS_VERTS = TPB * 4 * HS_ITER; // vertices a workgroup of k_hi_simp takes: one atomic add for 16 384 of them
-__global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint8_t *__restrict__ bridge,
-						  const uint32_t *__restrict__ psb, uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
+static constexpr uint32_t HS_ITER = LIST_ITER, HS_VERTS = LIST_SPAN; // vertices a workgroup of k_hi_simp takes: one atomic add for 16 384 of them
+static_assert(TPB == (int)LIST_TPB, "append_in_order is written for workgroups of 256");
+__global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__restrict__ gsize, const uint4 *__restrict__ brec,
+						  uint8_t *__restrict__ simp, uint8_t *__restrict__ hpf,
 						  uint8_t *__restrict__ capf, uint32_t *__restrict__ br_list, uint32_t *__restrict__ n_br)
 {
-	const uint32_t B0 = BIDX * HS_VERTS, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t B0 = BIDX * HS_VERTS;
+	// p0 = bridge vertices in front of t: simplifying iff t is the only one of its subtree
 	auto one = [&](uint32_t t, uint32_t sz, uint32_t br, uint32_t p0, uint32_t sz_next, uint32_t &sm, uint32_t &bch) {
-		sm = (sz && br && psb[t + sz] - p0 == 1) ? 1u : 0u;
+		sm = (sz && br && bitrank(brec, t + sz) - p0 == 1) ? 1u : 0u;
 		bch = (sz > 2 && t + 1 + max(sz_next, 1u) < t + sz) ? 1u : 0u; // the first child does not fill the subtree
 	};
 	unsigned long long bw = 0; // bit 4 it + j: vertex B0 + it * 1024 + 4 tid + j branches
@@ -263,13 +263,19 @@ __global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__r
 		const uint32_t t0 = B0 + it * (TPB * 4u) + threadIdx.x * 4u; // (four vertices a lane, 16-byte loads: see k_entry_list)
 		uint32_t b4 = 0;
 		if (t0 + 4 < T) { // (strictly: the last of the four looks at its successor's size)
-			const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0), p = *reinterpret_cast<const uint4 *>(psb + t0);
-			const uint32_t sz4 = gsize[t0 + 4], br = *reinterpret_cast<const uint32_t *>(bridge + t0);
+			const uint4 sz = *reinterpret_cast<const uint4 *>(gsize + t0);
+			const uint32_t sz4 = gsize[t0 + 4];
+			// the four flags and the count in front of them out of one record (t0 is a multiple of four: one record holds all four)
+			const uint4 r = brec[t0 >> 6];
+			const unsigned long long bits = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
+			const uint32_t br = (uint32_t)(bits >> (t0 & 63u)) & 15u;
+			const uint32_t p0 = r.z + (uint32_t)__popcll(bits & ((1ull << (t0 & 63u)) - 1ull));
+			const uint32_t p1 = p0 + (br & 1u), p2 = p1 + ((br >> 1) & 1u), p3 = p2 + ((br >> 2) & 1u);
 			uint32_t s0, s1, s2, s3, c0, c1, c2, c3;
-			one(t0, sz.x, br & 0xFFu, p.x, sz.y, s0, c0);
-			one(t0 + 1, sz.y, br & 0xFF00u, p.y, sz.z, s1, c1);
-			one(t0 + 2, sz.z, br & 0xFF0000u, p.z, sz.w, s2, c2);
-			one(t0 + 3, sz.w, br & 0xFF000000u, p.w, sz4, s3, c3);
+			one(t0, sz.x, br & 1u, p0, sz.y, s0, c0);
+			one(t0 + 1, sz.y, br & 2u, p1, sz.z, s1, c1);
+			one(t0 + 2, sz.z, br & 4u, p2, sz.w, s2, c2);
+			one(t0 + 3, sz.w, br & 8u, p3, sz4, s3, c3);
 			const uint32_t sw = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
 			*reinterpret_cast<uint32_t *>(simp + t0) = sw;
 			if (hpf)
@@ -279,7 +285,7 @@ __global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__r
 		} else {
 			for (uint32_t t = t0; t < T; t++) {
 				uint32_t sm, bch;
-				one(t, gsize[t], bridge[t], psb[t], gsize[t + 1], sm, bch);
+				one(t, gsize[t], bitrank_test(brec, t) ? 1u : 0u, bitrank(brec, t), gsize[t + 1], sm, bch);
 				simp[t] = (uint8_t)sm;
 				if (t == T - 1)
 					simp[T] = 0;
@@ -291,42 +297,16 @@ __global__ void __launch_bounds__(TPB) k_hi_simp(uint32_t T, const uint32_t *__r
 		}
 		bw |= (unsigned long long)b4 << (4 * it);
 	}
-	// the branching vertices go straight onto the list k_capping works through: one atomic add per workgroup, as
-	// k_entry_list does (the order of the list shows nowhere: every vertex on it is decided on its own)
-	const uint32_t cnt = (uint32_t)__popcll(bw);
-	uint32_t inc = cnt;
-	for (int off = 1; off < 64; off <<= 1) {
-		const uint32_t y = __shfl_up(inc, off);
-		if ((int)lane >= off)
-			inc += y;
-	}
-	__shared__ uint32_t wsum[TPB / 64], base;
-	if (lane == 63)
-		wsum[wave] = inc;
-	__syncthreads();
-	uint32_t before = 0, all = 0;
-	for (uint32_t w = 0; w < TPB / 64; w++) {
-		if (w < wave)
-			before += wsum[w];
-		all += wsum[w];
-	}
-	if (threadIdx.x == 0)
-		base = all ? atomicAdd(n_br, all) : 0u;
-	__syncthreads();
-	uint32_t at = base + before + inc - cnt;
-	while (bw) {
-		const int k = __ffsll((long long)bw) - 1;
-		bw &= bw - 1;
-		br_list[at++] = B0 + (uint32_t)(k >> 2) * (TPB * 4u) + threadIdx.x * 4u + (uint32_t)(k & 3);
-	}
+	// the branching vertices go straight onto the list k_capping works through, in vertex order (append_in_order, common.hpp)
+	append_in_order(bw, B0, br_list, n_br);
 }
 __global__ void k_capping(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const uint32_t *__restrict__ gsize,
-			  const uint32_t *__restrict__ hi0, const uint32_t *__restrict__ psb, const RootOf root_of, const SegTree segA,
+			  const uint32_t *__restrict__ hi0, const uint4 *__restrict__ brec, const RootOf root_of, const SegTree segA,
 			  uint32_t *__restrict__ cap_tgt, uint8_t *__restrict__ capf, uint32_t *__restrict__ literal_rule_seen)
 {
 	const uint32_t n = *n_list; // (the count only exists on the device: grid-stride)
 	for (uint32_t i = BIDX * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-		capping_of(list[i], gsize, hi0, psb, root_of, segA, cap_tgt, capf, literal_rule_seen);
+		capping_of(list[i], gsize, hi0, brec, root_of, segA, cap_tgt, capf, literal_rule_seen);
 }
 // Bracket list order = (mirror pre-order of the source) and, inside one source, the later pushed
 // first: simplifying, capping, ordinary edges by descending creation idx (flubbles.cpp:608-643).
@@ -1297,19 +1277,23 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	if (dense_nb0 < 0)
 		LAUNCH(k_hi0, NB0, s, NB0, pw.b_src, pw.b_tgt, pw.hi0, pw.cov, nullptr);
 	seg_build(pw.segA, pw.hi0, T, s);
-	uint8_t *bridge = pw.f8a, *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
-	uint32_t *psb = pw.psA, *pssimp = pw.psB, *pscap = pw.psC;
+	uint8_t *simp = pw.f8b, *capf = pw.f8c; // [T+1] flags, one byte each
+	uint32_t *pssimp = pw.psB, *pscap = pw.psC;
+	// bridge flags: a bit-rank directory (common.hpp) over T + 1 positions in psA's space: (T / 64 + 2) records of 16 bytes
+	// = T / 4 + 32 bytes, the counts its build scans in f8a's ((T / 64 + 2) words)
+	uint4 *brec = reinterpret_cast<uint4 *>(pw.psA);
+	uint32_t *brec_cnt = reinterpret_cast<uint32_t *>(pw.f8a);
 	uint32_t *pscov = pw.psB; // (free until the simplifying flags are scanned)
 	if (dense_nb0 >= 0) // back edges leaving a vertex (counted by the tree stage) minus those arriving (counted by k_hi0)
 		scan_exclusive_diff_u32(pw.lsz, pw.incnt, pscov, (size_t)T + 1, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	else
 		scan(pw.cov, pscov, (size_t)T + 1);
-	LAUNCH(k_bridge_flags, (T + 3) / 4, s, T, pw.gsize, pw.gpar, pscov, bridge);
-	scan8(bridge, psb, (size_t)T + 1);
+	KLAUNCH(k_bridge_flags, dim3(nblk(((size_t)T / 256 + 1) * 64)), dim3(TPB), 0, s, T, pw.gsize, pw.gpar, pscov, brec); // (whole waves: every record of [0, T] is written)
+	bitrank_build(brec, (size_t)T / 64 + 1, brec_cnt, pw.scan_tmp, pw.scan_tmp_bytes, s);
 	uint32_t *br_list = pw.vals_t, *n_br = pw.err + 10; // (the sort's value buffer is free until the class pass; the count was cleared with the other counters)
-	KLAUNCH(k_hi_simp, dim3((unsigned)(((size_t)T + HS_VERTS - 1) / HS_VERTS)), dim3(TPB), 0, s, T, pw.gsize, bridge, psb, simp, want_hp ? pw.hpf : nullptr, capf, br_list,
+	KLAUNCH(k_hi_simp, dim3((unsigned)(((size_t)T + HS_VERTS - 1) / HS_VERTS)), dim3(TPB), 0, s, T, pw.gsize, brec, simp, want_hp ? pw.hpf : nullptr, capf, br_list,
 		n_br);
-	KLAUNCH(k_capping, dim3(std::min<unsigned>(nblk(T / 8 + 1), 16384)), dim3(TPB), 0, s, n_br, br_list, pw.gsize, pw.hi0, psb, root_of,
+	KLAUNCH(k_capping, dim3(std::min<unsigned>(nblk(T / 8 + 1), 16384)), dim3(TPB), 0, s, n_br, br_list, pw.gsize, pw.hi0, brec, root_of,
 		pw.segA, pw.cap_tgt, capf, pw.err + 5);
 	// capping / simplifying vertices per tile of k_bracket_extra, scanned: [ntiles + 1] each, the totals in the last word
 	const uint32_t ntiles = (T + BX_TILE - 1) / BX_TILE;

@@ -498,6 +498,33 @@ __global__ void __launch_bounds__(CP_TPB) k_cp_write(const uint8_t *__restrict__
 		out[at++] = (uint32_t)(e0 + k);
 	}
 }
+__global__ void k_bitrank_counts(uint32_t W, uint4 *__restrict__ rec, uint32_t *__restrict__ cnt)
+{
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w > W)
+		return;
+	if (w == W) { // the closing record: rank(n) reads it
+		rec[W] = make_uint4(0u, 0u, 0u, 0u);
+		cnt[W] = 0;
+		return;
+	}
+	const uint4 r = rec[w];
+	cnt[w] = (uint32_t)(__popc(r.x) + __popc(r.y));
+}
+__global__ void k_bitrank_ranks(uint32_t W, const uint32_t *__restrict__ ps, uint4 *__restrict__ rec)
+{
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w <= W)
+		rec[w].z = ps[w];
+}
+void bitrank_build(uint4 *rec, size_t n_rec, uint32_t *tmp_counts, void *scan_tmp, size_t scan_tmp_bytes, hipStream_t s)
+{
+	const uint32_t W = (uint32_t)n_rec;
+	const unsigned blocks = (unsigned)((n_rec + 1 + 255) / 256);
+	KLAUNCH(k_bitrank_counts, dim3(blocks), dim3(256), 0, s, W, rec, tmp_counts);
+	scan_exclusive_u32(tmp_counts, tmp_counts, n_rec + 1, scan_tmp, scan_tmp_bytes, s);
+	KLAUNCH(k_bitrank_ranks, dim3(blocks), dim3(256), 0, s, W, tmp_counts, rec);
+}
 __global__ void k_publish_words(WordSrc src, int n, uint32_t *__restrict__ dst)
 {
 	if (threadIdx.x < (unsigned)n)

@@ -821,20 +821,17 @@ __global__ void k_bridges(uint32_t V, const uint4 *__restrict__ t0seg, const ulo
 // is alone in its class has nothing to walk: the walks start from the entries that share their class (multi)
 // (four sides a lane: one 16-byte, one 4-byte and one 8-byte load instead of twelve 4- and 1-byte ones -- a kernel of a few
 // loads per element is bound by the number of memory instructions its CU can retire, not by their bytes)
-static constexpr uint32_t EL_ITER = 16, EL_SIDES = TPB * 4 * EL_ITER; // sides a workgroup of k_entry_list lists: one atomic add for 16 384 of them
+static constexpr uint32_t EL_ITER = LIST_ITER, EL_SIDES = LIST_SPAN; // sides a workgroup of k_entry_list lists: one atomic add for 16 384 of them
+static_assert(TPB == (int)LIST_TPB, "append_in_order is written for workgroups of 256");
 __global__ void __launch_bounds__(TPB) k_entry_list(uint32_t nS, const uint32_t *__restrict__ pbr /* = cstate: only the bridge bit is read */,
 						     const uint8_t *__restrict__ multi, const uint32_t *__restrict__ ckey,
 						     const uint32_t *__restrict__ cproc, uint32_t *__restrict__ entry_list,
 						     uint32_t *__restrict__ n_entry)
 {
-	// The entries go straight onto the list the walks start from.  A workgroup looks at EL_SIDES consecutive sides (four a
-	// lane and round, the flags of all rounds kept in two registers), adds its counts up and takes its stretch of the list
-	// with ONE atomic add: atomic adds on one word retire at ~90 M/s on this chip (measured: one per wave of 256 sides made
-	// this kernel 8.9 ms), so they are kept to one per 16 384 sides.  Workgroups are dispatched in grid order: the list stays
-	// in side order up to the workgroups in flight and the interleaving of a workgroup's rounds -- all the walks want of it
-	// (neighbouring lanes on neighbouring classes); its exact order shows nowhere in the result.  Until round 5: a flag byte
-	// per side, written and then read twice by a count / scan / write compaction (four launches).
-	const uint32_t B0 = BIDX * EL_SIDES, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	// The entries go straight onto the list the walks start from, in side order (append_in_order, common.hpp: one atomic add
+	// per workgroup of 16 384 sides).  Until round 5: a flag byte per side, written and then read twice by a count / scan /
+	// write compaction (four launches).
+	const uint32_t B0 = BIDX * EL_SIDES;
 	unsigned long long fw = 0; // bit 4 it + j: side B0 + it * 1024 + 4 tid + j is an entry -- a root (NIL: all bits set) or the lower end of a bridge, in a component that is decomposed here
 #pragma unroll
 	for (uint32_t it = 0; it < EL_ITER; it++) {
@@ -853,33 +850,7 @@ __global__ void __launch_bounds__(TPB) k_entry_list(uint32_t nS, const uint32_t 
 		}
 		fw |= (unsigned long long)f << (4 * it);
 	}
-	// this lane's entries sit together in the list: prefix over the lanes of the workgroup
-	const uint32_t cnt = (uint32_t)__popcll(fw);
-	uint32_t inc = cnt;
-	for (int off = 1; off < 64; off <<= 1) {
-		const uint32_t y = __shfl_up(inc, off);
-		if ((int)lane >= off)
-			inc += y;
-	}
-	__shared__ uint32_t wsum[TPB / 64], base;
-	if (lane == 63)
-		wsum[wave] = inc;
-	__syncthreads();
-	uint32_t before = 0, all = 0;
-	for (uint32_t w = 0; w < TPB / 64; w++) {
-		if (w < wave)
-			before += wsum[w];
-		all += wsum[w];
-	}
-	if (threadIdx.x == 0)
-		base = all ? atomicAdd(n_entry, all) : 0u;
-	__syncthreads();
-	uint32_t at = base + before + inc - cnt;
-	while (fw) {
-		const int k = __ffsll((long long)fw) - 1;
-		fw &= fw - 1;
-		entry_list[at++] = B0 + (uint32_t)(k >> 2) * (TPB * 4u) + threadIdx.x * 4u + (uint32_t)(k & 3);
-	}
+	append_in_order(fw, B0, entry_list, n_entry);
 }
 
 // ------------------------------------------------------------------ 6. the DFS inside every class
@@ -1000,18 +971,46 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(const uint32_t *__restri
 				k = slot + 1;
 				// (loads of the next step before the stores of this one: vmcnt counts both in issue order,
 				// and a wait for a load behind a store waits for the store too)
-				const uint32_t nlo = loff[o], nhi = loff[o + 1];
+				// BLACK FOLLOW-THROUGH: a step over a link is nearly always followed by the step over the black edge of the
+				// segment it arrives at (slot 0 of the new side).  The list bounds of both sides of that segment are three
+				// consecutive words and their state words two: fetched together on arrival, and when the partner turns out
+				// unvisited both tree edges are made here -- three dependent round trips for the pair where one edge at a
+				// time took six, and the partner's state word is not gathered again with the candidates.
+				const uint32_t g2 = o & ~1u, odd = o & 1u;
+				uint32_t l0, l1, l2 = 0, wp = CS_VISITED;
+				if (slot == 0) { // came over the black edge: the partner is u, visited
+					l0 = loff[o], l1 = loff[o + 1];
+				} else {
+					l0 = loff[g2], l1 = loff[g2 + 1], l2 = loff[g2 + 2];
+					const uint2 cs2 = *reinterpret_cast<const uint2 *>(cstate + g2);
+					wp = odd ? cs2.x : cs2.y;
+				}
+				const uint32_t nlo = (slot == 0 || !odd) ? l0 : l1, nhi = (slot == 0) ? l1 : (odd ? l2 : l1);
 				cstate[o] = w | CS_VISITED;
 				dps[o] = make_uint2(u, slot);
 				if (depth < DFS_STK)
 					stk[depth][lane] = make_uint4(u, k, lo, n);
 				depth++;
-				u = o;
-				k = 0;
-				lo = nlo;
-				n = nhi - nlo;
-				adv = true;
 				sides++;
+				// (the black neighbour of the new side is known to be visited from here on: its scan starts at slot 1)
+				if (!(wp & CS_VISITED)) { // an unvisited partner is in this class (across a bridge it would be an entry: marked)
+					const uint32_t p = o ^ 1u, plo = odd ? l0 : l1, phi = odd ? l1 : l2;
+					cstate[p] = wp | CS_VISITED;
+					dps[p] = make_uint2(o, 0u);
+					if (depth < DFS_STK)
+						stk[depth][lane] = make_uint4(o, 1u, nlo, nhi - nlo);
+					depth++;
+					sides++;
+					u = p;
+					lo = plo;
+					n = phi - plo;
+				} else {
+					u = o;
+					lo = nlo;
+					n = nhi - nlo;
+				}
+				k = 1;
+				adv = true;
 				break;
 			}
 			if (adv) {
@@ -1104,6 +1103,15 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		r = urec_lane(a, b, 0);
 	}
 	uint32_t j0 = 0;
+	// BLACK FOLLOW-THROUGH.  In the biedged graph nearly every step over a link is followed by the step over the black edge of the
+	// segment it arrives at: the partner side c ^ 1 is the FIRST candidate of c's list.  The records of c and c ^ 1 share a
+	// 64-byte line (and their parent words 8 bytes), so the step that looks at a candidate fetches its partner's words with
+	// it; when the walk then moves to c and the partner is unvisited, the black step is taken straight from these registers --
+	// two tree edges per dependent round trip instead of one (the tangled workload walks one class of 6 * 10^5 sides at one
+	// Infinity-Cache round trip a step; BASELINE config 5 is bound by the instructions a step issues: half the steps).
+	bool have_pn = false; // pn / pn_vis hold the record and the parent word of u ^ 1, as of the step that led to u
+	uint32_t pn_vis = 0;
+	URec pn{};
 	uint32_t depth = 0, lds_lo = 0, n_chunks = 0; // stack entries; first entry cached in LDS; chunks taken from the pool
 	uint32_t win_lo = 0xFFFFFF00u; // (no window yet: no side id comes within W_WIN of this)
 	bool have_win = false;
@@ -1137,7 +1145,78 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 #define WCYC(acc)
 #define WSTAT_DONE()
 #endif
+	bool pool_ok = true;
+	// remembers (side, first candidate index still to look at) on the stack
+	auto push = [&](uint32_t side, uint32_t jn) {
+		const uint32_t d = depth;
+		if (d - lds_lo == 64) {
+			// the cache is full: its older half moves out to the HBM array, 32 entries in one store instruction (a
+			// stack that never holds more than 64 entries -- every small class -- never touches the pool); every entry
+			// finds its own chunk, the 32 may straddle two
+			const uint32_t ev = lds_lo;
+			if (ev + 32 > (n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : 0u)) { // the array grows into a new chunk (>= 64 entries: one is enough)
+				uint32_t base = 0;
+				if (lane == 0) {
+					const uint32_t sz = n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : W_CHUNK0;
+					base = atomicAdd(pool_top, sz);
+					if (base + sz > pool_cap || n_chunks >= 31) {
+						atomicExch(err, 1u);
+						base = NIL;
+					}
+					chunk_base[n_chunks] = base;
+				}
+				base = sgpr(base);
+				if (base == NIL) {
+					pool_ok = false; // (cannot happen: see the pool's size; the host stops the pass on err)
+					return;
+				}
+				n_chunks++;
+			}
+			__syncthreads(); // (one wave: lane 0 wrote the entries and the chunk table the other lanes now read)
+			if (lane < 32)
+				wstk[wstk_addr(ev + lane, chunk_base)] = ring[(ev + lane) & 63u];
+			lds_lo = ev + 32;
+		}
+		if (lane == 0)
+			ring[d & 63u] = make_uint2(side, jn);
+		depth = d + 1;
+	};
+	// the parent word of a side the walk just reached: into the window (and into memory when the window moves on), or
+	// straight into memory; true when it went into the window
+	auto set_parent = [&](uint32_t side, uint32_t par) {
+		const uint32_t kk = side - win_lo;
+		if (kk < W_WIN) {
+			if (lane == 0)
+				win_par[kk] = par;
+			if (kk < 64)
+				dirty0 |= 1ull << kk;
+			else
+				dirty1 |= 1ull << (kk - 64);
+			return true;
+		}
+		if (lane == 0)
+			wpar[side] = par;
+		return false;
+	};
 	for (;;) {
+		if (have_pn) {
+			have_pn = false;
+			if (j0 == 0 && r.n && r.c0 == (u ^ 1u) && pn_vis == W_UNVIS) {
+				// the black edge is scanned first and its far side is not visited: across it, out of registers.  What stands
+				// behind it in u's list was not looked at: u is remembered as if an unvisited candidate were left.
+				if (r.n > 1) {
+					push(u, 1u);
+					if (!pool_ok)
+						return;
+				}
+				(void)set_parent(u ^ 1u, u);
+				u ^= 1u;
+				r = pn;
+				WSTAT(st_fast);
+				WCYC(cy_fast);
+				continue;
+			}
+		}
 		// ---- look at the candidates [j0, j0 + 64) of u: lane l takes candidate j0 + l -- out of the scalar record when the
 		// list is short (a handful of selects, no memory), else out of the overflow list
 		const uint32_t idx = j0 + lane;
@@ -1157,12 +1236,15 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		}
 		// its visited word AND its record, out of the window: one LDS round trip serves this step and the next
 		const bool inw = cand - win_lo < W_WIN; // (false for NIL and while there is no window: see win_lo)
-		uint32_t vp = 0;
-		uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+		uint32_t vp = 0, vq = 0; // parent words of the candidate and of its segment partner (window: both or neither, it starts on an even side)
+		uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, q0 = c0, q1 = c0;
 		if (inw) {
 			vp = win_par[cand - win_lo];
 			c0 = win_rec[cand - win_lo][0];
 			c1 = win_rec[cand - win_lo][1];
+			vq = win_par[(cand ^ 1u) - win_lo];
+			q0 = win_rec[(cand ^ 1u) - win_lo][0];
+			q1 = win_rec[(cand ^ 1u) - win_lo][1];
 		}
 		// When the first unvisited candidate the window knows of has no candidate OUTSIDE the window in front of it, it is the
 		// child -- decided from LDS alone, no load is even issued.  (Whether an unvisited candidate follows it is then not known
@@ -1172,10 +1254,13 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		const bool fast = unv_in && !(miss & ((unv_in & (0ull - unv_in)) - 1ull));
 		unsigned long long m = unv_in;
 		if (!fast && miss) { // the candidates outside the window: visited word and record in one round trip to memory
-			if (cand != NIL && !inw) {
+			if (cand != NIL && !inw) { // (the partner's words sit in the same lines)
 				vp = wpar[cand];
 				c0 = wrec[2 * (size_t)cand];
 				c1 = wrec[2 * (size_t)cand + 1];
+				vq = wpar[cand ^ 1u];
+				q0 = wrec[2 * (size_t)(cand ^ 1u)];
+				q1 = wrec[2 * (size_t)(cand ^ 1u) + 1];
 			}
 			m = __ballot(cand != NIL && vp == W_UNVIS);
 		}
@@ -1190,49 +1275,19 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			const bool child_in = (unv_in >> f) & 1ull; // its words are in the window
 			// another unvisited candidate behind the chosen one (a second slot of the same side counts: harmless)?
 			if ((m & (m - 1)) || beyond || (fast && (miss >> f))) {
-				const uint32_t d = depth;
-				if (d - lds_lo == 64) {
-					// the cache is full: its older half moves out to the HBM array, 32 entries in one store instruction (a
-					// stack that never holds more than 64 entries -- every small class -- never touches the pool); every entry
-					// finds its own chunk, the 32 may straddle two
-					const uint32_t ev = lds_lo;
-					if (ev + 32 > (n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : 0u)) { // the array grows into a new chunk (>= 64 entries: one is enough)
-						uint32_t base = 0;
-						if (lane == 0) {
-							const uint32_t sz = n_chunks ? (W_CHUNK0 << (n_chunks - 1)) : W_CHUNK0;
-							base = atomicAdd(pool_top, sz);
-							if (base + sz > pool_cap || n_chunks >= 31) {
-								atomicExch(err, 1u);
-								base = NIL;
-							}
-							chunk_base[n_chunks] = base;
-						}
-						base = sgpr(base);
-						if (base == NIL)
-							return; // (cannot happen: see the pool's size; the host stops the pass on err)
-						n_chunks++;
-					}
-					__syncthreads(); // (one wave: lane 0 wrote the entries and the chunk table the other lanes now read)
-					if (lane < 32)
-						wstk[wstk_addr(ev + lane, chunk_base)] = ring[(ev + lane) & 63u];
-					lds_lo = ev + 32;
-				}
-				if (lane == 0)
-					ring[d & 63u] = make_uint2(u, j0 + (uint32_t)f + 1u);
-				depth = d + 1;
+				push(u, j0 + (uint32_t)f + 1u);
+				if (!pool_ok)
+					return;
 			}
 			const uint32_t child_par = u;
 			u = child;
 			j0 = 0;
 			r = urec_lane(c0, c1, f); // (the chosen lane holds the child's record: out of the window or out of memory)
+			pn = urec_lane(q0, q1, f); // ... and its segment partner's, for the black step that usually follows
+			pn_vis = lane_val(vq, f);
+			have_pn = true;
 			if (child_in) { // the parent word: into the window now, into memory when the window moves on
-				const uint32_t k = child - win_lo;
-				if (lane == 0)
-					win_par[k] = child_par;
-				if (k < 64)
-					dirty0 |= 1ull << k;
-				else
-					dirty1 |= 1ull << (k - 64);
+				(void)set_parent(child, child_par);
 				win_hits++;
 				WCYC(cy_fast);
 				continue;
@@ -1259,7 +1314,7 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			// current: some were never written to memory), the others out of memory -- where every word this wave ever wrote
 			// outside a window, or flushed out of an earlier one, has long arrived (a wave's stores and loads of one address
 			// stay in order; an agent-scope fence here cost 50 us a refill: it writes the L2 back).
-			const uint32_t new_lo = child > W_WIN_BACK ? child - W_WIN_BACK : 0u;
+			const uint32_t new_lo = (child > W_WIN_BACK ? child - W_WIN_BACK : 0u) & ~1u; // (even: a side and its segment partner are in the window together)
 			uint32_t keep[W_WIN / 64];
 #pragma unroll
 			for (uint32_t q = 0; q < W_WIN / 64; q++) {
@@ -1358,6 +1413,7 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			u = lane_val(eu, l);
 			j0 = lane_val(ej, l);
 			r = urec_lane(e0, e1, l);
+			have_pn = false;
 			if (lds_lo > depth)
 				lds_lo = depth;
 			found = true;
