@@ -888,7 +888,7 @@ void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s)
 
 bool sort_free_adjacency(const ResidentGraph &g, bool force_sorted_adjacency) { return g.max_vdeg <= SORT_FREE_MAX_VDEG && !force_sorted_adjacency; }
 
-uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
+uint32_t *label_components_enqueue(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
 {
 	const uint32_t V = g.V, E = g.E;
 	tm.begin("wcc_label");
@@ -911,15 +911,33 @@ uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm,
 	tm.end(7);
 	uint32_t *h = st.host->take<uint32_t>(3); // component count, the order flag and the self-loop flag in one round trip
 	publish_words(h, WordSrc{{st.crank + V, st.stats + 9, any_loop}}, 3, s);
-	HIP_CHECK(hipStreamSynchronize(s));
+	return h; // (valid once the stream -- or an event recorded now -- has completed: label_components_finish)
+}
+uint32_t label_components_finish(CompState &st, const uint32_t *h)
+{
 	st.comp_sorted = h[1] == 0;
 	st.has_self_loops = h[2] != 0;
 	return h[0];
 }
+uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s)
+{
+	const uint32_t *h = label_components_enqueue(g, st, tm, s);
+	HIP_CHECK(hipStreamSynchronize(s));
+	return label_components_finish(st, h);
+}
+
+// the re-index's adjacency kernel in the form it takes on a graph whose vertices are grouped by component, without hubs and
+// self loops -- started by povu_hip_decompose BEFORE the labelling's answer has reached the host (see there)
+void reindex_speculative_adj(const ResidentGraph &g, const CompState &st, uint32_t *ladj, uint32_t *lle, hipStream_t s)
+{
+	const size_t nS = 2 * (size_t)g.V;
+	KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, g.V, (const uint32_t *)nullptr, (const uint32_t *)nullptr, g.off, g.aoth, g.atwin,
+		(const uint32_t *)nullptr, g.off, st.hook, ladj, lle, false);
+}
 
 
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
-			bool force_sorted_adjacency)
+			bool force_sorted_adjacency, bool adj_done)
 {
 	const uint32_t V = g.V, E = g.E;
 	const size_t nS = 2 * (size_t)V;
@@ -964,7 +982,8 @@ void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, Stage
 			KLAUNCH(k_local_degree, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, ldeg8, st.stats);
 			scan_exclusive_u8(ldeg8, st.loff, nS + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 		}
-		KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, g.atwin, sbase,
+		if (!(adj_done && st.lean_identity && !st.has_self_loops)) // (adj_done: reindex_speculative_adj wrote exactly this into ladj / lle)
+			KLAUNCH(k_local_adj, dim3(nblk(nS)), dim3(TPB), 0, s, V, perm, pos_or_identity, g.off, g.aoth, g.atwin, sbase,
 				   st.loff, st.hook, st.ladj, st.lle, st.has_self_loops);
 		KLAUNCH(k_comp_edge_offsets, dim3(nblk((size_t)C + 1)), dim3(TPB), 0, s, C, st.voff, st.loff, st.eoff, st.stats,
 				   st.host_pub);

@@ -61,8 +61,14 @@ void mark_odd_u32(uint32_t *p, size_t n, hipStream_t s); // p[i] = 1 for odd i (
 // an unknown vertex or side (validated on the device).
 void build_global_csr(ResidentGraph &g, Arena &tmp_arena, hipStream_t s);
 uint32_t label_components(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
+// the same in two halves: everything queued, the answer (count, order flag, self-loop flag) published into page-locked memory
+// by the last kernel -- read by _finish once the stream (or an event recorded behind _enqueue) has completed
+uint32_t *label_components_enqueue(const ResidentGraph &g, CompState &st, StageTimer &tm, hipStream_t s);
+uint32_t label_components_finish(CompState &st, const uint32_t *h);
+void reindex_speculative_adj(const ResidentGraph &g, const CompState &st, uint32_t *ladj, uint32_t *lle, hipStream_t s);
+// adj_done: reindex_speculative_adj already filled st.ladj / st.lle (only honoured when this graph's re-index has that form)
 void reindex_components(const ResidentGraph &g, CompState &st, uint32_t C, StageTimer &tm, hipStream_t s,
-			bool force_sorted_adjacency = false);
+			bool force_sorted_adjacency = false, bool adj_done = false);
 // which builder the re-index will take for this graph (known from the upload: most links on one vertex)
 bool sort_free_adjacency(const ResidentGraph &g, bool force_sorted_adjacency);
 

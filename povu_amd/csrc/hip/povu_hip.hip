@@ -146,6 +146,7 @@ extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.fork2, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->tail_done, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->host_wait, hipEventDisableTiming));
 		ctx->timer.stream = ctx->stream;
 		return ctx.release();
 	} catch (const std::exception &e) {
@@ -189,6 +190,8 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 		(void)hipEventDestroy(ctx->side.fork2);
 	if (ctx->tail_done)
 		(void)hipEventDestroy(ctx->tail_done);
+	if (ctx->host_wait)
+		(void)hipEventDestroy(ctx->host_wait);
 	delete ctx;
 }
 
@@ -439,6 +442,9 @@ size_t rowb_carve_label(Arena *ar, const Sizes &z, CompState &cs)
 	return total + (1 << 16);
 }
 
+// what the re-index arena must hold already for the adjacency kernel to be started ahead of the component count
+size_t rowb_speculative_adj_bytes(const Sizes &z) { return 2 * (Arena::padded(2 * z.E + 8, 4) + 256) + 4096; }
+
 size_t rowb_carve_reindex(Arena *ar, const Sizes &z, size_t C, const RowBNeeds &need, CompState &cs)
 {
 	size_t total = 0;
@@ -451,11 +457,13 @@ size_t rowb_carve_reindex(Arena *ar, const Sizes &z, size_t C, const RowBNeeds &
 	};
 	const size_t V = z.V, E = z.E, nS = z.nS;
 	const bool lean = need.identity && need.sort_free; // sorted space = global vertex space, nothing is renumbered
+	// (ladj and lle FIRST: their place in the arena does not depend on the component count -- povu_hip_decompose starts the
+	// kernel that fills them before the count has reached the host, rowb_speculative_adj_bytes)
+	take(&cs.ladj, 2 * E + 8, 4); // (+8: the class walk reads a side's list words four at a time)
+	take(&cs.lle, 2 * E + 8, 4);  // (+8: the tour kernel reads a segment's slot words four at a time)
 	take(&cs.voff, C + 2, 4);
 	take(&cs.eoff, C + 2, 4);
 	take(&cs.start_key, C + 2, 8);
-	take(&cs.ladj, 2 * E + 8, 4); // (+8: the class walk reads a side's list words four at a time)
-	take(&cs.lle, 2 * E + 8, 4);  // (+8: the tour kernel reads a segment's slot words four at a time)
 	if (!lean) { // the vertices are renumbered (or the sorting builder wants the tables anyway)
 		take(&cs.tmp_a, V + 1, 4);
 		take(&cs.ckey, V + 1, 4);
@@ -779,20 +787,45 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		HIP_CHECK(hipEventRecord(f->ev0, s));
 
 		// ---- row B
-		const uint32_t C = label_components(g, cs, tm, s);
+		// The host has to know the component count (it sizes the workspaces) and then the components' sizes (the tables of the
+		// stages): two reads.  Neither is waited for with the stream idle: the words are published by a kernel, an EVENT is
+		// recorded behind it, and the stream is given its next kernel before the host waits for the event --
+		//  (1) behind the labelling: the re-index's adjacency kernel, on the assumption that holds for nearly every GFA (vertices
+		//      grouped by component, no hub, no self loop: it then needs nothing the labels say but the hooks; when the
+		//      assumption fails its output is simply overwritten by the real re-index);
+		//  (2) behind the re-index: the tree stage's first kernel (it reads the re-indexed adjacency only).
+		// Not with stage timers (the kernels would be booked on the wrong stage).
+		const bool force_sorted = (o.flags & POVU_HIP_F_SORTED_ADJ) != 0;
+		const bool par_tree = !all_seq && !(o.flags & POVU_HIP_F_SEQ_TREE);
+		uint32_t *lab = label_components_enqueue(g, cs, tm, s);
+		HIP_CHECK(hipEventRecord(ctx->host_wait, s));
+		bool spec_adj = false;
+		if (!tm.enabled && g.E && sort_free_adjacency(g, force_sorted) && ctx->ws_b.capacity() >= rowb_speculative_adj_bytes(z)) {
+			ctx->ws_b.reserve(0); // (rewinds the arena: the two arrays get the places rowb_carve_reindex will give them)
+			uint32_t *ladj = ctx->ws_b.take<uint32_t>(2 * z.E + 8), *lle = ctx->ws_b.take<uint32_t>(2 * z.E + 8);
+			reindex_speculative_adj(g, cs, ladj, lle, s);
+			spec_adj = true;
+		}
+		HIP_CHECK(hipEventSynchronize(ctx->host_wait));
+		const uint32_t C = label_components_finish(cs, lab);
 		{ // what the re-index of THIS graph needs, now that the count, the order and the self loops are known
-			const bool force_sorted = (o.flags & POVU_HIP_F_SORTED_ADJ) != 0;
 			const RowBNeeds need{C == 1 || cs.comp_sorted, sort_free_adjacency(g, force_sorted), cs.has_self_loops};
-			reserve(ctx->ws_b, rowb_carve_reindex(nullptr, z, C, need, cs));
+			const size_t need_b = rowb_carve_reindex(nullptr, z, C, need, cs);
+			if (spec_adj && need_b > ctx->ws_b.capacity()) { // the arena has to grow under a kernel that writes into it: let it finish, forget it
+				HIP_CHECK(hipStreamSynchronize(s));
+				spec_adj = false;
+			}
+			reserve(ctx->ws_b, need_b);
 			rowb_carve_reindex(&ctx->ws_b, z, C, need, cs);
+			spec_adj = spec_adj && need.identity && need.sort_free && !need.self_loops; // (else: a kernel that wrote nonsense into arrays about to be rewritten)
 		}
 		// component sizes on the host (shard assignment = LPT over link counts, launch order): the last
 		// re-index kernel writes them into pinned memory itself
 		uint32_t *pub = ctx->host.take<uint32_t>(2 * ((size_t)C + 1) + 4);
 		HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&cs.host_pub), pub, 0));
 		count_kernel_d2h((2 * ((size_t)C + 1) + 4) * 4);
-		reindex_components(g, cs, C, tm, s, (o.flags & POVU_HIP_F_SORTED_ADJ) != 0);
-		HIP_CHECK(hipStreamSynchronize(s));
+		reindex_components(g, cs, C, tm, s, force_sorted, spec_adj);
+		HIP_CHECK(hipEventRecord(ctx->host_wait, s));
 		const uint32_t *voff = pub, *eoff = pub + (size_t)C + 1, *gstats = pub + 2 * ((size_t)C + 1);
 		// stage workspaces, sized with the real component count
 		z.Cmax = C;
@@ -801,10 +834,21 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		const StageWsOpts so = stage_opts(z.V, z.E, C, g.n_empty_sides, (o.flags & POVU_HIP_F_SEQ_TREE) != 0, hairpins);
 		reserve(ctx->ws2, carve_workspace(nullptr, 1, z, cs, sw, hairpins) + (all_seq ? 0 : stage_workspace_bytes(z.V, z.E, C, so)));
 		carve_workspace(&ctx->ws2, 1, z, cs, sw, hairpins);
+		bool tail_waited = false;
 		if (!all_seq) {
 			stage_workspace_carve(ctx->ws2, ctx->pw, ctx->tw, z.V, z.E, C, so);
 			ctx->tw.walk_arena = &ctx->ws_walk;
+			ctx->tw.tour_words_done = false;
+			if (par_tree && !tm.enabled) {
+				if (ctx->tail_pending) { // first write into the stage workspace: behind the tail of the pass before
+					HIP_CHECK(hipStreamWaitEvent(s, ctx->tail_done, 0));
+					tail_waited = true;
+				}
+				cs.host = ctx->pw.host = ctx->tw.host = &ctx->host;
+				tree_tour_words(cs, (uint32_t)z.V, (uint32_t)z.E, ctx->tw, (o.flags & POVU_HIP_F_SPARSE_SPLITTERS) != 0, s);
+			}
 		}
+		HIP_CHECK(hipEventSynchronize(ctx->host_wait)); // the component sizes are in `pub`
 		bool seq_ws_ready = false;
 		auto need_seq_workspace = [&]() { // the one-lane kernels' lists live in their own arena
 			if (seq_ws_ready)
@@ -857,7 +901,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		}
 		stack_off[C] = n_stack;
 		const uint32_t n_processed = pc[C];
-		if (ctx->tail_pending) // first write into the stage workspace: behind the tail of the pass before (see above)
+		if (ctx->tail_pending && !tail_waited) // first write into the stage workspace: behind the tail of the pass before (see above)
 			HIP_CHECK(hipStreamWaitEvent(s, ctx->tail_done, 0));
 		HIP_CHECK(copy_async(sw.tables, tab_h, 5 * ((size_t)C + 1) * 4, hipMemcpyHostToDevice, s));
 
@@ -1208,8 +1252,10 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			if (leaf_sub)
 				fetch_seq_sub(all, f->sub_ai, f->sub_zi, f->sub_fam, total);
 		}
-		if (leaf_sub)
-			ctx->ws_leaf.release(); // (not part of the workspace a plain decompose keeps warm)
+		if (!leaf_sub)
+			ctx->ws_leaf.release(); // (kept from one -s pass to the next, like the inserting passes' arena below: a hipMalloc of
+						// several GB right after the hipFree of the pass before stalled for over a second once; a
+						// pass without the leaf passes gives it back)
 		if (!all_sub)
 			ctx->ws_sub.release(); // (the inserting passes keep their tables' arena from one -s pass to the next, no longer)
 		// stage times

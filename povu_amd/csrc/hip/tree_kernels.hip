@@ -1136,7 +1136,7 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 	} while (0)
 #define WSTAT_DONE()                                                                                                          \
 	do {                                                                                                                  \
-		if (lane == 0 && blockIdx.x < 2)                                                                              \
+		if (lane == 0 && (blockIdx.x < 2 || st_fast + st_slow > 50000u))                                              \
 			printf("walk %u: fast %u slow %u refills %u pops %u cycles %lld = fast %lld slow %lld refill %lld pop %lld\n", blockIdx.x, st_fast, st_slow, st_refill, st_pop, \
 			       clock64() - st_t0, cy_fast, cy_slow, cy_refill, cy_pop);                                          \
 	} while (0)
@@ -1992,6 +1992,19 @@ void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E,
 }
 
 // ------------------------------------------------------------------ driver
+void tree_tour_words(const CompState &cs, uint32_t V, uint32_t E, TreeWs &tw, bool force_sparse_splitters, hipStream_t s)
+{
+	const uint32_t nS = 2 * V;
+	const size_t n_slots = 2 * (size_t)E;
+	if (n_slots >= P0_END || 3 * (size_t)V >= P0_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
+		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^30");
+	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
+	ulonglong2 *hside = reinterpret_cast<ulonglong2 *>(tw.evt); // [nS] 16-byte words (evt, [max(4V, 2E)] 8-byte words, is free until the second ranking)
+	uint32_t *ft = tw.be_cnt;				    // [nS] (free until the back edges are counted)
+	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, tw.rk_pk, bitsA, hside, ft);
+	tw.tour_words_done = true;
+}
+
 int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw, uint32_t C, uint32_t event_lists,
 			   uint32_t max_side_links, bool force_big_class_dfs, bool force_sparse_splitters, StageTimer &tm,
 			   hipStream_t s)
@@ -2007,9 +2020,9 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	const unsigned bitsA = force_sparse_splitters ? 4u : rank_bucket_bits(n_slots);
 	ulonglong2 *hside = reinterpret_cast<ulonglong2 *>(tw.evt); // [nS] 16-byte words (evt, [max(4V, 2E)] 8-byte words, is free until the second ranking)
 	uint32_t *ft = tw.be_cnt;						    // [nS] (free until the back edges are counted)
-	if (n_slots >= P0_END || 3 * (size_t)V >= P0_END) // (the first ranking runs over the 2E slots, the second over 3 V events)
-		throw HipError("graph too large for the packed list ranking: 2 * links and 3 * segments must stay below 2^30");
-	LAUNCH(k_tour_words, nS, s, nS, cs.loff, cs.ladj, cs.lle, rb.pk, bitsA, hside, ft);
+	if (!tw.tour_words_done) // (else: started by povu_hip_decompose while the host still waited for the component sizes)
+		tree_tour_words(cs, V, E, tw, force_sparse_splitters, s);
+	tw.tour_words_done = false;
 	LAUNCH(k_tour_ends, C, s, C, cs.voff, start_key, cs.loff, cs.ladj, cs.lle, rb.pk, rb.heads);
 	if (n_slots)
 		list_rank_splitters<false>((uint32_t)n_slots, bitsA, tw.dist, nullptr, C, rb, s);
@@ -2055,8 +2068,11 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
 			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
 		uint32_t *n_over = pw.err + 4, *over_list = tw.entry_ps; // (a spare array of the entries' size)
+		uint32_t budget = CLASS_BUDGET;
+		if (const char *ev = getenv("POVU_HIP_CLASS_BUDGET")) // (tuning hook: sides a lane walks before it hands its class to the wave walk)
+			budget = (uint32_t)std::max(16, atoi(ev));
 		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry_dev, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps,
-			CLASS_BUDGET, n_over, over_list);
+			budget, n_over, over_list);
 		n_big = tw.host->read_u32(n_over, s);
 		big_list = over_list;
 	}

@@ -32,6 +32,7 @@ struct TreeWs {
 	uint2 *evt;					  // [4V+2] event ranks {enter count, depth} of the pre-order ranking
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
 	const uint8_t *last_dupflag;			  // dvis_slots when the last pass filled it, else null
+	bool tour_words_done = false;			  // tree_tour_words ran for this pass already (started ahead of the host's wait for the component sizes)
 	Arena *walk_arena = nullptr;			  // where the wave walk's arrays are taken from when the pass needs them and they are not inside the stage block
 	bool walk_inline = true;
 };
@@ -44,6 +45,10 @@ size_t stage_workspace_bytes(size_t V, size_t E, size_t Cmax, const StageWsOpts 
 void stage_workspace_carve(Arena &ar, ParWs &pw, TreeWs &tw, size_t V, size_t E, size_t Cmax, const StageWsOpts &o = StageWsOpts{});
 // the wave walk's arrays (records of all sides, stack pool, parents): only a pass with large 2-edge-connected classes needs them
 size_t walk_workspace_bytes(size_t V);
+
+// the tree stage's first kernel (Euler-tour words of the spanning forest): it reads the re-indexed adjacency only, so
+// povu_hip_decompose may start it before the host has the component sizes; run_parallel_tree then skips it
+void tree_tour_words(const CompState &cs, uint32_t V, uint32_t E, TreeWs &tw, bool force_sparse_splitters, hipStream_t s);
 
 // Builds the reference's spanning tree of every processed component (tree arrays in sw, T-space
 // layout) and the dense list of from_bd back edges (pw.b_src / pw.b_tgt).  Returns their count.

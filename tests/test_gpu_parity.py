@@ -98,6 +98,28 @@ def test_overlapped_passes_are_bit_exact(hip, golden_dir):
     assert a  # (anchors loaded: keeps the fixture dir in use)
 
 
+def test_kernels_started_ahead_of_the_hosts_reads(hip):
+    """Without stage timers povu_hip_decompose gives the stream its next kernel BEFORE it waits for the words it needs from the
+    device: the re-index's adjacency kernel ahead of the component count (on the assumption: vertices grouped by component, no
+    hub, no self loop), the tree stage's first kernel ahead of the component sizes.  Graphs that keep the assumption and graphs
+    that break it in every way, each twice on a warm context (the early start needs the arena of the pass before) and once
+    with timers: all equal the oracle."""
+    from povu_amd.hip import F_NO_STAGE_TIMES
+    base = W.hprc_shaped([4000, 1500, 300], seed=5, tiny=20)
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(base.n_vtx)  # the components interleaved in vertex order: the re-index has to renumber
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(base.n_vtx)
+    mixed = W._mk(base.vid[perm], inv[base.v1], base.s1, inv[base.v2], base.s2)
+    graphs = [base, W.random_bidirected(3000, 5200, 41, self_loops=True), mixed, W.hub_on_chain(2000, 3000),
+              W.chain_of_bubbles(5000), W.random_bidirected(2500, 2600, 43, self_loops=False), base]
+    for g in graphs:
+        want = O.decompose(g)
+        hip.upload(g)
+        for fl in (F_NO_STAGE_TIMES, F_NO_STAGE_TIMES, 0):
+            assert hip.decompose(flags=fl).texts() == want
+
+
 def test_lpa_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))
     g = _load_gfa_links(os.path.join(golden_dir, "gfa", "LPA.gfa"))
