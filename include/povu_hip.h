@@ -252,6 +252,12 @@ int povu_hip_multi_times(const povu_hip_multi *m, double out_ms[6]);
 /* "none" (one rank), "rccl", "peer-copy" (hipMemcpyPeerAsync; also the fallback when RCCL cannot be initialised: the
  * reason is appended) or "same-device" */
 const char *povu_hip_multi_transport(const povu_hip_multi *m);
+/* the context of worker `rank` (NULL when out of range): for the debug exports of the pass povu_hip_multi_decompose just ran --
+ * call them from the sink callback (it runs on the worker's own thread, the only one that may use the context then) */
+povu_hip_ctx *povu_hip_multi_context(povu_hip_multi *m, uint32_t rank);
+/* a context that holds a shard: ids[k] = id (1-based, of the whole graph) of the shard's k-th component, the rank the debug
+ * exports and the sidecar of --structure-export address a component by.  0 on success, 1 when the resident graph is no shard. */
+int povu_hip_shard_component_ids(const povu_hip_ctx *ctx, const uint32_t **ids, uint32_t *n);
 
 /* Completes a forest of a POVU_HIP_F_ASYNC decompose (no-op otherwise): returns when its arrays are in host memory. */
 int povu_hip_forest_wait(povu_hip_forest *f);

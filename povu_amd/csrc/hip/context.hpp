@@ -159,6 +159,8 @@ struct povu_hip_forest {
 		for (hipEvent_t e : more_events)
 			(void)hipEventDestroy(e);
 		release_block();
+		if (xblk && pool)
+			pool->put(xblk, xblk_cap, xblk_seg);
 		for (auto &b : extra)
 			if (b.p && b.pool)
 				b.pool->put(b.p, b.cap, b.seg);
@@ -180,6 +182,11 @@ struct povu_hip_forest {
 	std::vector<uint32_t> sub_ai, sub_zi;
 	std::vector<uint8_t> sub_fam;
 	std::shared_ptr<SubForest> subx; // with POVU_HIP_F_SUBFLUBBLES: the trees after all five passes of -s
+	// povu_hip_forest_share: a second shared-memory segment with what the five arrays do not hold (labels, hairpin
+	// boundaries, the extended trees of -s), kept alive as long as the forest
+	void *xblk = nullptr;
+	size_t xblk_cap = 0;
+	int xblk_seg = -1;
 };
 
 struct povu_hip_ctx {

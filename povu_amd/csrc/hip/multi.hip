@@ -255,6 +255,7 @@ extern "C" povu_hip_multi *povu_hip_multi_create(const int *devices, uint32_t n,
 }
 
 extern "C" uint32_t povu_hip_multi_world(const povu_hip_multi *m) { return m ? m->world : 0; }
+extern "C" povu_hip_ctx *povu_hip_multi_context(povu_hip_multi *m, uint32_t rank) { return (m && rank < m->world) ? m->w[rank]->ctx : nullptr; }
 extern "C" const char *povu_hip_multi_transport(const povu_hip_multi *m) { return m ? m->transport_name.c_str() : ""; }
 
 extern "C" int povu_hip_multi_upload(povu_hip_multi *m, uint32_t n_vtx, const uint32_t *vid, uint32_t n_links, const uint32_t *v1,

@@ -646,6 +646,15 @@ void adopt_forest(povu_hip_forest &out, povu_hip_forest &m)
 			out.sub_fam.assign(1, 0); // (povu_hip_forest_get_sub: "this forest carries labels"; the arrays are the blocks' own)
 }
 
+extern "C" int povu_hip_shard_component_ids(const povu_hip_ctx *ctx, const uint32_t **ids, uint32_t *n)
+{
+	if (!ctx || !ids || !n || ctx->shard_comp_ids.empty())
+		return 1;
+	*ids = ctx->shard_comp_ids.data();
+	*n = (uint32_t)ctx->shard_comp_ids.size();
+	return 0;
+}
+
 // ---------------------------------------------------------------- gather through shared memory (several processes, one node)
 // Every rank's PVST block already sits in page-locked HOST memory when its decompose returns -- copied there by its own
 // GPU over its own PCIe link.  When that memory is a named shared-memory segment (povu_hip_share_results) the root only
@@ -657,13 +666,52 @@ static constexpr uint64_t SHARE_EMPTY = ~0ull;
 // a forest whose trees sit in several blocks -> one block of its own pool, trees back to back (in place)
 static void compact_in_place(povu_hip_forest &f);
 
+// What the five arrays do not hold -- the leaf passes' labels (ai, zi, line letter per PVST vertex), the hairpin boundaries,
+// the extended trees of `-s` -- travels in a SECOND shared-memory segment of the rank's pool, announced in the header of the
+// tree table (words 3..5: segment, its mapped size, bytes used; ~0 = none).  Sections, each padded to 64 bytes, behind a
+// 128-byte header {magic, PVST vertices, hairpin pairs, flags, components + 1 of the extended trees, their vertices, their
+// child entries, bytes}: [ai][zi] u32 x total, [letter] u8 x total | [pairs] 2 x u64 | [voff] u64, [counts] u32 x 3,
+// [letter][or1][or2][route] u8 x vertices, [id1][id2] u32 x vertices, [coff] u32 x (vertices + 1), [child] u32.
+static constexpr uint64_t SHAREX_MAGIC = 0x7865726168735F76ull; // "v_sharex"
+namespace
+{
+struct XLayout {
+	size_t total = 0, pairs = 0, c1 = 0, nv = 0, nc = 0;
+	bool labels = false, hp = false, sub = false;
+	size_t o_ai = 0, o_zi = 0, o_fam = 0, o_hp = 0, o_voff = 0, o_cnt = 0, o_xfam = 0, o_or1 = 0, o_or2 = 0, o_route = 0, o_id1 = 0, o_id2 = 0,
+	       o_coff = 0, o_child = 0, bytes = 0;
+	void plan()
+	{
+		size_t q = 128;
+		auto sec = [&](size_t b) {
+			const size_t r = q;
+			q += (b + 63) & ~size_t(63);
+			return r;
+		};
+		if (labels)
+			o_ai = sec(total * 4), o_zi = sec(total * 4), o_fam = sec(total);
+		if (hp)
+			o_hp = sec(pairs * 16);
+		if (sub) {
+			o_voff = sec(c1 * 8), o_cnt = sec((c1 ? c1 - 1 : 0) * 12);
+			o_xfam = sec(nv), o_or1 = sec(nv), o_or2 = sec(nv), o_route = sec(nv);
+			o_id1 = sec(nv * 4), o_id2 = sec(nv * 4), o_coff = sec((nv + 1) * 4), o_child = sec(nc * 4);
+		}
+		bytes = q;
+	}
+};
+} // namespace
+
 extern "C" int povu_hip_forest_share(povu_hip_forest *f, uint64_t desc[8])
 {
 	if (!f || !desc)
 		return 1;
 	try {
-		if (!f->hairpins.empty() || !f->sub_fam.empty())
-			return 4; // (like the wire format: boundaries and labels do not travel)
+		const bool has_x = !f->hairpins.empty() || !f->sub_fam.empty() || f->subx;
+		if (has_x && !f->extra.empty())
+			return 4; // (labels / boundaries of a MERGED forest: share the parts; a rank's own forest has no extra blocks)
+		if (has_x)
+			f->ready(); // (the labels were copied by the pass itself; nothing of them is still in flight after this)
 		// (no wait for a POVU_HIP_F_ASYNC forest here: the descriptor and the tree table do not depend on the arrays still in
 		// flight.  The READER must not look at them before this rank has waited for the forest -- povu_hip_forest_wait --
 		// and told it so: in a loop of collectives, by taking part in the next one.)
@@ -692,6 +740,59 @@ extern "C" int povu_hip_forest_share(povu_hip_forest *f, uint64_t desc[8])
 		}
 		uint64_t *mh = reinterpret_cast<uint64_t *>(b + meta_off);
 		mh[0] = SHARE_MAGIC, mh[1] = nt, mh[2] = f->total_entries;
+		mh[3] = ~0ull, mh[4] = mh[5] = 0;
+		if (has_x) {
+			for (size_t i = 0; i < nt; i++) { // hairpin pairs and the component in the extended trees: the table's two spare words
+				meta[8 * i + 6] = f->trees[i].n_hairpins;
+				meta[8 * i + 7] = f->trees[i].sub_c;
+			}
+			XLayout L;
+			L.total = f->total_entries;
+			L.labels = !f->sub_fam.empty();
+			L.hp = !f->hairpins.empty();
+			L.pairs = f->hairpins.size() / 2;
+			const SubForest *x = f->subx.get();
+			L.sub = x != nullptr;
+			if (x)
+				L.c1 = x->voff.size(), L.nv = x->n_vtx, L.nc = x->n_child;
+			if (L.labels && (f->sub_ai.size() < L.total || f->sub_zi.size() < L.total || f->sub_fam.size() < L.total))
+				return 3;
+			L.plan();
+			if (f->xblk)
+				f->pool->put(f->xblk, f->xblk_cap, f->xblk_seg);
+			f->xblk = f->pool->get(L.bytes, f->xblk_cap, &f->xblk_seg);
+			if (f->xblk_seg < 0)
+				return 2;
+			char *xb = static_cast<char *>(f->xblk);
+			uint64_t *h = reinterpret_cast<uint64_t *>(xb);
+			std::fill(h, h + 16, 0ull);
+			h[0] = SHAREX_MAGIC, h[1] = L.total, h[2] = L.pairs, h[3] = (L.labels ? 1u : 0u) | (L.hp ? 2u : 0u) | (L.sub ? 4u : 0u);
+			h[4] = L.c1, h[5] = L.nv, h[6] = L.nc, h[7] = L.bytes;
+			if (L.labels) {
+				memcpy(xb + L.o_ai, f->sub_ai.data(), L.total * 4);
+				memcpy(xb + L.o_zi, f->sub_zi.data(), L.total * 4);
+				memcpy(xb + L.o_fam, f->sub_fam.data(), L.total);
+			}
+			if (L.hp)
+				memcpy(xb + L.o_hp, f->hairpins.data(), L.pairs * 16);
+			if (x) {
+				memcpy(xb + L.o_voff, x->voff.data(), L.c1 * 8);
+				if (L.c1 > 1)
+					memcpy(xb + L.o_cnt, x->counts.data(), (L.c1 - 1) * 12);
+				if (L.nv) {
+					memcpy(xb + L.o_xfam, x->fam, L.nv);
+					memcpy(xb + L.o_or1, x->or1, L.nv);
+					memcpy(xb + L.o_or2, x->or2, L.nv);
+					memcpy(xb + L.o_route, x->route, L.nv);
+					memcpy(xb + L.o_id1, x->id1, L.nv * 4);
+					memcpy(xb + L.o_id2, x->id2, L.nv * 4);
+				}
+				memcpy(xb + L.o_coff, x->coff, (L.nv + 1) * 4);
+				if (L.nc)
+					memcpy(xb + L.o_child, x->child, L.nc * 4);
+			}
+			mh[3] = (uint64_t)f->xblk_seg, mh[4] = f->xblk_cap, mh[5] = L.bytes;
+		}
 		__atomic_thread_fence(__ATOMIC_RELEASE); // (the descriptor leaves through a system call anyway)
 		desc[1] = (uint64_t)f->block_seg;
 		desc[2] = f->block_cap;
@@ -733,25 +834,29 @@ extern "C" povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_f
 			if (nt == 0 || nt > seg_bytes / 32 || total > seg_bytes / 4 || meta_off > seg_bytes ||
 			    meta_off + povu_hip_forest::meta_bytes(nt) > seg_bytes || povu_hip_forest::ExtraBlock::bytes_for(total) - 64 > meta_off)
 				throw HipError("attach: descriptor of rank " + std::to_string(d[7]) + " does not fit its segment");
-			auto it = ctx->attached.find(name);
-			if (it == ctx->attached.end()) {
-				const int fd = shm_open(name.c_str(), O_RDONLY, 0);
-				if (fd < 0)
-					throw HipError("attach: cannot open the result segment " + name);
-				struct stat st;
-				if (fstat(fd, &st) != 0 || (size_t)st.st_size < seg_bytes) {
+			// maps a segment of another rank read-only (mappings are kept by the context: the ranks reuse their segments)
+			auto map_segment = [&](const std::string &nm, size_t bytes) -> const char * {
+				auto it = ctx->attached.find(nm);
+				if (it == ctx->attached.end()) {
+					const int fd = shm_open(nm.c_str(), O_RDONLY, 0);
+					if (fd < 0)
+						throw HipError("attach: cannot open the result segment " + nm);
+					struct stat st;
+					if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {
+						(void)close(fd);
+						throw HipError("attach: the result segment " + nm + " is smaller than its descriptor says");
+					}
+					void *p = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
 					(void)close(fd);
-					throw HipError("attach: the result segment " + name + " is smaller than its descriptor says");
+					if (p == MAP_FAILED)
+						throw HipError("attach: cannot map the result segment " + nm);
+					it = ctx->attached.emplace(nm, povu_hip_ctx::Mapped{p, bytes}).first;
+				} else if (it->second.bytes < bytes) {
+					throw HipError("attach: the result segment " + nm + " changed its size");
 				}
-				void *p = mmap(nullptr, seg_bytes, PROT_READ, MAP_SHARED, fd, 0);
-				(void)close(fd);
-				if (p == MAP_FAILED)
-					throw HipError("attach: cannot map the result segment " + name);
-				it = ctx->attached.emplace(name, povu_hip_ctx::Mapped{p, seg_bytes}).first;
-			} else if (it->second.bytes < seg_bytes) {
-				throw HipError("attach: the result segment " + name + " changed its size");
-			}
-			const char *b = static_cast<const char *>(it->second.p);
+				return static_cast<const char *>(it->second.p);
+			};
+			const char *b = map_segment(name, seg_bytes);
 			const uint64_t *mh = reinterpret_cast<const uint64_t *>(b + meta_off);
 			if (mh[0] != SHARE_MAGIC || mh[1] != nt || mh[2] != total)
 				throw HipError("attach: the tree table of rank " + std::to_string(d[7]) + " does not match its descriptor");
@@ -759,9 +864,52 @@ extern "C" povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_f
 			blk.p = const_cast<char *>(b);
 			blk.cap = seg_bytes;
 			blk.carve(total);
+			// what the five arrays do not hold (povu_hip_forest_share): labels, hairpin boundaries, the extended trees of -s
+			XLayout L;
+			const char *xb = nullptr;
+			if (mh[3] != ~0ull) {
+				const size_t xcap = mh[4], xbytes = mh[5];
+				if (xbytes < 128 || xbytes > xcap)
+					throw HipError("attach: bad extras segment of rank " + std::to_string(d[7]));
+				xb = map_segment(PinnedPool::segment_name(std::string(job_tag) + "." + std::to_string(d[7]), (int)mh[3]), xcap);
+				const uint64_t *h = reinterpret_cast<const uint64_t *>(xb);
+				if (h[0] != SHAREX_MAGIC || h[1] != total || h[7] != xbytes)
+					throw HipError("attach: the extras segment of rank " + std::to_string(d[7]) + " does not match its forest");
+				L.total = total, L.pairs = h[2], L.labels = h[3] & 1u, L.hp = h[3] & 2u, L.sub = h[3] & 4u;
+				L.c1 = h[4], L.nv = h[5], L.nc = h[6];
+				// (numbers from another process: bound them before they size anything)
+				if (L.pairs > xbytes / 16 || L.c1 > xbytes / 8 || L.nv > xbytes || L.nc > xbytes / 4)
+					throw HipError("attach: the extras segment of rank " + std::to_string(d[7]) + " names sizes beyond itself");
+				L.plan();
+				if (L.bytes != xbytes)
+					throw HipError("attach: the extras segment of rank " + std::to_string(d[7]) + " has another layout than its header says");
+				if (L.labels) {
+					blk.sub_ai.assign(reinterpret_cast<const uint32_t *>(xb + L.o_ai), reinterpret_cast<const uint32_t *>(xb + L.o_ai) + total);
+					blk.sub_zi.assign(reinterpret_cast<const uint32_t *>(xb + L.o_zi), reinterpret_cast<const uint32_t *>(xb + L.o_zi) + total);
+					blk.sub_fam.assign(reinterpret_cast<const uint8_t *>(xb + L.o_fam), reinterpret_cast<const uint8_t *>(xb + L.o_fam) + total);
+					if (out->sub_fam.empty())
+						out->sub_fam.assign(1, 0); // (povu_hip_forest_get_sub: "this forest carries labels"; the arrays are the blocks' own)
+				}
+				if (L.sub) { // a view into the mapped segment (no pool, no block of its own: nothing to give back)
+					auto x = std::make_shared<SubForest>();
+					const uint64_t *vo = reinterpret_cast<const uint64_t *>(xb + L.o_voff);
+					x->voff.assign(vo, vo + L.c1);
+					const uint32_t *cn = reinterpret_cast<const uint32_t *>(xb + L.o_cnt);
+					x->counts.assign(cn, cn + (L.c1 ? 3 * (L.c1 - 1) : 0));
+					x->n_vtx = L.nv, x->n_child = L.nc;
+					if (!x->voff.empty() && x->voff.back() != L.nv)
+						throw HipError("attach: the extended trees of rank " + std::to_string(d[7]) + " do not add up");
+					x->fam = reinterpret_cast<const uint8_t *>(xb + L.o_xfam), x->or1 = reinterpret_cast<const uint8_t *>(xb + L.o_or1);
+					x->or2 = reinterpret_cast<const uint8_t *>(xb + L.o_or2), x->route = reinterpret_cast<const uint8_t *>(xb + L.o_route);
+					x->id1 = reinterpret_cast<const uint32_t *>(xb + L.o_id1), x->id2 = reinterpret_cast<const uint32_t *>(xb + L.o_id2);
+					x->coff = reinterpret_cast<const uint32_t *>(xb + L.o_coff), x->child = reinterpret_cast<const uint32_t *>(xb + L.o_child);
+					blk.subx = x;
+				}
+			}
 			const int bi = (int)out->extra.size();
 			out->extra.push_back(blk);
 			const uint32_t *meta = reinterpret_cast<const uint32_t *>(b + meta_off + 64);
+			size_t hp_seen = 0;
 			for (size_t k = 0; k < nt; k++) {
 				const uint32_t *q = meta + 8 * k;
 				povu_hip_forest::Tree t{};
@@ -770,6 +918,20 @@ extern "C" povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_f
 				t.blk = bi;
 				if (t.off > total || t.n_pvst > total - t.off)
 					throw HipError("attach: a tree of rank " + std::to_string(d[7]) + " lies outside its block");
+				if (xb) {
+					t.n_hairpins = L.hp ? q[6] : 0;
+					t.sub_c = q[7];
+					if (L.sub && (size_t)t.sub_c + 1 >= L.c1)
+						throw HipError("attach: a tree of rank " + std::to_string(d[7]) + " names a component its extended trees do not have");
+					if (t.n_hairpins) { // the rank's pairs sit in tree order: they go behind the merged forest's, tree by tree
+						if (hp_seen + t.n_hairpins > L.pairs)
+							throw HipError("attach: the hairpin boundaries of rank " + std::to_string(d[7]) + " do not add up");
+						const uint64_t *hp = reinterpret_cast<const uint64_t *>(xb + L.o_hp) + 2 * hp_seen;
+						t.hp_off = out->hairpins.size() / 2;
+						out->hairpins.insert(out->hairpins.end(), hp, hp + 2 * (size_t)t.n_hairpins);
+						hp_seen += t.n_hairpins;
+					}
+				}
 				out->trees.push_back(t);
 			}
 		}

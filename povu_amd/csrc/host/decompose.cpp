@@ -9,9 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <future>
+#include <fstream>
 #include <iostream>
+#include <map>
+#include <mutex>
+#include <sstream>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace povu_host
@@ -85,10 +90,43 @@ struct MultiSink {
 	const Config *cfg;
 	unsigned threads_per_rank;
 	std::atomic<bool> failed{false};
+	// --structure-export: every worker renders the frames of ITS components (the state they come from lives in its context);
+	// they are written in component order once all workers are done (flubbles.cpp:733: one frame per find_flubbles call)
+	povu_hip_multi *engine = nullptr;
+	std::mutex mu;
+	std::map<uint32_t, std::string> frames; // component id -> frame
 };
-int multi_sink(uint32_t, const povu_hip_forest *f, void *user)
+int multi_sink(uint32_t rank, const povu_hip_forest *f, void *user)
 {
 	MultiSink *s = static_cast<MultiSink *>(user);
+	if (!s->cfg->structure_export.empty()) {
+		try {
+			povu_hip_ctx *ctx = povu_hip_multi_context(s->engine, rank);
+			const uint32_t *ids = nullptr;
+			uint32_t n_ids = 0;
+			const uint32_t n = povu_hip_forest_tree_count(f);
+			if (n && (!ctx || povu_hip_shard_component_ids(ctx, &ids, &n_ids) != 0))
+				throw std::runtime_error("flubble debug sidecar: worker " + std::to_string(rank) + " holds no shard");
+			std::unordered_map<uint32_t, uint32_t> local; // component id of the whole graph -> rank inside the shard
+			for (uint32_t k = 0; k < n_ids; k++)
+				local[ids[k]] = k;
+			for (uint32_t i = 0; i < n; i++) {
+				povu_hip_tree t;
+				povu_hip_forest_get(f, i, &t);
+				const auto it = local.find(t.component_id);
+				if (it == local.end())
+					throw std::runtime_error("flubble debug sidecar: component " + std::to_string(t.component_id) + " is not of worker " + std::to_string(rank));
+				std::ostringstream frame;
+				write_debug_sidecar_frame(frame, ctx, it->second);
+				std::lock_guard<std::mutex> l(s->mu);
+				s->frames[t.component_id] = frame.str();
+			}
+		} catch (const std::exception &e) {
+			std::cerr << "[povu::decompose] " << e.what() << std::endl;
+			s->failed = true;
+			return 1;
+		}
+	}
 	write_forest(f, *s->cfg, s->threads_per_rank, s->failed);
 	return s->failed ? 1 : 0;
 }
@@ -96,8 +134,6 @@ int multi_sink(uint32_t, const povu_hip_forest *f, void *user)
 void do_decompose_multi(const Config &cfg)
 {
 	const int ll = cfg.verbosity;
-	if (!cfg.structure_export.empty())
-		throw std::runtime_error("--structure-export reads the device state of ONE context: run it without --gpus");
 	const double t0 = now_ms();
 	const std::vector<int> devs = multi_devices(cfg.gpus, std::getenv("POVU_HIP_DEVICES"), povu_hip_device_count());
 	char err[512] = {0};
@@ -130,6 +166,7 @@ void do_decompose_multi(const Config &cfg)
 		fail(err);
 	const double t2 = now_ms();
 	MultiSink sink{&cfg, (unsigned)std::max<size_t>(1, (size_t)std::max(1, cfg.threads) / devs.size())};
+	sink.engine = m;
 	const uint32_t flags = (cfg.hairpins ? POVU_HIP_F_HAIRPINS : 0u) | POVU_HIP_F_NO_STAGE_TIMES |
 			       (cfg.leaf_subflubbles ? POVU_HIP_F_LEAF_SUBFLUBBLES : 0u) | (cfg.subflubbles ? POVU_HIP_F_SUBFLUBBLES : 0u);
 	povu_hip_forest *f = povu_hip_multi_decompose(m, flags, multi_sink, &sink, err, sizeof err);
@@ -151,6 +188,17 @@ void do_decompose_multi(const Config &cfg)
 			for (uint32_t k = 0; k < t.n_hairpins; k++)
 				std::cerr << "Boundary: " << t.hairpins[2 * k] << " " << t.hairpins[2 * k + 1] << std::endl;
 		}
+	if (!cfg.structure_export.empty()) { // the frames the workers rendered, in component order (std::map)
+		const std::string sidecar = debug_sidecar_path(cfg.structure_export);
+		std::ofstream out(sidecar, std::ios::app);
+		if (!out.is_open())
+			fail(("could not open flubble debug sidecar: " + sidecar).c_str());
+		for (const auto &kv : sink.frames)
+			out << kv.second;
+		out.flush();
+		if (!out)
+			fail(("could not write flubble debug sidecar: " + sidecar).c_str());
+	}
 	if (std::getenv("POVU_STAGE_COST_TRACE")) {
 		double ms[6] = {0};
 		povu_hip_multi_times(m, ms);

@@ -2,6 +2,7 @@
 // Mirrors povu::subcommands::decompose::do_decompose (app/subcommand/decompose.cpp:94-160) and the
 // decompose-relevant part of core::config (include/povu/common/app.hpp:129-182).
 #pragma once
+#include <iosfwd>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -43,6 +44,8 @@ void do_info(const Config &cfg, bool print_tips);
 std::string debug_sidecar_path(const std::string &structure_export_path);
 void reset_debug_sidecar(const Config &cfg);
 void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t comp_rank);
+// the frame itself (one line of JSON), of component `comp_rank` of the graph or shard the context holds
+void write_debug_sidecar_frame(std::ostream &out, povu_hip_ctx *ctx, uint32_t comp_rank);
 
 // `povu gfa2vcf` (app/subcommand/gfa2vcf.cpp:18-87): decompose into a temporary forest, then run `call` of the
 // povu binary named by POVU_CALL_EXE on it (a child process); `call_args` are handed to it unchanged.

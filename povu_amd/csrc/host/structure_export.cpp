@@ -59,6 +59,18 @@ void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t c
 {
 	if (cfg.structure_export.empty())
 		return;
+	const std::string sidecar = debug_sidecar_path(cfg.structure_export);
+	std::ofstream out(sidecar, std::ios::app);
+	if (!out.is_open())
+		throw std::runtime_error("could not open flubble debug sidecar: " + sidecar);
+	write_debug_sidecar_frame(out, ctx, comp_rank);
+	out.flush();
+	if (!out)
+		throw std::runtime_error("could not write flubble debug sidecar: " + sidecar);
+}
+
+void write_debug_sidecar_frame(std::ostream &out, povu_hip_ctx *ctx, uint32_t comp_rank)
+{
 	uint32_t n_tree = 0, n_stack = 0;
 	if (povu_hip_debug_tree(ctx, comp_rank, &n_tree, nullptr, nullptr, nullptr, nullptr) != 0 ||
 	    povu_hip_debug_stack(ctx, comp_rank, &n_stack, nullptr, nullptr, nullptr) != 0)
@@ -85,10 +97,6 @@ void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t c
 			later[s_cls[i]] = i;
 		}
 	}
-	const std::string sidecar = debug_sidecar_path(cfg.structure_export);
-	std::ofstream out(sidecar, std::ios::app);
-	if (!out.is_open())
-		throw std::runtime_error("could not open flubble debug sidecar: " + sidecar);
 	out << '{';
 	key_str(out, "schema", "povu.flubble-debug.frame.v1");
 	out << ',';
@@ -154,85 +162,110 @@ void append_debug_sidecar_frame(const Config &cfg, povu_hip_ctx *ctx, uint32_t c
 		out << '}';
 	}
 	out << "]}\n";
-	out.flush();
-	if (!out)
-		throw std::runtime_error("could not write flubble debug sidecar: " + sidecar);
 }
 
 // ------------------------------------------------------------------ gfa2vcf
+// `povu gfa2vcf` = decompose into a scratch forest, then `povu call` on it (app/subcommand/gfa2vcf.cpp:18-87).  This build has
+// the first half; the second is an external povu binary (POVU_CALL_EXE) run as a CHILD process on the forest written here.
+// What a user can observe is kept: the scratch forest lives in /tmp/povu_gfa2vcf_XXXXXX and is gone afterwards whatever
+// happened, with -v the same three progress lines go to stderr, a failure prints "<fn> Error: <what>" and exits with
+// EXIT_FAILURE; the child's exit status becomes this process's.
+namespace
+{
+const char *const GFA2VCF_FN = "[povu::subcommands::do_gfa2vcf]";
+
+// the scratch forest directory: made on construction, removed on destruction (also on the way out through std::exit: see fail())
+class ScratchForest
+{
+public:
+	ScratchForest()
+	{
+		char tmpl[] = "/tmp/povu_gfa2vcf_XXXXXX";
+		if (const char *d = mkdtemp(tmpl))
+			path_ = d;
+	}
+	~ScratchForest() { drop(); }
+	ScratchForest(const ScratchForest &) = delete;
+	ScratchForest &operator=(const ScratchForest &) = delete;
+	bool ok() const { return !path_.empty(); }
+	const std::string &path() const { return path_; }
+	void drop()
+	{
+		if (!path_.empty()) {
+			std::error_code ec;
+			fs::remove_all(path_, ec);
+			path_.clear();
+		}
+	}
+
+private:
+	std::string path_;
+};
+
+[[noreturn]] void gfa2vcf_fail(ScratchForest *forest, const std::string &what)
+{
+	if (forest)
+		forest->drop(); // (std::exit runs no destructors of automatic objects)
+	std::cerr << GFA2VCF_FN << " Error: " << what << std::endl;
+	std::exit(EXIT_FAILURE);
+}
+
+// runs argv[0] with the given arguments as a child process and waits for it; the child's exit status (EXIT_FAILURE when it was
+// killed).  A child process, never an exec of this one: the GPU is initialised here.
+int run_child(std::vector<std::string> args)
+{
+	std::vector<char *> argv;
+	for (auto &a : args)
+		argv.push_back(a.data());
+	argv.push_back(nullptr);
+	pid_t pid = 0;
+	if (const int rc = posix_spawnp(&pid, argv[0], nullptr, nullptr, argv.data(), environ))
+		throw std::runtime_error("could not start " + args[0] + ": " + strerror(rc));
+	int ws = 0;
+	while (waitpid(pid, &ws, 0) < 0)
+		if (errno != EINTR)
+			throw std::runtime_error("waitpid failed");
+	return WIFEXITED(ws) ? WEXITSTATUS(ws) : EXIT_FAILURE;
+}
+} // namespace
+
 void do_gfa2vcf(const Config &cfg, const std::vector<std::string> &call_args)
 {
-	const std::string fn_name = "[povu::subcommands::do_gfa2vcf]";
-	const int ll = cfg.verbosity;
 	const char *exe = std::getenv("POVU_CALL_EXE");
-	if (!exe || !*exe) {
-		std::cerr << fn_name
-			  << " Error: variant calling is not part of the MI355X build; set POVU_CALL_EXE to a povu binary that "
-			     "provides `call` (it is run on the forest this build writes)"
-			  << std::endl;
-		std::exit(EXIT_FAILURE);
-	}
-	char temp_template[] = "/tmp/povu_gfa2vcf_XXXXXX";
-	char *temp_dir = mkdtemp(temp_template);
-	if (temp_dir == nullptr) {
-		std::cerr << fn_name << " Error: Could not create temporary directory" << std::endl;
-		std::exit(EXIT_FAILURE);
-	}
-	const std::string temp_dir_str(temp_dir);
-	if (ll > 0)
-		std::cerr << fn_name << " Using temporary directory: " << temp_dir_str << std::endl;
-	if (ll > 0)
-		std::cerr << fn_name << " Step 1: Decomposing graph..." << std::endl;
-	reset_debug_sidecar(cfg);
+	if (!exe || !*exe)
+		gfa2vcf_fail(nullptr, "variant calling is not part of the MI355X build; set POVU_CALL_EXE to a povu binary that "
+				      "provides `call` (it is run on the forest this build writes)");
+	ScratchForest forest;
+	if (!forest.ok())
+		gfa2vcf_fail(nullptr, "Could not create temporary directory");
+	auto say = [&](const std::string &line) {
+		if (cfg.verbosity > 0)
+			std::cerr << GFA2VCF_FN << ' ' << line << std::endl;
+	};
+	say("Using temporary directory: " + forest.path());
 	int status = EXIT_FAILURE;
 	try {
-		Config dc = cfg;
-		dc.output_dir = temp_dir_str;
-		do_decompose(dc);
-		if (ll > 0)
-			std::cerr << fn_name << " Step 2: Calling variants..." << std::endl;
-		std::vector<std::string> av{exe};
-		if (cfg.verbosity) {
-			av.push_back("-v");
-			av.push_back(std::to_string(cfg.verbosity));
-		}
-		av.push_back("-t");
-		av.push_back(std::to_string(cfg.threads));
-		av.push_back("call");
-		av.push_back("-i");
-		av.push_back(cfg.input_gfa);
-		av.push_back("-f");
-		av.push_back(temp_dir_str);
-		if (!cfg.structure_export.empty()) {
-			av.push_back("--structure-export");
-			av.push_back(cfg.structure_export);
-		}
-		for (const auto &a : call_args)
-			av.push_back(a);
-		std::vector<char *> argv;
-		for (auto &a : av)
-			argv.push_back(a.data());
-		argv.push_back(nullptr);
-		pid_t pid = 0;
-		// a child process, never an exec of this one: the GPU is initialised here
-		const int rc = posix_spawnp(&pid, exe, nullptr, nullptr, argv.data(), environ);
-		if (rc != 0)
-			throw std::runtime_error(std::string("could not start ") + exe + ": " + strerror(rc));
-		int ws = 0;
-		while (waitpid(pid, &ws, 0) < 0)
-			if (errno != EINTR)
-				throw std::runtime_error("waitpid failed");
-		status = WIFEXITED(ws) ? WEXITSTATUS(ws) : EXIT_FAILURE;
+		say("Step 1: Decomposing graph...");
+		reset_debug_sidecar(cfg);
+		Config into_forest = cfg;
+		into_forest.output_dir = forest.path();
+		do_decompose(into_forest);
+
+		say("Step 2: Calling variants...");
+		std::vector<std::string> call{exe};
+		if (cfg.verbosity)
+			call.insert(call.end(), {"-v", std::to_string(cfg.verbosity)});
+		call.insert(call.end(), {"-t", std::to_string(cfg.threads), "call", "-i", cfg.input_gfa, "-f", forest.path()});
+		if (!cfg.structure_export.empty())
+			call.insert(call.end(), {"--structure-export", cfg.structure_export});
+		call.insert(call.end(), call_args.begin(), call_args.end());
+		status = run_child(std::move(call));
 	} catch (const std::exception &e) {
-		fs::remove_all(temp_dir_str);
-		std::cerr << fn_name << " Error: " << e.what() << std::endl;
-		std::exit(EXIT_FAILURE);
+		gfa2vcf_fail(&forest, e.what());
 	} catch (...) {
-		fs::remove_all(temp_dir_str);
-		std::cerr << fn_name << " Error: unknown failure" << std::endl;
-		std::exit(EXIT_FAILURE);
+		gfa2vcf_fail(&forest, "unknown failure");
 	}
-	fs::remove_all(temp_dir_str);
+	forest.drop();
 	if (status != 0)
 		std::exit(status);
 }

@@ -386,7 +386,7 @@ class Forest:
         rc = self._lib.povu_hip_forest_share(self._h, d)
         if rc != 0:
             raise RuntimeError({2: "the forest's block is no shared segment: call HipDecomposer.share_results first",
-                                4: "hairpin boundaries / subflubble labels do not travel"}.get(rc, f"forest share failed ({rc})"))
+                                4: "a MERGED forest with hairpin boundaries / subflubble labels cannot be shared: share its parts"}.get(rc, f"forest share failed ({rc})"))
         out = np.array(list(d), dtype=np.uint64)
         out[7] = rank
         return out

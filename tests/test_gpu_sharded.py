@@ -257,6 +257,72 @@ def test_shared_memory_gather_crosses_pcie_once(tmp_path):
     assert all(r["own_entries"] > 0 for per_rank in got["rec"] for r in per_rank)
 
 
+def _shared_extras_worker(rank, world, port, out_path):
+    import json
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    from povu_amd import HipDecomposer
+    from povu_amd.hip import F_HAIRPINS, F_LEAF_SUBFLUBBLES, F_SUBFLUBBLES
+    work = HipDecomposer(0)
+    tag = [f"x{os.getpid()}" if rank == 0 else None]
+    dist.broadcast_object_list(tag, src=0)
+    work.share_results(f"{tag[0]}.{rank}")
+    full = None
+    if rank == 0:
+        full = HipDecomposer(0)
+        full.upload(_graph())
+    res, keep = {}, []
+    for name, flags in (("leaf", F_LEAF_SUBFLUBBLES), ("all", F_SUBFLUBBLES), ("hairpins", F_HAIRPINS), ("plain", 0), ("all2", F_SUBFLUBBLES)):
+        sharded.scatter_over_dist(full, work, rank, world, dev)
+        f = work.decompose_shard(flags=flags)
+        merged = sharded.gather_shared(work, f, rank, world, dev, tag[0])
+        keep.append(f)  # (the root reads this rank's segments in place)
+        if rank == 0:
+            res[name] = {str(k): v for k, v in merged.texts().items()}
+            if name == "hairpins":
+                res["hp"] = {str(merged.tree(i).component_id): merged.tree(i).hairpins.tolist() for i in range(len(merged))}
+            if name.startswith("all"):
+                res[name + "_counts"] = [[merged.subtree(i)[k] for k in ("n_concealed", "n_midi", "n_smothered")] for i in range(len(merged))]
+        dist.barrier()  # the other rank keeps its forest (and its extras segment) until the root has read
+        del merged
+    if rank == 0:
+        json.dump(res, open(out_path, "w"))
+    del keep
+    work.close()
+    if full:
+        full.close()
+    dist.destroy_process_group()
+
+
+def test_shared_memory_gather_carries_labels_boundaries_and_extended_trees(tmp_path):
+    """Two processes (two ranks on the one GPU of the box, gloo for the descriptors): the leaf passes' labels, the hairpin
+    boundaries and the extended trees of all five `-s` passes reach the root through a second shared-memory segment per rank
+    (povu_hip_forest_share / _attach) -- until round 5 they only moved inside one process.  The merged forests write the same
+    PVST text as the oracle (T / O / C / M / S lines included), the boundaries equal a single-GPU pass, and a plain pass between
+    two `-s` passes still works (the segments are reused)."""
+    import json
+    from povu_amd import HipDecomposer
+    from povu_amd.hip import F_HAIRPINS
+    out = str(tmp_path / "extras.json")
+    mp.spawn(_shared_extras_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = json.load(open(out))
+    g = _graph()
+    as_int = lambda d: {int(k): v for k, v in d.items()}  # noqa: E731
+    assert as_int(got["leaf"]) == O.decompose(g, leaf=True)
+    want_all = O.decompose(g, leaf=2)
+    assert as_int(got["all"]) == want_all and as_int(got["all2"]) == want_all
+    assert sum(c[0] for c in got["all_counts"]) > 0
+    assert as_int(got["plain"]) == O.decompose(g) == as_int(got["hairpins"])
+    one = HipDecomposer(0)
+    one.upload(g)
+    fh = one.decompose(flags=F_HAIRPINS)
+    assert {int(k): v for k, v in got["hp"].items()} == {fh.tree(i).component_id: fh.tree(i).hairpins.tolist() for i in range(len(fh))}
+    assert any(v for v in got["hp"].values())
+    one.close()
+
+
 def test_one_process_engine_three_ranks_on_one_device():
     """povu_hip_multi_*: one process, a context + host thread per rank (all three on the one GPU here, shards loaded straight
     from the partition block); the merged forest takes the workers' blocks over."""
@@ -327,6 +393,7 @@ def test_one_process_engine_on_two_real_devices(transport, monkeypatch):
 def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
     """`povu decompose --gpus 2` (both workers on the one GPU via POVU_HIP_DEVICES): every worker writes the files of its
     components; together they are what the single-GPU run writes."""
+    import json
     import subprocess
     from povu_amd import hip as H
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -347,6 +414,24 @@ def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
     assert outs["one"] == O.decompose(g) == outs["two"]
     assert outs["two_leaf"] == O.decompose(g, leaf=True)
     assert outs["two_sub"] == O.decompose(g, leaf=2)  # all five passes of -s, every worker on its own components
+    # --structure-export with --gpus: every worker renders the sidecar frames of its own components (the state they come
+    # from lives in its context), written in component order once all are done -- the file of the single-GPU run
+    side = {}
+    for name, extra, env in (("one", [], {}), ("two", ["--gpus", "2"], {"POVU_HIP_DEVICES": "0,0"})):
+        d = tmp_path / ("sx_" + name)
+        d.mkdir()
+        sx = d / "export.json"
+        r = subprocess.run([povu, "-t", "4", "decompose", "-i", gfa, "-o", str(d), "--structure-export", str(sx)] + extra,
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1000:]
+        frames = [json.loads(l) for l in open(str(sx) + ".flubble-debug.jsonl")]
+        for fr in frames:  # class ids are names: only which entries share one is the same in every run (a shard numbers its own)
+            names = {}
+            for e in fr["stack_entries"]:
+                e["class_id"] = names.setdefault(e["class_id"], len(names))
+        side[name] = frames
+        assert {int(p.name[:-5]): p.read_text() for p in d.glob("*.pvst")} == outs["one"]
+    assert side["one"] == side["two"] and len(side["one"]) == len(outs["one"])
     r = subprocess.run([povu, "decompose", "-i", gfa, "-o", str(tmp_path), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "device 1 is not visible" in r.stderr  # a one-GPU box has no second device
 
