@@ -15,7 +15,7 @@ import oracle_lib as O
 from povu_amd import HipDecomposer, workloads as W
 from povu_amd.hip import F_SUBFLUBBLES
 from test_oracle import _load_gfa_links
-from test_oracle_subflubbles import RULE_SEEDS, rule_graph, rule_tips
+from test_oracle_subflubbles import HAND_TRACED, RULE_SEEDS, hand_traced_graph, rule_graph, rule_tips
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -134,6 +134,24 @@ def test_config4_whole_genome_full_size_all_five_passes(hip):
     want = {k: hashlib.md5(v.encode()).hexdigest() for k, v in O.decompose(g, threads=os.cpu_count() or 1, lpt=True, leaf=2).items()}
     assert got == want
     assert n_c > 100000
+
+
+@pytest.mark.parametrize("name", sorted(HAND_TRACED))
+def test_hand_traced_cases_on_the_device(hip, name):
+    """The three cases traced by hand through the reference (tests/test_oracle_subflubbles.py: HAND_TRACED) and the first one
+    (pvst_tests_graph.gfa): the HIP path writes the hand-derived lines -- evidence for C / M / S that does not pass through
+    the oracle."""
+    hip.upload(hand_traced_graph(name))
+    text = hip.decompose(flags=F_SUBFLUBBLES).texts()
+    assert list(text) == [1]
+    rows = [l.split("\t") for l in text[1].splitlines()]
+    assert rows[0] == ["H", "0.0.3", ".", ".", "."] and rows[1:] == HAND_TRACED[name][1]
+
+
+def test_first_hand_traced_case_on_the_device(hip, golden_dir):
+    hip.upload(_load_gfa_links(os.path.join(golden_dir, "gfa", "pvst_tests_graph.gfa")))
+    rows = [l.split("\t") for l in hip.decompose(flags=F_SUBFLUBBLES).texts()[1].splitlines()]
+    assert rows[1:] == [["D", "0", ".", "1", "."], ["F", "1", ">1>7", "3", "L"], ["T", "2", ">4>6", "3", "L"], ["C", "3", ">4>7", ".", "L"]]
 
 
 @pytest.mark.parametrize("rule", sorted(RULE_SEEDS))

@@ -97,6 +97,78 @@ def test_hand_traced_concealed_vertex_under_a_tiny_flubble(golden_dir):
                             ["C", "3", ">4>7", ".", "L"]]
 
 
+# ---- three more cases traced by hand through the reference's code (one per family the first case does not reach): a TRUNK
+# midi bubble, an a-side nesting, a smothered vertex.  The graphs are workloads.random_bidirected(n_vtx, n_links, seed,
+# self_loops=False, connected) -- found by a search for the smallest graphs whose oracle run reaches the rule; what is
+# asserted is the text derived by hand below, for the oracle here and for the HIP path in tests/test_gpu_subflubbles.py.
+# Notation: tree vertex: segment side; "brackets(v)" = the ordinary back edges whose walk from parent(source) up to (not
+# including) the target passes v (collect_backedges_by_vertex, tree_utils.cpp:167-216, B = ordinary edges in creation
+# order, :640-648); lo[] = compute_LoA (tree_utils.cpp:224-273) run by hand (descending sweep, deepest queued target).
+HAND_TRACED = {
+    # segments 6 10 11 12 13; links 6l-10l 10r-11l 11r-12l 12l-13r 10r-6l 11l-13l.  Tips 6r, 12r; from_bd starts at (6, r).
+    # Tree: 0 D, 1 6r, 2 6l, 3 10l, 4 10r, 5 11l, 6 11r, 7 12l on one path, 8 12r (black) and 9 13r (gray) below 7, 10 13l below
+    # 9.  Ordinary back edges 4->2, 8->0 (12r has no link), 10->5; capping 7->5.  Flubble 1 = <6>12: ai 2, zi 7.
+    #   compute_m (concealed.cpp:206-253): IBE(2) = {4->2}, lca(4, 7) = 4 above zi -> m = 4.  compute_n (:255-300): 7's only
+    #   outgoing edge is the capping one -> n = zi = 7.  can_contain (:318-363): lo[7] = 5 (10->5 is queued when the sweep
+    #   reaches 7) is not above ai; m != ai -> yes.
+    #   ai_trunk (:367-522): {src 4, lca 4} passes cond i (depth 4 <= depth m); brackets(4) = {8->0} all end at or above ai ->
+    #   kept.  gen_ai_slubble (:69-151): a = 6l -> <6; g = vertex 4 = 10r below a black edge -> >10: "C <6>10", route e2s = R.
+    #   ai_branches (:525-583): neither child of 7 has hi == lo == ai.
+    #   ji_trunk (:702-781) -> override_ji_trunk (:617-700): child 8 of zi is j_x (hi 0 above ai); child 9 has ONE bracket
+    #   10->5 with m < 5 < n -> candidate 5; brackets(5) = {8->0}: source not above zi, target not below ai -> 5 wins.
+    #   gen_zi_slubble (:153-204): z = 12l -> >12, s = vertex 5 = 11l below a gray edge -> >11: "C >11>12", route s2e = L.
+    #   ji_branches (:783-917): zi == n -> none.  add_concealed (:1183-1196): PVST 2 and 3 under flubble 1, nothing to nest.
+    #   find_midi (midi.cpp:223-268): flubble 1 has two concealed children; handle_fl (:130-221): both slubble vertices (4, 5)
+    #   lie above zi -> the TRUNK case (:195-205); gen_midi_bub (:68-127): g from the ai_trunk vertex (>10), s from the
+    #   zi_trunk vertex (>11), route s2e: "M >10>11 L"; add_midi (:18-65): child of flubble 1, no flubble child to nest.
+    "midi_trunk": ((5, 6, 526540656, True),
+                   [["D", "0", ".", "1", "."], ["F", "1", "<6>12", "2, 3, 4", "L"], ["C", "2", "<6>10", ".", "R"],
+                    ["C", "3", ">11>12", ".", "L"], ["M", "4", ">10>11", ".", "L"]]),
+    # segments 2 8 10 15 17; links 2l-8r 8r-10l 10l-15r 15l-17r 2r-15l 2r-17l 15r-2l 15r-8r.  Tips 8l, 10r; start (8, l).
+    # Local link order (componetize, bidirected.cpp:558-569): 2l-8r, 15r-2l, 2r-15l, 2r-17l, 8r-10l, 15r-8r, 10l-15r, 15l-17r.
+    # Tree: 0 D, 1 8l, 2 8r, 3 2l, 4 2r, 5 15l, 6 15r, 7 10l, 8 10r on one path, 9 17r below 5, 10 17l below 9.  Ordinary back
+    # edges 6->3, 6->2, 8->0, 7->2, 10->4; capping 5->4.  Flubbles: 1 = >8>10 (ai 2, zi 7), 2 = >2>15 below it (ai 4, zi 5),
+    # which find_tiny turns into T (not a flubble any more: find_concealed skips it).
+    #   Flubble 1: compute_m: IBE(2) = {6->2, 7->2}; lca(6, 7) = 6 above zi -> candidate 6; lca(7, 7) = 7 is not above zi -> m = 6.
+    #   compute_n: 7->2 ends AT ai -> n = zi = 7.  can_contain: lo[7] = 4 (10->4 is queued: the sweep does not ask whether its
+    #   source lies below 7) is not above ai -> yes.  ai_trunk: {src 6, lca 6}; brackets(6) = {8->0, 7->2} end at or above ai ->
+    #   kept; gen_ai_slubble: a = 8r -> >8, g = vertex 6 = 15r below a black edge -> >15: "C >8>15 R".  zi has one child:
+    #   no branches; ji_trunk: child 8 is j_x, the edge 7->2 ends above n -> none.
+    #   add_conc_ai (:1046-1075) -> nest_trunk_ai (:953-987): child 2 (T: still fl_like) has zi 5 above g (depth 6 > 5) -> it
+    #   moves from flubble 1 to the concealed vertex.
+    "nest_trunk_ai": ((5, 8, 239188140, True),
+                      [["D", "0", ".", "1", "."], ["F", "1", ">8>10", "3", "L"], ["T", "2", ">2>15", ".", "L"], ["C", "3", ">8>15", "2", "R"]]),
+    # segments 3 8 9 11 18; links 18l-9r 8r-9l 3r-9l 9r-11l 8l-9l 8r-3r 9r-11l 18r-9l.  Tips 3l, 11r; start (3, l).
+    # Local link order: 3r-9l, 8r-3r, 8l-9l, 8r-9l, 18r-9l, 18l-9r, 9r-11l, 9r-11l.  Tree: 0 D, 1 3l, 2 3r, 3 9l, 4 9r, 5 18l, 6 18r;
+    # 7 11l, 8 11r below 4; 9 8l, 10 8r below 3.  Ordinary back edges 6->3, 8->0, 10->2, 10->3 (the second 9r-11l link leads to
+    # the tree parent: none); capping 4->3, 3->2.  Flubble 1 = >3>11: ai 2, zi 7.
+    #   compute_m: IBE(2) = {10->2} (the capping edge is skipped), lca(10, 7) = 3 above zi -> m = 3; n = zi = 7 (no outgoing
+    #   edge); can_contain: lo[7] = 3 not above ai.  ai_trunk: {src 10, lca 3}; brackets(3) = {8->0, 10->2} end at or above ai ->
+    #   kept; gen_ai_slubble: a = 3r -> >3, g = vertex 3 = 9l below a GRAY edge -> >9: "C >3>9 R".  Nothing on the z side.
+    #   find_smothered (smothered.cpp:385-431): the concealed vertex is an ai_trunk one -> g::trunk (:61-134) over the
+    #   children of vertex 3: child 4 has brackets {6->3, 8->0} from two sources -> no; child 9 has {10->2, 10->3}, one
+    #   source; the LAST one, 10->3, ends below ai; brackets(10) is empty -> e = comp_e(target 3 = 9l) = <9, g = >9, cn_b is no
+    #   ancestor: "S <9>9", route s2e = L.  add_smothered (:352-383): child of the concealed vertex; nest (:332-350) finds
+    #   nothing with bounds among its children.
+    "smothered_g_trunk": ((5, 8, 219224739, False),
+                          [["D", "0", ".", "1", "."], ["F", "1", ">3>11", "2", "L"], ["C", "2", ">3>9", "3", "R"], ["S", "3", "<9>9", ".", "L"]]),
+}
+
+
+def hand_traced_graph(name):
+    (nv, ne, seed, conn), _ = HAND_TRACED[name]
+    return W.random_bidirected(nv, ne, seed, self_loops=False, connected=conn)
+
+
+def test_three_more_hand_traced_cases():
+    """A trunk midi bubble (midi.cpp:195-205), an a-side nesting (concealed.cpp:953-987) and a smothered vertex
+    (smothered.cpp:61-134): the PVST text derived by hand from the reference's code (comments of HAND_TRACED), line by line."""
+    for name, (_, want) in HAND_TRACED.items():
+        text = O.decompose(hand_traced_graph(name), leaf=2)
+        assert list(text) == [1], name
+        assert _lines(text[1]) == want, name
+
+
 def _check_shape(plain, full):
     p, f = _lines(plain), _lines(full)
     n0 = len(p)
