@@ -268,49 +268,64 @@ __global__ void __launch_bounds__(UF_TPB) k_uf_tiles(uint32_t V, const uint32_t 
 			hook[k] = 1;
 		return false;
 	};
-	// A lane takes UF_BATCH sides at a time and keeps the loads of all of them in flight together: their offsets first (one
-	// round trip for the batch), then slot r of every side that has one (one round trip per r: sides have one to three
-	// slots).  The walk a side at a time that this replaces paid two dependent round trips PER SIDE, sixteen sides in a row
-	// per lane -- the kernel was bound by that chain, not by the bytes it reads (2.5 ms for 1.8 GB on the whole-genome graph).
-	constexpr uint32_t UF_BATCH = 8;
-	const uint32_t S0 = 2 * v0, S1 = 2 * v1;
-	for (uint32_t base = S0; base < S1; base += UF_BATCH * blockDim.x) { // uniform trip count: the ballots below need whole waves
-		uint32_t kb[UF_BATCH], ke[UF_BATCH];
+	// A lane takes FOUR CONSECUTIVE sides a round, UF_GROUPS groups of them at a time: the five offsets of a group in two load
+	// instructions, and the group's slots -- one contiguous stretch of aoth, five or six words on a pangenome graph -- four
+	// a load; the loads of all groups are in flight together.  (The walk a side at a time this replaces issued two 4-byte
+	// loads per side and one per slot, each a dependent round trip: 80 memory instructions a lane where this form has ~20,
+	// and the kernel was bound by them, not by the 1.8 GB it reads on the whole-genome graph.)
+	constexpr uint32_t UF_GROUPS = 2;
+	const uint32_t S0 = 2 * v0, S1 = 2 * v1; // (S0 is a multiple of 4: tiles hold an even number of vertices)
+	static_assert((2 * UF_TILE) % (4 * UF_GROUPS * UF_TPB) == 0, "a tile is a whole number of rounds");
+	for (uint32_t base = S0; base < S1; base += 4 * UF_GROUPS * blockDim.x) { // uniform trip count: the ballots below need whole waves
+		uint32_t b[UF_GROUPS][5], skip[UF_GROUPS]; // offsets of the group's sides; sides left to the workgroup (hubs)
 #pragma unroll
-		for (uint32_t j = 0; j < UF_BATCH; j++) {
-			const uint32_t S = base + j * blockDim.x + threadIdx.x;
-			kb[j] = ke[j] = 0;
-			if (S < S1) {
-				kb[j] = off[S];
-				ke[j] = off[S + 1];
+		for (uint32_t gq = 0; gq < UF_GROUPS; gq++) {
+			const uint32_t Sg = base + (gq * blockDim.x + threadIdx.x) * 4u;
+			skip[gq] = 0;
+			if (Sg + 4 <= S1) {
+				const uint4 o4 = *reinterpret_cast<const uint4 *>(off + Sg);
+				b[gq][0] = o4.x, b[gq][1] = o4.y, b[gq][2] = o4.z, b[gq][3] = o4.w, b[gq][4] = off[Sg + 4];
+			} else { // the tile's (= the graph's) last sides
+#pragma unroll
+				for (uint32_t j = 0; j < 5; j++)
+					b[gq][j] = off[min(Sg + j, S1)];
+				if (Sg >= S1)
+					b[gq][0] = b[gq][1] = b[gq][2] = b[gq][3] = b[gq][4] = 0;
 			}
-		}
 #pragma unroll
-		for (uint32_t j = 0; j < UF_BATCH; j++)
-			if (ke[j] - kb[j] > UF_HEAVY) { // a hub side: the whole workgroup walks it below
-				const uint32_t q = atomicAdd(&n_heavy, 1u);
-				if (q < UF_HEAVY_CAP) {
-					heavy[q] = base + j * blockDim.x + threadIdx.x;
-					ke[j] = kb[j];
+			for (uint32_t j = 0; j < 4; j++)
+				if (b[gq][j + 1] - b[gq][j] > UF_HEAVY) { // a hub side: the whole workgroup walks it below
+					const uint32_t q = atomicAdd(&n_heavy, 1u);
+					if (q < UF_HEAVY_CAP) {
+						heavy[q] = Sg + j;
+						skip[gq] |= 1u << j;
+					}
 				}
-			}
-		for (uint32_t r = 0;; r++) {
-			uint32_t o[UF_BATCH];
+		}
+		for (uint32_t r = 0;; r += 4) {
+			uint4 o[UF_GROUPS];
 			bool any = false;
 #pragma unroll
-			for (uint32_t j = 0; j < UF_BATCH; j++) {
-				const bool live = kb[j] + r < ke[j];
-				o[j] = live ? aoth[kb[j] + r] : 0u;
+			for (uint32_t gq = 0; gq < UF_GROUPS; gq++) {
+				const bool live = b[gq][0] + r < b[gq][4];
+				o[gq] = live ? load4_unaligned(aoth + b[gq][0] + r) : make_uint4(0u, 0u, 0u, 0u);
 				any = any || live;
 			}
 			if (!__any(any))
 				break;
 #pragma unroll
-			for (uint32_t j = 0; j < UF_BATCH; j++) {
-				const bool live = kb[j] + r < ke[j];
-				const uint32_t v = (base + j * blockDim.x + threadIdx.x) >> 1;
-				const bool cross = live && handle(v, kb[j] + r, o[j]);
-				wave_append(cross, v, kb[j] + r, xcount, xlist);
+			for (uint32_t gq = 0; gq < UF_GROUPS; gq++) {
+				const uint32_t Sg = base + (gq * blockDim.x + threadIdx.x) * 4u;
+				const uint32_t os[4] = {o[gq].x, o[gq].y, o[gq].z, o[gq].w};
+#pragma unroll
+				for (uint32_t q = 0; q < 4; q++) {
+					const uint32_t k = b[gq][0] + r + q;
+					const uint32_t j = (k >= b[gq][1] ? 1u : 0u) + (k >= b[gq][2] ? 1u : 0u) + (k >= b[gq][3] ? 1u : 0u); // the side the slot belongs to
+					const bool live = k < b[gq][4] && !((skip[gq] >> j) & 1u);
+					const uint32_t v = (Sg + j) >> 1;
+					const bool cross = live && handle(v, k, os[q]);
+					wave_append(cross, v, k, xcount, xlist);
+				}
 			}
 		}
 	}

@@ -427,11 +427,19 @@ def test_cli_gpus_flag_workers_write_their_own_files(tmp_path):
         frames = [json.loads(l) for l in open(str(sx) + ".flubble-debug.jsonl")]
         for fr in frames:  # class ids are names: only which entries share one is the same in every run (a shard numbers its own)
             names = {}
-            for e in fr["stack_entries"]:
+            for e in fr["stack_entries"] + fr["next_seen_table"]:
                 e["class_id"] = names.setdefault(e["class_id"], len(names))
         side[name] = frames
         assert {int(p.name[:-5]): p.read_text() for p in d.glob("*.pvst")} == outs["one"]
-    assert side["one"] == side["two"] and len(side["one"]) == len(outs["one"])
+    assert len(side["one"]) == len(side["two"]) == len(outs["one"])
+    for fi, (fa, fb) in enumerate(zip(side["one"], side["two"])):
+        for key in fa:
+            if isinstance(fa[key], list):
+                assert len(fa[key]) == len(fb[key]), (fi, key)
+                for ei, (ea, eb) in enumerate(zip(fa[key], fb[key])):
+                    assert ea == eb, (fi, key, ei, {k: (ea[k], eb[k]) for k in ea if ea[k] != eb[k]})
+            else:
+                assert fa[key] == fb[key], (fi, key, fa[key], fb[key])
     r = subprocess.run([povu, "decompose", "-i", gfa, "-o", str(tmp_path), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "device 1 is not visible" in r.stderr  # a one-GPU box has no second device
 
