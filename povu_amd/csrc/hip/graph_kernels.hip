@@ -410,20 +410,36 @@ __global__ void k_uf_cross(const uint32_t *__restrict__ xcount, const uint2 *__r
 
 __global__ void k_uf_flatten(uint32_t V, uint32_t *parent, uint8_t *__restrict__ is_root, uint32_t *__restrict__ unsorted)
 {
-	uint32_t v = BIDX * blockDim.x + threadIdx.x;
-	if (v == 0)
+	// four vertices a lane: their words in one 16-byte load and store (a kernel of a few loads per element is bound by the
+	// memory instructions it issues), the four walks to the roots side by side
+	const uint32_t v0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (v0 == 0)
 		*unsorted = 0; // (k_labels_sorted, the next launch, raises it)
-	if (v >= V)
+	if (v0 >= V)
 		return;
-	uint32_t r = v;
-	while (true) {
-		uint32_t p = parent[r];
-		if (p == r)
-			break;
-		r = p;
+	auto root_of = [&](uint32_t r) {
+		for (;;) {
+			const uint32_t p = parent[r];
+			if (p == r)
+				return r;
+			r = p;
+		}
+	};
+	if (v0 + 4 <= V) {
+		const uint4 p4 = *reinterpret_cast<const uint4 *>(parent + v0);
+		// (a vertex that is its own parent is a root; the others start their walk at the parent just loaded)
+		const uint32_t r0 = p4.x == v0 ? v0 : root_of(p4.x), r1 = p4.y == v0 + 1 ? v0 + 1 : root_of(p4.y);
+		const uint32_t r2 = p4.z == v0 + 2 ? v0 + 2 : root_of(p4.z), r3 = p4.w == v0 + 3 ? v0 + 3 : root_of(p4.w);
+		*reinterpret_cast<uint4 *>(parent + v0) = make_uint4(r0, r1, r2, r3); // readers of parent[] in this kernel only ever walk towards roots
+		*reinterpret_cast<uint32_t *>(is_root + v0) =
+			(r0 == v0 ? 1u : 0u) | (r1 == v0 + 1 ? 1u << 8 : 0u) | (r2 == v0 + 2 ? 1u << 16 : 0u) | (r3 == v0 + 3 ? 1u << 24 : 0u);
+		return;
 	}
-	parent[v] = r; // readers of parent[] in this kernel only ever walk towards roots
-	is_root[v] = (r == v) ? 1 : 0;
+	for (uint32_t v = v0; v < V; v++) {
+		const uint32_t r = root_of(v);
+		parent[v] = r;
+		is_root[v] = (r == v) ? 1 : 0;
+	}
 }
 
 // Are the vertices already grouped by component, in component order?  Components are ranked by their smallest vertex
@@ -920,7 +936,7 @@ uint32_t *label_components_enqueue(const ResidentGraph &g, CompState &st, StageT
 				   st.label, st.hook);
 	}
 	uint8_t *is_root = reinterpret_cast<uint8_t *>(st.flag);
-	KLAUNCH(k_uf_flatten, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, is_root, st.stats + 9);
+	KLAUNCH(k_uf_flatten, dim3(nblk(((size_t)V + 3) / 4)), dim3(TPB), 0, s, V, st.label, is_root, st.stats + 9);
 	KLAUNCH(k_labels_sorted, dim3(nblk(V)), dim3(TPB), 0, s, V, st.label, st.stats + 9);
 	scan_exclusive_u8(is_root, st.crank, (size_t)V + 1, nullptr, nullptr, 0, st.scan_tmp, st.scan_tmp_bytes, s);
 	tm.end(7);

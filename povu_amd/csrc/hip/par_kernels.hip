@@ -770,23 +770,10 @@ __global__ void k_cls_from_stack(uint32_t S, const uint32_t *__restrict__ s_vtx,
 // (an unflagged entry with a previous occurrence is always open).  The U / D events are then the machine's own -- and they
 // are all the PVST depends on --, so such a component needs no sequential redo (until round 4 it took one: 0.66 s per
 // 10^6 segments).  tests/test_laminar_fuzz.py checks the rule against the machine on arbitrary label sequences.
-__global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const SegTree segP, bool check,
-			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint8_t *__restrict__ xflag,
-			       const uint8_t *__restrict__ dflag, uint32_t *__restrict__ walk)
+__device__ __forceinline__ void laminar_check_one(uint32_t i, uint32_t p, const uint32_t *__restrict__ prev, const SegTree &segP,
+						   uint8_t *__restrict__ xflag)
 {
-	uint32_t i = BIDX * blockDim.x + threadIdx.x;
-	if (i >= S)
-		return;
-	const uint32_t p = prev[i];
-	uint32_t step = p != NIL ? 0xFFFFFFFFu : 0u; // U: -1
-	if (i > 0) {
-		step += dflag[i - 1]; // D of the entry before
-		const uint32_t cp = s_comp[i - 1];
-		if (cp != s_comp[i])
-			step -= 2 * (i - soff[cp]) + 2;
-	}
-	walk[i] = step;
-	if (!check || p == NIL || p + 1 >= i) // (!check: the class stage was exact, the intervals are laminar by construction)
+	if (p == NIL || p + 1 >= i)
 		return;
 	uint32_t lowest;
 	if (i - p <= 9) { // a class that comes back within a few entries: its neighbours' words sit next to prev[i]
@@ -798,6 +785,54 @@ __global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, co
 	}
 	if (lowest < p)
 		xflag[i] = 1; // (cleared by the caller)
+}
+__global__ void k_laminar_walk(uint32_t S, const uint32_t *__restrict__ prev, const SegTree segP, bool check,
+			       const uint32_t *__restrict__ s_comp, const uint32_t *__restrict__ soff, uint8_t *__restrict__ xflag,
+			       const uint8_t *__restrict__ dflag, uint32_t *__restrict__ walk)
+{
+	// four entries a lane (16-byte loads and one 16-byte store: a kernel of a few loads per element is bound by the memory
+	// instructions it issues)
+	const uint32_t i0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (i0 >= S)
+		return;
+	if (i0 + 4 <= S) {
+		const uint4 p4 = *reinterpret_cast<const uint4 *>(prev + i0), c4 = *reinterpret_cast<const uint4 *>(s_comp + i0);
+		const uint32_t d4 = *reinterpret_cast<const uint32_t *>(dflag + i0); // D of the entries i0 .. i0 + 3
+		const uint32_t cm = i0 ? s_comp[i0 - 1] : c4.x, dm = i0 ? dflag[i0 - 1] : 0u;
+		const uint32_t ps[4] = {p4.x, p4.y, p4.z, p4.w}, cs[5] = {cm, c4.x, c4.y, c4.z, c4.w};
+		const uint32_t ds[4] = {dm, d4 & 0xFFu, (d4 >> 8) & 0xFFu, (d4 >> 16) & 0xFFu}; // D of the entry before each
+		uint32_t w[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			const uint32_t i = i0 + j;
+			uint32_t step = ps[j] != NIL ? 0xFFFFFFFFu : 0u; // U: -1
+			if (i > 0) {
+				step += ds[j]; // D of the entry before
+				if (cs[j] != cs[j + 1])
+					step -= 2 * (i - soff[cs[j]]) + 2;
+			}
+			w[j] = step;
+		}
+		*reinterpret_cast<uint4 *>(walk + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+		if (check) // (!check: the class stage was exact, the intervals are laminar by construction)
+#pragma unroll
+			for (uint32_t j = 0; j < 4; j++)
+				laminar_check_one(i0 + j, ps[j], prev, segP, xflag);
+		return;
+	}
+	for (uint32_t i = i0; i < S; i++) {
+		const uint32_t p = prev[i];
+		uint32_t step = p != NIL ? 0xFFFFFFFFu : 0u; // U: -1
+		if (i > 0) {
+			step += dflag[i - 1]; // D of the entry before
+			const uint32_t cp = s_comp[i - 1];
+			if (cp != s_comp[i])
+				step -= 2 * (i - soff[cp]) + 2;
+		}
+		walk[i] = step;
+		if (check)
+			laminar_check_one(i, p, prev, segP, xflag);
+	}
 }
 // the flagged entries of every component, in stack order (xlist is ascending): crossed ones get xflag 2 and their U undone
 __global__ void k_resolve_crossings(uint32_t C, const uint32_t *__restrict__ soff, const uint32_t *__restrict__ n_x,
@@ -934,17 +969,30 @@ __global__ void k_levels(uint32_t S, const uint8_t *__restrict__ dflag, const ui
 			 const uint32_t *__restrict__ wb, const uint32_t *__restrict__ negmax,
 			 uint32_t *__restrict__ lev, uint32_t *__restrict__ e_i)
 {
-	uint32_t i = BIDX * blockDim.x + threadIdx.x;
-	if (i >= S || !dflag[i])
+	// four entries a lane: one load says which of them open a flubble (one in four or five does)
+	const uint32_t i0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
+	if (i0 >= S)
 		return;
-	const uint32_t c = s_comp[i], i0 = soff[c];
-	// zero of this component's walk = its value at the component's first entry (after the drop B_c, before any U or D)
-	const uint32_t zero = wb[i0];
-	// running minimum up to i (negmax = exclusive running maximum of ~wb): everything in front of i0 lies above `zero`
-	const uint32_t cur = wb[i], run = min(cur, ~negmax[i]);
-	uint32_t j = erank[i];
-	lev[j] = cur + 1 - min(zero, run); // depth of the new flubble (>= 1): the walk after this entry's own D
-	e_i[j] = i;
+	uint32_t fl = 0;
+	if (i0 + 4 <= S) {
+		fl = *reinterpret_cast<const uint32_t *>(dflag + i0);
+	} else {
+		for (uint32_t k = 0; i0 + k < S; k++)
+			fl |= (dflag[i0 + k] ? 1u : 0u) << (8 * k);
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < 4; k++) {
+		if (!((fl >> (8 * k)) & 0xFFu))
+			continue;
+		const uint32_t i = i0 + k, c = s_comp[i], f0 = soff[c];
+		// zero of this component's walk = its value at the component's first entry (after the drop B_c, before any U or D)
+		const uint32_t zero = wb[f0];
+		// running minimum up to i (negmax = exclusive running maximum of ~wb): everything in front of f0 lies above `zero`
+		const uint32_t cur = wb[i], run = min(cur, ~negmax[i]);
+		const uint32_t j = erank[i];
+		lev[j] = cur + 1 - min(zero, run); // depth of the new flubble (>= 1): the walk after this entry's own D
+		e_i[j] = i;
+	}
 }
 // PVST parent of every flubble = nearest earlier flubble of its component with a smaller level
 __global__ void k_pvst_emit(uint32_t NE, const uint32_t *__restrict__ lev, const uint32_t *__restrict__ e_i,
@@ -1471,7 +1519,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
 		HIP_CHECK(hipMemsetAsync(xflag, 0, (size_t)S + 1, s));
 	}
-	LAUNCH(k_laminar_walk, S, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, xflag, dflag, pw.walk);
+	LAUNCH(k_laminar_walk, ((size_t)S + 3) / 4, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, xflag, dflag, pw.walk);
 	if (pw.laminar_checked && S) { // the entries whose interval is crossed: decided in stack order, U undone where the class was popped
 		uint32_t *xlist = pw.wrun, *n_x = pw.err + 11, *n_crossed = pw.err + 12; // (wrun is written by the max-scan below; err words cleared at the start of the pass)
 		compact_flagged_u8(xflag, S, xlist, n_x, pw.scan_tmp, pw.scan_tmp_bytes, s);
@@ -1483,7 +1531,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
 	LAUNCH(k_walk_bias, ((size_t)S + 3) / 4, s, S, pw.walk, pw.walk_ps, wb, wneg);
 	scan_exclusive_max_u32(wneg, wrun, (size_t)S, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	LAUNCH(k_levels, S, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
+	LAUNCH(k_levels, ((size_t)S + 3) / 4, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
 	       pw.d_parent);

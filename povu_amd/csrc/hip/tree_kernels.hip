@@ -697,21 +697,32 @@ __device__ __forceinline__ uint32_t tour_rank(const uint4 *__restrict__ xrec, ui
 	const unsigned long long bits = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
 	return r.z + (uint32_t)__popcll(bits & ((1ull << (p & 63u)) - 1ull));
 }
-// one lane per segment (all reads in segment order): the value of a segment whose position bit is set
+// the value of every segment whose position bit is set (all reads in segment order).  Two segments a lane: their four ft
+// words in one 16-byte load -- five segments in six carry no value, and for them that load is all the kernel does
 __global__ void k_tour_values(uint32_t V, const uint4 *__restrict__ t0seg, const uint32_t *__restrict__ ft,
 			      const ulonglong2 *__restrict__ hside, const uint4 *__restrict__ xrec, ulonglong2 *__restrict__ xval)
 {
-	uint32_t g = BIDX * blockDim.x + threadIdx.x;
-	if (g >= V)
+	const uint32_t g0 = (BIDX * blockDim.x + threadIdx.x) * 2u;
+	if (g0 >= V)
 		return;
-	const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
-	if (!((f2.x | f2.y) & FT_HASH))
-		return;
-	const uint4 r = t0seg[g];
-	if (r.x == NIL) // a root is entered by no arc: its value is in no stretch
-		return;
+	uint4 f4;
+	if (g0 + 2 <= V) {
+		f4 = *reinterpret_cast<const uint4 *>(ft + 2 * g0);
+	} else {
+		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g0);
+		f4 = make_uint4(f2.x, f2.y, 0u, 0u);
+	}
 	const ulonglong2 z = make_ulonglong2(0ull, 0ull);
-	xval[tour_rank(xrec, r.z)] = hx((f2.x & FT_HASH) ? hside[2 * g] : z, (f2.y & FT_HASH) ? hside[2 * g + 1] : z);
+	auto one = [&](uint32_t g, uint32_t fl, uint32_t fr) {
+		if (!((fl | fr) & FT_HASH))
+			return;
+		const uint4 r = t0seg[g];
+		if (r.x == NIL) // a root is entered by no arc: its value is in no stretch
+			return;
+		xval[tour_rank(xrec, r.z)] = hx((fl & FT_HASH) ? hside[2 * g] : z, (fr & FT_HASH) ? hside[2 * g + 1] : z);
+	};
+	one(g0, f4.x, f4.y);
+	one(g0 + 1, f4.z, f4.w);
 }
 // parent word of side S: its parent in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree).
 // It lives in cstate[S] (below) next to the visited bit -- a separate array of them was 0.8 GB written and read once more.
@@ -980,23 +991,24 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(const uint32_t *__restri
 				uint32_t l0, l1, l2 = 0, wp = CS_VISITED;
 				if (slot == 0) { // came over the black edge: the partner is u, visited
 					l0 = loff[o], l1 = loff[o + 1];
-				} else {
-					l0 = loff[g2], l1 = loff[g2 + 1], l2 = loff[g2 + 2];
+				} else { // (the three offsets in one load instruction: the array carries slack behind its last word)
+					const uint4 l4 = load4_unaligned(loff + g2);
+					l0 = l4.x, l1 = l4.y, l2 = l4.z;
 					const uint2 cs2 = *reinterpret_cast<const uint2 *>(cstate + g2);
 					wp = odd ? cs2.x : cs2.y;
 				}
 				const uint32_t nlo = (slot == 0 || !odd) ? l0 : l1, nhi = (slot == 0) ? l1 : (odd ? l2 : l1);
-				cstate[o] = w | CS_VISITED;
-				dps[o] = make_uint2(u, slot);
 				if (depth < DFS_STK)
 					stk[depth][lane] = make_uint4(u, k, lo, n);
 				depth++;
 				sides++;
 				// (the black neighbour of the new side is known to be visited from here on: its scan starts at slot 1)
 				if (!(wp & CS_VISITED)) { // an unvisited partner is in this class (across a bridge it would be an entry: marked)
+					// both sides of the segment at once: their state words in one 8-byte store, their records in one of 16
 					const uint32_t p = o ^ 1u, plo = odd ? l0 : l1, phi = odd ? l1 : l2;
-					cstate[p] = wp | CS_VISITED;
-					dps[p] = make_uint2(o, 0u);
+					const uint32_t so = w | CS_VISITED, sp = wp | CS_VISITED;
+					*reinterpret_cast<uint2 *>(cstate + g2) = odd ? make_uint2(sp, so) : make_uint2(so, sp);
+					*reinterpret_cast<uint4 *>(dps + g2) = odd ? make_uint4(o, 0u, u, slot) : make_uint4(u, slot, o, 0u);
 					if (depth < DFS_STK)
 						stk[depth][lane] = make_uint4(o, 1u, nlo, nhi - nlo);
 					depth++;
@@ -1005,6 +1017,8 @@ __global__ void __launch_bounds__(64) k_class_dfs_small(const uint32_t *__restri
 					lo = plo;
 					n = phi - plo;
 				} else {
+					cstate[o] = w | CS_VISITED;
+					dps[o] = make_uint2(u, slot);
 					u = o;
 					lo = nlo;
 					n = nhi - nlo;
@@ -2038,7 +2052,7 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	LAUNCH(k_bit_counts, (size_t)XW + 1, s, XW, tw.xrec, tw.xrank);
 	scan_exclusive_u32(tw.xrank, tw.xrank, (size_t)XW + 1, pw.scan_tmp, pw.scan_tmp_bytes, s); // xrank[XW] = values in all
 	LAUNCH(k_bit_ranks, XW, s, XW, tw.xrank, tw.xrec);
-	LAUNCH(k_tour_values, V, s, V, tw.t0seg, ft, hside, tw.xrec, tw.xval);
+	LAUNCH(k_tour_values, ((size_t)V + 1) / 2, s, V, tw.t0seg, ft, hside, tw.xrec, tw.xval);
 	// (the number of values stays on the device: the scan is launched for the most there can be, one per segment, and
 	// stops at their count + 1)
 	scan_exclusive_xor_u128(tw.xval, tw.xps, (size_t)V + 1, pw.scan_tmp, pw.scan_tmp_bytes, s, tw.xrank + XW);
