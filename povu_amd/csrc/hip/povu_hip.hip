@@ -351,7 +351,7 @@ size_t carve_workspace(Arena *ar, int part, const Sizes &z, CompState &cs, SeqWs
 		take(&sw.t_gid, T, 4);
 		take(&sw.t_par, T, 4);
 		take(&sw.t_cls, T, 4);
-		take(&sw.t_size, T, 4);
+		take(&sw.t_size, T + 8, 4); // (+8: the class stage reads sizes eight words at a time)
 		take(&sw.t_depth, T, 4);
 		take(&sw.t_flags, T, 1);
 		take(&sw.cur, nS + 1, 4);

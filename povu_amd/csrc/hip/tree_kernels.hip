@@ -624,9 +624,11 @@ __global__ void k_t0_parents(uint32_t V, const uint32_t *__restrict__ dist, cons
 			     const uint32_t *__restrict__ lle,
 			     const uint32_t *__restrict__ ft, const uint32_t *__restrict__ heads,
 			     uint4 *__restrict__ t0seg, uint4 *__restrict__ xrec, uint32_t C,
-			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err)
+			     const unsigned long long *__restrict__ start_key, uint32_t *__restrict__ err, uint8_t *__restrict__ multi)
 {
 	uint32_t g = BIDX * blockDim.x + threadIdx.x;
+	if (g < V) // (the flags k_bridges raises, cleared here on the way: no fill kernel over 2 * 10^8 bytes)
+		*reinterpret_cast<uint16_t *>(multi + 2 * g) = 0;
 	if (g < C) { // the DFS start of component g roots its tree (no advance arc ever enters its segment)
 		const uint32_t r = comp_root_side(start_key, voff, g), L = 2 * (voff[g + 1] - voff[g] - 1);
 		t0seg[r >> 1] = make_uint4(NIL, (r & 1u) ? T0_RBIT : 0u, 0u, L ? L - 1 : 0u);
@@ -697,32 +699,22 @@ __device__ __forceinline__ uint32_t tour_rank(const uint4 *__restrict__ xrec, ui
 	const unsigned long long bits = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
 	return r.z + (uint32_t)__popcll(bits & ((1ull << (p & 63u)) - 1ull));
 }
-// the value of every segment whose position bit is set (all reads in segment order).  Two segments a lane: their four ft
-// words in one 16-byte load -- five segments in six carry no value, and for them that load is all the kernel does
+// one lane per segment (all reads in segment order): the value of a segment whose position bit is set
+// (two segments a lane -- one 16-byte load of their four ft words -- measured SLOWER: 1.22 ms against 1.00)
 __global__ void k_tour_values(uint32_t V, const uint4 *__restrict__ t0seg, const uint32_t *__restrict__ ft,
 			      const ulonglong2 *__restrict__ hside, const uint4 *__restrict__ xrec, ulonglong2 *__restrict__ xval)
 {
-	const uint32_t g0 = (BIDX * blockDim.x + threadIdx.x) * 2u;
-	if (g0 >= V)
+	uint32_t g = BIDX * blockDim.x + threadIdx.x;
+	if (g >= V)
 		return;
-	uint4 f4;
-	if (g0 + 2 <= V) {
-		f4 = *reinterpret_cast<const uint4 *>(ft + 2 * g0);
-	} else {
-		const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g0);
-		f4 = make_uint4(f2.x, f2.y, 0u, 0u);
-	}
+	const uint2 f2 = *reinterpret_cast<const uint2 *>(ft + 2 * g);
+	if (!((f2.x | f2.y) & FT_HASH))
+		return;
+	const uint4 r = t0seg[g];
+	if (r.x == NIL) // a root is entered by no arc: its value is in no stretch
+		return;
 	const ulonglong2 z = make_ulonglong2(0ull, 0ull);
-	auto one = [&](uint32_t g, uint32_t fl, uint32_t fr) {
-		if (!((fl | fr) & FT_HASH))
-			return;
-		const uint4 r = t0seg[g];
-		if (r.x == NIL) // a root is entered by no arc: its value is in no stretch
-			return;
-		xval[tour_rank(xrec, r.z)] = hx((fl & FT_HASH) ? hside[2 * g] : z, (fr & FT_HASH) ? hside[2 * g + 1] : z);
-	};
-	one(g0, f4.x, f4.y);
-	one(g0 + 1, f4.z, f4.w);
+	xval[tour_rank(xrec, r.z)] = hx((f2.x & FT_HASH) ? hside[2 * g] : z, (f2.y & FT_HASH) ? hside[2 * g + 1] : z);
 }
 // parent word of side S: its parent in the rooted forest, bit 31 set when the edge to it is a bridge (NIL: S roots its tree).
 // It lives in cstate[S] (below) next to the visited bit -- a separate array of them was 0.8 GB written and read once more.
@@ -1471,7 +1463,8 @@ __global__ void k_walk_finish(uint32_t nS, const uint32_t *__restrict__ wpar, co
 __device__ __forceinline__ uint32_t leave_event(uint32_t p, bool p_is_far) { return 3 * (p >> 1) + (p_is_far ? 1u : 2u); }
 __global__ void k_events(uint32_t V, const uint2 *__restrict__ dps, const uint32_t *__restrict__ loff,
 			 const uint32_t *__restrict__ ladj, const uint32_t *__restrict__ ckey, const uint32_t *__restrict__ cproc,
-			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b, uint8_t *__restrict__ merged)
+			 uint32_t *__restrict__ pk, uint32_t *__restrict__ heads, unsigned b, uint8_t *__restrict__ merged,
+			 uint32_t *__restrict__ sdl)
 {
 	// One lane per SEGMENT: it needs the first child of the far side o, the next sibling of o (= the first gray child of the
 	// entered side e, whose first child is o itself) and the next sibling of e -- three searches, the records of both sides
@@ -1479,6 +1472,9 @@ __global__ void k_events(uint32_t V, const uint2 *__restrict__ dps, const uint32
 	const uint32_t g = BIDX * blockDim.x + threadIdx.x;
 	if (g >= V)
 		return;
+	sdl[g] = 0; // (row E's difference array, filled by k_tree_emit with atomic adds: cleared here on the way, no fill kernel)
+	if (g == 0)
+		sdl[V] = sdl[V + 1] = 0;
 	const uint32_t A = 3 * g;
 	const uint4 d4 = *reinterpret_cast<const uint4 *>(dps + 2 * g);
 	if (d4.x != 2 * g + 1 && d4.z != 2 * g) { // a segment outside the decomposed components: three inert words
@@ -1550,7 +1546,8 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			    uint32_t *__restrict__ t_gid, uint8_t *__restrict__ t_flags, uint32_t *__restrict__ t_par,
 			    uint32_t *__restrict__ t_size, uint32_t *__restrict__ t_depth, uint32_t *__restrict__ side_tidx,
 			    uint32_t C, uint32_t *__restrict__ c_ntree, uint32_t *__restrict__ ordcnt, uint32_t *__restrict__ hi0,
-			    uint32_t *__restrict__ mpre, uint32_t *__restrict__ srccnt, uint32_t *__restrict__ sdl)
+			    uint32_t *__restrict__ mpre, uint32_t *__restrict__ srccnt, uint32_t *__restrict__ sdl,
+			    uint32_t *__restrict__ incnt)
 {
 	// The class stage works on the tree in T-space (component c owns [2 voff[c] + c, 2 voff[c+1] + c]) and reads, per tree
 	// vertex: t_size (0 marks a slot without a vertex), t_par (NIL = root), mpre = mirror pre-order (children visited in
@@ -1559,10 +1556,13 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 	// mpre(v) = depth(v) + N - v - size(v) in local indices) and srccnt (brackets per mirror pre-order position, written for
 	// every vertex later: only the slots without a vertex are cleared here).  All of it is written right here.
 	uint32_t S = BIDX * blockDim.x + threadIdx.x;
+	// incnt (brackets that end at a vertex: k_back_edges counts into it) is cleared here on the way -- every T-space slot gets
+	// its size from exactly one lane of this kernel, and its zero with it: no fill kernel over 8 * 10^8 bytes
 	if (S == 0) {
 		const uint32_t T = 2 * (nS >> 1) + C;
 		hi0[T] = NIL;
 		srccnt[T] = srccnt[T + 1] = 0;
+		incnt[T] = incnt[T + 1] = 0;
 	}
 	if (S < C) { // tree size of component S and its dummy root (spanning_tree.cpp:397-402)
 		const uint32_t Nr = 2 * (voff[S + 1] - voff[S]), tr = 2 * voff[S] + S;
@@ -1570,6 +1570,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			c_ntree[S] = 0;
 			t_size[tr + Nr] = 0; // the spare slot (the sides clear their own two below)
 			srccnt[tr + Nr] = 0;
+			incnt[tr + Nr] = 0;
 		} else {
 			const uint32_t hr = start_key[S] != ~0ull ? 1u : 0u;
 			c_ntree[S] = Nr + hr;
@@ -1578,6 +1579,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 				t_flags[tr] = 2;
 				t_par[tr] = NIL;
 				t_size[tr] = Nr + 1;
+				incnt[tr] = 0;
 				if (t_depth)
 					t_depth[tr] = 0;
 				mpre[tr] = tr;
@@ -1586,6 +1588,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 			} else {
 				t_size[tr + Nr] = 0;
 				srccnt[tr + Nr] = 0;
+				incnt[tr + Nr] = 0;
 			}
 		}
 	}
@@ -1600,6 +1603,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 		const uint32_t t = tb + 2 * (g - v0);
 		store2_unaligned(t_size + t, 0u, 0u);
 		store2_unaligned(srccnt + t, 0u, 0u);
+		store2_unaligned(incnt + t, 0u, 0u);
 		*reinterpret_cast<uint2 *>(side_tidx + 2 * g) = make_uint2(NIL, NIL);
 		return;
 	}
@@ -1624,6 +1628,7 @@ __global__ void k_tree_emit(uint32_t nS, const uint2 *__restrict__ cd, const uin
 	t_flags[t + 1] = (uint8_t)((o & 1u) | TF_BLACK);
 	store2_unaligned(t_par + t, par_e, l); // (o's parent is e)
 	store2_unaligned(t_size + t, size_e, size_o);
+	store2_unaligned(incnt + t, 0u, 0u);
 	if (t_depth) // (only the hairpin report's T-space setup reads the depths again)
 		store2_unaligned(t_depth + t, depth_e + hd, depth_e + 1 + hd);
 	store2_unaligned(mpre + t, tb + (depth_e + hd) + (Nh + hd) - l - size_e, tb + (depth_e + 1 + hd) + (Nh + hd) - (l + 1) - size_o);
@@ -2044,7 +2049,7 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	const uint32_t XW = NA / 64 + 1; // words of the position bitmap
 	HIP_CHECK(hipMemsetAsync(tw.xrec, 0, ((size_t)XW + 2) * 16, s));
 	LAUNCH(k_t0_parents, std::max(V, C), s, V, dist, cs.ckey, cs.voff, cs.loff, cs.ladj, cs.lle, ft, rb.heads,
-	       tw.t0seg, tw.xrec, C, start_key, pw.err + 2);
+	       tw.t0seg, tw.xrec, C, start_key, pw.err + 2, tw.dvis_slots);
 	tm.end(40);
 
 	// ---- 3-4. bridges and 2-edge-connected classes
@@ -2052,12 +2057,11 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	LAUNCH(k_bit_counts, (size_t)XW + 1, s, XW, tw.xrec, tw.xrank);
 	scan_exclusive_u32(tw.xrank, tw.xrank, (size_t)XW + 1, pw.scan_tmp, pw.scan_tmp_bytes, s); // xrank[XW] = values in all
 	LAUNCH(k_bit_ranks, XW, s, XW, tw.xrank, tw.xrec);
-	LAUNCH(k_tour_values, ((size_t)V + 1) / 2, s, V, tw.t0seg, ft, hside, tw.xrec, tw.xval);
+	LAUNCH(k_tour_values, V, s, V, tw.t0seg, ft, hside, tw.xrec, tw.xval);
 	// (the number of values stays on the device: the scan is launched for the most there can be, one per segment, and
 	// stops at their count + 1)
 	scan_exclusive_xor_u128(tw.xval, tw.xps, (size_t)V + 1, pw.scan_tmp, pw.scan_tmp_bytes, s, tw.xrank + XW);
-	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16)
-	HIP_CHECK(hipMemsetAsync(multi, 0, nS, s));
+	uint8_t *multi = tw.dvis_slots; // (see tree_spans: sized for max(2E, 2V) + 16; cleared by k_t0_parents)
 	uint32_t *cstate = sw.cur; // [nS+1]
 	LAUNCH(k_bridges, V, s, V, tw.t0seg, tw.xps, tw.xrec, hside, ft, dist, cs.loff, cs.lle, cs.ckey, tw.cproc, cs.voff, multi, cstate, tw.dps);
 	tm.end(8 + 44);
@@ -2118,19 +2122,17 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(n_events);
 	uint8_t *merged = tw.dvis; // [V] (the visited bytes of the class walk are dead)
 	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
-	LAUNCH(k_events, V, s, V, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged);
+	LAUNCH(k_events, V, s, V, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged, pw.sdl);
 	list_rank_splitters<true, true>(n_events, bitsE, nullptr, tw.evt, C, rb, s);
 	(void)event_lists;
 	tm.end(40);
 
 	// ---- 8. tree arrays in pre-order and the from_bd back edges
 	tm.begin("tree_emit");
-	HIP_CHECK(hipMemsetAsync(pw.sdl, 0, ((size_t)V + 2) * 4, s));
 	LAUNCH(k_tree_emit, std::max(V, C), s, nS, tw.evt, merged, tw.dps, cs.ckey, tw.cproc, cs.voff, start_key, cs.gid_s, sw.t_gid, sw.t_flags,
 	       sw.t_par, sw.t_size, (sw.hairpins || sw.want_depth) ? sw.t_depth : nullptr, tw.side_tidx, C, sw.c_ntree, pw.lsz, pw.hi0, pw.mpre, pw.dlt,
-	       pw.sdl);
+	       pw.sdl, pw.incnt); // (incnt: k_back_edges counts the brackets that end at a vertex into it)
 	pw.sdl_filled = true;
-	HIP_CHECK(hipMemsetAsync(pw.incnt, 0, ((size_t)2 * V + C + 2) * 4, s)); // k_back_edges counts the brackets that end at a vertex
 	const uint8_t *dupflag = nullptr;
 	if (max_side_links > 64 && E) { // see k_dup_flags
 		const uint32_t n_slots = 2 * E;
