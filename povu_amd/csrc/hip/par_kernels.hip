@@ -567,106 +567,10 @@ __global__ void k_top_bracket(uint32_t n, const uint32_t *__restrict__ gsize, co
 	if (hpf && rid[i] >= first_simp_id) // the top bracket is a simplifying edge (flubbles.cpp:644-656)
 		hpf[v] |= 2;
 }
-// The black-edge-only form, FOUR segment slots a lane (the slots are taken in descending order: consecutive lanes, and the
-// four of one lane, are neighbours in every array): the component words, the two shift words and -- when the four sit in
-// one component, nearly always -- the sizes and list positions of their black vertices come in 16-byte loads, the keys and
-// stack indices leave in 16-byte stores; the look-ups into the bracket list stay per vertex.  (One slot a lane issued
-// thirteen 4-byte loads and five 4-byte stores per vertex: 1.85 ms on 10^8 segments, bound by those instructions.)
-__global__ void __launch_bounds__(TPB) k_top_bracket_black4(uint32_t n, const uint32_t *__restrict__ gsize, const uint32_t *__restrict__ mpre,
-							     const uint32_t *__restrict__ bstart, const SegTree segB, const uint32_t *__restrict__ tgtR,
-							     const uint32_t *__restrict__ psin, uint32_t *__restrict__ ckey, uint32_t *__restrict__ cval,
-							     uint32_t *__restrict__ lsz, uint32_t *__restrict__ err, const uint32_t *__restrict__ seg_comp,
-							     const uint32_t *__restrict__ c_ntree, const StackPlace sp)
-{
-	const uint32_t q0 = (BIDX * blockDim.x + threadIdx.x) * 4u;
-	if (q0 >= n)
-		return;
-	const uint32_t cnt = min(4u, n - q0), gmax = n - 1 - q0; // slots gmax, gmax - 1, ... (cnt of them)
-	uint32_t cs[4], ds[4], dp[4], szs[4], ms[4], vs[4];
-	bool wide = cnt == 4;
-	if (wide) {
-		const uint4 c4 = load4_unaligned(seg_comp + gmax - 3);
-		wide = c4.x == c4.w; // (components are contiguous in slot order: equal ends = one component)
-		if (wide) {
-			const uint4 d4 = load4_unaligned(sp.dlt + gmax - 3), p4 = load4_unaligned(sp.dlt_ps + gmax - 3);
-			const uint32_t c = c4.x, vmin = 2 * (gmax - 3) + c + (c_ntree[c] & 1u) + 1;
-			const uint4 s0 = load4_unaligned(gsize + vmin), s1 = load4_unaligned(gsize + vmin + 4);
-			const uint4 m0 = load4_unaligned(mpre + vmin), m1 = load4_unaligned(mpre + vmin + 4);
-			// j-th of the lane = slot gmax - j = word 6 - 2 j of the eight
-			const uint32_t sw[4] = {s1.z, s1.x, s0.z, s0.x}, mw[4] = {m1.z, m1.x, m0.z, m0.x};
-			const uint32_t dw[4] = {d4.w, d4.z, d4.y, d4.x}, pw4[4] = {p4.w, p4.z, p4.y, p4.x};
-#pragma unroll
-			for (uint32_t j = 0; j < 4; j++)
-				cs[j] = c, ds[j] = dw[j], dp[j] = pw4[j], szs[j] = sw[j], ms[j] = mw[j], vs[j] = vmin + 6 - 2 * j;
-		}
-	}
-	if (!wide) {
-		for (uint32_t j = 0; j < cnt; j++) {
-			const uint32_t g = gmax - j, c = seg_comp[g], v = 2 * g + c + (c_ntree[c] & 1u) + 1;
-			cs[j] = c, ds[j] = sp.dlt[g], dp[j] = sp.dlt_ps[g], szs[j] = gsize[v], ms[j] = mpre[v], vs[j] = v;
-		}
-	}
-	uint32_t keys[4] = {NIL, NIL, NIL, NIL}, vals[4] = {0, 0, 0, 0};
-#pragma unroll
-	for (uint32_t j = 0; j < 4; j++) {
-		if (j >= cnt)
-			break;
-		const uint32_t g = gmax - j, v = vs[j], sz = szs[j], c = cs[j];
-		if (sz == 0) { // (no vertex in this slot: a component that is not decomposed here)
-			vals[j] = v;
-			continue;
-		}
-		// everything downstream lives in candidate-stack order, so the sort carries the entry's stack index and the entry
-		// itself (its tree vertex, its component) is written here; lsz is indexed by stack position too
-		const uint32_t at = sp.soff[c] + (g - sp.voff[c]) + dp[j] + ds[j];
-		sp.s_vtx[at] = v;
-		sp.s_comp[at] = c;
-		vals[j] = at;
-		const uint32_t m = ms[j], lo = bstart[m], hi = bstart[m + sz];
-		// Number of live brackets first (two prefix sums): in a chain of bubbles the brackets of everything below v are closed
-		// inside their bubbles and the few live ones -- a simplifying edge, a tip's edge to the root -- come from the
-		// deepest sources, i.e. sit at the END of the range.  When the last `live` entries are all live they are THE live
-		// ones, and the top bracket is the first of them: no search at all.
-		const uint32_t live = (hi - lo) - (psin[v + sz] - psin[v]);
-		uint32_t i = NIL;
-		if (live >= 1 && live <= 4) { // (the four words in one 16-byte load; the array carries slack behind its last entry)
-			const uint4 a = load4_unaligned(tgtR + (hi - live));
-			const bool all = a.x < v && (live < 2 || a.y < v) && (live < 3 || a.z < v) && (live < 4 || a.w < v);
-			if (all)
-				i = hi - live;
-		}
-		// otherwise the top bracket often is one of the first few of the range: probe them (one load) before falling back
-		// to the O(log n) descent
-		if (i == NIL) {
-			const uint32_t np = min(hi - lo, 4u);
-			const uint4 a = load4_unaligned(tgtR + lo);
-			if (np > 0 && a.x < v)
-				i = lo;
-			else if (np > 1 && a.y < v)
-				i = lo + 1;
-			else if (np > 2 && a.z < v)
-				i = lo + 2;
-			else if (np > 3 && a.w < v)
-				i = lo + 3;
-			if (i == NIL && lo + np < hi)
-				i = seg_first_less(segB, lo + np, hi, v);
-		}
-		if (i == NIL) {
-			atomicAdd(&err[0], 1u); // cannot happen: every list holds at least a simplifying bracket
-			lsz[at] = 0;
-			continue;
-		}
-		lsz[at] = live;
-		keys[j] = i;
-	}
-	if (cnt == 4) {
-		*reinterpret_cast<uint4 *>(ckey + q0) = make_uint4(keys[0], keys[1], keys[2], keys[3]);
-		*reinterpret_cast<uint4 *>(cval + q0) = make_uint4(vals[0], vals[1], vals[2], vals[3]);
-	} else {
-		for (uint32_t j = 0; j < cnt; j++)
-			ckey[q0 + j] = keys[j], cval[q0 + j] = vals[j];
-	}
-}
+// (Tried in round 5 and dropped: the black-edge-only form with FOUR segment slots a lane -- component, shift, size and list
+// position words in 16-byte loads, keys and stack indices in 16-byte stores.  3.43 ms against 1.86: the look-ups into the
+// bracket list are chains of dependent gathers, and four of them one after the other in a lane cost more than the narrow
+// loads of four lanes did; the wide form only pays in kernels that stream, gpurun_out r5l.)
 // a bracket hands out a new class whenever the list size differs from the size it saw last
 // (recent_size / recent_class, flubbles.cpp:668-676)
 // (also row F's marks: q + 1 where the vertex at sorted position q ends a black edge, see k_next_from_runs)
@@ -1511,8 +1415,8 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 		uint32_t *shift_ps = pw.topi; // (dlt_ps still holds the bracket range starts; nobody needs vertex -> stack index here)
 		scan(sdl, shift_ps, (size_t)V + 1);
 		const StackPlace sp{cs.voff, pw.soff, sdl, shift_ps, pw.s_vtx, pw.s_comp};
-		KLAUNCH(k_top_bracket_black4, dim3(nblk(((size_t)NC + 3) / 4)), dim3(TPB), 0, s, NC, pw.gsize, pw.mpre, bstart, pw.segB, pw.tgtR, pw.psin, ck,
-			pw.vals_t, pw.lsz, pw.err, cs.ckey, sw.c_ntree, sp);
+		LAUNCH(k_top_bracket<true>, NC, s, NC, pw.gsize, pw.gpar, pw.mpre, bstart, pw.segB, pw.tgtR, pw.psin, ck,
+		       pw.vals_t, pw.lsz, pw.err, pw.b_val2, NB0 + ncap, nullptr, cs.ckey, sw.c_ntree, sp);
 		sort_pairs_u32(ck, ck2, pw.vals_t, pw.vals_t2, NC, bits_for((uint64_t)NB + 1), pw.sort_tmp, pw.sort_tmp_bytes, s);
 		// invalid entries carry NIL; after the sort on the low bits they sit behind every valid key
 		tm.end(30 + 2 * 22);
