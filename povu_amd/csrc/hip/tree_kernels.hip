@@ -2077,12 +2077,13 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	const uint32_t *big_list = tw.entry_list;
 	uint32_t n_big = force_big_class_dfs ? tw.host->read_u32(n_entry_dev, s) : 0; // (A/B mode: every class through the wave walk)
 	if (!force_big_class_dfs) {
-		// Lanes in flight = a window of sides whose scattered stores meet again in L2: ~3000 x 64 lanes measured best
-		// from a few hundred thousand to twenty million small classes (wider windows thrash the caches, narrower
-		// ones leave latency uncovered).  The number of classes stays on the device: the launch is a grid-stride
-		// loop, one synchronisation (how many classes overflowed) serves both.
+		// Lanes in flight = a window of sides whose scattered stores meet again in L2.  Round 4's walk (one tree edge per
+		// three dependent round trips) was best at ~3000 x 64 lanes; with the black follow-through the walk issues fewer,
+		// wider accesses and more lanes in flight pay: 49 152 workgroups measured 0.2 ms faster on 2.3 * 10^7 classes
+		// (gpurun_out r5m / r5n: 3072 -> 2.96 ms, 24 576 -> 2.83, 49 152 -> 2.76, 196 608 -> 2.73).  The number of classes
+		// stays on the device: the launch is a grid-stride loop, one synchronisation (how many classes overflowed) serves both.
 		const unsigned all_blocks = (nS + 63) / 64;
-		unsigned dfs_blocks = std::min(all_blocks, 3072u);
+		unsigned dfs_blocks = std::min(all_blocks, 49152u);
 		if (const char *ev = getenv("POVU_HIP_DFS_BLOCKS")) // (tuning hook)
 			dfs_blocks = std::min(all_blocks, std::max(1u, (unsigned)atoi(ev)));
 		uint32_t *n_over = pw.err + 4, *over_list = tw.entry_ps; // (a spare array of the entries' size)
