@@ -1130,9 +1130,9 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		dirty0 = dirty1 = 0;
 	};
 #ifdef POVU_WALK_STATS
-	uint32_t st_fast = 0, st_slow = 0, st_refill = 0, st_pop = 0;
+	uint32_t st_fast = 0, st_slow = 0, st_refill = 0, st_pop = 0, st_ft = 0;
 	const long long st_t0 = clock64();
-	long long st_mark = st_t0, cy_fast = 0, cy_slow = 0, cy_refill = 0, cy_pop = 0;
+	long long st_mark = st_t0, cy_fast = 0, cy_slow = 0, cy_refill = 0, cy_pop = 0, cy_ft = 0;
 #define WSTAT(x) (x)++
 #define WCYC(acc)                                                                                                             \
 	do {                                                                                                                  \
@@ -1143,8 +1143,8 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 #define WSTAT_DONE()                                                                                                          \
 	do {                                                                                                                  \
 		if (lane == 0 && (blockIdx.x < 2 || st_fast + st_slow > 50000u))                                              \
-			printf("walk %u: fast %u slow %u refills %u pops %u cycles %lld = fast %lld slow %lld refill %lld pop %lld\n", blockIdx.x, st_fast, st_slow, st_refill, st_pop, \
-			       clock64() - st_t0, cy_fast, cy_slow, cy_refill, cy_pop);                                          \
+			printf("walk %u: fast %u slow %u refills %u pops %u black-follow %u cycles %lld = fast %lld slow %lld refill %lld pop %lld black-follow %lld\n", blockIdx.x, st_fast, st_slow, st_refill, st_pop, st_ft, \
+			       clock64() - st_t0, cy_fast, cy_slow, cy_refill, cy_pop, cy_ft);                                          \
 	} while (0)
 #else
 #define WSTAT(x)
@@ -1218,8 +1218,8 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 				(void)set_parent(u ^ 1u, u);
 				u ^= 1u;
 				r = pn;
-				WSTAT(st_fast);
-				WCYC(cy_fast);
+				WSTAT(st_ft);
+				WCYC(cy_ft);
 				continue;
 			}
 		}

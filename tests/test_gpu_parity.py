@@ -537,6 +537,22 @@ def test_tangled_hprc_shape_vs_oracle(hip, seed):
     assert {k: md5(v) for k, v in hip.decompose(flags=F_BIG_CLASS_DFS).texts().items()} == want
 
 
+def test_circular_component_and_hub_workloads_vs_oracle(hip):
+    """The two cliff workloads of bench.py's `secondary` at a size the oracle does in seconds: a tip-less (circular) HPRC-shaped
+    component -- ONE 2-edge-connected class, rooted at (l, vertex 0) with the 0 -> 0 back edge, walked by one wave with the
+    black follow-through -- and a chain of bubbles with a hub segment (one side with 4 * 10^4 links, the dense re-index);
+    plain passes and all five passes of -s."""
+    from povu_amd.hip import F_SUBFLUBBLES
+    for g in (W.hprc_circular(60000), W.hub_on_chain(20000, 40000)):
+        want = {k: md5(v) for k, v in O.decompose(g).items()}
+        hip.upload(g)
+        assert {k: md5(v) for k, v in hip.decompose().texts().items()} == want
+        assert hip.seq_redo_count() == 0
+    g = W.hprc_circular(20000)
+    hip.upload(g)
+    assert hip.decompose(flags=F_SUBFLUBBLES).texts() == O.decompose(g, leaf=2)
+
+
 def test_extracted_reference_structures_on_gpu(hip, golden_dir):
     """The structure expectations of the reference's conformance suite (tests/golden/reference_vectors.json)."""
     from test_oracle import check_structure, links_of_vector, reference_vectors

@@ -25,3 +25,14 @@ for WL in hprc-wg chain; do
   rm -f $O/pmc_fetch/*/*counter_collection.csv $O/pmc_write/*/*counter_collection.csv $O/kt/*/*kernel_trace.csv
   echo "== $WL"; cat $O/timeline_summary.txt; head -c 600 $O/bench.json; echo
 done
+# the workloads the class walks dominate: a kernel trace of the walk that ships (BASELINE config 5, the tangled graph, the
+# circular component)
+for WL in nest tangled circular; do
+  O=$R/gpurun_out/final/$WL
+  rm -rf $O && mkdir -p $O
+  A="--workload $WL --no-cpu-baseline --no-secondary --no-overlap --no-latency-leg --steps 2 --warmup 1"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py $A > $O/bench_under_rocprof.json 2> $O/kt.err || exit 5
+  cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/kernel_stats.csv
+  rm -rf $O/kt
+  echo "== $WL"; head -c 400 $O/bench_under_rocprof.json; echo
+done

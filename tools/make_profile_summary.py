@@ -88,6 +88,49 @@ for wl, title in (("hprc-wg", "BASELINE config 4 at full size (the headline work
     for (a, b), (c, d) in zip(fetch["top"][:12], write["top"][:12]):
         L.append(f"| `{a[:40]}` | {b*1024/1e6:.0f} | | `{c[:40]}` | {d*1024/1e6:.0f} |")
     L.append("")
+# ---- kernel -> bytes, the round before against this one (the headline workload): the top fetchers / writers of either round
+prev = os.path.join(P, f"r{int(tag[1:]) - 1:02d}_summary.md")
+D = os.path.join(F, "hprc-wg")
+if os.path.exists(prev) and os.path.isdir(D):
+    old_f, old_w = {}, {}
+    sect = 0
+    for line in open(prev):
+        if line.startswith("## "):
+            sect += 1
+        m = re.match(r"\| `([^`]+)` \| (\d+) \| \| `([^`]+)` \| (\d+) \|", line)
+        if m and sect == 1:  # (the first section is the headline workload)
+            old_f[m.group(1)] = int(m.group(2))
+            old_w[m.group(3)] = int(m.group(4))
+    fetch = json.load(open(os.path.join(D, "fetch_summary.json")))
+    write = json.load(open(os.path.join(D, "write_summary.json")))
+    new_f = {k[:40]: v * 1024 / 1e6 for k, v in fetch["top"]}
+    new_w = {k[:40]: v * 1024 / 1e6 for k, v in write["top"]}
+    L.append(f"### Kernel -> bytes, round {int(tag[1:]) - 1} against round {tag[1:]} (headline workload; MB per pass as counted; `-`: not among that round's top twelve / gone)\n")
+    L.append("| kernel | fetch before | fetch now | write before | write now |\n|---|---|---|---|---|")
+    names = list(dict.fromkeys(list(old_f) + list(old_w) + [k for k, _ in sorted(new_f.items(), key=lambda x: -x[1])[:12]] + [k for k, _ in sorted(new_w.items(), key=lambda x: -x[1])[:12]]))
+    fmt = lambda d, k: (f"{d[k]:.0f}" if k in d else "-")  # noqa: E731
+    for k in names:
+        L.append(f"| `{k}` | {fmt(old_f, k)} | {fmt(new_f, k)} | {fmt(old_w, k)} | {fmt(new_w, k)} |")
+    L.append("")
+# ---- the workloads the class walks dominate: kernel trace of the walk that ships
+for wl, title in (("nest", "BASELINE config 5 (nested towers)"), ("tangled", "tangled HPRC shape"), ("circular", "circular (tip-less) component")):
+    D = os.path.join(F, wl)
+    if not os.path.isdir(D) or not os.path.exists(os.path.join(D, "kernel_stats.csv")):
+        continue
+    shutil.copy(os.path.join(D, "kernel_stats.csv"), os.path.join(P, f"{tag}_{wl}_kernel_stats.csv"))
+    under = json.loads(open(os.path.join(D, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    rows = list(csv.DictReader(open(os.path.join(D, "kernel_stats.csv"))))
+    agg = {}
+    for r in rows:
+        a = agg.setdefault(short(r["Name"]), [0, 0])
+        a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
+    L.append(f"## {title}: kernel trace of the shipped walk\n")
+    L.append(f"Workload: {under['config']['workload']}.  `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --no-cpu-baseline --no-secondary "
+             f"--no-overlap --no-latency-leg --steps 2 --warmup 1` ({PASSES} passes): {under['ms_per_step']:.2f} ms per pass under the tracer; full table `{tag}_{wl}_kernel_stats.csv`.\n")
+    L.append("| kernel | calls/pass | ms/pass |\n|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda x: -x[1][1])[:8]:
+        L.append(f"| `{k}` | {v[0]/PASSES:.1f} | {v[1]/PASSES/1e6:.3f} |")
+    L.append("")
 json.dump(traffic, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 extra = os.path.join(P, f"{tag}_other.md")
 if os.path.exists(extra):
