@@ -1152,6 +1152,8 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 #define WSTAT_DONE()
 #endif
 	bool pool_ok = true;
+	bool pend = false, pend_push = false; // bookkeeping of a black follow-through step that the next step still has to carry out
+	uint32_t pend_side = 0;
 	// remembers (side, first candidate index still to look at) on the stack
 	auto push = [&](uint32_t side, uint32_t jn) {
 		const uint32_t d = depth;
@@ -1210,12 +1212,14 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			if (j0 == 0 && r.n && r.c0 == (u ^ 1u) && pn_vis == W_UNVIS) {
 				// the black edge is scanned first and its far side is not visited: across it, out of registers.  What stands
 				// behind it in u's list was not looked at: u is remembered as if an unvisited candidate were left.
-				if (r.n > 1) {
-					push(u, 1u);
-					if (!pool_ok)
-						return;
-				}
-				(void)set_parent(u ^ 1u, u);
+				// The bookkeeping of this step -- the push and the parent word of the far side -- is LEFT PENDING: the next
+				// step (always an ordinary one) carries it out right after it has issued its loads, in the shadow of their
+				// round trip (a step of bookkeeping alone costs ~1 000 cycles of dependent instructions on a lone wave,
+				// about as much as the round trip of the step behind it: profiles/r05_walk_stats.log).  Nothing reads the
+				// stack or the far side's parent word before that point (a side is no candidate of itself).
+				pend = true;
+				pend_push = r.n > 1;
+				pend_side = u;
 				u ^= 1u;
 				r = pn;
 				WSTAT(st_ft);
@@ -1268,6 +1272,17 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 				q0 = wrec[2 * (size_t)(cand ^ 1u)];
 				q1 = wrec[2 * (size_t)(cand ^ 1u) + 1];
 			}
+		}
+		if (pend) { // (the loads above are in flight: see the black follow-through)
+			pend = false;
+			if (pend_push) {
+				push(pend_side, 1u);
+				if (!pool_ok)
+					return;
+			}
+			(void)set_parent(pend_side ^ 1u, pend_side);
+		}
+		if (!fast && miss) {
 			m = __ballot(cand != NIL && vp == W_UNVIS);
 		}
 		if (fast)
