@@ -1626,6 +1626,40 @@ extern "C" int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in
 	}
 }
 
+// ---- timing hook for the scans: `reps` exclusive sum scans of n words (device resident, all ones), ms per scan by HIP events
+extern "C" double povu_hip_debug_scan_time(povu_hip_ctx *ctx, size_t n, int reps, int op)
+{
+	if (!ctx || !n || reps <= 0)
+		return -1.0;
+	try {
+		HIP_CHECK(hipSetDevice(ctx->device));
+		hipStream_t s = ctx->stream;
+		Arena ar;
+		const size_t tb = scan_tmp_bytes(n);
+		ar.reserve(2 * Arena::padded(n + 16, 4) + tb + 4096);
+		uint32_t *di = ar.take<uint32_t>(n + 16), *dout = ar.take<uint32_t>(n + 16);
+		void *tmp = ar.take<char>(tb);
+		HIP_CHECK(hipMemsetAsync(di, 1, n * 4, s));
+		hipEvent_t e0, e1;
+		HIP_CHECK(hipEventCreate(&e0));
+		HIP_CHECK(hipEventCreate(&e1));
+		for (int w = 0; w < 2; w++)
+			op ? scan_exclusive_max_u32(di, dout, n, tmp, tb, s) : scan_exclusive_u32(di, dout, n, tmp, tb, s);
+		HIP_CHECK(hipEventRecord(e0, s));
+		for (int r = 0; r < reps; r++)
+			op ? scan_exclusive_max_u32(di, dout, n, tmp, tb, s) : scan_exclusive_u32(di, dout, n, tmp, tb, s);
+		HIP_CHECK(hipEventRecord(e1, s));
+		HIP_CHECK(hipEventSynchronize(e1));
+		float ms = 0;
+		HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+		(void)hipEventDestroy(e0);
+		(void)hipEventDestroy(e1);
+		return (double)ms / reps;
+	} catch (const std::exception &) {
+		return -2.0;
+	}
+}
+
 // ---- stage-level parity hooks
 extern "C" int povu_hip_debug_components(povu_hip_ctx *ctx, uint32_t *comp_of, uint32_t *local_idx)
 {

@@ -39,6 +39,10 @@ struct ScanJob {
 	size_t n, chunk;
 	uint32_t blocks;
 	uint32_t *partial;
+	// single-launch form (k_scan_lookback): tiles of LB_TILE elements, one status word a tile, handed out by a ticket
+	uint32_t tiles;
+	unsigned long long *status;
+	uint32_t *ticket;
 };
 struct ScanJobs {
 	ScanJob j[2];
@@ -182,9 +186,210 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_chunks(const ScanJobs jobs)
 	}
 }
 
-size_t scan_tmp_bytes(size_t)
+// ---- the same scans in ONE launch and one read of the input (decoupled look-back).  A workgroup takes a ticket = its
+// tile (LB_TILE elements, all loaded up front: 32 a lane), publishes the tile's aggregate, then its first wave looks back
+// over the status words of the tiles in front of it, 64 at a time -- aggregates are added up until a tile is met that
+// already knows its inclusive prefix --, publishes its own inclusive prefix and the workgroup writes the tile out.  A tile
+// only ever waits for tiles with smaller tickets, i.e. for workgroups that are already running: no assumption about the
+// order workgroups are dispatched in.  Value and state of a tile share one 64-bit word (read and written with
+// agent-scope atomics: the L2 of another XCD never serves a stale one), so no fence orders anything.  The two-launch form
+// above reads its input twice (4.3 GB of the 170 GB a whole-genome pass moved in round 5, and 1.05 ms for the partials).
+static constexpr unsigned long long LB_AGG = 1ull << 32, LB_PREFIX = 2ull << 32;
+template <int MAX, int LB_SUB, bool TICKET>
+__global__ void __launch_bounds__(SC_TPB) k_scan_lookback(const ScanJobs jobs)
 {
-	return SC_MAX_BLOCKS * 16 + 256; // (two u32 jobs, or one job of 128-bit words)
+	constexpr int LB_TILE = SC_TILE * LB_SUB;
+	__shared__ uint32_t wave_tot[LB_SUB][4];
+	__shared__ uint32_t s_tile, s_carry;
+	const ScanJob &J = jobs.j[blockIdx.y];
+	if (blockIdx.x >= J.tiles)
+		return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t t = blockIdx.x;
+	if (TICKET && J.tiles > 1) { // (uniform: a one-tile job needs neither ticket nor status)
+		if (threadIdx.x == 0)
+			s_tile = atomicAdd(J.ticket, 1u);
+		__syncthreads();
+		t = s_tile;
+	}
+	const size_t b0 = (size_t)t * LB_TILE, b1 = b0 + LB_TILE < J.n ? b0 + LB_TILE : J.n;
+	uint32_t v[LB_SUB][SC_ITEMS], inc[LB_SUB];
+	if (b0 + LB_TILE <= J.n && !J.in8) { // a whole tile of words (uniform): every load of the lane is issued before the first is needed
+		const uint32_t *__restrict__ in = J.in + b0 + (size_t)threadIdx.x * SC_ITEMS;
+		uint4 a[LB_SUB][2];
+#pragma unroll
+		for (int q = 0; q < LB_SUB; q++)
+			a[q][0] = *reinterpret_cast<const uint4 *>(in + q * SC_TILE), a[q][1] = *reinterpret_cast<const uint4 *>(in + q * SC_TILE + 4);
+		if (J.sub) {
+			const uint32_t *__restrict__ sub = J.sub + b0 + (size_t)threadIdx.x * SC_ITEMS;
+#pragma unroll
+			for (int q = 0; q < LB_SUB; q++) {
+				const uint4 c = *reinterpret_cast<const uint4 *>(sub + q * SC_TILE), d = *reinterpret_cast<const uint4 *>(sub + q * SC_TILE + 4);
+				a[q][0].x -= c.x, a[q][0].y -= c.y, a[q][0].z -= c.z, a[q][0].w -= c.w;
+				a[q][1].x -= d.x, a[q][1].y -= d.y, a[q][1].z -= d.z, a[q][1].w -= d.w;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < LB_SUB; q++) {
+			v[q][0] = a[q][0].x, v[q][1] = a[q][0].y, v[q][2] = a[q][0].z, v[q][3] = a[q][0].w;
+			v[q][4] = a[q][1].x, v[q][5] = a[q][1].y, v[q][6] = a[q][1].z, v[q][7] = a[q][1].w;
+		}
+	} else if (b0 + LB_TILE <= J.n) { // a whole tile of bytes
+		const uint8_t *__restrict__ in8 = J.in8 + b0 + (size_t)threadIdx.x * SC_ITEMS;
+		uint2 a[LB_SUB];
+#pragma unroll
+		for (int q = 0; q < LB_SUB; q++)
+			a[q] = *reinterpret_cast<const uint2 *>(in8 + q * SC_TILE);
+#pragma unroll
+		for (int q = 0; q < LB_SUB; q++) {
+			v[q][0] = a[q].x & 0xFFu, v[q][1] = (a[q].x >> 8) & 0xFFu, v[q][2] = (a[q].x >> 16) & 0xFFu, v[q][3] = a[q].x >> 24;
+			v[q][4] = a[q].y & 0xFFu, v[q][5] = (a[q].y >> 8) & 0xFFu, v[q][6] = (a[q].y >> 16) & 0xFFu, v[q][7] = a[q].y >> 24;
+		}
+	} else {
+#pragma unroll
+		for (int q = 0; q < LB_SUB; q++)
+			sc_load_tile(J, b0 + (size_t)q * SC_TILE + (size_t)threadIdx.x * SC_ITEMS, b1, v[q]);
+	}
+#pragma unroll
+	for (int q = 0; q < LB_SUB; q++) {
+		uint32_t tot = 0; // lane-local exclusive scan
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const uint32_t x = v[q][k];
+			v[q][k] = tot;
+			tot = sc_op<MAX>(tot, x);
+		}
+		uint32_t i = tot; // inclusive scan of the lane totals across the wave
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t y = __shfl_up(i, off);
+			if (lane >= off)
+				i = sc_op<MAX>(i, y);
+		}
+		inc[q] = i;
+		if (lane == 63)
+			wave_tot[q][wave] = i;
+	}
+	__syncthreads();
+	if (wave == 0) {
+		uint32_t agg = 0;
+#pragma unroll
+		for (int q = 0; q < LB_SUB; q++)
+#pragma unroll
+			for (int w = 0; w < 4; w++)
+				agg = sc_op<MAX>(agg, wave_tot[q][w]);
+		uint32_t carry = 0;
+		if (t > 0) {
+			if (lane == 0)
+				__hip_atomic_store(J.status + t, LB_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (int64_t base = (int64_t)t - 1;;) {
+				const int64_t idx = base - lane;
+				// (in front of tile 0: an inclusive prefix of nothing)
+				const unsigned long long w = idx >= 0 ? __hip_atomic_load(J.status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
+				const unsigned long long has_p = __ballot((w >> 32) == 2ull), unset = __ballot((w >> 32) == 0ull);
+				const int stop = has_p ? __ffsll((long long)has_p) - 1 : 64; // nearest tile that knows its prefix
+				const unsigned long long need = stop >= 63 ? ~0ull : ((2ull << stop) - 1ull);
+				if (unset & need)
+					continue; // some tile up to there has not published yet: its workgroup is running, read again
+				uint32_t x = lane <= stop ? (uint32_t)w : 0u;
+				for (int off = 32; off; off >>= 1)
+					x = sc_op<MAX>(x, __shfl_down(x, off));
+				carry = sc_op<MAX>(carry, __shfl(x, 0));
+				if (has_p)
+					break;
+				base -= 64;
+			}
+		}
+		if (lane == 0) {
+			if (J.tiles > 1)
+				__hip_atomic_store(J.status + t, LB_PREFIX | sc_op<MAX>(carry, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s_carry = carry;
+		}
+	}
+	__syncthreads();
+	uint32_t pre_sub = s_carry; // everything in front of the sub-tile
+#pragma unroll
+	for (int q = 0; q < LB_SUB; q++) {
+		const size_t e0 = b0 + (size_t)q * SC_TILE + (size_t)threadIdx.x * SC_ITEMS;
+		uint32_t pre = pre_sub; // ... in front of this lane: earlier waves, earlier lanes
+		for (int w = 0; w < wave; w++)
+			pre = sc_op<MAX>(pre, wave_tot[q][w]);
+		const uint32_t lane_excl = __shfl_up(inc[q], 1);
+		if (lane > 0)
+			pre = sc_op<MAX>(pre, lane_excl);
+		if (e0 + SC_ITEMS <= b1) { // (always, in a whole tile)
+			uint4 a, b;
+			a.x = sc_op<MAX>(pre, v[q][0]), a.y = sc_op<MAX>(pre, v[q][1]), a.z = sc_op<MAX>(pre, v[q][2]), a.w = sc_op<MAX>(pre, v[q][3]);
+			b.x = sc_op<MAX>(pre, v[q][4]), b.y = sc_op<MAX>(pre, v[q][5]), b.z = sc_op<MAX>(pre, v[q][6]), b.w = sc_op<MAX>(pre, v[q][7]);
+			*reinterpret_cast<uint4 *>(J.out + e0) = a;
+			*reinterpret_cast<uint4 *>(J.out + e0 + 4) = b;
+		} else {
+			for (int k = 0; k < SC_ITEMS; k++)
+				if (e0 + k < b1)
+					J.out[e0 + k] = sc_op<MAX>(pre, v[q][k]);
+		}
+		pre_sub = sc_op<MAX>(pre_sub, sc_op<MAX>(sc_op<MAX>(wave_tot[q][0], wave_tot[q][1]), sc_op<MAX>(wave_tot[q][2], wave_tot[q][3])));
+	}
+}
+
+static constexpr size_t SC_LEGACY_BYTES = SC_MAX_BLOCKS * 16 + 256; // (two u32 jobs of the two-launch form, or one job of 128-bit words)
+// variants (POVU_HIP_LB_VARIANT, measured with tools/scan_time.py on 10^8 words: two launches 0.268 ms; 0: 0.271; 1: 0.249;
+// 2: 0.242; 3: 0.231): bit 1 = 64 elements a lane instead of 32, bit 0 = the tile is the workgroup's index instead of a
+// ticket (relies on workgroups being dispatched in index order: not the default)
+static int lb_variant()
+{
+	static const int v = getenv("POVU_HIP_LB_VARIANT") ? atoi(getenv("POVU_HIP_LB_VARIANT")) : 2;
+	return v;
+}
+// below this many elements the two-launch form is the faster one: its second read comes out of the Infinity Cache
+// (10^7 words: 0.023 ms against 0.035) -- except when every job fits one tile (one launch instead of two, no fill)
+static constexpr size_t LB_MIN = 48u << 20;
+static size_t lb_tile() { return (size_t)SC_TILE * ((lb_variant() & 2) ? 8 : 4); }
+static size_t lb_tiles(size_t n) { return (n + lb_tile() - 1) / lb_tile(); }
+static size_t lb_job_bytes(size_t n) { return 16 + 8 * lb_tiles(n); } // ticket (+ padding), status words
+size_t scan_tmp_bytes(size_t n)
+{
+	return SC_LEGACY_BYTES + 2 * lb_job_bytes(n) + 64; // the partials of the two-launch form, then ticket + status words of two jobs
+}
+// one or two jobs in one launch; false: the temporary storage was sized for fewer elements (the caller takes two launches)
+template <int MAX>
+static bool scan_lookback(ScanJobs &jobs, int nj, void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+	static const bool off = getenv("POVU_HIP_SCAN_TWO_LAUNCH") != nullptr; // (A/B hook)
+	if (off)
+		return false;
+	size_t need = SC_LEGACY_BYTES, clear = 0;
+	unsigned gx = 0;
+	char *at = static_cast<char *>(tmp) + SC_LEGACY_BYTES;
+	for (int j = 0; j < nj; j++) {
+		ScanJob &J = jobs.j[j];
+		const size_t tiles = lb_tiles(J.n);
+		if (tiles > 0xFFFFFFF0ull)
+			return false;
+		J.tiles = (uint32_t)tiles;
+		J.ticket = reinterpret_cast<uint32_t *>(at);
+		J.status = reinterpret_cast<unsigned long long *>(at + 16);
+		at += lb_job_bytes(J.n);
+		need += lb_job_bytes(J.n);
+		if (tiles > 1)
+			clear = need - SC_LEGACY_BYTES; // (the jobs lie back to back: one fill covers every job that needs one)
+		gx = std::max<unsigned>(gx, J.tiles);
+	}
+	if (need > tmp_bytes)
+		return false;
+	size_t n_max = 0;
+	for (int j = 0; j < nj; j++)
+		n_max = std::max(n_max, jobs.j[j].n);
+	if (clear && n_max < LB_MIN)
+		return false;
+	if (clear)
+		HIP_CHECK(hipMemsetAsync(static_cast<char *>(tmp) + SC_LEGACY_BYTES, 0, clear, s));
+	switch (lb_variant()) {
+	case 0: KLAUNCH((k_scan_lookback<MAX, 4, true>), dim3(gx, nj), dim3(SC_TPB), 0, s, jobs); break;
+	case 1: KLAUNCH((k_scan_lookback<MAX, 4, false>), dim3(gx, nj), dim3(SC_TPB), 0, s, jobs); break;
+	case 2: KLAUNCH((k_scan_lookback<MAX, 8, true>), dim3(gx, nj), dim3(SC_TPB), 0, s, jobs); break;
+	default: KLAUNCH((k_scan_lookback<MAX, 8, false>), dim3(gx, nj), dim3(SC_TPB), 0, s, jobs); break;
+	}
+	return true;
 }
 
 static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32_t *partial, const uint8_t *in8 = nullptr,
@@ -199,7 +404,7 @@ static ScanJob make_scan_job(const uint32_t *in, uint32_t *out, size_t n, uint32
 	size_t chunk = (n + blocks - 1) / blocks;
 	chunk = (chunk + SC_TILE - 1) / SC_TILE * SC_TILE; // whole tiles: every tile base stays 16-byte aligned
 	blocks = (n + chunk - 1) / chunk;
-	return ScanJob{in, sub, in8, out, n, chunk, (uint32_t)blocks, partial};
+	return ScanJob{in, sub, in8, out, n, chunk, (uint32_t)blocks, partial, 0u, nullptr, nullptr};
 }
 
 template <int MAX>
@@ -211,6 +416,8 @@ static void scan_exclusive(const uint32_t *in, uint32_t *out, size_t n, void *tm
 		throw HipError("scan: temporary storage too small");
 	ScanJobs jobs{};
 	jobs.j[0] = make_scan_job(in, out, n, static_cast<uint32_t *>(tmp));
+	if (scan_lookback<MAX>(jobs, 1, tmp, tmp_bytes, s))
+		return;
 	KLAUNCH(k_scan_partials<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 	KLAUNCH(k_scan_chunks<MAX>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 }
@@ -235,6 +442,8 @@ void scan_exclusive_u8(const uint8_t *in0, uint32_t *out0, size_t n0, const uint
 	}
 	if (!gy)
 		return;
+	if (scan_lookback<0>(jobs, (int)gy, tmp, tmp_bytes, s))
+		return;
 	KLAUNCH(k_scan_partials<0>, dim3(gx, gy), dim3(SC_TPB), 0, s, jobs);
 	KLAUNCH(k_scan_chunks<0>, dim3(gx, gy), dim3(SC_TPB), 0, s, jobs);
 }
@@ -252,6 +461,8 @@ void scan_exclusive_diff_u32(const uint32_t *in, const uint32_t *sub, uint32_t *
 		throw HipError("scan: temporary storage too small");
 	ScanJobs jobs{};
 	jobs.j[0] = make_scan_job(in, out, n, static_cast<uint32_t *>(tmp), nullptr, sub);
+	if (scan_lookback<0>(jobs, 1, tmp, tmp_bytes, s))
+		return;
 	KLAUNCH(k_scan_partials<0>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 	KLAUNCH(k_scan_chunks<0>, dim3(jobs.j[0].blocks, 1), dim3(SC_TPB), 0, s, jobs);
 }
@@ -270,6 +481,8 @@ static void scan_exclusive_pair(const uint32_t *in0, uint32_t *out0, size_t n0, 
 	ScanJobs jobs{};
 	jobs.j[0] = make_scan_job(in0, out0, n0, static_cast<uint32_t *>(tmp));
 	jobs.j[1] = make_scan_job(in1, out1, n1, static_cast<uint32_t *>(tmp) + SC_MAX_BLOCKS);
+	if (scan_lookback<OP>(jobs, 2, tmp, tmp_bytes, s))
+		return;
 	const unsigned gx = std::max(jobs.j[0].blocks, jobs.j[1].blocks);
 	KLAUNCH(k_scan_partials<OP>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);
 	KLAUNCH(k_scan_chunks<OP>, dim3(gx, 2), dim3(SC_TPB), 0, s, jobs);

@@ -945,13 +945,15 @@ struct XArrays {
 	uint32_t *vbeg, *vn, *vcap;
 	uint32_t *pool;
 };
-// One WAVE splices one component.  The control flow is the reference's, followed by all 64 lanes alike (every decision is
-// read from the same address by every lane); lane 0 does the stores, and the two loops that are long on a flubble with very
-// many children -- copying a vector that grows, filtering the children that leave -- are shared out over the lanes.
+// One WAVE works on the children vectors of ONE vertex and of the vertices it creates (see "the splice, in parallel"
+// below).  The control flow is the reference's, followed by all 64 lanes alike (every decision is read from the same address
+// by every lane); lane 0 does the stores, and the two loops that are long on a flubble with very many children -- copying a
+// vector that grows, filtering the children that leave -- are shared out over the lanes.
 struct Splice {
 	XArrays x;
-	uint32_t xb;		   // first X slot of the component
-	uint32_t pool_top, pool_end; // bump pointer inside the pool (the same in every lane)
+	uint32_t xb;	    // first X slot of the component
+	uint32_t *pool_top; // bump pointer inside the component's stretch of the pool: shared by the waves of the component
+	uint32_t pool_end;
 	uint32_t *err;
 	uint32_t lane;
 	__device__ __forceinline__ void sync() const { __syncthreads(); } // (one wave a workgroup)
@@ -964,20 +966,23 @@ struct Splice {
 		uint32_t ncap = cap ? cap : 4;
 		while (ncap < n + extra)
 			ncap *= 2;
-		if (pool_top + ncap > pool_end || ncap < n) {
+		uint32_t at = 0;
+		if (lane == 0)
+			at = ncap < n ? NIL : atomicAdd(pool_top, ncap);
+		at = __shfl(at, 0);
+		if (at == NIL || at + ncap > pool_end || at + ncap < at) {
 			if (lane == 0)
 				atomicOr(err, E_POOL);
 			return false;
 		}
 		const uint32_t from = x.vbeg[p];
 		for (uint32_t k = lane; k < n; k += 64)
-			x.pool[pool_top + k] = x.pool[from + k];
+			x.pool[at + k] = x.pool[from + k];
 		sync();
 		if (lane == 0) {
-			x.vbeg[p] = pool_top;
+			x.vbeg[p] = at;
 			x.vcap[p] = ncap;
 		}
-		pool_top += ncap;
 		sync();
 		return true;
 	}
@@ -1014,9 +1019,10 @@ struct Splice {
 	}
 	// The nestings of add_concealed / add_midi run over a COPY of the first nch children of f and move those that `leaves`
 	// says so, in order, under `dest` (to_child: the other way round -- `dest` is pushed into the vector of each of them,
-	// concealed.cpp:1077).  A stable filter, 64 children a round; returns false when the pool ran out.
-	template <typename Leaves, typename Touch>
-	__device__ bool filter(uint32_t f, uint32_t nch, uint32_t dest, bool to_child, Leaves &&leaves, Touch &&touch)
+	// concealed.cpp:1077: that push is the CHILD's, see k_sub_pin; here the child only leaves the vector of f).  A stable
+	// filter, 64 children a round; returns false when the pool ran out.
+	template <typename Leaves>
+	__device__ bool filter(uint32_t f, uint32_t nch, uint32_t dest, bool to_child, Leaves &&leaves)
 	{
 		const uint32_t pf = xb + f;
 		uint32_t w = 0;
@@ -1043,13 +1049,6 @@ struct Splice {
 					if (lane == 0)
 						x.vn[pd] = x.vn[pd] + cnt;
 					sync();
-				} else {
-					for (unsigned long long m = mm; m; m &= m - 1) {
-						const uint32_t c2 = __shfl(ch, __ffsll((long long)m) - 1);
-						if (!push(c2, dest))
-							return false;
-						touch(c2);
-					}
 				}
 			}
 			sync();
@@ -1138,154 +1137,201 @@ __global__ void k_sub_x_place(uint32_t Q, uint32_t NX, const uint32_t *__restric
 		return;
 	X.pool[X.vbeg[x] + (i - cap_ps[x])] = val[i];
 }
-__global__ void __launch_bounds__(64) k_sub_splice(uint32_t C, const SubT t, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ poff,
-						    const uint32_t *__restrict__ cn_off, const Slub *__restrict__ cn, const uint32_t *__restrict__ mn,
-						    const uint32_t *__restrict__ smo_off, const Smo *__restrict__ smo, XArrays X, uint32_t *__restrict__ counts)
+// ------------------------------------------------------------------ the splice, in parallel
+// Until round 5 one wave spliced a whole component, flubble after flubble (94 ms for the whole-genome workload: 10^4
+// flubbles of a chromosome with a concealed bubble, some ten dependent trips to memory each).  What add_concealed does to
+// one flubble f depends on nothing another flubble's turn writes:
+//  * its records (cn[]: found before, in ascending idx) each become the vertex n0 + (index of the record in the
+//    component) -- no counter;
+//  * a record's nesting moves children of f under the new vertex, or (z-side trunk) pushes the new vertex into the vector
+//    of the children that qualify and drops them from f's vector.  Whether a child qualifies is a function of the trees
+//    alone (cn_leaves), so the CHILD can work out by itself which vertex its parent's records push into its vector: it
+//    walks the parent's records in order until one takes it (k_sub_pin, one lane per PVST vertex; at most one vertex ever
+//    arrives, because the record that pushes it also drops the child from the parent's vector).  The parent has the
+//    smaller idx, its turn comes first: the pushed vertex stands in front of the child's own concealed vertices;
+//  * the vectors grow out of the component's pool by an atomic bump.
+// So: one wave per flubble that has records or takes a vertex in (k_sub_splice_cn); the flubbles that got a concealed child
+// are flagged instead of listed.  find_midi looks at each of them (k_sub_midi_find, all before the first is added, as in the
+// reference), a scan over their flags numbers the midi bubbles in ascending idx, k_sub_midi_add attaches them; add_smothered
+// works on the vector of one concealed vertex (k_sub_smothered, one wave per concealed vertex that has records).
+struct SpliceArgs {
+	SubT t;
+	CompAt comp;
+	const uint32_t *xoff, *poff;
+	uint32_t *ptop; // [C] bump pointers
+	const uint32_t *cn_off;
+	const Slub *cn;
+	const uint32_t *mn;
+	const uint32_t *smo_off;
+	const Smo *smo;
+	XArrays X;
+	uint32_t *pin;	  // [Q] the concealed vertex the parent's records push into the vector of this one (NIL: none)
+	uint8_t *act;	  // [Q] has records or takes a vertex in
+	uint8_t *touched; // [Q] got a concealed vertex as a child
+	uint8_t *md;	  // [Q] gets a midi bubble
+	const uint32_t *md_ps; // [Q + 1] exclusive scan of md
+};
+// what the nestings of add_concealed ask of a child of the flubble (ai, zi, n_of_f) for the slubble sl
+__device__ bool cn_leaves(const SubT &t, const XArrays &X, uint32_t xb, const Slub &sl, uint32_t ai, uint32_t zi, uint32_t n_of_f, uint32_t ch)
 {
-	const uint32_t c = blockIdx.x, lane = threadIdx.x;
-	if (c >= C)
-		return;
-	const uint32_t n0 = t.c_npvst[c];
-	if (lane == 0)
-		counts[3 * c] = counts[3 * c + 1] = counts[3 * c + 2] = 0;
-	if (!n0)
-		return;
-	const uint32_t q0 = t.doff[c], base = t.base_of(c), N = t.c_ntree[c];
-	Splice S{X, xoff[c], poff[c], poff[c + 1], t.err, lane};
-	const uint32_t xb = S.xb, cap_x = xoff[c + 1] - xoff[c];
-	// (the vertices of find_flubbles and their children vectors are in place: k_sub_x_init .. k_sub_x_place)  Behind them in
-	// the pool: the list of the flubbles that got a concealed vertex as a child (find_midi looks at no others)
-	S.pool_top += n0 - 1;
-	uint32_t *touched = X.pool + S.pool_top;
-	uint32_t n_touched = 0;
-	S.pool_top += n0;
-	if (S.pool_top > S.pool_end) {
-		if (lane == 0)
-			atomicOr(t.err, E_POOL);
-		return;
+	const uint8_t fam = X.fam[xb + ch];
+	if (!(fam == FAM_FLUBBLE || fam == FAM_TINY || fam == FAM_PARALLEL))
+		return false;
+	const uint32_t c_ai = X.ai[xb + ch], c_zi = X.zi[xb + ch];
+	if (sl.loc == CL_AI_TRUNK) // nest_trunk_ai, :945-979
+		return t.depth[sl.sl] > t.depth[c_zi] || t.is_desc(sl.sl, c_ai);
+	if (sl.loc == CL_AI_BRANCH) { // nest_branch_ai, :984-1034
+		bool has_br = false;  // a bracket of the child's zi that STARTS at ai (sic: get_src, :1006)
+		SubT::BrRange br = t.brackets(c_zi);
+		for (uint32_t e = t.br_next(br); e != NIL && !has_br; e = t.br_next(br))
+			has_br = t.b_src[e] == ai;
+		return t.is_desc(sl.sl, c_ai) && has_br;
 	}
-	auto touch = [&](uint32_t f) {
-		if (!X.loc[xb + f]) {
-			S.sync(); // (every lane has read the flag)
-			if (lane == 0) {
-				X.loc[xb + f] = 1;
-				touched[n_touched] = f;
-			}
-			n_touched++;
-			S.sync();
-		}
-	};
-	uint32_t nx = n0; // vertices so far
-	auto new_vertex = [&](uint8_t fam) -> uint32_t { // (the caller synchronises once it has filled the vertex in)
-		if (nx >= cap_x) {
-			if (lane == 0)
-				atomicOr(t.err, E_LAYOUT);
-			return NIL;
-		}
-		if (lane == 0) {
-			const uint32_t x = xb + nx;
-			X.fam[x] = fam;
-			X.vn[x] = X.vcap[x] = 0;
-			X.vbeg[x] = 0;
-			X.ai[x] = X.zi[x] = X.sl[x] = X.b_up[x] = X.b_lo[x] = NIL;
-			X.loc[x] = 0;
-		}
-		return nx++;
-	};
-	// ---- add_concealed, concealed.cpp:925-1196, flubbles in ascending idx
-	const uint32_t cn_b = cn_off[q0], cn_e = cn_off[q0 + n0];
-	for (uint32_t k = cn_b; k < cn_e;) {
-		const uint32_t q = cn[k].q, f = q - q0;
-		uint32_t ke = k;
-		while (ke < cn_e && cn[ke].q == q)
-			ke++;
-		const uint32_t ai = X.ai[xb + f], zi = X.zi[xb + f], n_of_f = mn[2 * (size_t)q + 1];
-		const bool is_leaf = f < N && t.nchild[base + f] == 0; // (sic) the SPANNING TREE's vertex f, concealed.cpp:1188
-		for (; k < ke; k++) {
-			const Slub sl = cn[k];
-			const uint32_t v = new_vertex(FAM_CONCEALED);
-			if (v == NIL)
-				return;
-			if (lane == 0) {
-				const uint32_t x = xb + v;
-				// gen_ai_slubble, concealed.cpp:70-152 / gen_zi_slubble, :154-206
-				const bool sl_r = (t.flags[sl.sl] & TF_TYPE_MASK) == 1u, black = (t.flags[sl.sl] & TF_BLACK) != 0;
-				uint32_t fl_id;
-				uint8_t fl_o;
-				const uint32_t sl_id = t.gid[sl.sl];
-				X.loc[x] = (uint8_t)sl.loc;
-				X.sl[x] = sl.sl;
-				if (sl.loc == CL_AI_TRUNK || sl.loc == CL_AI_BRANCH) {
-					side_id_or(t, ai, true, fl_id, fl_o);
-					const bool fwd_if_r = (sl.loc == CL_AI_TRUNK) == black;
-					const uint8_t sl_o = (sl_r == fwd_if_r) ? 0 : 1;
-					if (sl_o == 1 && fl_o == 1) {
-						X.id1[x] = sl_id, X.or1[x] = 0;
-						X.id2[x] = fl_id, X.or2[x] = 0;
-					} else {
-						X.id1[x] = fl_id, X.or1[x] = fl_o;
-						X.id2[x] = sl_id, X.or2[x] = sl_o;
+	// nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
+	return t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi);
+}
+__global__ void k_sub_ptop(uint32_t C, const uint32_t *__restrict__ poff, const uint32_t *__restrict__ c_npvst, uint32_t *__restrict__ ptop)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < C) // (the vectors of find_flubbles' vertices are in place: k_sub_x_init .. k_sub_x_place)
+		ptop[c] = poff[c] + (c_npvst[c] ? c_npvst[c] - 1 : 0u);
+}
+__global__ void k_sub_pin(uint32_t Q, const SpliceArgs A)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= Q)
+		return;
+	const SubT &t = A.t;
+	const uint32_t c = A.comp.of_slot(q), q0 = t.doff[c], ch = q - q0;
+	uint32_t pin = NIL;
+	const bool own = A.cn_off[q + 1] != A.cn_off[q];
+	if (ch) { // (the root has no parent)
+		const uint32_t f = t.p_parent[q], qf = q0 + f;
+		const uint32_t kb = A.cn_off[qf], ke = A.cn_off[qf + 1];
+		if (kb != ke) {
+			const uint32_t xb = A.xoff[c], base = t.base_of(c), N = t.c_ntree[c], n0 = t.c_npvst[c], cn_b = A.cn_off[q0];
+			const bool is_leaf = f < N && t.nchild[base + f] == 0; // (sic) the SPANNING TREE's vertex f, concealed.cpp:1188
+			if (!is_leaf) {
+				const uint32_t ai = A.X.ai[xb + f], zi = A.X.zi[xb + f], n_of_f = A.mn[2 * (size_t)qf + 1];
+				for (uint32_t k = kb; k < ke; k++) {
+					const Slub sl = A.cn[k];
+					if (sl.loc == CL_ZI_BRANCH)
+						continue;
+					if (cn_leaves(t, A.X, xb, sl, ai, zi, n_of_f, ch)) { // this record takes it out of f's vector
+						if (sl.loc == CL_ZI_TRUNK)
+							pin = n0 + (k - cn_b);
+						break;
 					}
-					X.route[x] = 'R';
-					if (sl.loc == CL_AI_TRUNK) {
-						if (t.is_desc(ai, sl.be_src))
-							X.b_up[x] = ai, X.b_lo[x] = sl.be_src;
-						else
-							X.b_up[x] = sl.be_src, X.b_lo[x] = ai;
-					} else {
-						X.b_up[x] = sl.sl, X.b_lo[x] = NIL;
-					}
-				} else {
-					side_id_or(t, zi, false, fl_id, fl_o);
-					const uint8_t sl_o = (sl_r == black) ? 0 : 1;
-					X.id1[x] = sl_id, X.or1[x] = (sl_o == 1 && fl_o == 1) ? 0 : sl_o;
-					X.id2[x] = fl_id, X.or2[x] = (sl_o == 1 && fl_o == 1) ? 0 : fl_o;
-					X.route[x] = 'L';
-					if (t.is_desc(zi, sl.sl))
-						X.b_up[x] = zi, X.b_lo[x] = sl.sl;
-					else
-						X.b_up[x] = sl.sl, X.b_lo[x] = zi;
 				}
 			}
-			S.sync();
-			if (!S.push(f, v))
-				return;
-			touch(f);
-			if (is_leaf || sl.loc == CL_ZI_BRANCH) // zi_branch: add_conc_zi asks for ai_branch (:1134) and ends in "sl type: unknown"
-				continue;
-			// the nestings: which of the children (the new vertex among them: it is no flubble) leave for the slubble
-			const uint32_t nch = X.vn[xb + f];
-			const bool ok = S.filter(
-				f, nch, v, sl.loc == CL_ZI_TRUNK,
-				[&](uint32_t ch) {
-					if (!S.fl_like(ch))
-						return false;
-					const uint32_t c_ai = X.ai[xb + ch], c_zi = X.zi[xb + ch];
-					if (sl.loc == CL_AI_TRUNK) // nest_trunk_ai, :945-979
-						return t.depth[sl.sl] > t.depth[c_zi] || t.is_desc(sl.sl, c_ai);
-					if (sl.loc == CL_AI_BRANCH) { // nest_branch_ai, :984-1034
-						bool has_br = false;  // a bracket of the child's zi that STARTS at ai (sic: get_src, :1006)
-						SubT::BrRange br = t.brackets(c_zi);
-						for (uint32_t e = t.br_next(br); e != NIL && !has_br; e = t.br_next(br))
-							has_br = t.b_src[e] == ai;
-						return t.is_desc(sl.sl, c_ai) && has_br;
-					}
-					// nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
-					return t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi);
-				},
-				touch);
-			if (!ok)
-				return;
 		}
 	}
-	const uint32_t n_cn = nx - n0;
-	// ---- find_midi, midi.cpp:225-268 (the branch case is undefined in the reference: nothing comes of it), add_midi :19-61
-	const uint32_t n1 = nx;
-	if (lane == 0)
-		sort_row(touched, n_touched, [](uint32_t a, uint32_t b) { return a < b; });
-	S.sync();
-	for (uint32_t k_t = 0; k_t < n_touched; k_t++) {
-		const uint32_t f = touched[k_t];
+	A.pin[q] = pin;
+	A.act[q] = (own || pin != NIL) ? 1 : 0;
+	A.touched[q] = 0;
+	A.md[q] = 0;
+}
+static constexpr unsigned SPLICE_WAVES = 8192; // waves of a splice kernel: each takes every SPLICE_WAVES-th entry of its list
+// ---- add_concealed, concealed.cpp:925-1196: one wave per flubble on the list
+__global__ void __launch_bounds__(64) k_sub_splice_cn(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const SpliceArgs A)
+{
+	const SubT &t = A.t;
+	const XArrays &X = A.X;
+	const uint32_t lane = threadIdx.x, n = *n_list;
+	for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+		const uint32_t q = list[it], c = A.comp.of_slot(q), q0 = t.doff[c], n0 = t.c_npvst[c], f = q - q0;
+		const uint32_t base = t.base_of(c), N = t.c_ntree[c], cn_b = A.cn_off[q0];
+		Splice S{X, A.xoff[c], A.ptop + c, A.poff[c + 1], t.err, lane};
+		const uint32_t xb = S.xb, pin = A.pin[q], par = f ? t.p_parent[q] : 0u;
+		bool got = false;
+		if (pin != NIL && par < f) { // pushed by the parent's turn, which came first (a parent has the smaller idx)
+			if (!S.push(f, pin))
+				return;
+			got = true;
+		}
+		const uint32_t kb = A.cn_off[q], ke = A.cn_off[q + 1];
+		if (kb != ke) {
+			const uint32_t ai = X.ai[xb + f], zi = X.zi[xb + f], n_of_f = A.mn[2 * (size_t)q + 1];
+			const bool is_leaf = f < N && t.nchild[base + f] == 0; // (sic) the SPANNING TREE's vertex f, concealed.cpp:1188
+			for (uint32_t k = kb; k < ke; k++) {
+				const Slub sl = A.cn[k];
+				const uint32_t v = n0 + (k - cn_b); // the k-th slubble of the component becomes its k-th concealed vertex
+				if (lane == 0) {
+					const uint32_t x = xb + v;
+					X.fam[x] = FAM_CONCEALED;
+					X.vn[x] = X.vcap[x] = 0;
+					X.vbeg[x] = 0;
+					X.ai[x] = X.zi[x] = NIL;
+					// gen_ai_slubble, concealed.cpp:70-152 / gen_zi_slubble, :154-206
+					const bool sl_r = (t.flags[sl.sl] & TF_TYPE_MASK) == 1u, black = (t.flags[sl.sl] & TF_BLACK) != 0;
+					uint32_t fl_id;
+					uint8_t fl_o;
+					const uint32_t sl_id = t.gid[sl.sl];
+					X.loc[x] = (uint8_t)sl.loc;
+					X.sl[x] = sl.sl;
+					if (sl.loc == CL_AI_TRUNK || sl.loc == CL_AI_BRANCH) {
+						side_id_or(t, ai, true, fl_id, fl_o);
+						const bool fwd_if_r = (sl.loc == CL_AI_TRUNK) == black;
+						const uint8_t sl_o = (sl_r == fwd_if_r) ? 0 : 1;
+						if (sl_o == 1 && fl_o == 1) {
+							X.id1[x] = sl_id, X.or1[x] = 0;
+							X.id2[x] = fl_id, X.or2[x] = 0;
+						} else {
+							X.id1[x] = fl_id, X.or1[x] = fl_o;
+							X.id2[x] = sl_id, X.or2[x] = sl_o;
+						}
+						X.route[x] = 'R';
+						if (sl.loc == CL_AI_TRUNK) {
+							if (t.is_desc(ai, sl.be_src))
+								X.b_up[x] = ai, X.b_lo[x] = sl.be_src;
+							else
+								X.b_up[x] = sl.be_src, X.b_lo[x] = ai;
+						} else {
+							X.b_up[x] = sl.sl, X.b_lo[x] = NIL;
+						}
+					} else {
+						side_id_or(t, zi, false, fl_id, fl_o);
+						const uint8_t sl_o = (sl_r == black) ? 0 : 1;
+						X.id1[x] = sl_id, X.or1[x] = (sl_o == 1 && fl_o == 1) ? 0 : sl_o;
+						X.id2[x] = fl_id, X.or2[x] = (sl_o == 1 && fl_o == 1) ? 0 : fl_o;
+						X.route[x] = 'L';
+						if (t.is_desc(zi, sl.sl))
+							X.b_up[x] = zi, X.b_lo[x] = sl.sl;
+						else
+							X.b_up[x] = sl.sl, X.b_lo[x] = zi;
+					}
+				}
+				S.sync();
+				if (!S.push(f, v))
+					return;
+				got = true;
+				if (is_leaf || sl.loc == CL_ZI_BRANCH) // zi_branch: add_conc_zi asks for ai_branch (:1134) and ends in "sl type: unknown"
+					continue;
+				// the nestings: which of the children (the new vertex among them: it is no flubble) leave for the slubble
+				const uint32_t nch = X.vn[xb + f];
+				if (!S.filter(f, nch, v, sl.loc == CL_ZI_TRUNK, [&](uint32_t ch) { return cn_leaves(t, X, xb, sl, ai, zi, n_of_f, ch); }))
+					return;
+			}
+		}
+		if (pin != NIL && par >= f) { // (never, with the PVST numbered parents first; the order of the reference all the same)
+			if (!S.push(f, pin))
+				return;
+			got = true;
+		}
+		if (got && lane == 0)
+			A.touched[q] = 1; // find_midi looks at it
+		S.sync();
+	}
+}
+// ---- find_midi, midi.cpp:225-268 (the branch case is undefined in the reference: nothing comes of it): one wave per
+// flubble that got a concealed vertex as a child
+__global__ void __launch_bounds__(64) k_sub_midi_find(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const SpliceArgs A)
+{
+	const SubT &t = A.t;
+	const XArrays &X = A.X;
+	const uint32_t lane = threadIdx.x, n = *n_list;
+	for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+		const uint32_t q = list[it], c = A.comp.of_slot(q), f = q - t.doff[c], xb = A.xoff[c];
 		if (X.fam[xb + f] != FAM_FLUBBLE)
 			continue;
 		uint32_t n_c = 0, n_trunk = 0, trunk[2] = {NIL, NIL};
@@ -1314,25 +1360,38 @@ __global__ void __launch_bounds__(64) k_sub_splice(uint32_t C, const SubT t, con
 		}
 		if (g_idx == NIL || s_idx == NIL)
 			continue;
-		// (all midi bubbles are found before the first is added: remember the pair in the flubble's spare fields)
+		// (all midi bubbles are found before the first is added: the pair is remembered in the flubble's spare fields)
 		if (lane == 0) {
 			X.b_up[xb + f] = g_idx;
 			X.b_lo[xb + f] = s_idx;
+			A.md[q] = 1;
 		}
 	}
-	S.sync();
-	for (uint32_t k_t = 0; k_t < n_touched; k_t++) {
-		const uint32_t f = touched[k_t];
-		if (X.fam[xb + f] != FAM_FLUBBLE || X.b_up[xb + f] == NIL)
+}
+// ---- add_midi, midi.cpp:19-61: the flubbles in ascending idx get the vertices behind the concealed ones
+__global__ void __launch_bounds__(64) k_sub_midi_add(const uint32_t *__restrict__ n_list, const uint32_t *__restrict__ list, const SpliceArgs A)
+{
+	const SubT &t = A.t;
+	const XArrays &X = A.X;
+	const uint32_t lane = threadIdx.x, n = *n_list;
+	for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+		const uint32_t q = list[it];
+		if (!A.md[q])
 			continue;
+		const uint32_t c = A.comp.of_slot(q), q0 = t.doff[c], n0 = t.c_npvst[c], f = q - q0, base = t.base_of(c), N = t.c_ntree[c];
+		Splice S{X, A.xoff[c], A.ptop + c, A.poff[c + 1], t.err, lane};
+		const uint32_t xb = S.xb;
 		const uint32_t g_idx = X.b_up[xb + f], s_idx = X.b_lo[xb + f];
 		const uint32_t up = min(g_idx, s_idx), lo = max(g_idx, s_idx);
 		const uint32_t nch = X.vn[xb + f]; // children before the midi bubble is attached
-		const uint32_t v = new_vertex(FAM_MIDI);
-		if (v == NIL)
-			return;
+		const uint32_t v = n0 + (A.cn_off[q0 + n0] - A.cn_off[q0]) + (A.md_ps[q] - A.md_ps[q0]);
 		if (lane == 0) {
 			const uint32_t x = xb + v;
+			X.fam[x] = FAM_MIDI;
+			X.vn[x] = X.vcap[x] = 0;
+			X.vbeg[x] = 0;
+			X.ai[x] = X.zi[x] = X.sl[x] = NIL;
+			X.loc[x] = 0;
 			// cn_b of a concealed vertex: the second boundary when it was formed with a, the first with z (Concealed::as_str)
 			X.id1[x] = X.id2[xb + g_idx], X.or1[x] = X.or2[xb + g_idx];
 			X.id2[x] = X.id1[xb + s_idx], X.or2[x] = X.or1[xb + s_idx];
@@ -1343,28 +1402,42 @@ __global__ void __launch_bounds__(64) k_sub_splice(uint32_t C, const SubT t, con
 		// (sic) spanning-tree depths at the PVST indices of the two concealed vertices; past the tree: +infinity
 		const uint32_t d_up = up < N ? t.dep(base + up) : 0xFFFFFFFFu, d_lo = lo < N ? t.dep(base + lo) : 0xFFFFFFFFu;
 		// the children before the bubble (a copy in the reference) are filtered, then the bubble itself goes behind them
-		const bool ok = S.filter(
-			f, nch, v, false,
-			[&](uint32_t ch) { return X.fam[xb + ch] == FAM_FLUBBLE && d_up < t.depth[X.ai[xb + ch]] && d_lo > t.depth[X.zi[xb + ch]]; },
-			touch);
+		const bool ok = S.filter(f, nch, v, false, [&](uint32_t ch) {
+			return X.fam[xb + ch] == FAM_FLUBBLE && d_up < t.depth[X.ai[xb + ch]] && d_lo > t.depth[X.zi[xb + ch]];
+		});
 		if (!ok || !S.push(f, v))
 			return;
 	}
-	const uint32_t n_md = nx - n1;
-	// ---- add_smothered, smothered.cpp:349-383: the concealed vertices in ascending idx, their records in search order
-	const uint32_t n2 = nx;
-	for (uint32_t k = cn_b; k < cn_e; k++) {
+}
+// ---- add_smothered, smothered.cpp:349-383: one wave per concealed vertex, its records in search order
+__global__ void __launch_bounds__(64) k_sub_smothered(uint32_t NC, const SpliceArgs A)
+{
+	const SubT &t = A.t;
+	const XArrays &X = A.X;
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t k = blockIdx.x; k < NC; k += gridDim.x) {
+		const uint32_t rb = A.smo_off[k], re = A.smo_off[k + 1];
+		if (rb == re)
+			continue;
+		const uint32_t q = A.cn[k].q, c = A.comp.of_slot(q), q0 = t.doff[c], n0 = t.c_npvst[c];
+		const uint32_t cn_b = A.cn_off[q0], cn_e = A.cn_off[q0 + n0];
+		Splice S{X, A.xoff[c], A.ptop + c, A.poff[c + 1], t.err, lane};
+		const uint32_t xb = S.xb;
 		const uint32_t cv = n0 + (k - cn_b); // the k-th slubble became the k-th concealed vertex
-		const bool is_g = cn[k].loc == CL_AI_TRUNK || cn[k].loc == CL_AI_BRANCH;
+		const uint32_t v0 = n0 + (cn_e - cn_b) + (A.md_ps[q0 + n0] - A.md_ps[q0]) - A.smo_off[cn_b]; // + r: behind the midi bubbles, in search order
+		const bool is_g = A.cn[k].loc == CL_AI_TRUNK || A.cn[k].loc == CL_AI_BRANCH;
 		const uint32_t cnb_id = is_g ? X.id2[xb + cv] : X.id1[xb + cv];
 		const uint8_t cnb_or = is_g ? X.or2[xb + cv] : X.or1[xb + cv];
-		for (uint32_t r = smo_off[k]; r < smo_off[k + 1]; r++) {
-			const Smo m = smo[r];
-			const uint32_t v = new_vertex(FAM_SMOTHERED);
-			if (v == NIL)
-				return;
+		for (uint32_t r = rb; r < re; r++) {
+			const Smo m = A.smo[r];
+			const uint32_t v = v0 + r;
 			if (lane == 0) {
 				const uint32_t x = xb + v;
+				X.fam[x] = FAM_SMOTHERED;
+				X.vn[x] = X.vcap[x] = 0;
+				X.vbeg[x] = 0;
+				X.ai[x] = X.zi[x] = X.sl[x] = NIL;
+				X.loc[x] = 0;
 				const uint32_t sm_id = t.gid[m.sm_st];
 				const uint8_t sm_or = (t.flags[m.sm_st] & TF_TYPE_MASK) == 0u ? 1 : 0; // comp_e / comp_w: type l -> reverse
 				if ((m.flags & 2u) && (m.flags & 1u)) { // Smothered::as_str, pvst.hpp:612-636
@@ -1402,11 +1475,21 @@ __global__ void __launch_bounds__(64) k_sub_splice(uint32_t C, const SubT t, con
 			}
 		}
 	}
-	if (lane == 0) {
-		counts[3 * c] = n_cn;
-		counts[3 * c + 1] = n_md;
-		counts[3 * c + 2] = nx - n2;
+}
+__global__ void k_sub_counts(uint32_t C, const SpliceArgs A, uint32_t *__restrict__ counts)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	const uint32_t n0 = A.t.c_npvst[c], q0 = A.t.doff[c];
+	uint32_t n_cn = 0, n_md = 0, n_sm = 0;
+	if (n0) {
+		const uint32_t cn_b = A.cn_off[q0], cn_e = A.cn_off[q0 + n0];
+		n_cn = cn_e - cn_b;
+		n_md = A.md_ps[q0 + n0] - A.md_ps[q0];
+		n_sm = A.smo_off[cn_e] - A.smo_off[cn_b];
 	}
+	counts[3 * c] = n_cn, counts[3 * c + 1] = n_md, counts[3 * c + 2] = n_sm;
 }
 // sizes of the final children lists (one lane per X slot), then the lists themselves into one compact array
 __global__ void k_sub_child_counts(uint32_t NX, const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ counts,
@@ -1652,8 +1735,31 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	}
 	mark("layout, PVST vectors");
 	uint32_t *counts = dev32(3 * (size_t)C + 4);
-	if (C)
-		KLAUNCH(k_sub_splice, dim3(C), dim3(64), 0, s, C, t, xoff, poff, cn_off, cn, mn, sm_off, smo, X, counts);
+	if (C && Q) {
+		SpliceArgs A{};
+		A.t = t, A.comp = comp_q, A.xoff = xoff, A.poff = poff, A.ptop = dev32((size_t)C + 4);
+		A.cn_off = cn_off, A.cn = cn, A.mn = mn, A.smo_off = sm_off, A.smo = smo, A.X = X;
+		A.pin = dev32((size_t)Q + 4);
+		A.act = dev8((size_t)Q + 16), A.touched = dev8((size_t)Q + 16), A.md = dev8((size_t)Q + 16);
+		uint32_t *md_ps = dev32((size_t)Q + 8), *list = dev32((size_t)Q + 8), *n_list = dev32(8);
+		A.md_ps = md_ps;
+		const size_t ctmp_bytes = compact_tmp_bytes((size_t)Q + 8);
+		void *ctmp = bufs.emplace_back().get<char>(ctmp_bytes, arena, need);
+		LAUNCH(k_sub_ptop, C, s, C, poff, sw.c_npvst, A.ptop);
+		LAUNCH(k_sub_pin, Q, s, Q, A);
+		compact_flagged_u8(A.act, Q, list, n_list, ctmp, ctmp_bytes, s);
+		KLAUNCH(k_sub_splice_cn, dim3(SPLICE_WAVES), dim3(64), 0, s, n_list, list, A);
+		compact_flagged_u8(A.touched, Q, list, n_list, ctmp, ctmp_bytes, s);
+		KLAUNCH(k_sub_midi_find, dim3(SPLICE_WAVES), dim3(64), 0, s, n_list, list, A);
+		HIP_CHECK(hipMemsetAsync(A.md + Q, 0, 1, s));
+		scan_exclusive_u8(A.md, md_ps, (size_t)Q + 1, nullptr, nullptr, 0, tmp, tmp_bytes, s);
+		KLAUNCH(k_sub_midi_add, dim3(SPLICE_WAVES), dim3(64), 0, s, n_list, list, A);
+		if (NS)
+			KLAUNCH(k_sub_smothered, dim3(std::min<unsigned>(NC, SPLICE_WAVES)), dim3(64), 0, s, NC, A);
+		LAUNCH(k_sub_counts, C, s, C, A, counts);
+	} else if (C) {
+		HIP_CHECK(hipMemsetAsync(counts, 0, 3 * (size_t)C * 4, s));
+	}
 	mark("splice");
 	const uint32_t e = host.read_u32(err, s);
 	if (e & E_POOL)

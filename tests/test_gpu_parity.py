@@ -425,7 +425,7 @@ def test_both_local_adjacency_builders(hip, seed):
     assert hip.decompose(flags=F_SORTED_ADJ).texts() == want
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 8192, 100003, 4 * 1024 * 1024 + 5, 30_000_001])
+@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 100003, 64 * 8192, 64 * 8192 + 1, 65 * 8192 + 7, 4 * 1024 * 1024 + 5, 30_000_001])
 def test_single_pass_scans(hip, n):
     """The device-wide exclusive scans against numpy: sum mod 2^32, running maximum, and two independent
     scans sharing their launches."""
