@@ -159,7 +159,22 @@ public:
 	{
 		for (auto &c : chunks_)
 			(void)hipHostFree(c.p);
+		if (ev_)
+			(void)hipEventDestroy(ev_);
 	}
+	HostScratch() = default;
+	HostScratch(const HostScratch &) = delete;
+	HostScratch &operator=(const HostScratch &) = delete;
+	// Words a kernel published into a span of this scratch (publish_words, or a kernel that writes page-locked memory itself)
+	// are read WITHOUT leaving the stream idle: mark() right behind the publishing kernel, then the stream is given the
+	// kernels that do not depend on the words, then wait() -- the host wakes up while they run.
+	void mark(hipStream_t s)
+	{
+		if (!ev_)
+			HIP_CHECK(hipEventCreateWithFlags(&ev_, hipEventDisableTiming));
+		HIP_CHECK(hipEventRecord(ev_, s));
+	}
+	void wait() { HIP_CHECK(hipEventSynchronize(ev_)); }
 	void reset()
 	{
 		for (auto &c : chunks_)
@@ -195,6 +210,7 @@ private:
 		size_t cap, top;
 	};
 	std::vector<Chunk> chunks_;
+	hipEvent_t ev_ = nullptr;
 };
 
 // HIP-event stage timer on the context's stream.

@@ -352,7 +352,10 @@ __global__ void __launch_bounds__(TPB) k_flag_tile_counts(uint32_t T, const uint
 }
 // Four vertices a lane (16-byte loads: a kernel of a few loads per element is bound by its memory INSTRUCTIONS), so a
 // wave covers exactly one tile of 256 vertices and ranks its flags with eight ballots; no LDS, no barrier.
-__global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0, uint32_t ncap, const uint8_t *__restrict__ capf,
+// (the counts it places by -- ordinary back edges, capping vertices -- are read from the device: the kernel is launched
+// before the host has them, see the driver)
+__global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0_host, const uint32_t *__restrict__ nb0_dev, uint32_t ntiles,
+							uint32_t nb_cap, const uint8_t *__restrict__ capf,
 							const uint32_t *__restrict__ tcap, const uint8_t *__restrict__ simp,
 							const uint32_t *__restrict__ tsimp, const uint32_t *__restrict__ cap_tgt,
 							const RootOf root_of, uint32_t *__restrict__ b_src, uint32_t *__restrict__ b_tgt,
@@ -360,6 +363,9 @@ __global__ void __launch_bounds__(TPB) k_bracket_extra(uint32_t T, uint32_t NB0,
 							const uint32_t *__restrict__ mpre, uint32_t *__restrict__ incnt,
 							uint32_t *__restrict__ srccnt)
 {
+	const uint32_t NB0 = nb0_dev ? *nb0_dev : NB0_host, ncap = tcap[ntiles];
+	if ((uint64_t)NB0 + ncap + tsimp[ntiles] > nb_cap)
+		return; // (an internal sizing bug: the host throws when it reads the counts; nothing is written out of bounds)
 	const uint32_t v0 = (BIDX * blockDim.x + threadIdx.x) * 4u, lane = threadIdx.x & 63u, tile = v0 / BX_TILE;
 	uint32_t cw = 0, sw = 0; // the four flag bytes of this lane
 	if (v0 + 4 <= T) {
@@ -1355,7 +1361,15 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint32_t *srccnt = pw.dlt, *bstart = pw.dlt_ps; // free until row E
 	uint32_t *extra = pw.host->take<uint32_t>(4);
 	publish_words(extra, WordSrc{{tcap + ntiles, tsimp + ntiles, pw.err + 5, pw.err + 6}}, 4, s); // counts | literal-rule flag | back edges of the tree stage
-	HIP_CHECK(hipStreamSynchronize(s));
+	// The stream is not left idle while the host reads them (HostScratch::mark): the kernel that places the capping and
+	// simplifying brackets takes the counts from the device, and the scan behind it does not need them at all.
+	pw.host->mark(s);
+	LAUNCH(k_bracket_extra, ((size_t)T + 3) / 4, s, T, NB0, dense_nb0 == NB0_ON_DEVICE ? pw.err + 6 : nullptr, ntiles,
+	       (uint32_t)std::min<size_t>(pw.nb_cap, 0xFFFFFFFFu), capf, tcap, simp, tsimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
+	       dense_nb0 >= 0 ? pw.lsz : nullptr, pw.gsize, pw.mpre, pw.incnt, srccnt);
+	if (dense_nb0 >= 0) // ranks inside every source and the counts per source are known: place directly
+		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
+	pw.host->wait();
 	if (dense_nb0 == NB0_ON_DEVICE) {
 		NB0 = extra[3];
 		if (NB0 > pw.nb_cap)
@@ -1381,10 +1395,7 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	// both take the all-vertices pass.
 	const bool black_only = !want_hp && !pw.all_vertex_classes && extra[2] == 0;
 	pw.black_only_used = black_only;
-	LAUNCH(k_bracket_extra, ((size_t)T + 3) / 4, s, T, NB0, ncap, capf, tcap, simp, tsimp, pw.cap_tgt, root_of, pw.b_src, pw.b_tgt,
-	       dense_nb0 >= 0 ? pw.lsz : nullptr, pw.gsize, pw.mpre, pw.incnt, srccnt);
-	if (dense_nb0 >= 0) { // ranks inside every source and the counts per source are known: place directly
-		scan2(pw.incnt, pw.psin, (size_t)T + 1, srccnt, bstart, (size_t)T + 1);
+	if (dense_nb0 >= 0) {
 		LAUNCH(k_bracket_place, NB, s, NB, NB0, ncap, pw.b_src, pw.b_tgt, pw.b_ord, pw.mpre, bstart, capf, simp, pw.tgtR,
 		       want_hp ? pw.b_val2 : nullptr);
 	} else {
@@ -1470,16 +1481,41 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	uint32_t *early = pw.host->take<uint32_t>(5 * (size_t)C + 8);
 	count_kernel_d2h((5 * (size_t)C + 8) * 4);
 	pass_summary(sw, &pw, C, early, s);
-	HIP_CHECK(hipStreamSynchronize(s));
+	const bool use_side = S && side.stream;
+	if (use_side) // (everything the endpoints need is computed: the side stream starts from here)
+		HIP_CHECK(hipEventRecord(side.fork, s));
+	// The stream is not left idle while the host reads the PVST count (HostScratch::mark): levels and parents of the
+	// flubbles need the stack only, their kernels go out first.
+	pw.host->mark(s);
+	// The (prev, i) intervals of exact cycle-equivalence classes never cross ("Row G"): the laminarity
+	// check is only needed when the literal hi_2 rule capped differently from the second-highest reach (extra[2]), i.e. when
+	// the classes may not be the exact ones -- or when a caller asks for it.  Without it nothing that follows can flag a
+	// component: the summary the host is about to read is the final one.
+	pw.laminar_checked = pw.check_laminar || extra[2] != 0;
+	uint8_t *xflag = pw.f8d; // [T + 32] >= S (the branching flags are long compacted)
+	if (pw.laminar_checked) {
+		seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
+		HIP_CHECK(hipMemsetAsync(xflag, 0, (size_t)S + 1, s));
+	}
+	LAUNCH(k_laminar_walk, ((size_t)S + 3) / 4, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, xflag, dflag, pw.walk);
+	if (pw.laminar_checked && S) { // the entries whose interval is crossed: decided in stack order, U undone where the class was popped
+		uint32_t *xlist = pw.wrun, *n_x = pw.err + 11, *n_crossed = pw.err + 12; // (wrun is written by the max-scan below; err words cleared at the start of the pass)
+		compact_flagged_u8(xflag, S, xlist, n_x, pw.scan_tmp, pw.scan_tmp_bytes, s);
+		KLAUNCH(k_resolve_crossings, dim3(std::min<unsigned>(nblk(C), 1024)), dim3(TPB), 0, s, C, pw.soff, n_x, xlist, pw.prev, pw.segP, xflag,
+			pw.walk, n_crossed);
+	}
+	scan(pw.walk, pw.walk_ps, (size_t)S);
+	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
+	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
+	LAUNCH(k_walk_bias, ((size_t)S + 3) / 4, s, S, pw.walk, pw.walk_ps, wb, wneg);
+	scan_exclusive_max_u32(wneg, wrun, (size_t)S, pw.scan_tmp, pw.scan_tmp_bytes, s);
+	LAUNCH(k_levels, ((size_t)S + 3) / 4, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
+	pw.host->wait();
 	const size_t total = early[4 + 4 * (size_t)C + C]; // doff[C] = flubbles + one root per processed component
 	if (total < n_processed || total - n_processed > S)
 		throw HipError("internal error: PVST size out of range");
 	const uint32_t NE = (uint32_t)(total - n_processed);
 	pw.n_emitted = NE;
-	// The laminarity check only runs when the literal hi_2 rule capped differently from the second-highest reach (extra[2]),
-	// i.e. when the classes may not be the exact ones ("Row G") -- or when a caller asks for it.  Without
-	// it nothing that follows can flag a component: the summary just read is the final one.
-	pw.laminar_checked = pw.check_laminar || extra[2] != 0;
 	tail.early_summary = early;
 	tail.summary_final = true; // (nothing after the count flags a component any more: crossings are resolved in place)
 	tail.overlapped = tail.want_overlap && tail.summary_final;
@@ -1500,42 +1536,22 @@ void run_parallel_dg(const CompState &cs, SeqWs &sw, ParWs &pw, uint32_t C, uint
 	pw.d_aor = reinterpret_cast<uint8_t *>(blk + 3 * p4);
 	pw.d_zor = reinterpret_cast<uint8_t *>(blk + 3 * p4 + p1);
 	pw.d_total = total;
-	LAUNCH(k_pvst_roots, (size_t)C, s, C, sw.c_ntree, pw.doff, pw.d_parent, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
-	const bool use_side = S && side.stream;
 	if (use_side) {
-		HIP_CHECK(hipEventRecord(side.fork, s));
+		// (the roots' slots with the endpoints: the copies behind them take whole arrays)
 		HIP_CHECK(hipStreamWaitEvent(side.stream, side.fork, 0));
+		KLAUNCH(k_pvst_roots, dim3(nblk((size_t)C)), dim3(TPB), 0, side.stream, C, sw.c_ntree, pw.doff, pw.d_parent, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 		KLAUNCH(k_emit_endpoints, dim3(staged ? nblk((S + 3) / 4) : std::min<unsigned>(nblk((S + 3) / 4), 160)), dim3(TPB), 0, side.stream, S, dflag, pw.erank,
 			pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags, sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 		if (staged) {
 			HIP_CHECK(copy_async(host_blk, blk, 2 * p4, hipMemcpyDeviceToHost, side.stream));
 			HIP_CHECK(copy_async(host_blk + 3 * p4, blk + 3 * p4, 2 * p1, hipMemcpyDeviceToHost, side.stream));
 		}
-	} else if (S) {
-		KLAUNCH(k_emit_endpoints, dim3(nblk((S + 3) / 4)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
-			sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+	} else {
+		LAUNCH(k_pvst_roots, (size_t)C, s, C, sw.c_ntree, pw.doff, pw.d_parent, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
+		if (S)
+			KLAUNCH(k_emit_endpoints, dim3(nblk((S + 3) / 4)), dim3(TPB), 0, s, S, dflag, pw.erank, pw.s_comp, pw.ns, pw.s_vtx, sw.t_flags,
+				sw.t_gid, pw.cproc_ps, pw.d_a, pw.d_z, pw.d_aor, pw.d_zor);
 	}
-	// The (prev, i) intervals of exact cycle-equivalence classes never cross ("Row G"): the check is
-	// only needed when the literal hi_2 rule capped differently from the second-highest reach (extra[2]), i.e. when the
-	// classes may not be the exact ones -- or when a caller asks for it.
-	uint8_t *xflag = pw.f8d; // [T + 32] >= S (the branching flags are long compacted)
-	if (pw.laminar_checked) {
-		seg_build(pw.segP, pw.prev, S, s); // NIL (= +inf) where a class has no earlier occurrence
-		HIP_CHECK(hipMemsetAsync(xflag, 0, (size_t)S + 1, s));
-	}
-	LAUNCH(k_laminar_walk, ((size_t)S + 3) / 4, s, S, pw.prev, pw.segP, pw.laminar_checked, pw.s_comp, pw.soff, xflag, dflag, pw.walk);
-	if (pw.laminar_checked && S) { // the entries whose interval is crossed: decided in stack order, U undone where the class was popped
-		uint32_t *xlist = pw.wrun, *n_x = pw.err + 11, *n_crossed = pw.err + 12; // (wrun is written by the max-scan below; err words cleared at the start of the pass)
-		compact_flagged_u8(xflag, S, xlist, n_x, pw.scan_tmp, pw.scan_tmp_bytes, s);
-		KLAUNCH(k_resolve_crossings, dim3(std::min<unsigned>(nblk(C), 1024)), dim3(TPB), 0, s, C, pw.soff, n_x, xlist, pw.prev, pw.segP, xflag,
-			pw.walk, n_crossed);
-	}
-	scan(pw.walk, pw.walk_ps, (size_t)S);
-	uint32_t *wb = pw.walk_ps; // in place: exclusive -> biased inclusive
-	uint32_t *wneg = pw.walk, *wrun = pw.wrun; // the steps themselves are dead after the bias kernel read them
-	LAUNCH(k_walk_bias, ((size_t)S + 3) / 4, s, S, pw.walk, pw.walk_ps, wb, wneg);
-	scan_exclusive_max_u32(wneg, wrun, (size_t)S, pw.scan_tmp, pw.scan_tmp_bytes, s);
-	LAUNCH(k_levels, ((size_t)S + 3) / 4, s, S, dflag, pw.erank, pw.s_comp, pw.soff, wb, wrun, pw.lev, pw.e_i);
 	seg_build(pw.segL, pw.lev, NE, s);
 	LAUNCH(k_pvst_emit, NE, s, NE, pw.lev, pw.e_i, pw.segL, pw.s_comp, pw.soff, pw.erank, pw.cproc_ps,
 	       pw.d_parent);

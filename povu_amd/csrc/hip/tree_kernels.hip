@@ -2090,6 +2090,15 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	// chain, at the price of a filtering pass over the adjacency (it marks visits in its own bytes and rewrites the same
 	// parents, so the abandoned attempt leaves nothing behind).
 	const uint32_t *big_list = tw.entry_list;
+	// (7.) one list per processed component, one two-event list per side of an unprocessed one
+	const uint32_t n_events = 3 * V; // three per segment
+	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(n_events);
+	uint8_t *merged = tw.dvis; // [V]
+	bool events_done = false;
+	auto enqueue_events = [&]() {
+		HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
+		LAUNCH(k_events, V, s, V, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged, pw.sdl);
+	};
 	uint32_t n_big = force_big_class_dfs ? tw.host->read_u32(n_entry_dev, s) : 0; // (A/B mode: every class through the wave walk)
 	if (!force_big_class_dfs) {
 		// Lanes in flight = a window of sides whose scattered stores meet again in L2.  Round 4's walk (one tree edge per
@@ -2107,7 +2116,21 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 			budget = (uint32_t)std::max(16, atoi(ev));
 		KLAUNCH(k_class_dfs_small, dim3(dfs_blocks), dim3(64), 0, s, n_entry_dev, tw.entry_list, cs.loff, cs.ladj, cstate, tw.dps,
 			budget, n_over, over_list);
-		n_big = tw.host->read_u32(n_over, s);
+		// How many classes overflowed is read without leaving the stream idle (HostScratch::mark): behind the word goes the
+		// next stage's first kernel, on the assumption that none did -- with large classes around it ran on half-filled
+		// records and simply runs again behind the walks (it writes every word of its outputs).  Not with stage timers (the
+		// kernel would be booked on this stage).
+		if (!tm.enabled) {
+			uint32_t *w = tw.host->take<uint32_t>(1);
+			publish_words(w, WordSrc{{n_over}}, 1, s);
+			tw.host->mark(s);
+			enqueue_events();
+			tw.host->wait();
+			n_big = *w;
+			events_done = n_big == 0;
+		} else {
+			n_big = tw.host->read_u32(n_over, s);
+		}
 		big_list = over_list;
 	}
 	if (n_big) { // large classes: one wave each (see section 6)
@@ -2133,12 +2156,8 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 	// ---- 7. pre-order, sizes, depths
 	tm.begin("tree_preorder");
 	(void)max_side_links;
-	// one list per processed component, one two-event list per side of an unprocessed one
-	const uint32_t n_events = 3 * V; // three per segment
-	const unsigned bitsE = force_sparse_splitters ? 4u : rank_bucket_bits(n_events);
-	uint8_t *merged = tw.dvis; // [V] (the visited bytes of the class walk are dead)
-	HIP_CHECK(hipMemsetAsync(rb.heads, 0xFF, (size_t)C * 4, s)); // components that are not decomposed head no list
-	LAUNCH(k_events, V, s, V, tw.dps, cs.loff, cs.ladj, cs.ckey, tw.cproc, rb.pk, rb.heads, bitsE, merged, pw.sdl);
+	if (!events_done)
+		enqueue_events();
 	list_rank_splitters<true, true>(n_events, bitsE, nullptr, tw.evt, C, rb, s);
 	(void)event_lists;
 	tm.end(40);
