@@ -334,7 +334,9 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_lookback(const ScanJobs jobs)
 static constexpr size_t SC_LEGACY_BYTES = SC_MAX_BLOCKS * 16 + 256; // (two u32 jobs of the two-launch form, or one job of 128-bit words)
 // variants (POVU_HIP_LB_VARIANT, measured with tools/scan_time.py on 10^8 words: two launches 0.268 ms; 0: 0.271; 1: 0.249;
 // 2: 0.242; 3: 0.231): bit 1 = 64 elements a lane instead of 32, bit 0 = the tile is the workgroup's index instead of a
-// ticket (relies on workgroups being dispatched in index order: not the default)
+// ticket (relies on workgroups being dispatched in index order: not the default).  Tried and dropped in round 5: a tile per
+// WAVE (2048 elements, no barrier behind the ticket: 0.248), and as many workgroups as are resident at once, each striding
+// over the tiles without a ticket (0.251) -- a streaming read + write of 8 bytes an element stays at ~3.4 TB/s either way.
 static int lb_variant()
 {
 	static const int v = getenv("POVU_HIP_LB_VARIANT") ? atoi(getenv("POVU_HIP_LB_VARIANT")) : 2;
