@@ -397,6 +397,9 @@ int povu_hip_debug_stack(povu_hip_ctx *ctx, uint32_t comp, uint32_t *n, uint32_t
  * 1 = running maximum) and, when in2 is given, an independent sum scan of in2[0..n2) in the same launch */
 int povu_hip_debug_scan(povu_hip_ctx *ctx, int op, const uint32_t *in, uint32_t *out, size_t n, const uint32_t *in2,
 			uint32_t *out2, size_t n2);
+/* timing hook (tools/scan_time.py): `reps` exclusive scans (op as above) of n device-resident words, ms per scan by HIP
+ * events; < 0 on error */
+double povu_hip_debug_scan_time(povu_hip_ctx *ctx, size_t n, int reps, int op);
 
 /* device workspace (bytes) one plain povu_hip_decompose call reserves for a graph of this size whose vertices come grouped
  * by component and that has no hub vertex (> 48 links) and no self loop -- a pangenome GFA --, excluding the resident graph

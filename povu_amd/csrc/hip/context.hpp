@@ -46,6 +46,77 @@ struct PinnedPool {
 	static std::string segment_name(const std::string &tag, int k) { return "/povu." + tag + "." + std::to_string(k); }
 };
 
+// A host array whose memory comes out of the context's pool of page-locked blocks when it is given one (the label arrays of
+// -s: 9 bytes per PVST vertex -- as pageable std::vectors their copy off the device took 10 - 30 ms on the whole-genome
+// workload, depending on what the allocator made of 220 fresh megabytes), else from malloc.  Just enough of std::vector's
+// surface for the code that uses it; resize() does not initialise (every caller overwrites).
+template <typename T>
+struct PinnedVec {
+	T *p = nullptr;
+	size_t n = 0, cap_bytes = 0;
+	int seg = -1;
+	std::shared_ptr<PinnedPool> pool; // null: malloc
+	PinnedVec() = default;
+	PinnedVec(const PinnedVec &) = delete;
+	PinnedVec &operator=(const PinnedVec &) = delete;
+	PinnedVec(PinnedVec &&o) noexcept { *this = std::move(o); }
+	PinnedVec &operator=(PinnedVec &&o) noexcept
+	{
+		if (this != &o) {
+			release();
+			p = o.p, n = o.n, cap_bytes = o.cap_bytes, seg = o.seg, pool = std::move(o.pool);
+			o.p = nullptr, o.n = 0, o.cap_bytes = 0, o.seg = -1;
+		}
+		return *this;
+	}
+	~PinnedVec() { release(); }
+	void release()
+	{
+		if (p) {
+			if (pool)
+				pool->put(p, cap_bytes, seg);
+			else
+				free(p);
+		}
+		p = nullptr, n = 0, cap_bytes = 0, seg = -1;
+		pool.reset();
+	}
+	void resize(size_t m, const std::shared_ptr<PinnedPool> &from = nullptr)
+	{
+		release();
+		if (!m)
+			return;
+		if (from && from->shared_tag.empty()) { // (a pool of named shared-memory segments keeps them for the PVST blocks)
+			pool = from;
+			p = static_cast<T *>(pool->get(m * sizeof(T), cap_bytes, &seg));
+		} else {
+			p = static_cast<T *>(malloc(m * sizeof(T)));
+			if (!p)
+				throw std::bad_alloc();
+		}
+		n = m;
+	}
+	void assign(size_t m, T v)
+	{
+		resize(m);
+		std::fill(p, p + m, v);
+	}
+	void assign(const T *a, const T *b)
+	{
+		resize((size_t)(b - a));
+		if (n)
+			memcpy(p, a, n * sizeof(T));
+	}
+	T *data() { return p; }
+	const T *data() const { return p; }
+	T *begin() { return p; }
+	const T *begin() const { return p; }
+	size_t size() const { return n; }
+	bool empty() const { return n == 0; }
+	T &operator[](size_t i) { return p[i]; }
+	const T &operator[](size_t i) const { return p[i]; }
+};
+
 template <typename T>
 struct Span { // just enough of std::vector's surface for the code below
 	T *p = nullptr;
@@ -123,8 +194,8 @@ struct povu_hip_forest {
 		std::shared_ptr<PinnedPool> pool; // null: the memory is not this forest's (a segment of another rank, mapped by the context)
 		uint32_t *a = nullptr, *z = nullptr, *parent = nullptr;
 		uint8_t *aor = nullptr, *zor = nullptr;
-		std::vector<uint32_t> sub_ai, sub_zi; // with POVU_HIP_F_LEAF_SUBFLUBBLES (see the forest's own sub_ai)
-		std::vector<uint8_t> sub_fam;
+		PinnedVec<uint32_t> sub_ai, sub_zi; // with POVU_HIP_F_LEAF_SUBFLUBBLES (see the forest's own sub_ai)
+		PinnedVec<uint8_t> sub_fam;
 		std::shared_ptr<SubForest> subx;
 		void carve(size_t total_entries)
 		{
@@ -179,8 +250,8 @@ struct povu_hip_forest {
 	std::vector<uint64_t> hairpins;
 	// with POVU_HIP_F_LEAF_SUBFLUBBLES: ai / zi (flubbles.cpp:264-290) and the line letter of every PVST vertex, indexed
 	// like the arrays of this forest's own block
-	std::vector<uint32_t> sub_ai, sub_zi;
-	std::vector<uint8_t> sub_fam;
+	PinnedVec<uint32_t> sub_ai, sub_zi;
+	PinnedVec<uint8_t> sub_fam;
 	std::shared_ptr<SubForest> subx; // with POVU_HIP_F_SUBFLUBBLES: the trees after all five passes of -s
 	// povu_hip_forest_share: a second shared-memory segment with what the five arrays do not hold (labels, hairpin
 	// boundaries, the extended trees of -s), kept alive as long as the forest

@@ -33,16 +33,22 @@ void *PinnedPool::get(size_t bytes, size_t &cap, int *seg)
 {
 	const bool shared = !shared_tag.empty();
 	{
+		// best fit: a pass with -s takes two blocks of different sizes (the PVST arrays, the extended trees); first fit let the
+		// smaller request walk off with the larger block, and the larger one page-locked a fresh 0.7 GB every call (60 ms)
 		std::lock_guard<std::mutex> g(m);
+		size_t best = free_blocks.size();
 		for (size_t i = 0; i < free_blocks.size(); i++)
-			if (free_blocks[i].cap >= bytes && (free_blocks[i].seg >= 0) == shared) {
-				const Block b = free_blocks[i];
-				free_blocks.erase(free_blocks.begin() + i);
-				cap = b.cap;
-				if (seg)
-					*seg = b.seg;
-				return b.p;
-			}
+			if (free_blocks[i].cap >= bytes && (free_blocks[i].seg >= 0) == shared &&
+			    (best == free_blocks.size() || free_blocks[i].cap < free_blocks[best].cap))
+				best = i;
+		if (best != free_blocks.size()) {
+			const Block b = free_blocks[best];
+			free_blocks.erase(free_blocks.begin() + best);
+			cap = b.cap;
+			if (seg)
+				*seg = b.seg;
+			return b.p;
+		}
 	}
 	void *p = nullptr;
 	cap = bytes + bytes / 4 + 4096;
@@ -1023,9 +1029,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				leaf_prepare(cs, sw, ctx->pw, ctx->tw, C, ctx->ws_leaf, leaf_state, s);
 				leaf_dense(leaf_state, sw, ctx->pw, C, s);
 				const size_t n = ctx->pw.d_total;
-				f->sub_ai.resize(n);
-				f->sub_zi.resize(n);
-				f->sub_fam.resize(n);
+				f->sub_ai.resize(n, ctx->pool); // (page-locked, out of the context's pool)
+				f->sub_zi.resize(n, ctx->pool);
+				f->sub_fam.resize(n, ctx->pool);
 				if (n) {
 					HIP_CHECK(copy_async(f->sub_ai.data(), leaf_state.dense.ai, n * 4, hipMemcpyDeviceToHost, s));
 					HIP_CHECK(copy_async(f->sub_zi.data(), leaf_state.dense.zi, n * 4, hipMemcpyDeviceToHost, s));
@@ -1171,8 +1177,8 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 			}
 		};
 		// ... and their subflubble labels (leaf_seq wrote them in the same per-component layout)
-		auto fetch_seq_sub = [&](std::vector<povu_hip_forest::Tree *> &ts, std::vector<uint32_t> &dai, std::vector<uint32_t> &dzi,
-					 std::vector<uint8_t> &dfam, size_t n_total) {
+		auto fetch_seq_sub = [&](std::vector<povu_hip_forest::Tree *> &ts, PinnedVec<uint32_t> &dai, PinnedVec<uint32_t> &dzi,
+					 PinnedVec<uint8_t> &dfam, size_t n_total) {
 			dai.assign(n_total, POVU_NIL);
 			dzi.assign(n_total, POVU_NIL);
 			dfam.assign(n_total, 0);
@@ -1221,7 +1227,7 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 				blk.pool = ctx->pool;
 				blk.p = ctx->pool->get(povu_hip_forest::ExtraBlock::bytes_for(redo_total), blk.cap);
 				blk.carve(redo_total);
-				f->extra.push_back(blk);
+				f->extra.push_back(std::move(blk)); // (the raw pointers of blk stay valid: only the owning members move)
 				for (auto *t : redo)
 					t->blk = 0;
 				fetch_seq(redo, blk.a, blk.z, blk.parent, blk.aor, blk.zor, redo_total);
@@ -1380,9 +1386,9 @@ extern "C" int povu_hip_forest_get_sub(const povu_hip_forest *f, uint32_t i, con
 	if (!f || i >= f->trees.size())
 		return 1;
 	const auto &t = f->trees[i];
-	const std::vector<uint32_t> &va = t.blk < 0 ? f->sub_ai : f->extra[(size_t)t.blk].sub_ai;
-	const std::vector<uint32_t> &vz = t.blk < 0 ? f->sub_zi : f->extra[(size_t)t.blk].sub_zi;
-	const std::vector<uint8_t> &vf = t.blk < 0 ? f->sub_fam : f->extra[(size_t)t.blk].sub_fam;
+	const PinnedVec<uint32_t> &va = t.blk < 0 ? f->sub_ai : f->extra[(size_t)t.blk].sub_ai;
+	const PinnedVec<uint32_t> &vz = t.blk < 0 ? f->sub_zi : f->extra[(size_t)t.blk].sub_zi;
+	const PinnedVec<uint8_t> &vf = t.blk < 0 ? f->sub_fam : f->extra[(size_t)t.blk].sub_fam;
 	if (f->sub_fam.empty() || t.off + t.n_pvst > vf.size())
 		return 3; // the forest was not decomposed with POVU_HIP_F_LEAF_SUBFLUBBLES
 	if (ai)

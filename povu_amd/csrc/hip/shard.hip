@@ -545,7 +545,7 @@ static void adopt_packed(povu_hip_forest &out, std::shared_ptr<PinnedPool> pool,
 	big_copy(blk.aor, b + L.aor, total);
 	big_copy(blk.zor, b + L.zor, total);
 	const int bi = (int)out.extra.size();
-	out.extra.push_back(blk);
+	out.extra.push_back(std::move(blk));
 	const uint32_t *meta = reinterpret_cast<const uint32_t *>(b + L.meta);
 	size_t at = 0;
 	for (size_t i = 0; i < n_trees; i++) {
@@ -907,7 +907,7 @@ extern "C" povu_hip_forest *povu_hip_forest_attach(povu_hip_ctx *ctx, povu_hip_f
 				}
 			}
 			const int bi = (int)out->extra.size();
-			out->extra.push_back(blk);
+			out->extra.push_back(std::move(blk));
 			const uint32_t *meta = reinterpret_cast<const uint32_t *>(b + meta_off + 64);
 			size_t hp_seen = 0;
 			for (size_t k = 0; k < nt; k++) {
@@ -1297,7 +1297,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			blk.pool = ctx->pool;
 			blk.p = ctx->pool->get(x.bb, blk.cap);
 			blk.carve(x.total);
-			out->extra.push_back(blk);
+			out->extra.push_back(std::move(blk));
 			uint32_t *hm = ctx->host.take<uint32_t>(8 * x.nt);
 			hmetas.push_back(hm);
 			HIP_CHECK(copy_async(hm, x.dmeta, x.nt * 32, hipMemcpyDeviceToHost, s));
@@ -1314,7 +1314,7 @@ extern "C" povu_hip_forest *povu_hip_comm_gather(povu_hip_comm *c, const povu_hi
 			own.seg = m->block_seg;
 			own.carve(m->total_entries);
 			const int bi = (int)out->extra.size();
-			out->extra.push_back(own);
+			out->extra.push_back(std::move(own));
 			for (auto t : m->trees) {
 				t.blk = bi;
 				out->trees.push_back(t);

@@ -1190,6 +1190,22 @@ __device__ bool cn_leaves(const SubT &t, const XArrays &X, uint32_t xb, const Sl
 	// nest_trunk_zi, :1054-1081: (sic) the edge goes from the child to the slubble
 	return t.is_desc(n_of_f, c_ai) && !t.is_desc(zi, c_zi);
 }
+// PVST vertices, concealed and smothered records of every component (what the host lays the splice out by)
+__global__ void k_sub_comp_counts(uint32_t C, const uint32_t *__restrict__ doff, const uint32_t *__restrict__ c_npvst,
+				  const uint32_t *__restrict__ cn_off, const uint32_t *__restrict__ smo_off, uint32_t *__restrict__ out)
+{
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= C)
+		return;
+	const uint32_t n0 = c_npvst[c], q0 = doff[c];
+	uint32_t ncn = 0, nsm = 0;
+	if (n0) {
+		const uint32_t b = cn_off[q0], e = cn_off[q0 + n0];
+		ncn = e - b;
+		nsm = smo_off[e] - smo_off[b];
+	}
+	out[3 * c] = n0, out[3 * c + 1] = ncn, out[3 * c + 2] = nsm;
+}
 __global__ void k_sub_ptop(uint32_t C, const uint32_t *__restrict__ poff, const uint32_t *__restrict__ c_npvst, uint32_t *__restrict__ ptop)
 {
 	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1681,23 +1697,26 @@ void run_subflubbles(const CompState &cs, const SeqWs &sw, const ParWs &pw, cons
 	LAUNCH(k_sub_smo_emit, NC, s, NC, t, comp, cn, sm_off, smo);
 	mark("find_smothered search");
 
-	// ---- layout of the splice: per component its stretch of X-space and of the vector pool
-	std::vector<uint32_t> h_doff((size_t)C + 1), h_np((size_t)C + 1), h_cnoff((size_t)Q + 1), h_smoff((size_t)NC + 1);
-	HIP_CHECK(hipMemcpyAsync(h_doff.data(), pw.doff, ((size_t)C + 1) * 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(h_np.data(), sw.c_npvst, (size_t)C * 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(h_cnoff.data(), cn_off, ((size_t)Q + 1) * 4, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(h_smoff.data(), sm_off, ((size_t)NC + 1) * 4, hipMemcpyDeviceToHost, s));
+	// ---- layout of the splice: per component its stretch of X-space and of the vector pool.  The host needs three numbers a
+	// component (PVST vertices, concealed and smothered records): worked out on the device and read through page-locked
+	// scratch (until round 5 the whole offset array of the records came back, 4 bytes per PVST vertex into a pageable vector:
+	// 5 - 20 ms on the whole-genome workload, depending on what the process's allocator made of a fresh 100 MB)
+	uint32_t *comp_counts = dev32(3 * (size_t)C + 4);
+	uint32_t *h_cc = host.take<uint32_t>(3 * (size_t)C + 4);
+	if (C) {
+		LAUNCH(k_sub_comp_counts, C, s, C, pw.doff, sw.c_npvst, cn_off, sm_off, comp_counts);
+		HIP_CHECK(copy_async(h_cc, comp_counts, 3 * (size_t)C * 4, hipMemcpyDeviceToHost, s));
+	}
 	HIP_CHECK(hipStreamSynchronize(s));
+	std::vector<uint32_t> h_np((size_t)C + 1);
 	std::vector<uint32_t> h_xoff((size_t)C + 1), h_poff((size_t)C + 1);
 	uint64_t xs = 0, ps = 0;
 	for (uint32_t c = 0; c < C; c++) {
 		h_xoff[c] = (uint32_t)xs;
 		h_poff[c] = (uint32_t)ps;
-		const uint64_t n0 = h_np[c];
+		const uint64_t n0 = h_np[c] = h_cc[3 * (size_t)c];
 		if (n0) {
-			const uint32_t q0 = h_doff[c];
-			const uint64_t ncn = h_cnoff[q0 + n0] - h_cnoff[q0];
-			const uint64_t nsm = h_smoff[h_cnoff[q0 + n0]] - h_smoff[h_cnoff[q0]];
+			const uint64_t ncn = h_cc[3 * (size_t)c + 1], nsm = h_cc[3 * (size_t)c + 2];
 			xs += 2 * n0 + ncn + nsm;
 			ps += 32 * n0 + 16 * (ncn + nsm) + 256;
 		}
