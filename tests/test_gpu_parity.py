@@ -101,9 +101,11 @@ def test_overlapped_passes_are_bit_exact(hip, golden_dir):
 def test_kernels_started_ahead_of_the_hosts_reads(hip):
     """Without stage timers povu_hip_decompose gives the stream its next kernel BEFORE it waits for the words it needs from the
     device: the re-index's adjacency kernel ahead of the component count (on the assumption: vertices grouped by component, no
-    hub, no self loop), the tree stage's first kernel ahead of the component sizes.  Graphs that keep the assumption and graphs
-    that break it in every way, each twice on a warm context (the early start needs the arena of the pass before) and once
-    with timers: all equal the oracle."""
+    hub, no self loop), the tree stage's first kernel ahead of the component sizes, the pre-order's event kernel ahead of the
+    count of overflowed classes (on the assumption that there are none: with large 2-edge-connected classes it runs again behind
+    the wave walks), the bracket placement ahead of the class stage's counts, the level kernels ahead of the PVST count.  Graphs
+    that keep the assumptions and graphs that break them in every way, each twice on a warm context (the early start needs the
+    arena of the pass before) and once with timers: all equal the oracle."""
     from povu_amd.hip import F_NO_STAGE_TIMES
     base = W.hprc_shaped([4000, 1500, 300], seed=5, tiny=20)
     rng = np.random.default_rng(9)
@@ -112,7 +114,8 @@ def test_kernels_started_ahead_of_the_hosts_reads(hip):
     inv[perm] = np.arange(base.n_vtx)
     mixed = W._mk(base.vid[perm], inv[base.v1], base.s1, inv[base.v2], base.s2)
     graphs = [base, W.random_bidirected(3000, 5200, 41, self_loops=True), mixed, W.hub_on_chain(2000, 3000),
-              W.chain_of_bubbles(5000), W.random_bidirected(2500, 2600, 43, self_loops=False), base]
+              W.chain_of_bubbles(5000), W.random_bidirected(2500, 2600, 43, self_loops=False), base,
+              W.nested_towers(200, 6), W.hprc_circular(3000), W.random_bidirected(4000, 9000, 47, connected=True), base]
     for g in graphs:
         want = O.decompose(g)
         hip.upload(g)
@@ -425,7 +428,8 @@ def test_both_local_adjacency_builders(hip, seed):
     assert hip.decompose(flags=F_SORTED_ADJ).texts() == want
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 100003, 64 * 8192, 64 * 8192 + 1, 65 * 8192 + 7, 4 * 1024 * 1024 + 5, 30_000_001])
+@pytest.mark.parametrize("n", [1, 2, 63, 4095, 4096, 4097, 8191, 8192, 8193, 16385, 100003, 64 * 8192, 64 * 8192 + 1, 65 * 8192 + 7, 4 * 1024 * 1024 + 5, 30_000_001,
+                               48 * 1024 * 1024 + 12_345])  # (from 48 * 2^20 elements: one launch with decoupled look-back)
 def test_single_pass_scans(hip, n):
     """The device-wide exclusive scans against numpy: sum mod 2^32, running maximum, and two independent
     scans sharing their launches."""
