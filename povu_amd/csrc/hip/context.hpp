@@ -295,6 +295,7 @@ struct povu_hip_ctx {
 	// the tail of the last POVU_HIP_F_ASYNC pass (side-stream kernels and copies that read the stage workspace): recorded
 	// behind it; the next pass waits for it before it touches that workspace, every other entry point before anything
 	hipEvent_t tail_done = nullptr;
+	SideStream walk_side; // the wave walks' second stream (tree stage: the two forms of the walk run side by side)
 	hipEvent_t host_wait = nullptr; // recorded behind a kernel whose words the host reads while LATER kernels already run (povu_hip_decompose)
 	bool tail_pending = false;
 	void wait_tail()

@@ -151,6 +151,9 @@ extern "C" povu_hip_ctx *povu_hip_create(int device, char *err, size_t errlen)
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.fork, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.join, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->side.fork2, hipEventDisableTiming));
+		HIP_CHECK(hipStreamCreateWithFlags(&ctx->walk_side.stream, hipStreamNonBlocking));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->walk_side.fork, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ctx->walk_side.join, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->tail_done, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ctx->host_wait, hipEventDisableTiming));
 		ctx->timer.stream = ctx->stream;
@@ -194,6 +197,12 @@ extern "C" void povu_hip_destroy(povu_hip_ctx *ctx)
 		(void)hipEventDestroy(ctx->side.join);
 	if (ctx->side.fork2)
 		(void)hipEventDestroy(ctx->side.fork2);
+	if (ctx->walk_side.stream)
+		(void)hipStreamDestroy(ctx->walk_side.stream);
+	if (ctx->walk_side.fork)
+		(void)hipEventDestroy(ctx->walk_side.fork);
+	if (ctx->walk_side.join)
+		(void)hipEventDestroy(ctx->walk_side.join);
 	if (ctx->tail_done)
 		(void)hipEventDestroy(ctx->tail_done);
 	if (ctx->host_wait)
@@ -844,6 +853,9 @@ extern "C" povu_hip_forest *povu_hip_decompose(povu_hip_ctx *ctx, const povu_hip
 		if (!all_seq) {
 			stage_workspace_carve(ctx->ws2, ctx->pw, ctx->tw, z.V, z.E, C, so);
 			ctx->tw.walk_arena = &ctx->ws_walk;
+			ctx->tw.walk_stream = ctx->walk_side.stream;
+			ctx->tw.walk_fork = ctx->walk_side.fork;
+			ctx->tw.walk_join = ctx->walk_side.join;
 			ctx->tw.tour_words_done = false;
 			if (par_tree && !tm.enabled) {
 				if (ctx->tail_pending) { // first write into the stage workspace: behind the tail of the pass before

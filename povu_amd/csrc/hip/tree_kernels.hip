@@ -1090,10 +1090,16 @@ __device__ __forceinline__ URec urec_lane(const uint4 a, const uint4 b, int l)
 	return URec{lane_val(a.x, l), lane_val(a.y, l), lane_val(a.z, l), lane_val(a.w, l),
 		    lane_val(b.x, l), lane_val(b.y, l), lane_val(b.z, l), lane_val(b.w, l)};
 }
+// Two kernels (HOT = with the hot loop in front of the general step / the general step alone, see the loop at the end), launched
+// side by side over the same list of classes: every wave works out from the records around the entry which of the two forms
+// its class gets, and the wave of the other kernel ends at once.  One kernel with both forms made the general step of a class
+// that never uses the hot loop 8 - 25 % slower (the step is bound by its dependent instructions and by where the compiler
+// puts them; 20 scalar registers spilled).
+template <bool HOT>
 __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const uint32_t *__restrict__ entry_list,
 							 const uint4 *__restrict__ wrec, const uint32_t *__restrict__ wadj,
 							 uint32_t *wpar, uint2 *wstk, uint32_t *__restrict__ pool_top, uint32_t pool_cap,
-							 uint32_t *__restrict__ err, uint32_t nS)
+							 uint32_t *__restrict__ err, uint32_t nS, uint32_t route)
 {
 	__shared__ uint4 win_rec[W_WIN][2]; // {n, overflow begin, c0, c1}, {c2 .. c5}
 	__shared__ uint32_t win_par[W_WIN];
@@ -1108,6 +1114,31 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		const uint4 a = wrec[2 * (size_t)u], b = wrec[2 * (size_t)u + 1];
 		r = urec_lane(a, b, 0);
 	}
+	// Which form: do neighbours in the class sit near one another in the index space (a chain of bubbles, a tower, a ring: the
+	// window answers most steps) or all over it (a tangle whose links were written in random order)?  A probe the way the walk
+	// will go -- over a link to a side, across its segment, over the first link there, ... -- W_PROBE hops from the entry (a
+	// dependent load each: some 20 us, once per class): "near" = the link leads within 64 sides.  Half of the hops near is enough
+	// for the hot loop (it leaves by itself when it does not pay, W_TRIAL below); the entry's own neighbourhood says little (a
+	// tangle is entered from the backbone, a ring from the link that closes it).  route: 0 = by the probe, 1 = every class with
+	// the hot loop, 2 = every class without.
+	{
+		constexpr uint32_t W_PROBE = 24;
+		uint32_t near = 0, tot = 0, x = u;
+		uint4 a = make_uint4(r.n, r.begin, r.c0, r.c1);
+		for (uint32_t h = 0; h < W_PROBE && route == 0; h++) {
+			// first candidate of x that is not its segment partner (the partner, when it is in the class, is candidate 0)
+			const uint32_t y = a.x == 0 ? NIL : (a.z != (x ^ 1u) ? a.z : (a.x > 1 ? a.w : NIL));
+			if (y == NIL)
+				break;
+			tot++;
+			near += (y - x + 64u) <= 128u ? 1u : 0u;
+			x = y ^ 1u;
+			a = wrec[2 * (size_t)x]; // (uniform: every lane reads the same record)
+		}
+		const bool windowy = route == 1 || (route == 0 && tot >= 4 && 2 * near >= tot); // (a probe that ends early says nothing: the form without)
+		if (windowy != HOT)
+			return; // (the other kernel's wave walks this class)
+	}
 	uint32_t j0 = 0;
 	// BLACK FOLLOW-THROUGH.  In the biedged graph nearly every step over a link is followed by the step over the black edge of the
 	// segment it arrives at: the partner side c ^ 1 is the FIRST candidate of c's list.  The records of c and c ^ 1 share a
@@ -1117,17 +1148,27 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 	// Infinity-Cache round trip a step; BASELINE config 5 is bound by the instructions a step issues: half the steps).
 	bool have_pn = false; // pn / pn_vis hold the record and the parent word of u ^ 1, as of the step that led to u
 	uint32_t pn_vis = 0;
+	// (the kernel with the hot loop is short of scalar registers: there the partner's record stays in the lanes' registers --
+	// lane pn_lane holds it -- and becomes scalars only when the black step is taken; the other kernel keeps it as scalars)
 	URec pn{};
+	uint4 pq0 = make_uint4(0, 0, 0, 0), pq1 = pq0;
+	int pn_lane = 0;
 	uint32_t depth = 0, lds_lo = 0, n_chunks = 0; // stack entries; first entry cached in LDS; chunks taken from the pool
 	uint32_t win_lo = 0xFFFFFF00u; // (no window yet: no side id comes within W_WIN of this)
 	bool have_win = false;
 	uint32_t win_hits = 0, win_wait = 0, win_penalty = 0; // hits since the last refill; steps until the next refill is allowed
-	unsigned long long dirty0 = 0, dirty1 = 0; // window slots whose parent word is not in memory yet
+	// A parent word the window holds but memory does not yet carries bit 31 in its LDS copy (side ids stay below 2^29; the
+	// "not reached" and "no word" patterns have the bit set too and are told apart by value): one store instead of the two
+	// 64-bit bitmaps the step used to update.  Every reader of the window compares with W_UNVIS only.
+	constexpr uint32_t W_DIRTY = 0x80000000u;
 	auto flush_window = [&]() {
-		for (uint32_t k = lane; k < W_WIN; k += 64)
-			if (((k < 64 ? dirty0 >> k : dirty1 >> (k - 64)) & 1ull))
-				wpar[win_lo + k] = win_par[k];
-		dirty0 = dirty1 = 0;
+		for (uint32_t k = lane; k < W_WIN; k += 64) {
+			const uint32_t w = win_par[k];
+			if ((w & W_DIRTY) && w < W_UNVIS) {
+				wpar[win_lo + k] = w & ~W_DIRTY;
+				win_par[k] = w & ~W_DIRTY;
+			}
+		}
 	};
 #ifdef POVU_WALK_STATS
 	uint32_t st_fast = 0, st_slow = 0, st_refill = 0, st_pop = 0, st_ft = 0;
@@ -1195,251 +1236,49 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 		const uint32_t kk = side - win_lo;
 		if (kk < W_WIN) {
 			if (lane == 0)
-				win_par[kk] = par;
-			if (kk < 64)
-				dirty0 |= 1ull << kk;
-			else
-				dirty1 |= 1ull << (kk - 64);
+				win_par[kk] = par | W_DIRTY;
 			return true;
 		}
 		if (lane == 0)
 			wpar[side] = par;
 		return false;
 	};
+	// candidate idx of a short list, out of the scalar record: a chain of selects (as a function taking the record by reference
+	// the compiler put the record into SCRATCH memory and indexed it there: a trip to memory per step)
+#define W_INLINE_CAND(rr, idx, out)                                                                                            \
+	do {                                                                                                                    \
+		uint32_t v__ = (rr).c0;                                                                                         \
+		v__ = (idx) == 1 ? (rr).c1 : v__;                                                                               \
+		v__ = (idx) == 2 ? (rr).c2 : v__;                                                                               \
+		v__ = (idx) == 3 ? (rr).c3 : v__;                                                                               \
+		v__ = (idx) == 4 ? (rr).c4 : v__;                                                                               \
+		v__ = (idx) == 5 ? (rr).c5 : v__;                                                                               \
+		(out) = (idx) < (rr).n ? v__ : NIL;                                                                             \
+	} while (0)
+	// The loop exists TWICE: with the hot loop in front of the general step, and without it.  The mere presence of the hot
+	// loop's code in the loop body made the general step a quarter slower (measured with the hot loop switched off at run
+	// time: tangled 116 -> 144 ms, the general step is bound by its dependent instructions and the compiler's placement of
+	// them), so a class whose steps the window rarely answers -- links all over the index space -- leaves the first form after
+	// a trial of W_TRIAL general steps and continues in the second from the same state.  (The loop body is walk_step.inc,
+	// included twice: as a generic lambda instantiated twice the captured state went to scratch memory.)
+	constexpr uint32_t W_TRIAL = 512;
+	uint32_t n_gen = 0, n_hot = 0; // steps taken by the general step / inside the hot loop
+	// ---- with the hot loop, while it pays
+	if (HOT) {
+		for (;;) {
+			if (n_gen >= W_TRIAL && n_hot < n_gen)
+				break; // (the only way out of this loop short of the end of the walk)
+			n_gen++;
+#define W_HOT 1
+#include "walk_step.inc"
+#undef W_HOT
+		}
+	}
+	// ---- the general step alone
 	for (;;) {
-		if (have_pn) {
-			have_pn = false;
-			if (j0 == 0 && r.n && r.c0 == (u ^ 1u) && pn_vis == W_UNVIS) {
-				// the black edge is scanned first and its far side is not visited: across it, out of registers.  What stands
-				// behind it in u's list was not looked at: u is remembered as if an unvisited candidate were left.
-				// The bookkeeping of this step -- the push and the parent word of the far side -- is LEFT PENDING: the next
-				// step (always an ordinary one) carries it out right after it has issued its loads, in the shadow of their
-				// round trip (a step of bookkeeping alone costs ~1 000 cycles of dependent instructions on a lone wave,
-				// about as much as the round trip of the step behind it: profiles/r05_walk_stats.log).  Nothing reads the
-				// stack or the far side's parent word before that point (a side is no candidate of itself).
-				pend = true;
-				pend_push = r.n > 1;
-				pend_side = u;
-				u ^= 1u;
-				r = pn;
-				WSTAT(st_ft);
-				WCYC(cy_ft);
-				continue;
-			}
-		}
-		// ---- look at the candidates [j0, j0 + 64) of u: lane l takes candidate j0 + l -- out of the scalar record when the
-		// list is short (a handful of selects, no memory), else out of the overflow list
-		const uint32_t idx = j0 + lane;
-		uint32_t cand;
-		if (r.n <= W_INLINE) {
-			uint32_t v = r.c0;
-			v = idx == 1 ? r.c1 : v;
-			v = idx == 2 ? r.c2 : v;
-			v = idx == 3 ? r.c3 : v;
-			v = idx == 4 ? r.c4 : v;
-			v = idx == 5 ? r.c5 : v;
-			cand = idx < r.n ? v : NIL;
-		} else {
-			cand = NIL;
-			if (idx < r.n)
-				cand = __builtin_nontemporal_load(wadj + r.begin + idx);
-		}
-		// its visited word AND its record, out of the window: one LDS round trip serves this step and the next
-		const bool inw = cand - win_lo < W_WIN; // (false for NIL and while there is no window: see win_lo)
-		uint32_t vp = 0, vq = 0; // parent words of the candidate and of its segment partner (window: both or neither, it starts on an even side)
-		uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, q0 = c0, q1 = c0;
-		if (inw) {
-			vp = win_par[cand - win_lo];
-			c0 = win_rec[cand - win_lo][0];
-			c1 = win_rec[cand - win_lo][1];
-			vq = win_par[(cand ^ 1u) - win_lo];
-			q0 = win_rec[(cand ^ 1u) - win_lo][0];
-			q1 = win_rec[(cand ^ 1u) - win_lo][1];
-		}
-		// When the first unvisited candidate the window knows of has no candidate OUTSIDE the window in front of it, it is the
-		// child -- decided from LDS alone, no load is even issued.  (Whether an unvisited candidate follows it is then not known
-		// for those outside: the side is remembered on the stack as if one did, which costs a look at it on the way back.)
-		const unsigned long long miss = __ballot(cand != NIL && !inw);
-		const unsigned long long unv_in = __ballot(inw && vp == W_UNVIS);
-		const bool fast = unv_in && !(miss & ((unv_in & (0ull - unv_in)) - 1ull));
-		unsigned long long m = unv_in;
-		if (!fast && miss) { // the candidates outside the window: visited word and record in one round trip to memory
-			if (cand != NIL && !inw) { // (the partner's words sit in the same lines)
-				vp = wpar[cand];
-				c0 = wrec[2 * (size_t)cand];
-				c1 = wrec[2 * (size_t)cand + 1];
-				vq = wpar[cand ^ 1u];
-				q0 = wrec[2 * (size_t)(cand ^ 1u)];
-				q1 = wrec[2 * (size_t)(cand ^ 1u) + 1];
-			}
-		}
-		if (pend) { // (the loads above are in flight: see the black follow-through)
-			pend = false;
-			if (pend_push) {
-				push(pend_side, 1u);
-				if (!pool_ok)
-					return;
-			}
-			(void)set_parent(pend_side ^ 1u, pend_side);
-		}
-		if (!fast && miss) {
-			m = __ballot(cand != NIL && vp == W_UNVIS);
-		}
-		if (fast)
-			WSTAT(st_fast);
-		else
-			WSTAT(st_slow);
-		const bool beyond = j0 + 64 < r.n; // (sides with more than 64 class neighbours: the next window)
-		if (m) {
-			const int f = __ffsll((long long)m) - 1;
-			const uint32_t child = lane_val(cand, f);
-			const bool child_in = (unv_in >> f) & 1ull; // its words are in the window
-			// another unvisited candidate behind the chosen one (a second slot of the same side counts: harmless)?
-			if ((m & (m - 1)) || beyond || (fast && (miss >> f))) {
-				push(u, j0 + (uint32_t)f + 1u);
-				if (!pool_ok)
-					return;
-			}
-			const uint32_t child_par = u;
-			u = child;
-			j0 = 0;
-			r = urec_lane(c0, c1, f); // (the chosen lane holds the child's record: out of the window or out of memory)
-			pn = urec_lane(q0, q1, f); // ... and its segment partner's, for the black step that usually follows
-			pn_vis = lane_val(vq, f);
-			have_pn = true;
-			if (child_in) { // the parent word: into the window now, into memory when the window moves on
-				(void)set_parent(child, child_par);
-				win_hits++;
-				WCYC(cy_fast);
-				continue;
-			}
-			if (lane == 0)
-				wpar[child] = child_par;
-			// ---- the window follows the walk
-			if (win_wait) {
-				win_wait--;
-				WCYC(cy_slow);
-				continue;
-			}
-			// few hits out of the last window: the class does not sit together in the index space, try again later
-			// (twice as much later every time, up to 1024 steps)
-			if (have_win && win_hits < 4)
-				win_penalty = min(win_penalty ? 2 * win_penalty : 8u, 1024u);
-			else
-				win_penalty = 0;
-			win_wait = win_penalty;
-			win_hits = 0;
-			WSTAT(st_refill);
-			__syncthreads(); // (one wave: the window's readers above are done)
-			// The parent words of the new window: those the old window holds come out of LDS (the only copy that is surely
-			// current: some were never written to memory), the others out of memory -- where every word this wave ever wrote
-			// outside a window, or flushed out of an earlier one, has long arrived (a wave's stores and loads of one address
-			// stay in order; an agent-scope fence here cost 50 us a refill: it writes the L2 back).
-			const uint32_t new_lo = (child > W_WIN_BACK ? child - W_WIN_BACK : 0u) & ~1u; // (even: a side and its segment partner are in the window together)
-			uint32_t keep[W_WIN / 64];
-#pragma unroll
-			for (uint32_t q = 0; q < W_WIN / 64; q++) {
-				const uint32_t x = new_lo + lane + 64 * q;
-				keep[q] = (have_win && x - win_lo < W_WIN) ? win_par[x - win_lo] : NIL; // (NIL is no parent word: "not in the old window")
-			}
-			if (have_win)
-				flush_window();
-			__syncthreads();
-			win_lo = new_lo;
-			have_win = true;
-#pragma unroll
-			for (uint32_t q = 0; q < W_WIN / 64; q++) {
-				const uint32_t k = lane + 64 * q, x = win_lo + k;
-				if (x < nS) {
-					win_rec[k][0] = wrec[2 * (size_t)x];
-					win_rec[k][1] = wrec[2 * (size_t)x + 1];
-					win_par[k] = keep[q] != NIL ? keep[q] : wpar[x];
-				} else {
-					win_par[k] = 0u; // (never asked for)
-				}
-			}
-			__syncthreads();
-			if (lane == 0)
-				win_par[child - win_lo] = child_par; // (stored a moment ago: not left to the order of that store and this load)
-			__syncthreads();
-			WCYC(cy_refill);
-			continue;
-		}
-		if (beyond) {
-			j0 += 64;
-			continue;
-		}
-		// ---- u is finished: back to the nearest remembered side that still has an unvisited candidate
-		bool found = false;
-		while (!found) {
-			if (depth == 0) {
-				WCYC(cy_pop);
-				WSTAT_DONE();
-				if (have_win) {
-					__syncthreads();
-					flush_window();
-				}
-				return; // the class is walked
-			}
-			WSTAT(st_pop);
-			__syncthreads(); // (one wave: orders lane 0's LDS writes of the pushes before the reads below)
-			if (lds_lo >= depth) { // nothing cached: fetch the top entries
-				const uint32_t cnt = min(depth, 64u);
-				if (lane < cnt) {
-					const uint32_t d = depth - 1 - lane;
-					ring[d & 63u] = wstk[wstk_addr(d, chunk_base)];
-				}
-				lds_lo = depth - cnt;
-				__syncthreads();
-			}
-			const uint32_t cnt = depth - lds_lo; // 1 .. 64 cached entries, lane l looks at entry depth - 1 - l
-			bool has = false;
-			uint32_t eu = 0, ej = 0;
-			uint4 e0 = make_uint4(0, 0, 0, 0), e1 = e0;
-			if (lane < cnt) {
-				const uint2 w = ring[(depth - 1 - lane) & 63u];
-				eu = w.x, ej = w.y;
-				if (eu - win_lo < W_WIN) {
-					e0 = win_rec[eu - win_lo][0];
-					e1 = win_rec[eu - win_lo][1];
-				} else {
-					e0 = wrec[2 * (size_t)eu];
-					e1 = wrec[2 * (size_t)eu + 1];
-				}
-				if (e0.x > W_INLINE) {
-					has = true; // a long list: let the window scan above decide
-				} else {
-					// the visited words of its remaining candidates: those in the window from LDS, the others in one round trip
-					uint32_t v[W_INLINE];
-#pragma unroll
-					for (uint32_t k = 0; k < W_INLINE; k++) {
-						const uint32_t x = wrec_cand(e0, e1, k);
-						const bool want = k >= ej && k < e0.x, w_in = want && x - win_lo < W_WIN;
-						v[k] = w_in ? win_par[x - win_lo] : 0u;
-						if (want && !w_in)
-							v[k] = wpar[x];
-					}
-#pragma unroll
-					for (uint32_t k = 0; k < W_INLINE; k++)
-						has = has || v[k] == W_UNVIS;
-				}
-			}
-			const unsigned long long hm = __ballot(has);
-			if (!hm) {
-				depth -= cnt;
-				continue;
-			}
-			const int l = __ffsll((long long)hm) - 1;
-			depth -= (uint32_t)l + 1u; // the entries above it are done for good; it is re-pushed if it keeps a candidate
-			u = lane_val(eu, l);
-			j0 = lane_val(ej, l);
-			r = urec_lane(e0, e1, l);
-			have_pn = false;
-			if (lds_lo > depth)
-				lds_lo = depth;
-			found = true;
-			WCYC(cy_pop);
-		}
+#define W_HOT 0
+#include "walk_step.inc"
+#undef W_HOT
 	}
 }
 // the wave walk leaves the DFS parent of every side it reached in wpar; the scan slot the parent found it through is
@@ -2145,8 +1984,22 @@ int64_t run_parallel_tree(const CompState &cs, SeqWs &sw, ParWs &pw, TreeWs &tw,
 		}
 		uint32_t *pool_top = pw.err + 7, *walk_err = pw.err + 8; // (cleared with the other counters at the start of the pass)
 		LAUNCH(k_class_recs, nS, s, nS, cs.loff, cs.ladj, cstate, cs.ckey, tw.cproc, tw.wadj, tw.wrec, tw.wpar);
-		KLAUNCH(k_class_walk_wave, dim3(n_big), dim3(64), 0, s, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top,
-			(uint32_t)std::min<size_t>(3 * (size_t)nS, 0xFFFFFFF0u), walk_err, nS);
+		const uint32_t route = getenv("POVU_HIP_WALK_ROUTE") ? (uint32_t)atoi(getenv("POVU_HIP_WALK_ROUTE")) : 0u; // (A/B hook)
+		const uint32_t pool_cap = (uint32_t)std::min<size_t>(3 * (size_t)nS, 0xFFFFFFF0u);
+		// the two forms side by side (see k_class_walk_wave): the second on the context's walk stream when there is one
+		hipStream_t s2 = tw.walk_stream ? tw.walk_stream : s;
+		if (s2 != s) {
+			HIP_CHECK(hipEventRecord(tw.walk_fork, s));
+			HIP_CHECK(hipStreamWaitEvent(s2, tw.walk_fork, 0));
+		}
+		KLAUNCH(k_class_walk_wave<false>, dim3(n_big), dim3(64), 0, s2, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top, pool_cap,
+			walk_err, nS, route);
+		KLAUNCH(k_class_walk_wave<true>, dim3(n_big), dim3(64), 0, s, n_big, big_list, tw.wrec, tw.wadj, tw.wpar, tw.wstk, pool_top, pool_cap,
+			walk_err, nS, route);
+		if (s2 != s) {
+			HIP_CHECK(hipEventRecord(tw.walk_join, s2));
+			HIP_CHECK(hipStreamWaitEvent(s, tw.walk_join, 0));
+		}
 		LAUNCH(k_walk_finish, nS, s, nS, tw.wpar, cstate, cs.loff, cs.ladj, tw.dps);
 		if (tw.host->read_u32(walk_err, s)) // (an unfinished walk leaves a broken tree: nothing downstream may run on it)
 			throw HipError("class walk: stack pool exhausted (internal sizing bug)");

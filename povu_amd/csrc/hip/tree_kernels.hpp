@@ -33,6 +33,8 @@ struct TreeWs {
 	uint32_t *cproc;				  // [C+1] 1 = component is decomposed by this shard
 	const uint8_t *last_dupflag;			  // dvis_slots when the last pass filled it, else null
 	bool tour_words_done = false;			  // tree_tour_words ran for this pass already (started ahead of the host's wait for the component sizes)
+	hipStream_t walk_stream = nullptr; // second stream of the wave walks (the context's; null: both forms on the pass's stream)
+	hipEvent_t walk_fork = nullptr, walk_join = nullptr;
 	Arena *walk_arena = nullptr;			  // where the wave walk's arrays are taken from when the pass needs them and they are not inside the stage block
 	bool walk_inline = true;
 };
