@@ -1117,12 +1117,12 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 	// Which form: do neighbours in the class sit near one another in the index space (a chain of bubbles, a tower, a ring: the
 	// window answers most steps) or all over it (a tangle whose links were written in random order)?  A probe the way the walk
 	// will go -- over a link to a side, across its segment, over the first link there, ... -- W_PROBE hops from the entry (a
-	// dependent load each: some 20 us, once per class): "near" = the link leads within 64 sides.  Half of the hops near is enough
+	// dependent load each: some 40 us, once per class): "near" = the link leads within 64 sides.  Three hops in four near are enough
 	// for the hot loop (it leaves by itself when it does not pay, W_TRIAL below); the entry's own neighbourhood says little (a
 	// tangle is entered from the backbone, a ring from the link that closes it).  route: 0 = by the probe, 1 = every class with
 	// the hot loop, 2 = every class without.
 	{
-		constexpr uint32_t W_PROBE = 24;
+		constexpr uint32_t W_PROBE = 48;
 		uint32_t near = 0, tot = 0, x = u;
 		uint4 a = make_uint4(r.n, r.begin, r.c0, r.c1);
 		for (uint32_t h = 0; h < W_PROBE && route == 0; h++) {
@@ -1135,7 +1135,11 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 			x = y ^ 1u;
 			a = wrec[2 * (size_t)x]; // (uniform: every lane reads the same record)
 		}
-		const bool windowy = route == 1 || (route == 0 && tot >= 4 && 2 * near >= tot); // (a probe that ends early says nothing: the form without)
+		const bool windowy = route == 1 || (route == 0 && tot == W_PROBE && 4 * near >= 3 * tot); // (a probe that ends early -- a dead end, a small class -- says nothing: the form without)
+#ifdef POVU_WALK_STATS
+		if (lane == 0 && HOT)
+			printf("route %u: entry %u n %u near %u tot %u -> %s\n", blockIdx.x, u, r.n, near, tot, windowy ? "hot" : "plain");
+#endif
 		if (windowy != HOT)
 			return; // (the other kernel's wave walks this class)
 	}
@@ -1234,7 +1238,7 @@ __global__ void __launch_bounds__(64) k_class_walk_wave(uint32_t n_entry, const 
 	// straight into memory; true when it went into the window
 	auto set_parent = [&](uint32_t side, uint32_t par) {
 		const uint32_t kk = side - win_lo;
-		if (kk < W_WIN) {
+		if (HOT && kk < W_WIN) {
 			if (lane == 0)
 				win_par[kk] = par | W_DIRTY;
 			return true;
