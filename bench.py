@@ -193,6 +193,7 @@ def end_to_end_cli(g, wl):
             o = os.path.join(d, "out")
             shutil.rmtree(o, ignore_errors=True)
             os.makedirs(o)
+            time.sleep(2.0)  # (untimed: the process before gave tens of gigabytes of device memory back a moment ago, see the note)
             t0 = time.perf_counter()
             r = subprocess.run([povu, "-t", threads, "decompose", "-i", gfa, "-o", o], capture_output=True, text=True, env=env)
             dt = time.perf_counter() - t0
@@ -212,9 +213,9 @@ def end_to_end_cli(g, wl):
                 "value_without_process_start": g.n_links / max(1e-9, med - t_start),
                 "host_ms": {k: round(v, 2) for k, v in parts.items()},
                 "gfa_written_in_s": t_write_gfa, "files_on": base or tempfile.gettempdir(),
-                "note": "MEDIAN of 3 runs of the CLI as a child process (all in wall_s_runs, the best in wall_s_best; host_ms are the best run's; a CLI process that starts right after "
+                "note": "MEDIAN of 3 runs of the CLI as a child process, two seconds apart (all in wall_s_runs, the best in wall_s_best; host_ms are the best run's; a CLI process that starts right after "
                         "another one released tens of gigabytes of device memory can spend seconds more in hipMalloc: DESIGN.md "
-                        "section 6 -- the workspace of this graph is 46 GB since round 4, below where that was ever seen); process_start_and_hip_bringup_s = the same CLI on a "
+                        "section 6 -- it still happens to one run in three or so); process_start_and_hip_bringup_s = the same CLI on a "
                         "one-segment graph (process start, library load, HIP context, nothing else); host_ms = the CLI's own "
                         "stage-cost lines (gfa_parse, upload_csr, decompose_call, write_pvst); the GFA text is written "
                         "before the timed runs"}
