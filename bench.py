@@ -42,7 +42,7 @@ def kernel_source_digest():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "povu_amd", "csrc", "hip")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
+        if name.endswith((".hip", ".hpp", ".inc")):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
