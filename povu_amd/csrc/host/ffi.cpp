@@ -282,7 +282,7 @@ static povu_hip_forest *run_decompose(PovuGraph *g, int device, int hairpins, Po
 	povu_hip_forest *f = nullptr;
 	if (povu_hip_graph_upload(ctx, (uint32_t)vid.size(), vid.data(), (uint32_t)g->v1.size(), g->v1.data(), g->s1.data(),
 				  g->v2.data(), g->s2.data(), tips, err, sizeof err) == 0) {
-		povu_hip_opts o{0, 1, hairpins ? POVU_HIP_F_HAIRPINS : 0u};
+		povu_hip_opts o{0, 1, (hairpins ? POVU_HIP_F_HAIRPINS : 0u) | POVU_HIP_F_NO_STAGE_TIMES}; // (no per-stage timers: the pass starts kernels ahead of its host reads)
 		f = povu_hip_decompose(ctx, &o, err, sizeof err);
 	}
 	povu_hip_destroy(ctx);
