@@ -123,6 +123,22 @@ def test_kernels_started_ahead_of_the_hosts_reads(hip):
             assert hip.decompose(flags=fl).texts() == want
 
 
+def test_both_forms_of_the_wave_walk_on_every_kind_of_large_class(hip, monkeypatch):
+    """Large 2-edge-connected classes are walked by one of two kernels -- with a hot loop for the steps the LDS window answers
+    alone, or without window at all --, picked per class by a probe of its records.  Forced either way (POVU_HIP_WALK_ROUTE)
+    both kernels have to produce the reference's tree on classes they would never be given: towers and a ring without the
+    hot loop, tangles with links all over the index space with it."""
+    graphs = [W.nested_towers(300, 5), W.hprc_circular(4000), W.hprc_tangled(3000, seed=7, tangle_every=700, max_tangle=2500),
+              W.random_bidirected(5000, 11000, 53, connected=True), W.hub_on_chain(1500, 2500)]
+    for g in graphs:
+        want = O.decompose(g)
+        hip.upload(g)
+        for route in ("1", "2", "0"):
+            monkeypatch.setenv("POVU_HIP_WALK_ROUTE", route)
+            assert hip.decompose().texts() == want, f"route {route}"
+    monkeypatch.delenv("POVU_HIP_WALK_ROUTE", raising=False)
+
+
 def test_lpa_md5(hip, golden_dir):
     a = json.load(open(os.path.join(golden_dir, "anchors.json")))
     g = _load_gfa_links(os.path.join(golden_dir, "gfa", "LPA.gfa"))
